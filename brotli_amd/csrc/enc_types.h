@@ -1,0 +1,100 @@
+// brotli_amd/csrc/enc_types.h — plain structs shared by host code and kernels.
+//
+// Vocabulary follows the reference: an encoder *shard* is one independent
+// encoder instance (BROTLI_PARAM_STREAM_OFFSET contract, encode.h:231-246);
+// it consumes its input in *blocks* of 1<<lgblock bytes (quality.h:75-92) and
+// emits *meta-blocks* (encode.c:1141-1166).
+#ifndef BROTLI_AMD_CSRC_ENC_TYPES_H_
+#define BROTLI_AMD_CSRC_ENC_TYPES_H_
+
+#include <stdint.h>
+
+// 16-byte command, field meaning as c/enc/command.h:106-116.
+struct Command {
+  uint32_t insert_len;
+  uint32_t copy_len;    // low 25 bits: length; high 7 bits: len_code - len
+  uint32_t dist_extra;
+  uint16_t cmd_prefix;
+  uint16_t dist_prefix;  // low 10 bits: distance symbol; high 6: #extra bits
+};
+
+// Hash-table record, one per bucket key: everything one FindLongestMatch /
+// Store touches for a key sits in ONE 128-byte line (the reference keeps
+// num_/tags_/buckets_ in three arrays, hash_longest_match64_simd_inc.h:100-110).
+// tag2 is an extra 16-bit fingerprint of the first four bytes at the stored
+// position: candidates whose first four bytes differ are rejected by the
+// reference anyway (:277-278), so filtering on it first cannot change results
+// and saves the random window read.
+#define REC_BYTES 128
+#define REC_SLOT_DW 0    // u32 slot[16]        dwords 0..15
+#define REC_TAG2_DW 16   // u16 tag2[16]        dwords 16..23
+#define REC_TAG_DW 24    // u8  tag[16]         dwords 24..27
+#define REC_NUM_DW 28    // u16 num             dword 28 (low half)
+
+struct JobParams {
+  int32_t quality, lgwin, lgblock;
+  uint32_t size_hint;
+  int32_t hasher_type;  // 68 (5-byte hash, 15-bit key) or 58 (4-byte hash)
+  int32_t bucket_bits, block_bits, ndist;
+  uint32_t ring_mask;           // (1 << (1 + max(lgwin, lgblock))) - 1
+  uint32_t max_backward_limit;  // (1 << lgwin) - 16
+  uint32_t spree_window;        // quality.h:116-119
+  uint32_t max_metablock_size, max_literals, max_commands;  // encode.c:1142-1145
+  uint32_t log2_lut_size;
+  uint32_t flags;
+};
+#define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
+
+// Per-shard description written by the host.
+struct ShardDesc {
+  uint64_t in_off;         // first byte of the shard in the job input buffer
+  uint32_t len;            // bytes of the shard available so far
+  uint32_t stream_offset;  // already clamped as encode.c:678-682
+  uint32_t final_op;       // 1 = FLUSH after the last byte, 2 = FINISH
+  uint32_t cmd_cap;
+  uint64_t table_off;      // 128 B * (1 << bucket_bits)
+  uint64_t cmds_off;       // Command[cmd_cap]
+  uint64_t lits_off;       // u16[len + 8]: (literal | context << 8) in order
+  uint64_t dsym_off;       // u16[cmd_cap]: distance symbols in order
+  uint64_t mb_off;         // MetaBlockWork
+  uint64_t scratch_off;    // u32[...] bit offsets (store kernel)
+  uint64_t out_off;        // shard output bytes
+  uint64_t out_cap;
+};
+
+// Persistent per-shard encoder state (c/enc/state.h:49-110 subset).
+struct ShardState {
+  uint32_t input_pos, last_processed_pos, last_flush_pos;
+  uint32_t last_insert_len, ncmds, nlits;
+  int32_t dist_cache[4];
+  int32_t saved_dist_cache[4];
+  uint32_t dict_lookups, dict_matches;
+  uint32_t last_bytes;       // u16 payload
+  uint32_t last_bytes_bits;
+  int32_t flint;             // BrotliEncoderFlintState
+  uint32_t prev_byte, prev_byte2;
+  uint32_t done;             // all input consumed and final op emitted
+  uint32_t error;
+  // meta-block handed from the parse kernel to the build/store kernels
+  uint32_t mb_valid, mb_start, mb_bytes, mb_is_last, mb_force_flush;
+  uint32_t mb_raw;           // ShouldCompress() said no (set by build kernel)
+  uint32_t mb_num_contexts, mb_context_map_id;
+  uint64_t out_bytes;        // whole bytes already final in the shard output
+  uint64_t stat_searches, stat_pairs, stat_b_used;
+};
+
+// Constant tables uploaded once per context.
+struct DeviceTables {
+  const uint8_t* context_lut;       // 512 B: CONTEXT_UTF8 pair of LUTs
+  const uint8_t* dict;              // RFC 7932 dictionary
+  const uint16_t* dict_hash_words;  // [32768]
+  const uint8_t* dict_hash_lengths; // [32768]
+  const double* log2_lut;           // FastLog2(v) for v < log2_lut_size
+  uint32_t dict_offsets_by_length[32];
+  uint8_t dict_size_bits_by_length[32];
+};
+
+// Greedy block-split result for one category (metablock.h:28-43).
+#define MB_MAX_TYPES 257
+
+#endif  // BROTLI_AMD_CSRC_ENC_TYPES_H_

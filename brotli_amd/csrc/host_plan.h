@@ -1,0 +1,159 @@
+// brotli_amd/csrc/host_plan.h — host-side job planning shared by the HIP layer
+// and the test simulator: parameter derivation (quality.h), the partition plan
+//  and the per-shard workspace layout in HBM.
+#ifndef BROTLI_AMD_CSRC_HOST_PLAN_H_
+#define BROTLI_AMD_CSRC_HOST_PLAN_H_
+
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+
+#include "enc_types.h"
+#include "mb_layout.h"
+
+struct JobPlan {
+  JobParams J;
+  std::vector<ShardDesc> shards;
+  uint64_t ws_bytes;
+  uint64_t in_bytes;
+  uint64_t max_out_bytes;
+};
+
+static inline uint64_t plan_align(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
+
+// Derives the encoder parameters exactly as the reference does for
+// qualities 5..6 (c/enc/quality.h:59-223, encode.c:642-700).  Returns false for
+// parameter combinations this library does not implement on the GPU.
+static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobParams* J) {
+  memset(J, 0, sizeof(*J));
+  if (quality < 5 || quality > 5) return false;      // block_bits 4 only (round 1)
+  if (lgwin < 17 || lgwin > 24) return false;        // H40-42 / large window: out of scope
+  J->quality = quality;
+  J->lgwin = lgwin;
+  J->lgblock = 16;                                   // ComputeLgBlock, quality.h:75-92
+  J->size_hint = size_hint;
+  if (size_hint >= (1u << 20) && lgwin >= 19) {      // ChooseHasher, quality.h:186-204
+    J->hasher_type = 68;
+    J->bucket_bits = 15;
+  } else {
+    J->hasher_type = 58;
+    J->bucket_bits = 14;
+  }
+  J->block_bits = quality - 1;
+  J->ndist = 4;
+  const int rb_bits = 1 + (lgwin > J->lgblock ? lgwin : J->lgblock);
+  J->ring_mask = (1u << rb_bits) - 1u;
+  J->max_backward_limit = (1u << lgwin) - 16u;
+  J->spree_window = 64;
+  J->max_metablock_size = 1u << (rb_bits < 24 ? rb_bits : 24);
+  J->max_literals = J->max_metablock_size / 8;
+  J->max_commands = J->max_metablock_size / 8;
+  return true;
+}
+
+// Partition plan + workspace layout.  shard_size == 0: one shard (Mode S).
+static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_hint,
+                            uint64_t shard_size, JobPlan* plan) {
+  if (size_hint == 0) size_hint = len >= (1u << 30) ? (1u << 30) : (uint32_t)len;
+  if (!plan_params(quality, lgwin, size_hint, &plan->J)) return false;
+  if (len == 0) return false;
+  if (shard_size == 0 || shard_size >= len) shard_size = len;
+  if (shard_size >= (3ull << 30)) return false;      // 32-bit positions, no wrap support
+  const uint64_t nshards = (len + shard_size - 1) / shard_size;
+  const JobParams& J = plan->J;
+  // FastLog2 LUT covers every count a meta-block histogram can reach.
+  const uint64_t max_mb = J.max_metablock_size < shard_size ? J.max_metablock_size : shard_size;
+  plan->J.log2_lut_size = (uint32_t)(max_mb + 2 < 256 ? 256 : max_mb + 2);
+  plan->shards.resize(nshards);
+  uint64_t off = 0;
+  uint64_t max_out = 0;
+  for (uint64_t k = 0; k < nshards; ++k) {
+    ShardDesc& D = plan->shards[k];
+    memset(&D, 0, sizeof(D));
+    const uint64_t in_off = k * shard_size;
+    const uint64_t n = len - in_off < shard_size ? len - in_off : shard_size;
+    D.in_off = in_off;
+    D.len = (uint32_t)n;
+    uint64_t so = in_off >= (1u << 30) ? (1u << 30) : in_off;
+    if (so > J.max_backward_limit) so = J.max_backward_limit;   // encode.c:678-682
+    D.stream_offset = (uint32_t)so;
+    D.final_op = (k + 1 == nshards) ? 2u : 1u;
+    D.cmd_cap = (uint32_t)(n / 2 + (n >> J.lgblock) + 16);
+    const uint64_t mb_len = n < J.max_metablock_size ? n : J.max_metablock_size;
+    D.table_off = off; off = plan_align(off + ((uint64_t)REC_BYTES << J.bucket_bits));
+    D.cmds_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * sizeof(Command));
+    D.lits_off = off;  off = plan_align(off + (mb_len + 8) * 2);
+    D.dsym_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * 2);
+    D.mb_off = off;    off = plan_align(off + mb_work_bytes(mb_len));
+    D.scratch_off = off; off = plan_align(off + ((uint64_t)D.cmd_cap + mb_len + 64) * 4);
+    D.out_cap = 2 * n + 1024 + 16 * ((n >> J.lgblock) + 2);
+    D.out_off = off;   off = plan_align(off + D.out_cap);
+    max_out += D.out_cap;
+  }
+  plan->ws_bytes = off;
+  plan->in_bytes = len;
+  plan->max_out_bytes = max_out;
+  return true;
+}
+
+// ---- format tables (brotli_amd/data/brotli_tables.bin, tools/gen_tables.c) --
+struct HostTables {
+  uint8_t context_lut[2048];
+  uint8_t size_bits_by_length[32];
+  uint32_t offsets_by_length[32];
+  std::vector<uint8_t> dict;
+  std::vector<uint16_t> hash_words;
+  std::vector<uint8_t> hash_lengths;
+};
+
+static inline bool host_tables_load(const char* path, HostTables* t) {
+  FILE* f = fopen(path, "rb");
+  if (!f) return false;
+  char magic[4];
+  uint32_t ver = 0, dsz = 0;
+  bool ok = fread(magic, 1, 4, f) == 4 && !memcmp(magic, "BRTB", 4) &&
+            fread(&ver, 4, 1, f) == 1 && ver == 1 &&
+            fread(t->context_lut, 1, 2048, f) == 2048 &&
+            fread(t->size_bits_by_length, 1, 32, f) == 32 &&
+            fread(t->offsets_by_length, 4, 32, f) == 32 && fread(&dsz, 4, 1, f) == 1;
+  if (ok) {
+    const uint32_t padded = (dsz + 3u) & ~3u;
+    t->dict.resize(padded + 64);
+    t->hash_words.resize(32768);
+    t->hash_lengths.resize(32768);
+    ok = fread(t->dict.data(), 1, padded, f) == padded &&
+         fread(t->hash_words.data(), 2, 32768, f) == 32768 &&
+         fread(t->hash_lengths.data(), 1, 32768, f) == 32768;
+  }
+  fclose(f);
+  return ok;
+}
+
+// FastLog2 (c/enc/fast_log.h:51-59): a table of float literals widened to
+// double below 256 (fast_log.c:14), libm log2() above.  Built with the host's
+// libm so device entropy decisions see exactly the reference's values.
+static inline void host_log2_lut(uint32_t n, std::vector<double>* lut) {
+  lut->resize(n);
+  (*lut)[0] = 0.0;
+  for (uint32_t i = 1; i < n; ++i) {
+    (*lut)[i] = i < 256 ? (double)(float)log2((double)i) : log2((double)i);
+  }
+}
+
+// Host-memory DeviceTables (simulator).  The HIP layer does the same with
+// device copies.
+static inline void host_tables_fill(const HostTables& h, uint32_t log2_n,
+                                    std::vector<double>* lut, DeviceTables* T) {
+  host_log2_lut(log2_n, lut);
+  T->context_lut = h.context_lut + (2 << 9);  // CONTEXT_UTF8, context.h:104
+  T->dict = h.dict.data();
+  T->dict_hash_words = h.hash_words.data();
+  T->dict_hash_lengths = h.hash_lengths.data();
+  T->log2_lut = lut->data();
+  memcpy(T->dict_offsets_by_length, h.offsets_by_length, sizeof(T->dict_offsets_by_length));
+  memcpy(T->dict_size_bits_by_length, h.size_bits_by_length, sizeof(T->dict_size_bits_by_length));
+}
+
+#endif  // BROTLI_AMD_CSRC_HOST_PLAN_H_

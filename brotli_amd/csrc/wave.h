@@ -1,0 +1,80 @@
+// brotli_amd/csrc/wave.h — wavefront-level primitives for gfx950 (wave64).
+//
+// Every kernel in this directory is written for ONE 64-lane wavefront per
+// workgroup owning one encoder shard: control flow is wave-uniform, the
+// cross-lane operations below are only ever called with all 64 lanes active.
+//
+// tests/simt (a host fiber simulator used to check kernel *logic* in CI
+// without a GPU) provides the same names when BROTLI_AMD_SIMT_SIM is defined;
+// the shipped library is always built without it.
+#ifndef BROTLI_AMD_CSRC_WAVE_H_
+#define BROTLI_AMD_CSRC_WAVE_H_
+
+#include <stdint.h>
+
+#if defined(BROTLI_AMD_SIMT_SIM)
+
+#include "simt.h"
+#define WAVE_SITE __LINE__
+#define wave_ballot(p) simt_ballot((p), WAVE_SITE)
+#define wave_shfl(v, src) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), (src), WAVE_SITE))
+#define wave_shfl64(v, src) simt_shfl64((uint64_t)(v), (src), WAVE_SITE)
+#define wave_bcast(v, lane) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), (lane), WAVE_SITE))
+#define wave_bcast64(v, lane) simt_shfl64((uint64_t)(v), (lane), WAVE_SITE)
+#define wave_sync() simt_sync(WAVE_SITE)
+static inline int wave_lane() { return (int)(threadIdx.x & 63); }
+static inline int dev_ctz64(uint64_t x) { return __builtin_ctzll(x); }
+static inline int dev_ctz32(uint32_t x) { return __builtin_ctz(x); }
+static inline int dev_clz32(uint32_t x) { return __builtin_clz(x); }
+static inline int dev_popc64(uint64_t x) { return __builtin_popcountll(x); }
+template <class T> static inline T lds_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> static inline T lds_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
+
+#else  // ---- gfx950 ---------------------------------------------------------
+
+#include <hip/hip_runtime.h>
+
+__device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63); }
+
+// 64-bit mask of lanes whose predicate holds (s_and / v_cmp into an SGPR pair).
+__device__ __forceinline__ uint64_t wave_ballot(bool p) { return __ballot(p); }
+
+// Arbitrary per-lane source (ds_bpermute_b32).
+__device__ __forceinline__ uint32_t wave_shfl(uint32_t v, int src) {
+  return (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)v);
+}
+__device__ __forceinline__ uint64_t wave_shfl64(uint64_t v, int src) {
+  uint32_t lo = wave_shfl((uint32_t)v, src), hi = wave_shfl((uint32_t)(v >> 32), src);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Wave-uniform source lane (v_readlane_b32 -> SGPR): the result is uniform.
+__device__ __forceinline__ uint32_t wave_bcast(uint32_t v, int lane) {
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+__device__ __forceinline__ uint64_t wave_bcast64(uint64_t v, int lane) {
+  uint32_t lo = wave_bcast((uint32_t)v, lane), hi = wave_bcast((uint32_t)(v >> 32), lane);
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Orders this wave's earlier global/LDS accesses before its later ones as seen
+// by the other lanes of the same wave.  Wavefront scope needs no cache action
+// or s_waitcnt on gfx950 (one wave issues its memory instructions in order to
+// one L1); it stops the compiler from moving accesses across.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int dev_ctz64(uint64_t x) { return __builtin_ctzll(x); }
+__device__ __forceinline__ int dev_ctz32(uint32_t x) { return __builtin_ctz(x); }
+__device__ __forceinline__ int dev_clz32(uint32_t x) { return __builtin_clz(x); }
+__device__ __forceinline__ int dev_popc64(uint64_t x) { return __builtin_popcountll(x); }
+template <class T> __device__ __forceinline__ T lds_atomic_add(T* p, T v) { return atomicAdd(p, v); }
+template <class T> __device__ __forceinline__ T lds_atomic_or(T* p, T v) { return atomicOr(p, v); }
+
+#endif
+
+#define DEV __device__ __forceinline__
+
+#endif  // BROTLI_AMD_CSRC_WAVE_H_

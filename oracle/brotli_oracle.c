@@ -663,13 +663,6 @@ static void CreateBackwardReferences(Enc* s, size_t num_bytes, size_t position) 
   }
   insert_length += pos_end - position;
   s->last_insert_len = insert_length;
-  if (g_tap) {
-    size_t k, n = (size_t)(commands - orig);
-    for (k = 0; k < n; ++k) {
-      if (*g_tap_n < g_tap_cap) g_tap[*g_tap_n] = orig[k];
-      ++*g_tap_n;
-    }
-  }
   s->ncmds += (size_t)(commands - orig);
 }
 
@@ -1631,6 +1624,13 @@ static void WriteMetaBlock(Enc* s, size_t bytes, int is_last, size_t* ix, uint8_
   size_t literal_context_map_size = 0;
   size_t i;
 
+  if (g_tap) { /* parity tap: the final command list of this meta-block */
+    size_t k;
+    for (k = 0; k < s->ncmds; ++k) {
+      if (*g_tap_n < g_tap_cap) g_tap[*g_tap_n] = s->cmds[k];
+      ++*g_tap_n;
+    }
+  }
   if (bytes == 0) {
     WriteBits(2, 3, ix, storage);
     *ix = (*ix + 7u) & ~(size_t)7u;

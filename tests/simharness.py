@@ -1,0 +1,75 @@
+"""Test-only ctypes wrapper around tests/simt/libsimkernels.so (kernel logic on
+the host SIMT simulator) and the oracle's command tap."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from refharness import ROOT, TABLES, Oracle
+
+SIM_SO = os.path.join(ROOT, "tests", "simt", "libsimkernels.so")
+
+CMD_DTYPE = np.dtype([("insert_len", "<u4"), ("copy_len", "<u4"),
+                      ("dist_extra", "<u4"), ("cmd_prefix", "<u2"),
+                      ("dist_prefix", "<u2")])
+
+
+def build_sim():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "simt")],
+                   check=True)
+
+
+class Sim:
+    def __init__(self):
+        build_sim()
+        self.L = C.CDLL(SIM_SO)
+        self.L.sim_parse.restype = C.c_long
+        self.L.sim_parse.argtypes = [
+            C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
+            C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
+            C.POINTER(C.c_uint64)]
+
+    def parse(self, data, quality=5, lgwin=22, size_hint=0, shard_size=0,
+              reverse=0, no_pair=0):
+        cap = len(data) // 2 + 64
+        arr = np.zeros(cap, dtype=CMD_DTYPE)
+        stats = (C.c_uint64 * 3)()
+        n = self.L.sim_parse(TABLES.encode(), bytes(data), len(data), quality,
+                             lgwin, size_hint, shard_size, reverse, no_pair,
+                             arr.ctypes.data, cap, stats)
+        assert n >= 0, n
+        return arr[:n], list(stats)
+
+
+def oracle_commands(oracle, data, quality=5, lgwin=22, size_hint=0,
+                    shard_size=0):
+    """Command lists (first real meta-block of every shard), concatenated.
+    The 2-byte flint meta-block of continuation shards (its single insert-only
+    command) is dropped: the device emits that block inline."""
+    L = oracle.L
+    L.oracle_set_command_tap.argtypes = [C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_size_t)]
+    n_total = len(data)
+    if not shard_size or shard_size >= n_total:
+        shard_size = n_total
+    hint = size_hint or min(n_total, 1 << 30)
+    out = []
+    off = 0
+    while off < n_total:
+        m = min(shard_size, n_total - off)
+        cap = m // 2 + 64
+        arr = np.zeros(cap, dtype=CMD_DTYPE)
+        n = C.c_size_t(0)
+        L.oracle_set_command_tap(arr.ctypes.data, cap, C.byref(n))
+        try:
+            oracle.encode_shard(data[off:off + m], quality, lgwin, hint,
+                                min(off, 1 << 30), off + m == n_total)
+        finally:
+            L.oracle_set_command_tap(None, 0, None)
+        cmds = arr[:n.value]
+        if off and m > 2:
+            cmds = cmds[1:]
+        out.append(cmds)
+        off += m
+    return np.concatenate(out)
