@@ -1,0 +1,387 @@
+// brotli_amd/csrc/hip_layer.hip — the HIP C-ABI layer (include/brotli_amd_hip.h):
+// context / workspace management, kernel launches on the context's stream,
+// HIP-event timing.  Written for gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/brotli_amd_hip.h"
+#include "host_plan.h"
+#include "kernels.h"
+
+struct BrotliAmdCtx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  HostTables ht;
+  uint8_t* d_lut = nullptr;
+  uint8_t* d_dict = nullptr;
+  uint16_t* d_hash_words = nullptr;
+  uint8_t* d_hash_lengths = nullptr;
+  double* d_log2 = nullptr;
+  uint32_t log2_n = 0;
+  DeviceTables* d_T = nullptr;
+  uint8_t* d_ws = nullptr;
+  uint64_t ws_cap = 0;
+  ShardDesc* d_shards = nullptr;
+  ShardState* d_states = nullptr;
+  uint64_t* d_scan = nullptr;       // nshards + 1 output offsets
+  uint32_t* d_counters = nullptr;   // [0] shards not done, [1] shards in error
+  uint64_t shard_cap = 0;
+  uint8_t* d_stage_in = nullptr;    // encode_host staging
+  uint8_t* d_stage_out = nullptr;
+  uint64_t stage_in_cap = 0, stage_out_cap = 0;
+  hipEvent_t ev[8] = {};
+  std::string err;
+};
+
+namespace {
+
+bool fail(BrotliAmdCtx* c, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  c->err = buf;
+  return false;
+}
+
+#define HIP_OK(c, expr)                                                        \
+  do {                                                                         \
+    hipError_t e_ = (expr);                                                    \
+    if (e_ != hipSuccess) {                                                    \
+      fail((c), "%s: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return false;                                                            \
+    }                                                                          \
+  } while (0)
+
+template <class T>
+bool dev_upload(BrotliAmdCtx* c, T** dst, const void* src, size_t bytes) {
+  HIP_OK(c, hipMalloc((void**)dst, bytes ? bytes : 1));
+  HIP_OK(c, hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+  return true;
+}
+
+bool ensure_log2(BrotliAmdCtx* c, uint32_t n) {
+  if (n <= c->log2_n) return true;
+  std::vector<double> lut;
+  host_log2_lut(n, &lut);
+  if (c->d_log2) HIP_OK(c, hipFree(c->d_log2));
+  c->d_log2 = nullptr;
+  HIP_OK(c, hipMalloc((void**)&c->d_log2, (size_t)n * sizeof(double)));
+  HIP_OK(c, hipMemcpy(c->d_log2, lut.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+  c->log2_n = n;
+  DeviceTables T;
+  memset(&T, 0, sizeof(T));
+  T.context_lut = c->d_lut + (2 << 9);  // CONTEXT_UTF8, c/common/context.h:104
+  T.dict = c->d_dict;
+  T.dict_hash_words = c->d_hash_words;
+  T.dict_hash_lengths = c->d_hash_lengths;
+  T.log2_lut = c->d_log2;
+  memcpy(T.dict_offsets_by_length, c->ht.offsets_by_length, sizeof(T.dict_offsets_by_length));
+  memcpy(T.dict_size_bits_by_length, c->ht.size_bits_by_length, sizeof(T.dict_size_bits_by_length));
+  if (!c->d_T) HIP_OK(c, hipMalloc((void**)&c->d_T, sizeof(DeviceTables)));
+  HIP_OK(c, hipMemcpy(c->d_T, &T, sizeof(T), hipMemcpyHostToDevice));
+  return true;
+}
+
+bool ensure_ws(BrotliAmdCtx* c, uint64_t ws_bytes, uint64_t nshards) {
+  if (ws_bytes > c->ws_cap) {
+    if (c->d_ws) HIP_OK(c, hipFree(c->d_ws));
+    c->d_ws = nullptr;
+    c->ws_cap = 0;
+    HIP_OK(c, hipMalloc((void**)&c->d_ws, ws_bytes));
+    c->ws_cap = ws_bytes;
+  }
+  if (nshards > c->shard_cap) {
+    if (c->d_shards) HIP_OK(c, hipFree(c->d_shards));
+    if (c->d_states) HIP_OK(c, hipFree(c->d_states));
+    if (c->d_scan) HIP_OK(c, hipFree(c->d_scan));
+    c->d_shards = nullptr; c->d_states = nullptr; c->d_scan = nullptr;
+    c->shard_cap = 0;
+    HIP_OK(c, hipMalloc((void**)&c->d_shards, nshards * sizeof(ShardDesc)));
+    HIP_OK(c, hipMalloc((void**)&c->d_states, nshards * sizeof(ShardState)));
+    HIP_OK(c, hipMalloc((void**)&c->d_scan, (nshards + 1) * sizeof(uint64_t)));
+    c->shard_cap = nshards;
+  }
+  if (!c->d_counters) HIP_OK(c, hipMalloc((void**)&c->d_counters, 16 * sizeof(uint32_t)));
+  return true;
+}
+
+int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, JobPlan* plan) {
+  if (len == 0) { fail(c, "empty job"); return BROTLI_AMD_UNSUPPORTED; }
+  if (p->shard_size && p->stream_base % p->shard_size) {
+    fail(c, "stream_base must be a multiple of shard_size");
+    return BROTLI_AMD_UNSUPPORTED;
+  }
+  if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
+                p->is_last != 0, plan)) {
+    fail(c, "parameters outside the GPU path (quality %d lgwin %d)", p->quality, p->lgwin);
+    return BROTLI_AMD_UNSUPPORTED;
+  }
+  if (p->flags & BROTLI_AMD_FLAG_NO_PAIR) plan->J.flags |= JOB_FLAG_NO_PAIR;
+  return BROTLI_AMD_OK;
+}
+
+enum { STAGE_PARSE = 1, STAGE_BUILD = 2, STAGE_STORE = 4, STAGE_ALL = 7 };
+
+// Runs the job's rounds on the context stream.  On return (synchronised) the
+// shard states describe the outputs sitting in the workspace.
+bool run_rounds(BrotliAmdCtx* c, const JobPlan& plan, const uint8_t* d_in, int stages,
+                BrotliAmdJobInfo* info, std::vector<ShardState>* states_out) {
+  const uint32_t nshards = (uint32_t)plan.shards.size();
+  if (!ensure_log2(c, plan.J.log2_lut_size)) return false;
+  if (!ensure_ws(c, plan.ws_bytes, nshards)) return false;
+  HIP_OK(c, hipMemcpyAsync(c->d_shards, plan.shards.data(), nshards * sizeof(ShardDesc),
+                           hipMemcpyHostToDevice, c->stream));
+  JobArgs a;
+  a.J = plan.J;
+  a.shards = c->d_shards;
+  a.states = c->d_states;
+  a.T = c->d_T;
+  a.input = d_in;
+  a.ws = c->d_ws;
+  a.nshards = nshards;
+  a.counters = c->d_counters;
+  // Table init: enough 256-thread blocks per shard to stream the 128-byte
+  // records at HBM rate without flooding the dispatcher.
+  uint32_t ibs = 4096u / (nshards < 4096u ? nshards : 4096u);
+  if (ibs < 1) ibs = 1;
+  if (ibs > 64) ibs = 64;
+  a.init_blocks_per_shard = ibs;
+
+  float ms_parse = 0, ms_build = 0, ms_store = 0;
+  HIP_OK(c, hipEventRecord(c->ev[0], c->stream));
+  hipLaunchKernelGGL(k_init, dim3(nshards * ibs), dim3(256), 0, c->stream, a);
+  HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
+  uint32_t rounds = 0;
+  for (;;) {
+    HIP_OK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
+    HIP_OK(c, hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_parse, dim3(nshards), dim3(64), 0, c->stream, a);
+    HIP_OK(c, hipEventRecord(c->ev[3], c->stream));
+    if (stages & STAGE_BUILD) hipLaunchKernelGGL(k_build, dim3(nshards), dim3(64), 0, c->stream, a);
+    HIP_OK(c, hipEventRecord(c->ev[4], c->stream));
+    if (stages & STAGE_STORE) hipLaunchKernelGGL(k_store, dim3(nshards), dim3(64), 0, c->stream, a);
+    HIP_OK(c, hipEventRecord(c->ev[5], c->stream));
+    uint32_t counters[16];
+    HIP_OK(c, hipMemcpyAsync(counters, c->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipGetLastError());
+    float t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[2], c->ev[3])); ms_parse += t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[3], c->ev[4])); ms_build += t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[4], c->ev[5])); ms_store += t;
+    ++rounds;
+    if (counters[1]) return fail(c, "%u shard(s) reported a device fault", counters[1]);
+    if (counters[0] == 0 || stages != STAGE_ALL) break;
+  }
+  if (info) {
+    float t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
+    info->ms_init = t;
+    info->ms_parse = ms_parse;
+    info->ms_build = ms_build;
+    info->ms_store = ms_store;
+    info->rounds = rounds;
+    info->nshards = nshards;
+    info->ws_bytes = plan.ws_bytes;
+  }
+  if (states_out) {
+    states_out->resize(nshards);
+    HIP_OK(c, hipMemcpy(states_out->data(), c->d_states, nshards * sizeof(ShardState),
+                        hipMemcpyDeviceToHost));
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** out) {
+  *out = nullptr;
+  BrotliAmdCtx* c = new BrotliAmdCtx();
+  *out = c;   // returned even on failure so the caller can read the error
+  c->device = device;
+  if (!host_tables_load(tables_path, &c->ht)) {
+    fail(c, "cannot load format tables from %s", tables_path);
+    return BROTLI_AMD_ERROR;
+  }
+  auto body = [&]() -> bool {
+    int n = 0;
+    HIP_OK(c, hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(c, "no HIP device %d (count %d)", device, n);
+    HIP_OK(c, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_OK(c, hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(c, "device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
+    HIP_OK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto& e : c->ev) HIP_OK(c, hipEventCreate(&e));
+    if (!dev_upload(c, &c->d_lut, c->ht.context_lut, 2048)) return false;
+    if (!dev_upload(c, &c->d_dict, c->ht.dict.data(), c->ht.dict.size())) return false;
+    if (!dev_upload(c, &c->d_hash_words, c->ht.hash_words.data(), 32768 * 2)) return false;
+    if (!dev_upload(c, &c->d_hash_lengths, c->ht.hash_lengths.data(), 32768)) return false;
+    return ensure_log2(c, 1u << 16);
+  };
+  return body() ? BROTLI_AMD_OK : BROTLI_AMD_ERROR;
+}
+
+void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* ptrs[] = {c->d_lut, c->d_dict, c->d_hash_words, c->d_hash_lengths, c->d_log2, c->d_T,
+                  c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters,
+                  c->d_stage_in, c->d_stage_out};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* brotli_amd_last_error(const BrotliAmdCtx* c) { return c ? c->err.c_str() : "no context"; }
+
+uint64_t brotli_amd_max_output(uint64_t len, const BrotliAmdJobParams* p) {
+  JobPlan plan;
+  if (len == 0) return 16;
+  if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
+                p->is_last != 0, &plan)) return 0;
+  return plan.max_out_bytes;
+}
+
+int brotli_amd_encode_device(BrotliAmdCtx* c, const void* d_in, uint64_t len,
+                             const BrotliAmdJobParams* p, void* d_out, uint64_t out_cap,
+                             uint64_t* out_size, uint64_t* d_shard_sizes,
+                             BrotliAmdJobInfo* info) {
+  BrotliAmdJobInfo local;
+  if (!info) info = &local;
+  memset(info, 0, sizeof(*info));
+  *out_size = 0;
+  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  JobPlan plan;
+  int rc = plan_from_params(c, len, p, &plan);
+  if (rc != BROTLI_AMD_OK) return rc;
+  const uint32_t nshards = (uint32_t)plan.shards.size();
+  auto body = [&]() -> bool {
+    HIP_OK(c, hipEventRecord(c->ev[6], c->stream));
+    if (!run_rounds(c, plan, (const uint8_t*)d_in, STAGE_ALL, info, nullptr)) return false;
+    // Concatenate the shard outputs: exclusive scan of sizes, then one
+    // 16-byte-per-lane copy grid.
+    JobArgs a;
+    a.J = plan.J;
+    a.shards = c->d_shards;
+    a.states = c->d_states;
+    a.T = c->d_T;
+    a.input = (const uint8_t*)d_in;
+    a.ws = c->d_ws;
+    a.nshards = nshards;
+    a.counters = c->d_counters;
+    a.init_blocks_per_shard = 1;
+    HIP_OK(c, hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(k_scan_sizes, dim3(1), dim3(1024), 0, c->stream, a, c->d_scan, d_shard_sizes);
+    uint64_t total = 0;
+    HIP_OK(c, hipMemcpyAsync(&total, c->d_scan + nshards, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    if (total > out_cap) { *out_size = total; c->err = "output capacity too small"; rc = BROTLI_AMD_OVERFLOW; return true; }
+    // ~64 KiB of output per block.
+    uint64_t avg = total / nshards + 1;
+    uint32_t bps = (uint32_t)((avg + 65535) / 65536);
+    if (bps < 1) bps = 1;
+    if (bps > 1024) bps = 1024;
+    hipLaunchKernelGGL(k_gather, dim3(nshards * bps), dim3(256), 0, c->stream, a, c->d_scan,
+                       (uint8_t*)d_out, bps);
+    HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_OK(c, hipEventRecord(c->ev[7], c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipGetLastError());
+    float t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[0], c->ev[1])); info->ms_gather = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[6], c->ev[7])); info->ms_total = t;
+    info->out_bytes = total;
+    *out_size = total;
+    return true;
+  };
+  if (!body()) return c->err.find("device fault") != std::string::npos ? BROTLI_AMD_DEVICE_FAULT : BROTLI_AMD_ERROR;
+  return rc;
+}
+
+int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
+                           const BrotliAmdJobParams* p, uint8_t* out, uint64_t out_cap,
+                           uint64_t* out_size, BrotliAmdJobInfo* info) {
+  *out_size = 0;
+  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  const uint64_t max_out = brotli_amd_max_output(len, p);
+  if (max_out == 0) { fail(c, "parameters outside the GPU path"); return BROTLI_AMD_UNSUPPORTED; }
+  auto stage = [&]() -> bool {
+    if (len + BROTLI_AMD_INPUT_SLACK > c->stage_in_cap) {
+      if (c->d_stage_in) HIP_OK(c, hipFree(c->d_stage_in));
+      c->d_stage_in = nullptr; c->stage_in_cap = 0;
+      HIP_OK(c, hipMalloc((void**)&c->d_stage_in, len + BROTLI_AMD_INPUT_SLACK));
+      c->stage_in_cap = len + BROTLI_AMD_INPUT_SLACK;
+    }
+    if (max_out > c->stage_out_cap) {
+      if (c->d_stage_out) HIP_OK(c, hipFree(c->d_stage_out));
+      c->d_stage_out = nullptr; c->stage_out_cap = 0;
+      HIP_OK(c, hipMalloc((void**)&c->d_stage_out, max_out));
+      c->stage_out_cap = max_out;
+    }
+    HIP_OK(c, hipMemcpyAsync(c->d_stage_in, in, len, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(c, hipMemsetAsync(c->d_stage_in + len, 0, BROTLI_AMD_INPUT_SLACK, c->stream));
+    return true;
+  };
+  if (!stage()) return BROTLI_AMD_ERROR;
+  uint64_t n = 0;
+  int rc = brotli_amd_encode_device(c, c->d_stage_in, len, p, c->d_stage_out, c->stage_out_cap, &n,
+                                    nullptr, info);
+  if (rc != BROTLI_AMD_OK) return rc;
+  *out_size = n;
+  if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
+  if (hipMemcpy(out, c->d_stage_out, n, hipMemcpyDeviceToHost) != hipSuccess) {
+    fail(c, "D2H copy failed");
+    return BROTLI_AMD_ERROR;
+  }
+  return BROTLI_AMD_OK;
+}
+
+int brotli_amd_debug_parse(BrotliAmdCtx* c, const void* d_in, uint64_t len,
+                           const BrotliAmdJobParams* p, void* h_cmds, uint64_t cmd_cap,
+                           uint64_t* ncmds, BrotliAmdJobInfo* info) {
+  BrotliAmdJobInfo local;
+  if (!info) info = &local;
+  memset(info, 0, sizeof(*info));
+  *ncmds = 0;
+  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  JobPlan plan;
+  int rc = plan_from_params(c, len, p, &plan);
+  if (rc != BROTLI_AMD_OK) return rc;
+  std::vector<ShardState> st;
+  if (!run_rounds(c, plan, (const uint8_t*)d_in, STAGE_PARSE, info, &st)) return BROTLI_AMD_ERROR;
+  uint64_t n = 0;
+  Command* dst = (Command*)h_cmds;
+  for (size_t k = 0; k < st.size(); ++k) {
+    const uint64_t m = st[k].ncmds;
+    info->searches += st[k].stat_searches;
+    info->search_steps += st[k].stat_pairs;
+    if (n + m <= cmd_cap && m) {
+      if (hipMemcpy(dst + n, c->d_ws + plan.shards[k].cmds_off, m * sizeof(Command),
+                    hipMemcpyDeviceToHost) != hipSuccess) {
+        fail(c, "command download failed");
+        return BROTLI_AMD_ERROR;
+      }
+    }
+    n += m;
+  }
+  info->commands = n;
+  *ncmds = n;
+  return n <= cmd_cap ? BROTLI_AMD_OK : BROTLI_AMD_OVERFLOW;
+}
+
+}  // extern "C"

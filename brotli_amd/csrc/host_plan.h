@@ -55,8 +55,12 @@ static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobPa
 
 // Partition plan + workspace layout.  shard_size == 0: one shard (Mode S).
 static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_hint,
-                            uint64_t shard_size, JobPlan* plan) {
-  if (size_hint == 0) size_hint = len >= (1u << 30) ? (1u << 30) : (uint32_t)len;
+                            uint64_t shard_size, uint64_t stream_base, bool is_last,
+                            JobPlan* plan) {
+  if (size_hint == 0) {
+    const uint64_t tot = stream_base + len;
+    size_hint = tot >= (1u << 30) ? (1u << 30) : (uint32_t)tot;
+  }
   if (!plan_params(quality, lgwin, size_hint, &plan->J)) return false;
   if (len == 0) return false;
   if (shard_size == 0 || shard_size >= len) shard_size = len;
@@ -76,10 +80,11 @@ static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_
     const uint64_t n = len - in_off < shard_size ? len - in_off : shard_size;
     D.in_off = in_off;
     D.len = (uint32_t)n;
-    uint64_t so = in_off >= (1u << 30) ? (1u << 30) : in_off;
+    uint64_t so = stream_base + in_off;
+    if (so > (1u << 30)) so = 1u << 30;
     if (so > J.max_backward_limit) so = J.max_backward_limit;   // encode.c:678-682
     D.stream_offset = (uint32_t)so;
-    D.final_op = (k + 1 == nshards) ? 2u : 1u;
+    D.final_op = (k + 1 == nshards && is_last) ? 2u : 1u;
     D.cmd_cap = (uint32_t)(n / 2 + (n >> J.lgblock) + 16);
     const uint64_t mb_len = n < J.max_metablock_size ? n : J.max_metablock_size;
     D.table_off = off; off = plan_align(off + ((uint64_t)REC_BYTES << J.bucket_bits));

@@ -5,6 +5,8 @@
 #define BROTLI_AMD_CSRC_KERNELS_H_
 
 #include "k_round.h"
+#include "k_build.h"
+#include "k_store.h"
 
 struct JobArgs {
   JobParams J;
@@ -15,6 +17,7 @@ struct JobArgs {
   uint8_t* ws;
   uint32_t nshards;
   uint32_t init_blocks_per_shard;
+  uint32_t* counters;   // [0] shards with work left after this round, [1] faults
 };
 
 // grid = nshards * init_blocks_per_shard, block = 256
@@ -33,6 +36,73 @@ __global__ void __launch_bounds__(64) k_parse(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
   parse_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
+  if (threadIdx.x == 0 && a.states[shard].error) atomicAdd(&a.counters[1], 1u);
+}
+
+// grid = nshards, block = 64: block splits, histograms, prefix codes.
+__global__ void __launch_bounds__(64) k_build(JobArgs a) {
+  const uint32_t shard = blockIdx.x;
+  if (shard >= a.nshards) return;
+  build_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
+}
+
+// grid = nshards, block = 64: bit-stream emission of the pending meta-block.
+__global__ void __launch_bounds__(64) k_store(JobArgs a) {
+  const uint32_t shard = blockIdx.x;
+  if (shard >= a.nshards) return;
+  store_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
+  if (threadIdx.x == 0) {
+    if (a.states[shard].error) atomicAdd(&a.counters[1], 1u);
+    else if (!a.states[shard].done) atomicAdd(&a.counters[0], 1u);
+  }
+}
+
+// grid = 1, block = 1024: exclusive scan of the shard output sizes.
+__global__ void __launch_bounds__(1024) k_scan_sizes(JobArgs a, uint64_t* scan, uint64_t* sizes_out) {
+  __shared__ uint64_t part[1024];
+  const uint32_t t = threadIdx.x;
+  const uint32_t per = (a.nshards + 1023u) / 1024u;
+  const uint32_t lo = t * per, hi = lo + per < a.nshards ? lo + per : a.nshards;
+  uint64_t sum = 0;
+  for (uint32_t k = lo; k < hi; ++k) sum += a.states[k].out_bytes;
+  part[t] = sum;
+  __syncthreads();
+  if (t == 0) {
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
+    scan[a.nshards] = run;
+  }
+  __syncthreads();
+  uint64_t run = part[t];
+  for (uint32_t k = lo; k < hi; ++k) {
+    scan[k] = run;
+    const uint64_t n = a.states[k].out_bytes;
+    if (sizes_out) sizes_out[k] = n;
+    run += n;
+  }
+}
+
+// grid = nshards * blocks_per_shard, block = 256: 16 bytes per lane per step.
+__global__ void __launch_bounds__(256) k_gather(JobArgs a, const uint64_t* scan, uint8_t* out,
+                                                uint32_t blocks_per_shard) {
+  const uint32_t shard = blockIdx.x / blocks_per_shard;
+  const uint32_t part = blockIdx.x % blocks_per_shard;
+  if (shard >= a.nshards) return;
+  const uint64_t n = a.states[shard].out_bytes;
+  const uint8_t* src = a.ws + a.shards[shard].out_off;
+  uint8_t* dst = out + scan[shard];
+  const uint64_t chunk = ((n + blocks_per_shard - 1) / blocks_per_shard + 15u) & ~(uint64_t)15u;
+  const uint64_t lo = (uint64_t)part * chunk;
+  const uint64_t hi = lo + chunk < n ? lo + chunk : n;
+  for (uint64_t i = lo + (uint64_t)threadIdx.x * 16u; i < hi; i += 256u * 16u) {
+    if (i + 16u <= hi) {
+      uint32_t v[4];
+      __builtin_memcpy(v, src + i, 16);
+      __builtin_memcpy(dst + i, v, 16);
+    } else {
+      for (uint64_t j = i; j < hi; ++j) dst[j] = src[j];
+    }
+  }
 }
 
 #endif  // BROTLI_AMD_CSRC_KERNELS_H_

@@ -1,0 +1,162 @@
+"""ctypes binding of the HIP C-ABI layer (include/brotli_amd_hip.h).
+
+Device buffers are torch tensors (torch is only the allocator here); every
+call goes through the C ABI of brotli_amd/lib/libbrotli_amd_hip.so.  There is
+no CPU fallback: if the library is missing or no gfx950 device is present the
+constructors raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libbrotli_amd_hip.so")
+TABLES_PATH = os.path.join(_HERE, "data", "brotli_tables.bin")
+INPUT_SLACK = 64
+
+OK, ERROR, UNSUPPORTED, OVERFLOW, DEVICE_FAULT = 0, -1, -2, -3, -4
+FLAG_NO_PAIR = 1
+
+
+class JobParams(C.Structure):
+    _fields_ = [("quality", C.c_int32), ("lgwin", C.c_int32),
+                ("size_hint", C.c_uint32), ("flags", C.c_uint32),
+                ("shard_size", C.c_uint64), ("stream_base", C.c_uint64),
+                ("is_last", C.c_int32), ("reserved", C.c_int32)]
+
+
+class JobInfo(C.Structure):
+    _fields_ = [("nshards", C.c_uint64), ("out_bytes", C.c_uint64),
+                ("ws_bytes", C.c_uint64), ("rounds", C.c_uint32),
+                ("reserved", C.c_uint32), ("ms_total", C.c_float),
+                ("ms_init", C.c_float), ("ms_parse", C.c_float),
+                ("ms_build", C.c_float), ("ms_store", C.c_float),
+                ("ms_gather", C.c_float), ("searches", C.c_uint64),
+                ("search_steps", C.c_uint64), ("commands", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+CMD_DTYPE = np.dtype([("insert_len", "<u4"), ("copy_len", "<u4"),
+                      ("dist_extra", "<u4"), ("cmd_prefix", "<u2"),
+                      ("dist_prefix", "<u2")])
+
+
+class BrotliAmdError(RuntimeError):
+    pass
+
+
+def load_library(path=LIB_PATH):
+    if not os.path.exists(path):
+        raise BrotliAmdError(
+            "HIP library %s is missing: run `python -c 'import __graft_entry__ "
+            "as g; g.build()'` (no CPU fallback exists)" % path)
+    L = C.CDLL(path)
+    L.brotli_amd_ctx_create.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
+    L.brotli_amd_ctx_destroy.argtypes = [C.c_void_p]
+    L.brotli_amd_last_error.argtypes = [C.c_void_p]
+    L.brotli_amd_last_error.restype = C.c_char_p
+    L.brotli_amd_max_output.argtypes = [C.c_uint64, C.POINTER(JobParams)]
+    L.brotli_amd_max_output.restype = C.c_uint64
+    L.brotli_amd_encode_device.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(JobParams), C.c_void_p,
+        C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(JobInfo)]
+    L.brotli_amd_encode_host.argtypes = [
+        C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(JobParams), C.c_void_p,
+        C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(JobInfo)]
+    L.brotli_amd_debug_parse.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(JobParams), C.c_void_p,
+        C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(JobInfo)]
+    return L
+
+
+def make_params(quality=5, lgwin=22, shard_size=0, size_hint=0, stream_base=0,
+                is_last=True, flags=0):
+    return JobParams(quality, lgwin, size_hint, flags, shard_size, stream_base,
+                     1 if is_last else 0, 0)
+
+
+class Context:
+    """One HIP context (device + stream + cached workspace)."""
+
+    def __init__(self, device=0, lib_path=LIB_PATH, tables_path=TABLES_PATH):
+        self.L = load_library(lib_path)
+        h = C.c_void_p()
+        rc = self.L.brotli_amd_ctx_create(device, tables_path.encode(), C.byref(h))
+        self.h = h
+        if rc != OK:
+            msg = self.L.brotli_amd_last_error(h).decode() if h else "?"
+            if h:
+                self.L.brotli_amd_ctx_destroy(h)
+            self.h = None
+            raise BrotliAmdError("brotli_amd_ctx_create failed: " + msg)
+        self.device = device
+
+    def close(self):
+        if self.h:
+            self.L.brotli_amd_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != OK:
+            raise BrotliAmdError("%s failed (%d): %s" % (
+                what, rc, self.L.brotli_amd_last_error(self.h).decode()))
+
+    def max_output(self, n, params):
+        return int(self.L.brotli_amd_max_output(n, C.byref(params)))
+
+    # -- device-resident job (torch uint8 tensors) --------------------------
+    def encode_device(self, d_in, n, params, d_out, d_shard_sizes=None):
+        """d_in: uint8 cuda tensor with >= n + INPUT_SLACK elements; d_out:
+        uint8 cuda tensor.  Returns (out_bytes, info dict)."""
+        assert d_in.is_cuda and d_in.numel() >= n + INPUT_SLACK
+        info = JobInfo()
+        out_size = C.c_uint64(0)
+        rc = self.L.brotli_amd_encode_device(
+            self.h, d_in.data_ptr(), n, C.byref(params), d_out.data_ptr(),
+            d_out.numel(), C.byref(out_size),
+            d_shard_sizes.data_ptr() if d_shard_sizes is not None else None,
+            C.byref(info))
+        self._check(rc, "brotli_amd_encode_device")
+        return int(out_size.value), info.as_dict()
+
+    def encode_host(self, data, params):
+        data = bytes(data)
+        cap = self.max_output(len(data), params)
+        if cap == 0:
+            raise BrotliAmdError("parameters outside the GPU path")
+        out = C.create_string_buffer(cap)
+        info = JobInfo()
+        out_size = C.c_uint64(0)
+        rc = self.L.brotli_amd_encode_host(self.h, data, len(data), C.byref(params),
+                                           out, cap, C.byref(out_size), C.byref(info))
+        self._check(rc, "brotli_amd_encode_host")
+        return out.raw[:out_size.value], info.as_dict()
+
+    def debug_parse(self, d_in, n, params):
+        cap = n // 2 + 64 * (1 + (n // max(1, params.shard_size or n)))
+        arr = np.zeros(cap, dtype=CMD_DTYPE)
+        info = JobInfo()
+        ncmds = C.c_uint64(0)
+        rc = self.L.brotli_amd_debug_parse(self.h, d_in.data_ptr(), n, C.byref(params),
+                                           arr.ctypes.data, cap, C.byref(ncmds),
+                                           C.byref(info))
+        self._check(rc, "brotli_amd_debug_parse")
+        return arr[:ncmds.value], info.as_dict()
+
+
+def to_device(data, device=0):
+    """bytes -> uint8 cuda tensor with the required slack."""
+    import torch
+    a = np.frombuffer(bytes(data), dtype=np.uint8)
+    t = torch.zeros(len(a) + INPUT_SLACK, dtype=torch.uint8, device="cuda:%d" % device)
+    t[:len(a)] = torch.from_numpy(a.copy()).to(t.device)
+    return t

@@ -1,0 +1,109 @@
+/* include/brotli_amd_hip.h — the thin HIP C-ABI layer under the Brotli encoder
+ * boundary (include/brotli_amd_encode.h).
+ *
+ * Plain C: opaque handles, raw pointers, sizes.  Device pointers are ordinary
+ * HIP allocations of the calling process (hipMalloc, or a torch tensor's
+ * data_ptr()).  The layer owns one HIP stream per context, is re-entrant across
+ * contexts (no process-wide state; SURVEY.md §8b "Threading") and never falls
+ * back to a CPU encoder: a parameter combination the kernels do not implement
+ * returns BROTLI_AMD_UNSUPPORTED.
+ *
+ * What it replaces in the reference: the body of EncodeData ->
+ * BrotliCreateBackwardReferences -> WriteMetaBlockInternal
+ * (c/enc/encode.c:985-1221, c/enc/backward_references.c:251-299,
+ * c/enc/encode.c:498-614) for every shard of a partition plan
+ * (BROTLI_PARAM_STREAM_OFFSET contract, c/include/brotli/encode.h:231-246).
+ */
+#ifndef BROTLI_AMD_HIP_H_
+#define BROTLI_AMD_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BROTLI_AMD_OK 0
+#define BROTLI_AMD_ERROR (-1)        /* HIP failure, see brotli_amd_last_error */
+#define BROTLI_AMD_UNSUPPORTED (-2)  /* parameters outside the GPU path */
+#define BROTLI_AMD_OVERFLOW (-3)     /* output capacity too small */
+#define BROTLI_AMD_DEVICE_FAULT (-4) /* a shard reported an internal error */
+
+/* Device input buffers must stay readable this many bytes past `len`
+   (the kernels load 32-byte strings at the last positions; the values read
+   there never influence the result). */
+#define BROTLI_AMD_INPUT_SLACK 64
+
+typedef struct BrotliAmdCtx BrotliAmdCtx;
+
+/* One job = one contiguous piece of one Brotli stream handled by one GPU. */
+typedef struct BrotliAmdJobParams {
+  int32_t quality;       /* BROTLI_PARAM_QUALITY (encode.h:175) */
+  int32_t lgwin;         /* BROTLI_PARAM_LGWIN (encode.h:185) */
+  uint32_t size_hint;    /* BROTLI_PARAM_SIZE_HINT of the WHOLE stream, capped
+                            at 1<<30 (encode.h:209, encode.c:1619-1632);
+                            0 = min(stream_base + len, 1<<30) */
+  uint32_t flags;        /* BROTLI_AMD_FLAG_* */
+  uint64_t shard_size;   /* partition plan: bytes per encoder shard; 0 = one
+                            shard (== BrotliEncoderCompress on the buffer) */
+  uint64_t stream_base;  /* offset of this buffer inside the whole stream; it
+                            must be a multiple of shard_size (multi-GPU: rank r
+                            passes the offset of its first shard) */
+  int32_t is_last;       /* 1: the buffer ends the stream (last shard FINISHes);
+                            0: every shard ends with FLUSH */
+  int32_t reserved;
+} BrotliAmdJobParams;
+
+#define BROTLI_AMD_FLAG_NO_PAIR 1u   /* debugging: no speculative (p,p+1) search */
+
+typedef struct BrotliAmdJobInfo {
+  uint64_t nshards;
+  uint64_t out_bytes;
+  uint64_t ws_bytes;        /* HBM workspace used by the job */
+  uint32_t rounds;          /* parse/build/store rounds (1 unless a shard holds
+                               several meta-blocks) */
+  uint32_t reserved;
+  float ms_total;           /* HIP-event time of the whole job on the stream */
+  float ms_init, ms_parse, ms_build, ms_store, ms_gather;
+  uint64_t searches;        /* FindLongestMatch calls (reference count) */
+  uint64_t search_steps;    /* paired search steps actually executed */
+  uint64_t commands;
+} BrotliAmdJobInfo;
+
+/* `tables_path`: brotli_amd/data/brotli_tables.bin (RFC 7932 format data). */
+int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** ctx);
+void brotli_amd_ctx_destroy(BrotliAmdCtx* ctx);
+const char* brotli_amd_last_error(const BrotliAmdCtx* ctx);
+
+/* Upper bound of the bytes a job can produce (sum over shards of the
+   reference's 2*n+503 storage bound, encode.c:1187, plus flush padding). */
+uint64_t brotli_amd_max_output(uint64_t len, const BrotliAmdJobParams* p);
+
+/* Encodes d_in[0,len) (device memory, BROTLI_AMD_INPUT_SLACK readable past
+   the end) into d_out (device memory, out_cap bytes): the concatenation of
+   the shards' outputs in order.  d_shard_sizes (device, may be NULL) receives
+   nshards u64 compressed sizes.  Synchronous on return. */
+int brotli_amd_encode_device(BrotliAmdCtx* ctx, const void* d_in, uint64_t len,
+                             const BrotliAmdJobParams* p, void* d_out,
+                             uint64_t out_cap, uint64_t* out_size,
+                             uint64_t* d_shard_sizes, BrotliAmdJobInfo* info);
+
+/* Same with host buffers (H2D + job + D2H on the context's stream). */
+int brotli_amd_encode_host(BrotliAmdCtx* ctx, const uint8_t* in, uint64_t len,
+                           const BrotliAmdJobParams* p, uint8_t* out,
+                           uint64_t out_cap, uint64_t* out_size,
+                           BrotliAmdJobInfo* info);
+
+/* Parity tap used by tests/: runs table init + the LZ77 parse only and copies
+   the command list of the first meta-block of every shard (16-byte records,
+   c/enc/command.h:106-116 field order) to host memory. */
+int brotli_amd_debug_parse(BrotliAmdCtx* ctx, const void* d_in, uint64_t len,
+                           const BrotliAmdJobParams* p, void* h_cmds,
+                           uint64_t cmd_cap, uint64_t* ncmds,
+                           BrotliAmdJobInfo* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif  /* BROTLI_AMD_HIP_H_ */

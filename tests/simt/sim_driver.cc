@@ -32,7 +32,7 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   HostTables ht;
   if (!host_tables_load(tables_path, &ht)) return -1;
   JobPlan plan;
-  if (!plan_job(len, quality, lgwin, size_hint, shard_size, &plan)) return -2;
+  if (!plan_job(len, quality, lgwin, size_hint, shard_size, 0, true, &plan)) return -2;
   if (no_pair) plan.J.flags |= JOB_FLAG_NO_PAIR;
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);
