@@ -94,7 +94,4 @@ struct DeviceTables {
   uint8_t dict_size_bits_by_length[32];
 };
 
-// Greedy block-split result for one category (metablock.h:28-43).
-#define MB_MAX_TYPES 257
-
 #endif  // BROTLI_AMD_CSRC_ENC_TYPES_H_

@@ -1,7 +1,554 @@
-// placeholder
-#ifndef K_BUILD_H_
-#define K_BUILD_H_
+// brotli_amd/csrc/k_build.h — K3/K4/K5: per-shard meta-block modelling by one
+// wavefront: literal-context decision, symbol streams, greedy block splitting
+// with histograms, and the RLE-friendly count smoothing.
+//
+// Semantics (bit-exact): ShouldCompress (c/enc/encode.c:457-483),
+// DecideOverLiteralContextModeling (encode.c:278-455),
+// BrotliBuildMetaBlockGreedy (c/enc/metablock.c:463-839,
+// c/enc/metablock_inc.h:48-183), BrotliBitsEntropy (c/enc/bit_cost.c:18-44),
+// BrotliOptimizeHistograms (metablock.c:841-859,
+// c/enc/entropy_encode.c:241-370).
+//
+// Design: the reference streams symbols one by one through three splitter
+// objects.  Block decisions only happen every min_block_size symbols, so the
+// wave (i) materialises the literal and distance symbol streams with wave
+// scans over the command list, (ii) histograms one chunk of min_block_size
+// symbols at a time into LDS with all 64 lanes (ds_add), and (iii) at a
+// decision point evaluates all 3 x num_contexts entropies in parallel, one
+// lane per histogram, each lane summing in the reference's index order so the
+// doubles are identical.  The running block lives in LDS; finished block-type
+// histograms live in HBM.
+#ifndef BROTLI_AMD_CSRC_K_BUILD_H_
+#define BROTLI_AMD_CSRC_K_BUILD_H_
+
 #include "device_common.h"
-DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
-                     const DeviceTables* T, const uint8_t* input, uint8_t* ws) {}
+#include "mb_layout.h"
+
+#define LDS_ROW(A) ((A) + 1u)   // padded row: lanes walking different rows hit different banks
+#define BUILD_LDS_WORDS (13u * 257u)
+
+// Static literal context maps (encode.c:283-295, 347-364); index = map_kind.
+static __device__ const uint8_t k_ctx_maps[4][64] = {
+    {0},
+    {1, 1, 2, 2},   // continuation bytes: 3 contexts
+    {0, 0, 1, 1},   // simple UTF-8: 2 contexts
+    {11, 11, 12, 12, 0, 0, 0, 0, 1, 1, 9, 9, 2, 2, 2, 2, 1, 1, 1, 1, 8, 3, 3, 3,
+     1, 1, 1, 1, 2, 2, 2, 2, 8, 4, 4, 4, 8, 7, 4, 4, 8, 0, 0, 0, 3, 3, 3, 3,
+     5, 5, 10, 5, 5, 5, 10, 5, 6, 6, 6, 6, 6, 6, 6, 6}};
+
+// ---- wave scans -------------------------------------------------------------
+DEV uint32_t wave_incl_scan(uint32_t v) {
+  const int lane = wave_lane();
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = wave_shfl(x, (lane - d) & 63);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+
+// ---- entropy (summation order of the reference) ------------------------------
+// BitsEntropy of a[k] + g[k] (either pointer may be null), bit_cost.c:18-44.
+DEV double bits_entropy2(const uint32_t* a, const uint32_t* g, uint32_t n, const double* lut) {
+  uint64_t sum = 0;
+  double r = 0.0;
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t p = (a ? a[k] : 0u) + (g ? g[k] : 0u);
+    if (p) {
+      sum += p;
+      r -= (double)p * lut[p];
+    }
+  }
+  if (sum) r += (double)sum * lut[sum];
+  if (r < (double)sum) r = (double)sum;
+  return r;
+}
+// EstimateEntropy, encode.c:258-269.
+DEV double estimate_entropy(const uint32_t* a, uint32_t n, const double* lut) {
+  uint64_t total = 0;
+  double r = 0.0;
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t p = a[k];
+    total += p;
+    r += (double)p * lut[p];
+  }
+  return (double)total * lut[total] - r;
+}
+
+struct BuildCtx {
+  const JobParams* J;
+  const uint8_t* data;     // shard byte 0
+  const DeviceTables* T;
+  uint8_t* mb;             // MetaBlockWork
+  MbLayout L;
+  const Command* cmds;
+  uint16_t* lits;
+  uint16_t* dsym;
+  uint32_t* lds;           // BUILD_LDS_WORDS
+  double* lds_ent;         // [3 * 13] entropies of the current decision
+  double* lds_last;        // [2 * 13] last_entropy
+  uint32_t nc, map_kind;
+};
+
+// ---- ShouldCompress (encode.c:457-483) ---------------------------------------
+DEV bool should_compress(BuildCtx& b, uint32_t start, uint32_t bytes, uint32_t nlits,
+                         uint32_t ncmds) {
+  const int lane = wave_lane();
+  if (bytes <= 2) return false;
+  if (ncmds < (bytes >> 8) + 2) {
+    if ((double)nlits > 0.99 * (double)bytes) {
+      for (uint32_t k = (uint32_t)lane; k < 256; k += 64) b.lds[k] = 0;
+      wave_sync();
+      const uint32_t t = (bytes + 12u) / 13u;
+      for (uint32_t i = (uint32_t)lane; i < t; i += 64) lds_atomic_add(&b.lds[b.data[start + 13u * i]], 1u);
+      wave_sync();
+      const double thr = (double)bytes * 7.92 * (1.0 / 13.0);
+      const double e = bits_entropy2(b.lds, nullptr, 256, b.T->log2_lut);
+      wave_sync();
+      if (e > thr) return false;
+    }
+  }
+  return true;
+}
+
+// ---- DecideOverLiteralContextModeling (encode.c:278-455) ----------------------
+DEV void decide_contexts(BuildCtx& b, uint32_t start, uint32_t length) {
+  const int lane = wave_lane();
+  const JobParams& J = *b.J;
+  const double* lut2 = b.T->log2_lut;
+  b.nc = 1;
+  b.map_kind = 0;
+  if (J.quality < 5 || length < 64) return;
+  const uint32_t end = start + length;
+  const uint8_t* clut = b.T->context_lut;
+  if (J.size_hint >= (1u << 20)) {
+    // ShouldUseComplexStaticContextMap, :342-420: 64-byte strides every 4 KiB.
+    for (uint32_t k = (uint32_t)lane; k < 32u * 14u; k += 64) b.lds[k] = 0;
+    wave_sync();
+    uint32_t total = 0;
+    for (uint32_t sp = start; sp + 64 <= end; sp += 4096) {
+      if (lane >= 2) {
+        const uint32_t pos = sp + (uint32_t)lane;
+        const uint32_t literal = b.data[pos];
+        const uint32_t ctx = k_ctx_maps[3][clut[b.data[pos - 1]] | clut[256 + b.data[pos - 2]]];
+        lds_atomic_add(&b.lds[literal >> 3], 1u);
+        lds_atomic_add(&b.lds[32u + (ctx << 5) + (literal >> 3)], 1u);
+      }
+      total += 62;
+    }
+    wave_sync();
+    double e1 = estimate_entropy(b.lds, 32, lut2);
+    double e2 = 0.0;
+    for (uint32_t i = 0; i < 13; ++i) e2 += estimate_entropy(b.lds + 32u + (i << 5), 32, lut2);
+    const double inv = 1.0 / (double)total;
+    e1 *= inv;
+    e2 *= inv;
+    wave_sync();
+    if (!(e2 > 3.0 || e1 - e2 < 0.2)) {
+      b.nc = 13;
+      b.map_kind = 3;
+      return;
+    }
+  }
+  // ChooseContextMap, :278-338: bigram histogram of the top two bits.
+  for (uint32_t k = (uint32_t)lane; k < 16; k += 64) b.lds[k] = 0;
+  wave_sync();
+  for (uint32_t sp = start; sp + 64 <= end; sp += 4096) {
+    if (lane >= 1) {
+      const uint32_t pos = sp + (uint32_t)lane;
+      const uint32_t l3 = (0x2100u >> ((b.data[pos] >> 6) * 4u)) & 3u;        // {0,0,1,2}
+      const uint32_t p3 = (0x2100u >> ((b.data[pos - 1] >> 6) * 4u)) & 3u;
+      lds_atomic_add(&b.lds[p3 * 3u + l3], 1u);
+    }
+  }
+  wave_sync();
+  uint32_t monogram[3] = {0, 0, 0}, two_prefix[6] = {0, 0, 0, 0, 0, 0}, bigram[9];
+  for (uint32_t i = 0; i < 9; ++i) bigram[i] = b.lds[i];
+  for (uint32_t i = 0; i < 9; ++i) {
+    monogram[i % 3] += bigram[i];
+    two_prefix[i % 6] += bigram[i];
+  }
+  double e1 = estimate_entropy(monogram, 3, lut2);
+  double e2 = estimate_entropy(two_prefix, 3, lut2) + estimate_entropy(two_prefix + 3, 3, lut2);
+  double e3 = 0.0;
+  for (uint32_t i = 0; i < 3; ++i) e3 += estimate_entropy(bigram + 3 * i, 3, lut2);
+  const uint32_t total = monogram[0] + monogram[1] + monogram[2];
+  const double inv = 1.0 / (double)total;
+  e1 *= inv;
+  e2 *= inv;
+  e3 *= inv;
+  if (J.quality < 7) e3 = e1 * 10;
+  wave_sync();
+  if (e1 - e2 < 0.2 && e1 - e3 < 0.2) {
+    b.nc = 1;
+  } else if (e2 - e3 < 0.02) {
+    b.nc = 2;
+    b.map_kind = 2;
+  } else {
+    b.nc = 3;
+    b.map_kind = 1;
+  }
+}
+
+// ---- symbol streams ------------------------------------------------------------
+// lits[k] = literal | context << 8 in stream order; dsym[k] = distance symbol of
+// the k-th command that carries one (metablock.c:741-769).
+DEV void build_streams(BuildCtx& b, uint32_t start, uint32_t ncmds, uint32_t* nlits_out,
+                       uint32_t* ndist_out) {
+  const int lane = wave_lane();
+  const uint8_t* clut = b.T->context_lut;
+  const uint8_t* cmap = k_ctx_maps[b.map_kind];
+  const bool use_ctx = b.nc > 1;
+  uint32_t pos = start, nlits = 0, ndist = 0;
+  for (uint32_t base = 0; base < ncmds; base += 64) {
+    const uint32_t i = base + (uint32_t)lane;
+    const bool valid = i < ncmds;
+    uint32_t ins = 0, cpy = 0, prefix = 0, dprefix = 0;
+    if (valid) {
+      const Command c = b.cmds[i];
+      ins = c.insert_len;
+      cpy = c.copy_len & 0x1FFFFFFu;
+      prefix = c.cmd_prefix;
+      dprefix = c.dist_prefix;
+    }
+    const uint32_t ins_incl = wave_incl_scan(ins);
+    const uint32_t adv_incl = wave_incl_scan(ins + cpy);
+    const uint32_t my_lit = nlits + ins_incl - ins;
+    const uint32_t my_pos = pos + adv_incl - (ins + cpy);
+    const bool has_dist = valid && cpy != 0 && prefix >= 128;
+    const uint64_t dm = wave_ballot(has_dist);
+    if (has_dist) {
+      const uint32_t k = ndist + (uint32_t)dev_popc64(dm & ((1ull << lane) - 1ull));
+      b.dsym[k] = (uint16_t)(dprefix & 0x3FFu);
+    }
+    // Short insert runs: one lane per command.  Long runs: the whole wave.
+    const bool is_long = ins >= 48u;
+    if (valid && !is_long) {
+      for (uint32_t j = 0; j < ins; ++j) {
+        const uint32_t p = my_pos + j;
+        uint32_t v = b.data[p];
+        if (use_ctx) {
+          const uint32_t p1 = p >= 1 ? b.data[p - 1] : 0u, p2 = p >= 2 ? b.data[p - 2] : 0u;
+          v |= (uint32_t)cmap[clut[p1] | clut[256 + p2]] << 8;
+        }
+        b.lits[my_lit + j] = (uint16_t)v;
+      }
+    }
+    uint64_t lm = wave_ballot(valid && is_long);
+    while (lm) {
+      const int src = dev_ctz64(lm);
+      lm &= lm - 1;
+      const uint32_t n = wave_bcast(ins, src), p0 = wave_bcast(my_pos, src), l0 = wave_bcast(my_lit, src);
+      for (uint32_t j = (uint32_t)lane; j < n; j += 64) {
+        const uint32_t p = p0 + j;
+        uint32_t v = b.data[p];
+        if (use_ctx) {
+          const uint32_t p1 = p >= 1 ? b.data[p - 1] : 0u, p2 = p >= 2 ? b.data[p - 2] : 0u;
+          v |= (uint32_t)cmap[clut[p1] | clut[256 + p2]] << 8;
+        }
+        b.lits[l0 + j] = (uint16_t)v;
+      }
+    }
+    nlits += wave_bcast(ins_incl, 63);
+    pos += wave_bcast(adv_incl, 63);
+    ndist += (uint32_t)dev_popc64(dm);
+  }
+  wave_sync();
+  *nlits_out = nlits;
+  *ndist_out = ndist;
+}
+
+// ---- greedy block splitter -------------------------------------------------------
+// CAT 0: literals (nc contexts), 1: commands, 2: distances.
+template <int CAT>
+DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
+  constexpr uint32_t A = CAT == 0 ? 256u : CAT == 1 ? 704u : 64u;
+  constexpr uint32_t MINB = CAT == 0 ? MB_LIT_MIN_BLOCK : CAT == 1 ? MB_CMD_MIN_BLOCK : MB_DIST_MIN_BLOCK;
+  constexpr uint32_t ROW = LDS_ROW(A);
+  const double threshold = CAT == 0 ? 400.0 : CAT == 1 ? 500.0 : 100.0;
+  const int lane = wave_lane();
+  const uint32_t nc = CAT == 0 ? b.nc : 1u;
+  const uint32_t max_types = MB_MAX_TYPES / nc;
+  const double* lut2 = b.T->log2_lut;
+  uint8_t* types = b.mb + b.L.types[CAT];
+  uint32_t* lengths = (uint32_t*)(b.mb + b.L.lengths[CAT]);
+  uint16_t* blkmap = (uint16_t*)(b.mb + b.L.blkmap[CAT]);
+  uint32_t* G = (uint32_t*)(b.mb + b.L.histos[CAT]);
+  uint32_t* cur = b.lds;
+
+  for (uint32_t k = (uint32_t)lane; k < nc * ROW; k += 64) cur[k] = 0;
+  wave_sync();
+
+  uint32_t num_blocks = 0, num_types = 0, block_size = 0, target = MINB, merge_last_count = 0;
+  uint32_t last_t0 = 0, last_t1 = 0;
+  uint32_t chunk_lo = 0, chunk_hi = 0;   // chunks of the running block
+
+  // One decision of BlockSplitterFinishBlock / ContextBlockSplitterFinishBlock.
+  auto finish = [&](bool is_final) {
+    if (block_size < MINB) block_size = MINB;
+    uint32_t blk_index;
+    if (num_blocks == 0) {
+      if ((uint32_t)lane < nc) {
+        const double e = bits_entropy2(cur + (uint32_t)lane * ROW, nullptr, A, lut2);
+        b.lds_last[lane] = e;
+        b.lds_last[nc + (uint32_t)lane] = e;
+#if defined(BROTLI_AMD_SIMT_SIM)
+        if (getenv("SIM_DEBUG2")) { uint32_t t = 0; for (uint32_t k = 0; k < A; ++k) t += cur[lane * ROW + k]; fprintf(stderr, "cat %d first e=%f total=%u bs=%u\n", CAT, e, t, block_size); }
 #endif
+      }
+      wave_sync();   // entropies read before any lane clears the block
+      if (lane == 0) { lengths[0] = block_size; types[0] = 0; }
+      for (uint32_t k = (uint32_t)lane; k < nc * A; k += 64) {
+        const uint32_t i = k / A, s = k % A;
+        G[k] = cur[i * ROW + s];
+        cur[i * ROW + s] = 0;
+      }
+      blk_index = 0;
+      num_blocks = 1;
+      num_types = 1;
+      block_size = 0;
+    } else {
+      // lane = 3 * ctx + which: 0 current block, 1 merged with the last type,
+      // 2 merged with the second last type.
+      if ((uint32_t)lane < 3u * nc) {
+        const uint32_t i = (uint32_t)lane / 3u, w = (uint32_t)lane % 3u;
+        const uint32_t* g = w == 0 ? nullptr : G + ((w == 1 ? last_t0 : last_t1) * nc + i) * A;
+        b.lds_ent[lane] = bits_entropy2(cur + i * ROW, g, A, lut2);
+      }
+      wave_sync();
+      double diff0 = 0.0, diff1 = 0.0;
+      for (uint32_t i = 0; i < nc; ++i) {
+        const double e = b.lds_ent[3 * i];
+        diff0 += b.lds_ent[3 * i + 1] - e - b.lds_last[i];
+        diff1 += b.lds_ent[3 * i + 2] - e - b.lds_last[nc + i];
+      }
+      wave_sync();
+#if defined(BROTLI_AMD_SIMT_SIM)
+      if (lane == 0 && getenv("SIM_DEBUG2")) fprintf(stderr, "cat %d nb=%u bs=%u e=%f c0=%f c1=%f l0=%f l1=%f d0=%f d1=%f\n", CAT, num_blocks, block_size, b.lds_ent[0], b.lds_ent[1], b.lds_ent[2], b.lds_last[0], b.lds_last[nc], diff0, diff1);
+#endif
+      if (num_types < max_types && diff0 > threshold && diff1 > threshold) {
+        // New block type.
+        if (lane == 0) { lengths[num_blocks] = block_size; types[num_blocks] = (uint8_t)num_types; }
+        last_t1 = last_t0;
+        last_t0 = num_types;
+        if ((uint32_t)lane < nc) {
+          b.lds_last[nc + (uint32_t)lane] = b.lds_last[lane];
+          b.lds_last[lane] = b.lds_ent[3 * lane];
+        }
+        uint32_t* dst = G + (size_t)num_types * nc * A;
+        for (uint32_t k = (uint32_t)lane; k < nc * A; k += 64) {
+          const uint32_t i = k / A, s = k % A;
+          dst[k] = cur[i * ROW + s];
+          cur[i * ROW + s] = 0;
+        }
+        blk_index = num_blocks;
+        ++num_blocks;
+        ++num_types;
+        block_size = 0;
+        merge_last_count = 0;
+        target = MINB;
+      } else if (diff1 < diff0 - 20.0) {
+        // Back to the second last type.
+        if (lane == 0) { lengths[num_blocks] = block_size; types[num_blocks] = types[num_blocks - 2]; }
+        const uint32_t t = last_t0; last_t0 = last_t1; last_t1 = t;
+        if ((uint32_t)lane < nc) {
+          b.lds_last[nc + (uint32_t)lane] = b.lds_last[lane];
+          b.lds_last[lane] = b.lds_ent[3 * lane + 2];
+        }
+        uint32_t* dst = G + (size_t)last_t0 * nc * A;
+        for (uint32_t k = (uint32_t)lane; k < nc * A; k += 64) {
+          const uint32_t i = k / A, s = k % A;
+          dst[k] += cur[i * ROW + s];
+          cur[i * ROW + s] = 0;
+        }
+        blk_index = num_blocks;
+        ++num_blocks;
+        block_size = 0;
+        merge_last_count = 0;
+        target = MINB;
+      } else {
+        // Extend the last block.
+        if (lane == 0) lengths[num_blocks - 1] += block_size;
+        if ((uint32_t)lane < nc) {
+          b.lds_last[lane] = b.lds_ent[3 * lane + 1];
+          if (num_types == 1) b.lds_last[nc + (uint32_t)lane] = b.lds_last[lane];
+        }
+        uint32_t* dst = G + (size_t)last_t0 * nc * A;
+        for (uint32_t k = (uint32_t)lane; k < nc * A; k += 64) {
+          const uint32_t i = k / A, s = k % A;
+          dst[k] += cur[i * ROW + s];
+          cur[i * ROW + s] = 0;
+        }
+        blk_index = num_blocks - 1;
+        block_size = 0;
+        if (++merge_last_count > 1) target += MINB;
+      }
+    }
+    for (uint32_t c = chunk_lo + (uint32_t)lane; c < chunk_hi; c += 64) blkmap[c] = (uint16_t)blk_index;
+    chunk_lo = chunk_hi;
+    wave_sync();
+    (void)is_final;
+  };
+
+  for (uint32_t s0 = 0; s0 < nsym; s0 += MINB) {
+    const uint32_t n = umin(MINB, nsym - s0);
+    for (uint32_t k = (uint32_t)lane; k < n; k += 64) {
+      uint32_t sym, ctx = 0;
+      if (CAT == 0) { const uint32_t v = b.lits[s0 + k]; sym = v & 0xFFu; ctx = v >> 8; }
+      else if (CAT == 1) sym = b.cmds[s0 + k].cmd_prefix;
+      else sym = b.dsym[s0 + k];
+      lds_atomic_add(&cur[ctx * ROW + sym], 1u);
+    }
+    wave_sync();
+    block_size += n;
+    ++chunk_hi;
+    if (block_size == target) finish(false);
+  }
+  finish(true);
+
+  if (lane == 0) {
+    MbInfo* info = (MbInfo*)(b.mb + b.L.info);
+    info->split[CAT].num_types = num_types;
+    info->split[CAT].num_blocks = num_blocks;
+    info->split[CAT].num_histograms = num_types * nc;
+    info->split[CAT].nsym = nsym;
+  }
+  wave_sync();
+}
+
+// ---- BrotliOptimizeHuffmanCountsForRle (entropy_encode.c:241-370) ----------------
+// One lane per histogram; `good` is that lane's private flag array.
+DEV void optimize_counts_for_rle(uint32_t length, uint32_t* counts, uint8_t* good) {
+  uint32_t nonzero_count = 0, i;
+  const uint32_t streak_limit = 1240;
+  for (i = 0; i < length; i++) if (counts[i]) ++nonzero_count;
+  if (nonzero_count < 16) return;
+  while (length != 0 && counts[length - 1] == 0) --length;
+  if (length == 0) return;
+  {
+    uint32_t nonzeros = 0, smallest_nonzero = 1u << 30;
+    for (i = 0; i < length; ++i) {
+      if (counts[i] != 0) {
+        ++nonzeros;
+        if (smallest_nonzero > counts[i]) smallest_nonzero = counts[i];
+      }
+    }
+    if (nonzeros < 5) return;
+    if (smallest_nonzero < 4) {
+      const uint32_t zeros = length - nonzeros;
+      if (zeros < 6) {
+        for (i = 1; i < length - 1; ++i) {
+          if (counts[i - 1] != 0 && counts[i] == 0 && counts[i + 1] != 0) counts[i] = 1;
+        }
+      }
+    }
+    if (nonzeros < 28) return;
+  }
+  for (i = 0; i < length; ++i) good[i] = 0;
+  {
+    uint32_t symbol = counts[0], step = 0;
+    for (i = 0; i <= length; ++i) {
+      if (i == length || counts[i] != symbol) {
+        if ((symbol == 0 && step >= 5) || (symbol != 0 && step >= 7)) {
+          for (uint32_t k = 0; k < step; ++k) good[i - k - 1] = 1;
+        }
+        step = 1;
+        if (i != length) symbol = counts[i];
+      } else {
+        ++step;
+      }
+    }
+  }
+  // The reference mixes uint32_t products with size_t (64-bit, wrapping)
+  // accumulators; the same widths are kept here.
+  uint64_t stride = 0, sum = 0;
+  uint64_t limit = (uint64_t)(256u * (counts[0] + counts[1] + counts[2]) / 3u + 420u);
+  for (i = 0; i <= length; ++i) {
+    if (i == length || good[i] || (i != 0 && good[i - 1]) ||
+        ((uint64_t)(256u * counts[i]) - limit + streak_limit) >= 2ull * streak_limit) {
+      if (stride >= 4 || (stride >= 3 && sum == 0)) {
+        uint64_t count = (sum + stride / 2) / stride;
+        if (count == 0) count = 1;
+        if (sum == 0) count = 0;
+        for (uint64_t k = 0; k < stride; ++k) counts[i - k - 1] = (uint32_t)count;
+      }
+      stride = 0;
+      sum = 0;
+      if (i + 2 < length) {
+        limit = (uint64_t)(256u * (counts[i] + counts[i + 1] + counts[i + 2]) / 3u + 420u);
+      } else if (i < length) {
+        limit = (uint64_t)(256u * counts[i]);
+      } else {
+        limit = 0;
+      }
+    }
+    ++stride;
+    if (i != length) {
+      sum += counts[i];
+      if (stride >= 4) limit = (256 * sum + stride / 2) / stride;
+      if (stride == 4) limit += 120;
+    }
+  }
+}
+
+// ---- the round --------------------------------------------------------------------
+DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
+                     const DeviceTables* T, const uint8_t* input, uint8_t* ws,
+                     uint32_t* lds, double* lds_ent, double* lds_last) {
+  const int lane = wave_lane();
+  if (!S->mb_valid || S->error) return;
+  BuildCtx b;
+  b.J = &J;
+  b.data = input + D.in_off;
+  b.T = T;
+  b.mb = ws + D.mb_off;
+  mb_layout(umin(D.len, J.max_metablock_size), &b.L);
+  b.cmds = (const Command*)(ws + D.cmds_off);
+  b.lits = (uint16_t*)(ws + D.lits_off);
+  b.dsym = (uint16_t*)(ws + D.dsym_off);
+  b.lds = lds;
+  b.lds_ent = lds_ent;
+  b.lds_last = lds_last;
+  b.nc = 1;
+  b.map_kind = 0;
+
+  const uint32_t start = S->mb_start, bytes = S->mb_bytes;
+  const uint32_t ncmds = S->ncmds, nlits_state = S->nlits;
+  MbInfo* info = (MbInfo*)(b.mb + b.L.info);
+
+  if (!should_compress(b, start, bytes, nlits_state, ncmds)) {
+    if (lane == 0) S->mb_raw = 1;
+    wave_sync();
+    return;
+  }
+  decide_contexts(b, start, bytes);
+  uint32_t nlits = 0, ndist = 0;
+  build_streams(b, start, ncmds, &nlits, &ndist);
+  if (lane == 0) {
+    info->num_contexts = b.nc;
+    info->map_kind = b.map_kind;
+    info->nlits = nlits;
+    info->ndist = ndist;
+    info->ncmds = ncmds;
+  }
+  run_splitter<0>(b, nlits);
+  run_splitter<1>(b, ncmds);
+  run_splitter<2>(b, ndist);
+
+  // BrotliOptimizeHistograms: one lane per histogram.
+  {
+    const uint32_t nh[3] = {info->split[0].num_histograms, info->split[1].num_histograms,
+                            info->split[2].num_histograms};
+    const uint32_t alpha[3] = {256u, 704u, 64u};
+    uint8_t* good = b.mb + b.L.rle_flags + (size_t)lane * 704u;
+    for (int c = 0; c < 3; ++c) {
+      uint32_t* G = (uint32_t*)(b.mb + b.L.histos[c]);
+      for (uint32_t h = (uint32_t)lane; h < nh[c]; h += 64)
+        optimize_counts_for_rle(alpha[c], G + (size_t)h * alpha[c], good);
+    }
+  }
+  wave_sync();
+}
+
+#endif  // BROTLI_AMD_CSRC_K_BUILD_H_

@@ -46,6 +46,38 @@ struct RoundRegs {
   uint64_t out_bytes;
 };
 
+DEV void regs_load(RoundRegs& r, const ShardState* S) {
+  r.input_pos = S->input_pos;
+  r.last_processed_pos = S->last_processed_pos;
+  r.last_flush_pos = S->last_flush_pos;
+  r.last_insert_len = S->last_insert_len;
+  r.ncmds = S->ncmds;
+  r.nlits = S->nlits;
+  r.last_bytes = S->last_bytes;
+  r.last_bytes_bits = S->last_bytes_bits;
+  r.flint = S->flint;
+  r.prev_byte = S->prev_byte;
+  r.prev_byte2 = S->prev_byte2;
+  r.out_bytes = S->out_bytes;
+  for (int i = 0; i < 4; ++i) r.saved_dc[i] = S->saved_dist_cache[i];
+}
+// Called by one lane.
+DEV void regs_save(const RoundRegs& r, ShardState* S) {
+  S->input_pos = r.input_pos;
+  S->last_processed_pos = r.last_processed_pos;
+  S->last_flush_pos = r.last_flush_pos;
+  S->last_insert_len = r.last_insert_len;
+  S->ncmds = r.ncmds;
+  S->nlits = r.nlits;
+  S->last_bytes = r.last_bytes;
+  S->last_bytes_bits = r.last_bytes_bits;
+  S->flint = r.flint;
+  S->prev_byte = r.prev_byte;
+  S->prev_byte2 = r.prev_byte2;
+  S->out_bytes = r.out_bytes;
+  for (int i = 0; i < 4; ++i) S->saved_dist_cache[i] = r.saved_dc[i];
+}
+
 DEV void after_metablock(RoundRegs& r, const int32_t* dc, const uint8_t* data,
                          uint8_t* out, BitWriter& w, bool force_flush) {
   bw_flush_bytes(w);
@@ -104,19 +136,7 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   for (int i = 0; i < 4; ++i) c.dc[i] = S->dist_cache[i];
 
   RoundRegs r;
-  r.input_pos = S->input_pos;
-  r.last_processed_pos = S->last_processed_pos;
-  r.last_flush_pos = S->last_flush_pos;
-  r.last_insert_len = S->last_insert_len;
-  r.ncmds = S->ncmds;
-  r.nlits = S->nlits;
-  r.last_bytes = S->last_bytes;
-  r.last_bytes_bits = S->last_bytes_bits;
-  r.flint = S->flint;
-  r.prev_byte = S->prev_byte;
-  r.prev_byte2 = S->prev_byte2;
-  r.out_bytes = S->out_bytes;
-  for (int i = 0; i < 4; ++i) r.saved_dc[i] = S->saved_dist_cache[i];
+  regs_load(r, S);
 
   Command* cmds = (Command*)(ws + D.cmds_off);
   uint8_t* out = ws + D.out_off;
@@ -202,24 +222,10 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
 
   wave_sync();
   if (lane == 0) {
-    S->input_pos = r.input_pos;
-    S->last_processed_pos = r.last_processed_pos;
-    S->last_flush_pos = r.last_flush_pos;
-    S->last_insert_len = r.last_insert_len;
-    S->ncmds = r.ncmds;
-    S->nlits = r.nlits;
-    S->last_bytes = r.last_bytes;
-    S->last_bytes_bits = r.last_bytes_bits;
-    S->flint = r.flint;
-    S->prev_byte = r.prev_byte;
-    S->prev_byte2 = r.prev_byte2;
-    S->out_bytes = r.out_bytes;
+    regs_save(r, S);
     S->dict_lookups = c.dict_lookups;
     S->dict_matches = c.dict_matches;
-    for (int i = 0; i < 4; ++i) {
-      S->dist_cache[i] = c.dc[i];
-      S->saved_dist_cache[i] = r.saved_dc[i];
-    }
+    for (int i = 0; i < 4; ++i) S->dist_cache[i] = c.dc[i];
     S->done = done ? 1u : 0u;
     S->mb_valid = have_mb ? 1u : 0u;
     if (have_mb) {

@@ -1,7 +1,920 @@
-// placeholder
-#ifndef K_STORE_H_
-#define K_STORE_H_
-#include "device_common.h"
+// brotli_amd/csrc/k_store.h — K6/K7/K9: prefix-code construction and bit-stream
+// emission of one meta-block per shard by one wavefront.
+//
+// Semantics (bit-exact): BrotliStoreMetaBlock (c/enc/brotli_bit_stream.c:947-1114)
+// with BuildAndStoreHuffmanTree (:349-397), BrotliStoreHuffmanTree (:283-345),
+// BuildAndStoreBlockSplitCode (:760-791), EncodeContextMap (:574-734),
+// StoreTrivialContextMap (:794-830), StoreSymbol/StoreBlockSwitch (:737-756,
+// 879-918); BrotliCreateHuffmanTree / BrotliWriteHuffmanTree /
+// BrotliConvertBitDepthsToSymbols (c/enc/entropy_encode.c:20-147, 160-239,
+// 372-497); BrotliStoreUncompressedMetaBlock (:1321-1352); the size check and
+// state update of WriteMetaBlockInternal / EncodeData (c/enc/encode.c:598-614,
+// 1188-1216).
+//
+// Design: the reference writes one bit field after another.  Here
+//  * every prefix code of the meta-block (literal / command / distance
+//    histograms, block-type and block-length codes, context-map codes) is an
+//    independent job: one lane builds the tree, assigns the canonical codes
+//    and serialises the code into a private 512-byte buffer;
+//  * the header is then assembled in order, splicing those buffers with
+//    wave-wide shifted copies;
+//  * the command stream is emitted 64 commands at a time: each lane sizes its
+//    command (symbol, extra bits, literals, distance, block switches), a wave
+//    scan turns sizes into bit offsets, and the lanes OR their bits into the
+//    zeroed output with dword atomics.  Block boundaries are multiples of the
+//    splitter's min_block_size, so "which block is symbol k in" is a table
+//    lookup (blkmap) instead of the reference's running counters.
+#ifndef BROTLI_AMD_CSRC_K_STORE_H_
+#define BROTLI_AMD_CSRC_K_STORE_H_
+
+#include "k_build.h"
+#include "k_round.h"
+
+// ---- output bit sink ---------------------------------------------------------
+struct BitSink {
+  uint32_t* base;     // 4-byte aligned
+  uint64_t bitpos;    // next bit, relative to base
+};
+
+// ORs the low `n` bits of `v` (n <= 64) at bit position `pos`.  One lane.
+DEV void or_bits(uint32_t* base, uint64_t pos, uint32_t n, uint64_t v) {
+  if (n == 0) return;
+  if (n < 64) v &= (1ull << n) - 1ull;
+  const uint64_t w = pos >> 5;
+  const uint32_t sh = (uint32_t)pos & 31u;
+  const uint64_t lo = v << sh;
+  const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
+  const uint32_t w2 = sh ? (uint32_t)(v >> (64u - sh)) : 0u;
+  if (w0) glb_atomic_or(base + w, w0);
+  if (w1) glb_atomic_or(base + w + 1, w1);
+  if (w2) glb_atomic_or(base + w + 2, w2);
+}
+// Uniform call: lane 0 writes, every lane advances.
+DEV void sink_put(BitSink& s, uint32_t n, uint64_t v) {
+  if (wave_lane() == 0) or_bits(s.base, s.bitpos, n, v);
+  s.bitpos += n;
+}
+// Splices `nbits` bits that start at byte `src` (whole wave).
+DEV void sink_splice(BitSink& s, const uint8_t* src, uint32_t nbits) {
+  const int lane = wave_lane();
+  const uint32_t nwords = (nbits + 31u) >> 5;
+  for (uint32_t j = (uint32_t)lane; j < nwords; j += 64) {
+    const uint32_t nb = umin(32u, nbits - 32u * j);
+    or_bits(s.base, s.bitpos + 32ull * j, nb, ld32(src + 4u * j));
+  }
+  s.bitpos += nbits;
+}
+DEV void sink_varlen_uint8(BitSink& s, uint32_t n) {   // StoreVarLenUint8
+  if (n == 0) {
+    sink_put(s, 1, 0);
+  } else {
+    const uint32_t nbits = log2floor(n);
+    sink_put(s, 1, 1);
+    sink_put(s, 3, nbits);
+    sink_put(s, nbits, n - (1u << nbits));
+  }
+}
+
+// ---- prefix-code construction (one lane) ---------------------------------------
+struct HNode { uint32_t total_count; int16_t left; int16_t right_or_value; };
+
+DEV bool hnode_less(const HNode& a, const HNode& b) {
+  if (a.total_count != b.total_count) return a.total_count < b.total_count;
+  return a.right_or_value > b.right_or_value;
+}
+
+// BrotliSetDepth, entropy_encode.c:20-42.
+DEV bool set_depth(int p0, const HNode* pool, uint8_t* depth, int max_depth) {
+  int stack[16];
+  int level = 0;
+  int p = p0;
+  stack[0] = -1;
+  for (;;) {
+    if (pool[p].left >= 0) {
+      level++;
+      if (level > max_depth) return false;
+      stack[level] = pool[p].right_or_value;
+      p = pool[p].left;
+      continue;
+    } else {
+      depth[pool[p].right_or_value] = (uint8_t)level;
+    }
+    while (level >= 0 && stack[level] == -1) level--;
+    if (level < 0) return true;
+    p = stack[level];
+    stack[level] = -1;
+  }
+}
+
+// The comparator is a total order (count, then symbol), so any sort yields the
+// reference's sequence; a shell sort with the reference's gaps is used.
+DEV void sort_nodes(HNode* items, uint32_t n) {
+  if (n < 13) {
+    for (uint32_t i = 1; i < n; ++i) {
+      const HNode tmp = items[i];
+      uint32_t k = i, j = i - 1;
+      while (hnode_less(tmp, items[j])) {
+        items[k] = items[j];
+        k = j;
+        if (!j--) break;
+      }
+      items[k] = tmp;
+    }
+  } else {
+    const uint32_t gaps[6] = {132, 57, 23, 10, 4, 1};
+    for (int g = n < 57 ? 2 : 0; g < 6; ++g) {
+      const uint32_t gap = gaps[g];
+      for (uint32_t i = gap; i < n; ++i) {
+        uint32_t j = i;
+        const HNode tmp = items[i];
+        for (; j >= gap && hnode_less(tmp, items[j - gap]); j -= gap) items[j] = items[j - gap];
+        items[j] = tmp;
+      }
+    }
+  }
+}
+
+// BrotliCreateHuffmanTree, entropy_encode.c:68-147.
+DEV void create_huffman_tree(const uint32_t* data, uint32_t length, int tree_limit,
+                             HNode* tree, uint8_t* depth) {
+  HNode sentinel;
+  sentinel.total_count = 0xFFFFFFFFu;
+  sentinel.left = -1;
+  sentinel.right_or_value = -1;
+  for (uint32_t count_limit = 1;; count_limit *= 2) {
+    uint32_t n = 0;
+    for (uint32_t i = length; i != 0;) {
+      --i;
+      if (data[i]) {
+        HNode t;
+        t.total_count = data[i] > count_limit ? data[i] : count_limit;
+        t.left = -1;
+        t.right_or_value = (int16_t)i;
+        tree[n++] = t;
+      }
+    }
+    if (n == 1) {
+      depth[tree[0].right_or_value] = 1;
+      break;
+    }
+    sort_nodes(tree, n);
+    tree[n] = sentinel;
+    tree[n + 1] = sentinel;
+    uint32_t i = 0, j = n + 1;
+    for (uint32_t k = n - 1; k != 0; --k) {
+      uint32_t left, right;
+      if (tree[i].total_count <= tree[j].total_count) { left = i; ++i; } else { left = j; ++j; }
+      if (tree[i].total_count <= tree[j].total_count) { right = i; ++i; } else { right = j; ++j; }
+      const uint32_t j_end = 2 * n - k;
+      HNode t;
+      t.total_count = tree[left].total_count + tree[right].total_count;
+      t.left = (int16_t)left;
+      t.right_or_value = (int16_t)right;
+      tree[j_end] = t;
+      tree[j_end + 1] = sentinel;
+    }
+    if (set_depth((int)(2 * n - 1), tree, depth, tree_limit)) break;
+  }
+}
+
+DEV void reverse_u8(uint8_t* v, uint32_t start, uint32_t end) {
+  --end;
+  while (start < end) {
+    const uint8_t t = v[start];
+    v[start] = v[end];
+    v[end] = t;
+    ++start;
+    --end;
+  }
+}
+// entropy_encode.c:160-239
+DEV void write_tree_reps(uint8_t prev, uint8_t value, uint32_t reps, uint32_t* n,
+                         uint8_t* tree, uint8_t* extra) {
+  if (prev != value) { tree[*n] = value; extra[*n] = 0; ++*n; --reps; }
+  if (reps == 7) { tree[*n] = value; extra[*n] = 0; ++*n; --reps; }
+  if (reps < 3) {
+    for (uint32_t i = 0; i < reps; ++i) { tree[*n] = value; extra[*n] = 0; ++*n; }
+  } else {
+    const uint32_t start = *n;
+    reps -= 3;
+    for (;;) {
+      tree[*n] = 16; extra[*n] = (uint8_t)(reps & 3); ++*n;
+      reps >>= 2;
+      if (reps == 0) break;
+      --reps;
+    }
+    reverse_u8(tree, start, *n);
+    reverse_u8(extra, start, *n);
+  }
+}
+DEV void write_tree_reps_zeros(uint32_t reps, uint32_t* n, uint8_t* tree, uint8_t* extra) {
+  if (reps == 11) { tree[*n] = 0; extra[*n] = 0; ++*n; --reps; }
+  if (reps < 3) {
+    for (uint32_t i = 0; i < reps; ++i) { tree[*n] = 0; extra[*n] = 0; ++*n; }
+  } else {
+    const uint32_t start = *n;
+    reps -= 3;
+    for (;;) {
+      tree[*n] = 17; extra[*n] = (uint8_t)(reps & 7); ++*n;
+      reps >>= 3;
+      if (reps == 0) break;
+      --reps;
+    }
+    reverse_u8(tree, start, *n);
+    reverse_u8(extra, start, *n);
+  }
+}
+// BrotliWriteHuffmanTree, entropy_encode.c:372-452.
+DEV void write_huffman_tree(const uint8_t* depth, uint32_t length, uint32_t* tree_size,
+                            uint8_t* tree, uint8_t* extra) {
+  uint8_t previous_value = 8;
+  bool rle_nz = false, rle_z = false;
+  uint32_t new_length = length;
+  for (uint32_t i = 0; i < length; ++i) {
+    if (depth[length - i - 1] == 0) --new_length; else break;
+  }
+  if (length > 50) {
+    uint32_t total_z = 0, total_nz = 0, cnt_z = 1, cnt_nz = 1;
+    for (uint32_t i = 0; i < new_length;) {
+      const uint8_t value = depth[i];
+      uint32_t reps = 1;
+      for (uint32_t k = i + 1; k < new_length && depth[k] == value; ++k) ++reps;
+      if (reps >= 3 && value == 0) { total_z += reps; ++cnt_z; }
+      if (reps >= 4 && value != 0) { total_nz += reps; ++cnt_nz; }
+      i += reps;
+    }
+    rle_nz = total_nz > cnt_nz * 2;
+    rle_z = total_z > cnt_z * 2;
+  }
+  for (uint32_t i = 0; i < new_length;) {
+    const uint8_t value = depth[i];
+    uint32_t reps = 1;
+    if ((value != 0 && rle_nz) || (value == 0 && rle_z)) {
+      for (uint32_t k = i + 1; k < new_length && depth[k] == value; ++k) ++reps;
+    }
+    if (value == 0) {
+      write_tree_reps_zeros(reps, tree_size, tree, extra);
+    } else {
+      write_tree_reps(previous_value, value, reps, tree_size, tree, extra);
+      previous_value = value;
+    }
+    i += reps;
+  }
+}
+
+// BrotliConvertBitDepthsToSymbols, entropy_encode.c:454-497.
+DEV uint16_t reverse_bits16(uint32_t num_bits, uint32_t bits) {
+  uint32_t r = dev_bitrev32(bits) >> (32u - num_bits);
+  return (uint16_t)r;
+}
+DEV void convert_bit_depths_to_symbols(const uint8_t* depth, uint32_t len, uint16_t* bits) {
+  uint16_t bl_count[16];
+  uint16_t next_code[16];
+  for (int i = 0; i < 16; ++i) bl_count[i] = 0;
+  for (uint32_t i = 0; i < len; ++i) ++bl_count[depth[i]];
+  bl_count[0] = 0;
+  next_code[0] = 0;
+  int code = 0;
+  for (int i = 1; i < 16; ++i) {
+    code = (code + bl_count[i - 1]) << 1;
+    next_code[i] = (uint16_t)code;
+  }
+  for (uint32_t i = 0; i < len; ++i) {
+    if (depth[i]) bits[i] = reverse_bits16(depth[i], next_code[depth[i]]++);
+  }
+}
+
+// BrotliStoreHuffmanTree, brotli_bit_stream.c:163-345.
+DEV void store_huffman_tree(const uint8_t* depths, uint32_t num, HNode* tree,
+                            uint8_t* huffman_tree, uint8_t* extra_bits, BitWriter& w) {
+  const uint8_t kStorageOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+  const uint8_t kSym[6] = {0, 7, 3, 2, 1, 15};
+  const uint8_t kLen[6] = {2, 4, 3, 2, 2, 4};
+  uint32_t huffman_tree_size = 0;
+  uint8_t cl_depth[18];
+  uint16_t cl_bits[18];
+  uint32_t histogram[18];
+  for (int i = 0; i < 18; ++i) { cl_depth[i] = 0; cl_bits[i] = 0; histogram[i] = 0; }
+  write_huffman_tree(depths, num, &huffman_tree_size, huffman_tree, extra_bits);
+  for (uint32_t i = 0; i < huffman_tree_size; ++i) ++histogram[huffman_tree[i]];
+  int num_codes = 0;
+  uint32_t code = 0;
+  for (uint32_t i = 0; i < 18; ++i) {
+    if (histogram[i]) {
+      if (num_codes == 0) { code = i; num_codes = 1; }
+      else if (num_codes == 1) { num_codes = 2; break; }
+    }
+  }
+  create_huffman_tree(histogram, 18, 5, tree, cl_depth);
+  convert_bit_depths_to_symbols(cl_depth, 18, cl_bits);
+  {
+    uint32_t skip_some = 0, codes_to_store = 18;
+    if (num_codes > 1) {
+      for (; codes_to_store > 0; --codes_to_store) {
+        if (cl_depth[kStorageOrder[codes_to_store - 1]] != 0) break;
+      }
+    }
+    if (cl_depth[kStorageOrder[0]] == 0 && cl_depth[kStorageOrder[1]] == 0) {
+      skip_some = 2;
+      if (cl_depth[kStorageOrder[2]] == 0) skip_some = 3;
+    }
+    bw_put(w, 2, skip_some);
+    for (uint32_t i = skip_some; i < codes_to_store; ++i) {
+      const uint32_t l = cl_depth[kStorageOrder[i]];
+      bw_put(w, kLen[l], kSym[l]);
+    }
+  }
+  if (num_codes == 1) cl_depth[code] = 0;
+  for (uint32_t i = 0; i < huffman_tree_size; ++i) {
+    const uint32_t v = huffman_tree[i];
+    bw_put(w, cl_depth[v], cl_bits[v]);
+    if (v == 16) bw_put(w, 2, extra_bits[i]);
+    else if (v == 17) bw_put(w, 3, extra_bits[i]);
+  }
+}
+
+// BuildAndStoreHuffmanTree, brotli_bit_stream.c:242-279, 349-397.  Returns the
+// number of bits written to `buf`.
+DEV uint32_t build_and_store_huffman_tree(const uint32_t* histogram, uint32_t histogram_length,
+                                          uint32_t alphabet_size, uint8_t* scratch,
+                                          uint8_t* depth, uint16_t* bits, uint8_t* buf) {
+  HNode* tree = (HNode*)scratch;
+  uint8_t* huffman_tree = scratch + 8u * (2u * 704u + 2u);
+  uint8_t* extra_bits = huffman_tree + 704u;
+  BitWriter w;
+  bw_init(w, buf, 0, 0);
+  uint32_t count = 0, s4[4] = {0, 0, 0, 0}, max_bits = 0;
+  for (uint32_t i = 0; i < histogram_length; i++) {
+    if (histogram[i]) {
+      if (count < 4) s4[count] = i; else if (count > 4) break;
+      count++;
+    }
+  }
+  for (uint32_t c = alphabet_size - 1; c; c >>= 1) ++max_bits;
+  if (count <= 1) {
+    bw_put(w, 4, 1);
+    bw_put(w, max_bits, s4[0]);
+    depth[s4[0]] = 0;
+    bits[s4[0]] = 0;
+  } else {
+    for (uint32_t i = 0; i < histogram_length; ++i) depth[i] = 0;
+    create_huffman_tree(histogram, histogram_length, 15, tree, depth);
+    convert_bit_depths_to_symbols(depth, histogram_length, bits);
+    if (count <= 4) {
+      bw_put(w, 2, 1);
+      bw_put(w, 2, count - 1);
+      for (uint32_t i = 0; i < count; i++) {
+        for (uint32_t j = i + 1; j < count; j++) {
+          if (depth[s4[j]] < depth[s4[i]]) { const uint32_t t = s4[j]; s4[j] = s4[i]; s4[i] = t; }
+        }
+      }
+      for (uint32_t i = 0; i < count; ++i) bw_put(w, max_bits, s4[i]);
+      if (count == 4) bw_put(w, 1, depth[s4[0]] == 1 ? 1 : 0);
+    } else {
+      store_huffman_tree(depth, histogram_length, tree, huffman_tree, extra_bits, w);
+    }
+  }
+  const uint32_t nbits = (uint32_t)bw_bitpos(w);
+  // flush the accumulator (whole bytes, then the partial byte)
+  bw_flush_bytes(w);
+  if (w.nacc) w.out[w.byte_pos] = (uint8_t)w.acc;
+  return nbits;
+}
+
+// ---- block-split bookkeeping ------------------------------------------------------
+// brotli_bit_stream.c:34-46 and the block-length prefix table of
+// c/common/constants.h:195-196.
+static __device__ const uint16_t k_blocklen_offset[26] = {
+    1, 5, 9, 13, 17, 25, 33, 41, 49, 65, 81, 97, 113, 145, 177, 209, 241, 305, 369, 497,
+    753, 1265, 2289, 4337, 8433, 16625};
+static __device__ const uint8_t k_blocklen_nbits[26] = {
+    2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 7, 8, 9, 10, 11, 12, 13, 24};
+DEV uint32_t block_length_prefix_code(uint32_t len) {
+  uint32_t code = (len >= 177) ? (len >= 753 ? 20 : 14) : (len >= 41 ? 7 : 0);
+  while (code < 25 && len >= k_blocklen_offset[code + 1]) ++code;
+  return code;
+}
+// NextBlockTypeCode for block b (b >= 0), brotli_bit_stream.c:709-716 with the
+// initial calculator state {last_type = 1, second_last_type = 0}.
+DEV uint32_t block_type_code(const uint8_t* types, uint32_t b) {
+  const uint32_t t = types[b];
+  const uint32_t last = b >= 1 ? types[b - 1] : 1u;
+  const uint32_t second = b >= 2 ? types[b - 2] : (b == 1 ? 1u : 0u);
+  return (t == last + 1) ? 1u : (t == second) ? 0u : t + 2u;
+}
+
+// command.h:31-88 tables.
+static __device__ const uint32_t k_ins_base[24] = {0, 1, 2, 3, 4, 5, 6, 8, 10, 14, 18, 26,
+    34, 50, 66, 98, 130, 194, 322, 578, 1090, 2114, 6210, 22594};
+static __device__ const uint8_t k_ins_extra[24] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4,
+    5, 5, 6, 7, 8, 9, 10, 12, 14, 24};
+static __device__ const uint32_t k_copy_base[24] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 14, 18,
+    22, 30, 38, 54, 70, 102, 134, 198, 326, 582, 1094, 2118};
+static __device__ const uint8_t k_copy_extra[24] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3,
+    4, 4, 5, 5, 6, 7, 8, 9, 10, 24};
+
+struct StoreCtx {
+  const JobParams* J;
+  const uint8_t* data;
+  uint8_t* mb;
+  MbLayout L;
+  const MbInfo* info;
+  SmallCodes* small;
+  const Command* cmds;
+  const uint16_t* lits;
+  const uint16_t* dsym;
+  uint64_t* sw;          // per category, per block: switch bits (low 56) | nbits << 56
+  uint32_t sw_off[3];
+  uint32_t nc;
+  // per category views
+  const uint8_t* types[3];
+  const uint32_t* lengths[3];
+  const uint16_t* blkmap[3];
+  const uint8_t* depths[3];
+  const uint16_t* bits[3];
+};
+
+// Code of stream symbol k of category CAT and, when k opens a new block, the
+// block switch that precedes it (StoreSymbol / StoreSymbolWithContext).
+struct SymBits {
+  uint64_t sw;      // block switch bits (<= 54)
+  uint32_t nsw;
+  uint32_t code;    // prefix code of the symbol (<= 15 bits)
+  uint32_t ncode;
+};
+template <int CAT>
+DEV SymBits symbol_bits(const StoreCtx& s, uint32_t k, uint32_t sym, uint32_t ctx) {
+  constexpr uint32_t A = CAT == 0 ? 256u : CAT == 1 ? 704u : 64u;
+  constexpr uint32_t MINB = CAT == 0 ? MB_LIT_MIN_BLOCK : CAT == 1 ? MB_CMD_MIN_BLOCK : MB_DIST_MIN_BLOCK;
+  const uint32_t chunk = k / MINB;
+  const uint32_t blk = s.blkmap[CAT][chunk];
+  SymBits r;
+  r.sw = 0;
+  r.nsw = 0;
+  if ((k % MINB) == 0 && chunk > 0 && s.blkmap[CAT][chunk - 1] != blk) {
+    const uint64_t e = s.sw[s.sw_off[CAT] + blk];
+    r.nsw = (uint32_t)(e >> 56);
+    r.sw = e & ((1ull << 56) - 1ull);
+  }
+  const uint32_t type = s.types[CAT][blk];
+  const uint32_t h = CAT == 0 ? type * s.nc + ctx : type;
+  r.ncode = s.depths[CAT][h * A + sym];
+  r.code = s.bits[CAT][h * A + sym];
+  return r;
+}
+DEV void or_sym(uint32_t* base, uint64_t pos, const SymBits& b) {
+  or_bits(base, pos, b.nsw, b.sw);
+  or_bits(base, pos + b.nsw, b.ncode, b.code);
+}
+
+// ---- the round -----------------------------------------------------------------------
+DEV void zero_output(uint8_t* out, uint64_t from, uint64_t bytes) {
+  const int lane = wave_lane();
+  // bytes up to the next dword boundary, then whole dwords
+  const uint64_t head = (4u - (from & 3u)) & 3u;
+  if ((uint64_t)lane < head) out[from + (uint64_t)lane] = 0;
+  uint32_t* p = (uint32_t*)(out + from + head);
+  const uint64_t nw = (bytes - head + 3) >> 2;
+  for (uint64_t i = (uint64_t)lane; i < nw; i += 64) p[i] = 0;
+  wave_mem_barrier();   // zeros are in the L2 before any atomic OR is issued
+}
+
 DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
-                     const DeviceTables* T, const uint8_t* input, uint8_t* ws) {}
-#endif
+                     const DeviceTables* T, const uint8_t* input, uint8_t* ws) {
+  const int lane = wave_lane();
+  if (!S->mb_valid || S->error) return;
+  const uint8_t* data = input + D.in_off;
+  uint8_t* out = ws + D.out_off;
+  RoundRegs r;
+  regs_load(r, S);
+  int32_t dc[4];
+  for (int i = 0; i < 4; ++i) dc[i] = S->dist_cache[i];
+  const uint32_t start = S->mb_start, bytes = S->mb_bytes;
+  const bool is_last = S->mb_is_last != 0, force_flush = S->mb_force_flush != 0;
+  bool raw = S->mb_raw != 0;
+
+  // Everything this meta-block can touch, zeroed; then the carried bits.
+  const uint64_t zero_bytes = 2ull * bytes + 520ull;
+  if (r.out_bytes + zero_bytes + 16 > D.out_cap) {
+    if (lane == 0) S->error = 2;
+    return;
+  }
+  uint64_t total_bits = 0;   // relative to out + r.out_bytes, carried bits included
+
+  if (!raw) {
+    zero_output(out, r.out_bytes, zero_bytes);
+    StoreCtx s;
+    s.J = &J;
+    s.data = data;
+    s.mb = ws + D.mb_off;
+    mb_layout(umin(D.len, J.max_metablock_size), &s.L);
+    s.info = (const MbInfo*)(s.mb + s.L.info);
+    s.small = (SmallCodes*)(s.mb + s.L.small);
+    s.cmds = (const Command*)(ws + D.cmds_off);
+    s.lits = (const uint16_t*)(ws + D.lits_off);
+    s.dsym = (const uint16_t*)(ws + D.dsym_off);
+    s.sw = (uint64_t*)(ws + D.scratch_off);
+    s.nc = s.info->num_contexts;
+    const uint32_t alpha[3] = {256u, 704u, 64u};
+    const uint32_t minb[3] = {MB_LIT_MIN_BLOCK, MB_CMD_MIN_BLOCK, MB_DIST_MIN_BLOCK};
+    uint32_t ntypes[3], nblocks[3], nhist[3];
+    for (int c = 0; c < 3; ++c) {
+      s.types[c] = s.mb + s.L.types[c];
+      s.lengths[c] = (const uint32_t*)(s.mb + s.L.lengths[c]);
+      s.blkmap[c] = (const uint16_t*)(s.mb + s.L.blkmap[c]);
+      s.depths[c] = s.mb + s.L.depths[c];
+      s.bits[c] = (const uint16_t*)(s.mb + s.L.bits[c]);
+      ntypes[c] = s.info->split[c].num_types;
+      nblocks[c] = s.info->split[c].num_blocks;
+      nhist[c] = s.info->split[c].num_histograms;
+    }
+    s.sw_off[0] = 0;
+    s.sw_off[1] = nblocks[0];
+    s.sw_off[2] = nblocks[0] + nblocks[1];
+    const uint32_t ncmds = s.info->ncmds;
+    SmallCodes* sc = s.small;
+    uint32_t* cmap_rle = (uint32_t*)(s.mb + s.L.cmap_rle);
+    const uint8_t* static_map = k_ctx_maps[s.info->map_kind];
+
+    // ---- phase 0: histograms of the small codes (a lane each) ----
+    uint32_t cmap_nrle = 0, cmap_max_prefix = 0;
+    if (lane < 3) {
+      const int c = lane;
+      for (uint32_t i = 0; i < ntypes[c] + 2; ++i) sc->type_histo[c][i] = 0;
+      for (uint32_t i = 0; i < 26; ++i) sc->len_histo[c][i] = 0;
+      for (uint32_t b = 0; b < nblocks[c]; ++b) {
+        if (b != 0) ++sc->type_histo[c][block_type_code(s.types[c], b)];
+        ++sc->len_histo[c][block_length_prefix_code(s.lengths[c][b])];
+      }
+    } else if (lane == 3 || lane == 4) {
+      // Trivial context maps (:794-830): literal (only when nc == 1), distance.
+      const int m = lane - 3;
+      const uint32_t num_types = m == 0 ? nhist[0] : nhist[2];
+      const uint32_t context_bits = m == 0 ? 6u : 2u;
+      if ((m == 1 || s.nc == 1) && num_types > 1) {
+        const uint32_t repeat_code = context_bits - 1u;
+        const uint32_t alphabet_size = num_types + repeat_code;
+        for (uint32_t i = 0; i < alphabet_size; ++i) sc->cmap_histo[m][i] = 0;
+        sc->cmap_histo[m][repeat_code] = num_types;
+        sc->cmap_histo[m][0] = 1;
+        for (uint32_t i = context_bits; i < alphabet_size; ++i) sc->cmap_histo[m][i] = 1;
+      }
+    } else if (lane == 5 && s.nc > 1) {
+      // EncodeContextMap (:574-734): move-to-front + zero run lengths of
+      // context_map[t * 64 + j] = t * nc + static_map[j] (metablock.c:677-697).
+      const uint32_t size = ntypes[0] << 6;
+      const uint32_t num_clusters = nhist[0];
+      uint8_t mtf[256];
+      const uint32_t max_value = (ntypes[0] - 1) * s.nc + (s.nc - 1);  // every context id occurs in the static maps
+      for (uint32_t i = 0; i <= max_value; ++i) mtf[i] = (uint8_t)i;
+      const uint32_t mtf_size = max_value + 1;
+      for (uint32_t i = 0; i < size; ++i) {
+        const uint8_t value = (uint8_t)((i >> 6) * s.nc + static_map[i & 63]);
+        uint32_t index = 0;
+        for (; index < mtf_size; ++index) if (mtf[index] == value) break;
+        cmap_rle[i] = index;
+        for (uint32_t k = index; k != 0; --k) mtf[k] = mtf[k - 1];
+        mtf[0] = value;
+      }
+      uint32_t max_reps = 0;
+      for (uint32_t i = 0; i < size;) {
+        uint32_t reps = 0;
+        for (; i < size && cmap_rle[i] != 0; ++i) {}
+        for (; i < size && cmap_rle[i] == 0; ++i) ++reps;
+        if (reps > max_reps) max_reps = reps;
+      }
+      uint32_t max_prefix = max_reps > 0 ? log2floor(max_reps) : 0;
+      if (max_prefix > 6) max_prefix = 6;
+      uint32_t num_rle = 0;
+      for (uint32_t i = 0; i < size;) {
+        if (cmap_rle[i] != 0) {
+          cmap_rle[num_rle++] = cmap_rle[i] + max_prefix;
+          ++i;
+        } else {
+          uint32_t reps = 1;
+          for (uint32_t k = i + 1; k < size && cmap_rle[k] == 0; ++k) ++reps;
+          i += reps;
+          while (reps != 0) {
+            if (reps < (2u << max_prefix)) {
+              const uint32_t p = log2floor(reps);
+              cmap_rle[num_rle++] = p + ((reps - (1u << p)) << 9);
+              break;
+            } else {
+              cmap_rle[num_rle++] = max_prefix + (((1u << max_prefix) - 1u) << 9);
+              reps -= (2u << max_prefix) - 1u;
+            }
+          }
+        }
+      }
+      for (uint32_t i = 0; i < MB_MAX_CMAP_SYMS; ++i) sc->cmap_histo[0][i] = 0;
+      for (uint32_t i = 0; i < num_rle; ++i) ++sc->cmap_histo[0][cmap_rle[i] & 511u];
+      cmap_nrle = num_rle;
+      cmap_max_prefix = max_prefix;
+      (void)num_clusters;
+    }
+    cmap_nrle = wave_bcast(cmap_nrle, 5);
+    cmap_max_prefix = wave_bcast(cmap_max_prefix, 5);
+    wave_sync();
+
+    // ---- phase 1: every prefix code, one lane per job ----
+    // job ids: 0-2 block types, 3-5 block lengths, 6 literal context map,
+    // 7 distance context map, then literal / command / distance histograms.
+    const uint32_t njobs = 8 + nhist[0] + nhist[1] + nhist[2];
+    uint8_t* tree_bufs = s.mb + s.L.tree_bufs;
+    uint32_t* job_nbits = (uint32_t*)(s.mb + s.L.jobs);
+    uint8_t* scratch = s.mb + s.L.lane_scratch + (size_t)lane * MB_LANE_SCRATCH_BYTES;
+    const uint32_t lit_cmap_alpha = s.nc > 1 ? nhist[0] + cmap_max_prefix : nhist[0] + 5u;
+    for (uint32_t j = (uint32_t)lane; j < njobs; j += 64) {
+      const uint32_t* histo = nullptr;
+      uint8_t* depth = nullptr;
+      uint16_t* bits = nullptr;
+      uint32_t length = 0;
+      bool skip = false;
+      if (j < 3) {
+        histo = sc->type_histo[j]; depth = sc->type_depth[j]; bits = sc->type_bits[j];
+        length = ntypes[j] + 2; skip = ntypes[j] <= 1;
+      } else if (j < 6) {
+        const uint32_t c = j - 3;
+        histo = sc->len_histo[c]; depth = sc->len_depth[c]; bits = sc->len_bits[c];
+        length = 26; skip = ntypes[c] <= 1;
+      } else if (j == 6) {
+        histo = sc->cmap_histo[0]; depth = sc->cmap_depth[0]; bits = sc->cmap_bits[0];
+        length = lit_cmap_alpha; skip = nhist[0] <= 1;
+      } else if (j == 7) {
+        histo = sc->cmap_histo[1]; depth = sc->cmap_depth[1]; bits = sc->cmap_bits[1];
+        length = nhist[2] + 1u; skip = nhist[2] <= 1;
+      } else {
+        uint32_t h = j - 8;
+        int c = 0;
+        if (h >= nhist[0]) { h -= nhist[0]; c = 1; if (h >= nhist[1]) { h -= nhist[1]; c = 2; } }
+        histo = (const uint32_t*)(s.mb + s.L.histos[c]) + (size_t)h * alpha[c];
+        depth = (uint8_t*)(s.mb + s.L.depths[c]) + (size_t)h * alpha[c];
+        bits = (uint16_t*)(s.mb + s.L.bits[c]) + (size_t)h * alpha[c];
+        length = alpha[c];
+      }
+      uint32_t nb = 0;
+      if (!skip) {
+        nb = build_and_store_huffman_tree(histo, length, length, scratch, depth, bits,
+                                          tree_bufs + (size_t)j * MB_TREE_BUF_BYTES);
+      }
+      job_nbits[j] = nb;
+    }
+    wave_sync();
+
+    // Block switch codes for every block b >= 1 (StoreBlockSwitch :737-756).
+    for (int c = 0; c < 3; ++c) {
+      for (uint32_t b = (uint32_t)lane; b < nblocks[c]; b += 64) {
+        uint64_t v = 0;
+        uint32_t n = 0;
+        if (ntypes[c] > 1) {
+          const uint32_t lencode = block_length_prefix_code(s.lengths[c][b]);
+          if (b != 0) {
+            const uint32_t tc = block_type_code(s.types[c], b);
+            v = sc->type_bits[c][tc];
+            n = sc->type_depth[c][tc];
+          }
+          v |= (uint64_t)sc->len_bits[c][lencode] << n;
+          n += sc->len_depth[c][lencode];
+          v |= (uint64_t)(s.lengths[c][b] - k_blocklen_offset[lencode]) << n;
+          n += k_blocklen_nbits[lencode];
+        }
+        s.sw[s.sw_off[c] + b] = v | ((uint64_t)n << 56);
+      }
+    }
+    wave_sync();
+
+    // ---- phase 2: header, in order ----
+    BitSink sink;
+    sink.base = (uint32_t*)(out + (r.out_bytes & ~(uint64_t)3));
+    sink.bitpos = (r.out_bytes & 3) * 8;
+    const uint64_t bit0 = sink.bitpos;
+    sink_put(sink, r.last_bytes_bits, r.last_bytes);
+    {
+      // StoreCompressedMetaBlockHeader :120-143
+      const uint32_t lg = (bytes == 1) ? 1u : log2floor(bytes - 1u) + 1u;
+      const uint32_t mnibbles = (lg < 16u ? 16u : (lg + 3u)) / 4u;
+      sink_put(sink, 1, is_last ? 1 : 0);
+      if (is_last) sink_put(sink, 1, 0);
+      sink_put(sink, 2, mnibbles - 4u);
+      sink_put(sink, mnibbles * 4u, bytes - 1u);
+      if (!is_last) sink_put(sink, 1, 0);
+    }
+    for (int c = 0; c < 3; ++c) {
+      sink_varlen_uint8(sink, ntypes[c] - 1u);
+      if (ntypes[c] > 1) {
+        sink_splice(sink, tree_bufs + (size_t)c * MB_TREE_BUF_BYTES, job_nbits[c]);
+        sink_splice(sink, tree_bufs + (size_t)(3 + c) * MB_TREE_BUF_BYTES, job_nbits[3 + c]);
+        const uint64_t e = s.sw[s.sw_off[c]];
+        sink_put(sink, (uint32_t)(e >> 56), e & ((1ull << 56) - 1ull));
+      }
+    }
+    sink_put(sink, 2, 0);   // NPOSTFIX
+    sink_put(sink, 4, 0);   // NDIRECT >> NPOSTFIX
+    for (uint32_t i = 0; i < ntypes[0]; ++i) sink_put(sink, 2, 2);   // CONTEXT_UTF8
+    if (s.nc == 1) {
+      // StoreTrivialContextMap(num literal histograms, 6 context bits)
+      sink_varlen_uint8(sink, nhist[0] - 1u);
+      if (nhist[0] > 1) {
+        sink_put(sink, 1, 1);
+        sink_put(sink, 4, 4);
+        sink_splice(sink, tree_bufs + 6u * MB_TREE_BUF_BYTES, job_nbits[6]);
+        for (uint32_t i = 0; i < nhist[0]; ++i) {
+          const uint32_t code = i == 0 ? 0u : i + 5u;
+          sink_put(sink, sc->cmap_depth[0][code], sc->cmap_bits[0][code]);
+          sink_put(sink, sc->cmap_depth[0][5], sc->cmap_bits[0][5]);
+          sink_put(sink, 5, 31);
+        }
+        sink_put(sink, 1, 1);
+      }
+    } else {
+      sink_varlen_uint8(sink, nhist[0] - 1u);
+      const bool use_rle = cmap_max_prefix > 0;
+      sink_put(sink, 1, use_rle ? 1 : 0);
+      if (use_rle) sink_put(sink, 4, cmap_max_prefix - 1u);
+      sink_splice(sink, tree_bufs + 6u * MB_TREE_BUF_BYTES, job_nbits[6]);
+      for (uint32_t i = 0; i < cmap_nrle; ++i) {
+        const uint32_t sym = cmap_rle[i] & 511u, extra = cmap_rle[i] >> 9;
+        sink_put(sink, sc->cmap_depth[0][sym], sc->cmap_bits[0][sym]);
+        if (sym > 0 && sym <= cmap_max_prefix) sink_put(sink, sym, extra);
+      }
+      sink_put(sink, 1, 1);
+    }
+    {
+      // StoreTrivialContextMap(num distance histograms, 2 context bits)
+      sink_varlen_uint8(sink, nhist[2] - 1u);
+      if (nhist[2] > 1) {
+        sink_put(sink, 1, 1);
+        sink_put(sink, 4, 0);
+        sink_splice(sink, tree_bufs + 7u * MB_TREE_BUF_BYTES, job_nbits[7]);
+        for (uint32_t i = 0; i < nhist[2]; ++i) {
+          const uint32_t code = i == 0 ? 0u : i + 1u;
+          sink_put(sink, sc->cmap_depth[1][code], sc->cmap_bits[1][code]);
+          sink_put(sink, sc->cmap_depth[1][1], sc->cmap_bits[1][1]);
+          sink_put(sink, 1, 1);
+        }
+        sink_put(sink, 1, 1);
+      }
+    }
+    for (uint32_t j = 8; j < njobs; ++j)
+      sink_splice(sink, tree_bufs + (size_t)j * MB_TREE_BUF_BYTES, job_nbits[j]);
+
+    // ---- phase 3: the commands, 64 per step ----
+    uint32_t lit_base = 0, dist_base = 0;
+    for (uint32_t base = 0; base < ncmds; base += 64) {
+      const uint32_t i = base + (uint32_t)lane;
+      const bool valid = i < ncmds;
+      Command c;
+      c.insert_len = 0; c.copy_len = 0; c.dist_extra = 0; c.cmd_prefix = 0; c.dist_prefix = 0;
+      if (valid) c = s.cmds[i];
+      const uint32_t ins = c.insert_len;
+      const uint32_t cpy = c.copy_len & 0x1FFFFFFu;
+      const bool has_dist = valid && cpy != 0 && c.cmd_prefix >= 128;
+      const uint64_t dm = wave_ballot(has_dist);
+      const uint32_t ins_incl = wave_incl_scan(ins);
+      const uint32_t my_lit = lit_base + ins_incl - ins;
+      const uint32_t my_dist = dist_base + (uint32_t)dev_popc64(dm & ((1ull << lane) - 1ull));
+      const bool is_long = ins >= 32u;
+
+      // command symbol + extra bits (StoreCommandExtra :82-93)
+      uint64_t xv = 0;
+      uint32_t cn = 0, xn = 0, dn = 0, dxn = 0;
+      SymBits cb, db;
+      cb.sw = db.sw = 0; cb.nsw = db.nsw = cb.code = db.code = cb.ncode = db.ncode = 0;
+      if (valid) {
+        cb = symbol_bits<1>(s, i, c.cmd_prefix, 0);
+        cn = cb.nsw + cb.ncode;
+        const uint32_t copylen_code = cmd_copy_len_code(c);
+        const uint32_t inscode = insert_length_code(ins);
+        const uint32_t copycode = copy_length_code(copylen_code);
+        const uint32_t insnumextra = k_ins_extra[inscode];
+        xv = ((uint64_t)(copylen_code - k_copy_base[copycode]) << insnumextra) |
+             (uint64_t)(ins - k_ins_base[inscode]);
+        xn = insnumextra + k_copy_extra[copycode];
+      }
+      if (has_dist) {
+        db = symbol_bits<2>(s, my_dist, c.dist_prefix & 0x3FFu, 0);
+        dn = db.nsw + db.ncode;
+        dxn = c.dist_prefix >> 10;
+      }
+      // literal bits of short runs
+      uint32_t ln = 0;
+      if (valid && !is_long) {
+        for (uint32_t j = 0; j < ins; ++j) {
+          const uint32_t v = s.lits[my_lit + j];
+          const SymBits lb = symbol_bits<0>(s, my_lit + j, v & 0xFFu, v >> 8);
+          ln += lb.nsw + lb.ncode;
+        }
+      }
+      // long runs: sized by the whole wave
+      const uint64_t longm = wave_ballot(valid && is_long);
+      for (uint64_t m = longm; m;) {
+        const int src = dev_ctz64(m);
+        m &= m - 1;
+        const uint32_t n = wave_bcast(ins, src), l0 = wave_bcast(my_lit, src);
+        uint32_t tot = 0;
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+          uint32_t nb = 0;
+          if (j0 + (uint32_t)lane < n) {
+            const uint32_t v = s.lits[l0 + j0 + (uint32_t)lane];
+            const SymBits lb = symbol_bits<0>(s, l0 + j0 + (uint32_t)lane, v & 0xFFu, v >> 8);
+            nb = lb.nsw + lb.ncode;
+          }
+          tot += wave_bcast(wave_incl_scan(nb), 63);
+        }
+        if (lane == src) ln = tot;
+      }
+      const uint32_t mybits = cn + xn + ln + dn + dxn;
+      const uint32_t bits_incl = wave_incl_scan(mybits);
+      uint64_t p = sink.bitpos + (bits_incl - mybits);
+      // write
+      if (valid) {
+        or_sym(sink.base, p, cb); p += cn;
+        or_bits(sink.base, p, xn, xv); p += xn;
+        if (!is_long) {
+          for (uint32_t j = 0; j < ins; ++j) {
+            const uint32_t v = s.lits[my_lit + j];
+            const SymBits lb = symbol_bits<0>(s, my_lit + j, v & 0xFFu, v >> 8);
+            or_sym(sink.base, p, lb);
+            p += lb.nsw + lb.ncode;
+          }
+        }
+      }
+      for (uint64_t m = longm; m;) {
+        const int src = dev_ctz64(m);
+        m &= m - 1;
+        const uint32_t n = wave_bcast(ins, src), l0 = wave_bcast(my_lit, src);
+        uint64_t q = wave_bcast64(p, src);
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
+          uint32_t nb = 0;
+          SymBits lb;
+          lb.sw = 0; lb.nsw = lb.code = lb.ncode = 0;
+          if (j0 + (uint32_t)lane < n) {
+            const uint32_t v = s.lits[l0 + j0 + (uint32_t)lane];
+            lb = symbol_bits<0>(s, l0 + j0 + (uint32_t)lane, v & 0xFFu, v >> 8);
+            nb = lb.nsw + lb.ncode;
+          }
+          const uint32_t incl = wave_incl_scan(nb);
+          or_sym(sink.base, q + (incl - nb), lb);
+          q += wave_bcast(incl, 63);
+        }
+        if (lane == src) p = q;
+      }
+      if (has_dist) {
+        or_sym(sink.base, p, db); p += dn;
+        or_bits(sink.base, p, dxn, c.dist_extra);
+      }
+      sink.bitpos += wave_bcast(bits_incl, 63);
+      lit_base += wave_bcast(ins_incl, 63);
+      dist_base += (uint32_t)dev_popc64(dm);
+    }
+    if (is_last) sink.bitpos = (sink.bitpos + 7u) & ~(uint64_t)7u;
+    total_bits = sink.bitpos - bit0;
+    wave_sync();
+    // encode.c:604-613: larger than the input + 4 bytes -> store uncompressed.
+    if ((uint64_t)bytes + 4u < (total_bits >> 3)) raw = true;
+  }
+
+  if (raw) {
+    zero_output(out, r.out_bytes, zero_bytes);
+    for (int i = 0; i < 4; ++i) dc[i] = r.saved_dc[i];
+    BitWriter w;
+    bw_init(w, out + r.out_bytes, r.last_bytes_bits, r.last_bytes);
+    emit_raw_metablock(w, data, start, bytes, is_last);
+    after_metablock(r, dc, data, out, w, force_flush);
+  } else {
+    // after_metablock for the atomically written stream
+    wave_mem_barrier();
+    r.out_bytes += total_bits >> 3;
+    r.last_bytes_bits = (uint32_t)(total_bits & 7u);
+    uint32_t lb = 0;
+    if (r.last_bytes_bits) {
+      uint32_t* wp = (uint32_t*)(out + (r.out_bytes & ~(uint64_t)3));
+      uint32_t word = 0;
+      if (lane == 0) word = glb_atomic_or(wp, 0u);
+      word = wave_bcast(word, 0);
+      lb = (word >> ((r.out_bytes & 3) * 8)) & 0xFFu;
+    }
+    r.last_bytes = lb;
+    r.last_flush_pos = r.input_pos;
+    r.last_processed_pos = r.input_pos;
+    if (r.last_flush_pos > 0) r.prev_byte = data[r.last_flush_pos - 1];
+    if (r.last_flush_pos > 1) r.prev_byte2 = data[r.last_flush_pos - 2];
+    r.ncmds = 0;
+    r.nlits = 0;
+    for (int i = 0; i < 4; ++i) r.saved_dc[i] = dc[i];
+  }
+  wave_mem_barrier();
+  if (force_flush) inject_flush_padding(r, out);
+  const bool done = is_last || (D.len - r.input_pos) == 0;
+  wave_sync();
+  if (lane == 0) {
+    regs_save(r, S);
+    for (int i = 0; i < 4; ++i) S->dist_cache[i] = dc[i];
+    S->mb_valid = 0;
+    S->mb_raw = 0;
+    S->done = done ? 1u : 0u;
+  }
+  wave_sync();
+}
+
+#endif  // BROTLI_AMD_CSRC_K_STORE_H_

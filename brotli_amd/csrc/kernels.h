@@ -36,14 +36,17 @@ __global__ void __launch_bounds__(64) k_parse(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
   parse_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
-  if (threadIdx.x == 0 && a.states[shard].error) atomicAdd(&a.counters[1], 1u);
+  if (threadIdx.x == 0 && a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
 }
 
 // grid = nshards, block = 64: block splits, histograms, prefix codes.
 __global__ void __launch_bounds__(64) k_build(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
-  build_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
+  __shared__ uint32_t lds[BUILD_LDS_WORDS];
+  __shared__ double lds_ent[3 * 13 + 1];
+  __shared__ double lds_last[2 * 13];
+  build_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds, lds_ent, lds_last);
 }
 
 // grid = nshards, block = 64: bit-stream emission of the pending meta-block.
@@ -52,8 +55,8 @@ __global__ void __launch_bounds__(64) k_store(JobArgs a) {
   if (shard >= a.nshards) return;
   store_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
   if (threadIdx.x == 0) {
-    if (a.states[shard].error) atomicAdd(&a.counters[1], 1u);
-    else if (!a.states[shard].done) atomicAdd(&a.counters[0], 1u);
+    if (a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
+    else if (!a.states[shard].done) glb_atomic_add(&a.counters[0], 1u);
   }
 }
 
@@ -66,13 +69,13 @@ __global__ void __launch_bounds__(1024) k_scan_sizes(JobArgs a, uint64_t* scan, 
   uint64_t sum = 0;
   for (uint32_t k = lo; k < hi; ++k) sum += a.states[k].out_bytes;
   part[t] = sum;
-  __syncthreads();
+  block_sync();
   if (t == 0) {
     uint64_t run = 0;
     for (uint32_t i = 0; i < 1024; ++i) { const uint64_t v = part[i]; part[i] = run; run += v; }
     scan[a.nshards] = run;
   }
-  __syncthreads();
+  block_sync();
   uint64_t run = part[t];
   for (uint32_t k = lo; k < hi; ++k) {
     scan[k] = run;

@@ -22,6 +22,7 @@
 #define wave_bcast(v, lane) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), (lane), WAVE_SITE))
 #define wave_bcast64(v, lane) simt_shfl64((uint64_t)(v), (lane), WAVE_SITE)
 #define wave_sync() simt_sync(WAVE_SITE)
+#define wave_mem_barrier() simt_sync(WAVE_SITE)
 static inline int wave_lane() { return (int)(threadIdx.x & 63); }
 static inline int dev_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 static inline int dev_ctz32(uint32_t x) { return __builtin_ctz(x); }
@@ -29,6 +30,15 @@ static inline int dev_clz32(uint32_t x) { return __builtin_clz(x); }
 static inline int dev_popc64(uint64_t x) { return __builtin_popcountll(x); }
 template <class T> static inline T lds_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T lds_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
+static inline uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
+static inline uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+static inline uint32_t dev_bitrev32(uint32_t x) {
+  x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+  x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+  x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+  return __builtin_bswap32(x);
+}
+#define block_sync() simt_sync(WAVE_SITE)
 
 #else  // ---- gfx950 ---------------------------------------------------------
 
@@ -66,12 +76,25 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// Waits until this wave's earlier stores / atomics have reached the device
+// level (L2) and drops stale L1 lines: used a few times per meta-block where
+// plain stores, dword atomics and plain loads touch the same output bytes.
+__device__ __forceinline__ void wave_mem_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+  __builtin_amdgcn_wave_barrier();
+}
+
 __device__ __forceinline__ int dev_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 __device__ __forceinline__ int dev_ctz32(uint32_t x) { return __builtin_ctz(x); }
 __device__ __forceinline__ int dev_clz32(uint32_t x) { return __builtin_clz(x); }
 __device__ __forceinline__ int dev_popc64(uint64_t x) { return __builtin_popcountll(x); }
 template <class T> __device__ __forceinline__ T lds_atomic_add(T* p, T v) { return atomicAdd(p, v); }
 template <class T> __device__ __forceinline__ T lds_atomic_or(T* p, T v) { return atomicOr(p, v); }
+// Device-scope OR on a global dword (executed at the L2; result optional).
+__device__ __forceinline__ uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
+__device__ __forceinline__ uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ uint32_t dev_bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }
+__device__ __forceinline__ void block_sync() { __syncthreads(); }
 
 #endif
 

@@ -1147,6 +1147,7 @@ static void SplitterFinishBlock(Splitter* b, int is_final) {
         diff[j] += combined_entropy[jx] - entropy[i] - last_entropy[jx];
       }
     }
+    if (getenv("ORACLE_DEBUG2")) fprintf(stderr, "oracle A=%zu nb=%zu bs=%zu e=%f c0=%f c1=%f l0=%f l1=%f d0=%f d1=%f\n", A, b->num_blocks, b->block_size, entropy[0], combined_entropy[0], combined_entropy[nc], last_entropy[0], last_entropy[nc], diff[0], diff[1]);
     if (split->num_types < b->max_block_types &&
         diff[0] > b->split_threshold && diff[1] > b->split_threshold) {
       split->lengths[b->num_blocks] = (uint32_t)b->block_size;
@@ -1689,6 +1690,17 @@ static void WriteMetaBlock(Enc* s, size_t bytes, int is_last, size_t* ix, uint8_
         size_t j;
         for (j = 0; j < 64; ++j) literal_context_map[(i << 6) + j] = offset + static_map[j];
       }
+    }
+  }
+  if (getenv("ORACLE_DEBUG")) {
+    const Split* sp[3] = {&lit_split, &cmd_split, &dist_split};
+    int c;
+    fprintf(stderr, "oracle nc=%zu ncmds=%zu\n", num_contexts, s->ncmds);
+    for (c = 0; c < 3; ++c) {
+      size_t b;
+      fprintf(stderr, "  cat %d types=%zu blocks=%zu:", c, sp[c]->num_types, sp[c]->num_blocks);
+      for (b = 0; b < sp[c]->num_blocks && b < 40; ++b) fprintf(stderr, " %u:%u", sp[c]->types[b], sp[c]->lengths[b]);
+      fprintf(stderr, "\n");
     }
   }
   { /* BrotliOptimizeHistograms */

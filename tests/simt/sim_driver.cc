@@ -6,6 +6,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <vector>
@@ -50,6 +51,8 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   a.ws = ws.data();
   a.nshards = (uint32_t)plan.shards.size();
   a.init_blocks_per_shard = 2;
+  uint32_t counters[16] = {0};
+  a.counters = counters;
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
   run(k_parse, a, a.nshards, 64, reverse);
   size_t n = 0;
@@ -63,6 +66,72 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
       ++n;
     }
     stats[0] += S.stat_searches; stats[1] += S.stat_pairs; stats[2] += S.stat_b_used;
+  }
+  return (long)n;
+}
+
+
+// Full encode of a plan on the simulator: init, then parse/build/store rounds
+// until every shard is done; outputs concatenated in shard order.
+// Returns the number of bytes or a negative error.
+long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int quality, int lgwin,
+                uint32_t size_hint, size_t shard_size, uint64_t stream_base, int is_last,
+                int reverse, uint8_t* out, size_t out_cap) {
+  HostTables ht;
+  if (!host_tables_load(tables_path, &ht)) return -1;
+  JobPlan plan;
+  if (!plan_job(len, quality, lgwin, size_hint, shard_size, stream_base, is_last != 0, &plan)) return -2;
+  std::vector<uint8_t> input(len + 64, 0);
+  memcpy(input.data(), in, len);
+  std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
+  std::vector<ShardState> states(plan.shards.size());
+  std::vector<double> log2lut;
+  DeviceTables T;
+  host_tables_fill(ht, plan.J.log2_lut_size, &log2lut, &T);
+  JobArgs a;
+  a.J = plan.J;
+  a.shards = plan.shards.data();
+  a.states = states.data();
+  a.T = &T;
+  a.input = input.data();
+  a.ws = ws.data();
+  a.nshards = (uint32_t)plan.shards.size();
+  a.init_blocks_per_shard = 2;
+  uint32_t counters[16] = {0};
+  a.counters = counters;
+  run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
+  for (int round = 0; round < 100000; ++round) {
+    memset(counters, 0, sizeof(counters));
+    run(k_parse, a, a.nshards, 64, reverse);
+    run(k_build, a, a.nshards, 64, reverse);
+    if (getenv("SIM_DEBUG")) {
+      for (size_t k = 0; k < plan.shards.size(); ++k) {
+        if (!states[k].mb_valid) continue;
+        MbLayout L;
+        mb_layout(plan.shards[k].len < plan.J.max_metablock_size ? plan.shards[k].len : plan.J.max_metablock_size, &L);
+        const uint8_t* mb = ws.data() + plan.shards[k].mb_off;
+        const MbInfo* I = (const MbInfo*)(mb + L.info);
+        fprintf(stderr, "shard %zu raw=%u nc=%u kind=%u nlits=%u ndist=%u ncmds=%u\n", k, states[k].mb_raw,
+                I->num_contexts, I->map_kind, I->nlits, I->ndist, I->ncmds);
+        for (int c = 0; c < 3; ++c) {
+          fprintf(stderr, "  cat %d types=%u blocks=%u:", c, I->split[c].num_types, I->split[c].num_blocks);
+          const uint8_t* ty = mb + L.types[c];
+          const uint32_t* le = (const uint32_t*)(mb + L.lengths[c]);
+          for (uint32_t b = 0; b < I->split[c].num_blocks && b < 40; ++b) fprintf(stderr, " %u:%u", ty[b], le[b]);
+          fprintf(stderr, "\n");
+        }
+      }
+    }
+    run(k_store, a, a.nshards, 64, reverse);
+    if (counters[1]) return -3;
+    if (counters[0] == 0) break;
+  }
+  size_t n = 0;
+  for (size_t k = 0; k < plan.shards.size(); ++k) {
+    const uint64_t m = states[k].out_bytes;
+    if (n + m > out_cap) return -4;
+    memcpy(out + n, ws.data() + plan.shards[k].out_off, m);
+    n += m;
   }
   return (long)n;
 }
