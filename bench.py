@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""bench.py — encode MB/s at quality 5, lgwin 22 (BASELINE.json metric).
+
+One "step" = one pass of the encoder hot path (table init, LZ77 parse, meta-block
+modelling, prefix codes + bit emission, shard concatenation) over the whole
+synthetic input, which is resident in HBM when the timed region starts.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size-mb M] [--shard-kb S]
+
+N = 1: BASELINE configs[1] (1 GiB synthetic enwik-style text, q5, lgwin 22, one
+MI355X).  N > 1 (launched by torch.distributed.run): weak scaling, every rank
+encodes its own M MiB piece of one stream (BROTLI_PARAM_STREAM_OFFSET shards,
+encode.h:231-246) and the ranks concatenate the compressed pieces with one
+RCCL all-gather of sizes + one of (padded) payloads inside the timed region.
+
+Rank 0 prints ONE JSON line (driver contract) with two extra objects:
+  roofline     — k_parse (the dominant kernel): algorithmic bytes per launch
+                 (A5 = 48 B per input byte) / its HIP-event time;
+  cpu_baseline — the reference encoder (oracle/_ref, built from /root/reference
+                 by oracle/Makefile) with the SAME partition plan on the host
+                 cores of this box, on a bounded sample (N = 1 only).
+The oracle / reference are only used as the baseline and for a spot check of
+the bytes; the measured path is the HIP library behind the C ABI.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+ALGO_BYTES_PER_INPUT_BYTE = 48.0   # SURVEY.md §8(d) q5/H68 model, DESIGN.md §5
+HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
+
+
+def cpu_baseline(data, quality, lgwin, shard_size, size_hint):
+    """Reference encoder, same plan, a thread per host core (ctypes drops the
+    GIL during the call; every shard is an independent encoder instance)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from refharness import Oracle, Ref, have_ref
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count()
+    except Exception:
+        cores = os.cpu_count()
+    cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    if have_ref():
+        enc, kind = Ref(), "reference"
+    else:
+        enc, kind = Oracle(), "port"
+    # bounded sample: ~10-20 s of CPU work at ~20 MB/s per core
+    nsh_total = -(-len(data) // shard_size)
+    nsh = min(nsh_total, max(cores, (cores * 256 << 20) // shard_size))
+    sample = data[:nsh * shard_size]
+
+    def one(k):
+        off = k * shard_size
+        piece = sample[off:off + shard_size]
+        return len(enc.encode_shard(piece, quality, lgwin, size_hint, min(off, 1 << 30),
+                                    off + len(piece) == len(data)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=cores) as ex:
+        out_bytes = sum(ex.map(one, range(nsh)))
+    dt = time.perf_counter() - t0
+    # single encoder instance on one core (what c/enc does by itself)
+    one_n = min(len(data), 16 << 20)
+    t1 = time.perf_counter()
+    enc.encode_shard(data[:one_n], quality, lgwin, size_hint, 0, one_n == len(data))
+    dt1 = time.perf_counter() - t1
+    return {
+        "value": round(len(sample) / 1e6 / dt, 1), "unit": "MB/s", "cores": cores, "kind": kind,
+        "sample": "first %d MiB of the same input, same plan (%d shards of %d KiB), %d threads, "
+                  "%.1f s; ratio %.3f" % (len(sample) >> 20, nsh, shard_size >> 10, cores, dt,
+                                          len(sample) / max(1, out_bytes)),
+        "single_stream_1core_MBps": round(one_n / 1e6 / dt1, 1),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size-mb", type=int, default=1024, help="input MiB per GPU")
+    ap.add_argument("--shard-kb", type=int, default=256, help="partition plan: KiB per encoder shard")
+    ap.add_argument("--quality", type=int, default=5)
+    ap.add_argument("--lgwin", type=int, default=22)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import gen_inputs as G
+    from brotli_amd import hip
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                 % (args.gpus, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    n = args.size_mb << 20
+    shard = args.shard_kb << 10
+    total = n * world
+    size_hint = min(total, 1 << 30)
+    data = G.enwik_text(n, seed=G.SEED + rank)
+    d_in = hip.to_device(data, local_rank)
+    ctx = hip.Context(local_rank)
+    params = hip.make_params(args.quality, args.lgwin, shard, size_hint, stream_base=rank * n,
+                             is_last=(rank == world - 1))
+    cap = ctx.max_output(n, params)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        nbytes, info = ctx.encode_device(d_in, n, params, d_out)
+        if dist is not None:
+            # C1: one all-gather of the sizes, one of the padded payloads.
+            from brotli_amd.dist import gather_stream
+            gathered, _, _ = gather_stream(d_out, nbytes, scratch=gathered)
+        return nbytes, info
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    infos = []
+    nbytes = 0
+    for _ in range(args.steps):
+        nbytes, info = step()
+        infos.append(info)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        tot_out = torch.tensor([nbytes], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot_out)
+        out_total = int(tot_out.item())
+    else:
+        out_total = nbytes
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        value = total / 1e6 / (dt / args.steps)
+        ms_parse = sum(i["ms_parse"] for i in infos) / len(infos)
+        achieved = ALGO_BYTES_PER_INPUT_BYTE * n / (ms_parse / 1e3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof):
+            t = json.load(open(prof))
+            key = "%d/%d" % (args.size_mb, args.shard_kb)
+            if key in t:
+                traffic = t[key]["hbm_bytes_per_launch"]
+        line = {
+            "metric": "encode MB/s at quality 5, lgwin 22, 1 GiB input; bit-exact vs c/enc",
+            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {
+                "workload": "%d MiB synthetic enwik-style text per GPU (tests/gen_inputs.enwik_text, "
+                            "seed %d+rank), quality %d, lgwin %d, %d x MI355X" % (
+                                args.size_mb, G.SEED, args.quality, args.lgwin, world),
+                "partition_plan": "%d shards of %d KiB per GPU (STREAM_OFFSET contract); "
+                                  "bytes identical to the reference driven with the same plan" % (
+                                      infos[-1]["nshards"], args.shard_kb),
+                "compressed_bytes": out_total, "ratio": round(total / out_total, 4),
+                "stage_ms": {k: round(sum(i[k] for i in infos) / len(infos), 3) for k in
+                             ("ms_total", "ms_init", "ms_parse", "ms_build", "ms_store", "ms_gather")},
+            },
+            "roofline": {"bound": "hbm", "kernel": "k_parse", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": traffic,
+                         "note": "algorithmic bytes = 48 B per input byte x %d bytes per launch; "
+                                 "kernel time %.3f ms (HIP events on the library's stream); the kernel "
+                                 "is SALU-issue/latency bound, not bandwidth bound (DESIGN.md)" % (n, ms_parse)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            # spot check of the bytes against the oracle on the first shards, then the baseline
+            from refharness import Oracle
+            o = Oracle()
+            comp = d_out[:nbytes].cpu().numpy().tobytes()
+            k = min(4, -(-n // shard))
+            want = b"".join(o.encode_shard(data[i * shard:(i + 1) * shard], args.quality, args.lgwin,
+                                           size_hint, min(i * shard, 1 << 30), (i + 1) * shard >= n)
+                            for i in range(k))
+            line["config"]["spot_check_first_shards_bit_exact"] = comp[:len(want)] == want
+            line["cpu_baseline"] = cpu_baseline(data, args.quality, args.lgwin, shard, size_hint)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

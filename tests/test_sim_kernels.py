@@ -1,0 +1,85 @@
+"""Kernel LOGIC on the host SIMT simulator (tests/simt) against the oracle: the
+same headers that hipcc compiles for gfx950 are compiled for the host with the
+wave primitives replaced by a 64-fiber rendezvous scheduler.  No GPU needed;
+sizes are small because the simulator switches fibers at every cross-lane op.
+The `-m gpu` tests run the real kernels at full sizes."""
+import numpy as np
+import pytest
+
+import gen_inputs as G
+from simharness import Sim, oracle_commands
+
+ALICE = open(__file__.replace("test_sim_kernels.py", "golden/alice29.txt"), "rb").read()
+
+
+@pytest.fixture(scope="module")
+def sim():
+    return Sim()
+
+
+def _oracle_plan(oracle, data, hint, shard):
+    n = len(data)
+    shard = shard or n
+    parts, off = [], 0
+    while off < n:
+        m = min(shard, n - off)
+        parts.append(oracle.encode_shard(data[off:off + m], 5, 22, hint or min(n, 1 << 30),
+                                         min(off, 1 << 30), off + m == n))
+        off += m
+    return b"".join(parts)
+
+
+def test_parse_commands_alice_prefix(sim, oracle):
+    data = ALICE[:60000]
+    want = oracle_commands(oracle, data, 5, 22, 0, 0)
+    got, stats = sim.parse(data, 5, 22, 0, 0)
+    assert np.array_equal(want, got)
+    assert stats[0] > 0 and stats[1] > 0
+
+
+@pytest.mark.parametrize("reverse,no_pair", [(1, 0), (0, 1)])
+def test_parse_lane_order_and_unpaired(sim, oracle, reverse, no_pair):
+    """Lanes scheduled high-to-low (catches missing wave_sync) and the search
+    without the speculative (p, p+1) pair must give the same commands."""
+    data = G.enwik_text(40000, seed=7, vocab=5000)
+    want = oracle_commands(oracle, data, 5, 22, 1 << 30, 1 << 15)
+    got, _ = sim.parse(data, 5, 22, 1 << 30, 1 << 15, reverse=reverse, no_pair=no_pair)
+    assert np.array_equal(want, got)
+
+
+CASES = {
+    "alice_48k": (ALICE[:48000], 0, 0),                                  # H58, 1 context
+    "text_hint_2shards": (G.enwik_text(1 << 16, seed=11, vocab=20000), 1 << 30, 1 << 15),  # H68, 13 contexts, flint
+    "ragged_shards": (G.enwik_text(50000, seed=5, vocab=3000), 0, 17000),
+    "mixed": (G.mixed_corpus(1 << 16)[:50000], 0, 0),
+    "random_raw": (G.random_bytes(20000), 0, 0),
+    "text_then_random": (G.enwik_text(20000, seed=2) + G.random_bytes(20000), 0, 0),
+    "zeros": (bytes(70000), 0, 0),
+    "rle": ((b"abcdefgh" * 9000)[:70001], 0, 0),
+    "tiny1": (b"x", 0, 0), "tiny2": (b"xy", 0, 0), "tiny3": (b"xyz", 0, 0),
+    "tiny9": (b"123456789", 0, 0), "x64": (b"x" * 64, 0, 0),
+    "shards_of_1_2_3": (b"abcabcabcabc", 0, 3),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_encode_bytes_match_oracle(sim, oracle, name):
+    data, hint, shard = CASES[name]
+    assert sim.encode(data, 5, 22, hint, shard) == _oracle_plan(oracle, data, hint, shard)
+
+
+def test_encode_reverse_lane_order(sim, oracle):
+    data = G.enwik_text(30000, seed=9, vocab=4000)
+    assert sim.encode(data, 5, 22, 1 << 30, 0, reverse=1) == _oracle_plan(oracle, data, 1 << 30, 0)
+
+
+def test_rank_piece_is_slice_of_whole_plan(sim, oracle):
+    """Multi-GPU contract: a rank that encodes the middle piece of a stream
+    (stream_base > 0, is_last = 0) produces exactly that slice of the whole
+    plan's output."""
+    data = G.enwik_text(60000, seed=4, vocab=4000)
+    shard, hint = 10000, 60000
+    whole = _oracle_plan(oracle, data, hint, shard)
+    pieces = [sim.encode(data[a:b], 5, 22, hint, shard, stream_base=a, is_last=(b == len(data)))
+              for a, b in ((0, 20000), (20000, 40000), (40000, 60000))]
+    assert b"".join(pieces) == whole
