@@ -44,6 +44,8 @@ struct JobParams {
   uint32_t flags;
 };
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
+#define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal
+#define JOB_FLAG_FORCE_SLOW 4u // k_parse4: always take the step-by-step candidate resolve
 
 // Per-shard description written by the host.
 struct ShardDesc {

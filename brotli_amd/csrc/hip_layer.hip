@@ -126,6 +126,13 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
     return BROTLI_AMD_UNSUPPORTED;
   }
   if (p->flags & BROTLI_AMD_FLAG_NO_PAIR) plan->J.flags |= JOB_FLAG_NO_PAIR;
+  if (p->flags & BROTLI_AMD_FLAG_FORCE_SLOW) plan->J.flags |= JOB_FLAG_FORCE_SLOW;
+  // Four shards per wave (k_parse4.h) whenever no shard can wrap the ring or
+  // see a candidate beyond the window.
+  uint64_t longest = 0;
+  for (const ShardDesc& D : plan->shards) if (D.len > longest) longest = D.len;
+  if (!(p->flags & BROTLI_AMD_FLAG_NO_QUAD) && longest <= plan->J.max_backward_limit)
+    plan->J.flags |= JOB_FLAG_QUAD;
   return BROTLI_AMD_OK;
 }
 
@@ -164,7 +171,10 @@ bool run_rounds(BrotliAmdCtx* c, const JobPlan& plan, const uint8_t* d_in, int s
   for (;;) {
     HIP_OK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
     HIP_OK(c, hipEventRecord(c->ev[2], c->stream));
-    hipLaunchKernelGGL(k_parse, dim3(nshards), dim3(64), 0, c->stream, a);
+    if (plan.J.flags & JOB_FLAG_QUAD)
+      hipLaunchKernelGGL(k_parse4, dim3((nshards + 3) / 4), dim3(64), 0, c->stream, a);
+    else
+      hipLaunchKernelGGL(k_parse, dim3(nshards), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev[3], c->stream));
     if (stages & STAGE_BUILD) hipLaunchKernelGGL(k_build, dim3(nshards), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev[4], c->stream));

@@ -1,0 +1,680 @@
+// brotli_amd/csrc/k_parse4.h — K1, second generation: the LZ77 parse with FOUR
+// encoder shards per wavefront (16 lanes each).
+//
+// Semantics: identical to k_parse.h / k_round.h (CreateBackwardReferences,
+// c/enc/backward_references_inc.h:10-242; H68 / H58,
+// c/enc/hash_longest_match64_simd_inc.h:114-302; static dictionary,
+// c/enc/hash.h:140-202; EncodeData glue, c/enc/encode.c:905-1173).
+//
+// Why: with one shard per wave every decision is wave-uniform and lands on
+// the scalar unit (one per CU, shared by 32 waves); rocprofv3 showed the first
+// kernel bound by SALU issue (131 SALU + 53 VALU per input byte,
+// profiles/r01_a_*).  Here a 16-lane group owns a shard: lane t of a group is
+// slot t of the 16-slot bucket row, lanes 0..3 double as the distance-cache
+// probes, and all encoder state is kept per lane (replicated inside a group),
+// so one VALU instruction advances four encoders and the scalar unit only
+// runs the loop skeleton.  A 128-byte bucket record is one coalesced access of
+// a group; four groups keep four independent memory round trips in flight.
+//
+// Preconditions (checked by the host, hip_layer.hip): every shard is at most
+// (1 << lgwin) - 16 bytes, so positions never wrap the ring and no candidate
+// is ever farther than the window; longer shards use k_parse.h.
+//
+// The order-dependent candidate resolve of FindLongestMatch is evaluated as an
+// arg-max over the group (exact whenever no candidate needs the reference's
+// byte "gate" to decide, which is detected) with a step-by-step emulation as
+// the fallback (resolve_slow), also reachable with JOB_FLAG_FORCE_SLOW so the
+// tests can pin one against the other.
+#ifndef BROTLI_AMD_CSRC_K_PARSE4_H_
+#define BROTLI_AMD_CSRC_K_PARSE4_H_
+
+#include "k_round.h"
+
+#define Q_GROUPS 4
+#define Q_DUP_SLOTS 1024u
+
+enum QState { Q_PRE = 0, Q_SETUP = 1, Q_SEARCH = 2, Q_LAZY = 3, Q_POST = 4, Q_DONE = 5 };
+
+// All fields are identical in the 16 lanes of a group.
+struct QShard {
+  // shard constants
+  const uint8_t* data;
+  uint8_t* table;
+  Command* cmds;
+  uint8_t* out;
+  uint32_t len, stream_offset, final_op, cmd_cap;
+  // stream state (RoundRegs)
+  RoundRegs r;
+  int32_t dc[4];
+  uint32_t dict_lookups, dict_matches;
+  // current block
+  uint32_t blk_is_last, blk_force_flush, blk_bytes, blk_pos;
+  uint32_t want_stitch, want_extend;
+  uint32_t position, pos_end, store_end, insert_length, apply_random_heuristics;
+  // lazy matching
+  uint32_t sr_len, sr_dist, sr_score;
+  int32_t sr_delta;
+  uint32_t delayed;
+  // pending ordered insertions: first + i * stride, i < count
+  uint32_t st_first, st_count, st_stride;
+  uint32_t state;
+  uint32_t error, have_mb, done;
+  uint32_t stat_searches;
+};
+
+DEV int q_t() { return wave_lane() & 15; }
+DEV int q_base() { return wave_lane() & 48; }
+DEV uint32_t q_mask16(uint64_t ballot) { return (uint32_t)(ballot >> q_base()) & 0xFFFFu; }
+DEV bool wave_any(bool p) { return wave_ballot(p) != 0; }
+DEV uint32_t q_bcast(uint32_t v, int t) { return wave_shfl(v, q_base() | t); }
+DEV uint32_t q_max(uint32_t v) {
+  const int lane = wave_lane();
+#pragma unroll
+  for (int k = 1; k < 16; k <<= 1) {
+    const uint32_t o = wave_shfl(v, lane ^ k);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+DEV uint16_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
+
+// Byte the reference reads at ring index x <= pos_end on the first lap.
+DEV uint32_t q_ring_byte(const QShard& g, uint32_t x) { return x < g.pos_end ? g.data[x] : 0u; }
+
+DEV uint32_t q_dc_entry(const QShard& g, int i) {
+  return (uint32_t)(i == 0 ? g.dc[0] : i == 1 ? g.dc[1] : i == 2 ? g.dc[2] : g.dc[3]);
+}
+
+// Match length of data[a..] and data[b..] beyond the first 32 bytes
+// (find_match_length.h:19-40), limit = bytes available at a.
+DEV uint32_t q_extend(const uint8_t* data, uint32_t a, uint32_t b, uint32_t limit) {
+  uint32_t off = 32;
+  while (off + 8 <= limit) {
+    const uint64_t x = ld64(data + a + off) ^ ld64(data + b + off);
+    if (x) return off + ((uint32_t)dev_ctz64(x) >> 3);
+    off += 8;
+  }
+  while (off < limit && data[a + off] == data[b + off]) ++off;
+  return off;
+}
+
+// ---- ordered insertion of up to 16 positions per group ---------------------------
+// Store / StoreRange (..64_simd_inc.h:114-137).  `act`: this lane inserts `pos`.
+DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, uint8_t* lds_dup) {
+  const int t = q_t();
+  KeyTag kt;
+  kt.key = 0; kt.tag = 0; kt.tag2 = 0;
+  if (act) kt = hash_pos(ld64(g.data + pos), J.hasher_type, J.bucket_bits);
+  // Two lanes of a group with one key must be ranked; detect that case through
+  // an LDS scoreboard (false positives only cost time).
+  uint8_t* sb = lds_dup + (size_t)(q_base() >> 4) * Q_DUP_SLOTS + (kt.key & (Q_DUP_SLOTS - 1u));
+  if (act) *sb = (uint8_t)t;
+  wave_sync();
+  const bool dup = act && *sb != (uint8_t)t;
+  const bool any_dup = wave_any(dup);
+  uint8_t* rec = g.table + (size_t)kt.key * REC_BYTES;
+  uint32_t num = 0;
+  if (act) num = ld16(rec + REC_NUM_DW * 4);
+  wave_sync();
+  if (!any_dup) {
+    if (act) {
+      const uint32_t s = num & 15u;
+      st32(rec + REC_SLOT_DW * 4 + s * 4, pos);
+      st16(rec + REC_TAG2_DW * 4 + s * 2, (uint16_t)kt.tag2);
+      rec[REC_TAG_DW * 4 + s] = (uint8_t)kt.tag;
+      st16(rec + REC_NUM_DW * 4, (uint16_t)(num - 1u));
+    }
+  } else {
+    // same = lanes of my group that insert the same key
+    uint64_t same = ~0ull;
+    for (int b = 0; b < J.bucket_bits; ++b) {
+      const bool bit = (kt.key >> b) & 1;
+      const uint64_t m = wave_ballot(act && bit);
+      same &= bit ? m : ~m;
+    }
+    same &= wave_ballot(act);
+    const uint32_t same16 = q_mask16(same);
+    if (act) {
+      const uint32_t below = (uint32_t)__builtin_popcount(same16 & ((1u << t) - 1u));
+      const uint32_t total = (uint32_t)__builtin_popcount(same16);
+      const uint32_t s = (num - below) & 15u;
+      st32(rec + REC_SLOT_DW * 4 + s * 4, pos);
+      st16(rec + REC_TAG2_DW * 4 + s * 2, (uint16_t)kt.tag2);
+      rec[REC_TAG_DW * 4 + s] = (uint8_t)kt.tag;
+      if (below + 1 == total) st16(rec + REC_NUM_DW * 4, (uint16_t)(num - total));
+    }
+  }
+  wave_sync();
+}
+
+// Drains every group's pending insertions.
+DEV void q_drain_stores(const JobParams& J, QShard& g, uint8_t* lds_dup) {
+  while (wave_any(g.st_count != 0)) {
+    const uint32_t n = umin(g.st_count, 16u);
+    const bool act = (uint32_t)q_t() < n;
+    q_store16(J, g, act, g.st_first + (uint32_t)q_t() * g.st_stride, lds_dup);
+    g.st_first += n * g.st_stride;
+    g.st_count -= n;
+  }
+}
+
+// ---- one FindLongestMatch per group ------------------------------------------------
+struct QResult { uint32_t len, distance, score; int32_t delta; };
+
+// Exact step-by-step emulation (..64_simd_inc.h:201-292) over the candidates
+// the lanes hold: distance-cache entries in lanes 0..ndist-1, bucket slots in
+// ring order starting at `head`.
+DEV QResult q_resolve_slow(const QShard& g, bool want, uint32_t P, uint32_t max_length,
+                           uint32_t head, int ndist, bool d_ok, uint32_t d_len, uint32_t d_prev,
+                           uint32_t d_score, bool b_ok, uint32_t b_len, uint32_t b_prev,
+                           uint32_t b_score) {
+  QResult r;
+  r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; r.delta = 0;
+  uint32_t best_len = 0;
+  for (int i = 0; i < ndist; ++i) {
+    const bool ok = q_bcast(d_ok ? 1u : 0u, i) != 0;
+    const uint32_t len_i = q_bcast(d_len, i), prev_i = q_bcast(d_prev, i), score_i = q_bcast(d_score, i);
+    if (!want || !ok) continue;
+    if (q_ring_byte(g, P + best_len) != q_ring_byte(g, prev_i + best_len)) continue;
+    if (!(len_i >= 3 || (len_i == 2 && i < 2))) continue;
+    if (!(r.score < score_i)) continue;
+    best_len = len_i;
+    r.len = len_i; r.distance = P - prev_i; r.score = score_i;
+  }
+  if (best_len < 3) best_len = 3;
+  for (int j = 0; j < 16; ++j) {
+    const int src = (int)((head + (uint32_t)j) & 15u);
+    const bool ok = q_bcast(b_ok ? 1u : 0u, src) != 0;
+    const uint32_t len_j = q_bcast(b_len, src), prev_j = q_bcast(b_prev, src), score_j = q_bcast(b_score, src);
+    if (!want || !ok) continue;
+    bool pass = true;
+    for (uint32_t k = best_len - 3; k <= best_len; ++k) {
+      if (q_ring_byte(g, P + k) != q_ring_byte(g, prev_j + k)) { pass = false; break; }
+    }
+    if (!pass) continue;
+    if (len_j < 4) continue;
+    if (!(r.score < score_j)) continue;
+    best_len = len_j;
+    r.len = len_j; r.distance = P - prev_j; r.score = score_j;
+  }
+  (void)max_length;
+  return r;
+}
+
+// Static dictionary probe (hash.h:140-202): lanes 0 and 1 of a group take one
+// hash slot each; acceptance is sequential (slot 0 first).  `want`: this
+// group's search found nothing.
+DEV void q_dict_search(const JobParams& J, const DeviceTables* T, QShard& g, bool want, uint32_t P,
+                       uint32_t max_length, QResult& out) {
+  const int t = q_t();
+  const bool go = want && !(g.dict_matches < (g.dict_lookups >> 7));
+  if (!wave_any(go)) return;
+  uint32_t matchlen = 0, wlen = 0, widx = 0;
+  if (go && t < 2) {
+    const uint32_t key = (((ld32(g.data + P) * 0x1E35A7BDu) >> (32 - 14)) << 1) + (uint32_t)t;
+    wlen = T->dict_hash_lengths[key];
+    widx = T->dict_hash_words[key];
+    if (wlen != 0 && wlen <= max_length) {
+      const uint8_t* w = T->dict + T->dict_offsets_by_length[wlen & 31] + wlen * widx;
+      while (matchlen < wlen && g.data[P + matchlen] == w[matchlen]) ++matchlen;
+    }
+  }
+  const uint32_t dictionary_start = umin(P + g.stream_offset, J.max_backward_limit);
+  for (int i = 0; i < 2; ++i) {
+    const uint32_t len = q_bcast(wlen, i), word_idx = q_bcast(widx, i), ml = q_bcast(matchlen, i);
+    if (!go) continue;
+    g.dict_lookups++;
+    if (len == 0 || len > max_length) continue;
+    if (ml + 10 <= len || ml == 0) continue;
+    const uint32_t cut = len - ml;
+    const uint32_t transform_id = (cut << 2) + (uint32_t)((0x071B520ADA2D3200ull >> (cut * 6)) & 0x3F);
+    const uint32_t backward = dictionary_start + 1u + word_idx +
+        (transform_id << T->dict_size_bits_by_length[len]);
+    if (backward > 0x3FFFFFCu) continue;   // params->dist.max_distance
+    const uint32_t score = 1920u + 135u * ml - 30u * log2floor(backward);
+    if (score < out.score) continue;
+    out.len = ml;
+    out.delta = (int32_t)len - (int32_t)ml;
+    out.distance = backward;
+    out.score = score;
+    g.dict_matches++;
+  }
+}
+
+// Searches position P for every group with want set.  Inserts P afterwards.
+DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool want, uint32_t P) {
+  const int t = q_t();
+  const int ndist = J.ndist;
+  const uint32_t max_length = g.pos_end - P;
+  const uint32_t max_backward = umin(P, J.max_backward_limit);
+  B32 cur32;
+  cur32.q[0] = cur32.q[1] = cur32.q[2] = cur32.q[3] = 0;
+  if (want) cur32 = load_b32(g.data + P);
+  const KeyTag kt = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits);
+  const uint8_t* rec = g.table + (size_t)kt.key * REC_BYTES;
+  uint32_t slot = 0, tag2 = 0, tag = 0, num = 0;
+  if (want) {
+    slot = ld32(rec + REC_SLOT_DW * 4 + t * 4);
+    tag2 = ld16(rec + REC_TAG2_DW * 4 + t * 2);
+    tag = rec[REC_TAG_DW * 4 + t];
+    num = ld16(rec + REC_NUM_DW * 4);
+  }
+  const uint32_t head = (num + 1u) & 15u;
+  const uint32_t n = (65535u - num) & 0xFFFFu;
+  const uint32_t logical = ((uint32_t)t - head) & 15u;   // 0 = newest
+  // bucket candidate of this lane (:246-262)
+  const bool b_cand = want && (n >= 16u || logical < n) && tag == kt.tag && tag2 == kt.tag2 &&
+                      (P - slot) <= max_backward;
+  // distance-cache candidate of this lane (:201-240)
+  const uint32_t backward = q_dc_entry(g, t);
+  const bool d_cand = want && t < ndist && (int32_t)backward > 0 && backward <= max_backward;
+  const uint32_t b_prev = slot, d_prev = P - backward;
+  uint32_t b_len = 0, d_len = 0;
+  bool b_ext = false, d_ext = false;
+  if (b_cand) {
+    const B32 p32 = load_b32(g.data + b_prev);
+    const uint32_t m = common_prefix32(cur32, p32);
+    b_len = umin(m, max_length);
+    b_ext = m == 32u && max_length > 32u;
+  }
+  if (d_cand) {
+    const B32 p32 = load_b32(g.data + d_prev);
+    const uint32_t m = common_prefix32(cur32, p32);
+    d_len = umin(m, max_length);
+    d_ext = m == 32u && max_length > 32u;
+  }
+  if (wave_any(b_ext || d_ext)) {
+    if (b_ext) b_len = q_extend(g.data, P, b_prev, max_length);
+    if (d_ext) d_len = q_extend(g.data, P, d_prev, max_length);
+  }
+  // scores (hash.h:123-138)
+  const uint32_t b_score = 1920u + 135u * b_len - 30u * log2floor((P - b_prev) | 1u);
+  uint32_t d_score = 135u * d_len + 1935u;
+  if (t != 0) d_score -= 39u + ((0x1CA10u >> ((uint32_t)t & 0xEu)) & 0xEu);
+  const bool b_ok = b_cand && b_len >= 4u;
+  const bool d_ok = d_cand && (d_len >= 3u || (d_len == 2u && t < 2));
+
+  // Arg-max with the reference's order as the tie break: distance cache
+  // entries 0..3 first, then bucket slots newest to oldest.
+  const uint32_t d_key = d_ok ? (d_score << 5) | (31u - (uint32_t)t) : 0u;
+  const uint32_t b_key = b_ok ? (b_score << 5) | (27u - logical) : 0u;
+  const uint32_t d_best = q_max(d_key);
+  const uint32_t dc_score = d_best ? (d_best >> 5) : K_MIN_SCORE;
+  // length of the distance-cache winner (needed for the gate test below)
+  const uint64_t dwin_m = wave_ballot(d_key != 0 && d_key == d_best);
+  const uint32_t dwin16 = q_mask16(dwin_m);
+  const int dwin_t = dwin16 ? dev_ctz32(dwin16) : 0;
+  const uint32_t dc_len_b = q_bcast(d_len, dwin_t);
+  const uint32_t dc_len = dwin16 ? dc_len_b : 0u;
+  const uint32_t dc_len3 = dc_len < 3u ? 3u : dc_len;
+  // A bucket candidate that beats the distance-cache winner without being
+  // longer depends on the byte gate: take the exact path for that group.
+  const bool unsure = b_ok && b_score > dc_score && b_len <= dc_len3;
+  const bool force_slow = (J.flags & JOB_FLAG_FORCE_SLOW) != 0;
+  const bool slow = q_mask16(wave_ballot(unsure)) != 0 || (force_slow && want);
+  const uint32_t best = q_max(b_key > d_key ? b_key : d_key);
+  const uint64_t win_m = wave_ballot(best != 0 && (b_key == best || d_key == best));
+  const uint32_t win16 = q_mask16(win_m);
+  const int win_t = win16 ? dev_ctz32(win16) : 0;
+  const bool win_is_d = d_key == best;
+  const uint32_t my_len = win_is_d ? d_len : b_len;
+  const uint32_t my_dist = win_is_d ? backward : P - b_prev;
+  QResult r;
+  r.len = q_bcast(my_len, win_t);
+  r.distance = q_bcast(my_dist, win_t);
+  r.score = best >> 5;
+  r.delta = 0;
+  if (best == 0 || r.score <= K_MIN_SCORE) { r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; }
+  if (wave_any(slow)) {
+    const QResult s = q_resolve_slow(g, want, P, max_length, head, ndist, d_ok || (d_cand), d_len,
+                                     d_prev, d_score, b_cand, b_len, b_prev, b_score);
+    if (slow) r = s;
+  }
+  // insert P (:293-295)
+  if (want && (uint32_t)t == (num & 15u)) {
+    uint8_t* wrec = g.table + (size_t)kt.key * REC_BYTES;
+    st32(wrec + REC_SLOT_DW * 4 + t * 4, P);
+    st16(wrec + REC_TAG2_DW * 4 + t * 2, (uint16_t)kt.tag2);
+    wrec[REC_TAG_DW * 4 + t] = (uint8_t)kt.tag;
+    st16(wrec + REC_NUM_DW * 4, (uint16_t)(num - 1u));
+  }
+  wave_sync();
+  // static dictionary when nothing was found (hash.h:179-202)
+  q_dict_search(J, T, g, want && r.score == K_MIN_SCORE, P, max_length, r);
+  return r;
+}
+
+// ---- stream driver pieces (k_round.h's parse_round, per lane) ------------------------
+DEV void q_flush_padding(QShard& g, bool writer) {
+  RoundRegs& r = g.r;
+  if (r.last_bytes_bits != 0) {
+    const uint32_t seal = r.last_bytes | (0x6u << r.last_bytes_bits);
+    const uint32_t seal_bits = r.last_bytes_bits + 6u;
+    const uint32_t nb = (seal_bits + 7u) >> 3;
+    if (writer) for (uint32_t i = 0; i < nb; ++i) g.out[r.out_bytes + i] = (uint8_t)(seal >> (8u * i));
+    r.out_bytes += nb;
+    r.last_bytes = 0;
+    r.last_bytes_bits = 0;
+  }
+  if (r.flint == -1) r.flint = -2;
+}
+
+// Loop top of BrotliEncoderCompressStream up to the start of EncodeData.
+DEV void q_driver_pre(const JobParams& J, QShard& g) {
+  RoundRegs& r = g.r;
+  const uint32_t block = 1u << J.lgblock;
+  const uint32_t htl = J.hasher_type == 68 ? 8u : 4u;
+  for (;;) {
+    const uint32_t avail = g.len - r.input_pos;
+    const uint32_t d = r.input_pos - r.last_processed_pos;
+    uint32_t remaining = d >= block ? 0u : block - d;
+    if (r.flint >= 0 && remaining > (uint32_t)r.flint) remaining = (uint32_t)r.flint;
+    if (remaining != 0 && avail != 0) {
+      const uint32_t n = umin(remaining, avail);
+      r.input_pos += n;
+      if (r.flint > 0) r.flint -= (int32_t)n;
+      continue;
+    }
+    bool is_last = avail == 0 && g.final_op == 2;
+    bool force_flush = avail == 0 && g.final_op == 1;
+    if (!is_last && r.flint == 0) { r.flint = -1; force_flush = true; }
+    const uint32_t bytes = r.input_pos - r.last_processed_pos;
+    const uint32_t pos = r.last_processed_pos;
+    if (r.ncmds + bytes / 2u + 2u > g.cmd_cap) { g.error = 1; g.state = Q_DONE; return; }
+    g.blk_is_last = is_last;
+    g.blk_force_flush = force_flush;
+    g.blk_bytes = bytes;
+    g.blk_pos = pos;
+    g.pos_end = r.input_pos;
+    g.want_stitch = bytes >= htl - 1u && pos >= 3u;
+    g.want_extend = r.ncmds != 0 && r.last_insert_len == 0;
+    g.state = Q_SETUP;
+    return;
+  }
+}
+
+// After CreateBackwardReferences of a block: merge / cut decision (encode.c:1141-1216).
+DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
+  RoundRegs& r = g.r;
+  const uint32_t block = 1u << J.lgblock;
+  const bool is_last = g.blk_is_last != 0, force_flush = g.blk_force_flush != 0;
+  const uint32_t avail = g.len - r.input_pos;
+  {
+    const uint32_t processed = r.input_pos - r.last_flush_pos;
+    const bool next_fits = processed + block <= J.max_metablock_size;
+    if (!is_last && !force_flush && next_fits && r.nlits < J.max_literals && r.ncmds < J.max_commands) {
+      r.last_processed_pos = r.input_pos;
+      g.state = Q_PRE;
+      return;
+    }
+  }
+  if (r.last_insert_len > 0) {
+    if (writer) g.cmds[r.ncmds] = make_insert_command(r.last_insert_len);
+    ++r.ncmds;
+    r.nlits += r.last_insert_len;
+    r.last_insert_len = 0;
+  }
+  if (!is_last && r.input_pos == r.last_flush_pos) {
+    r.last_processed_pos = r.input_pos;
+    if (force_flush) q_flush_padding(g, writer);
+    if (avail == 0) { g.done = 1; g.state = Q_DONE; } else g.state = Q_PRE;
+    return;
+  }
+  const uint32_t mbytes = r.input_pos - r.last_flush_pos;
+  if (mbytes <= 2u) {
+    // ShouldCompress() is false for <= 2 bytes (encode.c:461): flint blocks
+    // and tiny tails are written right here by the group's lane 0.
+    BitWriter w;
+    bw_init(w, g.out + r.out_bytes, r.last_bytes_bits, r.last_bytes);
+    if (mbytes == 0) {
+      bw_put(w, 2, 3);
+      bw_align_byte(w);
+    } else {
+      for (int i = 0; i < 4; ++i) g.dc[i] = r.saved_dc[i];
+      // BrotliStoreUncompressedMetaBlock (brotli_bit_stream.c:1321-1352)
+      bw_put(w, 1, 0);
+      bw_put(w, 2, 0);
+      bw_put(w, 16, mbytes - 1u);
+      bw_put(w, 1, 1);
+      bw_align_byte(w);
+      for (uint32_t i = 0; i < mbytes; ++i) bw_put(w, 8, g.data[r.last_flush_pos + i]);
+      if (is_last) {
+        bw_put(w, 1, 1);
+        bw_put(w, 1, 1);
+        bw_align_byte(w);
+      }
+    }
+    // flush whole bytes; only the group's writer lane touches memory
+    while (w.nacc >= 8) {
+      if (writer) w.out[w.byte_pos] = (uint8_t)w.acc;
+      w.byte_pos += 1;
+      w.acc >>= 8;
+      w.nacc -= 8;
+    }
+    r.out_bytes += w.byte_pos;
+    r.last_bytes = (uint32_t)(w.acc & 0xFF);
+    r.last_bytes_bits = w.nacc;
+    r.last_flush_pos = r.input_pos;
+    r.last_processed_pos = r.input_pos;
+    if (r.last_flush_pos > 0) r.prev_byte = g.data[r.last_flush_pos - 1];
+    if (r.last_flush_pos > 1) r.prev_byte2 = g.data[r.last_flush_pos - 2];
+    r.ncmds = 0;
+    r.nlits = 0;
+    for (int i = 0; i < 4; ++i) r.saved_dc[i] = g.dc[i];
+    if (force_flush) q_flush_padding(g, writer);
+    if (is_last || avail == 0) { g.done = 1; g.state = Q_DONE; } else g.state = Q_PRE;
+    return;
+  }
+  g.have_mb = 1;
+  g.state = Q_DONE;
+}
+
+// ExtendLastCommand (encode.c:905-971) for the groups with want set; then the
+// CreateBackwardReferences prologue.
+DEV void q_setup_block(const JobParams& J, QShard& g, bool want, uint8_t* lds_dup) {
+  const int t = q_t();
+  const uint32_t htl = J.hasher_type == 68 ? 8u : 4u;
+  // StitchToPreviousBlock (..64_simd_inc.h:139-151)
+  if (want && g.want_stitch) {
+    g.st_first = g.blk_pos - 3u;
+    g.st_count = 3;
+    g.st_stride = 1;
+  }
+  q_drain_stores(J, g, lds_dup);
+  uint32_t bytes = g.blk_bytes, pos = g.blk_pos;
+  bool ext = false;
+  uint32_t cmd_dist = 0;
+  Command last;
+  last.insert_len = last.copy_len = last.dist_extra = 0;
+  last.cmd_prefix = last.dist_prefix = 0;
+  const bool try_ext = want && g.want_extend;
+  if (try_ext) {
+    last = g.cmds[g.r.ncmds - 1];
+    const uint32_t last_copy_len = last.copy_len & 0x1FFFFFFu;
+    const uint32_t lpp = g.r.last_processed_pos - last_copy_len;
+    const uint32_t max_distance = umin(lpp, J.max_backward_limit);
+    cmd_dist = (uint32_t)g.dc[0];
+    uint32_t distance_code;
+    const uint32_t dcode = last.dist_prefix & 0x3FFu;
+    if (dcode < 16) {
+      distance_code = dcode;
+    } else {
+      const uint32_t nbits = last.dist_prefix >> 10;
+      const uint32_t hcode = dcode - 16u;
+      const uint32_t offset = ((2u + (hcode & 1u)) << nbits) - 4u;
+      distance_code = offset + last.dist_extra + 16u;
+    }
+    const bool code_ok = distance_code < 16u || distance_code - 15u == cmd_dist;
+    ext = code_ok && g.dc[0] > 0 && cmd_dist <= max_distance;
+    if (!code_ok) last.insert_len = 0xFFFFFFFFu;   // marker: leave the command alone
+  }
+  bool running = ext;
+  while (wave_any(running)) {
+    const bool ok = running && (uint32_t)t < bytes &&
+        g.data[pos + (uint32_t)t] == g.data[pos + (uint32_t)t - cmd_dist];
+    const uint32_t m16 = q_mask16(wave_ballot(ok));
+    const uint32_t run = (m16 == 0xFFFFu) ? 16u : (uint32_t)dev_ctz32(~m16);
+    if (running) {
+      last.copy_len += run;
+      bytes -= run;
+      pos += run;
+      if (run < 16u || bytes == 0) running = false;
+    }
+  }
+  if (try_ext && last.insert_len != 0xFFFFFFFFu) {
+    last.cmd_prefix = (uint16_t)combine_length_codes(insert_length_code(last.insert_len),
+        copy_length_code((uint32_t)((int)(last.copy_len & 0x1FFFFFFu) + (int)(last.copy_len >> 25))),
+        (last.dist_prefix & 0x3FF) == 0);
+    if (t == 0) g.cmds[g.r.ncmds - 1] = last;
+  }
+  wave_sync();
+  if (want) {
+    g.position = pos;
+    g.pos_end = pos + bytes;
+    g.store_end = bytes >= htl ? g.pos_end - htl + 1u : pos;
+    g.insert_length = g.r.last_insert_len;
+    g.apply_random_heuristics = pos + J.spree_window;
+    g.state = Q_SEARCH;
+  }
+}
+
+// ---- the kernel body: up to four shards per wave ---------------------------------------
+DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* states,
+                      uint32_t nshards, const DeviceTables* T, const uint8_t* input, uint8_t* ws,
+                      uint32_t wave_index, uint8_t* lds_dup) {
+  const int t = q_t();
+  const uint32_t shard = wave_index * Q_GROUPS + (uint32_t)(wave_lane() >> 4);
+  const bool alive = shard < nshards;
+  const bool writer = alive && t == 0;
+  const uint32_t htl = J.hasher_type == 68 ? 8u : 4u;
+  const ShardDesc& D = shards[alive ? shard : 0];
+  ShardState* S = &states[alive ? shard : 0];
+
+  QShard g;
+  g.data = input + D.in_off;
+  g.table = ws + D.table_off;
+  g.cmds = (Command*)(ws + D.cmds_off);
+  g.out = ws + D.out_off;
+  g.len = D.len;
+  g.stream_offset = D.stream_offset;
+  g.final_op = D.final_op;
+  g.cmd_cap = D.cmd_cap;
+  regs_load(g.r, S);
+  for (int i = 0; i < 4; ++i) g.dc[i] = S->dist_cache[i];
+  g.dict_lookups = S->dict_lookups;
+  g.dict_matches = S->dict_matches;
+  g.blk_is_last = g.blk_force_flush = g.blk_bytes = g.blk_pos = 0;
+  g.want_stitch = g.want_extend = 0;
+  g.position = g.pos_end = g.store_end = g.insert_length = g.apply_random_heuristics = 0;
+  g.sr_len = g.sr_dist = 0; g.sr_score = K_MIN_SCORE; g.sr_delta = 0; g.delayed = 0;
+  g.st_first = g.st_count = 0; g.st_stride = 1;
+  g.error = 0; g.have_mb = 0; g.done = 0;
+  g.stat_searches = 0;
+  g.state = (alive && !S->done && !S->mb_valid && !S->error) ? Q_PRE : Q_DONE;
+  const bool participated = g.state != Q_DONE;
+
+  while (wave_any(g.state != Q_DONE)) {
+    // stream driver up to the next block
+    if (g.state == Q_PRE) q_driver_pre(J, g);
+    if (wave_any(g.state == Q_SETUP)) q_setup_block(J, g, g.state == Q_SETUP, lds_dup);
+
+    // block finished? (loop guard of CreateBackwardReferences, :44 and :239-241)
+    if (g.state == Q_SEARCH && !(g.position + htl < g.pos_end)) {
+      g.insert_length += g.pos_end - g.position;
+      g.r.last_insert_len = g.insert_length;
+      g.state = Q_POST;
+    }
+    const bool want = g.state == Q_SEARCH || g.state == Q_LAZY;
+    if (wave_any(want)) {
+      const uint32_t P = g.position + (g.state == Q_LAZY ? 1u : 0u);
+      const QResult cur = q_search(J, T, g, want, P);
+      if (want) g.stat_searches++;
+      bool commit = false;
+      if (g.state == Q_SEARCH) {
+        if (cur.score > K_MIN_SCORE) {
+          g.sr_len = cur.len; g.sr_dist = cur.distance; g.sr_score = cur.score; g.sr_delta = cur.delta;
+          g.delayed = 0;
+          g.state = Q_LAZY;
+        } else {
+          ++g.insert_length;
+          ++g.position;
+          if (g.position > g.apply_random_heuristics) {
+            // literal spree (:208-236): sparse insertions, no searches
+            uint32_t step, span, margin;
+            if (g.position > g.apply_random_heuristics + 4u * J.spree_window) {
+              step = 4; span = 16; margin = umax(htl - 1u, 4u);
+            } else {
+              step = 2; span = 8; margin = umax(htl - 1u, 2u);
+            }
+            const uint32_t pos_jump = umin(g.position + span, g.pos_end - margin);
+            if (g.position < pos_jump) {
+              const uint32_t cnt = (pos_jump - g.position + step - 1u) / step;
+              g.st_first = g.position;
+              g.st_count = cnt;
+              g.st_stride = step;
+              g.position += cnt * step;
+              g.insert_length += cnt * step;
+            }
+          }
+        }
+      } else if (g.state == Q_LAZY) {
+        commit = true;
+        if (cur.score >= g.sr_score + 175u) {
+          ++g.position;
+          ++g.insert_length;
+          g.sr_len = cur.len; g.sr_dist = cur.distance; g.sr_score = cur.score; g.sr_delta = cur.delta;
+          if (++g.delayed < 4 && g.position + htl < g.pos_end) commit = false;
+        }
+      }
+      if (commit) {
+        g.state = Q_SEARCH;
+        g.apply_random_heuristics = g.position + 2u * g.sr_len + J.spree_window;
+        const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit);
+        const uint32_t distance_code = compute_distance_code(g.sr_dist, dictionary_start, g.dc);
+        if (g.sr_dist <= dictionary_start && distance_code > 0) {
+          g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)g.sr_dist;
+        }
+        if (t == 0) g.cmds[g.r.ncmds] = make_command(g.insert_length, g.sr_len, g.sr_delta, distance_code);
+        ++g.r.ncmds;
+        g.r.nlits += g.insert_length;
+        g.insert_length = 0;
+        uint32_t range_start = g.position + 2u;
+        const uint32_t range_end = umin(g.position + g.sr_len, g.store_end);
+        if (g.sr_dist < (g.sr_len >> 2)) {
+          range_start = umin(range_end, umax(range_start, g.position + g.sr_len - (g.sr_dist << 2)));
+        }
+        if (range_start < range_end) {
+          g.st_first = range_start;
+          g.st_count = range_end - range_start;
+          g.st_stride = 1;
+        }
+        g.position += g.sr_len;
+      }
+      q_drain_stores(J, g, lds_dup);
+    }
+    if (g.state == Q_POST) q_driver_post(J, g, writer);
+  }
+
+  wave_sync();
+  if (writer && participated) {
+    regs_save(g.r, S);
+    for (int i = 0; i < 4; ++i) S->dist_cache[i] = g.dc[i];
+    S->dict_lookups = g.dict_lookups;
+    S->dict_matches = g.dict_matches;
+    S->done = g.done;
+    S->mb_valid = g.have_mb;
+    if (g.error) S->error = g.error;
+    if (g.have_mb) {
+      S->mb_start = g.r.last_flush_pos;
+      S->mb_bytes = g.r.input_pos - g.r.last_flush_pos;
+      S->mb_is_last = g.blk_is_last;
+      S->mb_force_flush = g.blk_force_flush;
+      S->mb_raw = 0;
+    }
+    S->stat_searches += g.stat_searches;
+    S->stat_pairs += g.stat_searches;
+  }
+  wave_sync();
+}
+
+#endif  // BROTLI_AMD_CSRC_K_PARSE4_H_

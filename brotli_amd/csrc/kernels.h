@@ -5,6 +5,7 @@
 #define BROTLI_AMD_CSRC_KERNELS_H_
 
 #include "k_round.h"
+#include "k_parse4.h"
 #include "k_build.h"
 #include "k_store.h"
 
@@ -37,6 +38,15 @@ __global__ void __launch_bounds__(64) k_parse(JobArgs a) {
   if (shard >= a.nshards) return;
   parse_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
   if (threadIdx.x == 0 && a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
+}
+
+// grid = ceil(nshards / 4), block = 64: four shards per wave.
+__global__ void __launch_bounds__(64) k_parse4(JobArgs a) {
+  __shared__ uint8_t lds_dup[Q_GROUPS * Q_DUP_SLOTS];
+  parse4_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_dup);
+  const uint32_t shard = blockIdx.x * Q_GROUPS + (threadIdx.x >> 4);
+  if ((threadIdx.x & 15) == 0 && shard < a.nshards && a.states[shard].error)
+    glb_atomic_add(&a.counters[1], 1u);
 }
 
 // grid = nshards, block = 64: block splits, histograms, prefix codes.

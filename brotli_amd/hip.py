@@ -16,7 +16,7 @@ TABLES_PATH = os.path.join(_HERE, "data", "brotli_tables.bin")
 INPUT_SLACK = 64
 
 OK, ERROR, UNSUPPORTED, OVERFLOW, DEVICE_FAULT = 0, -1, -2, -3, -4
-FLAG_NO_PAIR = 1
+FLAG_NO_PAIR, FLAG_NO_QUAD, FLAG_FORCE_SLOW = 1, 2, 4
 
 
 class JobParams(C.Structure):

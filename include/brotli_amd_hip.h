@@ -55,7 +55,9 @@ typedef struct BrotliAmdJobParams {
   int32_t reserved;
 } BrotliAmdJobParams;
 
-#define BROTLI_AMD_FLAG_NO_PAIR 1u   /* debugging: no speculative (p,p+1) search */
+#define BROTLI_AMD_FLAG_NO_PAIR 1u    /* debugging: no speculative (p,p+1) search (k_parse) */
+#define BROTLI_AMD_FLAG_NO_QUAD 2u    /* always one shard per wave (k_parse) */
+#define BROTLI_AMD_FLAG_FORCE_SLOW 4u /* k_parse4: step-by-step candidate resolve */
 
 typedef struct BrotliAmdJobInfo {
   uint64_t nshards;

@@ -33,16 +33,16 @@ class Sim:
         self.L.sim_encode.restype = C.c_long
         self.L.sim_encode.argtypes = [
             C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
-            C.c_size_t, C.c_uint64, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+            C.c_size_t, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
 
     def encode(self, data, quality=5, lgwin=22, size_hint=0, shard_size=0,
-               stream_base=0, is_last=True, reverse=0):
+               stream_base=0, is_last=True, reverse=0, flags=0):
         nsh = 1 if not shard_size else max(1, -(-len(data) // shard_size))
         cap = 2 * len(data) + 2048 * (nsh + 1)
         out = C.create_string_buffer(cap)
         n = self.L.sim_encode(TABLES.encode(), bytes(data), len(data), quality,
                               lgwin, size_hint, shard_size, stream_base,
-                              1 if is_last else 0, reverse, out, cap)
+                              1 if is_last else 0, reverse, flags, out, cap)
         assert n >= 0, n
         return out.raw[:n]
 

@@ -34,7 +34,9 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   if (!host_tables_load(tables_path, &ht)) return -1;
   JobPlan plan;
   if (!plan_job(len, quality, lgwin, size_hint, shard_size, 0, true, &plan)) return -2;
-  if (no_pair) plan.J.flags |= JOB_FLAG_NO_PAIR;
+  if (no_pair & 1) plan.J.flags |= JOB_FLAG_NO_PAIR;
+  if (no_pair & 2) plan.J.flags |= JOB_FLAG_QUAD;
+  if (no_pair & 4) plan.J.flags |= JOB_FLAG_FORCE_SLOW;
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);
   std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
@@ -54,7 +56,8 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   uint32_t counters[16] = {0};
   a.counters = counters;
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
-  run(k_parse, a, a.nshards, 64, reverse);
+  if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
+  else run(k_parse, a, a.nshards, 64, reverse);
   size_t n = 0;
   stats[0] = stats[1] = stats[2] = 0;
   for (size_t k = 0; k < plan.shards.size(); ++k) {
@@ -76,11 +79,12 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
 // Returns the number of bytes or a negative error.
 long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int quality, int lgwin,
                 uint32_t size_hint, size_t shard_size, uint64_t stream_base, int is_last,
-                int reverse, uint8_t* out, size_t out_cap) {
+                int reverse, int flags, uint8_t* out, size_t out_cap) {
   HostTables ht;
   if (!host_tables_load(tables_path, &ht)) return -1;
   JobPlan plan;
   if (!plan_job(len, quality, lgwin, size_hint, shard_size, stream_base, is_last != 0, &plan)) return -2;
+  plan.J.flags |= (uint32_t)flags;
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);
   std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
@@ -102,7 +106,8 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
   for (int round = 0; round < 100000; ++round) {
     memset(counters, 0, sizeof(counters));
-    run(k_parse, a, a.nshards, 64, reverse);
+    if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
+    else run(k_parse, a, a.nshards, 64, reverse);
     run(k_build, a, a.nshards, 64, reverse);
     if (getenv("SIM_DEBUG")) {
       for (size_t k = 0; k < plan.shards.size(); ++k) {

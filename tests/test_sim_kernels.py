@@ -68,6 +68,23 @@ def test_encode_bytes_match_oracle(sim, oracle, name):
     assert sim.encode(data, 5, 22, hint, shard) == _oracle_plan(oracle, data, hint, shard)
 
 
+@pytest.mark.parametrize("flags", [2, 6])
+@pytest.mark.parametrize("name", ["text_hint_2shards", "ragged_shards", "mixed", "text_then_random",
+                                  "zeros", "rle", "tiny3", "shards_of_1_2_3", "alice_48k"])
+def test_quad_kernel_bytes_match_oracle(sim, oracle, name, flags):
+    """Four shards per wave (k_parse4.h): arg-max resolve (flags=2) and the
+    step-by-step resolve (flags=6) both reproduce the oracle."""
+    data, hint, shard = CASES[name]
+    assert sim.encode(data, 5, 22, hint, shard, flags=flags) == _oracle_plan(oracle, data, hint, shard)
+
+
+def test_quad_kernel_many_shards_reverse(sim, oracle):
+    """7 shards over 2 waves (one group idle), lanes scheduled high-to-low."""
+    data = G.enwik_text(70000, seed=13, vocab=3000)
+    assert sim.encode(data, 5, 22, 1 << 30, 10000, reverse=1, flags=2) == \
+        _oracle_plan(oracle, data, 1 << 30, 10000)
+
+
 def test_encode_reverse_lane_order(sim, oracle):
     data = G.enwik_text(30000, seed=9, vocab=4000)
     assert sim.encode(data, 5, 22, 1 << 30, 0, reverse=1) == _oracle_plan(oracle, data, 1 << 30, 0)
