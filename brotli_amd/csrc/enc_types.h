@@ -46,6 +46,7 @@ struct JobParams {
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
 #define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal
 #define JOB_FLAG_FORCE_SLOW 4u // k_parse4: always take the step-by-step candidate resolve
+#define JOB_FLAG_NO_HEADER 8u  // stream header already emitted: shard 0 starts byte aligned
 
 // Per-shard description written by the host.
 struct ShardDesc {

@@ -1,0 +1,442 @@
+/* brotli_amd/csrc/encode_abi.c — host side of the drop-in boundary
+ * (include/brotli_amd_encode.h): the google/brotli encoder C ABI
+ * (c/include/brotli/encode.h, 13 symbols) implemented over the HIP C-ABI layer
+ * (include/brotli_amd_hip.h).  Plain C; built into
+ * brotli_amd/lib/libbrotlienc_amd.so.
+ *
+ * What is re-stated here from c/enc/encode.c is only the *stream protocol*:
+ * parameter latching (encode.c:60-123), the size-hint rule (:1619-1632), the
+ * PROCESS / FLUSH / FINISH state machine and output hand-off (:1393-1423,
+ * :1634-1750), the one-shot wrapper and its raw fallback (:1251-1354).  All
+ * compression work happens on the GPU; unsupported parameters fail with
+ * BROTLI_FALSE (there is no CPU encoder behind this library).
+ */
+#define _GNU_SOURCE
+#include <dlfcn.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/brotli_amd_encode.h"
+#include "../../include/brotli_amd_hip.h"
+
+enum { OP_PROCESS = 0, OP_FLUSH = 1, OP_FINISH = 2, OP_EMIT_METADATA = 3 };
+enum { ST_PROCESSING = 0, ST_FLUSH_REQUESTED = 1, ST_FINISHED = 2 };
+enum {  /* BrotliEncoderParameter, encode.h:160-265 */
+  P_MODE = 0, P_QUALITY = 1, P_LGWIN = 2, P_LGBLOCK = 3, P_DISABLE_CTX = 4, P_SIZE_HINT = 5,
+  P_LARGE_WINDOW = 6, P_NPOSTFIX = 7, P_NDIRECT = 8, P_STREAM_OFFSET = 9, P_BASE64_MODE = 10,
+  P_MAX_BASE64_REGIONS = 11, P_SIMD_HASHER = 12
+};
+
+struct BrotliEncoderStateStruct {
+  brotli_amd_alloc_func alloc;
+  brotli_amd_free_func free_;
+  void* opaque;
+  /* parameters as set by the caller */
+  int mode, quality, lgwin, lgblock, disable_ctx, large_window, base64_mode, simd_hasher;
+  uint32_t size_hint, npostfix, ndirect, stream_offset, max_base64_regions;
+  uint64_t shard_bytes;
+  int device;
+  /* latched at first use */
+  int initialized, failed;
+  uint32_t eff_hint;
+  int hint_fixed;
+  /* input not yet handed to the device */
+  uint8_t* in_buf;
+  size_t in_len, in_cap;
+  uint64_t total_in, submitted;
+  /* produced, not yet taken */
+  uint8_t* out_buf;
+  size_t out_len, out_pos, out_cap;
+  uint64_t total_out;
+  int stream_state;
+  int header_written;   /* plan mode: the stream header left the library */
+  BrotliAmdCtx* ctx;
+  BrotliAmdStream* stream;
+};
+
+static void* st_alloc(BrotliEncoderState* s, size_t n) {
+  return s->alloc ? s->alloc(s->opaque, n) : malloc(n);
+}
+static void st_free(BrotliEncoderState* s, void* p) {
+  if (!p) return;
+  if (s->free_) s->free_(s->opaque, p); else free(p);
+}
+static int grow(BrotliEncoderState* s, uint8_t** buf, size_t* cap, size_t used, size_t need) {
+  uint8_t* n;
+  size_t c = *cap ? *cap : 65536;
+  if (need <= *cap) return 1;
+  while (c < need) c *= 2;
+  n = (uint8_t*)st_alloc(s, c);
+  if (!n) return 0;
+  if (used) memcpy(n, *buf, used);
+  st_free(s, *buf);
+  *buf = n;
+  *cap = c;
+  return 1;
+}
+static int verbose(void) { return getenv("BROTLI_AMD_VERBOSE") != NULL; }
+
+static void tables_path(char* out, size_t cap) {
+  const char* env = getenv("BROTLI_AMD_TABLES");
+  Dl_info info;
+  if (env) { snprintf(out, cap, "%s", env); return; }
+  if (dladdr((void*)&tables_path, &info) && info.dli_fname) {
+    char dir[4096];
+    char* slash;
+    snprintf(dir, sizeof(dir), "%s", info.dli_fname);
+    slash = strrchr(dir, '/');
+    if (slash) *slash = 0; else snprintf(dir, sizeof(dir), ".");
+    snprintf(out, cap, "%s/../data/brotli_tables.bin", dir);
+    return;
+  }
+  snprintf(out, cap, "brotli_tables.bin");
+}
+
+BrotliEncoderState* BrotliEncoderCreateInstance(brotli_amd_alloc_func alloc_func,
+                                                brotli_amd_free_func free_func, void* opaque) {
+  BrotliEncoderState* s;
+  const char* e;
+  if ((alloc_func == NULL) != (free_func == NULL)) return NULL;   /* encode.h:295-299 */
+  s = (BrotliEncoderState*)(alloc_func ? alloc_func(opaque, sizeof(*s)) : malloc(sizeof(*s)));
+  if (!s) return NULL;
+  memset(s, 0, sizeof(*s));
+  s->alloc = alloc_func;
+  s->free_ = free_func;
+  s->opaque = opaque;
+  s->quality = 11;   /* BROTLI_DEFAULT_QUALITY */
+  s->lgwin = 22;     /* BROTLI_DEFAULT_WINDOW */
+  s->max_base64_regions = 16;
+  e = getenv("BROTLI_AMD_SHARD_KB");
+  if (e) s->shard_bytes = strtoull(e, NULL, 10) << 10;
+  e = getenv("BROTLI_AMD_DEVICE");
+  if (e) s->device = atoi(e);
+  return s;
+}
+
+void BrotliEncoderDestroyInstance(BrotliEncoderState* s) {
+  if (!s) return;
+  if (s->stream) brotli_amd_stream_destroy(s->stream);
+  if (s->ctx) brotli_amd_ctx_destroy(s->ctx);
+  st_free(s, s->in_buf);
+  st_free(s, s->out_buf);
+  st_free(s, s);
+}
+
+BROTLI_BOOL BrotliEncoderSetParameter(BrotliEncoderState* s, int p, uint32_t value) {
+  if (s->initialized) return BROTLI_FALSE;   /* encode.c:63 */
+  switch ((uint32_t)p) {
+    case P_MODE: s->mode = (int)value; return BROTLI_TRUE;
+    case P_QUALITY: s->quality = (int)value; return BROTLI_TRUE;
+    case P_LGWIN: s->lgwin = (int)value; return BROTLI_TRUE;
+    case P_LGBLOCK: s->lgblock = (int)value; return BROTLI_TRUE;
+    case P_DISABLE_CTX:
+      if (value != 0 && value != 1) return BROTLI_FALSE;
+      s->disable_ctx = (int)value;
+      return BROTLI_TRUE;
+    case P_SIZE_HINT: s->size_hint = value; return BROTLI_TRUE;
+    case P_LARGE_WINDOW: s->large_window = value != 0; return BROTLI_TRUE;
+    case P_NPOSTFIX: s->npostfix = value; return BROTLI_TRUE;
+    case P_NDIRECT: s->ndirect = value; return BROTLI_TRUE;
+    case P_STREAM_OFFSET:
+      if (value > (1u << 30)) return BROTLI_FALSE;
+      s->stream_offset = value;
+      return BROTLI_TRUE;
+    case P_BASE64_MODE: s->base64_mode = (int)(value & 1); return BROTLI_TRUE;
+    case P_MAX_BASE64_REGIONS: s->max_base64_regions = value; return BROTLI_TRUE;
+    case P_SIMD_HASHER:
+      if (value > 2) return BROTLI_FALSE;
+      s->simd_hasher = (int)value;
+      return BROTLI_TRUE;
+    case BROTLI_AMD_PARAM_SHARD_BYTES: s->shard_bytes = value; return BROTLI_TRUE;
+    default: return BROTLI_FALSE;   /* encode.c:121 */
+  }
+}
+
+static int ensure_initialized(BrotliEncoderState* s) {
+  char path[4200];
+  if (s->initialized) return !s->failed;
+  s->initialized = 1;
+  /* SanitizeParams, c/enc/quality.h:59-73 */
+  if (s->quality < 0) s->quality = 0;
+  if (s->quality > 11) s->quality = 11;
+  if (s->lgwin < 10) s->lgwin = 10;
+  if (s->lgwin > 24 && !s->large_window) s->lgwin = 24;
+  /* What the kernels implement: quality 5, H68 / H58, default
+     block size, default distance parameters, no base64 regions, literal
+     context modelling on, the x86-64 default hashers. */
+  if (s->quality != 5 || s->lgwin < 17 || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
+      s->mode == 2 /* FONT: non-zero distance parameters, encode.c:616-640 */ ||
+      s->npostfix != 0 || s->ndirect != 0 || s->base64_mode != 0 || s->disable_ctx != 0 ||
+      s->simd_hasher == 1 /* BROTLI_SIMD_HASHER_NONE: H5 / H6 */) {
+    s->failed = 1;
+    if (verbose())
+      fprintf(stderr, "brotli_amd: parameters outside the GPU path (quality %d, lgwin %d); "
+                      "no CPU fallback exists\n", s->quality, s->lgwin);
+    return 0;
+  }
+  tables_path(path, sizeof(path));
+  if (brotli_amd_ctx_create(s->device, path, &s->ctx) != BROTLI_AMD_OK) {
+    s->failed = 1;
+    if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+    return 0;
+  }
+  if (s->size_hint != 0) { s->eff_hint = s->size_hint; s->hint_fixed = 1; }
+  return 1;
+}
+
+/* EncodeWindowBits, encode.c:191-211 (no large window). */
+static void window_bits(int lgwin, uint32_t* bits, uint32_t* nbits) {
+  if (lgwin == 16) { *bits = 0; *nbits = 1; }
+  else if (lgwin == 17) { *bits = 1; *nbits = 7; }
+  else if (lgwin > 17) { *bits = (uint32_t)(((lgwin - 17) << 1) | 1); *nbits = 4; }
+  else { *bits = (uint32_t)(((lgwin - 8) << 4) | 1); *nbits = 7; }
+}
+
+static int out_append(BrotliEncoderState* s, const uint8_t* p, size_t n) {
+  if (s->out_pos == s->out_len) s->out_pos = s->out_len = 0;
+  if (!grow(s, &s->out_buf, &s->out_cap, s->out_len, s->out_len + n)) return 0;
+  memcpy(s->out_buf + s->out_len, p, n);
+  s->out_len += n;
+  return 1;
+}
+
+/* Hands everything buffered to the device and applies `op` (1 flush, 2 finish). */
+static int submit(BrotliEncoderState* s, int op) {
+  if (s->shard_bytes == 0) {
+    /* One encoder instance: the persistent device stream reproduces the
+       reference for any op sequence. */
+    const uint8_t* out;
+    uint64_t out_len;
+    if (!s->stream) {
+      if (brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
+                                   &s->stream) != BROTLI_AMD_OK) {
+        if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+        return 0;
+      }
+    }
+    if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, op, &out, &out_len) != BROTLI_AMD_OK) {
+      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      return 0;
+    }
+    s->submitted += s->in_len;
+    s->in_len = 0;
+    s->header_written = 1;
+    return out_append(s, out, (size_t)out_len);
+  }
+  /* Partition plan: the buffered bytes become ceil(n / shard) independent
+     shards that start at stream offset stream_offset + submitted. */
+  if (s->in_len == 0) {
+    if (!s->header_written) {
+      /* Nothing was ever encoded: the header bits are still pending
+         (encode.c:1356-1415 for FLUSH, :1004-1014 for FINISH). */
+      uint32_t bits, nbits, v;
+      uint8_t b[2];
+      if (s->stream_offset != 0) {
+        if (op == OP_FINISH) { b[0] = 3; return out_append(s, b, 1); }
+        return 1;
+      }
+      window_bits(s->lgwin, &bits, &nbits);
+      if (op == OP_FINISH) { v = bits | (3u << nbits); nbits += 2; }
+      else { v = bits | (6u << nbits); nbits += 6; s->header_written = 2; /* header gone, no data yet */ }
+      b[0] = (uint8_t)v;
+      b[1] = (uint8_t)(v >> 8);
+      if (op == OP_FINISH) s->header_written = 1;
+      return out_append(s, b, (nbits + 7) >> 3);
+    }
+    if (op == OP_FINISH) { uint8_t b = 3; return out_append(s, &b, 1); }   /* ISLAST + ISEMPTY */
+    return 1;   /* every job ends byte aligned: an empty flush adds nothing */
+  }
+  {
+    BrotliAmdJobParams p;
+    BrotliAmdJobInfo info;
+    uint64_t cap, n = 0;
+    memset(&p, 0, sizeof(p));
+    p.quality = s->quality;
+    p.lgwin = s->lgwin;
+    p.size_hint = s->eff_hint;
+    p.shard_size = s->shard_bytes;
+    p.stream_base = (uint64_t)s->stream_offset + s->submitted;
+    p.is_last = op == OP_FINISH;
+    if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
+    cap = brotli_amd_max_output(s->in_len, &p);
+    if (cap == 0) return 0;
+    if (s->out_pos == s->out_len) s->out_pos = s->out_len = 0;
+    if (!grow(s, &s->out_buf, &s->out_cap, s->out_len, s->out_len + cap)) return 0;
+    if (brotli_amd_encode_host(s->ctx, s->in_buf, s->in_len, &p, s->out_buf + s->out_len, cap, &n,
+                               &info) != BROTLI_AMD_OK) {
+      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      return 0;
+    }
+    s->out_len += (size_t)n;
+    s->submitted += s->in_len;
+    s->in_len = 0;
+    s->header_written = 1;
+  }
+  return 1;
+}
+
+static void push_output(BrotliEncoderState* s, size_t* available_out, uint8_t** next_out,
+                        size_t* total_out) {
+  size_t n = s->out_len - s->out_pos;
+  if (available_out && *available_out < n) n = *available_out;
+  if (!available_out) n = 0;
+  if (n) {
+    memcpy(*next_out, s->out_buf + s->out_pos, n);
+    *next_out += n;
+    *available_out -= n;
+    s->out_pos += n;
+    s->total_out += n;
+  }
+  if (total_out) *total_out = (size_t)s->total_out;
+  /* CheckFlushComplete, encode.c:1417-1423 */
+  if (s->stream_state == ST_FLUSH_REQUESTED && s->out_pos == s->out_len) s->stream_state = ST_PROCESSING;
+}
+
+BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* available_in,
+                                        const uint8_t** next_in, size_t* available_out,
+                                        uint8_t** next_out, size_t* total_out) {
+  if (!ensure_initialized(s)) return BROTLI_FALSE;
+  if (op == OP_EMIT_METADATA) {
+    /* Metadata blocks share the partial last byte of the previous meta-block
+       (encode.c:1223-1249); that hand-off is not implemented on the device. */
+    if (verbose()) fprintf(stderr, "brotli_amd: BROTLI_OPERATION_EMIT_METADATA is not supported\n");
+    return BROTLI_FALSE;
+  }
+  if (op < 0 || op > 2) return BROTLI_FALSE;
+  if (s->stream_state != ST_PROCESSING && *available_in != 0) return BROTLI_FALSE;   /* encode.c:1657 */
+  if (s->stream_state == ST_PROCESSING) {
+    const size_t a = *available_in;
+    /* UpdateSizeHint at the reference's first EncodeData (encode.c:1619-1632):
+       when the first input block fills, or at the first op other than PROCESS. */
+    if (!s->hint_fixed) {
+      const uint64_t threshold = s->stream_offset ? 2u : 65536u;   /* flint, lgblock 16 */
+      const uint64_t seen = s->total_in + a;
+      if (seen >= threshold || op != OP_PROCESS) {
+        s->eff_hint = seen >= (1u << 30) ? (1u << 30) : (uint32_t)seen;
+        s->hint_fixed = 1;
+      }
+    }
+    if (a) {
+      if (!grow(s, &s->in_buf, &s->in_cap, s->in_len, s->in_len + a)) return BROTLI_FALSE;
+      memcpy(s->in_buf + s->in_len, *next_in, a);
+      s->in_len += a;
+      s->total_in += a;
+      *next_in += a;
+      *available_in = 0;
+    }
+    if (op != OP_PROCESS) {
+      if (!submit(s, op)) { s->failed = 1; return BROTLI_FALSE; }
+      s->stream_state = op == OP_FINISH ? ST_FINISHED : ST_FLUSH_REQUESTED;
+    }
+  }
+  push_output(s, available_out, next_out, total_out);
+  return BROTLI_TRUE;
+}
+
+BROTLI_BOOL BrotliEncoderIsFinished(BrotliEncoderState* s) {
+  return s->stream_state == ST_FINISHED && s->out_pos == s->out_len;
+}
+
+BROTLI_BOOL BrotliEncoderHasMoreOutput(BrotliEncoderState* s) { return s->out_pos != s->out_len; }
+
+const uint8_t* BrotliEncoderTakeOutput(BrotliEncoderState* s, size_t* size) {
+  size_t n = s->out_len - s->out_pos;
+  const uint8_t* p = s->out_buf + s->out_pos;
+  if (*size && *size < n) n = *size;
+  if (n == 0) { *size = 0; return NULL; }
+  s->out_pos += n;
+  s->total_out += n;
+  if (s->stream_state == ST_FLUSH_REQUESTED && s->out_pos == s->out_len) s->stream_state = ST_PROCESSING;
+  *size = n;
+  return p;
+}
+
+size_t BrotliEncoderMaxCompressedSize(size_t input_size) {
+  /* encode.c:1251-1258 */
+  size_t num_large_blocks = input_size >> 14;
+  size_t overhead = 2 + (4 * num_large_blocks) + 3 + 1;
+  size_t result = input_size + overhead;
+  if (input_size == 0) return 2;
+  return (result < input_size) ? 0 : result;
+}
+
+/* encode.c:1264-1294 */
+static size_t make_uncompressed_stream(const uint8_t* input, size_t input_size, uint8_t* output) {
+  size_t size = input_size, result = 0, offset = 0;
+  if (input_size == 0) { output[0] = 6; return 1; }
+  output[result++] = 0x21;
+  output[result++] = 0x03;
+  while (size > 0) {
+    uint32_t nibbles = 0, chunk_size, bits;
+    chunk_size = (size > (1u << 24)) ? (1u << 24) : (uint32_t)size;
+    if (chunk_size > (1u << 16)) nibbles = (chunk_size > (1u << 20)) ? 2 : 1;
+    bits = (nibbles << 1) | ((chunk_size - 1) << 3) | (1u << (19 + 4 * nibbles));
+    output[result++] = (uint8_t)bits;
+    output[result++] = (uint8_t)(bits >> 8);
+    output[result++] = (uint8_t)(bits >> 16);
+    if (nibbles == 2) output[result++] = (uint8_t)(bits >> 24);
+    memcpy(&output[result], &input[offset], chunk_size);
+    result += chunk_size;
+    offset += chunk_size;
+    size -= chunk_size;
+  }
+  output[result++] = 3;
+  return result;
+}
+
+BROTLI_BOOL BrotliEncoderCompress(int quality, int lgwin, int mode, size_t input_size,
+                                  const uint8_t* input_buffer, size_t* encoded_size,
+                                  uint8_t* encoded_buffer) {
+  BrotliEncoderState* s;
+  const size_t out_size = *encoded_size;
+  const size_t max_out_size = BrotliEncoderMaxCompressedSize(input_size);
+  if (out_size == 0) return BROTLI_FALSE;
+  if (input_size == 0) { *encoded_size = 1; *encoded_buffer = 6; return BROTLI_TRUE; }
+  s = BrotliEncoderCreateInstance(0, 0, 0);
+  if (!s) return BROTLI_FALSE;
+  {
+    size_t available_in = input_size, available_out = *encoded_size, total_out = 0;
+    const uint8_t* next_in = input_buffer;
+    uint8_t* next_out = encoded_buffer;
+    BROTLI_BOOL result, unsupported;
+    BrotliEncoderSetParameter(s, P_QUALITY, (uint32_t)quality);
+    BrotliEncoderSetParameter(s, P_LGWIN, (uint32_t)lgwin);
+    BrotliEncoderSetParameter(s, P_MODE, (uint32_t)mode);
+    BrotliEncoderSetParameter(s, P_SIZE_HINT, (uint32_t)input_size);
+    if (lgwin > 24) BrotliEncoderSetParameter(s, P_LARGE_WINDOW, 1);
+    result = BrotliEncoderCompressStream(s, OP_FINISH, &available_in, &next_in, &available_out,
+                                         &next_out, &total_out);
+    unsupported = s->failed;
+    if (!BrotliEncoderIsFinished(s)) result = 0;
+    *encoded_size = total_out;
+    BrotliEncoderDestroyInstance(s);
+    if (unsupported) { *encoded_size = 0; return BROTLI_FALSE; }   /* fail loudly, no raw stream */
+    if (result && !(max_out_size && *encoded_size > max_out_size)) return BROTLI_TRUE;
+  }
+  /* The compressed stream does not fit: store raw (encode.c:1345-1353). */
+  *encoded_size = 0;
+  if (!max_out_size) return BROTLI_FALSE;
+  if (out_size >= max_out_size) {
+    *encoded_size = make_uncompressed_stream(input_buffer, input_size, encoded_buffer);
+    return BROTLI_TRUE;
+  }
+  return BROTLI_FALSE;
+}
+
+uint32_t BrotliEncoderVersion(void) { return 0x1002000; }   /* 1.2.0, c/common/version.h */
+
+BrotliEncoderPreparedDictionary* BrotliEncoderPrepareDictionary(
+    int type, size_t data_size, const uint8_t* data, int quality,
+    brotli_amd_alloc_func alloc_func, brotli_amd_free_func free_func, void* opaque) {
+  (void)type; (void)data_size; (void)data; (void)quality; (void)alloc_func; (void)free_func; (void)opaque;
+  return NULL;
+}
+void BrotliEncoderDestroyPreparedDictionary(BrotliEncoderPreparedDictionary* dictionary) {
+  (void)dictionary;
+}
+BROTLI_BOOL BrotliEncoderAttachPreparedDictionary(BrotliEncoderState* state,
+                                                  const BrotliEncoderPreparedDictionary* dictionary) {
+  (void)state; (void)dictionary;
+  return BROTLI_FALSE;
+}

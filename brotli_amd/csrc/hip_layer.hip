@@ -116,10 +116,6 @@ bool ensure_ws(BrotliAmdCtx* c, uint64_t ws_bytes, uint64_t nshards) {
 
 int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, JobPlan* plan) {
   if (len == 0) { fail(c, "empty job"); return BROTLI_AMD_UNSUPPORTED; }
-  if (p->shard_size && p->stream_base % p->shard_size) {
-    fail(c, "stream_base must be a multiple of shard_size");
-    return BROTLI_AMD_UNSUPPORTED;
-  }
   if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
                 p->is_last != 0, plan)) {
     fail(c, "parameters outside the GPU path (quality %d lgwin %d)", p->quality, p->lgwin);
@@ -127,6 +123,7 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
   }
   if (p->flags & BROTLI_AMD_FLAG_NO_PAIR) plan->J.flags |= JOB_FLAG_NO_PAIR;
   if (p->flags & BROTLI_AMD_FLAG_FORCE_SLOW) plan->J.flags |= JOB_FLAG_FORCE_SLOW;
+  if (p->flags & BROTLI_AMD_FLAG_NO_HEADER) plan->J.flags |= JOB_FLAG_NO_HEADER;
   // Four shards per wave (k_parse4.h) whenever no shard can wrap the ring or
   // see a candidate beyond the window.
   uint64_t longest = 0;
@@ -359,6 +356,182 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
     return BROTLI_AMD_ERROR;
   }
   return BROTLI_AMD_OK;
+}
+
+// ---- incremental single-shard stream ------------------------------------------------
+}  // extern "C"
+
+struct BrotliAmdStream {
+  BrotliAmdCtx* c = nullptr;
+  JobParams J;
+  ShardDesc D;
+  uint8_t* d_in = nullptr;
+  uint64_t in_cap = 0;
+  uint8_t* d_ws = nullptr;
+  uint8_t* d_out = nullptr;
+  uint64_t out_cap = 0;
+  ShardDesc* d_desc = nullptr;
+  ShardState* d_state = nullptr;
+  uint32_t* d_counters = nullptr;
+  uint64_t fed = 0;
+  bool finished = false;
+  std::vector<uint8_t> host_out;
+};
+
+namespace {
+bool stream_init(BrotliAmdStream* s, uint32_t stream_offset) {
+  BrotliAmdCtx* c = s->c;
+  const JobParams& J = s->J;
+  const uint64_t mb = J.max_metablock_size;
+  if (!ensure_log2(c, (uint32_t)(mb + 2))) return false;
+  ShardDesc& D = s->D;
+  memset(&D, 0, sizeof(D));
+  uint64_t so = stream_offset;
+  if (so > (1u << 30)) so = 1u << 30;
+  if (so > J.max_backward_limit) so = J.max_backward_limit;
+  D.stream_offset = (uint32_t)so;
+  D.cmd_cap = (uint32_t)(mb / 2 + (mb >> J.lgblock) + 64);
+  uint64_t off = 0;
+  D.table_off = off; off = plan_align(off + ((uint64_t)REC_BYTES << J.bucket_bits));
+  D.cmds_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * sizeof(Command));
+  D.lits_off = off;  off = plan_align(off + (mb + 8) * 2);
+  D.dsym_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * 2);
+  D.mb_off = off;    off = plan_align(off + mb_work_bytes(mb));
+  D.scratch_off = off; off = plan_align(off + ((uint64_t)D.cmd_cap + mb + 64) * 4);
+  HIP_OK(c, hipMalloc((void**)&s->d_ws, off));
+  HIP_OK(c, hipMalloc((void**)&s->d_desc, sizeof(ShardDesc)));
+  HIP_OK(c, hipMalloc((void**)&s->d_state, sizeof(ShardState)));
+  HIP_OK(c, hipMalloc((void**)&s->d_counters, 16 * sizeof(uint32_t)));
+  HIP_OK(c, hipMemcpyAsync(s->d_desc, &D, sizeof(D), hipMemcpyHostToDevice, c->stream));
+  JobArgs a;
+  a.J = J;
+  a.shards = s->d_desc;
+  a.states = s->d_state;
+  a.T = c->d_T;
+  a.input = nullptr;
+  a.ws = s->d_ws;
+  a.nshards = 1;
+  a.init_blocks_per_shard = 64;
+  a.counters = s->d_counters;
+  hipLaunchKernelGGL(k_init, dim3(64), dim3(256), 0, c->stream, a);
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  HIP_OK(c, hipGetLastError());
+  return true;
+}
+
+bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
+  BrotliAmdCtx* c = s->c;
+  const JobParams& J = s->J;
+  if (s->fed + len >= (3ull << 30)) return fail(c, "stream longer than 3 GiB is not supported");
+  // input: the whole stream stays resident (positions are stream offsets)
+  const uint64_t need_in = s->fed + len + BROTLI_AMD_INPUT_SLACK;
+  if (need_in > s->in_cap) {
+    uint64_t cap = s->in_cap ? s->in_cap * 2 : (1u << 20);
+    while (cap < need_in) cap *= 2;
+    uint8_t* n = nullptr;
+    HIP_OK(c, hipMalloc((void**)&n, cap));
+    if (s->d_in) {
+      HIP_OK(c, hipMemcpyAsync(n, s->d_in, s->fed, hipMemcpyDeviceToDevice, c->stream));
+      HIP_OK(c, hipStreamSynchronize(c->stream));
+      HIP_OK(c, hipFree(s->d_in));
+    }
+    s->d_in = n;
+    s->in_cap = cap;
+  }
+  if (len) HIP_OK(c, hipMemcpyAsync(s->d_in + s->fed, data, len, hipMemcpyHostToDevice, c->stream));
+  HIP_OK(c, hipMemsetAsync(s->d_in + s->fed + len, 0, BROTLI_AMD_INPUT_SLACK, c->stream));
+  s->fed += len;
+  // output of this call: everything not yet emitted can come out at once
+  const uint64_t need_out = 2 * (len + (uint64_t)J.max_metablock_size + (2ull << J.lgblock)) + 8192;
+  if (need_out > s->out_cap) {
+    if (s->d_out) HIP_OK(c, hipFree(s->d_out));
+    s->d_out = nullptr;
+    HIP_OK(c, hipMalloc((void**)&s->d_out, need_out));
+    s->out_cap = need_out;
+  }
+  ShardDesc& D = s->D;
+  D.in_off = 0;
+  D.len = (uint32_t)s->fed;
+  D.final_op = (uint32_t)op;
+  D.out_off = (uint64_t)(s->d_out - s->d_ws);   // ws + out_off == d_out (mod 2^64)
+  D.out_cap = s->out_cap;
+  HIP_OK(c, hipMemcpyAsync(s->d_desc, &D, sizeof(D), hipMemcpyHostToDevice, c->stream));
+  const uint32_t zero32 = 0;
+  const uint64_t zero64 = 0;
+  HIP_OK(c, hipMemcpyAsync(&s->d_state->done, &zero32, 4, hipMemcpyHostToDevice, c->stream));
+  HIP_OK(c, hipMemcpyAsync(&s->d_state->out_bytes, &zero64, 8, hipMemcpyHostToDevice, c->stream));
+  JobArgs a;
+  a.J = J;
+  a.shards = s->d_desc;
+  a.states = s->d_state;
+  a.T = c->d_T;
+  a.input = s->d_in;
+  a.ws = s->d_ws;
+  a.nshards = 1;
+  a.init_blocks_per_shard = 1;
+  a.counters = s->d_counters;
+  for (;;) {
+    HIP_OK(c, hipMemsetAsync(s->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(k_parse, dim3(1), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_build, dim3(1), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_store, dim3(1), dim3(64), 0, c->stream, a);
+    uint32_t counters[16];
+    HIP_OK(c, hipMemcpyAsync(counters, s->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipGetLastError());
+    if (counters[1]) return fail(c, "stream shard reported a device fault");
+    if (counters[0] == 0) break;
+  }
+  ShardState st;
+  HIP_OK(c, hipMemcpy(&st, s->d_state, sizeof(st), hipMemcpyDeviceToHost));
+  if (st.error) return fail(c, "stream shard error %u", st.error);
+  s->host_out.resize(st.out_bytes);
+  if (st.out_bytes) HIP_OK(c, hipMemcpy(s->host_out.data(), s->d_out, st.out_bytes, hipMemcpyDeviceToHost));
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t size_hint,
+                             uint32_t stream_offset, BrotliAmdStream** out) {
+  *out = nullptr;
+  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  BrotliAmdStream* s = new BrotliAmdStream();
+  s->c = c;
+  if (!plan_params(quality, lgwin, size_hint, &s->J)) {
+    delete s;
+    fail(c, "parameters outside the GPU path (quality %d lgwin %d)", quality, lgwin);
+    return BROTLI_AMD_UNSUPPORTED;
+  }
+  s->J.log2_lut_size = s->J.max_metablock_size + 2;
+  if (!stream_init(s, stream_offset)) { brotli_amd_stream_destroy(s); return BROTLI_AMD_ERROR; }
+  *out = s;
+  return BROTLI_AMD_OK;
+}
+
+int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op,
+                            const uint8_t** out, uint64_t* out_len) {
+  *out = nullptr;
+  *out_len = 0;
+  BrotliAmdCtx* c = s->c;
+  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  if (s->finished) { fail(c, "stream already finished"); return BROTLI_AMD_ERROR; }
+  if (op < 0 || op > 2) { fail(c, "bad stream op"); return BROTLI_AMD_UNSUPPORTED; }
+  if (!stream_run(s, data, len, op)) return BROTLI_AMD_ERROR;
+  if (op == BROTLI_AMD_OP_FINISH) s->finished = true;
+  *out = s->host_out.data();
+  *out_len = s->host_out.size();
+  return BROTLI_AMD_OK;
+}
+
+void brotli_amd_stream_destroy(BrotliAmdStream* s) {
+  if (!s) return;
+  (void)hipSetDevice(s->c->device);
+  (void)hipStreamSynchronize(s->c->stream);
+  void* ptrs[] = {s->d_in, s->d_ws, s->d_out, s->d_desc, s->d_state, s->d_counters};
+  for (void* p : ptrs) if (p) (void)hipFree(p);
+  delete s;
 }
 
 int brotli_amd_debug_parse(BrotliAmdCtx* c, const void* d_in, uint64_t len,

@@ -375,6 +375,7 @@ DEV void q_driver_pre(const JobParams& J, QShard& g) {
       if (r.flint > 0) r.flint -= (int32_t)n;
       continue;
     }
+    if (remaining != 0 && avail == 0 && g.final_op == 0) { g.done = 1; g.state = Q_DONE; return; }
     bool is_last = avail == 0 && g.final_op == 2;
     bool force_flush = avail == 0 && g.final_op == 1;
     if (!is_last && r.flint == 0) { r.flint = -1; force_flush = true; }

@@ -157,6 +157,9 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
       if (r.flint > 0) r.flint -= (int32_t)n;
       continue;
     }
+    // BROTLI_OPERATION_PROCESS with a partly filled block: wait for more input
+    // (encode.c:1700: EncodeData only when the block is full or op != PROCESS).
+    if (remaining != 0 && avail == 0 && D.final_op == 0) { done = true; break; }
     bool is_last = avail == 0 && D.final_op == 2;
     bool force_flush = avail == 0 && D.final_op == 1;
     if (!is_last && r.flint == 0) { r.flint = -1; force_flush = true; }
@@ -267,7 +270,8 @@ DEV void init_shard_state(const JobParams& J, const ShardDesc& D, ShardState* S)
     s.dist_cache[0] = 4; s.dist_cache[1] = 11; s.dist_cache[2] = 15; s.dist_cache[3] = 16;
     for (int i = 0; i < 4; ++i) s.saved_dist_cache[i] = s.dist_cache[i];
     // EncodeWindowBits, encode.c:191-211 (lgwin 17..24, no large window)
-    if (J.lgwin == 17) { s.last_bytes = 1; s.last_bytes_bits = 7; }
+    if (J.flags & JOB_FLAG_NO_HEADER) { s.last_bytes = 0; s.last_bytes_bits = 0; }
+    else if (J.lgwin == 17) { s.last_bytes = 1; s.last_bytes_bits = 7; }
     else { s.last_bytes = (uint32_t)(((J.lgwin - 17) << 1) | 1); s.last_bytes_bits = 4; }
   }
   *S = s;

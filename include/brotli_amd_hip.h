@@ -47,9 +47,9 @@ typedef struct BrotliAmdJobParams {
   uint32_t flags;        /* BROTLI_AMD_FLAG_* */
   uint64_t shard_size;   /* partition plan: bytes per encoder shard; 0 = one
                             shard (== BrotliEncoderCompress on the buffer) */
-  uint64_t stream_base;  /* offset of this buffer inside the whole stream; it
-                            must be a multiple of shard_size (multi-GPU: rank r
-                            passes the offset of its first shard) */
+  uint64_t stream_base;  /* offset of this buffer inside the whole stream
+                            (multi-GPU: rank r passes the offset of its first
+                            shard); shard k starts at stream_base + k * shard_size */
   int32_t is_last;       /* 1: the buffer ends the stream (last shard FINISHes);
                             0: every shard ends with FLUSH */
   int32_t reserved;
@@ -58,6 +58,9 @@ typedef struct BrotliAmdJobParams {
 #define BROTLI_AMD_FLAG_NO_PAIR 1u    /* debugging: no speculative (p,p+1) search (k_parse) */
 #define BROTLI_AMD_FLAG_NO_QUAD 2u    /* always one shard per wave (k_parse) */
 #define BROTLI_AMD_FLAG_FORCE_SLOW 4u /* k_parse4: step-by-step candidate resolve */
+#define BROTLI_AMD_FLAG_NO_HEADER 8u  /* the stream header (window bits) has already been
+                                         written by the caller (empty FLUSH at stream start,
+                                         encode.c:1356-1415): the first shard starts byte aligned */
 
 typedef struct BrotliAmdJobInfo {
   uint64_t nshards;
@@ -96,6 +99,24 @@ int brotli_amd_encode_host(BrotliAmdCtx* ctx, const uint8_t* in, uint64_t len,
                            const BrotliAmdJobParams* p, uint8_t* out,
                            uint64_t out_cap, uint64_t* out_size,
                            BrotliAmdJobInfo* info);
+
+/* ---- one encoder instance fed incrementally (BrotliEncoderCompressStream) ----
+   A stream is ONE shard whose state (hash table, ring positions, distance
+   cache, partial last byte) stays on the device between calls, so any sequence
+   of PROCESS / FLUSH / FINISH operations yields the reference's bytes
+   (c/enc/encode.c:1634-1722).  `stream_offset` as BROTLI_PARAM_STREAM_OFFSET. */
+typedef struct BrotliAmdStream BrotliAmdStream;
+#define BROTLI_AMD_OP_PROCESS 0
+#define BROTLI_AMD_OP_FLUSH 1
+#define BROTLI_AMD_OP_FINISH 2
+int brotli_amd_stream_create(BrotliAmdCtx* ctx, int quality, int lgwin, uint32_t size_hint,
+                             uint32_t stream_offset, BrotliAmdStream** stream);
+/* Appends `len` host bytes and applies `op`.  `*out` / `*out_len` receive the
+   bytes produced by this call; the pointer stays valid until the next call on
+   the stream. */
+int brotli_amd_stream_write(BrotliAmdStream* stream, const uint8_t* data, uint64_t len, int op,
+                            const uint8_t** out, uint64_t* out_len);
+void brotli_amd_stream_destroy(BrotliAmdStream* stream);
 
 /* Parity tap used by tests/: runs table init + the LZ77 parse only and copies
    the command list of the first meta-block of every shard (16-byte records,

@@ -1,0 +1,182 @@
+"""The drop-in boundary on the GPU: the reference's own call sequences driven
+through libbrotlienc_amd.so and through the reference library give the same
+bytes (same helper, two libraries); the reference CLI linked against our
+library compresses alice29.txt to the known answer."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+import gen_inputs as G
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIBDIR = os.path.join(ROOT, "brotli_amd", "lib")
+ALICE = open(os.path.join(ROOT, "tests", "golden", "alice29.txt"), "rb").read()
+ALICE_SHA = "b4bf4f4f62af5e94769b822b0f24e4edebdb95477e001b4886eb02f2043834f3"
+
+
+def _bind(path):
+    L = C.CDLL(path)
+    L.BrotliEncoderCreateInstance.restype = C.c_void_p
+    L.BrotliEncoderCreateInstance.argtypes = [C.c_void_p] * 3
+    L.BrotliEncoderDestroyInstance.argtypes = [C.c_void_p]
+    L.BrotliEncoderSetParameter.argtypes = [C.c_void_p, C.c_int, C.c_uint32]
+    L.BrotliEncoderCompressStream.argtypes = [
+        C.c_void_p, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+        C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    L.BrotliEncoderIsFinished.argtypes = [C.c_void_p]
+    L.BrotliEncoderHasMoreOutput.argtypes = [C.c_void_p]
+    L.BrotliEncoderTakeOutput.restype = C.c_void_p
+    L.BrotliEncoderTakeOutput.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    L.BrotliEncoderCompress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_char_p,
+                                        C.POINTER(C.c_size_t), C.c_char_p]
+    L.BrotliEncoderMaxCompressedSize.restype = C.c_size_t
+    L.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
+    return L
+
+
+@pytest.fixture(scope="module")
+def amd():
+    return _bind(os.path.join(LIBDIR, "libbrotlienc_amd.so"))
+
+
+@pytest.fixture(scope="module")
+def stock(ref):
+    return _bind(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
+
+
+def drive(L, data, ops, params=(), out_chunk=1 << 16, take=False):
+    """ops: list of (nbytes, op).  Returns all output bytes."""
+    st = L.BrotliEncoderCreateInstance(None, None, None)
+    for k, v in ((1, 5), (2, 22)) + tuple(params):
+        assert L.BrotliEncoderSetParameter(st, k, v)
+    buf = C.create_string_buffer(bytes(data), len(data))
+    out = C.create_string_buffer(out_chunk)
+    res = bytearray()
+    off = 0
+    for n, op in ops:
+        avail_in = C.c_size_t(n)
+        next_in = C.c_void_p(C.addressof(buf) + off)
+        off += n
+        while True:
+            if take:
+                avail_out = C.c_size_t(0)
+                next_out = C.c_void_p(0)
+            else:
+                avail_out = C.c_size_t(out_chunk)
+                next_out = C.c_void_p(C.addressof(out))
+            assert L.BrotliEncoderCompressStream(st, op, C.byref(avail_in), C.byref(next_in),
+                                                 C.byref(avail_out), C.byref(next_out), None)
+            if take:
+                while True:
+                    sz = C.c_size_t(0)
+                    p = L.BrotliEncoderTakeOutput(st, C.byref(sz))
+                    if not sz.value:
+                        break
+                    res += C.string_at(p, sz.value)
+            else:
+                res += out.raw[:out_chunk - avail_out.value]
+            if avail_in.value == 0 and not L.BrotliEncoderHasMoreOutput(st):
+                break
+    fin = bool(L.BrotliEncoderIsFinished(st))
+    L.BrotliEncoderDestroyInstance(st)
+    return bytes(res), fin
+
+
+def _chunks(n, size, last_op, flush_every=0):
+    ops, off, i = [], 0, 0
+    while off < n:
+        m = min(size, n - off)
+        off += m
+        i += 1
+        op = last_op if off == n else (1 if flush_every and i % flush_every == 0 else 0)
+        ops.append((m, op))
+    return ops
+
+
+def test_one_shot_alice(amd):
+    cap = amd.BrotliEncoderMaxCompressedSize(len(ALICE))
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t(cap)
+    assert amd.BrotliEncoderCompress(5, 22, 0, len(ALICE), ALICE, C.byref(n), out)
+    assert hashlib.sha256(out.raw[:n.value]).hexdigest() == ALICE_SHA
+
+
+def test_one_shot_empty_and_small_buffer(amd):
+    out = C.create_string_buffer(16)
+    n = C.c_size_t(16)
+    assert amd.BrotliEncoderCompress(5, 22, 0, 0, b"", C.byref(n), out)
+    assert out.raw[:n.value] == b"\x06"
+    n = C.c_size_t(8)      # too small for alice: FALSE like the reference (encode.c:1340-1353)
+    assert not amd.BrotliEncoderCompress(5, 22, 0, len(ALICE), ALICE, C.byref(n), out)
+
+
+def test_unsupported_quality_fails_loudly(amd):
+    out = C.create_string_buffer(1 << 20)
+    n = C.c_size_t(1 << 20)
+    assert not amd.BrotliEncoderCompress(11, 22, 0, len(ALICE), ALICE, C.byref(n), out)
+    assert n.value == 0
+
+
+@pytest.mark.parametrize("name,ops_fn", [
+    ("single_finish", lambda n: [(n, 2)]),
+    ("chunks_2k", lambda n: _chunks(n, 2048, 2)),
+    ("chunks_2k_flush_every_16", lambda n: _chunks(n, 2048, 2, 16)),
+    ("chunks_100k_flush_each", lambda n: _chunks(n, 100000, 2, 1)),
+    ("flush_then_empty_finish", lambda n: [(n, 1), (0, 2)]),
+    ("empty_flush_first", lambda n: [(0, 1)] + _chunks(n, 70000, 2)),
+])
+def test_stream_sequences_equal_reference(amd, stock, name, ops_fn):
+    data = G.enwik_text(700000, seed=17, vocab=8000)
+    ops = ops_fn(len(data))
+    want, fin_w = drive(stock, data, ops)
+    got, fin_g = drive(amd, data, ops)
+    assert fin_w and fin_g
+    assert got == want
+
+
+def test_take_output_path_equals_reference(amd, stock):
+    """Go / Java bindings: available_out = 0 and BrotliEncoderTakeOutput."""
+    data = ALICE
+    ops = _chunks(len(data), 30000, 2, 2)
+    want, _ = drive(stock, data, ops, take=True)
+    got, fin = drive(amd, data, ops, take=True)
+    assert fin and got == want
+
+
+def test_stream_offset_parameter(amd, stock):
+    data = ALICE[:100000]
+    ops = [(len(data), 1)]
+    want, _ = drive(stock, data, ops, params=((5, 300000), (9, 200000)))
+    got, _ = drive(amd, data, ops, params=((5, 300000), (9, 200000)))
+    assert got == want
+
+
+def test_plan_parameter_equals_oracle_plan(amd, oracle):
+    data = G.enwik_text(1 << 20, seed=11, vocab=20000)
+    got, fin = drive(amd, data, [(len(data), 2)], params=((5, len(data)), (0x4D490001, 1 << 17)))
+    assert fin and got == oracle.encode_plan(data, 5, 22, 1 << 17)
+
+
+def test_reference_cli_on_our_library():
+    """c/tools/brotli.c compiled unmodified and linked against libbrotlienc_amd.so
+    (oracle/Makefile target cli_amd): config 1 of BASELINE.json."""
+    cli = os.path.join(ROOT, "oracle", "_ref", "brotli_cli_amd")
+    if not os.path.exists(cli):
+        pytest.skip("oracle/_ref/brotli_cli_amd not built")
+    dropin = os.path.join(LIBDIR, "dropin")
+    os.makedirs(dropin, exist_ok=True)
+    for name, target in (("libbrotlienc.so.1", "../libbrotlienc_amd.so"),
+                         ("libbrotli_amd_hip.so", "../libbrotli_amd_hip.so")):
+        p = os.path.join(dropin, name)
+        if not os.path.lexists(p):
+            os.symlink(target, p)
+    env = dict(os.environ, LD_LIBRARY_PATH=dropin + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    src = os.path.join(ROOT, "tests", "golden", "alice29.txt")
+    r = subprocess.run([cli, "-q", "5", "-w", "22", "-c", src], capture_output=True, env=env, check=True)
+    assert hashlib.sha256(r.stdout).hexdigest() == ALICE_SHA
+    d = subprocess.run([cli, "-d", "-c"], input=r.stdout, capture_output=True, env=env, check=True)
+    assert d.stdout == ALICE
