@@ -84,7 +84,8 @@ static void tables_path(char* out, size_t cap) {
   if (dladdr((void*)&tables_path, &info) && info.dli_fname) {
     char dir[4096];
     char* slash;
-    snprintf(dir, sizeof(dir), "%s", info.dli_fname);
+    /* the library may have been found through the dropin/ symlink */
+    if (!realpath(info.dli_fname, dir)) snprintf(dir, sizeof(dir), "%s", info.dli_fname);
     slash = strrchr(dir, '/');
     if (slash) *slash = 0; else snprintf(dir, sizeof(dir), ".");
     snprintf(out, cap, "%s/../data/brotli_tables.bin", dir);
@@ -168,7 +169,7 @@ static int ensure_initialized(BrotliEncoderState* s) {
   if (s->quality != 5 || s->lgwin < 17 || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
       s->mode == 2 /* FONT: non-zero distance parameters, encode.c:616-640 */ ||
       s->npostfix != 0 || s->ndirect != 0 || s->base64_mode != 0 || s->disable_ctx != 0 ||
-      s->simd_hasher == 1 /* BROTLI_SIMD_HASHER_NONE: H5 / H6 */) {
+      s->simd_hasher == 2 /* BROTLI_SIMD_HASHER_DISABLE: H5 / H6 */) {
     s->failed = 1;
     if (verbose())
       fprintf(stderr, "brotli_amd: parameters outside the GPU path (quality %d, lgwin %d); "
