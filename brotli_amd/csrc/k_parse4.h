@@ -60,6 +60,10 @@ struct QShard {
   uint32_t state;
   uint32_t error, have_mb, done;
   uint32_t stat_searches;
+  // software prefetch of bucket records: value of the load issued last step
+  // (consumed one step later so nothing waits on it) and a sink that keeps the
+  // loads alive
+  uint32_t pf_val, pf_acc;
 };
 
 DEV int q_t() { return wave_lane() & 15; }
@@ -67,15 +71,18 @@ DEV int q_base() { return wave_lane() & 48; }
 DEV uint32_t q_mask16(uint64_t ballot) { return (uint32_t)(ballot >> q_base()) & 0xFFFFu; }
 DEV bool wave_any(bool p) { return wave_ballot(p) != 0; }
 DEV uint32_t q_bcast(uint32_t v, int t) { return wave_shfl(v, q_base() | t); }
+// Maximum over the 16 lanes of a group, delivered to every lane of the group:
+// four DPP row rotations (VALU only).
 DEV uint32_t q_max(uint32_t v) {
-  const int lane = wave_lane();
-#pragma unroll
-  for (int k = 1; k < 16; k <<= 1) {
-    const uint32_t o = wave_shfl(v, lane ^ k);
-    v = o > v ? o : v;
-  }
+  uint32_t o;
+  o = wave_row_ror(v, 8); v = o > v ? o : v;
+  o = wave_row_ror(v, 4); v = o > v ? o : v;
+  o = wave_row_ror(v, 2); v = o > v ? o : v;
+  o = wave_row_ror(v, 1); v = o > v ? o : v;
   return v;
 }
+// Value held by lane i of the group (v is an unsigned payload).
+DEV uint32_t q_from(uint32_t v, int i) { return q_max(q_t() == i ? v : 0u); }
 DEV uint16_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 
 // Byte the reference reads at ring index x <= pos_end on the first lap.
@@ -96,6 +103,15 @@ DEV uint32_t q_extend(const uint8_t* data, uint32_t a, uint32_t b, uint32_t limi
   }
   while (off < limit && data[a + off] == data[b + off]) ++off;
   return off;
+}
+
+// Touches the 128-byte record of `key` (8 bytes per lane of the group) so that
+// the search that will need it finds it in the L2 / L1.  The loaded value is
+// folded into a sink one step later.
+DEV void q_prefetch_record(QShard& g, bool act, uint32_t key) {
+  g.pf_acc ^= g.pf_val;
+  g.pf_val = 0;
+  if (act) g.pf_val = ld32(g.table + (size_t)key * REC_BYTES + (uint32_t)q_t() * 8u);
 }
 
 // ---- ordered insertion of up to 16 positions per group ---------------------------
@@ -221,7 +237,7 @@ DEV void q_dict_search(const JobParams& J, const DeviceTables* T, QShard& g, boo
   }
   const uint32_t dictionary_start = umin(P + g.stream_offset, J.max_backward_limit);
   for (int i = 0; i < 2; ++i) {
-    const uint32_t len = q_bcast(wlen, i), word_idx = q_bcast(widx, i), ml = q_bcast(matchlen, i);
+    const uint32_t len = q_from(wlen, i), word_idx = q_from(widx, i), ml = q_from(matchlen, i);
     if (!go) continue;
     g.dict_lookups++;
     if (len == 0 || len > max_length) continue;
@@ -283,6 +299,14 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
     d_len = umin(m, max_length);
     d_ext = m == 32u && max_length > 32u;
   }
+  // The next search is at P + 1 in the two common cases (no match here; the
+  // lazy look-ahead after a match): pull its record towards the core now.  Its
+  // key only needs the bytes already in registers.
+  {
+    const uint64_t x1 = (cur32.q[0] >> 8) | (cur32.q[1] << 56);
+    const KeyTag k1 = hash_pos(x1, J.hasher_type, J.bucket_bits);
+    q_prefetch_record(g, want, k1.key);
+  }
   if (wave_any(b_ext || d_ext)) {
     if (b_ext) b_len = q_extend(g.data, P, b_prev, max_length);
     if (d_ext) d_len = q_extend(g.data, P, d_prev, max_length);
@@ -301,11 +325,7 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   const uint32_t d_best = q_max(d_key);
   const uint32_t dc_score = d_best ? (d_best >> 5) : K_MIN_SCORE;
   // length of the distance-cache winner (needed for the gate test below)
-  const uint64_t dwin_m = wave_ballot(d_key != 0 && d_key == d_best);
-  const uint32_t dwin16 = q_mask16(dwin_m);
-  const int dwin_t = dwin16 ? dev_ctz32(dwin16) : 0;
-  const uint32_t dc_len_b = q_bcast(d_len, dwin_t);
-  const uint32_t dc_len = dwin16 ? dc_len_b : 0u;
+  const uint32_t dc_len = q_max((d_key != 0 && d_key == d_best) ? d_len : 0u);
   const uint32_t dc_len3 = dc_len < 3u ? 3u : dc_len;
   // A bucket candidate that beats the distance-cache winner without being
   // longer depends on the byte gate: take the exact path for that group.
@@ -313,15 +333,13 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   const bool force_slow = (J.flags & JOB_FLAG_FORCE_SLOW) != 0;
   const bool slow = q_mask16(wave_ballot(unsure)) != 0 || (force_slow && want);
   const uint32_t best = q_max(b_key > d_key ? b_key : d_key);
-  const uint64_t win_m = wave_ballot(best != 0 && (b_key == best || d_key == best));
-  const uint32_t win16 = q_mask16(win_m);
-  const int win_t = win16 ? dev_ctz32(win16) : 0;
-  const bool win_is_d = d_key == best;
-  const uint32_t my_len = win_is_d ? d_len : b_len;
-  const uint32_t my_dist = win_is_d ? backward : P - b_prev;
+  // the winner's payload: keys are unique inside a group, so exactly one lane
+  // (or none) contributes a non-zero value to each reduction
+  const bool win_is_d = best != 0 && d_key == best;
+  const bool win_is_b = best != 0 && b_key == best;
   QResult r;
-  r.len = q_bcast(my_len, win_t);
-  r.distance = q_bcast(my_dist, win_t);
+  r.len = q_max(win_is_d ? d_len : win_is_b ? b_len : 0u);
+  r.distance = q_max(win_is_d ? backward : win_is_b ? P - b_prev : 0u);
   r.score = best >> 5;
   r.delta = 0;
   if (best == 0 || r.score <= K_MIN_SCORE) { r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; }
@@ -571,6 +589,7 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
   g.st_first = g.st_count = 0; g.st_stride = 1;
   g.error = 0; g.have_mb = 0; g.done = 0;
   g.stat_searches = 0;
+  g.pf_val = g.pf_acc = 0;
   g.state = (alive && !S->done && !S->mb_valid && !S->error) ? Q_PRE : Q_DONE;
   const bool participated = g.state != Q_DONE;
 
@@ -651,6 +670,15 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
         }
         g.position += g.sr_len;
       }
+      // After a copy the next search position is known: fetch its record
+      // while the copied range is being inserted.
+      if (wave_any(commit)) {
+        KeyTag kn;
+        kn.key = 0;
+        const bool pf = commit && g.position + htl < g.pos_end;
+        if (pf) kn = hash_pos(ld64(g.data + g.position), J.hasher_type, J.bucket_bits);
+        q_prefetch_record(g, pf, kn.key);
+      }
       q_drain_stores(J, g, lds_dup);
     }
     if (g.state == Q_POST) q_driver_post(J, g, writer);
@@ -674,6 +702,7 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
     }
     S->stat_searches += g.stat_searches;
     S->stat_pairs += g.stat_searches;
+    S->stat_b_used = g.pf_acc ^ g.pf_val;   // keeps the prefetch loads observable
   }
   wave_sync();
 }

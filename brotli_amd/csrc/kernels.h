@@ -6,6 +6,17 @@
 
 #include "k_round.h"
 #include "k_parse4.h"
+
+// Register budgets (waves per SIMD the compiler must leave room for).
+#ifndef PARSE4_WAVES
+#define PARSE4_WAVES 4
+#endif
+#ifndef BUILD_WAVES
+#define BUILD_WAVES 4
+#endif
+#ifndef STORE_WAVES
+#define STORE_WAVES 4
+#endif
 #include "k_build.h"
 #include "k_store.h"
 
@@ -41,7 +52,7 @@ __global__ void __launch_bounds__(64) k_parse(JobArgs a) {
 }
 
 // grid = ceil(nshards / 4), block = 64: four shards per wave.
-__global__ void __launch_bounds__(64) k_parse4(JobArgs a) {
+__global__ void __launch_bounds__(64, PARSE4_WAVES) k_parse4(JobArgs a) {
   __shared__ uint8_t lds_dup[Q_GROUPS * Q_DUP_SLOTS];
   parse4_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_dup);
   const uint32_t shard = blockIdx.x * Q_GROUPS + (threadIdx.x >> 4);
@@ -50,7 +61,7 @@ __global__ void __launch_bounds__(64) k_parse4(JobArgs a) {
 }
 
 // grid = nshards, block = 64: block splits, histograms, prefix codes.
-__global__ void __launch_bounds__(64) k_build(JobArgs a) {
+__global__ void __launch_bounds__(64, BUILD_WAVES) k_build(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
   __shared__ uint32_t lds[BUILD_LDS_WORDS];
@@ -60,7 +71,7 @@ __global__ void __launch_bounds__(64) k_build(JobArgs a) {
 }
 
 // grid = nshards, block = 64: bit-stream emission of the pending meta-block.
-__global__ void __launch_bounds__(64) k_store(JobArgs a) {
+__global__ void __launch_bounds__(64, STORE_WAVES) k_store(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
   store_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);

@@ -39,6 +39,8 @@ static inline uint32_t dev_bitrev32(uint32_t x) {
   return __builtin_bswap32(x);
 }
 #define block_sync() simt_sync(WAVE_SITE)
+// Rotation inside rows of 16 lanes (DPP row_ror on the device).
+#define wave_row_ror(v, k) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), (wave_lane() & 48) | ((wave_lane() + (k)) & 15), WAVE_SITE))
 
 #else  // ---- gfx950 ---------------------------------------------------------
 
@@ -95,6 +97,9 @@ __device__ __forceinline__ uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { ret
 __device__ __forceinline__ uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t dev_bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
+// Rotation inside rows of 16 lanes: one VALU v_mov_b32 with DPP row_ror:k, no
+// LDS crossbar round trip (ds_bpermute costs ~100 cycles of latency each).
+#define wave_row_ror(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x120 + (k), 0xF, 0xF, true))
 
 #endif
 

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbrotli_amd_hip.so")
+LIB_PATH = os.environ.get("BROTLI_AMD_HIP_LIB") or os.path.join(_HERE, "lib", "libbrotli_amd_hip.so")
 TABLES_PATH = os.path.join(_HERE, "data", "brotli_tables.bin")
 INPUT_SLACK = 64
 
