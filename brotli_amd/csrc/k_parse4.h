@@ -31,7 +31,18 @@
 #include "k_round.h"
 
 #define Q_GROUPS 4
+
+// Optional phase timing (build with -DQ_PROFILE): shader-clock cycles per phase
+// accumulated per shard into ShardState::prof[].
+#if defined(Q_PROFILE) && !defined(BROTLI_AMD_SIMT_SIM)
+#define QP_NOW() __builtin_amdgcn_s_memtime()
+#define QP_ADD(g, i, t0) do { const uint64_t qp_n = QP_NOW(); (g).prof[i] += qp_n - (t0); (t0) = qp_n; } while (0)
+#else
+#define QP_NOW() 0ull
+#define QP_ADD(g, i, t0) do { (void)(t0); } while (0)
+#endif
 #define Q_DUP_SLOTS 1024u
+#define QREC_ENTRY(i) ((uint32_t)(i) * 8u)   // byte offset of entry i in a record (see q_entry)
 
 enum QState { Q_PRE = 0, Q_SETUP = 1, Q_SEARCH = 2, Q_LAZY = 3, Q_POST = 4, Q_DONE = 5 };
 
@@ -57,6 +68,8 @@ struct QShard {
   uint32_t delayed;
   // pending ordered insertions: first + i * stride, i < count
   uint32_t st_first, st_count, st_stride;
+  uint64_t st_x;          // bytes at st_first + t * st_stride, fetched ahead of the first step
+  uint32_t st_x_valid;
   uint32_t state;
   uint32_t error, have_mb, done;
   uint32_t stat_searches;
@@ -64,6 +77,7 @@ struct QShard {
   // (consumed one step later so nothing waits on it) and a sink that keeps the
   // loads alive
   uint32_t pf_val, pf_acc;
+  uint64_t prof[8];
 };
 
 DEV int q_t() { return wave_lane() & 15; }
@@ -107,20 +121,36 @@ DEV uint32_t q_extend(const uint8_t* data, uint32_t a, uint32_t b, uint32_t limi
 
 // Touches the 128-byte record of `key` (8 bytes per lane of the group) so that
 // the search that will need it finds it in the L2 / L1.  The loaded value is
-// folded into a sink one step later.
+// folded into a sink one step later.  Measured on MI355X (profiles/
+// r01_e_variants.log): with the memory system already saturated by request
+// count, these prefetches cost more than they hide, so they are compiled in
+// only with -DQ_NEXT_PREFETCH / -DQ_COMMIT_PREFETCH.
 DEV void q_prefetch_record(QShard& g, bool act, uint32_t key) {
   g.pf_acc ^= g.pf_val;
   g.pf_val = 0;
-  if (act) g.pf_val = ld32(g.table + (size_t)key * REC_BYTES + (uint32_t)q_t() * 8u);
+  if (act) g.pf_val = ld32(g.table + (size_t)key * REC_BYTES + QREC_ENTRY(q_t()));
+}
+
+// ---- bucket records of this kernel ---------------------------------------------------
+// 128 bytes per key, sixteen 8-byte entries {u32 position, u16 tag2, u8 tag,
+// u8 aux}: lane t of a group owns entry t, so a probe is ONE dwordx2 load per
+// lane (one coalesced 128-byte access per group) and an insertion is one
+// 8-byte store.  The reference's 16-bit counter num_ lives in the aux bytes of
+// entries 0 (low byte) and 1 (high byte).  (k_parse.h keeps its own
+// array-of-fields layout; k_init writes either, see init_shard_table.)
+DEV uint64_t q_entry(uint32_t pos, uint32_t tag2, uint32_t tag, uint32_t aux) {
+  return (uint64_t)pos | ((uint64_t)(tag2 & 0xFFFFu) << 32) | ((uint64_t)(tag & 0xFFu) << 48) |
+         ((uint64_t)(aux & 0xFFu) << 56);
 }
 
 // ---- ordered insertion of up to 16 positions per group ---------------------------
 // Store / StoreRange (..64_simd_inc.h:114-137).  `act`: this lane inserts `pos`.
-DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, uint8_t* lds_dup) {
+DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, bool have_x,
+                   uint64_t x, uint8_t* lds_dup) {
   const int t = q_t();
   KeyTag kt;
   kt.key = 0; kt.tag = 0; kt.tag2 = 0;
-  if (act) kt = hash_pos(ld64(g.data + pos), J.hasher_type, J.bucket_bits);
+  if (act) kt = hash_pos(have_x ? x : ld64(g.data + pos), J.hasher_type, J.bucket_bits);
   // Two lanes of a group with one key must be ranked; detect that case through
   // an LDS scoreboard (false positives only cost time).
   uint8_t* sb = lds_dup + (size_t)(q_base() >> 4) * Q_DUP_SLOTS + (kt.key & (Q_DUP_SLOTS - 1u));
@@ -129,18 +159,13 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
   const bool dup = act && *sb != (uint8_t)t;
   const bool any_dup = wave_any(dup);
   uint8_t* rec = g.table + (size_t)kt.key * REC_BYTES;
-  uint32_t num = 0;
-  if (act) num = ld16(rec + REC_NUM_DW * 4);
+  // entries 0 and 1 carry the counter
+  uint64_t e0 = 0, e1 = 0;
+  if (act) { e0 = ld64(rec); e1 = ld64(rec + 8); }
+  const uint32_t num = (uint32_t)(e0 >> 56) | ((uint32_t)(e1 >> 56) << 8);
   wave_sync();
-  if (!any_dup) {
-    if (act) {
-      const uint32_t s = num & 15u;
-      st32(rec + REC_SLOT_DW * 4 + s * 4, pos);
-      st16(rec + REC_TAG2_DW * 4 + s * 2, (uint16_t)kt.tag2);
-      rec[REC_TAG_DW * 4 + s] = (uint8_t)kt.tag;
-      st16(rec + REC_NUM_DW * 4, (uint16_t)(num - 1u));
-    }
-  } else {
+  uint32_t below = 0, total = 1;
+  if (any_dup) {
     // same = lanes of my group that insert the same key
     uint64_t same = ~0ull;
     for (int b = 0; b < J.bucket_bits; ++b) {
@@ -150,15 +175,20 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
     }
     same &= wave_ballot(act);
     const uint32_t same16 = q_mask16(same);
-    if (act) {
-      const uint32_t below = (uint32_t)__builtin_popcount(same16 & ((1u << t) - 1u));
-      const uint32_t total = (uint32_t)__builtin_popcount(same16);
-      const uint32_t s = (num - below) & 15u;
-      st32(rec + REC_SLOT_DW * 4 + s * 4, pos);
-      st16(rec + REC_TAG2_DW * 4 + s * 2, (uint16_t)kt.tag2);
-      rec[REC_TAG_DW * 4 + s] = (uint8_t)kt.tag;
-      if (below + 1 == total) st16(rec + REC_NUM_DW * 4, (uint16_t)(num - total));
-    }
+    below = (uint32_t)__builtin_popcount(same16 & ((1u << t) - 1u));
+    total = (uint32_t)__builtin_popcount(same16);
+  }
+  if (act) {
+    const uint32_t s = (num - below) & 15u;
+    const uint32_t aux = s == 0 ? (uint32_t)(e0 >> 56) : s == 1 ? (uint32_t)(e1 >> 56) : 0u;
+    const uint64_t e = q_entry(pos, kt.tag2, kt.tag, aux);
+    __builtin_memcpy(rec + QREC_ENTRY(s), &e, 8);
+  }
+  wave_sync();   // the counter bytes go last (another lane may have rewritten entry 0 / 1)
+  if (act && below + 1 == total) {
+    const uint32_t nn = (num - total) & 0xFFFFu;
+    rec[7] = (uint8_t)nn;
+    if ((nn >> 8) != (num >> 8)) rec[15] = (uint8_t)(nn >> 8);
   }
   wave_sync();
 }
@@ -168,7 +198,8 @@ DEV void q_drain_stores(const JobParams& J, QShard& g, uint8_t* lds_dup) {
   while (wave_any(g.st_count != 0)) {
     const uint32_t n = umin(g.st_count, 16u);
     const bool act = (uint32_t)q_t() < n;
-    q_store16(J, g, act, g.st_first + (uint32_t)q_t() * g.st_stride, lds_dup);
+    q_store16(J, g, act, g.st_first + (uint32_t)q_t() * g.st_stride, g.st_x_valid != 0, g.st_x, lds_dup);
+    g.st_x_valid = 0;
     g.st_first += n * g.st_stride;
     g.st_count -= n;
   }
@@ -263,21 +294,24 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   const int ndist = J.ndist;
   const uint32_t max_length = g.pos_end - P;
   const uint32_t max_backward = umin(P, J.max_backward_limit);
+  uint64_t qt = QP_NOW();
   B32 cur32;
   cur32.q[0] = cur32.q[1] = cur32.q[2] = cur32.q[3] = 0;
   if (want) cur32 = load_b32(g.data + P);
   const KeyTag kt = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits);
   const uint8_t* rec = g.table + (size_t)kt.key * REC_BYTES;
-  uint32_t slot = 0, tag2 = 0, tag = 0, num = 0;
-  if (want) {
-    slot = ld32(rec + REC_SLOT_DW * 4 + t * 4);
-    tag2 = ld16(rec + REC_TAG2_DW * 4 + t * 2);
-    tag = rec[REC_TAG_DW * 4 + t];
-    num = ld16(rec + REC_NUM_DW * 4);
-  }
+  uint64_t ent = 0;
+  if (want) ent = ld64(rec + QREC_ENTRY(t));
+  const uint32_t slot = (uint32_t)ent;
+  const uint32_t tag2 = (uint32_t)(ent >> 32) & 0xFFFFu;
+  const uint32_t tag = (uint32_t)(ent >> 48) & 0xFFu;
+  const uint32_t aux = (uint32_t)(ent >> 56);
+  const uint32_t num = q_max(t == 0 ? aux : 0u) | (q_max(t == 1 ? aux : 0u) << 8);
   const uint32_t head = (num + 1u) & 15u;
   const uint32_t n = (65535u - num) & 0xFFFFu;
   const uint32_t logical = ((uint32_t)t - head) & 15u;   // 0 = newest
+  if (wave_any(want && tag == 0x1234567u)) g.pf_acc++;   // (profiling fence: record values consumed)
+  QP_ADD(g, 0, qt);
   // bucket candidate of this lane (:246-262)
   const bool b_cand = want && (n >= 16u || logical < n) && tag == kt.tag && tag2 == kt.tag2 &&
                       (P - slot) <= max_backward;
@@ -285,32 +319,46 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   const uint32_t backward = q_dc_entry(g, t);
   const bool d_cand = want && t < ndist && (int32_t)backward > 0 && backward <= max_backward;
   const uint32_t b_prev = slot, d_prev = P - backward;
+  // Both candidate strings are fetched in one round trip: no branches around
+  // the loads (a lane without a candidate re-reads its own position).
   uint32_t b_len = 0, d_len = 0;
   bool b_ext = false, d_ext = false;
-  if (b_cand) {
-    const B32 p32 = load_b32(g.data + b_prev);
-    const uint32_t m = common_prefix32(cur32, p32);
-    b_len = umin(m, max_length);
-    b_ext = m == 32u && max_length > 32u;
-  }
-  if (d_cand) {
-    const B32 p32 = load_b32(g.data + d_prev);
-    const uint32_t m = common_prefix32(cur32, p32);
-    d_len = umin(m, max_length);
-    d_ext = m == 32u && max_length > 32u;
-  }
-  // The next search is at P + 1 in the two common cases (no match here; the
-  // lazy look-ahead after a match): pull its record towards the core now.  Its
-  // key only needs the bytes already in registers.
   {
-    const uint64_t x1 = (cur32.q[0] >> 8) | (cur32.q[1] << 56);
-    const KeyTag k1 = hash_pos(x1, J.hasher_type, J.bucket_bits);
-    q_prefetch_record(g, want, k1.key);
+    const uint32_t b_at = b_cand ? b_prev : P;
+    const uint32_t d_at = d_cand ? d_prev : P;
+    B32 pb, pd;
+    pb.q[0] = pb.q[1] = pb.q[2] = pb.q[3] = 0;
+    pd = pb;
+#if defined(Q_CAND_ALL_LANES)
+    if (want) {
+      pb = load_b32(g.data + b_at);
+      pd = load_b32(g.data + d_at);
+    }
+#else
+    if (b_cand) pb = load_b32(g.data + b_at);
+    if (d_cand) pd = load_b32(g.data + d_at);
+#endif
+    // The next search is at P + 1 in the two common cases (no match here; the
+    // lazy look-ahead after a match): pull its record towards the core now,
+    // behind the candidate loads.  Its key only needs bytes already in registers.
+    {
+#if defined(Q_NEXT_PREFETCH)
+      const uint64_t x1 = (cur32.q[0] >> 8) | (cur32.q[1] << 56);
+      const KeyTag k1 = hash_pos(x1, J.hasher_type, J.bucket_bits);
+      q_prefetch_record(g, want, k1.key);
+#endif
+    }
+    const uint32_t mb = common_prefix32(cur32, pb);
+    const uint32_t md = common_prefix32(cur32, pd);
+    if (b_cand) { b_len = umin(mb, max_length); b_ext = mb == 32u && max_length > 32u; }
+    if (d_cand) { d_len = umin(md, max_length); d_ext = md == 32u && max_length > 32u; }
   }
   if (wave_any(b_ext || d_ext)) {
     if (b_ext) b_len = q_extend(g.data, P, b_prev, max_length);
     if (d_ext) d_len = q_extend(g.data, P, d_prev, max_length);
   }
+  if (wave_any(b_len + d_len == 0xFFFFFFFFu)) g.pf_acc++;   // (profiling fence: candidate bytes consumed)
+  QP_ADD(g, 1, qt);
   // scores (hash.h:123-138)
   const uint32_t b_score = 1920u + 135u * b_len - 30u * log2floor((P - b_prev) | 1u);
   uint32_t d_score = 135u * d_len + 1935u;
@@ -348,17 +396,24 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
                                      d_prev, d_score, b_cand, b_len, b_prev, b_score);
     if (slow) r = s;
   }
-  // insert P (:293-295)
-  if (want && (uint32_t)t == (num & 15u)) {
-    uint8_t* wrec = g.table + (size_t)kt.key * REC_BYTES;
-    st32(wrec + REC_SLOT_DW * 4 + t * 4, P);
-    st16(wrec + REC_TAG2_DW * 4 + t * 2, (uint16_t)kt.tag2);
-    wrec[REC_TAG_DW * 4 + t] = (uint8_t)kt.tag;
-    st16(wrec + REC_NUM_DW * 4, (uint16_t)(num - 1u));
+  QP_ADD(g, 2, qt);
+  // insert P (:293-295): the lane that owns ring slot num & 15 writes the new
+  // entry; lanes 0 / 1 refresh the counter bytes kept in their entries.
+  {
+    const uint32_t ts = num & 15u, nn = (num - 1u) & 0xFFFFu;
+    const bool mine = (uint32_t)t == ts;
+    const bool hi_changed = (nn >> 8) != (num >> 8);
+    if (want && (mine || t == 0 || (t == 1 && hi_changed))) {
+      const uint32_t naux = t == 0 ? (nn & 0xFFu) : t == 1 ? (nn >> 8) : 0u;
+      const uint64_t e = mine ? q_entry(P, kt.tag2, kt.tag, naux) : q_entry(slot, tag2, tag, naux);
+      __builtin_memcpy(g.table + (size_t)kt.key * REC_BYTES + QREC_ENTRY(t), &e, 8);
+    }
   }
   wave_sync();
   // static dictionary when nothing was found (hash.h:179-202)
+  QP_ADD(g, 3, qt);
   q_dict_search(J, T, g, want && r.score == K_MIN_SCORE, P, max_length, r);
+  QP_ADD(g, 4, qt);
   return r;
 }
 
@@ -587,16 +642,20 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
   g.position = g.pos_end = g.store_end = g.insert_length = g.apply_random_heuristics = 0;
   g.sr_len = g.sr_dist = 0; g.sr_score = K_MIN_SCORE; g.sr_delta = 0; g.delayed = 0;
   g.st_first = g.st_count = 0; g.st_stride = 1;
+  g.st_x = 0; g.st_x_valid = 0;
   g.error = 0; g.have_mb = 0; g.done = 0;
   g.stat_searches = 0;
   g.pf_val = g.pf_acc = 0;
+  for (int i = 0; i < 8; ++i) g.prof[i] = 0;
   g.state = (alive && !S->done && !S->mb_valid && !S->error) ? Q_PRE : Q_DONE;
   const bool participated = g.state != Q_DONE;
 
   while (wave_any(g.state != Q_DONE)) {
+    uint64_t qt0 = QP_NOW();
     // stream driver up to the next block
     if (g.state == Q_PRE) q_driver_pre(J, g);
     if (wave_any(g.state == Q_SETUP)) q_setup_block(J, g, g.state == Q_SETUP, lds_dup);
+    QP_ADD(g, 7, qt0);
 
     // block finished? (loop guard of CreateBackwardReferences, :44 and :239-241)
     if (g.state == Q_SEARCH && !(g.position + htl < g.pos_end)) {
@@ -608,6 +667,7 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
     if (wave_any(want)) {
       const uint32_t P = g.position + (g.state == Q_LAZY ? 1u : 0u);
       const QResult cur = q_search(J, T, g, want, P);
+      uint64_t qt = QP_NOW();
       if (want) g.stat_searches++;
       bool commit = false;
       if (g.state == Q_SEARCH) {
@@ -648,6 +708,23 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
       }
       if (commit) {
         g.state = Q_SEARCH;
+        // StoreRange bounds first, so that the bytes of the first insertion
+        // step (and the next search position's key) travel while the command
+        // is being built.
+        uint32_t range_start = g.position + 2u;
+        const uint32_t range_end = umin(g.position + g.sr_len, g.store_end);
+        if (g.sr_dist < (g.sr_len >> 2)) {
+          range_start = umin(range_end, umax(range_start, g.position + g.sr_len - (g.sr_dist << 2)));
+        }
+        if (range_start < range_end) {
+          g.st_first = range_start;
+          g.st_count = range_end - range_start;
+          g.st_stride = 1;
+#if defined(Q_EARLY_STX)
+          g.st_x = ld64(g.data + range_start + (uint32_t)t);
+          g.st_x_valid = 1;
+#endif
+        }
         g.apply_random_heuristics = g.position + 2u * g.sr_len + J.spree_window;
         const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit);
         const uint32_t distance_code = compute_distance_code(g.sr_dist, dictionary_start, g.dc);
@@ -658,20 +735,11 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
         ++g.r.ncmds;
         g.r.nlits += g.insert_length;
         g.insert_length = 0;
-        uint32_t range_start = g.position + 2u;
-        const uint32_t range_end = umin(g.position + g.sr_len, g.store_end);
-        if (g.sr_dist < (g.sr_len >> 2)) {
-          range_start = umin(range_end, umax(range_start, g.position + g.sr_len - (g.sr_dist << 2)));
-        }
-        if (range_start < range_end) {
-          g.st_first = range_start;
-          g.st_count = range_end - range_start;
-          g.st_stride = 1;
-        }
         g.position += g.sr_len;
       }
       // After a copy the next search position is known: fetch its record
       // while the copied range is being inserted.
+#if defined(Q_COMMIT_PREFETCH)
       if (wave_any(commit)) {
         KeyTag kn;
         kn.key = 0;
@@ -679,7 +747,10 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
         if (pf) kn = hash_pos(ld64(g.data + g.position), J.hasher_type, J.bucket_bits);
         q_prefetch_record(g, pf, kn.key);
       }
+#endif
+      QP_ADD(g, 5, qt);
       q_drain_stores(J, g, lds_dup);
+      QP_ADD(g, 6, qt);
     }
     if (g.state == Q_POST) q_driver_post(J, g, writer);
   }
@@ -703,6 +774,9 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
     S->stat_searches += g.stat_searches;
     S->stat_pairs += g.stat_searches;
     S->stat_b_used = g.pf_acc ^ g.pf_val;   // keeps the prefetch loads observable
+#if defined(Q_PROFILE)
+    for (int i = 0; i < 8; ++i) S->prof[i] += g.prof[i];
+#endif
   }
   wave_sync();
 }

@@ -249,12 +249,18 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
 // encode.c:642-700, 745-790) and its hash table (Prepare,
 // ..64_simd_inc.h:81-98: every count 0xFFFF).  256 threads per block,
 // grid-stride over records.
-DEV void init_shard_table(uint8_t* table, uint32_t nrec, uint32_t tid, uint32_t nthreads) {
-  // One record = 128 B = 8 x 16 B; thread t clears 16-byte piece t.
+DEV void init_shard_table(uint8_t* table, uint32_t nrec, uint32_t tid, uint32_t nthreads, bool quad) {
+  // One record = 128 B = 8 x 16 B; thread t clears 16-byte piece t.  The
+  // counter starts at 0xFFFF: dword 28 in k_parse.h's layout, the aux bytes of
+  // entries 0 and 1 (bytes 7 and 15) in k_parse4.h's.
   const uint32_t pieces = nrec * 8u;
   for (uint32_t p = tid; p < pieces; p += nthreads) {
     uint32_t v[4] = {0, 0, 0, 0};
-    if ((p & 7u) == 7u) v[0] = 0xFFFFu;  // dword 28 = num
+    if (quad) {
+      if ((p & 7u) == 0u) { v[1] = 0xFF000000u; v[3] = 0xFF000000u; }
+    } else if ((p & 7u) == 7u) {
+      v[0] = 0xFFFFu;
+    }
     __builtin_memcpy(table + (size_t)p * 16u, v, 16);
   }
 }

@@ -30,6 +30,15 @@
 #include "k_build.h"
 #include "k_round.h"
 
+// Optional phase timing (-DS_PROFILE): cycles per phase into ShardState::prof[].
+#if defined(S_PROFILE) && !defined(BROTLI_AMD_SIMT_SIM)
+#define SP_NOW() __builtin_amdgcn_s_memtime()
+#define SP_ADD(S, i, t0) do { const uint64_t sp_n = SP_NOW(); if (wave_lane() == 0) (S)->prof[i] += sp_n - (t0); (t0) = sp_n; } while (0)
+#else
+#define SP_NOW() 0ull
+#define SP_ADD(S, i, t0) do { (void)(t0); } while (0)
+#endif
+
 // ---- output bit sink ---------------------------------------------------------
 struct BitSink {
   uint32_t* base;     // 4-byte aligned
@@ -500,6 +509,7 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     return;
   }
   uint64_t total_bits = 0;   // relative to out + r.out_bytes, carried bits included
+  uint64_t spt = SP_NOW();
 
   if (!raw) {
     zero_output(out, r.out_bytes, zero_bytes);
@@ -536,6 +546,7 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     uint32_t* cmap_rle = (uint32_t*)(s.mb + s.L.cmap_rle);
     const uint8_t* static_map = k_ctx_maps[s.info->map_kind];
 
+    SP_ADD(S, 0, spt);
     // ---- phase 0: histograms of the small codes (a lane each) ----
     uint32_t cmap_nrle = 0, cmap_max_prefix = 0;
     if (lane < 3) {
@@ -616,6 +627,7 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     cmap_max_prefix = wave_bcast(cmap_max_prefix, 5);
     wave_sync();
 
+    SP_ADD(S, 1, spt);
     // ---- phase 1: every prefix code, one lane per job ----
     // job ids: 0-2 block types, 3-5 block lengths, 6 literal context map,
     // 7 distance context map, then literal / command / distance histograms.
@@ -661,6 +673,7 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     }
     wave_sync();
 
+    SP_ADD(S, 2, spt);
     // Block switch codes for every block b >= 1 (StoreBlockSwitch :737-756).
     for (int c = 0; c < 3; ++c) {
       for (uint32_t b = (uint32_t)lane; b < nblocks[c]; b += 64) {
@@ -683,6 +696,7 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     }
     wave_sync();
 
+    SP_ADD(S, 3, spt);
     // ---- phase 2: header, in order ----
     BitSink sink;
     sink.base = (uint32_t*)(out + (r.out_bytes & ~(uint64_t)3));
@@ -758,6 +772,7 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     for (uint32_t j = 8; j < njobs; ++j)
       sink_splice(sink, tree_bufs + (size_t)j * MB_TREE_BUF_BYTES, job_nbits[j]);
 
+    SP_ADD(S, 4, spt);
     // ---- phase 3: the commands, 64 per step ----
     uint32_t lit_base = 0, dist_base = 0;
     for (uint32_t base = 0; base < ncmds; base += 64) {
@@ -867,6 +882,7 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
       lit_base += wave_bcast(ins_incl, 63);
       dist_base += (uint32_t)dev_popc64(dm);
     }
+    SP_ADD(S, 5, spt);
     if (is_last) sink.bitpos = (sink.bitpos + 7u) & ~(uint64_t)7u;
     total_bits = sink.bitpos - bit0;
     wave_sync();

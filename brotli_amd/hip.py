@@ -33,10 +33,13 @@ class JobInfo(C.Structure):
                 ("ms_init", C.c_float), ("ms_parse", C.c_float),
                 ("ms_build", C.c_float), ("ms_store", C.c_float),
                 ("ms_gather", C.c_float), ("searches", C.c_uint64),
-                ("search_steps", C.c_uint64), ("commands", C.c_uint64)]
+                ("search_steps", C.c_uint64), ("commands", C.c_uint64),
+                ("prof", C.c_uint64 * 8)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "prof")}
+        d["prof"] = list(self.prof)
+        return d
 
 
 CMD_DTYPE = np.dtype([("insert_len", "<u4"), ("copy_len", "<u4"),

@@ -18,6 +18,8 @@ ALICE = open(os.path.join(HERE, "golden", "alice29.txt"), "rb").read()
 
 @pytest.fixture(scope="module")
 def ctx():
+    import torch
+    torch.cuda.init()       # same initialisation order as bench.py: torch first
     from brotli_amd import hip
     c = hip.Context(0)      # raises if the HIP library or a gfx950 device is missing
     yield c

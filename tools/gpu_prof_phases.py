@@ -1,0 +1,21 @@
+"""Phase cycle breakdown of k_parse4 (library built with -DQ_PROFILE)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import gen_inputs as G
+from brotli_amd import hip
+N = int(os.environ.get("PROBE_MB", "256")) << 20
+data = G.enwik_text(N)
+ctx = hip.Context(0)
+d = hip.to_device(data)
+names = ["rec_wait", "cand_wait", "resolve", "insert", "dict", "decide", "stores", "driver"]
+for shard in [int(x) for x in os.environ.get("PROBE_SHARDS", "262144,65536").split(",")]:
+    for rep in range(2):
+        got, info = ctx.debug_parse(d, N, hip.make_params(5, 22, shard, 1 << 30))
+    prof = info["prof"]; tot = sum(prof)
+    iters = info["search_steps"]
+    print("PHASES shard=%d parse=%.1fms searches=%d cmds=%d total_cycles/shard-iter=%.0f" % (
+        shard, info["ms_parse"], info["searches"], info["commands"], tot / max(1, iters)))
+    for n, p in zip(names, prof):
+        print("   %-10s %5.1f%%  %.0f cycles per search" % (n, 100.0 * p / tot, p / max(1, iters)))
