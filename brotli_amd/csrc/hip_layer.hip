@@ -314,7 +314,7 @@ int brotli_amd_encode_device(BrotliAmdCtx* c, const void* d_in, uint64_t len,
     HIP_OK(c, hipEventElapsedTime(&t, c->ev[6], c->ev[7])); info->ms_total = t;
     info->out_bytes = total;
     *out_size = total;
-#if defined(S_PROFILE)
+#if defined(S_PROFILE) || defined(B_PROFILE)
     {  // prof_out: phase cycles of the store kernel, summed over shards
       std::vector<ShardState> st(nshards);
       HIP_OK(c, hipMemcpy(st.data(), c->d_states, nshards * sizeof(ShardState), hipMemcpyDeviceToHost));

@@ -24,6 +24,14 @@
 #include "device_common.h"
 #include "mb_layout.h"
 
+#if defined(B_PROFILE) && !defined(BROTLI_AMD_SIMT_SIM)
+#define BP_NOW() __builtin_amdgcn_s_memtime()
+#define BP_ADD(S, i, t0) do { const uint64_t bp_n = BP_NOW(); if (wave_lane() == 0) (S)->prof[i] += bp_n - (t0); (t0) = bp_n; } while (0)
+#else
+#define BP_NOW() 0ull
+#define BP_ADD(S, i, t0) do { (void)(t0); } while (0)
+#endif
+
 #define LDS_ROW(A) ((A) + 1u)   // padded row: lanes walking different rows hit different banks
 #define BUILD_LDS_WORDS (13u * 257u)
 
@@ -193,13 +201,20 @@ DEV void decide_contexts(BuildCtx& b, uint32_t start, uint32_t length) {
 
 // ---- symbol streams ------------------------------------------------------------
 // lits[k] = literal | context << 8 in stream order; dsym[k] = distance symbol of
-// the k-th command that carries one (metablock.c:741-769).
+// the k-th command that carries one (metablock.c:741-769).  64 commands per
+// step: wave scans give every command its first literal index and source
+// position; the literals of the step are then copied FLAT, one literal per
+// lane, each lane finding its command by a binary search over the 64 start
+// indices kept in LDS (so one long insert run is spread over all lanes and
+// every load of a step is independent).
 DEV void build_streams(BuildCtx& b, uint32_t start, uint32_t ncmds, uint32_t* nlits_out,
                        uint32_t* ndist_out) {
   const int lane = wave_lane();
   const uint8_t* clut = b.T->context_lut;
   const uint8_t* cmap = k_ctx_maps[b.map_kind];
   const bool use_ctx = b.nc > 1;
+  uint32_t* s_start = b.lds;        // [65] first literal index of command i of the step
+  uint32_t* s_src = b.lds + 65;     // [64] source position of that literal
   uint32_t pos = start, nlits = 0, ndist = 0;
   for (uint32_t base = 0; base < ncmds; base += 64) {
     const uint32_t i = base + (uint32_t)lane;
@@ -222,35 +237,28 @@ DEV void build_streams(BuildCtx& b, uint32_t start, uint32_t ncmds, uint32_t* nl
       const uint32_t k = ndist + (uint32_t)dev_popc64(dm & ((1ull << lane) - 1ull));
       b.dsym[k] = (uint16_t)(dprefix & 0x3FFu);
     }
-    // Short insert runs: one lane per command.  Long runs: the whole wave.
-    const bool is_long = ins >= 48u;
-    if (valid && !is_long) {
-      for (uint32_t j = 0; j < ins; ++j) {
-        const uint32_t p = my_pos + j;
-        uint32_t v = b.data[p];
-        if (use_ctx) {
-          const uint32_t p1 = p >= 1 ? b.data[p - 1] : 0u, p2 = p >= 2 ? b.data[p - 2] : 0u;
-          v |= (uint32_t)cmap[clut[p1] | clut[256 + p2]] << 8;
-        }
-        b.lits[my_lit + j] = (uint16_t)v;
+    const uint32_t total = wave_bcast(ins_incl, 63);
+    s_start[lane] = my_lit;
+    s_src[lane] = my_pos;
+    if (lane == 63) s_start[64] = nlits + total;
+    wave_sync();
+    for (uint32_t L = nlits + (uint32_t)lane; L < nlits + total; L += 64) {
+      // largest c with s_start[c] <= L
+      uint32_t lo = 0, hi = 63;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (s_start[mid] <= L) lo = mid; else hi = mid - 1;
       }
-    }
-    uint64_t lm = wave_ballot(valid && is_long);
-    while (lm) {
-      const int src = dev_ctz64(lm);
-      lm &= lm - 1;
-      const uint32_t n = wave_bcast(ins, src), p0 = wave_bcast(my_pos, src), l0 = wave_bcast(my_lit, src);
-      for (uint32_t j = (uint32_t)lane; j < n; j += 64) {
-        const uint32_t p = p0 + j;
-        uint32_t v = b.data[p];
-        if (use_ctx) {
-          const uint32_t p1 = p >= 1 ? b.data[p - 1] : 0u, p2 = p >= 2 ? b.data[p - 2] : 0u;
-          v |= (uint32_t)cmap[clut[p1] | clut[256 + p2]] << 8;
-        }
-        b.lits[l0 + j] = (uint16_t)v;
+      const uint32_t p = s_src[lo] + (L - s_start[lo]);
+      uint32_t v = b.data[p];
+      if (use_ctx) {
+        const uint32_t p1 = p >= 1 ? b.data[p - 1] : 0u, p2 = p >= 2 ? b.data[p - 2] : 0u;
+        v |= (uint32_t)cmap[clut[p1] | clut[256 + p2]] << 8;
       }
+      b.lits[L] = (uint16_t)v;
     }
-    nlits += wave_bcast(ins_incl, 63);
+    wave_sync();
+    nlits += total;
     pos += wave_bcast(adv_incl, 63);
     ndist += (uint32_t)dev_popc64(dm);
   }
@@ -517,6 +525,7 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   const uint32_t ncmds = S->ncmds, nlits_state = S->nlits;
   MbInfo* info = (MbInfo*)(b.mb + b.L.info);
 
+  uint64_t bpt = BP_NOW();
   if (!should_compress(b, start, bytes, nlits_state, ncmds)) {
     if (lane == 0) S->mb_raw = 1;
     wave_sync();
@@ -524,7 +533,9 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   }
   decide_contexts(b, start, bytes);
   uint32_t nlits = 0, ndist = 0;
+  BP_ADD(S, 0, bpt);
   build_streams(b, start, ncmds, &nlits, &ndist);
+  BP_ADD(S, 1, bpt);
   if (lane == 0) {
     info->num_contexts = b.nc;
     info->map_kind = b.map_kind;
@@ -533,8 +544,11 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     info->ncmds = ncmds;
   }
   run_splitter<0>(b, nlits);
+  BP_ADD(S, 2, bpt);
   run_splitter<1>(b, ncmds);
+  BP_ADD(S, 3, bpt);
   run_splitter<2>(b, ndist);
+  BP_ADD(S, 4, bpt);
 
   // BrotliOptimizeHistograms: one lane per histogram.
   {
@@ -549,6 +563,7 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     }
   }
   wave_sync();
+  BP_ADD(S, 5, bpt);
 }
 
 #endif  // BROTLI_AMD_CSRC_K_BUILD_H_

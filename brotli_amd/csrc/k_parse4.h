@@ -31,6 +31,12 @@
 #include "k_round.h"
 
 #define Q_GROUPS 4
+#if defined(BROTLI_AMD_SIMT_SIM)
+extern unsigned long long g_sim_counts[16];
+#define SIM_COUNT(i, n) do { if (wave_lane() == 0) g_sim_counts[i] += (n); } while (0)
+#else
+#define SIM_COUNT(i, n) do { } while (0)
+#endif
 
 // Optional phase timing (build with -DQ_PROFILE): shader-clock cycles per phase
 // accumulated per shard into ShardState::prof[].
@@ -158,6 +164,7 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
   wave_sync();
   const bool dup = act && *sb != (uint8_t)t;
   const bool any_dup = wave_any(dup);
+  if (any_dup) SIM_COUNT(6, 1);                        // insertion steps with a key collision
   uint8_t* rec = g.table + (size_t)kt.key * REC_BYTES;
   // entries 0 and 1 carry the counter
   uint64_t e0 = 0, e1 = 0;
@@ -196,6 +203,7 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
 // Drains every group's pending insertions.
 DEV void q_drain_stores(const JobParams& J, QShard& g, uint8_t* lds_dup) {
   while (wave_any(g.st_count != 0)) {
+    SIM_COUNT(3, 1);                                   // insertion steps (wave level)
     const uint32_t n = umin(g.st_count, 16u);
     const bool act = (uint32_t)q_t() < n;
     q_store16(J, g, act, g.st_first + (uint32_t)q_t() * g.st_stride, g.st_x_valid != 0, g.st_x, lds_dup);
@@ -256,6 +264,7 @@ DEV void q_dict_search(const JobParams& J, const DeviceTables* T, QShard& g, boo
   const int t = q_t();
   const bool go = want && !(g.dict_matches < (g.dict_lookups >> 7));
   if (!wave_any(go)) return;
+  SIM_COUNT(4, 1);                                     // dictionary probes (wave level)
   uint32_t matchlen = 0, wlen = 0, widx = 0;
   if (go && t < 2) {
     const uint32_t key = (((ld32(g.data + P) * 0x1E35A7BDu) >> (32 - 14)) << 1) + (uint32_t)t;
@@ -295,13 +304,19 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   const uint32_t max_length = g.pos_end - P;
   const uint32_t max_backward = umin(P, J.max_backward_limit);
   uint64_t qt = QP_NOW();
-  B32 cur32;
-  cur32.q[0] = cur32.q[1] = cur32.q[2] = cur32.q[3] = 0;
-  if (want) cur32 = load_b32(g.data + P);
+  // No branches around the first-round loads, so that the compiler can count
+  // them precisely (s_waitcnt vmcnt(n)): idle lanes read offset 0.
+  const B32 cur32 = load_b32(g.data + (want ? P : 0u));
+  // The distance-cache probes (:201-240) depend only on P and the cache, not on
+  // the hash table: their strings are requested right away, in the same round
+  // trip as the bytes at P and overlapping the bucket-record access.
+  const uint32_t backward = q_dc_entry(g, t);
+  const bool d_cand = want && t < ndist && (int32_t)backward > 0 && backward <= max_backward;
+  const uint32_t d_prev = P - backward;
+  const B32 pd = load_b32(g.data + (d_cand ? d_prev : (want ? P : 0u)));
   const KeyTag kt = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits);
   const uint8_t* rec = g.table + (size_t)kt.key * REC_BYTES;
-  uint64_t ent = 0;
-  if (want) ent = ld64(rec + QREC_ENTRY(t));
+  const uint64_t ent = ld64((want ? rec : g.table) + QREC_ENTRY(t));
   const uint32_t slot = (uint32_t)ent;
   const uint32_t tag2 = (uint32_t)(ent >> 32) & 0xFFFFu;
   const uint32_t tag = (uint32_t)(ent >> 48) & 0xFFu;
@@ -310,54 +325,44 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   const uint32_t head = (num + 1u) & 15u;
   const uint32_t n = (65535u - num) & 0xFFFFu;
   const uint32_t logical = ((uint32_t)t - head) & 15u;   // 0 = newest
+#if defined(Q_PROFILE)
   if (wave_any(want && tag == 0x1234567u)) g.pf_acc++;   // (profiling fence: record values consumed)
+#endif
   QP_ADD(g, 0, qt);
   // bucket candidate of this lane (:246-262)
   const bool b_cand = want && (n >= 16u || logical < n) && tag == kt.tag && tag2 == kt.tag2 &&
                       (P - slot) <= max_backward;
-  // distance-cache candidate of this lane (:201-240)
-  const uint32_t backward = q_dc_entry(g, t);
-  const bool d_cand = want && t < ndist && (int32_t)backward > 0 && backward <= max_backward;
-  const uint32_t b_prev = slot, d_prev = P - backward;
-  // Both candidate strings are fetched in one round trip: no branches around
-  // the loads (a lane without a candidate re-reads its own position).
+  const uint32_t b_prev = slot;
+  // Bucket candidates need a second round trip (their positions come from the
+  // record); most searches on text have at most one after the tag2 filter.
   uint32_t b_len = 0, d_len = 0;
   bool b_ext = false, d_ext = false;
   {
-    const uint32_t b_at = b_cand ? b_prev : P;
-    const uint32_t d_at = d_cand ? d_prev : P;
-    B32 pb, pd;
+    B32 pb;
     pb.q[0] = pb.q[1] = pb.q[2] = pb.q[3] = 0;
-    pd = pb;
-#if defined(Q_CAND_ALL_LANES)
-    if (want) {
-      pb = load_b32(g.data + b_at);
-      pd = load_b32(g.data + d_at);
-    }
-#else
-    if (b_cand) pb = load_b32(g.data + b_at);
-    if (d_cand) pd = load_b32(g.data + d_at);
-#endif
-    // The next search is at P + 1 in the two common cases (no match here; the
-    // lazy look-ahead after a match): pull its record towards the core now,
-    // behind the candidate loads.  Its key only needs bytes already in registers.
-    {
+    if (b_cand) pb = load_b32(g.data + b_prev);
 #if defined(Q_NEXT_PREFETCH)
+    {
       const uint64_t x1 = (cur32.q[0] >> 8) | (cur32.q[1] << 56);
       const KeyTag k1 = hash_pos(x1, J.hasher_type, J.bucket_bits);
       q_prefetch_record(g, want, k1.key);
-#endif
     }
+#endif
     const uint32_t mb = common_prefix32(cur32, pb);
     const uint32_t md = common_prefix32(cur32, pd);
     if (b_cand) { b_len = umin(mb, max_length); b_ext = mb == 32u && max_length > 32u; }
     if (d_cand) { d_len = umin(md, max_length); d_ext = md == 32u && max_length > 32u; }
   }
+  SIM_COUNT(0, 1);                                     // search steps (wave level)
+  if (wave_any(b_cand)) SIM_COUNT(1, 1);               // steps with a bucket candidate load
   if (wave_any(b_ext || d_ext)) {
+    SIM_COUNT(2, 1);                                   // steps with a > 32 byte extension
     if (b_ext) b_len = q_extend(g.data, P, b_prev, max_length);
     if (d_ext) d_len = q_extend(g.data, P, d_prev, max_length);
   }
+#if defined(Q_PROFILE)
   if (wave_any(b_len + d_len == 0xFFFFFFFFu)) g.pf_acc++;   // (profiling fence: candidate bytes consumed)
+#endif
   QP_ADD(g, 1, qt);
   // scores (hash.h:123-138)
   const uint32_t b_score = 1920u + 135u * b_len - 30u * log2floor((P - b_prev) | 1u);
@@ -392,6 +397,7 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   r.delta = 0;
   if (best == 0 || r.score <= K_MIN_SCORE) { r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; }
   if (wave_any(slow)) {
+    SIM_COUNT(5, 1);                                   // exact resolves
     const QResult s = q_resolve_slow(g, want, P, max_length, head, ndist, d_ok || (d_cand), d_len,
                                      d_prev, d_score, b_cand, b_len, b_prev, b_score);
     if (slow) r = s;

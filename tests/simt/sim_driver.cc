@@ -14,6 +14,7 @@
 #include "../../brotli_amd/csrc/kernels.h"
 #include "../../brotli_amd/csrc/host_plan.h"
 
+unsigned long long g_sim_counts[16];
 namespace {
 struct Launch { void (*fn)(JobArgs); JobArgs a; };
 void tramp(void* p) { Launch* l = (Launch*)p; l->fn(l->a); }
@@ -58,6 +59,11 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
   if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
   else run(k_parse, a, a.nshards, 64, reverse);
+  if (getenv("SIM_COUNTS")) {
+    fprintf(stderr, "sim counts: steps=%llu with_bucket_cand=%llu ext=%llu store_steps=%llu dict=%llu slow=%llu dup=%llu\n",
+            g_sim_counts[0], g_sim_counts[1], g_sim_counts[2], g_sim_counts[3], g_sim_counts[4], g_sim_counts[5], g_sim_counts[6]);
+    memset(g_sim_counts, 0, sizeof(g_sim_counts));
+  }
   size_t n = 0;
   stats[0] = stats[1] = stats[2] = 0;
   for (size_t k = 0; k < plan.shards.size(); ++k) {
