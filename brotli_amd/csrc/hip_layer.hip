@@ -404,7 +404,7 @@ bool stream_init(BrotliAmdStream* s, uint32_t stream_offset) {
   D.lits_off = off;  off = plan_align(off + (mb + 8) * 2);
   D.dsym_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * 2);
   D.mb_off = off;    off = plan_align(off + mb_work_bytes(mb));
-  D.scratch_off = off; off = plan_align(off + ((uint64_t)D.cmd_cap + mb + 64) * 4);
+  D.scratch_off = off; off = plan_align(off + (mb / 256 + 64) * 8 + (2 * mb + 64) * 4);
   HIP_OK(c, hipMalloc((void**)&s->d_ws, off));
   HIP_OK(c, hipMalloc((void**)&s->d_desc, sizeof(ShardDesc)));
   HIP_OK(c, hipMalloc((void**)&s->d_state, sizeof(ShardState)));

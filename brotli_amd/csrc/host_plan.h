@@ -92,7 +92,8 @@ static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_
     D.lits_off = off;  off = plan_align(off + (mb_len + 8) * 2);
     D.dsym_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * 2);
     D.mb_off = off;    off = plan_align(off + mb_work_bytes(mb_len));
-    D.scratch_off = off; off = plan_align(off + ((uint64_t)D.cmd_cap + mb_len + 64) * 4);
+    // k_store scratch: block-switch codes + two words per literal
+    D.scratch_off = off; off = plan_align(off + (mb_len / 256 + 64) * 8 + (2 * mb_len + 64) * 4);
     D.out_cap = 2 * n + 1024 + 16 * ((n >> J.lgblock) + 2);
     D.out_off = off;   off = plan_align(off + D.out_cap);
     max_out += D.out_cap;

@@ -433,6 +433,8 @@ struct StoreCtx {
   const uint16_t* lits;
   const uint16_t* dsym;
   uint64_t* sw;          // per category, per block: switch bits (low 56) | nbits << 56
+  uint32_t* lsum;        // [nlits + 1] bits of the literals before literal k
+  uint32_t* lcode;       // [nlits] code | length << 16 of literal k
   uint32_t sw_off[3];
   uint32_t nc;
   // per category views
@@ -489,7 +491,7 @@ DEV void zero_output(uint8_t* out, uint64_t from, uint64_t bytes) {
 }
 
 DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
-                     const DeviceTables* T, const uint8_t* input, uint8_t* ws) {
+                     const DeviceTables* T, const uint8_t* input, uint8_t* ws, uint32_t* lds_store) {
   const int lane = wave_lane();
   if (!S->mb_valid || S->error) return;
   const uint8_t* data = input + D.in_off;
@@ -523,7 +525,11 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     s.cmds = (const Command*)(ws + D.cmds_off);
     s.lits = (const uint16_t*)(ws + D.lits_off);
     s.dsym = (const uint16_t*)(ws + D.dsym_off);
+    // scratch: switch codes (<= mb / 256 + 64 blocks in total), then two words per literal
+    const uint32_t mb_cap = umin(D.len, J.max_metablock_size);
     s.sw = (uint64_t*)(ws + D.scratch_off);
+    s.lsum = (uint32_t*)(ws + D.scratch_off + ((uint64_t)mb_cap / 256u + 64u) * 8u);
+    s.lcode = s.lsum + (mb_cap + 16u);
     s.nc = s.info->num_contexts;
     const uint32_t alpha[3] = {256u, 704u, 64u};
     const uint32_t minb[3] = {MB_LIT_MIN_BLOCK, MB_CMD_MIN_BLOCK, MB_DIST_MIN_BLOCK};
@@ -773,8 +779,38 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
       sink_splice(sink, tree_bufs + (size_t)j * MB_TREE_BUF_BYTES, job_nbits[j]);
 
     SP_ADD(S, 4, spt);
-    // ---- phase 3: the commands, 64 per step ----
-    uint32_t lit_base = 0, dist_base = 0;
+    // ---- phase 3: the command stream ----
+    // (a) every literal of the meta-block, flat: code, length, and the running
+    //     sum of literal bits (lsum[k] = bits of literals [0, k)).
+    const uint32_t nlits = s.info->nlits;
+    uint32_t* lsum = s.lsum;
+    uint32_t* lcode = s.lcode;
+    {
+      uint32_t carry = 0;
+      for (uint32_t k0 = 0; k0 < nlits; k0 += 64) {
+        const uint32_t k = k0 + (uint32_t)lane;
+        uint32_t nb = 0;
+        if (k < nlits) {
+          const uint32_t v = s.lits[k];
+          const SymBits lb = symbol_bits<0>(s, k, v & 0xFFu, v >> 8);
+          nb = lb.nsw + lb.ncode;
+          lcode[k] = lb.code | (lb.ncode << 16);
+        }
+        const uint32_t incl = wave_incl_scan(nb);
+        if (k < nlits) lsum[k] = carry + incl - nb;
+        carry += wave_bcast(incl, 63);
+      }
+      if (lane == 0) lsum[nlits] = carry;
+      wave_sync();
+    }
+    // (b) 64 commands per step: command / distance codes per lane, a wave scan
+    //     for their offsets, then the literals of the step written flat (one
+    //     literal per lane; its command is found by a binary search over the
+    //     step's first-literal indices kept in LDS).
+    uint32_t* s_start = lds_store;        // [65]
+    uint32_t* s_base = lds_store + 65;    // [64] bit offset of literal 0 of the stream as seen from command c
+    const uint64_t bit_cmds = sink.bitpos;
+    uint32_t lit_base = 0, dist_base = 0, cbits = 0;
     for (uint32_t base = 0; base < ncmds; base += 64) {
       const uint32_t i = base + (uint32_t)lane;
       const bool valid = i < ncmds;
@@ -788,13 +824,12 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
       const uint32_t ins_incl = wave_incl_scan(ins);
       const uint32_t my_lit = lit_base + ins_incl - ins;
       const uint32_t my_dist = dist_base + (uint32_t)dev_popc64(dm & ((1ull << lane) - 1ull));
-      const bool is_long = ins >= 32u;
-
-      // command symbol + extra bits (StoreCommandExtra :82-93)
+      // command symbol + extra bits (StoreCommandExtra :82-93), distance symbol + extra
       uint64_t xv = 0;
       uint32_t cn = 0, xn = 0, dn = 0, dxn = 0;
       SymBits cb, db;
       cb.sw = db.sw = 0; cb.nsw = db.nsw = cb.code = db.code = cb.ncode = db.ncode = 0;
+      uint32_t ls = 0, le = 0;
       if (valid) {
         cb = symbol_bits<1>(s, i, c.cmd_prefix, 0);
         cn = cb.nsw + cb.ncode;
@@ -805,83 +840,54 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
         xv = ((uint64_t)(copylen_code - k_copy_base[copycode]) << insnumextra) |
              (uint64_t)(ins - k_ins_base[inscode]);
         xn = insnumextra + k_copy_extra[copycode];
+        ls = lsum[my_lit];
+        le = lsum[my_lit + ins];
       }
       if (has_dist) {
         db = symbol_bits<2>(s, my_dist, c.dist_prefix & 0x3FFu, 0);
         dn = db.nsw + db.ncode;
         dxn = c.dist_prefix >> 10;
       }
-      // literal bits of short runs
-      uint32_t ln = 0;
-      if (valid && !is_long) {
-        for (uint32_t j = 0; j < ins; ++j) {
-          const uint32_t v = s.lits[my_lit + j];
-          const SymBits lb = symbol_bits<0>(s, my_lit + j, v & 0xFFu, v >> 8);
-          ln += lb.nsw + lb.ncode;
-        }
-      }
-      // long runs: sized by the whole wave
-      const uint64_t longm = wave_ballot(valid && is_long);
-      for (uint64_t m = longm; m;) {
-        const int src = dev_ctz64(m);
-        m &= m - 1;
-        const uint32_t n = wave_bcast(ins, src), l0 = wave_bcast(my_lit, src);
-        uint32_t tot = 0;
-        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-          uint32_t nb = 0;
-          if (j0 + (uint32_t)lane < n) {
-            const uint32_t v = s.lits[l0 + j0 + (uint32_t)lane];
-            const SymBits lb = symbol_bits<0>(s, l0 + j0 + (uint32_t)lane, v & 0xFFu, v >> 8);
-            nb = lb.nsw + lb.ncode;
-          }
-          tot += wave_bcast(wave_incl_scan(nb), 63);
-        }
-        if (lane == src) ln = tot;
-      }
-      const uint32_t mybits = cn + xn + ln + dn + dxn;
-      const uint32_t bits_incl = wave_incl_scan(mybits);
-      uint64_t p = sink.bitpos + (bits_incl - mybits);
-      // write
+      const uint32_t own = cn + xn + dn + dxn;
+      const uint32_t own_incl = wave_incl_scan(own);
+      // bits before this command = codes of earlier commands + literals before its first literal
+      const uint64_t p0 = bit_cmds + cbits + (own_incl - own) + ls;
+      const uint32_t total_ins = wave_bcast(ins_incl, 63);
+      s_start[lane] = my_lit;
+      s_base[lane] = (uint32_t)(p0 + cn + xn - bit_cmds) - ls;
+      if (lane == 63) s_start[64] = lit_base + total_ins;
+      wave_sync();
       if (valid) {
-        or_sym(sink.base, p, cb); p += cn;
-        or_bits(sink.base, p, xn, xv); p += xn;
-        if (!is_long) {
-          for (uint32_t j = 0; j < ins; ++j) {
-            const uint32_t v = s.lits[my_lit + j];
-            const SymBits lb = symbol_bits<0>(s, my_lit + j, v & 0xFFu, v >> 8);
-            or_sym(sink.base, p, lb);
-            p += lb.nsw + lb.ncode;
-          }
-        }
-      }
-      for (uint64_t m = longm; m;) {
-        const int src = dev_ctz64(m);
-        m &= m - 1;
-        const uint32_t n = wave_bcast(ins, src), l0 = wave_bcast(my_lit, src);
-        uint64_t q = wave_bcast64(p, src);
-        for (uint32_t j0 = 0; j0 < n; j0 += 64) {
-          uint32_t nb = 0;
-          SymBits lb;
-          lb.sw = 0; lb.nsw = lb.code = lb.ncode = 0;
-          if (j0 + (uint32_t)lane < n) {
-            const uint32_t v = s.lits[l0 + j0 + (uint32_t)lane];
-            lb = symbol_bits<0>(s, l0 + j0 + (uint32_t)lane, v & 0xFFu, v >> 8);
-            nb = lb.nsw + lb.ncode;
-          }
-          const uint32_t incl = wave_incl_scan(nb);
-          or_sym(sink.base, q + (incl - nb), lb);
-          q += wave_bcast(incl, 63);
-        }
-        if (lane == src) p = q;
+        or_sym(sink.base, p0, cb);
+        or_bits(sink.base, p0 + cn, xn, xv);
       }
       if (has_dist) {
-        or_sym(sink.base, p, db); p += dn;
-        or_bits(sink.base, p, dxn, c.dist_extra);
+        const uint64_t pd = p0 + cn + xn + (le - ls);
+        or_sym(sink.base, pd, db);
+        or_bits(sink.base, pd + dn, dxn, c.dist_extra);
       }
-      sink.bitpos += wave_bcast(bits_incl, 63);
-      lit_base += wave_bcast(ins_incl, 63);
+      for (uint32_t L = lit_base + (uint32_t)lane; L < lit_base + total_ins; L += 64) {
+        uint32_t lo = 0, hi = 63;
+        while (lo < hi) {
+          const uint32_t mid = (lo + hi + 1) >> 1;
+          if (s_start[mid] <= L) lo = mid; else hi = mid - 1;
+        }
+        const uint64_t pos = bit_cmds + s_base[lo] + lsum[L];
+        if ((L % MB_LIT_MIN_BLOCK) == 0 && L != 0) {
+          // possibly the first literal of a block: re-derive the block switch
+          const uint32_t v = s.lits[L];
+          or_sym(sink.base, pos, symbol_bits<0>(s, L, v & 0xFFu, v >> 8));
+        } else {
+          const uint32_t lc = lcode[L];
+          or_bits(sink.base, pos, lc >> 16, lc & 0xFFFFu);
+        }
+      }
+      wave_sync();
+      cbits += wave_bcast(own_incl, 63);
+      lit_base += total_ins;
       dist_base += (uint32_t)dev_popc64(dm);
     }
+    sink.bitpos = bit_cmds + cbits + lsum[nlits];
     SP_ADD(S, 5, spt);
     if (is_last) sink.bitpos = (sink.bitpos + 7u) & ~(uint64_t)7u;
     total_bits = sink.bitpos - bit0;

@@ -75,7 +75,8 @@ __global__ void __launch_bounds__(64, BUILD_WAVES) k_build(JobArgs a) {
 __global__ void __launch_bounds__(64, STORE_WAVES) k_store(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
-  store_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
+  __shared__ uint32_t lds_store[65 + 64];
+  store_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds_store);
   if (threadIdx.x == 0) {
     if (a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
     else if (!a.states[shard].done) glb_atomic_add(&a.counters[0], 1u);
