@@ -28,6 +28,13 @@ struct BrotliAmdCtx {
   DeviceTables* d_T = nullptr;
   uint8_t* d_ws = nullptr;
   uint64_t ws_cap = 0;
+  // Hash tables live in their own allocation: with the generation-stamped
+  // records of k_parse4 the memory is cleared once and reused by later jobs.
+  uint8_t* d_tables = nullptr;
+  uint64_t tables_cap = 0;
+  uint64_t tables_clean = 0;      // prefix that holds stamped records (or zeros)
+  uint32_t tables_epoch = 0;      // stamp of the last job
+  bool tables_quad = false;
   ShardDesc* d_shards = nullptr;
   ShardState* d_states = nullptr;
   uint64_t* d_scan = nullptr;       // nshards + 1 output offsets
@@ -91,6 +98,39 @@ bool ensure_log2(BrotliAmdCtx* c, uint32_t n) {
   return true;
 }
 
+// Points every shard at its table and makes the table memory usable for this
+// job: quad jobs get a fresh stamp (memset only when new memory, a format switch
+// or stamp exhaustion requires it); other jobs are cleared by k_init.
+bool prepare_tables(BrotliAmdCtx* c, JobPlan* plan) {
+  const uint64_t tbytes = (uint64_t)REC_BYTES << plan->J.bucket_bits;
+  const uint64_t need = tbytes * plan->shards.size();
+  const bool quad = (plan->J.flags & JOB_FLAG_QUAD) != 0;
+  if (need > c->tables_cap) {
+    if (c->d_tables) HIP_OK(c, hipFree(c->d_tables));
+    c->d_tables = nullptr;
+    c->tables_cap = 0;
+    c->tables_clean = 0;
+    HIP_OK(c, hipMalloc((void**)&c->d_tables, need));
+    c->tables_cap = need;
+  }
+  if (quad) {
+    if (!c->tables_quad || need > c->tables_clean || c->tables_epoch >= 0xFFFEu) {
+      HIP_OK(c, hipMemsetAsync(c->d_tables, 0, c->tables_cap, c->stream));
+      c->tables_clean = c->tables_cap;
+      c->tables_epoch = 0;
+    }
+    c->tables_quad = true;
+    plan->J.flags |= JOB_FLAG_LAZY_TABLES;
+    plan->J.epoch = ++c->tables_epoch;
+  } else {
+    c->tables_quad = false;
+    c->tables_clean = 0;
+  }
+  for (size_t k = 0; k < plan->shards.size(); ++k)
+    plan->shards[k].table_off = (uint64_t)(c->d_tables - c->d_ws) + k * tbytes;   // ws + off (mod 2^64)
+  return true;
+}
+
 bool ensure_ws(BrotliAmdCtx* c, uint64_t ws_bytes, uint64_t nshards) {
   if (ws_bytes > c->ws_cap) {
     if (c->d_ws) HIP_OK(c, hipFree(c->d_ws));
@@ -117,7 +157,7 @@ bool ensure_ws(BrotliAmdCtx* c, uint64_t ws_bytes, uint64_t nshards) {
 int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, JobPlan* plan) {
   if (len == 0) { fail(c, "empty job"); return BROTLI_AMD_UNSUPPORTED; }
   if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
-                p->is_last != 0, plan)) {
+                p->is_last != 0, plan, /*tables_in_ws=*/false)) {
     fail(c, "parameters outside the GPU path (quality %d lgwin %d)", p->quality, p->lgwin);
     return BROTLI_AMD_UNSUPPORTED;
   }
@@ -137,11 +177,13 @@ enum { STAGE_PARSE = 1, STAGE_BUILD = 2, STAGE_STORE = 4, STAGE_ALL = 7 };
 
 // Runs the job's rounds on the context stream.  On return (synchronised) the
 // shard states describe the outputs sitting in the workspace.
-bool run_rounds(BrotliAmdCtx* c, const JobPlan& plan, const uint8_t* d_in, int stages,
+bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
                 BrotliAmdJobInfo* info, std::vector<ShardState>* states_out) {
   const uint32_t nshards = (uint32_t)plan.shards.size();
   if (!ensure_log2(c, plan.J.log2_lut_size)) return false;
   if (!ensure_ws(c, plan.ws_bytes, nshards)) return false;
+  HIP_OK(c, hipEventRecord(c->ev[0], c->stream));
+  if (!prepare_tables(c, &plan)) return false;
   HIP_OK(c, hipMemcpyAsync(c->d_shards, plan.shards.data(), nshards * sizeof(ShardDesc),
                            hipMemcpyHostToDevice, c->stream));
   JobArgs a;
@@ -161,7 +203,6 @@ bool run_rounds(BrotliAmdCtx* c, const JobPlan& plan, const uint8_t* d_in, int s
   a.init_blocks_per_shard = ibs;
 
   float ms_parse = 0, ms_build = 0, ms_store = 0;
-  HIP_OK(c, hipEventRecord(c->ev[0], c->stream));
   hipLaunchKernelGGL(k_init, dim3(nshards * ibs), dim3(256), 0, c->stream, a);
   HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
   uint32_t rounds = 0;
@@ -246,7 +287,7 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_lut, c->d_dict, c->d_hash_words, c->d_hash_lengths, c->d_log2, c->d_T,
-                  c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters,
+                  c->d_ws, c->d_tables, c->d_shards, c->d_states, c->d_scan, c->d_counters,
                   c->d_stage_in, c->d_stage_out};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);

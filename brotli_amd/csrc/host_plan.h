@@ -56,7 +56,7 @@ static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobPa
 // Partition plan + workspace layout.  shard_size == 0: one shard (Mode S).
 static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_hint,
                             uint64_t shard_size, uint64_t stream_base, bool is_last,
-                            JobPlan* plan) {
+                            JobPlan* plan, bool tables_in_ws = true) {
   if (size_hint == 0) {
     const uint64_t tot = stream_base + len;
     size_hint = tot >= (1u << 30) ? (1u << 30) : (uint32_t)tot;
@@ -87,7 +87,10 @@ static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_
     D.final_op = (k + 1 == nshards && is_last) ? 2u : 1u;
     D.cmd_cap = (uint32_t)(n / 2 + (n >> J.lgblock) + 16);
     const uint64_t mb_len = n < J.max_metablock_size ? n : J.max_metablock_size;
-    D.table_off = off; off = plan_align(off + ((uint64_t)REC_BYTES << J.bucket_bits));
+    // The HIP layer keeps the hash tables in their own allocation (and patches
+    // table_off); the simulator carves them out of the workspace.
+    D.table_off = off;
+    if (tables_in_ws) off = plan_align(off + ((uint64_t)REC_BYTES << J.bucket_bits));
     D.cmds_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * sizeof(Command));
     D.lits_off = off;  off = plan_align(off + (mb_len + 8) * 2);
     D.dsym_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * 2);

@@ -58,6 +58,18 @@ DEV void or_bits(uint32_t* base, uint64_t pos, uint32_t n, uint64_t v) {
   if (w1) glb_atomic_or(base + w + 1, w1);
   if (w2) glb_atomic_or(base + w + 2, w2);
 }
+// The same into an LDS window whose dword 0 starts at bit 0 of `w`.
+DEV void lds_or_bits(uint32_t* w, uint32_t pos, uint32_t n, uint64_t v) {
+  if (n == 0) return;
+  if (n < 64) v &= (1ull << n) - 1ull;
+  const uint32_t d = pos >> 5, sh = pos & 31u;
+  const uint64_t lo = v << sh;
+  const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
+  const uint32_t w2 = sh ? (uint32_t)(v >> (64u - sh)) : 0u;
+  if (w0) lds_atomic_or(w + d, w0);
+  if (w1) lds_atomic_or(w + d + 1, w1);
+  if (w2) lds_atomic_or(w + d + 2, w2);
+}
 // Uniform call: lane 0 writes, every lane advances.
 DEV void sink_put(BitSink& s, uint32_t n, uint64_t v) {
   if (wave_lane() == 0) or_bits(s.base, s.bitpos, n, v);
@@ -83,6 +95,8 @@ DEV void sink_varlen_uint8(BitSink& s, uint32_t n) {   // StoreVarLenUint8
     sink_put(s, nbits, n - (1u << nbits));
   }
 }
+
+#define STORE_WIN_DW 2048u   // LDS output window of the command stream (64 Kbit)
 
 // ---- prefix-code construction (one lane) ---------------------------------------
 struct HNode { uint32_t total_count; int16_t left; int16_t right_or_value; };
@@ -806,10 +820,19 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     // (b) 64 commands per step: command / distance codes per lane, a wave scan
     //     for their offsets, then the literals of the step written flat (one
     //     literal per lane; its command is found by a binary search over the
-    //     step's first-literal indices kept in LDS).
+    //     step's first-literal indices kept in LDS).  The bits of a step are
+    //     OR-ed into an LDS window (ds_or) and leave as whole dwords with plain
+    //     coalesced stores; only a step whose span exceeds the window (a very
+    //     long literal run) goes to HBM with dword atomics.
     uint32_t* s_start = lds_store;        // [65]
     uint32_t* s_base = lds_store + 65;    // [64] bit offset of literal 0 of the stream as seen from command c
+    uint32_t* W = lds_store + 132;        // [STORE_WIN_DW + 4] output window
     const uint64_t bit_cmds = sink.bitpos;
+    uint64_t wbit = bit_cmds & ~(uint64_t)31;   // bit position of W[0]
+    for (uint32_t j = (uint32_t)lane; j < STORE_WIN_DW + 4u; j += 64) W[j] = 0;
+    wave_mem_barrier();                   // header atomics have landed
+    if (lane == 0) W[0] = glb_atomic_or(sink.base + (wbit >> 5), 0u);
+    wave_sync();
     uint32_t lit_base = 0, dist_base = 0, cbits = 0;
     for (uint32_t base = 0; base < ncmds; base += 64) {
       const uint32_t i = base + (uint32_t)lane;
@@ -853,18 +876,39 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
       // bits before this command = codes of earlier commands + literals before its first literal
       const uint64_t p0 = bit_cmds + cbits + (own_incl - own) + ls;
       const uint32_t total_ins = wave_bcast(ins_incl, 63);
+      const uint32_t total_own = wave_bcast(own_incl, 63);
+      const uint64_t span_end = bit_cmds + cbits + total_own + lsum[lit_base + total_ins];
+      const bool in_window = span_end - wbit <= (uint64_t)STORE_WIN_DW * 32u;
       s_start[lane] = my_lit;
       s_base[lane] = (uint32_t)(p0 + cn + xn - bit_cmds) - ls;
       if (lane == 63) s_start[64] = lit_base + total_ins;
-      wave_sync();
-      if (valid) {
-        or_sym(sink.base, p0, cb);
-        or_bits(sink.base, p0 + cn, xn, xv);
+      if (!in_window) {
+        // hand the partial dword back to memory; this step uses HBM atomics
+        if (lane == 0 && W[0]) glb_atomic_or(sink.base + (wbit >> 5), W[0]);
+        if (lane == 0) W[0] = 0;
       }
-      if (has_dist) {
-        const uint64_t pd = p0 + cn + xn + (le - ls);
-        or_sym(sink.base, pd, db);
-        or_bits(sink.base, pd + dn, dxn, c.dist_extra);
+      wave_sync();
+      const uint64_t pd = p0 + cn + xn + (le - ls);
+      if (in_window) {
+        if (valid) {
+          lds_or_bits(W, (uint32_t)(p0 - wbit), cb.nsw, cb.sw);
+          lds_or_bits(W, (uint32_t)(p0 - wbit) + cb.nsw, cb.ncode, cb.code);
+          lds_or_bits(W, (uint32_t)(p0 - wbit) + cn, xn, xv);
+        }
+        if (has_dist) {
+          lds_or_bits(W, (uint32_t)(pd - wbit), db.nsw, db.sw);
+          lds_or_bits(W, (uint32_t)(pd - wbit) + db.nsw, db.ncode, db.code);
+          lds_or_bits(W, (uint32_t)(pd - wbit) + dn, dxn, c.dist_extra);
+        }
+      } else {
+        if (valid) {
+          or_sym(sink.base, p0, cb);
+          or_bits(sink.base, p0 + cn, xn, xv);
+        }
+        if (has_dist) {
+          or_sym(sink.base, pd, db);
+          or_bits(sink.base, pd + dn, dxn, c.dist_extra);
+        }
       }
       for (uint32_t L = lit_base + (uint32_t)lane; L < lit_base + total_ins; L += 64) {
         uint32_t lo = 0, hi = 63;
@@ -873,21 +917,52 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
           if (s_start[mid] <= L) lo = mid; else hi = mid - 1;
         }
         const uint64_t pos = bit_cmds + s_base[lo] + lsum[L];
+        SymBits lb;
+        lb.sw = 0; lb.nsw = 0;
         if ((L % MB_LIT_MIN_BLOCK) == 0 && L != 0) {
           // possibly the first literal of a block: re-derive the block switch
           const uint32_t v = s.lits[L];
-          or_sym(sink.base, pos, symbol_bits<0>(s, L, v & 0xFFu, v >> 8));
+          lb = symbol_bits<0>(s, L, v & 0xFFu, v >> 8);
         } else {
           const uint32_t lc = lcode[L];
-          or_bits(sink.base, pos, lc >> 16, lc & 0xFFFFu);
+          lb.code = lc & 0xFFFFu;
+          lb.ncode = lc >> 16;
+        }
+        if (in_window) {
+          lds_or_bits(W, (uint32_t)(pos - wbit), lb.nsw, lb.sw);
+          lds_or_bits(W, (uint32_t)(pos - wbit) + lb.nsw, lb.ncode, lb.code);
+        } else {
+          or_sym(sink.base, pos, lb);
         }
       }
       wave_sync();
-      cbits += wave_bcast(own_incl, 63);
+      if (in_window) {
+        // whole dwords leave the window; the partial one moves to W[0]
+        const uint32_t ndw = (uint32_t)((span_end - wbit) >> 5);
+        const uint32_t carry = W[ndw];
+        wave_sync();
+        uint32_t* dst = sink.base + (wbit >> 5);
+        for (uint32_t j = (uint32_t)lane; j <= ndw; j += 64) {
+          if (j < ndw) dst[j] = W[j];
+          W[j] = 0;
+        }
+        wave_sync();
+        if (lane == 0) W[0] = carry;
+        wbit += (uint64_t)ndw * 32u;
+      } else {
+        wave_mem_barrier();
+        wbit = span_end & ~(uint64_t)31;
+        if (lane == 0) W[0] = glb_atomic_or(sink.base + (wbit >> 5), 0u);
+      }
+      wave_sync();
+      cbits += total_own;
       lit_base += total_ins;
       dist_base += (uint32_t)dev_popc64(dm);
     }
     sink.bitpos = bit_cmds + cbits + lsum[nlits];
+    // the last partial dword
+    if (lane == 0 && W[0]) sink.base[wbit >> 5] = W[0];
+    wave_sync();
     SP_ADD(S, 5, spt);
     if (is_last) sink.bitpos = (sink.bitpos + 7u) & ~(uint64_t)7u;
     total_bits = sink.bitpos - bit0;

@@ -38,9 +38,10 @@ __global__ void __launch_bounds__(256) k_init(JobArgs a) {
   const uint32_t b = blockIdx.x % a.init_blocks_per_shard;
   if (shard >= a.nshards) return;
   const ShardDesc& D = a.shards[shard];
-  init_shard_table(a.ws + D.table_off, 1u << a.J.bucket_bits,
-                   b * blockDim.x + threadIdx.x, a.init_blocks_per_shard * blockDim.x,
-                   (a.J.flags & JOB_FLAG_QUAD) != 0);
+  if (!(a.J.flags & JOB_FLAG_LAZY_TABLES))
+    init_shard_table(a.ws + D.table_off, 1u << a.J.bucket_bits,
+                     b * blockDim.x + threadIdx.x, a.init_blocks_per_shard * blockDim.x,
+                     (a.J.flags & JOB_FLAG_QUAD) != 0);
   if (b == 0 && threadIdx.x == 0) init_shard_state(a.J, D, &a.states[shard]);
 }
 
@@ -75,7 +76,7 @@ __global__ void __launch_bounds__(64, BUILD_WAVES) k_build(JobArgs a) {
 __global__ void __launch_bounds__(64, STORE_WAVES) k_store(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
-  __shared__ uint32_t lds_store[65 + 64];
+  __shared__ uint32_t lds_store[132 + STORE_WIN_DW + 4];
   store_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds_store);
   if (threadIdx.x == 0) {
     if (a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
