@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size-mb", type=int, default=1024, help="input MiB per GPU")
-    ap.add_argument("--shard-kb", type=int, default=256, help="partition plan: KiB per encoder shard")
+    ap.add_argument("--shard-kb", type=int, default=128, help="partition plan: KiB per encoder shard")
     ap.add_argument("--quality", type=int, default=5)
     ap.add_argument("--lgwin", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -127,7 +127,7 @@ def main():
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                  % (args.gpus, args.gpus))
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):   # the latter: exercise the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -213,7 +213,7 @@ def main():
                 "stage_ms": {k: round(sum(i[k] for i in infos) / len(infos), 3) for k in
                              ("ms_total", "ms_init", "ms_parse", "ms_build", "ms_store", "ms_gather")},
             },
-            "roofline": {"bound": "hbm", "kernel": "k_parse", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_parse4", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic,
                          "note": "algorithmic bytes = 48 B per input byte x %d bytes per launch; "

@@ -42,13 +42,11 @@ struct JobParams {
   uint32_t max_metablock_size, max_literals, max_commands;  // encode.c:1142-1145
   uint32_t log2_lut_size;
   uint32_t flags;
-  uint32_t epoch;               // JOB_FLAG_LAZY_TABLES: generation stamp of this job's records
 };
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
 #define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal
 #define JOB_FLAG_FORCE_SLOW 4u // k_parse4: always take the step-by-step candidate resolve
 #define JOB_FLAG_NO_HEADER 8u  // stream header already emitted: shard 0 starts byte aligned
-#define JOB_FLAG_LAZY_TABLES 16u  // k_parse4: records carry a generation stamp; k_init leaves the tables alone
 
 // Per-shard description written by the host.
 struct ShardDesc {

@@ -28,13 +28,10 @@ struct BrotliAmdCtx {
   DeviceTables* d_T = nullptr;
   uint8_t* d_ws = nullptr;
   uint64_t ws_cap = 0;
-  // Hash tables live in their own allocation: with the generation-stamped
-  // records of k_parse4 the memory is cleared once and reused by later jobs.
+  // Hash tables live in their own allocation.
   uint8_t* d_tables = nullptr;
   uint64_t tables_cap = 0;
-  uint64_t tables_clean = 0;      // prefix that holds stamped records (or zeros)
-  uint32_t tables_epoch = 0;      // stamp of the last job
-  bool tables_quad = false;
+
   ShardDesc* d_shards = nullptr;
   ShardState* d_states = nullptr;
   uint64_t* d_scan = nullptr;       // nshards + 1 output offsets
@@ -98,33 +95,17 @@ bool ensure_log2(BrotliAmdCtx* c, uint32_t n) {
   return true;
 }
 
-// Points every shard at its table and makes the table memory usable for this
-// job: quad jobs get a fresh stamp (memset only when new memory, a format switch
-// or stamp exhaustion requires it); other jobs are cleared by k_init.
+// Points every shard at its table (own allocation, 128 B * 2^bucket_bits per
+// shard; cleared by k_init at the start of every job).
 bool prepare_tables(BrotliAmdCtx* c, JobPlan* plan) {
   const uint64_t tbytes = (uint64_t)REC_BYTES << plan->J.bucket_bits;
   const uint64_t need = tbytes * plan->shards.size();
-  const bool quad = (plan->J.flags & JOB_FLAG_QUAD) != 0;
   if (need > c->tables_cap) {
     if (c->d_tables) HIP_OK(c, hipFree(c->d_tables));
     c->d_tables = nullptr;
     c->tables_cap = 0;
-    c->tables_clean = 0;
     HIP_OK(c, hipMalloc((void**)&c->d_tables, need));
     c->tables_cap = need;
-  }
-  if (quad) {
-    if (!c->tables_quad || need > c->tables_clean || c->tables_epoch >= 0xFFFEu) {
-      HIP_OK(c, hipMemsetAsync(c->d_tables, 0, c->tables_cap, c->stream));
-      c->tables_clean = c->tables_cap;
-      c->tables_epoch = 0;
-    }
-    c->tables_quad = true;
-    plan->J.flags |= JOB_FLAG_LAZY_TABLES;
-    plan->J.epoch = ++c->tables_epoch;
-  } else {
-    c->tables_quad = false;
-    c->tables_clean = 0;
   }
   for (size_t k = 0; k < plan->shards.size(); ++k)
     plan->shards[k].table_off = (uint64_t)(c->d_tables - c->d_ws) + k * tbytes;   // ws + off (mod 2^64)

@@ -149,10 +149,11 @@ DEV void q_prefetch_record(QShard& g, bool act, uint32_t key) {
 // u8 aux}: lane t of a group owns entry t, so a probe is ONE dwordx2 load per
 // lane (one coalesced 128-byte access per group) and an insertion is one
 // 8-byte store.  The reference's 16-bit counter num_ lives in the aux bytes of
-// entries 0 (low byte) and 1 (high byte); entries 2 and 3 carry a 16-bit
-// generation stamp: with JOB_FLAG_LAZY_TABLES a record whose stamp differs from
-// the job's epoch is an empty bucket (Prepare(), ..64_simd_inc.h:81-98, becomes
-// free: the table memory is cleared once per allocation, not once per job).  (k_parse.h keeps its own
+// entries 0 (low byte) and 1 (high byte).  Two alternatives were measured on
+// MI355X and lost at the shard counts that matter (profiles/r01_g_*): a
+// generation stamp in entries 2 / 3 that makes clearing lazy (first touches
+// cost more than k_init saves above 64 KiB shards), and a separate dense
+// counter array (a second HBM line per bucket update).  (k_parse.h keeps its own
 // array-of-fields layout; k_init writes either, see init_shard_table.)
 DEV uint64_t q_entry(uint32_t pos, uint32_t tag2, uint32_t tag, uint32_t aux) {
   return (uint64_t)pos | ((uint64_t)(tag2 & 0xFFFFu) << 32) | ((uint64_t)(tag & 0xFFu) << 48) |
@@ -176,12 +177,10 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
   const bool any_dup = wave_any(dup);
   if (any_dup) SIM_COUNT(6, 1);                        // insertion steps with a key collision
   uint8_t* rec = g.table + (size_t)kt.key * REC_BYTES;
-  // entries 0 and 1 carry the counter, 2 and 3 the generation stamp
-  uint64_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-  if (act) { e0 = ld64(rec); e1 = ld64(rec + 8); e2 = ld64(rec + 16); e3 = ld64(rec + 24); }
-  const bool lazy = (J.flags & JOB_FLAG_LAZY_TABLES) != 0;
-  const bool stale = lazy && ((uint32_t)(e2 >> 56) | ((uint32_t)(e3 >> 56) << 8)) != J.epoch;
-  const uint32_t num = stale ? 0xFFFFu : ((uint32_t)(e0 >> 56) | ((uint32_t)(e1 >> 56) << 8));
+  // entries 0 and 1 carry the counter
+  uint64_t e0 = 0, e1 = 0;
+  if (act) { e0 = ld64(rec); e1 = ld64(rec + 8); }
+  const uint32_t num = (uint32_t)(e0 >> 56) | ((uint32_t)(e1 >> 56) << 8);
   wave_sync();
   uint32_t below = 0, total = 1;
   if (any_dup) {
@@ -199,8 +198,7 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
   }
   if (act) {
     const uint32_t s = (num - below) & 15u;
-    const uint32_t aux = s == 0 ? (uint32_t)(e0 >> 56) : s == 1 ? (uint32_t)(e1 >> 56) :
-                         s == 2 ? (uint32_t)(e2 >> 56) : s == 3 ? (uint32_t)(e3 >> 56) : 0u;
+    const uint32_t aux = s == 0 ? (uint32_t)(e0 >> 56) : s == 1 ? (uint32_t)(e1 >> 56) : 0u;
     const uint64_t e = q_entry(pos, kt.tag2, kt.tag, aux);
     __builtin_memcpy(rec + QREC_ENTRY(s), &e, 8);
   }
@@ -208,8 +206,7 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
   if (act && below + 1 == total) {
     const uint32_t nn = (num - total) & 0xFFFFu;
     rec[7] = (uint8_t)nn;
-    if (stale || (nn >> 8) != (num >> 8)) rec[15] = (uint8_t)(nn >> 8);
-    if (stale) { rec[23] = (uint8_t)J.epoch; rec[31] = (uint8_t)(J.epoch >> 8); }
+    if ((nn >> 8) != (num >> 8)) rec[15] = (uint8_t)(nn >> 8);
   }
   wave_sync();
 }
@@ -335,11 +332,8 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   const uint32_t tag2 = (uint32_t)(ent >> 32) & 0xFFFFu;
   const uint32_t tag = (uint32_t)(ent >> 48) & 0xFFu;
   const uint32_t aux = (uint32_t)(ent >> 56);
-  // aux bytes of entries 0..3 = counter | stamp << 16, gathered with one reduction
-  const uint32_t meta = q_or(t < 4 ? aux << (8 * t) : 0u);
-  const bool lazy = (J.flags & JOB_FLAG_LAZY_TABLES) != 0;
-  const bool stale = lazy && (meta >> 16) != J.epoch;
-  const uint32_t num = stale ? 0xFFFFu : (meta & 0xFFFFu);
+  // aux bytes of entries 0 and 1 = the counter, gathered with one reduction
+  const uint32_t num = q_or(t < 2 ? aux << (8 * t) : 0u);
   const uint32_t head = (num + 1u) & 15u;
   const uint32_t n = (65535u - num) & 0xFFFFu;
   const uint32_t logical = ((uint32_t)t - head) & 15u;   // 0 = newest
@@ -427,9 +421,8 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
     const uint32_t ts = num & 15u, nn = (num - 1u) & 0xFFFFu;
     const bool mine = (uint32_t)t == ts;
     const bool hi_changed = (nn >> 8) != (num >> 8);
-    if (want && (mine || t == 0 || (t == 1 && hi_changed) || (stale && t < 4))) {
-      const uint32_t naux = t == 0 ? (nn & 0xFFu) : t == 1 ? (nn >> 8) :
-                            t == 2 ? (J.epoch & 0xFFu) : t == 3 ? (J.epoch >> 8) : 0u;
+    if (want && (mine || t == 0 || (t == 1 && hi_changed))) {
+      const uint32_t naux = t == 0 ? (nn & 0xFFu) : t == 1 ? (nn >> 8) : 0u;
       const uint64_t e = mine ? q_entry(P, kt.tag2, kt.tag, naux) : q_entry(slot, tag2, tag, naux);
       __builtin_memcpy(g.table + (size_t)kt.key * REC_BYTES + QREC_ENTRY(t), &e, 8);
     }

@@ -38,8 +38,7 @@ __global__ void __launch_bounds__(256) k_init(JobArgs a) {
   const uint32_t b = blockIdx.x % a.init_blocks_per_shard;
   if (shard >= a.nshards) return;
   const ShardDesc& D = a.shards[shard];
-  if (!(a.J.flags & JOB_FLAG_LAZY_TABLES))
-    init_shard_table(a.ws + D.table_off, 1u << a.J.bucket_bits,
+  init_shard_table(a.ws + D.table_off, 1u << a.J.bucket_bits,
                      b * blockDim.x + threadIdx.x, a.init_blocks_per_shard * blockDim.x,
                      (a.J.flags & JOB_FLAG_QUAD) != 0);
   if (b == 0 && threadIdx.x == 0) init_shard_state(a.J, D, &a.states[shard]);

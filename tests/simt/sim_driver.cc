@@ -109,29 +109,6 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   a.init_blocks_per_shard = 2;
   uint32_t counters[16] = {0};
   a.counters = counters;
-  // flags & 32 (simulator only): lazily initialised tables.  The table memory
-  // is zeroed once, a job with stamp 1 encodes a scrambled copy of the input,
-  // then the real input is encoded with stamp 2 on the SAME table memory.
-  if ((flags & 32) && (plan.J.flags & JOB_FLAG_QUAD)) {
-    a.J.flags = (a.J.flags & ~32u) | JOB_FLAG_LAZY_TABLES;
-    for (size_t k = 0; k < plan.shards.size(); ++k)
-      memset(ws.data() + plan.shards[k].table_off, 0, (size_t)REC_BYTES << plan.J.bucket_bits);
-    std::vector<uint8_t> scrambled(input);
-    for (size_t i = 0; i + 1 < len; i += 2) { uint8_t t = scrambled[i]; scrambled[i] = scrambled[i + 1]; scrambled[i + 1] = (uint8_t)(t ^ 1); }
-    a.J.epoch = 1;
-    a.input = scrambled.data();
-    run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
-    for (int round = 0; round < 100000; ++round) {
-      memset(counters, 0, sizeof(counters));
-      run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
-      run(k_build, a, a.nshards, 64, reverse);
-      run(k_store, a, a.nshards, 64, reverse);
-      if (counters[1]) return -5;
-      if (counters[0] == 0) break;
-    }
-    a.J.epoch = 2;
-    a.input = input.data();
-  }
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
   for (int round = 0; round < 100000; ++round) {
     memset(counters, 0, sizeof(counters));

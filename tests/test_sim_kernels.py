@@ -78,14 +78,6 @@ def test_quad_kernel_bytes_match_oracle(sim, oracle, name, flags):
     assert sim.encode(data, 5, 22, hint, shard, flags=flags) == _oracle_plan(oracle, data, hint, shard)
 
 
-@pytest.mark.parametrize("name", ["text_hint_2shards", "mixed", "text_then_random", "zeros", "alice_48k"])
-def test_quad_kernel_lazy_tables_reuse(sim, oracle, name):
-    """Generation-stamped bucket records: a second job on table memory that a
-    different job (stamp 1) has filled gives the oracle's bytes (flags 2 + 32)."""
-    data, hint, shard = CASES[name]
-    assert sim.encode(data, 5, 22, hint, shard, flags=2 | 32) == _oracle_plan(oracle, data, hint, shard)
-
-
 def test_quad_kernel_many_shards_reverse(sim, oracle):
     """7 shards over 2 waves (one group idle), lanes scheduled high-to-low."""
     data = G.enwik_text(70000, seed=13, vocab=3000)
