@@ -84,7 +84,7 @@ struct ShardState {
   uint32_t mb_num_contexts, mb_context_map_id;
   uint64_t out_bytes;        // whole bytes already final in the shard output
   uint64_t stat_searches, stat_pairs, stat_b_used;
-  uint64_t prof[8];          // -DQ_PROFILE: cycles per phase of k_parse4
+  uint64_t prof[12];         // -DQ_PROFILE: cycles per phase of k_parse4
 };
 
 // Constant tables uploaded once per context.

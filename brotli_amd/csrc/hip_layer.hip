@@ -340,7 +340,7 @@ int brotli_amd_encode_device(BrotliAmdCtx* c, const void* d_in, uint64_t len,
     {  // prof_out: phase cycles of the store kernel, summed over shards
       std::vector<ShardState> st(nshards);
       HIP_OK(c, hipMemcpy(st.data(), c->d_states, nshards * sizeof(ShardState), hipMemcpyDeviceToHost));
-      for (uint32_t k = 0; k < nshards; ++k) for (int i = 0; i < 8; ++i) info->prof[i] += st[k].prof[i];
+      for (uint32_t k = 0; k < nshards; ++k) for (int i = 0; i < 12; ++i) info->prof[i] += st[k].prof[i];
     }
 #endif
     return true;
@@ -582,7 +582,7 @@ int brotli_amd_debug_parse(BrotliAmdCtx* c, const void* d_in, uint64_t len,
     const uint64_t m = st[k].ncmds;
     info->searches += st[k].stat_searches;
     info->search_steps += st[k].stat_pairs;
-    for (int i = 0; i < 8; ++i) info->prof[i] += st[k].prof[i];
+    for (int i = 0; i < 12; ++i) info->prof[i] += st[k].prof[i];
     if (n + m <= cmd_cap && m) {
       if (hipMemcpy(dst + n, c->d_ws + plan.shards[k].cmds_off, m * sizeof(Command),
                     hipMemcpyDeviceToHost) != hipSuccess) {

@@ -34,6 +34,7 @@
 
 #define LDS_ROW(A) ((A) + 1u)   // padded row: lanes walking different rows hit different banks
 #define BUILD_LDS_WORDS (13u * 257u)
+#define BUILD_TERMS 768u          // 3 x 256 (three literal evaluations at once) >= 704
 
 // Static literal context maps (encode.c:283-295, 347-364); index = map_kind.
 static __device__ const uint8_t k_ctx_maps[4][64] = {
@@ -84,6 +85,38 @@ DEV double estimate_entropy(const uint32_t* a, uint32_t n, const double* lut) {
   return (double)total * lut[total] - r;
 }
 
+// BitsEntropy (bit_cost.c:18-44) of `ne` histograms at once, whole wave: every
+// lane computes the p * log2(p) terms of a strided share of the entries into
+// LDS (independent, coalesced loads), then lane e < ne adds the terms of
+// histogram e in index order — the doubles are those of the reference's loop.
+// Histogram e is a[e][k] + g[e][k] (either may be null); results in out[e].
+DEV void bits_entropy_wave(const uint32_t* const* a, const uint32_t* const* g, uint32_t ne, uint32_t n,
+                           const double* lut, double* terms, uint32_t* sums, double* out) {
+  const int lane = wave_lane();
+  if ((uint32_t)lane < ne) sums[lane] = 0;
+  wave_sync();
+  for (uint32_t e = 0; e < ne; ++e) {
+    uint32_t part = 0;
+    for (uint32_t k = (uint32_t)lane; k < n; k += 64) {
+      const uint32_t p = (a[e] ? a[e][k] : 0u) + (g[e] ? g[e][k] : 0u);
+      terms[e * n + k] = (double)p * lut[p];
+      part += p;
+    }
+    if (part) lds_atomic_add(&sums[e], part);   // exact integer total of the histogram
+  }
+  wave_sync();
+  if ((uint32_t)lane < ne) {
+    const double* t = terms + (uint32_t)lane * n;
+    double r = 0.0;
+    for (uint32_t k = 0; k < n; ++k) r -= t[k];
+    const uint32_t sum = sums[lane];
+    if (sum) r += (double)sum * lut[sum];
+    if (r < (double)sum) r = (double)sum;
+    out[lane] = r;
+  }
+  wave_sync();
+}
+
 struct BuildCtx {
   const JobParams* J;
   const uint8_t* data;     // shard byte 0
@@ -94,8 +127,11 @@ struct BuildCtx {
   uint16_t* lits;
   uint16_t* dsym;
   uint32_t* lds;           // BUILD_LDS_WORDS
-  double* lds_ent;         // [3 * 13] entropies of the current decision
+  double* lds_ent;         // [3] results of one bits_entropy_wave call
+  double* lds_ent3;        // [3 * 13] entropies of the current decision
+  uint32_t* lds_sums;      // [3]
   double* lds_last;        // [2 * 13] last_entropy
+  double* lds_terms;       // [BUILD_TERMS] p * log2(p) terms of the histograms being evaluated
   uint32_t nc, map_kind;
 };
 
@@ -277,6 +313,7 @@ DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
   const double threshold = CAT == 0 ? 400.0 : CAT == 1 ? 500.0 : 100.0;
   const int lane = wave_lane();
   const uint32_t nc = CAT == 0 ? b.nc : 1u;
+  constexpr uint32_t EPR = (A * 3u <= BUILD_TERMS) ? 3u : 1u;   // evaluations per round
   const uint32_t max_types = MB_MAX_TYPES / nc;
   const double* lut2 = b.T->log2_lut;
   uint8_t* types = b.mb + b.L.types[CAT];
@@ -297,15 +334,27 @@ DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
     if (block_size < MINB) block_size = MINB;
     uint32_t blk_index;
     if (num_blocks == 0) {
-      if ((uint32_t)lane < nc) {
-        const double e = bits_entropy2(cur + (uint32_t)lane * ROW, nullptr, A, lut2);
-        b.lds_last[lane] = e;
-        b.lds_last[nc + (uint32_t)lane] = e;
-#if defined(BROTLI_AMD_SIMT_SIM)
-        if (getenv("SIM_DEBUG2")) { uint32_t t = 0; for (uint32_t k = 0; k < A; ++k) t += cur[lane * ROW + k]; fprintf(stderr, "cat %d first e=%f total=%u bs=%u\n", CAT, e, t, block_size); }
-#endif
+      if (nc > 3) {
+        if ((uint32_t)lane < nc) {
+          const double e = bits_entropy2(cur + (uint32_t)lane * ROW, nullptr, A, lut2);
+          b.lds_last[lane] = e;
+          b.lds_last[nc + (uint32_t)lane] = e;
+        }
+        wave_sync();
       }
-      wave_sync();   // entropies read before any lane clears the block
+      for (uint32_t i0 = 0; nc <= 3 && i0 < nc; i0 += EPR) {
+        const uint32_t ne = umin(EPR, nc - i0);
+        const uint32_t* ap[3];
+        const uint32_t* gp[3];
+        for (uint32_t e = 0; e < 3; ++e) { ap[e] = cur + (i0 + (e < ne ? e : 0)) * ROW; gp[e] = nullptr; }
+        bits_entropy_wave(ap, gp, ne, A, lut2, b.lds_terms, b.lds_sums, b.lds_ent);
+        if ((uint32_t)lane < ne) {
+          const double e = b.lds_ent[lane];
+          b.lds_last[i0 + (uint32_t)lane] = e;
+          b.lds_last[nc + i0 + (uint32_t)lane] = e;
+        }
+        wave_sync();
+      }
       if (lane == 0) { lengths[0] = block_size; types[0] = 0; }
       for (uint32_t k = (uint32_t)lane; k < nc * A; k += 64) {
         const uint32_t i = k / A, s = k % A;
@@ -319,21 +368,42 @@ DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
     } else {
       // lane = 3 * ctx + which: 0 current block, 1 merged with the last type,
       // 2 merged with the second last type.
-      if ((uint32_t)lane < 3u * nc) {
-        const uint32_t i = (uint32_t)lane / 3u, w = (uint32_t)lane % 3u;
-        const uint32_t* g = w == 0 ? nullptr : G + ((w == 1 ? last_t0 : last_t1) * nc + i) * A;
-        b.lds_ent[lane] = bits_entropy2(cur + i * ROW, g, A, lut2);
+      // For every context: the current block alone, merged with the last type
+      // and merged with the second last type (lds_ent3[3 * ctx + which]).
+      if (nc > 3) {
+        // 13 literal contexts: 39 independent evaluations, one lane each
+        if ((uint32_t)lane < 3u * nc) {
+          const uint32_t i = (uint32_t)lane / 3u, w = (uint32_t)lane % 3u;
+          const uint32_t* g = w == 0 ? nullptr : G + ((w == 1 ? last_t0 : last_t1) * nc + i) * A;
+          b.lds_ent3[lane] = bits_entropy2(cur + i * ROW, g, A, lut2);
+        }
+        wave_sync();
+      } else if (A * 3u <= BUILD_TERMS) {
+        for (uint32_t i = 0; i < nc; ++i) {
+          const uint32_t* ap[3] = {cur + i * ROW, cur + i * ROW, cur + i * ROW};
+          const uint32_t* gp[3] = {nullptr, G + (last_t0 * nc + i) * A, G + (last_t1 * nc + i) * A};
+          bits_entropy_wave(ap, gp, 3, A, lut2, b.lds_terms, b.lds_sums, b.lds_ent);
+          if (lane < 3) b.lds_ent3[3 * i + (uint32_t)lane] = b.lds_ent[lane];
+          wave_sync();
+        }
+      } else {
+        for (uint32_t w = 0; w < 3; ++w) {      // 704-symbol alphabet: one evaluation at a time
+          const uint32_t* ap[3] = {cur, cur, cur};
+          const uint32_t* gp[3] = {w == 0 ? nullptr : G + (w == 1 ? last_t0 : last_t1) * A, nullptr, nullptr};
+          bits_entropy_wave(ap, gp, 1, A, lut2, b.lds_terms, b.lds_sums, b.lds_ent);
+          if (lane == 0) b.lds_ent3[w] = b.lds_ent[0];
+          wave_sync();
+        }
       }
-      wave_sync();
       double diff0 = 0.0, diff1 = 0.0;
       for (uint32_t i = 0; i < nc; ++i) {
-        const double e = b.lds_ent[3 * i];
-        diff0 += b.lds_ent[3 * i + 1] - e - b.lds_last[i];
-        diff1 += b.lds_ent[3 * i + 2] - e - b.lds_last[nc + i];
+        const double e = b.lds_ent3[3 * i];
+        diff0 += b.lds_ent3[3 * i + 1] - e - b.lds_last[i];
+        diff1 += b.lds_ent3[3 * i + 2] - e - b.lds_last[nc + i];
       }
       wave_sync();
 #if defined(BROTLI_AMD_SIMT_SIM)
-      if (lane == 0 && getenv("SIM_DEBUG2")) fprintf(stderr, "cat %d nb=%u bs=%u e=%f c0=%f c1=%f l0=%f l1=%f d0=%f d1=%f\n", CAT, num_blocks, block_size, b.lds_ent[0], b.lds_ent[1], b.lds_ent[2], b.lds_last[0], b.lds_last[nc], diff0, diff1);
+      if (lane == 0 && getenv("SIM_DEBUG2")) fprintf(stderr, "cat %d nb=%u bs=%u e=%f c0=%f c1=%f l0=%f l1=%f d0=%f d1=%f\n", CAT, num_blocks, block_size, b.lds_ent3[0], b.lds_ent3[1], b.lds_ent3[2], b.lds_last[0], b.lds_last[nc], diff0, diff1);
 #endif
       if (num_types < max_types && diff0 > threshold && diff1 > threshold) {
         // New block type.
@@ -342,7 +412,7 @@ DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
         last_t0 = num_types;
         if ((uint32_t)lane < nc) {
           b.lds_last[nc + (uint32_t)lane] = b.lds_last[lane];
-          b.lds_last[lane] = b.lds_ent[3 * lane];
+          b.lds_last[lane] = b.lds_ent3[3 * lane];
         }
         uint32_t* dst = G + (size_t)num_types * nc * A;
         for (uint32_t k = (uint32_t)lane; k < nc * A; k += 64) {
@@ -362,7 +432,7 @@ DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
         const uint32_t t = last_t0; last_t0 = last_t1; last_t1 = t;
         if ((uint32_t)lane < nc) {
           b.lds_last[nc + (uint32_t)lane] = b.lds_last[lane];
-          b.lds_last[lane] = b.lds_ent[3 * lane + 2];
+          b.lds_last[lane] = b.lds_ent3[3 * lane + 2];
         }
         uint32_t* dst = G + (size_t)last_t0 * nc * A;
         for (uint32_t k = (uint32_t)lane; k < nc * A; k += 64) {
@@ -379,7 +449,7 @@ DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
         // Extend the last block.
         if (lane == 0) lengths[num_blocks - 1] += block_size;
         if ((uint32_t)lane < nc) {
-          b.lds_last[lane] = b.lds_ent[3 * lane + 1];
+          b.lds_last[lane] = b.lds_ent3[3 * lane + 1];
           if (num_types == 1) b.lds_last[nc + (uint32_t)lane] = b.lds_last[lane];
         }
         uint32_t* dst = G + (size_t)last_t0 * nc * A;
@@ -503,7 +573,7 @@ DEV void optimize_counts_for_rle(uint32_t length, uint32_t* counts, uint8_t* goo
 // ---- the round --------------------------------------------------------------------
 DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
                      const DeviceTables* T, const uint8_t* input, uint8_t* ws,
-                     uint32_t* lds, double* lds_ent, double* lds_last) {
+                     uint32_t* lds, double* lds_ent, double* lds_last, double* lds_terms) {
   const int lane = wave_lane();
   if (!S->mb_valid || S->error) return;
   BuildCtx b;
@@ -516,8 +586,11 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   b.lits = (uint16_t*)(ws + D.lits_off);
   b.dsym = (uint16_t*)(ws + D.dsym_off);
   b.lds = lds;
-  b.lds_ent = lds_ent;
+  b.lds_ent = lds_ent;               // [0..2] call results, [4..4+39) per-decision table
+  b.lds_ent3 = lds_ent + 4;
   b.lds_last = lds_last;
+  b.lds_terms = lds_terms;
+  b.lds_sums = (uint32_t*)(lds_terms + BUILD_TERMS);
   b.nc = 1;
   b.map_kind = 0;
 
@@ -550,16 +623,29 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   run_splitter<2>(b, ndist);
   BP_ADD(S, 4, bpt);
 
-  // BrotliOptimizeHistograms: one lane per histogram.
+  // BrotliOptimizeHistograms: one lane per histogram, but on LDS copies (the
+  // smoothing is a serial scan with data-dependent rewrites: ~5 passes of
+  // dependent accesses per entry).  Batches of as many histograms as fit the
+  // block-splitter's LDS row buffer; the flag bytes live in the term buffer.
   {
     const uint32_t nh[3] = {info->split[0].num_histograms, info->split[1].num_histograms,
                             info->split[2].num_histograms};
     const uint32_t alpha[3] = {256u, 704u, 64u};
-    uint8_t* good = b.mb + b.L.rle_flags + (size_t)lane * 704u;
+    uint8_t* flags = (uint8_t*)b.lds_terms;
     for (int c = 0; c < 3; ++c) {
       uint32_t* G = (uint32_t*)(b.mb + b.L.histos[c]);
-      for (uint32_t h = (uint32_t)lane; h < nh[c]; h += 64)
-        optimize_counts_for_rle(alpha[c], G + (size_t)h * alpha[c], good);
+      const uint32_t A = alpha[c];
+      uint32_t per = umin(BUILD_LDS_WORDS / A, (BUILD_TERMS * 8u) / A);
+      per = umin(per, 64u);
+      for (uint32_t h0 = 0; h0 < nh[c]; h0 += per) {
+        const uint32_t nb = umin(per, nh[c] - h0);
+        for (uint32_t k = (uint32_t)lane; k < nb * A; k += 64) b.lds[k] = G[(size_t)h0 * A + k];
+        wave_sync();
+        if ((uint32_t)lane < nb) optimize_counts_for_rle(A, b.lds + (uint32_t)lane * A, flags + (uint32_t)lane * A);
+        wave_sync();
+        for (uint32_t k = (uint32_t)lane; k < nb * A; k += 64) G[(size_t)h0 * A + k] = b.lds[k];
+        wave_sync();
+      }
     }
   }
   wave_sync();

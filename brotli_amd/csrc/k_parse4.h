@@ -83,7 +83,7 @@ struct QShard {
   // (consumed one step later so nothing waits on it) and a sink that keeps the
   // loads alive
   uint32_t pf_val, pf_acc;
-  uint64_t prof[8];
+  uint64_t prof[12];
 };
 
 DEV int q_t() { return wave_lane() & 15; }
@@ -326,6 +326,10 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   const uint32_t d_prev = P - backward;
   const B32 pd = load_b32(g.data + (d_cand ? d_prev : (want ? P : 0u)));
   const KeyTag kt = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits);
+#if defined(Q_PROFILE)
+  if (wave_any(want && kt.key == 0x7FFFFFFFu)) g.pf_acc++;   // (profiling fence: bytes at P consumed)
+#endif
+  QP_ADD(g, 8, qt);
   const uint8_t* rec = g.table + (size_t)kt.key * REC_BYTES;
   const uint64_t ent = ld64((want ? rec : g.table) + QREC_ENTRY(t));
   const uint32_t slot = (uint32_t)ent;
@@ -360,8 +364,16 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
       q_prefetch_record(g, want, k1.key);
     }
 #endif
-    const uint32_t mb = common_prefix32(cur32, pb);
     const uint32_t md = common_prefix32(cur32, pd);
+#if defined(Q_PROFILE)
+    if (wave_any(want && md == 77u)) g.pf_acc++;   // (profiling fence: distance-cache strings consumed)
+#endif
+    QP_ADD(g, 9, qt);
+    const uint32_t mb = common_prefix32(cur32, pb);
+#if defined(Q_PROFILE)
+    if (wave_any(want && mb == 77u)) g.pf_acc++;   // (profiling fence: bucket candidate strings consumed)
+#endif
+    QP_ADD(g, 10, qt);
     if (b_cand) { b_len = umin(mb, max_length); b_ext = mb == 32u && max_length > 32u; }
     if (d_cand) { d_len = umin(md, max_length); d_ext = md == 32u && max_length > 32u; }
   }
@@ -664,7 +676,7 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
   g.error = 0; g.have_mb = 0; g.done = 0;
   g.stat_searches = 0;
   g.pf_val = g.pf_acc = 0;
-  for (int i = 0; i < 8; ++i) g.prof[i] = 0;
+  for (int i = 0; i < 12; ++i) g.prof[i] = 0;
   g.state = (alive && !S->done && !S->mb_valid && !S->error) ? Q_PRE : Q_DONE;
   const bool participated = g.state != Q_DONE;
 
@@ -793,7 +805,7 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
     S->stat_pairs += g.stat_searches;
     S->stat_b_used = g.pf_acc ^ g.pf_val;   // keeps the prefetch loads observable
 #if defined(Q_PROFILE)
-    for (int i = 0; i < 8; ++i) S->prof[i] += g.prof[i];
+    for (int i = 0; i < 12; ++i) S->prof[i] += g.prof[i];
 #endif
   }
   wave_sync();

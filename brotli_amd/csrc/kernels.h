@@ -66,9 +66,10 @@ __global__ void __launch_bounds__(64, BUILD_WAVES) k_build(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
   __shared__ uint32_t lds[BUILD_LDS_WORDS];
-  __shared__ double lds_ent[3 * 13 + 1];
+  __shared__ double lds_ent[4 + 3 * 13 + 1];
   __shared__ double lds_last[2 * 13];
-  build_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds, lds_ent, lds_last);
+  __shared__ double lds_terms[BUILD_TERMS + 2];
+  build_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds, lds_ent, lds_last, lds_terms);
 }
 
 // grid = nshards, block = 64: bit-stream emission of the pending meta-block.

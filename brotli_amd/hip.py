@@ -34,7 +34,7 @@ class JobInfo(C.Structure):
                 ("ms_build", C.c_float), ("ms_store", C.c_float),
                 ("ms_gather", C.c_float), ("searches", C.c_uint64),
                 ("search_steps", C.c_uint64), ("commands", C.c_uint64),
-                ("prof", C.c_uint64 * 8)]
+                ("prof", C.c_uint64 * 12)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "prof")}

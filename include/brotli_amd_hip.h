@@ -74,7 +74,7 @@ typedef struct BrotliAmdJobInfo {
   uint64_t searches;        /* FindLongestMatch calls (reference count) */
   uint64_t search_steps;    /* paired search steps actually executed */
   uint64_t commands;
-  uint64_t prof[8];         /* debug_parse with a -DQ_PROFILE build: cycles per phase */
+  uint64_t prof[12];        /* debug_parse with a -DQ_PROFILE build: cycles per phase */
 } BrotliAmdJobInfo;
 
 /* `tables_path`: brotli_amd/data/brotli_tables.bin (RFC 7932 format data). */
