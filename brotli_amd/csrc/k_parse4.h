@@ -76,6 +76,10 @@ struct QShard {
   uint32_t st_first, st_count, st_stride;
   uint64_t st_x;          // bytes at st_first + t * st_stride, fetched ahead of the first step
   uint32_t st_x_valid;
+  // the 32 bytes at the next search position, requested at the end of a step so
+  // that they travel during the insertions (-DQ_NEXT32)
+  B32 n32;
+  uint32_t n32_pos;
   uint32_t state;
   uint32_t error, have_mb, done;
   uint32_t stat_searches;
@@ -317,7 +321,14 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   uint64_t qt = QP_NOW();
   // No branches around the first-round loads, so that the compiler can count
   // them precisely (s_waitcnt vmcnt(n)): idle lanes read offset 0.
+#if !defined(Q_NO_NEXT32)
+  B32 cur32 = g.n32;
+  if (wave_any(want && g.n32_pos != P)) {
+    if (want && g.n32_pos != P) cur32 = load_b32(g.data + P);
+  }
+#else
   const B32 cur32 = load_b32(g.data + (want ? P : 0u));
+#endif
   // The distance-cache probes (:201-240) depend only on P and the cache, not on
   // the hash table: their strings are requested right away, in the same round
   // trip as the bytes at P and overlapping the bucket-record access.
@@ -673,6 +684,8 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
   g.sr_len = g.sr_dist = 0; g.sr_score = K_MIN_SCORE; g.sr_delta = 0; g.delayed = 0;
   g.st_first = g.st_count = 0; g.st_stride = 1;
   g.st_x = 0; g.st_x_valid = 0;
+  g.n32.q[0] = g.n32.q[1] = g.n32.q[2] = g.n32.q[3] = 0;
+  g.n32_pos = 0xFFFFFFFFu;
   g.error = 0; g.have_mb = 0; g.done = 0;
   g.stat_searches = 0;
   g.pf_val = g.pf_acc = 0;
@@ -776,6 +789,15 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
         const bool pf = commit && g.position + htl < g.pos_end;
         if (pf) kn = hash_pos(ld64(g.data + g.position), J.hasher_type, J.bucket_bits);
         q_prefetch_record(g, pf, kn.key);
+      }
+#endif
+#if !defined(Q_NO_NEXT32)
+      {
+        // the next search position is settled: SEARCH at position, LAZY at position + 1
+        const bool nx = g.state == Q_SEARCH || g.state == Q_LAZY;
+        const uint32_t pn = g.position + (g.state == Q_LAZY ? 1u : 0u);
+        g.n32 = load_b32(g.data + (nx ? pn : 0u));
+        g.n32_pos = nx ? pn : 0xFFFFFFFFu;
       }
 #endif
       QP_ADD(g, 5, qt);
