@@ -23,13 +23,22 @@ DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 // first four bytes (enc_types.h).
 struct KeyTag { uint32_t key, tag, tag2; };
 
+// Bytes a hasher reads per position (HashTypeLength == StoreLookahead).
+DEV uint32_t hasher_htl(int hasher_type) { return (hasher_type == 68 || hasher_type == 6) ? 8u : 4u; }
+
 DEV KeyTag hash_pos(uint64_t x, int hasher_type, int bucket_bits) {
   KeyTag r;
   uint32_t h;
   if (hasher_type == 68) {
     h = (uint32_t)((x * (0x1FE35A7BD3579BD3ull << 24)) >> (64 - 15 - 8));
-  } else {
+  } else if (hasher_type == 58) {
     h = ((uint32_t)x * 0x1E35A7BDu) >> (32 - bucket_bits - 8);
+  } else if (hasher_type == 6) {
+    // H6, hash_longest_match64_inc.h:23-29: no tag
+    h = (uint32_t)((x * (0x1FE35A7BD3579BD3ull << 24)) >> (64 - 15)) << 8;
+  } else {
+    // H5, hash_longest_match_inc.h: 32-bit hash, no tag
+    h = (((uint32_t)x * 0x1E35A7BDu) >> (32 - bucket_bits)) << 8;
   }
   r.key = h >> 8;
   r.tag = h & 0xFF;

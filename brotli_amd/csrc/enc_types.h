@@ -42,11 +42,13 @@ struct JobParams {
   uint32_t max_metablock_size, max_literals, max_commands;  // encode.c:1142-1145
   uint32_t log2_lut_size;
   uint32_t flags;
+  uint32_t rec_bytes;           // bytes of one bucket record (128 for 16 slots, 8 per slot otherwise)
 };
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
 #define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal
 #define JOB_FLAG_FORCE_SLOW 4u // k_parse4: always take the step-by-step candidate resolve
 #define JOB_FLAG_NO_HEADER 8u  // stream header already emitted: shard 0 starts byte aligned
+#define JOB_FLAG_DEEP 16u      // one shard per wave, 32 .. 256 slots per bucket (k_parse_deep.h)
 
 // Per-shard description written by the host.
 struct ShardDesc {
@@ -55,7 +57,8 @@ struct ShardDesc {
   uint32_t stream_offset;  // already clamped as encode.c:678-682
   uint32_t final_op;       // 1 = FLUSH after the last byte, 2 = FINISH
   uint32_t cmd_cap;
-  uint64_t table_off;      // 128 B * (1 << bucket_bits)
+  uint64_t table_off;      // J.rec_bytes * (1 << bucket_bits)
+  uint64_t num_off;        // k_parse_deep: u16[1 << bucket_bits] bucket counters
   uint64_t cmds_off;       // Command[cmd_cap]
   uint64_t lits_off;       // u16[len + 8]: (literal | context << 8) in order
   uint64_t dsym_off;       // u16[cmd_cap]: distance symbols in order

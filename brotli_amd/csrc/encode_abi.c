@@ -163,13 +163,13 @@ static int ensure_initialized(BrotliEncoderState* s) {
   if (s->quality > 11) s->quality = 11;
   if (s->lgwin < 10) s->lgwin = 10;
   if (s->lgwin > 24 && !s->large_window) s->lgwin = 24;
-  /* What the kernels implement: quality 5, H68 / H58, default
-     block size, default distance parameters, no base64 regions, literal
-     context modelling on, the x86-64 default hashers. */
-  if (s->quality != 5 || s->lgwin < 17 || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
+  /* What the kernels implement: qualities 5..9 (H68 / H58 / H6 /
+     H5), default block size, default distance parameters, no base64 regions,
+     literal context modelling on, the x86-64 default hashers. */
+  if (s->quality < 5 || s->quality > 9 || s->lgwin < 17 || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
       s->mode == 2 /* FONT: non-zero distance parameters, encode.c:616-640 */ ||
       s->npostfix != 0 || s->ndirect != 0 || s->base64_mode != 0 || s->disable_ctx != 0 ||
-      s->simd_hasher == 2 /* BROTLI_SIMD_HASHER_DISABLE: H5 / H6 */) {
+      s->simd_hasher != 0 /* ENABLE / DISABLE change the hasher choice at q5-q7 */) {
     s->failed = 1;
     if (verbose())
       fprintf(stderr, "brotli_amd: parameters outside the GPU path (quality %d, lgwin %d); "
@@ -204,7 +204,25 @@ static int out_append(BrotliEncoderState* s, const uint8_t* p, size_t n) {
 
 /* Hands everything buffered to the device and applies `op` (1 flush, 2 finish). */
 static int submit(BrotliEncoderState* s, int op) {
-  if (s->shard_bytes == 0) {
+  if (s->shard_bytes == 0 && s->quality != 5) {
+    /* The device-resident single-shard stream exists for the 16-slot hashers
+       only; deeper qualities take a single stream as one shard at FINISH. */
+    if (op != OP_FINISH || s->submitted != 0) {
+      if (verbose()) fprintf(stderr, "brotli_amd: FLUSH needs quality 5 or a partition plan\n");
+      return 0;
+    }
+    if (s->in_len == 0) {
+      uint32_t bits, nbits, v;
+      uint8_t b[2];
+      if (s->stream_offset != 0) { b[0] = 3; return out_append(s, b, 1); }
+      window_bits(s->lgwin, &bits, &nbits);
+      v = bits | (3u << nbits);
+      nbits += 2;
+      b[0] = (uint8_t)v;
+      b[1] = (uint8_t)(v >> 8);
+      return out_append(s, b, (nbits + 7) >> 3);
+    }
+  } else if (s->shard_bytes == 0) {
     /* One encoder instance: the persistent device stream reproduces the
        reference for any op sequence. */
     const uint8_t* out;

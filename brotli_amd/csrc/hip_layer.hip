@@ -98,8 +98,10 @@ bool ensure_log2(BrotliAmdCtx* c, uint32_t n) {
 // Points every shard at its table (own allocation, 128 B * 2^bucket_bits per
 // shard; cleared by k_init at the start of every job).
 bool prepare_tables(BrotliAmdCtx* c, JobPlan* plan) {
-  const uint64_t tbytes = (uint64_t)REC_BYTES << plan->J.bucket_bits;
-  const uint64_t need = tbytes * plan->shards.size();
+  const uint64_t tbytes = (uint64_t)plan->J.rec_bytes << plan->J.bucket_bits;
+  const uint64_t nbytes = (plan->J.flags & JOB_FLAG_DEEP) ? ((uint64_t)2 << plan->J.bucket_bits) : 0;
+  const uint64_t n = plan->shards.size();
+  const uint64_t need = (tbytes + nbytes) * n;
   if (need > c->tables_cap) {
     if (c->d_tables) HIP_OK(c, hipFree(c->d_tables));
     c->d_tables = nullptr;
@@ -107,8 +109,11 @@ bool prepare_tables(BrotliAmdCtx* c, JobPlan* plan) {
     HIP_OK(c, hipMalloc((void**)&c->d_tables, need));
     c->tables_cap = need;
   }
-  for (size_t k = 0; k < plan->shards.size(); ++k)
+  uint8_t* nums = c->d_tables + tbytes * n;   // counters of all shards behind the records
+  for (uint64_t k = 0; k < n; ++k) {
     plan->shards[k].table_off = (uint64_t)(c->d_tables - c->d_ws) + k * tbytes;   // ws + off (mod 2^64)
+    plan->shards[k].num_off = (uint64_t)(nums - c->d_ws) + k * nbytes;
+  }
   return true;
 }
 
@@ -149,8 +154,17 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
   // see a candidate beyond the window.
   uint64_t longest = 0;
   for (const ShardDesc& D : plan->shards) if (D.len > longest) longest = D.len;
-  if (!(p->flags & BROTLI_AMD_FLAG_NO_QUAD) && longest <= plan->J.max_backward_limit)
-    plan->J.flags |= JOB_FLAG_QUAD;
+  if (plan->J.quality == 5) {
+    if (!(p->flags & BROTLI_AMD_FLAG_NO_QUAD) && longest <= plan->J.max_backward_limit)
+      plan->J.flags |= JOB_FLAG_QUAD;
+  } else {
+    // deep-bucket qualities: shards must fit the window (no ring-wrap rules in k_parse_deep.h)
+    if (longest > plan->J.max_backward_limit) {
+      fail(c, "quality %d needs shards of at most %u bytes", plan->J.quality, plan->J.max_backward_limit);
+      return BROTLI_AMD_UNSUPPORTED;
+    }
+    plan->J.flags |= JOB_FLAG_DEEP;
+  }
   return BROTLI_AMD_OK;
 }
 
@@ -190,7 +204,11 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
   for (;;) {
     HIP_OK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
     HIP_OK(c, hipEventRecord(c->ev[2], c->stream));
-    if (plan.J.flags & JOB_FLAG_QUAD)
+    if (plan.J.flags & JOB_FLAG_DEEP) {
+      if (plan.J.block_bits <= 6) hipLaunchKernelGGL(k_parse_deep<1>, dim3(nshards), dim3(64), 0, c->stream, a);
+      else if (plan.J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(nshards), dim3(64), 0, c->stream, a);
+      else hipLaunchKernelGGL(k_parse_deep<4>, dim3(nshards), dim3(64), 0, c->stream, a);
+    } else if (plan.J.flags & JOB_FLAG_QUAD)
       hipLaunchKernelGGL(k_parse4, dim3((nshards + 3) / 4), dim3(64), 0, c->stream, a);
     else
       hipLaunchKernelGGL(k_parse, dim3(nshards), dim3(64), 0, c->stream, a);
@@ -528,7 +546,7 @@ int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t s
   if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   BrotliAmdStream* s = new BrotliAmdStream();
   s->c = c;
-  if (!plan_params(quality, lgwin, size_hint, &s->J)) {
+  if (quality != 5 || !plan_params(quality, lgwin, size_hint, &s->J)) {   // k_parse.h: 16-slot buckets only
     delete s;
     fail(c, "parameters outside the GPU path (quality %d lgwin %d)", quality, lgwin);
     return BROTLI_AMD_UNSUPPORTED;

@@ -28,25 +28,27 @@ static inline uint64_t plan_align(uint64_t x) { return (x + 255u) & ~(uint64_t)2
 // parameter combinations this library does not implement on the GPU.
 static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobParams* J) {
   memset(J, 0, sizeof(*J));
-  if (quality < 5 || quality > 5) return false;      // block_bits 4 only (round 1)
+  if (quality < 5 || quality > 9) return false;      // q0-4 / q10-11: other algorithms
   if (lgwin < 17 || lgwin > 24) return false;        // H40-42 / large window: out of scope
   J->quality = quality;
   J->lgwin = lgwin;
   J->lgblock = 16;                                   // ComputeLgBlock, quality.h:75-92
+  if (quality >= 9) J->lgblock = lgwin < 18 ? lgwin : 18;
   J->size_hint = size_hint;
   if (size_hint >= (1u << 20) && lgwin >= 19) {      // ChooseHasher, quality.h:186-204
-    J->hasher_type = 68;
+    J->hasher_type = quality <= 6 ? 68 : 6;
     J->bucket_bits = 15;
   } else {
-    J->hasher_type = 58;
-    J->bucket_bits = 14;
+    J->hasher_type = quality <= 6 ? 58 : 5;
+    J->bucket_bits = quality < 7 ? 14 : 15;
   }
   J->block_bits = quality - 1;
-  J->ndist = 4;
+  J->ndist = quality < 7 ? 4 : quality < 9 ? 10 : 16;
+  J->rec_bytes = quality == 5 ? REC_BYTES : (8u << J->block_bits);
   const int rb_bits = 1 + (lgwin > J->lgblock ? lgwin : J->lgblock);
   J->ring_mask = (1u << rb_bits) - 1u;
   J->max_backward_limit = (1u << lgwin) - 16u;
-  J->spree_window = 64;
+  J->spree_window = quality < 9 ? 64 : 512;          // quality.h:116-119
   J->max_metablock_size = 1u << (rb_bits < 24 ? rb_bits : 24);
   J->max_literals = J->max_metablock_size / 8;
   J->max_commands = J->max_metablock_size / 8;
@@ -90,7 +92,9 @@ static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_
     // The HIP layer keeps the hash tables in their own allocation (and patches
     // table_off); the simulator carves them out of the workspace.
     D.table_off = off;
-    if (tables_in_ws) off = plan_align(off + ((uint64_t)REC_BYTES << J.bucket_bits));
+    if (tables_in_ws) off = plan_align(off + ((uint64_t)J.rec_bytes << J.bucket_bits));
+    D.num_off = off;
+    if (tables_in_ws) off = plan_align(off + ((uint64_t)2 << J.bucket_bits));
     D.cmds_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * sizeof(Command));
     D.lits_off = off;  off = plan_align(off + (mb_len + 8) * 2);
     D.dsym_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * 2);

@@ -57,6 +57,7 @@ struct QShard {
   // shard constants
   const uint8_t* data;
   uint8_t* table;
+  uint16_t* nums;          // k_parse_deep.h: bucket counters (separate array)
   Command* cmds;
   uint8_t* out;
   uint32_t len, stream_offset, final_op, cmd_cap;
@@ -477,7 +478,7 @@ DEV void q_flush_padding(QShard& g, bool writer) {
 DEV void q_driver_pre(const JobParams& J, QShard& g) {
   RoundRegs& r = g.r;
   const uint32_t block = 1u << J.lgblock;
-  const uint32_t htl = J.hasher_type == 68 ? 8u : 4u;
+  const uint32_t htl = hasher_htl(J.hasher_type);
   for (;;) {
     const uint32_t avail = g.len - r.input_pos;
     const uint32_t d = r.input_pos - r.last_processed_pos;
@@ -588,7 +589,7 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
 // CreateBackwardReferences prologue.
 DEV void q_setup_block(const JobParams& J, QShard& g, bool want, uint8_t* lds_dup) {
   const int t = q_t();
-  const uint32_t htl = J.hasher_type == 68 ? 8u : 4u;
+  const uint32_t htl = hasher_htl(J.hasher_type);
   // StitchToPreviousBlock (..64_simd_inc.h:139-151)
   if (want && g.want_stitch) {
     g.st_first = g.blk_pos - 3u;
@@ -661,7 +662,7 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
   const uint32_t shard = wave_index * Q_GROUPS + (uint32_t)(wave_lane() >> 4);
   const bool alive = shard < nshards;
   const bool writer = alive && t == 0;
-  const uint32_t htl = J.hasher_type == 68 ? 8u : 4u;
+  const uint32_t htl = hasher_htl(J.hasher_type);
   const ShardDesc& D = shards[alive ? shard : 0];
   ShardState* S = &states[alive ? shard : 0];
 

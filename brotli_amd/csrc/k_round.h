@@ -124,7 +124,7 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   c.hasher_type = J.hasher_type;
   c.bucket_bits = J.bucket_bits;
   c.ndist = J.ndist;
-  c.htl = J.hasher_type == 68 ? 8 : 4;
+  c.htl = (int)hasher_htl(J.hasher_type);
   c.ring_mask = J.ring_mask;
   c.ring_size = J.ring_mask + 1u;
   c.max_backward_limit = J.max_backward_limit;

@@ -6,6 +6,7 @@
 
 #include "k_round.h"
 #include "k_parse4.h"
+#include "k_parse_deep.h"
 
 // Register budgets (waves per SIMD the compiler must leave room for).
 #ifndef PARSE4_WAVES
@@ -38,9 +39,17 @@ __global__ void __launch_bounds__(256) k_init(JobArgs a) {
   const uint32_t b = blockIdx.x % a.init_blocks_per_shard;
   if (shard >= a.nshards) return;
   const ShardDesc& D = a.shards[shard];
-  init_shard_table(a.ws + D.table_off, 1u << a.J.bucket_bits,
+  if (a.J.flags & JOB_FLAG_DEEP) {
+    // only the counters: 0xFFFF counting down (H68 / H58), 0 counting up (H5 / H6)
+    uint32_t* nums = (uint32_t*)(a.ws + D.num_off);
+    const uint32_t v = a.J.hasher_type >= 58 ? 0xFFFFFFFFu : 0u;
+    for (uint32_t p = b * blockDim.x + threadIdx.x; p < (1u << a.J.bucket_bits) / 2u;
+         p += a.init_blocks_per_shard * blockDim.x) nums[p] = v;
+  } else {
+    init_shard_table(a.ws + D.table_off, 1u << a.J.bucket_bits,
                      b * blockDim.x + threadIdx.x, a.init_blocks_per_shard * blockDim.x,
                      (a.J.flags & JOB_FLAG_QUAD) != 0);
+  }
   if (b == 0 && threadIdx.x == 0) init_shard_state(a.J, D, &a.states[shard]);
 }
 
@@ -59,6 +68,16 @@ __global__ void __launch_bounds__(64, PARSE4_WAVES) k_parse4(JobArgs a) {
   const uint32_t shard = blockIdx.x * Q_GROUPS + (threadIdx.x >> 4);
   if ((threadIdx.x & 15) == 0 && shard < a.nshards && a.states[shard].error)
     glb_atomic_add(&a.counters[1], 1u);
+}
+
+// grid = nshards, block = 64: one shard per wave, E = slots / 64 entries per lane.
+template <int E>
+__global__ void __launch_bounds__(64, 2) k_parse_deep(JobArgs a) {
+  __shared__ uint8_t lds_dup[D_DUP_SLOTS];
+  const uint32_t shard = blockIdx.x;
+  if (shard >= a.nshards) return;
+  parse_deep_round<E>(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds_dup);
+  if (threadIdx.x == 0 && a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
 }
 
 // grid = nshards, block = 64: block splits, histograms, prefix codes.

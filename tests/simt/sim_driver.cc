@@ -38,6 +38,7 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   if (no_pair & 1) plan.J.flags |= JOB_FLAG_NO_PAIR;
   if (no_pair & 2) plan.J.flags |= JOB_FLAG_QUAD;
   if (no_pair & 4) plan.J.flags |= JOB_FLAG_FORCE_SLOW;
+  if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~JOB_FLAG_QUAD) | JOB_FLAG_DEEP;
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);
   std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
@@ -57,7 +58,11 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   uint32_t counters[16] = {0};
   a.counters = counters;
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
-  if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
+  if (plan.J.flags & JOB_FLAG_DEEP) {
+    if (plan.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
+    else if (plan.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
+    else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
+  } else if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
   else run(k_parse, a, a.nshards, 64, reverse);
   if (getenv("SIM_COUNTS")) {
     fprintf(stderr, "sim counts: steps=%llu with_bucket_cand=%llu ext=%llu store_steps=%llu dict=%llu slow=%llu dup=%llu\n",
@@ -91,6 +96,7 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   JobPlan plan;
   if (!plan_job(len, quality, lgwin, size_hint, shard_size, stream_base, is_last != 0, &plan)) return -2;
   plan.J.flags |= (uint32_t)flags;
+  if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~JOB_FLAG_QUAD) | JOB_FLAG_DEEP;
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);
   std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
@@ -112,7 +118,11 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
   for (int round = 0; round < 100000; ++round) {
     memset(counters, 0, sizeof(counters));
-    if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
+    if (plan.J.flags & JOB_FLAG_DEEP) {
+      if (plan.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
+      else if (plan.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
+      else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
+    } else if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
     else run(k_parse, a, a.nshards, 64, reverse);
     run(k_build, a, a.nshards, 64, reverse);
     if (getenv("SIM_DEBUG")) {

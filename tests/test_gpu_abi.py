@@ -114,6 +114,19 @@ def test_one_shot_empty_and_small_buffer(amd):
     assert not amd.BrotliEncoderCompress(5, 22, 0, len(ALICE), ALICE, C.byref(n), out)
 
 
+@pytest.mark.parametrize("quality,lgwin", [(6, 22), (9, 24)])
+def test_one_shot_deep_quality_equals_reference(amd, stock, quality, lgwin):
+    data = G.enwik_text(1 << 20, seed=29, vocab=10000)
+    outs = []
+    for L in (amd, stock):
+        cap = L.BrotliEncoderMaxCompressedSize(len(data))
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t(cap)
+        assert L.BrotliEncoderCompress(quality, lgwin, 0, len(data), data, C.byref(n), out)
+        outs.append(out.raw[:n.value])
+    assert outs[0] == outs[1]
+
+
 def test_unsupported_quality_fails_loudly(amd):
     out = C.create_string_buffer(1 << 20)
     n = C.c_size_t(1 << 20)

@@ -88,7 +88,7 @@ def test_golden_vectors(ctx):
     gold = json.load(open(os.path.join(HERE, "golden", "golden.json")))
     n = 0
     for case in gold["cases"]:
-        if case["quality"] != 5 or case["lgwin"] not in range(17, 25):
+        if case["quality"] not in range(5, 10) or case["lgwin"] not in range(17, 25):
             continue
         data = G.make(case["input"])
         if len(data) == 0:
@@ -112,6 +112,26 @@ def test_other_windows(ctx, oracle, lgwin):
         parts.append(oracle.encode_shard(data[off:off + m], 5, lgwin, n, off, off + m == n))
         off += m
     assert got == b"".join(parts)
+
+
+@pytest.mark.parametrize("quality,lgwin,shard", [(6, 22, 1 << 18), (7, 22, 1 << 18), (8, 20, 1 << 17),
+                                                 (9, 22, 1 << 20), (9, 24, 0), (9, 24, 1 << 19)])
+@pytest.mark.parametrize("name", ["text", "mixed", "text_rand_text"])
+def test_deep_qualities_equal_oracle(ctx, oracle, name, quality, lgwin, shard):
+    """BASELINE config 5 family: quality 9 / lgwin 24 (H6, 256-slot buckets, 16
+    distance-cache probes, 256 KiB input blocks, up to 3 literal contexts) and
+    qualities 6 - 8, single stream and partition plans."""
+    from brotli_amd import hip
+    data = {"text": TEXT4M, "mixed": G.mixed_corpus(2 << 20),
+            "text_rand_text": TEXT4M[:200000] + G.random_bytes(150000) + TEXT4M[:100000]}[name]
+    if shard == 0:
+        data = data[:3 << 20]
+    got, info = ctx.encode_host(data, hip.make_params(quality, lgwin, shard))
+    n = len(data)
+    s = shard or n
+    want = b"".join(oracle.encode_shard(data[o:o + s], quality, lgwin, min(n, 1 << 30), o, o + s >= n)
+                    for o in range(0, n, s))
+    assert got == want
 
 
 def test_multi_metablock_and_ring_wrap_single_stream(ctx, oracle):
@@ -139,6 +159,8 @@ def test_unsupported_parameters_fail_loudly(ctx):
     from brotli_amd import hip
     with pytest.raises(hip.BrotliAmdError):
         ctx.encode_host(b"hello world", hip.make_params(11, 22, 0))
+    with pytest.raises(hip.BrotliAmdError):      # deep qualities: a shard must fit the window
+        ctx.encode_host(bytes(300000), hip.make_params(9, 17, 0))
     with pytest.raises(hip.BrotliAmdError):
         ctx.encode_host(b"hello world", hip.make_params(5, 30, 0))
 

@@ -78,6 +78,34 @@ def test_quad_kernel_bytes_match_oracle(sim, oracle, name, flags):
     assert sim.encode(data, 5, 22, hint, shard, flags=flags) == _oracle_plan(oracle, data, hint, shard)
 
 
+def _oracle_plan_q(oracle, data, quality, lgwin, hint, shard):
+    n = len(data)
+    shard = shard or n
+    parts, off = [], 0
+    while off < n:
+        m = min(shard, n - off)
+        parts.append(oracle.encode_shard(data[off:off + m], quality, lgwin, hint or min(n, 1 << 30),
+                                         min(off, 1 << 30), off + m == n))
+        off += m
+    return b"".join(parts)
+
+
+@pytest.mark.parametrize("quality,lgwin", [(6, 22), (7, 22), (8, 20), (9, 24)])
+@pytest.mark.parametrize("name", ["text_hint_2shards", "mixed", "text_then_random", "shards_of_1_2_3"])
+def test_deep_kernel_bytes_match_oracle(sim, oracle, name, quality, lgwin):
+    """k_parse_deep.h: 32-slot tagged buckets (q6) and the H5 / H6 hashers with
+    64 / 128 / 256 slots and 10 / 16 distance-cache probes (q7 - q9)."""
+    data, hint, shard = CASES[name]
+    assert sim.encode(data, quality, lgwin, hint, shard) == _oracle_plan_q(oracle, data, quality, lgwin, hint, shard)
+
+
+@pytest.mark.parametrize("quality", [6, 9])
+def test_deep_kernel_step_by_step_resolve(sim, oracle, quality):
+    data = G.enwik_text(30000, seed=31, vocab=2000)
+    assert sim.encode(data, quality, 22, 1 << 30, 0, flags=4, reverse=1) == \
+        _oracle_plan_q(oracle, data, quality, 22, 1 << 30, 0)
+
+
 def test_quad_kernel_many_shards_reverse(sim, oracle):
     """7 shards over 2 waves (one group idle), lanes scheduled high-to-low."""
     data = G.enwik_text(70000, seed=13, vocab=3000)
