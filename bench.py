@@ -33,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-ALGO_BYTES_PER_INPUT_BYTE = 48.0   # SURVEY.md §8(d) q5/H68 model, DESIGN.md §5
+# SURVEY.md §8(d) models: q5 / H68 48 B per input byte; q9 / H6 0.47 KiB.
+ALGO_BYTES_PER_INPUT_BYTE = {5: 48.0, 6: 48.0, 7: 481.0, 8: 481.0, 9: 481.0}
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
@@ -189,7 +190,8 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = total / 1e6 / (dt / args.steps)
         ms_parse = sum(i["ms_parse"] for i in infos) / len(infos)
-        achieved = ALGO_BYTES_PER_INPUT_BYTE * n / (ms_parse / 1e3) / 1e9
+        algo = ALGO_BYTES_PER_INPUT_BYTE[args.quality]
+        achieved = algo * n / (ms_parse / 1e3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
@@ -198,7 +200,8 @@ def main():
             if key in t:
                 traffic = t[key]["hbm_bytes_per_launch"]
         line = {
-            "metric": "encode MB/s at quality 5, lgwin 22, 1 GiB input; bit-exact vs c/enc",
+            "metric": "encode MB/s at quality %d, lgwin %d, 1 GiB input; bit-exact vs c/enc" % (
+                args.quality, args.lgwin),
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
@@ -213,12 +216,12 @@ def main():
                 "stage_ms": {k: round(sum(i[k] for i in infos) / len(infos), 3) for k in
                              ("ms_total", "ms_init", "ms_parse", "ms_build", "ms_store", "ms_gather")},
             },
-            "roofline": {"bound": "hbm", "kernel": "k_parse4", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_parse4" if args.quality == 5 else "k_parse_deep", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": traffic,
-                         "note": "algorithmic bytes = 48 B per input byte x %d bytes per launch; "
+                         "note": "algorithmic bytes = %.0f B per input byte x %d bytes per launch; "
                                  "kernel time %.3f ms (HIP events on the library's stream); the kernel "
-                                 "is SALU-issue/latency bound, not bandwidth bound (DESIGN.md)" % (n, ms_parse)},
+                                 "is latency bound (dependent random accesses), not bandwidth bound (DESIGN.md)" % (algo, n, ms_parse)},
         }
         if world == 1 and not args.no_cpu_baseline:
             # spot check of the bytes against the oracle on the first shards, then the baseline

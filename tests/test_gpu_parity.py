@@ -26,9 +26,9 @@ def ctx():
     c.close()
 
 
-def _gpu(ctx, data, shard=0, hint=0, **kw):
+def _gpu(ctx, data, shard=0, hint=0, quality=5, lgwin=22, **kw):
     from brotli_amd import hip
-    out, info = ctx.encode_host(data, hip.make_params(5, 22, shard, hint, **kw))
+    out, info = ctx.encode_host(data, hip.make_params(quality, lgwin, shard, hint, **kw))
     return out, info
 
 
@@ -93,7 +93,7 @@ def test_golden_vectors(ctx):
         data = G.make(case["input"])
         if len(data) == 0:
             continue
-        got, _ = _gpu(ctx, data, case["shard_size"])
+        got, _ = _gpu(ctx, data, case["shard_size"], quality=case["quality"], lgwin=case["lgwin"])
         assert len(got) == case["size"], case
         assert hashlib.sha256(got).hexdigest() == case["sha256"], case
         n += 1
