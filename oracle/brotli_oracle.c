@@ -2048,3 +2048,603 @@ size_t oracle_encode_plan(const uint8_t* in, size_t len, int quality, int lgwin,
   }
   return total;
 }
+
+/* ======================================================================== */
+/* Quality 1: the two-pass fragment compressor.        */
+/* Restates c/enc/compress_fragment_two_pass.c, the fast tree writer         */
+/* c/enc/brotli_bit_stream.c:404-573 and the driver                           */
+/* BrotliEncoderCompressStreamFast c/enc/encode.c:1425-1547.                 */
+
+#define F_BLOCK ((size_t)1 << 17)          /* kCompressFragmentTwoPassBlockSize */
+#define F_MAX_DISTANCE ((long)(((size_t)1 << 18) - 16)) /* compress_fragment_two_pass.c:29 */
+
+/* Static code-length code of the fast tree writer, generated instead of
+   tabulated (entropy_encode_static.h:20-22, 82-90): depths 4 for symbols
+   0..12, 16, 17; 5 for 13, 14; 15 unused. */
+static uint8_t f_cl_depth[18];
+static uint16_t f_cl_bits[18];
+static uint64_t f_zero_bits[704], f_nonzero_bits[704];
+static uint8_t f_zero_depth[704], f_nonzero_depth[704];
+static int f_static_ready;
+
+static void FastStaticInit(void) {
+  size_t reps, i;
+  if (f_static_ready) return;
+  for (i = 0; i < 18; ++i) f_cl_depth[i] = 4;
+  f_cl_depth[13] = f_cl_depth[14] = 5;
+  f_cl_depth[15] = 0;
+  ConvertBitDepthsToSymbols(f_cl_depth, 18, f_cl_bits);
+  /* A run of `reps` zeros / `reps + 3` repeats of the previous non-zero length as
+     the bit string the tree serialiser would emit for it (entropy_encode.c:160-239
+     without the "7" / value special cases the fast writer handles itself). */
+  for (reps = 0; reps < 704; ++reps) {
+    uint8_t tree[16], extra[16];
+    size_t n = 0, k;
+    uint64_t bits = 0; unsigned nb = 0;
+    WriteTreeRepsZeros(reps, &n, tree, extra);
+    for (k = 0; k < n; ++k) {
+      bits |= (uint64_t)f_cl_bits[tree[k]] << nb; nb += f_cl_depth[tree[k]];
+      if (tree[k] == 17) { bits |= (uint64_t)extra[k] << nb; nb += 3; }
+    }
+    f_zero_bits[reps] = bits; f_zero_depth[reps] = (uint8_t)nb;
+    {
+      size_t r = reps, start = 0;
+      n = 0; bits = 0; nb = 0;
+      for (;;) {
+        tree[n] = 16; extra[n] = (uint8_t)(r & 3); ++n;
+        r >>= 2;
+        if (r == 0) break;
+        --r;
+      }
+      Reverse(tree, start, n);
+      Reverse(extra, start, n);
+      for (k = 0; k < n; ++k) {
+        bits |= (uint64_t)f_cl_bits[16] << nb; nb += f_cl_depth[16];
+        bits |= (uint64_t)extra[k] << nb; nb += 2;
+      }
+      f_nonzero_bits[reps] = bits; f_nonzero_depth[reps] = (uint8_t)nb;
+    }
+  }
+  f_static_ready = 1;
+}
+
+/* test hook: lets tests/ compare the generated tables with the reference's */
+void oracle_fast_static_tables(const uint64_t** zb, const uint8_t** zd,
+                               const uint64_t** nzb, const uint8_t** nzd) {
+  FastStaticInit();
+  *zb = f_zero_bits; *zd = f_zero_depth; *nzb = f_nonzero_bits; *nzd = f_nonzero_depth;
+}
+
+/* entropy_encode.h:82-115 with the count-only comparator of
+   brotli_bit_stream.c:399-402 */
+static void SortTreeByCount(HTree* items, size_t n) {
+  static const size_t gaps[] = {132, 57, 23, 10, 4, 1};
+  if (n < 13) {
+    size_t i;
+    for (i = 1; i < n; ++i) {
+      HTree tmp = items[i];
+      size_t k = i, j = i - 1;
+      while (tmp.total_count < items[j].total_count) {
+        items[k] = items[j];
+        k = j;
+        if (!j--) break;
+      }
+      items[k] = tmp;
+    }
+  } else {
+    int g = n < 57 ? 2 : 0;
+    for (; g < 6; ++g) {
+      size_t gap = gaps[g], i;
+      for (i = gap; i < n; ++i) {
+        size_t j = i;
+        HTree tmp = items[i];
+        for (; j >= gap && tmp.total_count < items[j - gap].total_count; j -= gap) items[j] = items[j - gap];
+        items[j] = tmp;
+      }
+    }
+  }
+}
+
+/* brotli_bit_stream.c:404-573 */
+static void BuildAndStoreHuffmanTreeFast(HTree* tree, const uint32_t* histogram,
+    size_t histogram_total, size_t max_bits, uint8_t* depth, uint16_t* bits,
+    size_t* ix, uint8_t* storage) {
+  size_t count = 0, symbols[4] = {0}, length = 0, total = histogram_total;
+  while (total != 0) {
+    if (histogram[length]) {
+      if (count < 4) symbols[count] = length;
+      ++count;
+      total -= histogram[length];
+    }
+    ++length;
+  }
+  if (count <= 1) {
+    WriteBits(4, 1, ix, storage);
+    WriteBits(max_bits, symbols[0], ix, storage);
+    depth[symbols[0]] = 0;
+    bits[symbols[0]] = 0;
+    return;
+  }
+  memset(depth, 0, length);
+  {
+    uint32_t count_limit;
+    HTree sentinel;
+    sentinel.total_count = 0xFFFFFFFFu; sentinel.left = -1; sentinel.right_or_value = -1;
+    for (count_limit = 1;; count_limit *= 2) {
+      size_t n = 0, l;
+      int i = 0, j, k;
+      for (l = length; l != 0;) {
+        --l;
+        if (histogram[l]) {
+          tree[n].total_count = histogram[l] >= count_limit ? histogram[l] : count_limit;
+          tree[n].left = -1; tree[n].right_or_value = (int16_t)l;
+          ++n;
+        }
+      }
+      SortTreeByCount(tree, n);
+      tree[n] = sentinel;
+      tree[n + 1] = sentinel;
+      j = (int)n + 1;
+      for (k = (int)n - 1; k > 0; --k) {
+        int left, right;
+        size_t end = 2 * n - (size_t)k;
+        if (tree[i].total_count <= tree[j].total_count) { left = i; ++i; } else { left = j; ++j; }
+        if (tree[i].total_count <= tree[j].total_count) { right = i; ++i; } else { right = j; ++j; }
+        tree[end].total_count = tree[left].total_count + tree[right].total_count;
+        tree[end].left = (int16_t)left;
+        tree[end].right_or_value = (int16_t)right;
+        tree[end + 1] = sentinel;
+      }
+      if (SetDepth((int)(2 * n - 1), tree, depth, 14)) break;
+    }
+  }
+  ConvertBitDepthsToSymbols(depth, length, bits);
+  if (count <= 4) {
+    size_t i, j;
+    WriteBits(2, 1, ix, storage);
+    WriteBits(2, count - 1, ix, storage);
+    for (i = 0; i < count; i++) {
+      for (j = i + 1; j < count; j++) {
+        if (depth[symbols[j]] < depth[symbols[i]]) { size_t t = symbols[j]; symbols[j] = symbols[i]; symbols[i] = t; }
+      }
+    }
+    for (i = 0; i < count; ++i) WriteBits(max_bits, symbols[i], ix, storage);
+    if (count == 4) WriteBits(1, depth[symbols[0]] == 1 ? 1 : 0, ix, storage);
+  } else {
+    uint8_t previous_value = 8;
+    size_t i;
+    WriteBits(40, ((uint64_t)0xFFu << 32) | 0x55555554u, ix, storage);
+    for (i = 0; i < length;) {
+      const uint8_t value = depth[i];
+      size_t reps = 1, k;
+      for (k = i + 1; k < length && depth[k] == value; ++k) ++reps;
+      i += reps;
+      if (value == 0) {
+        WriteBits(f_zero_depth[reps], f_zero_bits[reps], ix, storage);
+      } else {
+        if (previous_value != value) { WriteBits(f_cl_depth[value], f_cl_bits[value], ix, storage); --reps; }
+        if (reps < 3) {
+          while (reps != 0) { reps--; WriteBits(f_cl_depth[value], f_cl_bits[value], ix, storage); }
+        } else {
+          reps -= 3;
+          WriteBits(f_nonzero_depth[reps], f_nonzero_bits[reps], ix, storage);
+        }
+        previous_value = value;
+      }
+    }
+  }
+}
+
+/* compress_fragment_two_pass.c:31-52 */
+static uint32_t FHash(const uint8_t* p, size_t shift, size_t length) {
+  const uint64_t h = (Load64(p) << ((8 - length) * 8)) * 0x1E35A7BDu;
+  return (uint32_t)(h >> shift);
+}
+static uint32_t FHashAt(uint64_t v, size_t offset, size_t shift, size_t length) {
+  const uint64_t h = ((v >> (8 * offset)) << ((8 - length) * 8)) * 0x1E35A7BDu;
+  return (uint32_t)(h >> shift);
+}
+static int FIsMatch(const uint8_t* p1, const uint8_t* p2, size_t length) {
+  if (Load32(p1) != Load32(p2)) return 0;
+  if (length == 4) return 1;
+  return p1[4] == p2[4] && p1[5] == p2[5];
+}
+
+/* Two-pass command words: low byte = code in the 128-symbol working alphabet
+   (0..23 insert, 24..39 copy after a repeated distance, 40..63 copy, 64..127
+   distance), upper 24 bits = extra-bit value.  :106-214 */
+static uint32_t FInsertLen(uint32_t insertlen) {
+  if (insertlen < 6) return insertlen;
+  if (insertlen < 130) {
+    const uint32_t tail = insertlen - 2, nbits = Log2Floor(tail) - 1u, prefix = tail >> nbits;
+    return ((nbits << 1) + prefix + 2) | ((tail - (prefix << nbits)) << 8);
+  }
+  if (insertlen < 2114) {
+    const uint32_t tail = insertlen - 66, nbits = Log2Floor(tail);
+    return (nbits + 10) | ((tail - (1u << nbits)) << 8);
+  }
+  if (insertlen < 6210) return 21 | ((insertlen - 2114) << 8);
+  if (insertlen < 22594) return 22 | ((insertlen - 6210) << 8);
+  return 23 | ((insertlen - 22594) << 8);
+}
+static uint32_t FCopyLen(size_t copylen) {
+  if (copylen < 10) return (uint32_t)(copylen + 38);
+  if (copylen < 134) {
+    const size_t tail = copylen - 6, nbits = Log2Floor(tail) - 1, prefix = tail >> nbits;
+    return (uint32_t)(((nbits << 1) + prefix + 44) | ((tail - (prefix << nbits)) << 8));
+  }
+  if (copylen < 2118) {
+    const size_t tail = copylen - 70, nbits = Log2Floor(tail);
+    return (uint32_t)((nbits + 52) | ((tail - ((size_t)1 << nbits)) << 8));
+  }
+  return (uint32_t)(63 | ((copylen - 2118) << 8));
+}
+/* returns the number of words written (1 or 2) */
+static int FCopyLenLastDistance(size_t copylen, uint32_t* w) {
+  if (copylen < 12) { w[0] = (uint32_t)(copylen + 20); return 1; }
+  if (copylen < 72) {
+    const size_t tail = copylen - 8, nbits = Log2Floor(tail) - 1, prefix = tail >> nbits;
+    w[0] = (uint32_t)(((nbits << 1) + prefix + 28) | ((tail - (prefix << nbits)) << 8));
+    return 1;
+  }
+  if (copylen < 136) {
+    const size_t tail = copylen - 8;
+    w[0] = (uint32_t)(((tail >> 5) + 54) | ((tail & 31) << 8));
+  } else if (copylen < 2120) {
+    const size_t tail = copylen - 72, nbits = Log2Floor(tail);
+    w[0] = (uint32_t)((nbits + 52) | ((tail - ((size_t)1 << nbits)) << 8));
+  } else {
+    w[0] = (uint32_t)(63 | ((copylen - 2120) << 8));
+  }
+  w[1] = 64;
+  return 2;
+}
+static uint32_t FDistance(uint32_t distance) {
+  const uint32_t d = distance + 3, nbits = Log2Floor(d) - 1, prefix = (d >> nbits) & 1;
+  const uint32_t offset = (2 + prefix) << nbits;
+  return (2 * (nbits - 1) + prefix + 80) | ((d - offset) << 8);
+}
+
+/* :216-232 */
+static void FStoreMetaBlockHeader(size_t len, int is_uncompressed, size_t* ix, uint8_t* storage) {
+  size_t nibbles = 6;
+  WriteBits(1, 0, ix, storage);
+  if (len <= (1u << 16)) nibbles = 4; else if (len <= (1u << 20)) nibbles = 5;
+  WriteBits(2, nibbles - 4, ix, storage);
+  WriteBits(nibbles * 4, len - 1, ix, storage);
+  WriteBits(1, (uint64_t)is_uncompressed, ix, storage);
+}
+
+/* Hash-table refresh after a copy (:354-386 and :410-442).  `first` selects the
+   variant used right after the first match of a scan, which for 4-byte hashes
+   keys the third store with offset 0 again (:362-363). */
+static uint32_t FAfterCopy(const uint8_t* ip, const uint8_t* base_ip, int* table, size_t shift,
+                           size_t min_match, int first) {
+  uint64_t v; uint32_t cur;
+  if (min_match == 4) {
+    v = Load64(ip - 3);
+    cur = FHashAt(v, 3, shift, 4);
+    table[FHashAt(v, 0, shift, 4)] = (int)(ip - base_ip - 3);
+    table[FHashAt(v, 1, shift, 4)] = (int)(ip - base_ip - 2);
+    table[FHashAt(v, first ? 0 : 2, shift, 4)] = (int)(ip - base_ip - 1);
+  } else {
+    v = Load64(ip - 5);
+    table[FHashAt(v, 0, shift, 6)] = (int)(ip - base_ip - 5);
+    table[FHashAt(v, 1, shift, 6)] = (int)(ip - base_ip - 4);
+    table[FHashAt(v, 2, shift, 6)] = (int)(ip - base_ip - 3);
+    v = Load64(ip - 2);
+    cur = FHashAt(v, 2, shift, 6);
+    table[FHashAt(v, 0, shift, 6)] = (int)(ip - base_ip - 2);
+    table[FHashAt(v, 1, shift, 6)] = (int)(ip - base_ip - 1);
+  }
+  return cur;
+}
+
+/* :234-459 */
+static void FCreateCommands(const uint8_t* input, size_t block_size, size_t input_size,
+    const uint8_t* base_ip, int* table, size_t table_bits, size_t min_match,
+    uint8_t** literals, uint32_t** commands) {
+  const uint8_t* ip = input;
+  const size_t shift = 64u - table_bits;
+  const uint8_t* ip_end = input + block_size;
+  const uint8_t* next_emit = input;
+  int last_distance = -1;
+  if (block_size >= 16) {
+    const size_t a = block_size - min_match, b = input_size - 16;
+    const uint8_t* ip_limit = input + (a < b ? a : b);
+    uint32_t next_hash;
+    for (next_hash = FHash(++ip, shift, min_match);;) {
+      uint32_t skip = 32;
+      const uint8_t* next_ip = ip;
+      const uint8_t* candidate;
+    trawl:
+      do {
+        uint32_t hash = next_hash;
+        uint32_t step = skip++ >> 5;
+        ip = next_ip;
+        next_ip = ip + step;
+        if (next_ip > ip_limit) goto emit_remainder;
+        next_hash = FHash(next_ip, shift, min_match);
+        candidate = ip - last_distance;
+        if (FIsMatch(ip, candidate, min_match)) {
+          if (candidate < ip) { table[hash] = (int)(ip - base_ip); break; }
+        }
+        candidate = base_ip + table[hash];
+        table[hash] = (int)(ip - base_ip);
+      } while (!FIsMatch(ip, candidate, min_match));
+      if (ip - candidate > F_MAX_DISTANCE) goto trawl;
+      {
+        const uint8_t* base = ip;
+        size_t matched = min_match + FindMatchLength(candidate + min_match, ip + min_match,
+                                                     (size_t)(ip_end - ip) - min_match);
+        int distance = (int)(base - candidate);
+        int insert = (int)(base - next_emit);
+        ip += matched;
+        *(*commands)++ = FInsertLen((uint32_t)insert);
+        memcpy(*literals, next_emit, (size_t)insert);
+        *literals += insert;
+        if (distance == last_distance) {
+          *(*commands)++ = 64;
+        } else {
+          *(*commands)++ = FDistance((uint32_t)distance);
+          last_distance = distance;
+        }
+        *commands += FCopyLenLastDistance(matched, *commands);
+        next_emit = ip;
+        if (ip >= ip_limit) goto emit_remainder;
+        {
+          uint32_t cur = FAfterCopy(ip, base_ip, table, shift, min_match, 1);
+          candidate = base_ip + table[cur];
+          table[cur] = (int)(ip - base_ip);
+        }
+      }
+      while (ip - candidate <= F_MAX_DISTANCE && FIsMatch(ip, candidate, min_match)) {
+        const uint8_t* base = ip;
+        size_t matched = min_match + FindMatchLength(candidate + min_match, ip + min_match,
+                                                     (size_t)(ip_end - ip) - min_match);
+        ip += matched;
+        last_distance = (int)(base - candidate);
+        *(*commands)++ = FCopyLen(matched);
+        *(*commands)++ = FDistance((uint32_t)last_distance);
+        next_emit = ip;
+        if (ip >= ip_limit) goto emit_remainder;
+        {
+          uint32_t cur = FAfterCopy(ip, base_ip, table, shift, min_match, 0);
+          candidate = base_ip + table[cur];
+          table[cur] = (int)(ip - base_ip);
+        }
+      }
+      next_hash = FHash(++ip, shift, min_match);
+    }
+  }
+emit_remainder:
+  if (next_emit < ip_end) {
+    const uint32_t insert = (uint32_t)(ip_end - next_emit);
+    *(*commands)++ = FInsertLen(insert);
+    memcpy(*literals, next_emit, insert);
+    *literals += insert;
+  }
+}
+
+/* Working-alphabet code -> the order in which BuildAndStoreCommandPrefixCode
+   (:56-104) lines the 64 command codes up for canonical code assignment, and the
+   full 704-symbol alphabet slot each occupies. */
+static const uint8_t kFOrder[64] = {
+  24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47,
+  0, 1, 2, 3, 4, 5, 6, 7, 48, 49, 50, 51, 52, 53, 54, 55, 8, 9, 10, 11, 12, 13, 14, 15,
+  56, 57, 58, 59, 60, 61, 62, 63, 16, 17, 18, 19, 20, 21, 22, 23};
+
+typedef struct {
+  uint32_t lit_histo[256];
+  uint8_t lit_depth[256];
+  uint16_t lit_bits[256];
+  uint32_t cmd_histo[128];
+  uint8_t cmd_depth[128];
+  uint16_t cmd_bits[128];
+  HTree tree[2 * 704 + 1];
+} FArena;
+
+static void FBuildAndStoreCommandPrefixCode(FArena* s, size_t* ix, uint8_t* storage) {
+  uint8_t tmp_depth[704];
+  uint16_t tmp_bits[64];
+  size_t i;
+  CreateHuffmanTree(s->cmd_histo, 64, 15, s->tree, s->cmd_depth);
+  CreateHuffmanTree(&s->cmd_histo[64], 64, 14, s->tree, &s->cmd_depth[64]);
+  for (i = 0; i < 64; ++i) tmp_depth[i] = s->cmd_depth[kFOrder[i]];
+  memset(tmp_bits, 0, sizeof(tmp_bits));
+  ConvertBitDepthsToSymbols(tmp_depth, 64, tmp_bits);
+  for (i = 0; i < 64; ++i) s->cmd_bits[kFOrder[i]] = tmp_bits[i];
+  ConvertBitDepthsToSymbols(&s->cmd_depth[64], 64, &s->cmd_bits[64]);
+  memset(tmp_depth, 0, sizeof(tmp_depth));
+  for (i = 0; i < 8; ++i) {
+    tmp_depth[i] = s->cmd_depth[24 + i];
+    tmp_depth[64 + i] = s->cmd_depth[32 + i];
+    tmp_depth[128 + i] = s->cmd_depth[40 + i];
+    tmp_depth[192 + i] = s->cmd_depth[48 + i];
+    tmp_depth[384 + i] = s->cmd_depth[56 + i];
+  }
+  for (i = 0; i < 8; ++i) {
+    tmp_depth[128 + 8 * i] = s->cmd_depth[i];
+    tmp_depth[256 + 8 * i] = s->cmd_depth[8 + i];
+    tmp_depth[448 + 8 * i] = s->cmd_depth[16 + i];
+  }
+  StoreHuffmanTree(tmp_depth, 704, s->tree, ix, storage);
+  StoreHuffmanTree(&s->cmd_depth[64], 64, s->tree, ix, storage);
+}
+
+static uint32_t FNumExtraBits(uint32_t code) {
+  static const uint8_t ins[24] = {0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 12, 14, 24};
+  static const uint8_t cpy[24] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 8, 9, 10, 24};
+  if (code < 24) return ins[code];
+  if (code < 40) return cpy[code - 24];
+  if (code < 64) return cpy[code - 40];
+  if (code < 80) return 0;
+  return (code - 80) / 2 + 1;
+}
+static const uint32_t kFInsertOffset[24] = {0, 1, 2, 3, 4, 5, 6, 8, 10, 14, 18, 26, 34, 50, 66, 98,
+    130, 194, 322, 578, 1090, 2114, 6210, 22594};
+
+/* :461-522 */
+static void FStoreCommands(FArena* s, const uint8_t* literals, size_t num_literals,
+    const uint32_t* commands, size_t num_commands, size_t* ix, uint8_t* storage) {
+  size_t i;
+  memset(s->lit_histo, 0, sizeof(s->lit_histo));
+  memset(s->cmd_depth, 0, sizeof(s->cmd_depth));
+  memset(s->cmd_bits, 0, sizeof(s->cmd_bits));
+  memset(s->cmd_histo, 0, sizeof(s->cmd_histo));
+  for (i = 0; i < num_literals; ++i) ++s->lit_histo[literals[i]];
+  BuildAndStoreHuffmanTreeFast(s->tree, s->lit_histo, num_literals, 8, s->lit_depth, s->lit_bits, ix, storage);
+  for (i = 0; i < num_commands; ++i) ++s->cmd_histo[commands[i] & 0xFF];
+  s->cmd_histo[1] += 1;
+  s->cmd_histo[2] += 1;
+  s->cmd_histo[64] += 1;
+  s->cmd_histo[84] += 1;
+  FBuildAndStoreCommandPrefixCode(s, ix, storage);
+  for (i = 0; i < num_commands; ++i) {
+    const uint32_t cmd = commands[i], code = cmd & 0xFF, extra = cmd >> 8;
+    WriteBits(s->cmd_depth[code], s->cmd_bits[code], ix, storage);
+    WriteBits(FNumExtraBits(code), extra, ix, storage);
+    if (code < 24) {
+      uint32_t insert = kFInsertOffset[code] + extra, j;
+      for (j = 0; j < insert; ++j) {
+        const uint8_t lit = *literals++;
+        WriteBits(s->lit_depth[lit], s->lit_bits[lit], ix, storage);
+      }
+    }
+  }
+}
+
+/* :524-544 */
+static int FShouldCompress(FArena* s, const uint8_t* input, size_t input_size, size_t num_literals) {
+  double corpus_size = (double)input_size;
+  if ((double)num_literals < 0.98 * corpus_size) return 1;
+  {
+    const double max_total_bit_cost = corpus_size * 8 * 0.98 / 43;
+    size_t i;
+    memset(s->lit_histo, 0, sizeof(s->lit_histo));
+    for (i = 0; i < input_size; i += 43) ++s->lit_histo[input[i]];
+    return BitsEntropy(s->lit_histo, 256) < max_total_bit_cost;
+  }
+}
+
+/* :554-562 */
+static void FEmitUncompressedMetaBlock(const uint8_t* input, size_t input_size, size_t* ix, uint8_t* storage) {
+  FStoreMetaBlockHeader(input_size, 1, ix, storage);
+  *ix = (*ix + 7u) & ~(size_t)7u;
+  memcpy(&storage[*ix >> 3], input, input_size);
+  *ix += input_size << 3;
+  storage[*ix >> 3] = 0;
+}
+
+/* BrotliCompressFragmentTwoPass :564-641 */
+static void FCompressFragmentTwoPass(FArena* s, const uint8_t* input, size_t input_size, int is_last,
+    uint32_t* command_buf, uint8_t* literal_buf, int* table, size_t table_size,
+    size_t* ix, uint8_t* storage) {
+  const size_t initial_ix = *ix;
+  const size_t table_bits = Log2Floor(table_size);
+  const size_t min_match = table_bits <= 15 ? 4 : 6;
+  const uint8_t* base_ip = input;
+  const uint8_t* in = input;
+  size_t left = input_size;
+  while (left > 0) {
+    size_t block_size = left < F_BLOCK ? left : F_BLOCK;
+    uint32_t* commands = command_buf;
+    uint8_t* literals = literal_buf;
+    size_t num_literals;
+    FCreateCommands(in, block_size, left, base_ip, table, table_bits, min_match, &literals, &commands);
+    num_literals = (size_t)(literals - literal_buf);
+    if (FShouldCompress(s, in, block_size, num_literals)) {
+      FStoreMetaBlockHeader(block_size, 0, ix, storage);
+      WriteBits(13, 0, ix, storage);
+      FStoreCommands(s, literal_buf, num_literals, command_buf, (size_t)(commands - command_buf), ix, storage);
+    } else {
+      FEmitUncompressedMetaBlock(in, block_size, ix, storage);
+    }
+    in += block_size;
+    left -= block_size;
+  }
+  if (*ix - initial_ix > 31 + (input_size << 3)) {
+    storage[initial_ix >> 3] &= (uint8_t)((1u << (initial_ix & 7)) - 1);   /* RewindBitPosition :546-552 */
+    *ix = initial_ix;
+    FEmitUncompressedMetaBlock(input, input_size, ix, storage);
+  }
+  if (is_last) {
+    WriteBits(1, 1, ix, storage);
+    WriteBits(1, 1, ix, storage);
+    *ix = (*ix + 7u) & ~(size_t)7u;
+  }
+}
+
+/* One encoder instance at quality 1 driven through BrotliEncoderCompressStream
+   (encode.c:1425-1547): call k feeds call_sizes[k] bytes with operation
+   call_ops[k] (0 PROCESS, 1 FLUSH, 2 FINISH) and an unbounded output buffer, so
+   each call is cut into fragments of min(1 << lgwin, bytes left in the call).
+   A one-shot BrotliEncoderCompress is the single call {len, FINISH}. */
+size_t oracle_encode_fast(const uint8_t* in, size_t len, int lgwin,
+    const uint64_t* call_sizes, const uint8_t* call_ops, size_t ncalls,
+    uint8_t* out, size_t out_cap) {
+  FArena* s;
+  uint32_t* command_buf;
+  uint8_t* literal_buf;
+  int* table;
+  uint8_t* storage;
+  uint16_t last_bytes;
+  uint8_t last_bytes_bits;
+  size_t out_len = 0, k, pos = 0;
+  const size_t block_limit = (size_t)1 << lgwin;
+  int hl = lgwin < 18 ? 18 : lgwin;            /* encode.c:670-674 */
+  int finished = 0, overflow = 0;
+  FastStaticInit();
+  s = (FArena*)malloc(sizeof(FArena));
+  command_buf = (uint32_t*)malloc(F_BLOCK * 4);
+  literal_buf = (uint8_t*)malloc(F_BLOCK);
+  table = (int*)malloc(sizeof(int) << 17);
+  storage = (uint8_t*)malloc(2 * block_limit + 503 + 16);
+  last_bytes = (uint16_t)(((hl - 17) << 1) | 1); last_bytes_bits = 4;   /* EncodeWindowBits, lgwin > 17 */
+  for (k = 0; k < ncalls && !finished && !overflow; ++k) {
+    size_t avail = (size_t)call_sizes[k];
+    const int op = call_ops[k];
+    if (pos + avail > len) { overflow = 1; break; }
+    for (;;) {
+      if (avail != 0 || op != 0) {
+        size_t block_size = avail < block_limit ? avail : block_limit;
+        int is_last = (avail == block_size) && op == 2;
+        int force_flush = (avail == block_size) && op == 1;
+        size_t ix = last_bytes_bits, table_size = 256, out_bytes;
+        if (!(force_flush && block_size == 0)) {
+          storage[0] = (uint8_t)last_bytes;
+          storage[1] = (uint8_t)(last_bytes >> 8);
+          while (table_size < ((size_t)1 << 17) && table_size < block_size) table_size <<= 1;   /* :148-154 */
+          memset(table, 0, table_size * sizeof(int));
+          FCompressFragmentTwoPass(s, in + pos, block_size, is_last, command_buf, literal_buf,
+                                   table, table_size, &ix, storage);
+          pos += block_size; avail -= block_size;
+          out_bytes = ix >> 3;
+          if (out_len + out_bytes > out_cap) { overflow = 1; break; }
+          memcpy(out + out_len, storage, out_bytes);
+          out_len += out_bytes;
+          last_bytes = (uint16_t)storage[ix >> 3];
+          last_bytes_bits = (uint8_t)(ix & 7u);
+        }
+        if (force_flush) {                    /* InjectBytePaddingBlock, :1356-1380 */
+          if (last_bytes_bits != 0) {
+            uint32_t seal = last_bytes;
+            size_t seal_bits = last_bytes_bits, nb, q;
+            seal |= 0x6u << seal_bits;
+            seal_bits += 6;
+            nb = (seal_bits + 7) >> 3;
+            if (out_len + nb > out_cap) { overflow = 1; break; }
+            for (q = 0; q < nb; ++q) out[out_len++] = (uint8_t)(seal >> (8 * q));
+            last_bytes = 0; last_bytes_bits = 0;
+          }
+          break;
+        }
+        if (is_last) { finished = 1; break; }
+        continue;
+      }
+      break;
+    }
+  }
+  free(s); free(command_buf); free(literal_buf); free(table); free(storage);
+  return overflow ? 0 : out_len;
+}

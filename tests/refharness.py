@@ -88,6 +88,35 @@ class Ref:
         L.BrotliEncoderDestroyInstance(st)
         return out.raw[:total.value]
 
+    def encode_calls(self, data, quality, lgwin, calls):
+        """One instance driven with an explicit call sequence [(nbytes, op), ...];
+        every call is repeated until its input is consumed and the output drained
+        (what the CLI / bindings do)."""
+        L = self.L
+        st = L.BrotliEncoderCreateInstance(None, None, None)
+        assert L.BrotliEncoderSetParameter(st, PARAM_QUALITY, quality)
+        assert L.BrotliEncoderSetParameter(st, PARAM_LGWIN, lgwin)
+        cap = 2 * len(data) + 1024 + 64 * len(calls)
+        out = C.create_string_buffer(cap)
+        inbuf = C.create_string_buffer(bytes(data), max(len(data), 1))
+        avail_out = C.c_size_t(cap)
+        next_out = C.c_void_p(C.addressof(out))
+        total = C.c_size_t(0)
+        pos = 0
+        for nbytes, op in calls:
+            avail_in = C.c_size_t(nbytes)
+            next_in = C.c_void_p(C.addressof(inbuf) + pos)
+            pos += nbytes
+            while True:
+                ok = L.BrotliEncoderCompressStream(
+                    st, op, C.byref(avail_in), C.byref(next_in),
+                    C.byref(avail_out), C.byref(next_out), C.byref(total))
+                assert ok
+                if avail_in.value == 0 and not L.BrotliEncoderHasMoreOutput(st):
+                    break
+        L.BrotliEncoderDestroyInstance(st)
+        return out.raw[:total.value]
+
     def encode_plan(self, data, quality, lgwin, shard_size):
         n = len(data)
         if n == 0:
@@ -123,10 +152,27 @@ class Oracle:
         L.oracle_encode_shard.argtypes = [
             C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
             C.c_int, C.c_char_p, C.c_size_t]
+        L.oracle_encode_fast.restype = C.c_size_t
+        L.oracle_encode_fast.argtypes = [
+            C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64),
+            C.POINTER(C.c_uint8), C.c_size_t, C.c_char_p, C.c_size_t]
         L.oracle_encode_plan.restype = C.c_size_t
         L.oracle_encode_plan.argtypes = [
             C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_char_p,
             C.c_size_t, C.POINTER(C.c_uint64)]
+
+    def encode_fast(self, data, lgwin=22, calls=None):
+        """Quality 1; `calls` = [(nbytes, op), ...], default one FINISH call."""
+        if calls is None:
+            calls = [(len(data), OP_FINISH)]
+        sizes = (C.c_uint64 * len(calls))(*[c[0] for c in calls])
+        ops = (C.c_uint8 * len(calls))(*[c[1] for c in calls])
+        cap = 2 * len(data) + 1024 + 64 * len(calls)
+        out = C.create_string_buffer(cap)
+        n = self.L.oracle_encode_fast(bytes(data), len(data), lgwin, sizes, ops,
+                                      len(calls), out, cap)
+        assert n > 0
+        return out.raw[:n]
 
     def encode_shard(self, data, quality, lgwin, size_hint, stream_offset,
                      is_last):
