@@ -101,4 +101,54 @@ struct DeviceTables {
   uint8_t dict_size_bits_by_length[32];
 };
 
+// ---- quality 1: fragments of the two-pass compressor (k_fast.h) ------------------
+// A fragment = one BrotliCompressFragmentTwoPass call (encode.c:1478-1513): its
+// own zeroed hash table, positions relative to its first byte.  Its 128 KiB
+// blocks (compress_fragment_two_pass.c:575-603) share the table, so a fragment is
+// parsed by one wave, block after block; everything after the parse is per block.
+#define FAST_BLOCK (1u << 17)
+#define FAST_MAX_DISTANCE ((1u << 18) - 16u)   // compress_fragment_two_pass.c:29
+#define FAST_TABLE_BYTES (4u << 17)            // int[1 << 17], encode.c:136-146
+#define FAST_RAW 0xFFFFFFFFu
+
+struct FastFrag {
+  uint64_t in_off;        // first byte in the job input
+  uint32_t len;
+  uint32_t first_block, nblocks;
+  uint32_t table_bits;    // 8 .. 17 (HashTableSize, encode.c:148-154); min match 4 up to 15 bits, else 6
+};
+struct FastBlock {
+  uint64_t in_off;
+  uint32_t len;
+  uint32_t left;          // bytes of the fragment from this block's first byte on
+  uint32_t frag;
+  uint32_t off_in_frag;
+};
+struct FastBlockState {
+  uint32_t ncmds, nlits;  // two-pass command words / literal bytes (parse kernel)
+  uint32_t bits;          // bits of the block's compressed meta-block, FAST_RAW = store uncompressed
+  uint32_t error;
+};
+struct FastFragState {
+  uint64_t bits[8];       // bits the fragment occupies when it starts at bit residue r
+  uint64_t start;         // first bit of the fragment in the job output
+  uint32_t rewrite_mask;  // bit r: at residue r the fragment is rewritten as one raw meta-block (:622-627)
+  uint32_t pad;
+};
+struct FastArgs {
+  const FastFrag* frags;
+  const FastBlock* blocks;
+  FastBlockState* bstate;
+  FastFragState* fstate;
+  const DeviceTables* T;
+  const uint8_t* input;
+  uint8_t* ws;
+  uint8_t* out;
+  uint64_t* result;       // [0] total bits of the job output, [1] error flags
+  uint64_t cmds_base, lits_base, lsum_base, scr_base, tables_base, out_cap;
+  uint32_t nfrags, nblocks, nslots;
+  uint32_t carry_bits, carry_value;   // bits already pending at the start of the output (stream header / last_bytes_)
+  uint32_t is_last;
+};
+
 #endif  // BROTLI_AMD_CSRC_ENC_TYPES_H_

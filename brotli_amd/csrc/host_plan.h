@@ -144,6 +144,68 @@ static inline bool host_tables_load(const char* path, HostTables* t) {
   return ok;
 }
 
+// ---- quality 1 --------------------------------------------------------------------------
+// Fragments of the two-pass compressor for one run of CompressStream calls
+// (encode.c:1467-1540): call k hands `call_sizes[k]` bytes, cut into fragments of
+// min(1 << lgwin, bytes left in the call); a zero-byte call yields an empty
+// fragment (only meaningful as the carrier of the final ISLAST bits).
+struct FastPlan {
+  std::vector<FastFrag> frags;
+  std::vector<FastBlock> blocks;
+  uint64_t cmds_base, lits_base, lsum_base, scr_base, tables_base, ws_bytes;
+  uint32_t nslots;
+  uint64_t max_out_bytes;
+};
+
+static inline bool plan_fast(uint64_t len, int lgwin, const uint64_t* call_sizes, size_t ncalls,
+                             FastPlan* plan) {
+  if (lgwin < 10 || lgwin > 24) return false;
+  const uint64_t limit = (uint64_t)1 << lgwin;
+  plan->frags.clear();
+  plan->blocks.clear();
+  uint64_t pos = 0;
+  for (size_t k = 0; k < ncalls; ++k) {
+    uint64_t avail = call_sizes[k];
+    if (pos + avail > len) return false;
+    do {
+      const uint64_t n = avail < limit ? avail : limit;
+      FastFrag F;
+      F.in_off = pos;
+      F.len = (uint32_t)n;
+      F.first_block = (uint32_t)plan->blocks.size();
+      F.nblocks = (uint32_t)((n + FAST_BLOCK - 1) / FAST_BLOCK);
+      uint32_t bits = 8;                                  // HashTableSize, encode.c:148-154
+      while (bits < 17 && ((uint64_t)1 << bits) < n) ++bits;
+      F.table_bits = bits;
+      for (uint32_t b = 0; b < F.nblocks; ++b) {
+        FastBlock B;
+        B.off_in_frag = b * FAST_BLOCK;
+        B.in_off = pos + B.off_in_frag;
+        B.left = (uint32_t)n - B.off_in_frag;
+        B.len = B.left < FAST_BLOCK ? B.left : FAST_BLOCK;
+        B.frag = (uint32_t)plan->frags.size();
+        plan->blocks.push_back(B);
+      }
+      plan->frags.push_back(F);
+      pos += n;
+      avail -= n;
+    } while (avail != 0);
+  }
+  if (pos != len) return false;
+  const uint64_t nb = plan->blocks.size(), nf = plan->frags.size();
+  auto al = [](uint64_t v) { return (v + 255) & ~(uint64_t)255; };
+  uint64_t off = 0;
+  plan->cmds_base = off;   off = al(off + 4 * len + 64);
+  plan->lits_base = off;   off = al(off + len + 64);
+  plan->lsum_base = off;   off = al(off + 4 * (len + nb) + 64);
+  plan->scr_base = off;    off = al(off + 2 * len + 1024 * nb + 64);
+  plan->nslots = (uint32_t)(nf < 8192 ? (nf ? nf : 1) : 8192);
+  plan->tables_base = off; off = al(off + (uint64_t)plan->nslots * FAST_TABLE_BYTES);
+  plan->ws_bytes = off;
+  plan->max_out_bytes = len + 8 * nf + 64;   // a fragment never exceeds its raw form by more than 31 bits + padding (:622)
+  return true;
+}
+
 // FastLog2 (c/enc/fast_log.h:51-59): a table of float literals widened to
 // double below 256 (fast_log.c:14), libm log2() above.  Built with the host's
 // libm so device entropy decisions see exactly the reference's values.

@@ -151,4 +151,34 @@ __global__ void __launch_bounds__(256) k_gather(JobArgs a, const uint64_t* scan,
   }
 }
 
+// ---- quality 1 (k_fast.h) ---------------------------------------------------------------
+#include "k_fast.h"
+
+// grid = nslots (<= nfrags), block = 64: wave w takes fragments w, w + nslots, ... and
+// owns hash-table slot w.
+__global__ void __launch_bounds__(64) k_fast_parse(FastArgs a) {
+  uint32_t* table = (uint32_t*)(a.ws + a.tables_base + (uint64_t)blockIdx.x * FAST_TABLE_BYTES);
+  for (uint32_t f = blockIdx.x; f < a.nfrags; f += a.nslots) fast_parse_fragment(a, f, table);
+}
+
+// grid = nblocks, block = 64
+__global__ void __launch_bounds__(64) k_fast_store(FastArgs a) {
+  __shared__ uint32_t lds_fast[FAST_STORE_LDS_WORDS];
+  if (blockIdx.x < a.nblocks) fast_store_block(a, blockIdx.x, lds_fast);
+}
+
+// grid = ceil(8 * nfrags / 256), block = 256
+__global__ void __launch_bounds__(256) k_fast_sizes(FastArgs a) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 8u * a.nfrags) fast_fragment_sizes(a, t >> 3, t & 7u);
+}
+
+// grid = 1, block = 64
+__global__ void __launch_bounds__(64) k_fast_scan(FastArgs a) { fast_scan_fragments(a); }
+
+// grid = nblocks, block = 256
+__global__ void __launch_bounds__(256) k_fast_emit(FastArgs a) {
+  if (blockIdx.x < a.nblocks) fast_emit_block(a, blockIdx.x, threadIdx.x, blockDim.x);
+}
+
 #endif  // BROTLI_AMD_CSRC_KERNELS_H_

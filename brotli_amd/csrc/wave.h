@@ -39,6 +39,18 @@ static inline uint32_t dev_bitrev32(uint32_t x) {
   return __builtin_bswap32(x);
 }
 #define block_sync() simt_sync(WAVE_SITE)
+// Lanes [0, n) hold v: prev = highest lane below this one with the same v (-1 if
+// none), next = lowest lane above it with the same v (64 if none).
+static inline void wave_equal_neighbours(uint32_t v, int n, int* prev, int* next) {
+  simt::rendezvous(v, 7001);
+  const int lane = wave_lane();
+  int p = -1, x = 64;
+  for (int k = 0; k < n; ++k) {
+    if ((uint32_t)simt::peek((int)((threadIdx.x & ~63u) + k)) != v) continue;
+    if (k < lane) p = k; else if (k > lane && x == 64) x = k;
+  }
+  *prev = p; *next = x;
+}
 // Rotation inside rows of 16 lanes (DPP row_ror on the device).
 #define wave_row_ror(v, k) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), (wave_lane() & 48) | ((wave_lane() + (k)) & 15), WAVE_SITE))
 
@@ -97,6 +109,20 @@ __device__ __forceinline__ uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { ret
 __device__ __forceinline__ uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t dev_bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
+// Lanes [0, n) hold v: prev = highest lane below this one with the same v (-1 if
+// none), next = lowest lane above it with the same v (64 if none).  n readlanes
+// (SGPR broadcast) and two compares each: no LDS traffic.
+__device__ __forceinline__ void wave_equal_neighbours(uint32_t v, int n, int* prev, int* next) {
+  const int lane = wave_lane();
+  int p = -1, x = 64;
+  for (int k = 0; k < n; ++k) {
+    const uint32_t vk = (uint32_t)__builtin_amdgcn_readlane((int)v, k);
+    if (vk == v) {
+      if (k < lane) p = k; else if (k > lane && x == 64) x = k;
+    }
+  }
+  *prev = p; *next = x;
+}
 // Rotation inside rows of 16 lanes: one VALU v_mov_b32 with DPP row_ror:k, no
 // LDS crossbar round trip (ds_bpermute costs ~100 cycles of latency each).
 #define wave_row_ror(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x120 + (k), 0xF, 0xF, true))

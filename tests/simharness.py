@@ -30,10 +30,29 @@ class Sim:
             C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_size_t,
             C.POINTER(C.c_uint64)]
 
+        self.L.sim_encode_fast.restype = C.c_long
+        self.L.sim_encode_fast.argtypes = [
+            C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64), C.c_size_t,
+            C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
         self.L.sim_encode.restype = C.c_long
         self.L.sim_encode.argtypes = [
             C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
             C.c_size_t, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+
+    def encode_fast(self, data, lgwin=22, calls=None, reverse=0):
+        """Quality 1 through the k_fast_* kernels; `calls` = [(nbytes, op), ...] ending
+        with FINISH, no FLUSH inside (the host layer splits runs at flushes)."""
+        if calls is None:
+            calls = [(len(data), 2)]
+        assert calls[-1][1] == 2 and all(c[1] == 0 for c in calls[:-1])
+        sizes = (C.c_uint64 * len(calls))(*[c[0] for c in calls])
+        hl = max(lgwin, 18)
+        cap = len(data) + 64 * len(calls) + 64 * (len(data) >> min(lgwin, 17)) + 1024
+        out = C.create_string_buffer(cap)
+        nbits = self.L.sim_encode_fast(TABLES.encode(), bytes(data), len(data), lgwin, sizes,
+                                       len(calls), 4, ((hl - 17) << 1) | 1, 1, reverse, out, cap)
+        assert nbits >= 0 and nbits % 8 == 0, nbits
+        return out.raw[:nbits // 8]
 
     def encode(self, data, quality=5, lgwin=22, size_hint=0, shard_size=0,
                stream_base=0, is_last=True, reverse=0, flags=0):

@@ -157,4 +157,65 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   return (long)n;
 }
 
+// Quality 1 on the simulator: the k_fast_* pipeline for one run of calls ending in
+// FINISH (is_last) or at a byte-pending point.  Returns the number of output bits
+// (bytes = (bits + 7) / 8 are written), negative on error.
+namespace {
+struct FLaunch { void (*fn)(FastArgs); FastArgs a; };
+void ftramp(void* p) { FLaunch* l = (FLaunch*)p; l->fn(l->a); }
+void frun(void (*fn)(FastArgs), const FastArgs& a, unsigned grid, unsigned block, int reverse) {
+  FLaunch l{fn, a};
+  simt::launch(grid, block, ftramp, &l, reverse);
+}
+}  // namespace
+
+long sim_encode_fast(const char* tables_path, const uint8_t* in, size_t len, int lgwin,
+                     const uint64_t* call_sizes, size_t ncalls, uint32_t carry_bits,
+                     uint32_t carry_value, int is_last, int reverse, uint8_t* out, size_t out_cap) {
+  HostTables ht;
+  if (!host_tables_load(tables_path, &ht)) return -1;
+  FastPlan plan;
+  if (!plan_fast(len, lgwin, call_sizes, ncalls, &plan)) return -2;
+  std::vector<uint8_t> input(len + 64, 0);
+  memcpy(input.data(), in, len);
+  std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
+  std::vector<FastBlockState> bstate(plan.blocks.size() + 1);
+  std::vector<FastFragState> fstate(plan.frags.size() + 1);
+  memset(fstate.data(), 0, fstate.size() * sizeof(FastFragState));
+  memset(bstate.data(), 0, bstate.size() * sizeof(FastBlockState));
+  std::vector<double> log2lut;
+  DeviceTables T;
+  host_tables_fill(ht, 4096, &log2lut, &T);
+  std::vector<uint8_t> obuf(plan.max_out_bytes + 64, 0);
+  uint64_t result[2] = {0, 0};
+  FastArgs a;
+  a.frags = plan.frags.data();
+  a.blocks = plan.blocks.data();
+  a.bstate = bstate.data();
+  a.fstate = fstate.data();
+  a.T = &T;
+  a.input = input.data();
+  a.ws = ws.data();
+  a.out = obuf.data();
+  a.result = result;
+  a.cmds_base = plan.cmds_base; a.lits_base = plan.lits_base; a.lsum_base = plan.lsum_base;
+  a.scr_base = plan.scr_base; a.tables_base = plan.tables_base;
+  a.out_cap = plan.max_out_bytes;
+  a.nfrags = (uint32_t)plan.frags.size();
+  a.nblocks = (uint32_t)plan.blocks.size();
+  a.nslots = plan.nslots;
+  if (getenv("SIM_FAST_SLOTS")) a.nslots = (uint32_t)atoi(getenv("SIM_FAST_SLOTS"));
+  a.carry_bits = carry_bits; a.carry_value = carry_value; a.is_last = (uint32_t)is_last;
+  frun(k_fast_parse, a, a.nslots, 64, reverse);
+  if (a.nblocks) frun(k_fast_store, a, a.nblocks, 64, reverse);
+  frun(k_fast_sizes, a, (8 * a.nfrags + 255) / 256, 256, reverse);
+  frun(k_fast_scan, a, 1, 64, reverse);
+  if (a.nblocks) frun(k_fast_emit, a, a.nblocks, 256, reverse);
+  if (result[1]) return -3;
+  const size_t nbytes = (size_t)((result[0] + 7) / 8);
+  if (nbytes > out_cap) return -4;
+  memcpy(out, obuf.data(), nbytes);
+  return (long)result[0];
+}
+
 }  // extern "C"

@@ -128,3 +128,53 @@ def test_rank_piece_is_slice_of_whole_plan(sim, oracle):
     pieces = [sim.encode(data[a:b], 5, 22, hint, shard, stream_base=a, is_last=(b == len(data)))
               for a, b in ((0, 20000), (20000, 40000), (40000, 60000))]
     assert b"".join(pieces) == whole
+
+
+# --- quality 1: k_fast_* (two-pass fragment compressor) -------------------------------------------
+
+def _fast_inputs():
+    text = G.enwik_text(400000, seed=5, vocab=20000)
+    yield "alice", ALICE
+    yield "random", G.random_bytes(400000, seed=1)                      # raw blocks, fragment rewritten raw
+    yield "text_rand", text[:200000] + G.random_bytes(150000, seed=2) + text[:100000]   # raw block inside a compressed fragment
+    yield "mixed", G.mixed_corpus(1 << 19)
+    yield "zeros", bytes(300000)                                         # one literal symbol, long copies
+    yield "rle", (b"abcdefgh" * 50000)[:333333]
+    for n in (1, 2, 15, 16, 17, 257, 32768, 32769, 131072, 131073):
+        yield "text%d" % n, G.enwik_text(n, seed=n, vocab=2000)
+
+
+FAST = dict(_fast_inputs())
+
+
+@pytest.mark.parametrize("name", list(FAST))
+def test_fast_kernels_one_call(sim, oracle, name):
+    """Whole input in one FINISH call: fragments of 1 << lgwin (table size and 4- or
+    6-byte matches follow the fragment size), both lane orders."""
+    data = FAST[name]
+    for lgwin, reverse in ((22, 0), (16, 1), (10, 0)):
+        if lgwin == 10 and len(data) > 200000:
+            continue
+        assert sim.encode_fast(data, lgwin, None, reverse) == oracle.encode_fast(data, lgwin), (lgwin, reverse)
+
+
+@pytest.mark.parametrize("name", ["alice", "text_rand", "mixed", "text131073"])
+@pytest.mark.parametrize("chunk", [65536, 100000])
+def test_fast_kernels_call_sequences(sim, oracle, name, chunk):
+    """CLI-style feeding: every call is its own run of fragments; the last call is an
+    empty FINISH (a zero-length fragment that only carries ISLAST)."""
+    data = FAST[name]
+    calls, off = [], 0
+    while off < len(data):
+        m = min(chunk, len(data) - off)
+        off += m
+        calls.append((m, 0))
+    calls.append((0, 2))
+    assert sim.encode_fast(data, 22, calls) == oracle.encode_fast(data, 22, calls)
+
+
+def test_fast_kernels_table_slots_are_reused(sim, oracle, monkeypatch):
+    """More fragments than table slots: a wave re-zeroes its table between fragments."""
+    monkeypatch.setenv("SIM_FAST_SLOTS", "2")
+    data = FAST["mixed"]
+    assert sim.encode_fast(data, 16) == oracle.encode_fast(data, 16)
