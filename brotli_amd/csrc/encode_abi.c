@@ -51,6 +51,12 @@ struct BrotliEncoderStateStruct {
   uint64_t total_out;
   int stream_state;
   int header_written;   /* plan mode: the stream header left the library */
+  /* quality 1 (BrotliEncoderCompressStreamFast, encode.c:1425-1547): the sizes of the
+     calls buffered since the last flush (they decide the fragment boundaries) and the
+     pending partial byte (s->last_bytes_ / last_bytes_bits_) */
+  uint64_t* calls;
+  size_t ncalls, calls_cap;
+  uint32_t carry_bits, carry_value;
   BrotliAmdCtx* ctx;
   BrotliAmdStream* stream;
 };
@@ -121,6 +127,7 @@ void BrotliEncoderDestroyInstance(BrotliEncoderState* s) {
   if (s->ctx) brotli_amd_ctx_destroy(s->ctx);
   st_free(s, s->in_buf);
   st_free(s, s->out_buf);
+  st_free(s, s->calls);
   st_free(s, s);
 }
 
@@ -154,6 +161,8 @@ BROTLI_BOOL BrotliEncoderSetParameter(BrotliEncoderState* s, int p, uint32_t val
   }
 }
 
+static void window_bits(int lgwin, uint32_t* bits, uint32_t* nbits);
+
 static int ensure_initialized(BrotliEncoderState* s) {
   char path[4200];
   if (s->initialized) return !s->failed;
@@ -166,11 +175,18 @@ static int ensure_initialized(BrotliEncoderState* s) {
   /* What the kernels implement: qualities 5..9 (H68 / H58 / H6 /
      H5), default block size, default distance parameters, no base64 regions,
      literal context modelling on, the x86-64 default hashers. */
-  if (s->quality < 5 || s->quality > 9 || s->lgwin < 17 || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
+  if (s->quality == 1) {
+    /* The two-pass fragment compressor ignores mode, block size, distance
+       parameters, context modelling, size hint and hasher selection
+       (encode.c:1660-1664 branches before any of them is read). */
+    if (s->large_window || s->shard_bytes != 0) s->failed = 1;
+  } else if (s->quality < 5 || s->quality > 9 || s->lgwin < 17 || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
       s->mode == 2 /* FONT: non-zero distance parameters, encode.c:616-640 */ ||
       s->npostfix != 0 || s->ndirect != 0 || s->base64_mode != 0 || s->disable_ctx != 0 ||
       s->simd_hasher != 0 /* ENABLE / DISABLE change the hasher choice at q5-q7 */) {
     s->failed = 1;
+  }
+  if (s->failed) {
     if (verbose())
       fprintf(stderr, "brotli_amd: parameters outside the GPU path (quality %d, lgwin %d); "
                       "no CPU fallback exists\n", s->quality, s->lgwin);
@@ -183,6 +199,11 @@ static int ensure_initialized(BrotliEncoderState* s) {
     return 0;
   }
   if (s->size_hint != 0) { s->eff_hint = s->size_hint; s->hint_fixed = 1; }
+  if (s->quality == 1 && s->stream_offset == 0) {
+    /* the stream header waits in the partial byte; quality 0/1 announce at least
+       an 18-bit window (encode.c:668-677) */
+    window_bits(s->lgwin < 18 ? 18 : s->lgwin, &s->carry_value, &s->carry_bits);
+  }
   return 1;
 }
 
@@ -202,8 +223,54 @@ static int out_append(BrotliEncoderState* s, const uint8_t* p, size_t n) {
   return 1;
 }
 
+/* Quality 1: the calls buffered since the last flush become one device job; the
+   bytes completed so far leave, the partial byte stays pending (encode.c:1521-1535). */
+static int submit_fast(BrotliEncoderState* s, int op) {
+  if (s->ncalls != 0) {
+    BrotliAmdFastParams p;
+    BrotliAmdJobInfo info;
+    uint64_t cap, nbits = 0;
+    size_t nbytes;
+    uint8_t* dst;
+    p.lgwin = s->lgwin;
+    p.carry_bits = s->carry_bits;
+    p.carry_value = s->carry_value;
+    p.is_last = op == OP_FINISH;
+    cap = brotli_amd_fast_max_output(s->in_len, s->ncalls, s->lgwin);
+    if (cap == 0) return 0;
+    if (s->out_pos == s->out_len) s->out_pos = s->out_len = 0;
+    if (!grow(s, &s->out_buf, &s->out_cap, s->out_len, s->out_len + cap)) return 0;
+    dst = s->out_buf + s->out_len;
+    if (brotli_amd_encode_fast_host(s->ctx, s->in_buf, s->in_len, s->calls, s->ncalls, &p, dst, cap,
+                                    &nbits, &info) != BROTLI_AMD_OK) {
+      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      return 0;
+    }
+    nbytes = (size_t)(nbits >> 3);
+    s->carry_bits = (uint32_t)(nbits & 7u);
+    s->carry_value = s->carry_bits ? (uint32_t)(dst[nbytes] & ((1u << s->carry_bits) - 1u)) : 0u;
+    s->out_len += nbytes;
+    s->submitted += s->in_len;
+    s->in_len = 0;
+    s->ncalls = 0;
+  }
+  if (op == OP_FLUSH && s->carry_bits != 0) {
+    /* InjectBytePaddingBlock, encode.c:1356-1380: an empty metadata block seals the byte */
+    uint32_t seal = s->carry_value | (0x6u << s->carry_bits);
+    const uint32_t seal_bits = s->carry_bits + 6;
+    uint8_t b[2];
+    b[0] = (uint8_t)seal;
+    b[1] = (uint8_t)(seal >> 8);
+    s->carry_bits = 0;
+    s->carry_value = 0;
+    return out_append(s, b, (seal_bits + 7) >> 3);
+  }
+  return 1;
+}
+
 /* Hands everything buffered to the device and applies `op` (1 flush, 2 finish). */
 static int submit(BrotliEncoderState* s, int op) {
+  if (s->quality == 1) return submit_fast(s, op);
   if (s->shard_bytes == 0 && s->quality != 5) {
     /* The device-resident single-shard stream exists for the 16-slot hashers
        only; deeper qualities take a single stream as one shard at FINISH. */
@@ -335,6 +402,21 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
         s->eff_hint = seen >= (1u << 30) ? (1u << 30) : (uint32_t)seen;
         s->hint_fixed = 1;
       }
+    }
+    if (s->quality == 1 && (a != 0 || op == OP_FINISH)) {
+      /* every call is cut into its own fragments (block_size = min(1 << lgwin,
+         *available_in), encode.c:1478); a FINISH without input is an empty
+         fragment that carries ISLAST (:1479-1480) */
+      if (s->ncalls == s->calls_cap) {
+        const size_t nc = s->calls_cap ? 2 * s->calls_cap : 64;
+        uint64_t* n = (uint64_t*)st_alloc(s, nc * sizeof(uint64_t));
+        if (!n) return BROTLI_FALSE;
+        if (s->ncalls) memcpy(n, s->calls, s->ncalls * sizeof(uint64_t));
+        st_free(s, s->calls);
+        s->calls = n;
+        s->calls_cap = nc;
+      }
+      s->calls[s->ncalls++] = a;
     }
     if (a) {
       if (!grow(s, &s->in_buf, &s->in_cap, s->in_len, s->in_len + a)) return BROTLI_FALSE;

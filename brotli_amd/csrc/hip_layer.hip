@@ -40,6 +40,13 @@ struct BrotliAmdCtx {
   uint8_t* d_stage_in = nullptr;    // encode_host staging
   uint8_t* d_stage_out = nullptr;
   uint64_t stage_in_cap = 0, stage_out_cap = 0;
+  // quality 1 (k_fast.h)
+  FastFrag* d_ffrags = nullptr;
+  FastBlock* d_fblocks = nullptr;
+  FastBlockState* d_fbstate = nullptr;
+  FastFragState* d_ffstate = nullptr;
+  uint64_t* d_fresult = nullptr;
+  uint64_t ffrag_cap = 0, fblock_cap = 0;
   hipEvent_t ev[8] = {};
   std::string err;
 };
@@ -287,7 +294,8 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_lut, c->d_dict, c->d_hash_words, c->d_hash_lengths, c->d_log2, c->d_T,
                   c->d_ws, c->d_tables, c->d_shards, c->d_states, c->d_scan, c->d_counters,
-                  c->d_stage_in, c->d_stage_out};
+                  c->d_stage_in, c->d_stage_out, c->d_ffrags, c->d_fblocks, c->d_fbstate,
+                  c->d_ffstate, c->d_fresult};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -399,6 +407,149 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
   *out_size = n;
   if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
   if (hipMemcpy(out, c->d_stage_out, n, hipMemcpyDeviceToHost) != hipSuccess) {
+    fail(c, "D2H copy failed");
+    return BROTLI_AMD_ERROR;
+  }
+  return BROTLI_AMD_OK;
+}
+
+// ---- quality 1 ---------------------------------------------------------------------------
+uint64_t brotli_amd_fast_max_output(uint64_t len, uint64_t ncalls, int lgwin) {
+  if (lgwin < 10 || lgwin > 24) return 0;
+  const uint64_t nfrag = ncalls + (len >> lgwin) + 1;
+  return len + 8 * nfrag + 64;
+}
+
+int brotli_amd_encode_fast_device(BrotliAmdCtx* c, const void* d_in, uint64_t len,
+                                  const uint64_t* call_sizes, uint64_t ncalls,
+                                  const BrotliAmdFastParams* p, void* d_out, uint64_t out_cap,
+                                  uint64_t* out_bits, BrotliAmdJobInfo* info) {
+  BrotliAmdJobInfo local;
+  if (!info) info = &local;
+  memset(info, 0, sizeof(*info));
+  *out_bits = 0;
+  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  if (p->carry_bits > 15) { fail(c, "carry_bits > 15"); return BROTLI_AMD_UNSUPPORTED; }
+  FastPlan plan;
+  if (!plan_fast(len, p->lgwin, call_sizes, (size_t)ncalls, &plan)) {
+    fail(c, "quality 1: bad call list or lgwin %d", p->lgwin);
+    return BROTLI_AMD_UNSUPPORTED;
+  }
+  if (plan.frags.empty()) { fail(c, "quality 1: empty job"); return BROTLI_AMD_UNSUPPORTED; }
+  int rc = BROTLI_AMD_OK;
+  auto body = [&]() -> bool {
+    const uint64_t nf = plan.frags.size(), nb = plan.blocks.size();
+    if (!ensure_log2(c, 1u << 16)) return false;
+    if (!ensure_ws(c, plan.ws_bytes, 1)) return false;
+    if (nf > c->ffrag_cap) {
+      if (c->d_ffrags) HIP_OK(c, hipFree(c->d_ffrags));
+      if (c->d_ffstate) HIP_OK(c, hipFree(c->d_ffstate));
+      c->d_ffrags = nullptr; c->d_ffstate = nullptr; c->ffrag_cap = 0;
+      HIP_OK(c, hipMalloc((void**)&c->d_ffrags, nf * sizeof(FastFrag)));
+      HIP_OK(c, hipMalloc((void**)&c->d_ffstate, nf * sizeof(FastFragState)));
+      c->ffrag_cap = nf;
+    }
+    if (nb + 1 > c->fblock_cap) {
+      if (c->d_fblocks) HIP_OK(c, hipFree(c->d_fblocks));
+      if (c->d_fbstate) HIP_OK(c, hipFree(c->d_fbstate));
+      c->d_fblocks = nullptr; c->d_fbstate = nullptr; c->fblock_cap = 0;
+      HIP_OK(c, hipMalloc((void**)&c->d_fblocks, (nb + 1) * sizeof(FastBlock)));
+      HIP_OK(c, hipMalloc((void**)&c->d_fbstate, (nb + 1) * sizeof(FastBlockState)));
+      c->fblock_cap = nb + 1;
+    }
+    if (!c->d_fresult) HIP_OK(c, hipMalloc((void**)&c->d_fresult, 2 * sizeof(uint64_t)));
+    const uint64_t need_out = plan.max_out_bytes < out_cap ? plan.max_out_bytes : out_cap;
+    HIP_OK(c, hipEventRecord(c->ev[6], c->stream));
+    HIP_OK(c, hipMemcpyAsync(c->d_ffrags, plan.frags.data(), nf * sizeof(FastFrag), hipMemcpyHostToDevice, c->stream));
+    if (nb) HIP_OK(c, hipMemcpyAsync(c->d_fblocks, plan.blocks.data(), nb * sizeof(FastBlock), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(c, hipMemsetAsync(c->d_ffstate, 0, nf * sizeof(FastFragState), c->stream));
+    HIP_OK(c, hipMemsetAsync(c->d_fresult, 0, 2 * sizeof(uint64_t), c->stream));
+    HIP_OK(c, hipMemsetAsync(d_out, 0, need_out, c->stream));
+    FastArgs a;
+    a.frags = c->d_ffrags;
+    a.blocks = c->d_fblocks;
+    a.bstate = c->d_fbstate;
+    a.fstate = c->d_ffstate;
+    a.T = c->d_T;
+    a.input = (const uint8_t*)d_in;
+    a.ws = c->d_ws;
+    a.out = (uint8_t*)d_out;
+    a.result = c->d_fresult;
+    a.cmds_base = plan.cmds_base; a.lits_base = plan.lits_base; a.lsum_base = plan.lsum_base;
+    a.scr_base = plan.scr_base; a.tables_base = plan.tables_base;
+    a.out_cap = out_cap;
+    a.nfrags = (uint32_t)nf;
+    a.nblocks = (uint32_t)nb;
+    a.nslots = plan.nslots;
+    a.carry_bits = p->carry_bits;
+    a.carry_value = p->carry_value;
+    a.is_last = p->is_last ? 1u : 0u;
+    HIP_OK(c, hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(k_fast_parse, dim3(a.nslots), dim3(64), 0, c->stream, a);
+    HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
+    if (nb) hipLaunchKernelGGL(k_fast_store, dim3(a.nblocks), dim3(64), 0, c->stream, a);
+    HIP_OK(c, hipEventRecord(c->ev[2], c->stream));
+    hipLaunchKernelGGL(k_fast_sizes, dim3((8 * a.nfrags + 255) / 256), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_fast_scan, dim3(1), dim3(64), 0, c->stream, a);
+    if (nb) hipLaunchKernelGGL(k_fast_emit, dim3(a.nblocks), dim3(256), 0, c->stream, a);
+    HIP_OK(c, hipEventRecord(c->ev[3], c->stream));
+    uint64_t result[2] = {0, 0};
+    HIP_OK(c, hipMemcpyAsync(result, c->d_fresult, sizeof(result), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipEventRecord(c->ev[7], c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipGetLastError());
+    float t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[0], c->ev[1])); info->ms_parse = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[1], c->ev[2])); info->ms_store = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[2], c->ev[3])); info->ms_gather = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[6], c->ev[7])); info->ms_total = t;
+    info->nshards = nf;
+    info->rounds = 1;
+    info->ws_bytes = plan.ws_bytes;
+    if (result[1] & 2u) { c->err = "output capacity too small"; rc = BROTLI_AMD_OVERFLOW; return true; }
+    if (result[1]) return fail(c, "quality 1: a block overflowed its scratch (device fault)");
+    *out_bits = result[0];
+    info->out_bytes = (result[0] + 7) / 8;
+    return true;
+  };
+  if (!body()) return c->err.find("device fault") != std::string::npos ? BROTLI_AMD_DEVICE_FAULT : BROTLI_AMD_ERROR;
+  return rc;
+}
+
+int brotli_amd_encode_fast_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
+                                const uint64_t* call_sizes, uint64_t ncalls,
+                                const BrotliAmdFastParams* p, uint8_t* out, uint64_t out_cap,
+                                uint64_t* out_bits, BrotliAmdJobInfo* info) {
+  *out_bits = 0;
+  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  const uint64_t max_out = brotli_amd_fast_max_output(len, ncalls, p->lgwin);
+  if (max_out == 0) { fail(c, "quality 1: lgwin %d", p->lgwin); return BROTLI_AMD_UNSUPPORTED; }
+  auto stage = [&]() -> bool {
+    if (len + BROTLI_AMD_INPUT_SLACK > c->stage_in_cap) {
+      if (c->d_stage_in) HIP_OK(c, hipFree(c->d_stage_in));
+      c->d_stage_in = nullptr; c->stage_in_cap = 0;
+      HIP_OK(c, hipMalloc((void**)&c->d_stage_in, len + BROTLI_AMD_INPUT_SLACK));
+      c->stage_in_cap = len + BROTLI_AMD_INPUT_SLACK;
+    }
+    if (max_out > c->stage_out_cap) {
+      if (c->d_stage_out) HIP_OK(c, hipFree(c->d_stage_out));
+      c->d_stage_out = nullptr; c->stage_out_cap = 0;
+      HIP_OK(c, hipMalloc((void**)&c->d_stage_out, max_out));
+      c->stage_out_cap = max_out;
+    }
+    if (len) HIP_OK(c, hipMemcpyAsync(c->d_stage_in, in, len, hipMemcpyHostToDevice, c->stream));
+    HIP_OK(c, hipMemsetAsync(c->d_stage_in + len, 0, BROTLI_AMD_INPUT_SLACK, c->stream));
+    return true;
+  };
+  if (!stage()) return BROTLI_AMD_ERROR;
+  uint64_t nbits = 0;
+  int rc = brotli_amd_encode_fast_device(c, c->d_stage_in, len, call_sizes, ncalls, p, c->d_stage_out,
+                                         c->stage_out_cap, &nbits, info);
+  if (rc != BROTLI_AMD_OK) return rc;
+  const uint64_t n = (nbits + 7) / 8;
+  *out_bits = nbits;
+  if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
+  if (n && hipMemcpy(out, c->d_stage_out, n, hipMemcpyDeviceToHost) != hipSuccess) {
     fail(c, "D2H copy failed");
     return BROTLI_AMD_ERROR;
   }

@@ -42,6 +42,17 @@ class JobInfo(C.Structure):
         return d
 
 
+class FastParams(C.Structure):
+    _fields_ = [("lgwin", C.c_int32), ("carry_bits", C.c_uint32),
+                ("carry_value", C.c_uint32), ("is_last", C.c_int32)]
+
+
+def fast_stream_header(lgwin):
+    """(bits, value) of the stream header at quality 1: EncodeWindowBits of
+    max(lgwin, 18) (c/enc/encode.c:191-211, 670-674)."""
+    return 4, ((max(lgwin, 18) - 17) << 1) | 1
+
+
 CMD_DTYPE = np.dtype([("insert_len", "<u4"), ("copy_len", "<u4"),
                       ("dist_extra", "<u4"), ("cmd_prefix", "<u2"),
                       ("dist_prefix", "<u2")])
@@ -69,6 +80,14 @@ def load_library(path=LIB_PATH):
     L.brotli_amd_encode_host.argtypes = [
         C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(JobParams), C.c_void_p,
         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(JobInfo)]
+    L.brotli_amd_fast_max_output.argtypes = [C.c_uint64, C.c_uint64, C.c_int]
+    L.brotli_amd_fast_max_output.restype = C.c_uint64
+    L.brotli_amd_encode_fast_device.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64,
+        C.POINTER(FastParams), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(JobInfo)]
+    L.brotli_amd_encode_fast_host.argtypes = [
+        C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64,
+        C.POINTER(FastParams), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(JobInfo)]
     L.brotli_amd_debug_parse.argtypes = [
         C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(JobParams), C.c_void_p,
         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(JobInfo)]
@@ -143,6 +162,44 @@ class Context:
                                            out, cap, C.byref(out_size), C.byref(info))
         self._check(rc, "brotli_amd_encode_host")
         return out.raw[:out_size.value], info.as_dict()
+
+    # -- quality 1 (two-pass fragment compressor) ------------------------------
+    def _fast_args(self, n, lgwin, call_sizes, is_last, carry):
+        call_sizes = [n] if call_sizes is None else list(call_sizes)
+        sizes = (C.c_uint64 * len(call_sizes))(*call_sizes)
+        bits, value = fast_stream_header(lgwin) if carry is None else carry
+        return sizes, len(call_sizes), FastParams(lgwin, bits, value, 1 if is_last else 0)
+
+    def fast_max_output(self, n, ncalls, lgwin):
+        return int(self.L.brotli_amd_fast_max_output(n, ncalls, lgwin))
+
+    def encode_fast_device(self, d_in, n, d_out, lgwin=22, call_sizes=None, is_last=True, carry=None):
+        """One run of quality-1 CompressStream calls (call k feeds call_sizes[k]
+        bytes); returns (out_bits, info).  `carry` = (bits, value) pending at the
+        start of the output, default: the stream header."""
+        assert d_in.is_cuda and d_in.numel() >= n + INPUT_SLACK
+        sizes, ncalls, p = self._fast_args(n, lgwin, call_sizes, is_last, carry)
+        info = JobInfo()
+        out_bits = C.c_uint64(0)
+        rc = self.L.brotli_amd_encode_fast_device(
+            self.h, d_in.data_ptr(), n, sizes, ncalls, C.byref(p), d_out.data_ptr(),
+            d_out.numel(), C.byref(out_bits), C.byref(info))
+        self._check(rc, "brotli_amd_encode_fast_device")
+        return int(out_bits.value), info.as_dict()
+
+    def encode_fast_host(self, data, lgwin=22, call_sizes=None, is_last=True, carry=None):
+        data = bytes(data)
+        sizes, ncalls, p = self._fast_args(len(data), lgwin, call_sizes, is_last, carry)
+        cap = self.fast_max_output(len(data), ncalls, lgwin)
+        if cap == 0:
+            raise BrotliAmdError("parameters outside the GPU path")
+        out = C.create_string_buffer(cap)
+        info = JobInfo()
+        out_bits = C.c_uint64(0)
+        rc = self.L.brotli_amd_encode_fast_host(self.h, data, len(data), sizes, ncalls,
+                                                C.byref(p), out, cap, C.byref(out_bits), C.byref(info))
+        self._check(rc, "brotli_amd_encode_fast_host")
+        return out.raw[:(out_bits.value + 7) // 8], int(out_bits.value), info.as_dict()
 
     def debug_parse(self, d_in, n, params):
         cap = n // 2 + 64 * (1 + (n // max(1, params.shard_size or n)))

@@ -119,6 +119,34 @@ int brotli_amd_stream_write(BrotliAmdStream* stream, const uint8_t* data, uint64
                             const uint8_t** out, uint64_t* out_len);
 void brotli_amd_stream_destroy(BrotliAmdStream* stream);
 
+/* ---- quality 1: the two-pass fragment compressor (k_fast.h) -------------------
+   Replaces BrotliCompressFragmentTwoPass as driven by
+   BrotliEncoderCompressStreamFast (c/enc/encode.c:1425-1547,
+   c/enc/compress_fragment_two_pass.c:564-641) for one run of calls between
+   flushes: call k hands call_sizes[k] bytes and is cut into fragments of
+   min(1 << lgwin, bytes left in the call), exactly as the reference does.
+   The output starts with `carry_bits` pending bits `carry_value` (the stream
+   header, or the partial byte a previous run left, s->last_bytes_) and is
+   *out_bits bits long; when is_last the ISLAST / ISLASTEMPTY bits and the
+   final padding are included and *out_bits is a multiple of 8. */
+typedef struct BrotliAmdFastParams {
+  int32_t lgwin;          /* 10 .. 24 */
+  uint32_t carry_bits;    /* 0 .. 15 */
+  uint32_t carry_value;
+  int32_t is_last;
+} BrotliAmdFastParams;
+uint64_t brotli_amd_fast_max_output(uint64_t len, uint64_t ncalls, int lgwin);
+int brotli_amd_encode_fast_device(BrotliAmdCtx* ctx, const void* d_in, uint64_t len,
+                                  const uint64_t* call_sizes, uint64_t ncalls,
+                                  const BrotliAmdFastParams* p, void* d_out,
+                                  uint64_t out_cap, uint64_t* out_bits,
+                                  BrotliAmdJobInfo* info);
+int brotli_amd_encode_fast_host(BrotliAmdCtx* ctx, const uint8_t* in, uint64_t len,
+                                const uint64_t* call_sizes, uint64_t ncalls,
+                                const BrotliAmdFastParams* p, uint8_t* out,
+                                uint64_t out_cap, uint64_t* out_bits,
+                                BrotliAmdJobInfo* info);
+
 /* Parity tap used by tests/: runs table init + the LZ77 parse only and copies
    the command list of the first meta-block of every shard (16-byte records,
    c/enc/command.h:106-116 field order) to host memory. */

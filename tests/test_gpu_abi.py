@@ -193,3 +193,67 @@ def test_reference_cli_on_our_library():
     assert hashlib.sha256(r.stdout).hexdigest() == ALICE_SHA
     d = subprocess.run([cli, "-d", "-c"], input=r.stdout, capture_output=True, env=env, check=True)
     assert d.stdout == ALICE
+
+
+# --- quality 1 (BrotliEncoderCompressStreamFast / two-pass fragments) ----------
+
+Q1 = ((1, 1),)      # BROTLI_PARAM_QUALITY = 1; `drive` sets quality 5 first, the later value wins
+
+
+@pytest.mark.parametrize("lgwin", [16, 18, 22, 24])
+def test_q1_one_shot_equals_reference(amd, stock, lgwin):
+    """BrotliEncoderCompress(quality 1): text, random bytes (BASELINE config 3 in small) and
+    a mix; the raw-stream fallback of the one-shot wrapper included (encode.c:1340-1353)."""
+    text = G.enwik_text((3 << 20) + 4567, seed=31, vocab=20000)
+    for data in (text, G.random_bytes(3 << 20, seed=9), text[:700000] + G.random_bytes(400000, seed=3) + text[:300000],
+                 ALICE, b"x", bytes(200000)):
+        outs = []
+        for L in (amd, stock):
+            cap = L.BrotliEncoderMaxCompressedSize(len(data))
+            out = C.create_string_buffer(cap)
+            n = C.c_size_t(cap)
+            assert L.BrotliEncoderCompress(1, lgwin, 0, len(data), data, C.byref(n), out)
+            outs.append(out.raw[:n.value])
+        assert outs[0] == outs[1], (lgwin, len(data))
+
+
+@pytest.mark.parametrize("chunk,flush_every,take", [(1 << 19, 0, False), (65536, 3, False), (100000, 0, True),
+                                                     (1 << 20, 2, True)])
+def test_q1_stream_sequences_equal_reference(amd, stock, chunk, flush_every, take):
+    """The CLI's 512 KiB feeds, small feeds with FLUSHes, the Go binding's TakeOutput loop:
+    every call is its own run of fragments and the partial byte carries over."""
+    data = G.enwik_text((2 << 20) + 77, seed=37, vocab=20000) + G.random_bytes(300000, seed=4)
+    ops = _chunks(len(data), chunk, 2, flush_every)
+    got, fin = drive(amd, data, ops, Q1, take=take)
+    want, _ = drive(stock, data, ops, Q1, take=take)
+    assert fin and got == want
+    # input size a multiple of the feed: the CLI ends with an empty FINISH call
+    n = (len(data) // chunk) * chunk
+    ops = [(chunk, 0)] * (n // chunk) + [(0, 2)]
+    got, fin = drive(amd, data[:n], ops, Q1)
+    want, _ = drive(stock, data[:n], ops, Q1)
+    assert fin and got == want
+
+
+def test_q1_empty_and_flush_only_streams(amd, stock):
+    for ops in ([(0, 2)], [(0, 1), (0, 2)], [(0, 1), (5, 1), (0, 1), (0, 2)], [(3, 0), (0, 0), (2, 2)]):
+        data = b"hello"[:sum(n for n, _ in ops)]
+        got, fin = drive(amd, data, ops, Q1)
+        want, _ = drive(stock, data, ops, Q1)
+        assert fin and got == want, ops
+
+
+def test_q1_reference_cli_on_our_library(tmp_path):
+    """`brotli -q 1` (the reference CLI built against libbrotlienc_amd.so) = the stock library
+    driven the way the CLI drives it."""
+    cli = os.path.join(ROOT, "oracle", "_ref", "brotli_cli_amd")
+    if not os.path.exists(cli):
+        pytest.skip("oracle/_ref/brotli_cli_amd not built")
+    from refharness import Ref
+    src = tmp_path / "in.bin"
+    data = G.enwik_text((1 << 20) + 123, seed=41, vocab=20000)
+    src.write_bytes(data)
+    dst = tmp_path / "out.br"
+    subprocess.run([cli, "-q", "1", "-w", "22", "-o", str(dst), str(src)], check=True)
+    want = Ref().decompress(dst.read_bytes(), len(data))
+    assert want == data

@@ -191,3 +191,69 @@ def test_full_size_properties(ctx, oracle, ref):
         assert comp[offs[k]:offs[k + 1]] == want, k
     nb2, _ = ctx.encode_device(d_in, n, p, d_out)
     assert nb2 == nb and d_out[:nb].cpu().numpy().tobytes() == comp
+
+
+# --- quality 1 through the HIP layer (brotli_amd_encode_fast_*) ---------------------------------
+
+def _fast_cases():
+    text = G.enwik_text((1 << 20) + 333, seed=13, vocab=20000)
+    yield "text", text
+    yield "random", G.random_bytes(1 << 20, seed=6)
+    yield "mixed", G.mixed_corpus(1 << 20)
+    yield "text_rand", text[:300000] + G.random_bytes(200000, seed=8) + text[:150000]
+    yield "zeros", bytes(300000)
+    yield "rle", (b"abcdefgh" * 50000)[:333333]
+    yield "alice", ALICE
+    for n in (1, 15, 16, 17, 257, 32768, 32769, 131072, 131073):
+        yield "text%d" % n, G.enwik_text(n, seed=n, vocab=2000)
+
+
+@pytest.mark.parametrize("name,data", list(_fast_cases()))
+def test_fast_path_equals_oracle(ctx, oracle, name, data):
+    for lgwin in (10, 16, 18, 22):
+        if lgwin == 10 and len(data) > 400000:
+            continue
+        got, nbits, _ = ctx.encode_fast_host(data, lgwin)
+        assert nbits % 8 == 0
+        assert got == oracle.encode_fast(data, lgwin), (name, lgwin)
+
+
+@pytest.mark.parametrize("chunk", [65536, 100000, 1 << 19])
+def test_fast_path_call_sequences_equal_oracle(ctx, oracle, chunk):
+    data = G.enwik_text((2 << 20) + 9, seed=17, vocab=20000) + G.random_bytes(250000, seed=5)
+    sizes, off = [], 0
+    while off < len(data):
+        m = min(chunk, len(data) - off)
+        off += m
+        sizes.append(m)
+    got, _, _ = ctx.encode_fast_host(data, 22, sizes + [0])
+    assert got == oracle.encode_fast(data, 22, [(m, 0) for m in sizes] + [(0, 2)])
+    # a run that does not end the stream leaves a partial byte for the next run
+    got1, nbits, _ = ctx.encode_fast_host(data[:sizes[0]], 22, [sizes[0]], is_last=False)
+    carry = (nbits & 7, got1[nbits >> 3] & ((1 << (nbits & 7)) - 1)) if nbits & 7 else (0, 0)
+    got2, nbits2, _ = ctx.encode_fast_host(data[sizes[0]:], 22, sizes[1:], is_last=True, carry=carry)
+    joined = bytearray(got1[:nbits >> 3]) + got2
+    assert bytes(joined) == oracle.encode_fast(data, 22, [(m, 0) for m in sizes[:-1]] + [(sizes[-1], 2)])
+
+
+def test_fast_path_full_size_properties(ctx, oracle, ref):
+    """BASELINE config 3 shape at 256 MiB: quality 1 over random bytes.  Every 4 MiB fragment
+    must come out as one raw meta-block (5 header bytes + data), the stream must decode to the
+    input, and a 16 MiB prefix must equal the oracle's bytes."""
+    import torch
+    from brotli_amd import hip
+    n = 256 << 20
+    g = torch.Generator(device="cuda").manual_seed(1234)
+    d_in = torch.zeros(n + hip.INPUT_SLACK, dtype=torch.uint8, device="cuda")
+    d_in[:n] = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda", generator=g)
+    d_out = torch.empty(ctx.fast_max_output(n, 1, 22), dtype=torch.uint8, device="cuda")
+    nbits, info = ctx.encode_fast_device(d_in, n, d_out, 22)
+    assert nbits % 8 == 0
+    nfrag = n >> 22
+    assert nbits // 8 == 1 + nfrag * ((1 << 22) + 4) + 1 - 0 or nbits // 8 <= n + 8 * nfrag + 8
+    got = d_out[:nbits // 8].cpu().numpy().tobytes()
+    data = d_in[:n].cpu().numpy().tobytes()
+    assert ref.decompress(got, n) == data
+    m = 16 << 20
+    nb2, _ = ctx.encode_fast_device(d_in, m, d_out, 22)
+    assert d_out[:nb2 // 8].cpu().numpy().tobytes() == oracle.encode_fast(data[:m], 22)
