@@ -243,17 +243,18 @@ def test_q1_empty_and_flush_only_streams(amd, stock):
         assert fin and got == want, ops
 
 
-def test_q1_reference_cli_on_our_library(tmp_path):
+def test_q1_reference_cli_on_our_library(tmp_path, stock):
     """`brotli -q 1` (the reference CLI built against libbrotlienc_amd.so) = the stock library
-    driven the way the CLI drives it."""
+    driven the way the CLI drives it: 512 KiB reads, FINISH with the read that hits EOF
+    (c/tools/brotli.c:1419-1463)."""
     cli = os.path.join(ROOT, "oracle", "_ref", "brotli_cli_amd")
     if not os.path.exists(cli):
         pytest.skip("oracle/_ref/brotli_cli_amd not built")
-    from refharness import Ref
     src = tmp_path / "in.bin"
     data = G.enwik_text((1 << 20) + 123, seed=41, vocab=20000)
     src.write_bytes(data)
-    dst = tmp_path / "out.br"
-    subprocess.run([cli, "-q", "1", "-w", "22", "-o", str(dst), str(src)], check=True)
-    want = Ref().decompress(dst.read_bytes(), len(data))
-    assert want == data
+    dropin = os.path.join(LIBDIR, "dropin")
+    env = dict(os.environ, LD_LIBRARY_PATH=dropin + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    r = subprocess.run([cli, "-q", "1", "-w", "22", "-c", str(src)], capture_output=True, env=env, check=True)
+    want, _ = drive(stock, data, _chunks(len(data), 1 << 19, 2), Q1)
+    assert r.stdout == want
