@@ -104,6 +104,101 @@ def cpu_baseline(data, quality, lgwin, shard_size, size_hint):
                       "ratio %.3f" % (len(sample) >> 20, cores, dt, len(sample) / max(1, out_bytes))}
 
 
+def main_q1(args):
+    """BASELINE configs[2]: quality 1 (two-pass fragment compressor) on one GPU.  The stream is
+    the reference's own unpartitioned stream: one BrotliEncoderCompress-style FINISH call
+    (fragments of 1 << lgwin) or, with --feed-kb, the CLI's call pattern."""
+    import torch
+    import gen_inputs as G
+    from brotli_amd import hip
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+        sys.exit("quality 1 is a single-GPU configuration (BASELINE configs[2])")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    n = args.size_mb << 20
+    if args.data == "random":
+        g = torch.Generator(device="cuda").manual_seed(G.SEED)
+        d_in = torch.zeros(n + hip.INPUT_SLACK, dtype=torch.uint8, device=dev)
+        d_in[:n] = torch.randint(0, 256, (n,), dtype=torch.uint8, device=dev, generator=g)
+        data = None
+    else:
+        data = G.enwik_text(n, seed=G.SEED)
+        d_in = hip.to_device(data, 0)
+    ctx = hip.Context(0)
+    feed = args.feed_kb << 10
+    calls = None
+    if feed:
+        calls = [min(feed, n - o) for o in range(0, n, feed)]
+        if n % feed == 0:
+            calls.append(0)
+    d_out = torch.empty(ctx.fast_max_output(n, len(calls) if calls else 1, args.lgwin), dtype=torch.uint8, device=dev)
+
+    def step():
+        return ctx.encode_fast_device(d_in, n, d_out, args.lgwin, calls)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    infos = []
+    nbits = 0
+    for _ in range(args.steps):
+        nbits, info = step()
+        infos.append(info)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    nbytes = nbits // 8
+    stage = {k: round(sum(i[k] for i in infos) / len(infos), 3) for k in ("ms_total", "ms_parse", "ms_store", "ms_gather")}
+    stage["ms_place"] = stage.pop("ms_gather")
+    dom = max(("ms_parse", "ms_store", "ms_place"), key=lambda k: stage[k])
+    kernel = {"ms_parse": "k_fast_parse", "ms_store": "k_fast_store", "ms_place": "k_fast_sizes+scan+emit"}[dom]
+    # algorithmic bytes per launch (DESIGN.md): parse reads the input once and writes the literal
+    # bytes + command words it keeps; store reads those and writes the bit string; place moves
+    # the output once (read + write).
+    out_b = float(nbytes)
+    algo = {"ms_parse": 2.0 * n, "ms_store": 2.0 * n + out_b, "ms_place": 2.0 * out_b}[dom]
+    achieved = algo / (stage[dom] / 1e3) / 1e9
+    line = {
+        "metric": "encode MB/s at quality 1, lgwin %d, %d MiB %s input; bit-exact vs c/enc" % (
+            args.lgwin, args.size_mb, args.data),
+        "value": round(n / 1e6 / (dt / args.steps), 1), "unit": "MB/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {
+            "workload": "%d MiB %s, quality 1, lgwin %d, 1 x MI355X" % (
+                args.size_mb, "uniform random bytes (torch.randint on the device, seed %d)" % G.SEED
+                if args.data == "random" else "synthetic enwik-style text (tests/gen_inputs.enwik_text)", args.lgwin),
+            "call_pattern": "one FINISH call (fragments of %d KiB)" % (1 << (args.lgwin - 10)) if not feed else
+                            "%d KiB per CompressStream call (c/tools/brotli.c pattern)" % args.feed_kb,
+            "fragments": infos[-1]["nshards"], "compressed_bytes": nbytes, "ratio": round(n / max(1, nbytes), 4),
+            "stage_ms": stage,
+        },
+        "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "note": "dominant stage %s: %.3f ms per launch (HIP events on the library's stream), "
+                             "algorithmic bytes %.0f per launch" % (dom, stage[dom], algo)},
+    }
+    if not args.no_cpu_baseline:
+        from refharness import Ref, have_ref, Oracle
+        m = min(n, 256 << 20)
+        sample = d_in[:m].cpu().numpy().tobytes() if data is None else data[:m]
+        # spot check: the first 16 MiB against the oracle
+        k = min(n, 16 << 20)
+        nb2, _ = ctx.encode_fast_device(d_in, k, d_out, args.lgwin)
+        line["config"]["spot_check_first_16MiB_bit_exact"] = \
+            d_out[:nb2 // 8].cpu().numpy().tobytes() == Oracle().encode_fast(sample[:k], args.lgwin)
+        if have_ref():
+            r = Ref()
+            t0 = time.perf_counter()
+            out = r.encode_calls(sample, 1, args.lgwin, [(len(sample), 2)])
+            dtc = time.perf_counter() - t0
+            line["cpu_baseline"] = {"value": round(len(sample) / 1e6 / dtc, 1), "unit": "MB/s", "cores": 1,
+                                    "kind": "reference",
+                                    "sample": "first %d MiB, one reference encoder instance (the reference has no "
+                                              "threads), %.2f s, ratio %.3f" % (m >> 20, dtc, len(sample) / len(out))}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,7 +209,11 @@ def main():
     ap.add_argument("--quality", type=int, default=5)
     ap.add_argument("--lgwin", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--data", choices=["text", "random"], default="text", help="quality 1 only")
+    ap.add_argument("--feed-kb", type=int, default=0, help="quality 1 only: KiB per CompressStream call (0 = one call)")
     args = ap.parse_args()
+    if args.quality == 1:
+        return main_q1(args)
 
     import numpy as np
     import torch
