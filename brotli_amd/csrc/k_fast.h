@@ -147,13 +147,26 @@ DEV uint32_t fast_match_length(const uint8_t* a, const uint8_t* b, uint32_t limi
 DEV void fast_copy_literals(uint8_t* dst, const uint8_t* src, uint32_t n) {
   const int lane = wave_lane();
   if (n >= 1024) {
-    const uint32_t n16 = n & ~15u;
-    for (uint32_t j = 16u * (uint32_t)lane; j < n16; j += 1024) {
+    // long literal runs (incompressible data): 4 KiB per step, four 16-byte loads in
+    // flight per lane before the stores
+    const uint32_t n4k = n & ~4095u, n16 = n & ~15u;
+    uint32_t j = 16u * (uint32_t)lane;
+    for (; j < n4k; j += 4096) {
+      uint64_t v[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { v[2 * q] = ld64(src + j + 1024u * q); v[2 * q + 1] = ld64(src + j + 1024u * q + 8); }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        __builtin_memcpy(dst + j + 1024u * q, &v[2 * q], 8);
+        __builtin_memcpy(dst + j + 1024u * q + 8, &v[2 * q + 1], 8);
+      }
+    }
+    for (; j < n16; j += 1024) {
       const uint64_t lo = ld64(src + j), hi = ld64(src + j + 8);
       __builtin_memcpy(dst + j, &lo, 8);
       __builtin_memcpy(dst + j + 8, &hi, 8);
     }
-    for (uint32_t j = n16 + (uint32_t)lane; j < n; j += 64) dst[j] = src[j];
+    for (uint32_t k = n16 + (uint32_t)lane; k < n; k += 64) dst[k] = src[k];
   } else {
     for (uint32_t j = (uint32_t)lane; j < n; j += 64) dst[j] = src[j];
   }
