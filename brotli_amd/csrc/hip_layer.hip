@@ -162,8 +162,13 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
   uint64_t longest = 0;
   for (const ShardDesc& D : plan->shards) if (D.len > longest) longest = D.len;
   if (plan->J.quality == 5) {
-    if (!(p->flags & BROTLI_AMD_FLAG_NO_QUAD) && longest <= plan->J.max_backward_limit)
+    if (!(p->flags & BROTLI_AMD_FLAG_NO_QUAD) && longest <= plan->J.max_backward_limit) {
       plan->J.flags |= JOB_FLAG_QUAD;
+      if (const char* e = getenv("BROTLI_AMD_QGROUPS")) {   // experiment knob: shards per wave (1, 2, 4)
+        const int v = atoi(e);
+        if (v == 1 || v == 2) plan->J.flags |= (uint32_t)v << JOB_FLAG_GROUPS_SHIFT;
+      }
+    }
   } else {
     // deep-bucket qualities: shards must fit the window (no ring-wrap rules in k_parse_deep.h)
     if (longest > plan->J.max_backward_limit) {
@@ -204,6 +209,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
   if (ibs > 64) ibs = 64;
   a.init_blocks_per_shard = ibs;
 
+  const uint32_t gpw = ((plan.J.flags >> JOB_FLAG_GROUPS_SHIFT) & 3u) ? ((plan.J.flags >> JOB_FLAG_GROUPS_SHIFT) & 3u) : 4u;
   float ms_parse = 0, ms_build = 0, ms_store = 0;
   hipLaunchKernelGGL(k_init, dim3(nshards * ibs), dim3(256), 0, c->stream, a);
   HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
@@ -216,7 +222,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       else if (plan.J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(nshards), dim3(64), 0, c->stream, a);
       else hipLaunchKernelGGL(k_parse_deep<4>, dim3(nshards), dim3(64), 0, c->stream, a);
     } else if (plan.J.flags & JOB_FLAG_QUAD)
-      hipLaunchKernelGGL(k_parse4, dim3((nshards + 3) / 4), dim3(64), 0, c->stream, a);
+      hipLaunchKernelGGL(k_parse4, dim3((nshards + gpw - 1) / gpw), dim3(64), 0, c->stream, a);
     else
       hipLaunchKernelGGL(k_parse, dim3(nshards), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev[3], c->stream));

@@ -654,13 +654,19 @@ DEV void q_setup_block(const JobParams& J, QShard& g, bool want, uint8_t* lds_du
   }
 }
 
+DEV uint32_t q_groups_per_wave(const JobParams& J) {
+  const uint32_t v = (J.flags >> JOB_FLAG_GROUPS_SHIFT) & 3u;
+  return v ? v : (uint32_t)Q_GROUPS;
+}
+
 // ---- the kernel body: up to four shards per wave ---------------------------------------
 DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* states,
                       uint32_t nshards, const DeviceTables* T, const uint8_t* input, uint8_t* ws,
                       uint32_t wave_index, uint8_t* lds_dup) {
   const int t = q_t();
-  const uint32_t shard = wave_index * Q_GROUPS + (uint32_t)(wave_lane() >> 4);
-  const bool alive = shard < nshards;
+  const uint32_t gpw = q_groups_per_wave(J);
+  const uint32_t shard = wave_index * gpw + (uint32_t)(wave_lane() >> 4);
+  const bool alive = (uint32_t)(wave_lane() >> 4) < gpw && shard < nshards;
   const bool writer = alive && t == 0;
   const uint32_t htl = hasher_htl(J.hasher_type);
   const ShardDesc& D = shards[alive ? shard : 0];

@@ -62,7 +62,7 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
     if (plan.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
     else if (plan.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
     else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
-  } else if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
+  } else if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
   else run(k_parse, a, a.nshards, 64, reverse);
   if (getenv("SIM_COUNTS")) {
     fprintf(stderr, "sim counts: steps=%llu with_bucket_cand=%llu ext=%llu store_steps=%llu dict=%llu slow=%llu dup=%llu\n",
@@ -122,7 +122,7 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
       if (plan.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
       else if (plan.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
       else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
-    } else if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + 3) / 4, 64, reverse);
+    } else if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
     else run(k_parse, a, a.nshards, 64, reverse);
     run(k_build, a, a.nshards, 64, reverse);
     if (getenv("SIM_DEBUG")) {

@@ -106,6 +106,16 @@ def test_deep_kernel_step_by_step_resolve(sim, oracle, quality):
         _oracle_plan_q(oracle, data, quality, 22, 1 << 30, 0)
 
 
+@pytest.mark.parametrize("groups", [1, 2])
+def test_quad_kernel_fewer_shards_per_wave(sim, oracle, groups):
+    """JOB_FLAG_GROUPS: one or two 16-lane groups of a wave own a shard, the others idle."""
+    data, shard, hint = CASES["ragged_shards"]
+    assert sim.encode(data, size_hint=hint, shard_size=shard, flags=2 | (groups << 8)) == \
+        oracle.encode_plan(data, 5, 22, shard) if not hint else True
+    data = G.enwik_text(300000, seed=77, vocab=5000)
+    assert sim.encode(data, shard_size=50000, flags=2 | (groups << 8)) == oracle.encode_plan(data, 5, 22, 50000)
+
+
 def test_quad_kernel_many_shards_reverse(sim, oracle):
     """7 shards over 2 waves (one group idle), lanes scheduled high-to-low."""
     data = G.enwik_text(70000, seed=13, vocab=3000)
