@@ -17,6 +17,7 @@
 
 struct BrotliAmdCtx {
   int device = 0;
+  int num_cus = 256;
   hipStream_t stream = nullptr;
   HostTables ht;
   uint8_t* d_lut = nullptr;
@@ -164,10 +165,14 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
   if (plan->J.quality == 5) {
     if (!(p->flags & BROTLI_AMD_FLAG_NO_QUAD) && longest <= plan->J.max_backward_limit) {
       plan->J.flags |= JOB_FLAG_QUAD;
-      if (const char* e = getenv("BROTLI_AMD_QGROUPS")) {   // experiment knob: shards per wave (1, 2, 4)
-        const int v = atoi(e);
-        if (v == 1 || v == 2) plan->J.flags |= (uint32_t)v << JOB_FLAG_GROUPS_SHIFT;
-      }
+      // Shards per wave: the kernel holds <= 128 VGPRs, i.e. 16 waves per CU stay resident.
+      // While every shard can have a wave (or half of one) to itself, lock-stepping four
+      // shards only makes each wait for the others' phases (measured, profiles/r01_k_*:
+      // 4096 shards of 256 KiB: 315 / 288 / 280 ms with 4 / 2 / 1 shards per wave).
+      const uint64_t resident = (uint64_t)c->num_cus * 16u;
+      int v = plan->shards.size() <= resident ? 1 : plan->shards.size() <= 2 * resident ? 2 : 4;
+      if (const char* e = getenv("BROTLI_AMD_QGROUPS")) v = atoi(e);   // experiment knob
+      if (v == 1 || v == 2) plan->J.flags |= (uint32_t)v << JOB_FLAG_GROUPS_SHIFT;
     }
   } else {
     // deep-bucket qualities: shards must fit the window (no ring-wrap rules in k_parse_deep.h)
@@ -283,6 +288,7 @@ int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** ou
     HIP_OK(c, hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
       return fail(c, "device %d is %s; this library contains gfx950 code only", device, prop.gcnArchName);
+    c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_OK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_OK(c, hipEventCreate(&e));
     if (!dev_upload(c, &c->d_lut, c->ht.context_lut, 2048)) return false;

@@ -172,26 +172,40 @@ DEV void fast_copy_literals(uint8_t* dst, const uint8_t* src, uint32_t n) {
   }
 }
 
+// The hash-table refresh after a copy (:354-386, :410-442): NE ordered (hash,
+// position) stores inside the copy just made, then the probe at `ip`.  Lane j < NE
+// holds store j, lane NE the probe; a later store to the same slot wins, and the
+// probe sees the latest of them (or memory).  Returns the probe's candidate.
+// `first`: the variant used after the first match of a scan, which with 4-byte
+// hashes keys the third store with the first store's bytes again (:362-363).
+template <int MM>
+DEV uint32_t fast_refresh(const uint8_t* base, uint32_t ip, uint32_t* table, uint32_t shift, bool first) {
+  const int lane = wave_lane();
+  const int NE = MM == 4 ? 3 : 5;
+  uint32_t h = 0xFFFFFFFFu, val = 0, tv = 0;
+  if (lane <= NE) {
+    uint32_t p = ip - (uint32_t)NE + (uint32_t)lane;   // position whose bytes are hashed
+    val = p;
+    if (MM == 4 && first && lane == 2) p = ip - 3;       // hashed bytes of store 0, value ip - 1
+    h = fast_hash<MM>(ld64(base + p), shift);
+    if (lane == NE) tv = table[h];
+  }
+  int prev, next;
+  wave_equal_neighbours(h, NE + 1, &prev, &next);
+  const uint32_t pv = wave_shfl(val, prev < 0 ? 0 : prev);
+  const uint32_t cand = prev >= 0 ? pv : tv;
+  if (lane <= NE && next > NE) table[h] = val;
+  wave_sync();
+  return wave_bcast(cand, NE);
+}
+
 // ---- CreateCommands (:234-459) of one block, one wave ----------------------------------
 // Positions are offsets from the fragment's first byte (`base`).
-//
-// One step of the loop below runs up to 64 table probes of the reference at once:
-//   * after a copy, lanes [0, NE) are the hash-table refresh stores inside the copy
-//     just made (:354-386, :410-442) and lane NE is the probe at the copy's end (the
-//     "no literals in between" match test, :388-391);
-//   * the remaining lanes are consecutive probes of the scan (:264-289), whose
-//     positions follow from the skip counter alone.
-// Every probe reads table[hash] and then stores its own position there, in probe
-// order: lane l sees the store of the latest earlier lane with the same hash
-// (wave_equal_neighbours), else memory; of equal hashes only the last lane that
-// really ran writes.  The first lane that finds a usable match (ballot) — or runs
-// out of input — ends the step; later lanes never happened.
 template <int MM>
 DEV void fast_create_commands(const uint8_t* base, uint32_t in0, uint32_t block_size, uint32_t left,
                               uint32_t* table, uint32_t shift, uint32_t* cmds, uint8_t* lits,
                               uint32_t* ncmds_out, uint32_t* nlits_out) {
   const int lane = wave_lane();
-  const int NE = MM == 4 ? 3 : 5;
   uint32_t ncmds = 0, nlits = 0;
   const uint32_t ip_end = in0 + block_size;
   uint32_t next_emit = in0;
@@ -199,35 +213,29 @@ DEV void fast_create_commands(const uint8_t* base, uint32_t in0, uint32_t block_
     const uint32_t la = block_size - MM, lb = left - 16u;
     const uint32_t ip_limit = in0 + (la < lb ? la : lb);
     int32_t last_distance = -1;
-    uint32_t ip = in0 + 1;     // scan mode: next probe; after a copy: the copy's end
+    uint32_t ip = in0 + 1;
     uint32_t skip = 32;
-    bool after_copy = false, first = false;
+    // Probes per step: on compressible data a scan ends within a few probes, and a
+    // lone wave pays for every instruction of the step (the same-hash ranking below is
+    // a loop over the participating lanes), so a scan starts 16 wide and doubles while
+    // nothing is found; incompressible data runs 64 wide almost always.
+    int width = 16;
     for (;;) {
-      const int R = after_copy ? NE + 1 : 0;          // lanes that are not scan probes
-      const uint32_t sk = after_copy ? 32u : skip;
-      const uint32_t scan_ip = after_copy ? ip + 1u : ip;
-      const bool is_scan = lane >= R;
-      // scan probe t looks at scan_ip + sum of (s >> 5) for s in [sk, sk + t): closed form
-      const uint32_t t = (uint32_t)(lane - R);
-      const uint32_t s = sk + t, q = s >> 5, r = s & 31u;
-      const uint32_t q0 = sk >> 5, r0 = sk & 31u;
-      uint32_t pos = scan_ip + (16u * q * (q - 1u) + q * r) - (16u * q0 * (q0 - 1u) + q0 * r0);
+      // -- the next `width` probes of the scan: probe t looks at ip + sum of (s >> 5) for
+      //    s in [skip, skip + t), a closed form in skip + t
+      const uint32_t s = skip + (uint32_t)lane, q = s >> 5, r = s & 31u;
+      const uint32_t q0 = skip >> 5, r0 = skip & 31u;
+      const uint32_t pos = ip + (16u * q * (q - 1u) + q * r) - (16u * q0 * (q0 - 1u) + q0 * r0);
       const uint32_t nxt = pos + q;
-      bool valid = nxt <= ip_limit;                   // monotonic over the scan lanes
-      uint32_t hpos = pos;                            // position whose bytes are hashed
-      if (!is_scan) {
-        valid = true;
-        pos = ip - (uint32_t)NE + (uint32_t)lane;     // refresh store j: ip - NE + j; probe (lane NE): ip
-        hpos = pos;
-        if (MM == 4 && first && lane == 2) hpos = ip - 3u;   // :362-363 keys the third store with the first one's bytes
-      }
+      const bool active = lane < width;
+      const bool valid = active && nxt <= ip_limit;   // monotonic in the lane
       uint64_t x = 0, yl = 0;
       uint32_t h = 0xFFFFFFFFu, tv = 0;
       if (valid) {
-        x = ld64(base + hpos);
-        if (is_scan && last_distance > 0) yl = ld64(base + pos - (uint32_t)last_distance);
+        x = ld64(base + pos);
+        if (last_distance > 0) yl = ld64(base + pos - (uint32_t)last_distance);
         h = fast_hash<MM>(x, shift);
-        if (lane >= R - 1) tv = table[h];             // refresh stores do not read the table
+        tv = table[h];
       }
       const int nv = dev_popc64(wave_ballot(valid));
       int prev, next;
@@ -235,39 +243,31 @@ DEV void fast_create_commands(const uint8_t* base, uint32_t in0, uint32_t block_
       const uint32_t pv = wave_shfl(pos, prev < 0 ? 0 : prev);
       const uint32_t cand = prev >= 0 ? pv : tv;     // what table[h] holds when this probe runs
       bool hit_l = false, hit_t = false;
-      if (valid && lane >= R - 1) {
-        hit_l = is_scan && last_distance > 0 && fast_is_match<MM>(x, yl);
+      if (valid) {
+        hit_l = last_distance > 0 && fast_is_match<MM>(x, yl);
         hit_t = fast_is_match<MM>(x, ld64(base + cand)) && pos - cand <= FAST_MAX_DISTANCE;
       }
-      const uint64_t stops = wave_ballot(!valid || hit_l || hit_t);
+      const uint64_t stops = wave_ballot(active && (!valid || hit_l || hit_t));
       const int f = stops ? dev_ctz64(stops) : 64;
-      const bool f_hit = f < nv;                      // valid lanes stop only on hits
-      const int last_commit = f_hit ? f : f - 1;      // probes that ran and wrote the table
+      const bool f_hit = f < nv;                      // lane f is a hit (valid lanes stop only on hits)
+      const int last_commit = f_hit ? f : (f == 64 ? width - 1 : f - 1);   // probes that ran and wrote the table
       if (valid && lane <= last_commit && next > last_commit) table[h] = pos;
       wave_sync();
       if (f == 64) {
-        skip = sk + (uint32_t)(64 - R);
-        ip = wave_bcast(nxt, 63);
-        after_copy = false;
+        skip += (uint32_t)width;
+        ip = wave_bcast(nxt, width - 1);
+        if (width < 64) width *= 2;
         continue;
       }
       if (!f_hit) break;                              // next_ip > ip_limit: emit_remainder
       // -- a match at lane f
-      const uint32_t mpos = wave_bcast(pos, f);
+      ip = wave_bcast(pos, f);
       const bool by_last = wave_bcast((uint32_t)hit_l, f) != 0;
-      const uint32_t candidate = by_last ? mpos - (uint32_t)last_distance : wave_bcast(cand, f);
-      const uint32_t matched = MM + fast_match_length(base + candidate + MM, base + mpos + MM, ip_end - mpos - MM);
-      const uint32_t distance = mpos - candidate;
-      if (f < R) {
-        // the probe at the end of the previous copy: a copy without literals (:392-409)
-        if (lane == 0) {
-          cmds[ncmds] = fast_copy_word(matched);
-          cmds[ncmds + 1] = fast_distance_word(distance);
-        }
-        ncmds += 2;
-        first = false;
-      } else {
-        const uint32_t insert = mpos - next_emit;
+      uint32_t candidate = by_last ? ip - (uint32_t)last_distance : wave_bcast(cand, f);
+      {
+        const uint32_t matched = MM + fast_match_length(base + candidate + MM, base + ip + MM, ip_end - ip - MM);
+        const uint32_t distance = ip - candidate;
+        const uint32_t insert = ip - next_emit;
         uint32_t w0;
         const uint32_t nw = fast_copy_last_words(matched, &w0);
         const bool same = (int32_t)distance == last_distance;
@@ -281,13 +281,35 @@ DEV void fast_create_commands(const uint8_t* base, uint32_t in0, uint32_t block_
         fast_copy_literals(lits + nlits, base + next_emit, insert);
         ncmds += 2u + nw;
         nlits += insert;
-        first = true;
+        last_distance = (int32_t)distance;
+        ip += matched;
+        next_emit = ip;
       }
-      last_distance = (int32_t)distance;
-      ip = mpos + matched;
-      next_emit = ip;
       if (ip >= ip_limit) break;
-      after_copy = true;
+      candidate = fast_refresh<MM>(base, ip, table, shift, true);
+      bool out_of_input = false;
+      for (;;) {
+        // matches that start exactly where the previous copy ended (:388-443)
+        if (ip - candidate > FAST_MAX_DISTANCE) break;
+        uint64_t xa = 0, xb = 0;
+        if (lane == 0) { xa = ld64(base + ip); xb = ld64(base + candidate); }
+        if (!wave_bcast((uint32_t)fast_is_match<MM>(xa, xb), 0)) break;
+        const uint32_t matched = MM + fast_match_length(base + candidate + MM, base + ip + MM, ip_end - ip - MM);
+        last_distance = (int32_t)(ip - candidate);
+        if (lane == 0) {
+          cmds[ncmds] = fast_copy_word(matched);
+          cmds[ncmds + 1] = fast_distance_word((uint32_t)last_distance);
+        }
+        ncmds += 2;
+        ip += matched;
+        next_emit = ip;
+        if (ip >= ip_limit) { out_of_input = true; break; }
+        candidate = fast_refresh<MM>(base, ip, table, shift, false);
+      }
+      if (out_of_input) break;
+      ++ip;
+      skip = 32;
+      width = 16;
     }
   }
   // emit_remainder
