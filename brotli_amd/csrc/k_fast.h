@@ -144,6 +144,23 @@ DEV uint32_t fast_match_length(const uint8_t* a, const uint8_t* b, uint32_t limi
   }
 }
 
+// Same-hash ranking of the lanes [0, n) of a step (see fast_create_commands): exact
+// answer from wave_equal_neighbours, but only after an LDS scoreboard says two lanes
+// may share a hash at all — on text they almost never do, and for a lone wave the
+// n-iteration readlane loop is a visible part of a step.
+#define FAST_SB_SLOTS 8192u
+DEV void fast_rank_equal(uint32_t h, int n, uint8_t* sb, int* prev, int* next) {
+  const int lane = wave_lane();
+  uint8_t* p = sb + (h & (FAST_SB_SLOTS - 1u));
+  if (lane < n) *p = (uint8_t)lane;
+  wave_sync();
+  const bool maybe = lane < n && *p != (uint8_t)lane;
+  wave_sync();
+  *prev = -1;
+  *next = 64;
+  if (wave_ballot(maybe) != 0) wave_equal_neighbours(h, n, prev, next);
+}
+
 DEV void fast_copy_literals(uint8_t* dst, const uint8_t* src, uint32_t n) {
   const int lane = wave_lane();
   if (n >= 1024) {
@@ -179,7 +196,8 @@ DEV void fast_copy_literals(uint8_t* dst, const uint8_t* src, uint32_t n) {
 // `first`: the variant used after the first match of a scan, which with 4-byte
 // hashes keys the third store with the first store's bytes again (:362-363).
 template <int MM>
-DEV uint32_t fast_refresh(const uint8_t* base, uint32_t ip, uint32_t* table, uint32_t shift, bool first) {
+DEV uint32_t fast_refresh(const uint8_t* base, uint32_t ip, uint32_t* table, uint32_t shift, bool first,
+                          uint8_t* sb) {
   const int lane = wave_lane();
   const int NE = MM == 4 ? 3 : 5;
   uint32_t h = 0xFFFFFFFFu, val = 0, tv = 0;
@@ -191,7 +209,7 @@ DEV uint32_t fast_refresh(const uint8_t* base, uint32_t ip, uint32_t* table, uin
     if (lane == NE) tv = table[h];
   }
   int prev, next;
-  wave_equal_neighbours(h, NE + 1, &prev, &next);
+  fast_rank_equal(h, NE + 1, sb, &prev, &next);
   const uint32_t pv = wave_shfl(val, prev < 0 ? 0 : prev);
   const uint32_t cand = prev >= 0 ? pv : tv;
   if (lane <= NE && next > NE) table[h] = val;
@@ -204,7 +222,7 @@ DEV uint32_t fast_refresh(const uint8_t* base, uint32_t ip, uint32_t* table, uin
 template <int MM>
 DEV void fast_create_commands(const uint8_t* base, uint32_t in0, uint32_t block_size, uint32_t left,
                               uint32_t* table, uint32_t shift, uint32_t* cmds, uint8_t* lits,
-                              uint32_t* ncmds_out, uint32_t* nlits_out) {
+                              uint32_t* ncmds_out, uint32_t* nlits_out, uint8_t* sb) {
   const int lane = wave_lane();
   uint32_t ncmds = 0, nlits = 0;
   const uint32_t ip_end = in0 + block_size;
@@ -239,7 +257,7 @@ DEV void fast_create_commands(const uint8_t* base, uint32_t in0, uint32_t block_
       }
       const int nv = dev_popc64(wave_ballot(valid));
       int prev, next;
-      wave_equal_neighbours(h, nv, &prev, &next);
+      fast_rank_equal(h, nv, sb, &prev, &next);
       const uint32_t pv = wave_shfl(pos, prev < 0 ? 0 : prev);
       const uint32_t cand = prev >= 0 ? pv : tv;     // what table[h] holds when this probe runs
       bool hit_l = false, hit_t = false;
@@ -286,7 +304,7 @@ DEV void fast_create_commands(const uint8_t* base, uint32_t in0, uint32_t block_
         next_emit = ip;
       }
       if (ip >= ip_limit) break;
-      candidate = fast_refresh<MM>(base, ip, table, shift, true);
+      candidate = fast_refresh<MM>(base, ip, table, shift, true, sb);
       bool out_of_input = false;
       for (;;) {
         // matches that start exactly where the previous copy ended (:388-443)
@@ -304,7 +322,7 @@ DEV void fast_create_commands(const uint8_t* base, uint32_t in0, uint32_t block_
         ip += matched;
         next_emit = ip;
         if (ip >= ip_limit) { out_of_input = true; break; }
-        candidate = fast_refresh<MM>(base, ip, table, shift, false);
+        candidate = fast_refresh<MM>(base, ip, table, shift, false, sb);
       }
       if (out_of_input) break;
       ++ip;
@@ -325,7 +343,7 @@ DEV void fast_create_commands(const uint8_t* base, uint32_t in0, uint32_t block_
 }
 
 // One fragment: zero the table (GetHashTable, encode.c:156-189), then its blocks.
-DEV void fast_parse_fragment(const FastArgs& a, uint32_t f, uint32_t* table) {
+DEV void fast_parse_fragment(const FastArgs& a, uint32_t f, uint32_t* table, uint8_t* sb) {
   const int lane = wave_lane();
   const FastFrag F = a.frags[f];
   if (F.nblocks == 0) return;
@@ -342,9 +360,9 @@ DEV void fast_parse_fragment(const FastArgs& a, uint32_t f, uint32_t* table) {
     const FastBlock B = a.blocks[bidx];
     uint32_t ncmds, nlits;
     if (F.table_bits <= 15)
-      fast_create_commands<4>(base, B.off_in_frag, B.len, B.left, table, shift, fast_cmds(a, B), fast_lits(a, B), &ncmds, &nlits);
+      fast_create_commands<4>(base, B.off_in_frag, B.len, B.left, table, shift, fast_cmds(a, B), fast_lits(a, B), &ncmds, &nlits, sb);
     else
-      fast_create_commands<6>(base, B.off_in_frag, B.len, B.left, table, shift, fast_cmds(a, B), fast_lits(a, B), &ncmds, &nlits);
+      fast_create_commands<6>(base, B.off_in_frag, B.len, B.left, table, shift, fast_cmds(a, B), fast_lits(a, B), &ncmds, &nlits, sb);
     if (lane == 0) {
       a.bstate[bidx].ncmds = ncmds;
       a.bstate[bidx].nlits = nlits;

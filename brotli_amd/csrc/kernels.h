@@ -159,7 +159,8 @@ __global__ void __launch_bounds__(256) k_gather(JobArgs a, const uint64_t* scan,
 // owns hash-table slot w.
 __global__ void __launch_bounds__(64) k_fast_parse(FastArgs a) {
   uint32_t* table = (uint32_t*)(a.ws + a.tables_base + (uint64_t)blockIdx.x * FAST_TABLE_BYTES);
-  for (uint32_t f = blockIdx.x; f < a.nfrags; f += a.nslots) fast_parse_fragment(a, f, table);
+  __shared__ uint8_t lds_sb[FAST_SB_SLOTS];
+  for (uint32_t f = blockIdx.x; f < a.nfrags; f += a.nslots) fast_parse_fragment(a, f, table, lds_sb);
 }
 
 // grid = nblocks, block = 64
