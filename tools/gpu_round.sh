@@ -17,5 +17,14 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
   python tools/pmc_summary.py gpurun_out/prof_pmc_$n | grep -E "PMC k_parse4|KERNEL k_parse4" >> gpurun_out/prof_pmc_summary.txt
 done
 cat gpurun_out/prof_pmc_summary.txt
+# quality 1 (BASELINE config 3: random bytes) and quality 9 (config 5): bench lines + kernel stats of the q1 job
+( timeout 600 python bench.py --quality 1 --data random --steps 5 --warmup 1 ) > gpurun_out/bench_q1_random.log 2>&1; tail -1 gpurun_out/bench_q1_random.log | cut -c1-400
+( timeout 600 python bench.py --quality 1 --data text --lgwin 18 --steps 3 --warmup 1 ) > gpurun_out/bench_q1_text_lgwin18.log 2>&1; tail -1 gpurun_out/bench_q1_text_lgwin18.log | cut -c1-400
+( timeout 600 python bench.py --quality 1 --data text --feed-kb 512 --steps 3 --warmup 1 --no-cpu-baseline ) > gpurun_out/bench_q1_text_cli.log 2>&1; tail -1 gpurun_out/bench_q1_text_cli.log | cut -c1-400
+( timeout 600 python bench.py --quality 9 --lgwin 24 --shard-kb 512 --steps 2 --warmup 1 --no-cpu-baseline ) > gpurun_out/bench_q9.log 2>&1; tail -1 gpurun_out/bench_q9.log | cut -c1-400
+rm -rf gpurun_out/prof_stats_q1
+( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_stats_q1 -o bench -- python /root/repo/bench.py --quality 1 --data random --steps 3 --warmup 1 --no-cpu-baseline ) > gpurun_out/prof_stats_q1.log 2>&1
+python tools/pmc_summary.py gpurun_out/prof_stats_q1 > gpurun_out/prof_stats_q1_summary.txt 2>&1
+grep -E "KERNEL k_" gpurun_out/prof_stats_q1_summary.txt
 find gpurun_out -name "*.db" -delete
 BENCH_FORCE_DIST=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 2 --warmup 1 --no-cpu-baseline --size-mb 256 > gpurun_out/bench_dist1.log 2>&1; tail -2 gpurun_out/bench_dist1.log | cut -c1-600
