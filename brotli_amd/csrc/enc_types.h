@@ -50,6 +50,8 @@ struct JobParams {
 #define JOB_FLAG_NO_HEADER 8u  // stream header already emitted: shard 0 starts byte aligned
 #define JOB_FLAG_GROUPS_SHIFT 8  // k_parse4: bits 8-9 = shards per wave (0 = 4, else 1 / 2): fewer lock-stepped
                                 //   shards per wave when the job is too small to fill the chip anyway
+#define JOB_FLAG_DUO 32u       // k_parse4 with <= 2 shards per wave: every shard gets a second 16-lane group that
+                               //   searches the next position in the same step (k_parse4.h)
 #define JOB_FLAG_DEEP 16u      // one shard per wave, 32 .. 256 slots per bucket (k_parse_deep.h)
 
 // Per-shard description written by the host.

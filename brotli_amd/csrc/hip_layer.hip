@@ -172,7 +172,12 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
       const uint64_t resident = (uint64_t)c->num_cus * 16u;
       int v = plan->shards.size() <= resident ? 1 : plan->shards.size() <= 2 * resident ? 2 : 4;
       if (const char* e = getenv("BROTLI_AMD_QGROUPS")) v = atoi(e);   // experiment knob
-      if (v == 1 || v == 2) plan->J.flags |= (uint32_t)v << JOB_FLAG_GROUPS_SHIFT;
+      if (v == 1 || v == 2) {
+        plan->J.flags |= (uint32_t)v << JOB_FLAG_GROUPS_SHIFT;
+        // the lanes a shard does not need for itself search one position ahead (k_parse4.h)
+        const char* d = getenv("BROTLI_AMD_DUO");
+        if (!d || atoi(d) != 0) plan->J.flags |= JOB_FLAG_DUO;
+      }
     }
   } else {
     // deep-bucket qualities: shards must fit the window (no ring-wrap rules in k_parse_deep.h)

@@ -84,6 +84,10 @@ struct QShard {
   uint32_t state;
   uint32_t error, have_mb, done;
   uint32_t stat_searches;
+  // JOB_FLAG_DUO: two groups serve one shard with identical state; role 0 (primary)
+  // searches the position the state machine asks for and owns every memory write,
+  // role 1 (scout) searches the position after it in the same step
+  uint32_t role;
   // software prefetch of bucket records: value of the load issued last step
   // (consumed one step later so nothing waits on it) and a sink that keeps the
   // loads alive
@@ -172,6 +176,7 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
   const int t = q_t();
   KeyTag kt;
   kt.key = 0; kt.tag = 0; kt.tag2 = 0;
+  act = act && g.role == 0;
   if (act) kt = hash_pos(have_x ? x : ld64(g.data + pos), J.hasher_type, J.bucket_bits);
   // Two lanes of a group with one key must be ranked; detect that case through
   // an LDS scoreboard (false positives only cost time).
@@ -313,8 +318,27 @@ DEV void q_dict_search(const JobParams& J, const DeviceTables* T, QShard& g, boo
   }
 }
 
-// Searches position P for every group with want set.  Inserts P afterwards.
-DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool want, uint32_t P) {
+// What the insertion of the searched position needs from its search (per lane).
+struct QIns { uint32_t key, tag, tag2, num, slot_e, tag2_e, tag_e; };
+
+// insert P (:293-295): the lane that owns ring slot num & 15 writes the new
+// entry; lanes 0 / 1 refresh the counter bytes kept in their entries.
+DEV void q_insert(QShard& g, bool act, uint32_t P, const QIns& in) {
+  const int t = q_t();
+  const uint32_t num = in.num;
+  const uint32_t ts = num & 15u, nn = (num - 1u) & 0xFFFFu;
+  const bool mine = (uint32_t)t == ts;
+  const bool hi_changed = (nn >> 8) != (num >> 8);
+  if (act && (mine || t == 0 || (t == 1 && hi_changed))) {
+    const uint32_t naux = t == 0 ? (nn & 0xFFu) : t == 1 ? (nn >> 8) : 0u;
+    const uint64_t e = mine ? q_entry(P, in.tag2, in.tag, naux) : q_entry(in.slot_e, in.tag2_e, in.tag_e, naux);
+    __builtin_memcpy(g.table + (size_t)in.key * REC_BYTES + QREC_ENTRY(t), &e, 8);
+  }
+}
+
+// Searches position P for every group with want set (hash table and distance
+// cache only); the caller inserts P (q_insert) and runs the dictionary probe.
+DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool want, uint32_t P, QIns& ins) {
   const int t = q_t();
   const int ndist = J.ndist;
   const uint32_t max_length = g.pos_end - P;
@@ -439,23 +463,9 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
     if (slow) r = s;
   }
   QP_ADD(g, 2, qt);
-  // insert P (:293-295): the lane that owns ring slot num & 15 writes the new
-  // entry; lanes 0 / 1 refresh the counter bytes kept in their entries.
-  {
-    const uint32_t ts = num & 15u, nn = (num - 1u) & 0xFFFFu;
-    const bool mine = (uint32_t)t == ts;
-    const bool hi_changed = (nn >> 8) != (num >> 8);
-    if (want && (mine || t == 0 || (t == 1 && hi_changed))) {
-      const uint32_t naux = t == 0 ? (nn & 0xFFu) : t == 1 ? (nn >> 8) : 0u;
-      const uint64_t e = mine ? q_entry(P, kt.tag2, kt.tag, naux) : q_entry(slot, tag2, tag, naux);
-      __builtin_memcpy(g.table + (size_t)kt.key * REC_BYTES + QREC_ENTRY(t), &e, 8);
-    }
-  }
-  wave_sync();
-  // static dictionary when nothing was found (hash.h:179-202)
-  QP_ADD(g, 3, qt);
-  q_dict_search(J, T, g, want && r.score == K_MIN_SCORE, P, max_length, r);
-  QP_ADD(g, 4, qt);
+  ins.key = kt.key; ins.tag = kt.tag; ins.tag2 = kt.tag2; ins.num = num;
+  ins.slot_e = slot; ins.tag2_e = tag2; ins.tag_e = tag;
+  (void)T;
   return r;
 }
 
@@ -641,7 +651,7 @@ DEV void q_setup_block(const JobParams& J, QShard& g, bool want, uint8_t* lds_du
     last.cmd_prefix = (uint16_t)combine_length_codes(insert_length_code(last.insert_len),
         copy_length_code((uint32_t)((int)(last.copy_len & 0x1FFFFFFu) + (int)(last.copy_len >> 25))),
         (last.dist_prefix & 0x3FF) == 0);
-    if (t == 0) g.cmds[g.r.ncmds - 1] = last;
+    if (t == 0 && g.role == 0) g.cmds[g.r.ncmds - 1] = last;
   }
   wave_sync();
   if (want) {
@@ -652,6 +662,83 @@ DEV void q_setup_block(const JobParams& J, QShard& g, bool want, uint8_t* lds_du
     g.apply_random_heuristics = pos + J.spree_window;
     g.state = Q_SEARCH;
   }
+}
+
+// One step of the CreateBackwardReferences state machine (:44-242) for the groups in
+// `act`, given the search result `cur` of the position they were waiting for.
+// Returns whether a command was committed (the copied range is then pending in st_*).
+DEV bool q_transition(const JobParams& J, QShard& g, bool act, const QResult& cur, uint32_t htl) {
+  const int t = q_t();
+  (void)t;
+  bool commit = false;
+  if (act && g.state == Q_SEARCH) {
+    if (cur.score > K_MIN_SCORE) {
+      g.sr_len = cur.len; g.sr_dist = cur.distance; g.sr_score = cur.score; g.sr_delta = cur.delta;
+      g.delayed = 0;
+      g.state = Q_LAZY;
+    } else {
+      ++g.insert_length;
+      ++g.position;
+      if (g.position > g.apply_random_heuristics) {
+        // literal spree (:208-236): sparse insertions, no searches
+        uint32_t step, span, margin;
+        if (g.position > g.apply_random_heuristics + 4u * J.spree_window) {
+          step = 4; span = 16; margin = umax(htl - 1u, 4u);
+        } else {
+          step = 2; span = 8; margin = umax(htl - 1u, 2u);
+        }
+        const uint32_t pos_jump = umin(g.position + span, g.pos_end - margin);
+        if (g.position < pos_jump) {
+          const uint32_t cnt = (pos_jump - g.position + step - 1u) / step;
+          g.st_first = g.position;
+          g.st_count = cnt;
+          g.st_stride = step;
+          g.position += cnt * step;
+          g.insert_length += cnt * step;
+        }
+      }
+    }
+  } else if (act && g.state == Q_LAZY) {
+    commit = true;
+    if (cur.score >= g.sr_score + 175u) {
+      ++g.position;
+      ++g.insert_length;
+      g.sr_len = cur.len; g.sr_dist = cur.distance; g.sr_score = cur.score; g.sr_delta = cur.delta;
+      if (++g.delayed < 4 && g.position + htl < g.pos_end) commit = false;
+    }
+  }
+  if (commit) {
+    g.state = Q_SEARCH;
+    // StoreRange bounds first, so that the bytes of the first insertion
+    // step (and the next search position's key) travel while the command
+    // is being built.
+    uint32_t range_start = g.position + 2u;
+    const uint32_t range_end = umin(g.position + g.sr_len, g.store_end);
+    if (g.sr_dist < (g.sr_len >> 2)) {
+      range_start = umin(range_end, umax(range_start, g.position + g.sr_len - (g.sr_dist << 2)));
+    }
+    if (range_start < range_end) {
+      g.st_first = range_start;
+      g.st_count = range_end - range_start;
+      g.st_stride = 1;
+#if defined(Q_EARLY_STX)
+      g.st_x = ld64(g.data + range_start + (uint32_t)t);
+      g.st_x_valid = 1;
+#endif
+    }
+    g.apply_random_heuristics = g.position + 2u * g.sr_len + J.spree_window;
+    const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit);
+    const uint32_t distance_code = compute_distance_code(g.sr_dist, dictionary_start, g.dc);
+    if (g.sr_dist <= dictionary_start && distance_code > 0) {
+      g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)g.sr_dist;
+    }
+    if (t == 0 && g.role == 0) g.cmds[g.r.ncmds] = make_command(g.insert_length, g.sr_len, g.sr_delta, distance_code);
+    ++g.r.ncmds;
+    g.r.nlits += g.insert_length;
+    g.insert_length = 0;
+    g.position += g.sr_len;
+  }
+  return commit;
 }
 
 DEV uint32_t q_groups_per_wave(const JobParams& J) {
@@ -665,9 +752,12 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
                       uint32_t wave_index, uint8_t* lds_dup) {
   const int t = q_t();
   const uint32_t gpw = q_groups_per_wave(J);
-  const uint32_t shard = wave_index * gpw + (uint32_t)(wave_lane() >> 4);
-  const bool alive = (uint32_t)(wave_lane() >> 4) < gpw && shard < nshards;
-  const bool writer = alive && t == 0;
+  const bool duo = (J.flags & JOB_FLAG_DUO) != 0;          // gpw <= 2: a shard owns two groups
+  const uint32_t gi = (uint32_t)(wave_lane() >> 4) >> (duo ? 1 : 0);
+  const uint32_t shard = wave_index * gpw + gi;
+  const bool alive = gi < gpw && shard < nshards;
+  const uint32_t role = duo ? ((uint32_t)(wave_lane() >> 4) & 1u) : 0u;
+  const bool writer = alive && t == 0 && role == 0;
   const uint32_t htl = hasher_htl(J.hasher_type);
   const ShardDesc& D = shards[alive ? shard : 0];
   ShardState* S = &states[alive ? shard : 0];
@@ -695,6 +785,7 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
   g.n32_pos = 0xFFFFFFFFu;
   g.error = 0; g.have_mb = 0; g.done = 0;
   g.stat_searches = 0;
+  g.role = role;
   g.pf_val = g.pf_acc = 0;
   for (int i = 0; i < 12; ++i) g.prof[i] = 0;
   g.state = (alive && !S->done && !S->mb_valid && !S->error) ? Q_PRE : Q_DONE;
@@ -715,77 +806,55 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
     }
     const bool want = g.state == Q_SEARCH || g.state == Q_LAZY;
     if (wave_any(want)) {
-      const uint32_t P = g.position + (g.state == Q_LAZY ? 1u : 0u);
-      const QResult cur = q_search(J, T, g, want, P);
+      const uint32_t P0 = g.position + (g.state == Q_LAZY ? 1u : 0u);
+      const uint32_t P = P0 + g.role;
+      QIns ins;
+      QResult mine = q_search(J, T, g, want, P, ins);
       uint64_t qt = QP_NOW();
-      if (want) g.stat_searches++;
-      bool commit = false;
-      if (g.state == Q_SEARCH) {
-        if (cur.score > K_MIN_SCORE) {
-          g.sr_len = cur.len; g.sr_dist = cur.distance; g.sr_score = cur.score; g.sr_delta = cur.delta;
-          g.delayed = 0;
-          g.state = Q_LAZY;
-        } else {
-          ++g.insert_length;
-          ++g.position;
-          if (g.position > g.apply_random_heuristics) {
-            // literal spree (:208-236): sparse insertions, no searches
-            uint32_t step, span, margin;
-            if (g.position > g.apply_random_heuristics + 4u * J.spree_window) {
-              step = 4; span = 16; margin = umax(htl - 1u, 4u);
-            } else {
-              step = 2; span = 8; margin = umax(htl - 1u, 2u);
-            }
-            const uint32_t pos_jump = umin(g.position + span, g.pos_end - margin);
-            if (g.position < pos_jump) {
-              const uint32_t cnt = (pos_jump - g.position + step - 1u) / step;
-              g.st_first = g.position;
-              g.st_count = cnt;
-              g.st_stride = step;
-              g.position += cnt * step;
-              g.insert_length += cnt * step;
-            }
-          }
-        }
-      } else if (g.state == Q_LAZY) {
-        commit = true;
-        if (cur.score >= g.sr_score + 175u) {
-          ++g.position;
-          ++g.insert_length;
-          g.sr_len = cur.len; g.sr_dist = cur.distance; g.sr_score = cur.score; g.sr_delta = cur.delta;
-          if (++g.delayed < 4 && g.position + htl < g.pos_end) commit = false;
-        }
+      q_insert(g, want && g.role == 0, P, ins);
+      wave_sync();
+      QP_ADD(g, 3, qt);
+      // static dictionary when nothing was found (hash.h:179-202); its two counters are
+      // stream state, so the scout probes after the primary and continues from its counts
+      q_dict_search(J, T, g, want && g.role == 0 && mine.score == K_MIN_SCORE, P, g.pos_end - P, mine);
+      QResult r0 = mine, r1 = mine;
+      bool r1_ok = false;
+      uint32_t dl1 = 0, dm1 = 0;
+      if (duo) {
+        const int lane = wave_lane();
+        const uint32_t dl0 = wave_shfl(g.dict_lookups, lane & ~16), dm0 = wave_shfl(g.dict_matches, lane & ~16);
+        if (g.role == 1) { g.dict_lookups = dl0; g.dict_matches = dm0; }
+        q_dict_search(J, T, g, want && g.role == 1 && mine.score == K_MIN_SCORE, P, g.pos_end - P, mine);
+        QResult other;
+        other.len = wave_shfl(mine.len, lane ^ 16);
+        other.distance = wave_shfl(mine.distance, lane ^ 16);
+        other.score = wave_shfl(mine.score, lane ^ 16);
+        other.delta = (int32_t)wave_shfl((uint32_t)mine.delta, lane ^ 16);
+        const uint32_t other_key = wave_shfl(ins.key, lane ^ 16);
+        r0 = g.role == 0 ? mine : other;
+        r1 = g.role == 0 ? other : mine;
+        dl1 = wave_shfl(g.dict_lookups, lane | 16);
+        dm1 = wave_shfl(g.dict_matches, lane | 16);
+        g.dict_lookups = dl0;
+        g.dict_matches = dm0;
+        r1_ok = ins.key != other_key;      // equal keys: the scout read the bucket before P went in
       }
-      if (commit) {
-        g.state = Q_SEARCH;
-        // StoreRange bounds first, so that the bytes of the first insertion
-        // step (and the next search position's key) travel while the command
-        // is being built.
-        uint32_t range_start = g.position + 2u;
-        const uint32_t range_end = umin(g.position + g.sr_len, g.store_end);
-        if (g.sr_dist < (g.sr_len >> 2)) {
-          range_start = umin(range_end, umax(range_start, g.position + g.sr_len - (g.sr_dist << 2)));
+      QP_ADD(g, 4, qt);
+      if (want) g.stat_searches++;
+      bool commit = q_transition(J, g, want, r0, htl);
+      if (duo) {
+        // second step: the position the scout searched is the one the state machine
+        // asks for next, its bucket was not touched by the primary's insertion, and
+        // nothing is pending in between
+        const bool st2 = want && r1_ok && !commit && g.st_count == 0 &&
+            (g.state == Q_SEARCH ? (g.position == P0 + 1u && g.position + htl < g.pos_end)
+                                 : (g.state == Q_LAZY && g.position == P0));
+        if (wave_any(st2)) {
+          q_insert(g, st2 && g.role == 1, P0 + 1u, ins);   // the scout's own position, now that its search counts
+          wave_sync();
+          if (st2) { g.dict_lookups = dl1; g.dict_matches = dm1; g.stat_searches++; }
+          commit = q_transition(J, g, st2, r1, htl) || commit;
         }
-        if (range_start < range_end) {
-          g.st_first = range_start;
-          g.st_count = range_end - range_start;
-          g.st_stride = 1;
-#if defined(Q_EARLY_STX)
-          g.st_x = ld64(g.data + range_start + (uint32_t)t);
-          g.st_x_valid = 1;
-#endif
-        }
-        g.apply_random_heuristics = g.position + 2u * g.sr_len + J.spree_window;
-        const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit);
-        const uint32_t distance_code = compute_distance_code(g.sr_dist, dictionary_start, g.dc);
-        if (g.sr_dist <= dictionary_start && distance_code > 0) {
-          g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)g.sr_dist;
-        }
-        if (t == 0) g.cmds[g.r.ncmds] = make_command(g.insert_length, g.sr_len, g.sr_delta, distance_code);
-        ++g.r.ncmds;
-        g.r.nlits += g.insert_length;
-        g.insert_length = 0;
-        g.position += g.sr_len;
       }
       // After a copy the next search position is known: fetch its record
       // while the copied range is being inserted.
@@ -803,8 +872,8 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
         // the next search position is settled: SEARCH at position, LAZY at position + 1
         const bool nx = g.state == Q_SEARCH || g.state == Q_LAZY;
         const uint32_t pn = g.position + (g.state == Q_LAZY ? 1u : 0u);
-        g.n32 = load_b32(g.data + (nx ? pn : 0u));
-        g.n32_pos = nx ? pn : 0xFFFFFFFFu;
+        g.n32 = load_b32(g.data + (nx ? pn + g.role : 0u));
+        g.n32_pos = nx ? pn + g.role : 0xFFFFFFFFu;
       }
 #endif
       QP_ADD(g, 5, qt);

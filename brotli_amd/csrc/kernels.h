@@ -66,8 +66,10 @@ __global__ void __launch_bounds__(64, PARSE4_WAVES) k_parse4(JobArgs a) {
   __shared__ uint8_t lds_dup[Q_GROUPS * Q_DUP_SLOTS];
   parse4_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_dup);
   const uint32_t gpw = q_groups_per_wave(a.J);
-  const uint32_t shard = blockIdx.x * gpw + (threadIdx.x >> 4);
-  if ((threadIdx.x & 15) == 0 && (threadIdx.x >> 4) < gpw && shard < a.nshards && a.states[shard].error)
+  const bool duo = (a.J.flags & JOB_FLAG_DUO) != 0;
+  const uint32_t gi = (threadIdx.x >> 4) >> (duo ? 1 : 0);
+  const uint32_t shard = blockIdx.x * gpw + gi;
+  if ((threadIdx.x & (duo ? 31 : 15)) == 0 && gi < gpw && shard < a.nshards && a.states[shard].error)
     glb_atomic_add(&a.counters[1], 1u);
 }
 

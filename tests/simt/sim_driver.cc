@@ -38,6 +38,7 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   if (no_pair & 1) plan.J.flags |= JOB_FLAG_NO_PAIR;
   if (no_pair & 2) plan.J.flags |= JOB_FLAG_QUAD;
   if (no_pair & 4) plan.J.flags |= JOB_FLAG_FORCE_SLOW;
+  plan.J.flags |= (uint32_t)(no_pair & ~7);   // other job flags pass through (DUO, GROUPS)
   if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~JOB_FLAG_QUAD) | JOB_FLAG_DEEP;
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);

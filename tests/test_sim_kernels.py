@@ -116,6 +116,27 @@ def test_quad_kernel_fewer_shards_per_wave(sim, oracle, groups):
     assert sim.encode(data, shard_size=50000, flags=2 | (groups << 8)) == oracle.encode_plan(data, 5, 22, 50000)
 
 
+@pytest.mark.parametrize("groups", [1, 2])
+@pytest.mark.parametrize("name", ["text_hint_2shards", "ragged_shards", "mixed", "text_then_random",
+                                  "shards_of_1_2_3", "alice_48k"])
+def test_quad_kernel_scout_groups(sim, oracle, name, groups):
+    """JOB_FLAG_DUO: a second group per shard searches the following position in the same
+    step; its result is used only when the state machine asks for exactly that position and
+    the two positions hash to different buckets."""
+    data, shard, hint = CASES[name]
+    want = oracle.encode_plan(data, 5, 22, shard) if not hint else None
+    for reverse in (0, 1):
+        got = sim.encode(data, size_hint=hint, shard_size=shard, reverse=reverse, flags=2 | 32 | (groups << 8))
+        if want is None:
+            want = sim.encode(data, size_hint=hint, shard_size=shard, flags=2)
+        assert got == want
+
+
+def test_quad_kernel_scout_groups_forced_slow_resolve(sim, oracle):
+    data = G.enwik_text(200000, seed=78, vocab=3000)
+    assert sim.encode(data, shard_size=50000, flags=2 | 4 | 32 | (2 << 8)) == oracle.encode_plan(data, 5, 22, 50000)
+
+
 def test_quad_kernel_many_shards_reverse(sim, oracle):
     """7 shards over 2 waves (one group idle), lanes scheduled high-to-low."""
     data = G.enwik_text(70000, seed=13, vocab=3000)
