@@ -59,6 +59,8 @@ CASES = {
     "tiny1": (b"x", 0, 0), "tiny2": (b"xy", 0, 0), "tiny3": (b"xyz", 0, 0),
     "tiny9": (b"123456789", 0, 0), "x64": (b"x" * 64, 0, 0),
     "shards_of_1_2_3": (b"abcabcabcabc", 0, 3),
+    # runs of one byte between random stretches: up to 32 insertions of one bucket key in a step
+    "runs": (b"".join(G.random_bytes(37 + 11 * i, seed=i) + bytes([65 + i]) * (20 + 7 * i) for i in range(40)), 0, 0),
 }
 
 
@@ -118,7 +120,7 @@ def test_quad_kernel_fewer_shards_per_wave(sim, oracle, groups):
 
 @pytest.mark.parametrize("groups", [1, 2])
 @pytest.mark.parametrize("name", ["text_hint_2shards", "ragged_shards", "mixed", "text_then_random",
-                                  "shards_of_1_2_3", "alice_48k"])
+                                  "shards_of_1_2_3", "alice_48k", "zeros", "rle", "x64", "random_raw", "runs"])
 def test_quad_kernel_scout_groups(sim, oracle, name, groups):
     """JOB_FLAG_DUO: a second group per shard searches the following position in the same
     step; its result is used only when the state machine asks for exactly that position and
