@@ -88,7 +88,6 @@ struct QShard {
   // searches the position the state machine asks for and owns every memory write,
   // role 1 (scout) searches the position after it in the same step
   uint32_t role;
-  uint32_t duo;
   // software prefetch of bucket records: value of the load issued last step
   // (consumed one step later so nothing waits on it) and a sink that keeps the
   // loads alive
@@ -177,17 +176,14 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
   const int t = q_t();
   KeyTag kt;
   kt.key = 0; kt.tag = 0; kt.tag2 = 0;
+  act = act && g.role == 0;
   if (act) kt = hash_pos(have_x ? x : ld64(g.data + pos), J.hasher_type, J.bucket_bits);
-  // Two lanes of a shard with one key must be ranked; detect that case through
-  // an LDS scoreboard (false positives only cost time).  With scout groups
-  // (g.duo) the two groups of a shard insert 32 consecutive positions together:
-  // `me` is the lane's index among them, the scoreboard is the pair's.
-  const uint32_t me = (uint32_t)t + 16u * g.role;
-  const uint32_t sb_slots = g.duo ? 2u * Q_DUP_SLOTS : Q_DUP_SLOTS;
-  uint8_t* sb = lds_dup + (size_t)((q_base() >> 4) & (g.duo ? 2 : 3)) * Q_DUP_SLOTS + (kt.key & (sb_slots - 1u));
-  if (act) *sb = (uint8_t)me;
+  // Two lanes of a group with one key must be ranked; detect that case through
+  // an LDS scoreboard (false positives only cost time).
+  uint8_t* sb = lds_dup + (size_t)(q_base() >> 4) * Q_DUP_SLOTS + (kt.key & (Q_DUP_SLOTS - 1u));
+  if (act) *sb = (uint8_t)t;
   wave_sync();
-  const bool dup = act && *sb != (uint8_t)me;
+  const bool dup = act && *sb != (uint8_t)t;
   const bool any_dup = wave_any(dup);
   if (any_dup) SIM_COUNT(6, 1);                        // insertion steps with a key collision
   uint8_t* rec = g.table + (size_t)kt.key * REC_BYTES;
@@ -206,13 +202,11 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
       same &= bit ? m : ~m;
     }
     same &= wave_ballot(act);
-    const uint32_t mine32 = g.duo ? (uint32_t)(same >> (wave_lane() & 32)) : q_mask16(same);
-    below = (uint32_t)__builtin_popcount(mine32 & ((1u << me) - 1u));
-    total = (uint32_t)__builtin_popcount(mine32);
+    const uint32_t same16 = q_mask16(same);
+    below = (uint32_t)__builtin_popcount(same16 & ((1u << t) - 1u));
+    total = (uint32_t)__builtin_popcount(same16);
   }
-  // (more than 16 positions of one key in a step wrap around the bucket: only the
-  // last one that lands on a slot writes it)
-  if (act && below + 16u >= total) {
+  if (act) {
     const uint32_t s = (num - below) & 15u;
     const uint32_t aux = s == 0 ? (uint32_t)(e0 >> 56) : s == 1 ? (uint32_t)(e1 >> 56) : 0u;
     const uint64_t e = q_entry(pos, kt.tag2, kt.tag, aux);
@@ -231,10 +225,9 @@ DEV void q_store16(const JobParams& J, const QShard& g, bool act, uint32_t pos, 
 DEV void q_drain_stores(const JobParams& J, QShard& g, uint8_t* lds_dup) {
   while (wave_any(g.st_count != 0)) {
     SIM_COUNT(3, 1);                                   // insertion steps (wave level)
-    const uint32_t n = umin(g.st_count, g.duo ? 32u : 16u);
-    const uint32_t me = (uint32_t)q_t() + 16u * g.role;
-    const bool act = me < n;
-    q_store16(J, g, act, g.st_first + me * g.st_stride, g.st_x_valid != 0, g.st_x, lds_dup);
+    const uint32_t n = umin(g.st_count, 16u);
+    const bool act = (uint32_t)q_t() < n;
+    q_store16(J, g, act, g.st_first + (uint32_t)q_t() * g.st_stride, g.st_x_valid != 0, g.st_x, lds_dup);
     g.st_x_valid = 0;
     g.st_first += n * g.st_stride;
     g.st_count -= n;
@@ -793,7 +786,6 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
   g.error = 0; g.have_mb = 0; g.done = 0;
   g.stat_searches = 0;
   g.role = role;
-  g.duo = duo ? 1u : 0u;
   g.pf_val = g.pf_acc = 0;
   for (int i = 0; i < 12; ++i) g.prof[i] = 0;
   g.state = (alive && !S->done && !S->mb_valid && !S->error) ? Q_PRE : Q_DONE;

@@ -388,7 +388,6 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   g.stat_searches = 0;
   g.pf_val = g.pf_acc = 0;
   g.role = 0;
-  g.duo = 0;
   g.state = Q_PRE;
 
   while (g.state != Q_DONE) {       // all state is wave-uniform here
