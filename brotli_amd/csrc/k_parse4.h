@@ -50,6 +50,13 @@ extern unsigned long long g_sim_counts[16];
 #define Q_DUP_SLOTS 1024u
 #define QREC_ENTRY(i) ((uint32_t)(i) * 8u)   // byte offset of entry i in a record (see q_entry)
 
+#define QST_DONE 1u
+#define QST_ERROR 2u
+#define QST_HAVE_MB 4u
+#define QBLK_LAST 1u
+#define QBLK_FLUSH 2u
+#define QBLK_STITCH 4u
+#define QBLK_EXTEND 8u
 enum QState { Q_PRE = 0, Q_SETUP = 1, Q_SEARCH = 2, Q_LAZY = 3, Q_POST = 4, Q_DONE = 5 };
 
 // All fields are identical in the 16 lanes of a group.
@@ -59,15 +66,20 @@ struct QShard {
   uint8_t* table;
   uint16_t* nums;          // k_parse_deep.h: bucket counters (separate array)
   Command* cmds;
-  uint8_t* out;
-  uint32_t len, stream_offset, final_op, cmd_cap;
+  uint32_t stream_offset;
+  // cold shard facts (length, final operation, command capacity, output buffer) are
+  // re-read from the descriptor when a block starts or ends: `descs` / `wsb` are
+  // wave-uniform kernel arguments, `shard` is the only per-lane register they cost
+  const ShardDesc* descs;
+  uint8_t* wsb;
+  uint32_t shard;
   // stream state (RoundRegs)
   RoundRegs r;
   int32_t dc[4];
   uint32_t dict_lookups, dict_matches;
   // current block
-  uint32_t blk_is_last, blk_force_flush, blk_bytes, blk_pos;
-  uint32_t want_stitch, want_extend;
+  uint32_t blk_flags;      // QBLK_*: cold per-block facts in one register
+  uint32_t blk_bytes, blk_pos;
   uint32_t position, pos_end, store_end, insert_length, apply_random_heuristics;
   // lazy matching
   uint32_t sr_len, sr_dist, sr_score;
@@ -82,7 +94,7 @@ struct QShard {
   B32 n32;
   uint32_t n32_pos;
   uint32_t state;
-  uint32_t error, have_mb, done;
+  uint32_t status;         // QST_*
   uint32_t stat_searches;
   // JOB_FLAG_DUO: two groups serve one shard with identical state; role 0 (primary)
   // searches the position the state machine asks for and owns every memory write,
@@ -95,6 +107,8 @@ struct QShard {
   uint64_t prof[12];
 };
 
+DEV const ShardDesc& q_desc(const QShard& g) { return g.descs[g.shard]; }
+DEV uint8_t* q_out(const QShard& g) { return g.wsb + q_desc(g).out_off; }
 DEV int q_t() { return wave_lane() & 15; }
 DEV int q_base() { return wave_lane() & 48; }
 DEV uint32_t q_mask16(uint64_t ballot) { return (uint32_t)(ballot >> q_base()) & 0xFFFFu; }
@@ -319,20 +333,24 @@ DEV void q_dict_search(const JobParams& J, const DeviceTables* T, QShard& g, boo
 }
 
 // What the insertion of the searched position needs from its search (per lane).
-struct QIns { uint32_t key, tag, tag2, num, slot_e, tag2_e, tag_e; };
+// Packed (the scout keeps it across the primary's transition and the kernel sits at its
+// 128-VGPR budget): key | tag << 16; tag2 | num << 16; the lane's own entry for the
+// counter-byte rewrite: position, tag2 | tag << 16.
+struct QIns { uint32_t key_tag, tag2_num, slot_e, e_tags; };
 
 // insert P (:293-295): the lane that owns ring slot num & 15 writes the new
 // entry; lanes 0 / 1 refresh the counter bytes kept in their entries.
 DEV void q_insert(QShard& g, bool act, uint32_t P, const QIns& in) {
   const int t = q_t();
-  const uint32_t num = in.num;
+  const uint32_t num = in.tag2_num >> 16;
   const uint32_t ts = num & 15u, nn = (num - 1u) & 0xFFFFu;
   const bool mine = (uint32_t)t == ts;
   const bool hi_changed = (nn >> 8) != (num >> 8);
   if (act && (mine || t == 0 || (t == 1 && hi_changed))) {
     const uint32_t naux = t == 0 ? (nn & 0xFFu) : t == 1 ? (nn >> 8) : 0u;
-    const uint64_t e = mine ? q_entry(P, in.tag2, in.tag, naux) : q_entry(in.slot_e, in.tag2_e, in.tag_e, naux);
-    __builtin_memcpy(g.table + (size_t)in.key * REC_BYTES + QREC_ENTRY(t), &e, 8);
+    const uint64_t e = mine ? q_entry(P, in.tag2_num & 0xFFFFu, in.key_tag >> 16, naux)
+                            : q_entry(in.slot_e, in.e_tags & 0xFFFFu, in.e_tags >> 16, naux);
+    __builtin_memcpy(g.table + (size_t)(in.key_tag & 0xFFFFu) * REC_BYTES + QREC_ENTRY(t), &e, 8);
   }
 }
 
@@ -463,8 +481,10 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
     if (slow) r = s;
   }
   QP_ADD(g, 2, qt);
-  ins.key = kt.key; ins.tag = kt.tag; ins.tag2 = kt.tag2; ins.num = num;
-  ins.slot_e = slot; ins.tag2_e = tag2; ins.tag_e = tag;
+  ins.key_tag = kt.key | (kt.tag << 16);
+  ins.tag2_num = kt.tag2 | (num << 16);
+  ins.slot_e = slot;
+  ins.e_tags = tag2 | (tag << 16);
   (void)T;
   return r;
 }
@@ -476,7 +496,7 @@ DEV void q_flush_padding(QShard& g, bool writer) {
     const uint32_t seal = r.last_bytes | (0x6u << r.last_bytes_bits);
     const uint32_t seal_bits = r.last_bytes_bits + 6u;
     const uint32_t nb = (seal_bits + 7u) >> 3;
-    if (writer) for (uint32_t i = 0; i < nb; ++i) g.out[r.out_bytes + i] = (uint8_t)(seal >> (8u * i));
+    if (writer) for (uint32_t i = 0; i < nb; ++i) q_out(g)[r.out_bytes + i] = (uint8_t)(seal >> (8u * i));
     r.out_bytes += nb;
     r.last_bytes = 0;
     r.last_bytes_bits = 0;
@@ -490,7 +510,7 @@ DEV void q_driver_pre(const JobParams& J, QShard& g) {
   const uint32_t block = 1u << J.lgblock;
   const uint32_t htl = hasher_htl(J.hasher_type);
   for (;;) {
-    const uint32_t avail = g.len - r.input_pos;
+    const uint32_t avail = q_desc(g).len - r.input_pos;
     const uint32_t d = r.input_pos - r.last_processed_pos;
     uint32_t remaining = d >= block ? 0u : block - d;
     if (r.flint >= 0 && remaining > (uint32_t)r.flint) remaining = (uint32_t)r.flint;
@@ -500,20 +520,19 @@ DEV void q_driver_pre(const JobParams& J, QShard& g) {
       if (r.flint > 0) r.flint -= (int32_t)n;
       continue;
     }
-    if (remaining != 0 && avail == 0 && g.final_op == 0) { g.done = 1; g.state = Q_DONE; return; }
-    bool is_last = avail == 0 && g.final_op == 2;
-    bool force_flush = avail == 0 && g.final_op == 1;
+    if (remaining != 0 && avail == 0 && q_desc(g).final_op == 0) { g.status |= QST_DONE; g.state = Q_DONE; return; }
+    bool is_last = avail == 0 && q_desc(g).final_op == 2;
+    bool force_flush = avail == 0 && q_desc(g).final_op == 1;
     if (!is_last && r.flint == 0) { r.flint = -1; force_flush = true; }
     const uint32_t bytes = r.input_pos - r.last_processed_pos;
     const uint32_t pos = r.last_processed_pos;
-    if (r.ncmds + bytes / 2u + 2u > g.cmd_cap) { g.error = 1; g.state = Q_DONE; return; }
-    g.blk_is_last = is_last;
-    g.blk_force_flush = force_flush;
+    if (r.ncmds + bytes / 2u + 2u > q_desc(g).cmd_cap) { g.status |= QST_ERROR; g.state = Q_DONE; return; }
+    g.blk_flags = (is_last ? QBLK_LAST : 0u) | (force_flush ? QBLK_FLUSH : 0u);
     g.blk_bytes = bytes;
     g.blk_pos = pos;
     g.pos_end = r.input_pos;
-    g.want_stitch = bytes >= htl - 1u && pos >= 3u;
-    g.want_extend = r.ncmds != 0 && r.last_insert_len == 0;
+    if (bytes >= htl - 1u && pos >= 3u) g.blk_flags |= QBLK_STITCH;
+    if (r.ncmds != 0 && r.last_insert_len == 0) g.blk_flags |= QBLK_EXTEND;
     g.state = Q_SETUP;
     return;
   }
@@ -523,8 +542,8 @@ DEV void q_driver_pre(const JobParams& J, QShard& g) {
 DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
   RoundRegs& r = g.r;
   const uint32_t block = 1u << J.lgblock;
-  const bool is_last = g.blk_is_last != 0, force_flush = g.blk_force_flush != 0;
-  const uint32_t avail = g.len - r.input_pos;
+  const bool is_last = (g.blk_flags & QBLK_LAST) != 0, force_flush = (g.blk_flags & QBLK_FLUSH) != 0;
+  const uint32_t avail = q_desc(g).len - r.input_pos;
   {
     const uint32_t processed = r.input_pos - r.last_flush_pos;
     const bool next_fits = processed + block <= J.max_metablock_size;
@@ -543,7 +562,7 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
   if (!is_last && r.input_pos == r.last_flush_pos) {
     r.last_processed_pos = r.input_pos;
     if (force_flush) q_flush_padding(g, writer);
-    if (avail == 0) { g.done = 1; g.state = Q_DONE; } else g.state = Q_PRE;
+    if (avail == 0) { g.status |= QST_DONE; g.state = Q_DONE; } else g.state = Q_PRE;
     return;
   }
   const uint32_t mbytes = r.input_pos - r.last_flush_pos;
@@ -551,7 +570,7 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
     // ShouldCompress() is false for <= 2 bytes (encode.c:461): flint blocks
     // and tiny tails are written right here by the group's lane 0.
     BitWriter w;
-    bw_init(w, g.out + r.out_bytes, r.last_bytes_bits, r.last_bytes);
+    bw_init(w, q_out(g) + r.out_bytes, r.last_bytes_bits, r.last_bytes);
     if (mbytes == 0) {
       bw_put(w, 2, 3);
       bw_align_byte(w);
@@ -588,10 +607,10 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
     r.nlits = 0;
     for (int i = 0; i < 4; ++i) r.saved_dc[i] = g.dc[i];
     if (force_flush) q_flush_padding(g, writer);
-    if (is_last || avail == 0) { g.done = 1; g.state = Q_DONE; } else g.state = Q_PRE;
+    if (is_last || avail == 0) { g.status |= QST_DONE; g.state = Q_DONE; } else g.state = Q_PRE;
     return;
   }
-  g.have_mb = 1;
+  g.status |= QST_HAVE_MB;
   g.state = Q_DONE;
 }
 
@@ -601,7 +620,7 @@ DEV void q_setup_block(const JobParams& J, QShard& g, bool want, uint8_t* lds_du
   const int t = q_t();
   const uint32_t htl = hasher_htl(J.hasher_type);
   // StitchToPreviousBlock (..64_simd_inc.h:139-151)
-  if (want && g.want_stitch) {
+  if (want && (g.blk_flags & QBLK_STITCH)) {
     g.st_first = g.blk_pos - 3u;
     g.st_count = 3;
     g.st_stride = 1;
@@ -613,7 +632,7 @@ DEV void q_setup_block(const JobParams& J, QShard& g, bool want, uint8_t* lds_du
   Command last;
   last.insert_len = last.copy_len = last.dist_extra = 0;
   last.cmd_prefix = last.dist_prefix = 0;
-  const bool try_ext = want && g.want_extend;
+  const bool try_ext = want && (g.blk_flags & QBLK_EXTEND) != 0;
   if (try_ext) {
     last = g.cmds[g.r.ncmds - 1];
     const uint32_t last_copy_len = last.copy_len & 0x1FFFFFFu;
@@ -760,35 +779,33 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
   const bool writer = alive && t == 0 && role == 0;
   const uint32_t htl = hasher_htl(J.hasher_type);
   const ShardDesc& D = shards[alive ? shard : 0];
-  ShardState* S = &states[alive ? shard : 0];
+  const ShardState* S0 = &states[alive ? shard : 0];
 
   QShard g;
   g.data = input + D.in_off;
   g.table = ws + D.table_off;
   g.cmds = (Command*)(ws + D.cmds_off);
-  g.out = ws + D.out_off;
-  g.len = D.len;
+  g.descs = shards;
+  g.wsb = ws;
+  g.shard = alive ? shard : 0u;
   g.stream_offset = D.stream_offset;
-  g.final_op = D.final_op;
-  g.cmd_cap = D.cmd_cap;
-  regs_load(g.r, S);
-  for (int i = 0; i < 4; ++i) g.dc[i] = S->dist_cache[i];
-  g.dict_lookups = S->dict_lookups;
-  g.dict_matches = S->dict_matches;
-  g.blk_is_last = g.blk_force_flush = g.blk_bytes = g.blk_pos = 0;
-  g.want_stitch = g.want_extend = 0;
+  regs_load(g.r, S0);
+  for (int i = 0; i < 4; ++i) g.dc[i] = S0->dist_cache[i];
+  g.dict_lookups = S0->dict_lookups;
+  g.dict_matches = S0->dict_matches;
+  g.blk_flags = g.blk_bytes = g.blk_pos = 0;
   g.position = g.pos_end = g.store_end = g.insert_length = g.apply_random_heuristics = 0;
   g.sr_len = g.sr_dist = 0; g.sr_score = K_MIN_SCORE; g.sr_delta = 0; g.delayed = 0;
   g.st_first = g.st_count = 0; g.st_stride = 1;
   g.st_x = 0; g.st_x_valid = 0;
   g.n32.q[0] = g.n32.q[1] = g.n32.q[2] = g.n32.q[3] = 0;
   g.n32_pos = 0xFFFFFFFFu;
-  g.error = 0; g.have_mb = 0; g.done = 0;
+  g.status = 0;
   g.stat_searches = 0;
   g.role = role;
   g.pf_val = g.pf_acc = 0;
   for (int i = 0; i < 12; ++i) g.prof[i] = 0;
-  g.state = (alive && !S->done && !S->mb_valid && !S->error) ? Q_PRE : Q_DONE;
+  g.state = (alive && !S0->done && !S0->mb_valid && !S0->error) ? Q_PRE : Q_DONE;
   const bool participated = g.state != Q_DONE;
 
   while (wave_any(g.state != Q_DONE)) {
@@ -830,14 +847,14 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
         other.distance = wave_shfl(mine.distance, lane ^ 16);
         other.score = wave_shfl(mine.score, lane ^ 16);
         other.delta = (int32_t)wave_shfl((uint32_t)mine.delta, lane ^ 16);
-        const uint32_t other_key = wave_shfl(ins.key, lane ^ 16);
+        const uint32_t other_key = wave_shfl(ins.key_tag & 0xFFFFu, lane ^ 16);
         r0 = g.role == 0 ? mine : other;
         r1 = g.role == 0 ? other : mine;
         dl1 = wave_shfl(g.dict_lookups, lane | 16);
         dm1 = wave_shfl(g.dict_matches, lane | 16);
         g.dict_lookups = dl0;
         g.dict_matches = dm0;
-        r1_ok = ins.key != other_key;      // equal keys: the scout read the bucket before P went in
+        r1_ok = (ins.key_tag & 0xFFFFu) != other_key;      // equal keys: the scout read the bucket before P went in
       }
       QP_ADD(g, 4, qt);
       if (want) g.stat_searches++;
@@ -885,18 +902,19 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
 
   wave_sync();
   if (writer && participated) {
+    ShardState* S = &states[shard];      // (recomputed: not worth two registers across the loop)
     regs_save(g.r, S);
     for (int i = 0; i < 4; ++i) S->dist_cache[i] = g.dc[i];
     S->dict_lookups = g.dict_lookups;
     S->dict_matches = g.dict_matches;
-    S->done = g.done;
-    S->mb_valid = g.have_mb;
-    if (g.error) S->error = g.error;
-    if (g.have_mb) {
+    S->done = (g.status & QST_DONE) ? 1u : 0u;
+    S->mb_valid = (g.status & QST_HAVE_MB) ? 1u : 0u;
+    if (g.status & QST_ERROR) S->error = 1;
+    if (g.status & QST_HAVE_MB) {
       S->mb_start = g.r.last_flush_pos;
       S->mb_bytes = g.r.input_pos - g.r.last_flush_pos;
-      S->mb_is_last = g.blk_is_last;
-      S->mb_force_flush = g.blk_force_flush;
+      S->mb_is_last = (g.blk_flags & QBLK_LAST) ? 1u : 0u;
+      S->mb_force_flush = (g.blk_flags & QBLK_FLUSH) ? 1u : 0u;
       S->mb_raw = 0;
     }
     S->stat_searches += g.stat_searches;

@@ -301,14 +301,14 @@ template <int E>
 DEV void d_setup_block(const JobParams& J, const DeepGeom& G, QShard& g, uint8_t* lds_dup) {
   const int lane = wave_lane();
   const uint32_t htl = hasher_htl(J.hasher_type);
-  if (g.want_stitch) {
+  if (g.blk_flags & QBLK_STITCH) {
     g.st_first = g.blk_pos - 3u;
     g.st_count = 3;
     g.st_stride = 1;
   }
   d_drain_stores<E>(J, G, g, lds_dup);
   uint32_t bytes = g.blk_bytes, pos = g.blk_pos;
-  if (g.want_extend) {
+  if (g.blk_flags & QBLK_EXTEND) {
     Command last = g.cmds[g.r.ncmds - 1];
     const uint32_t last_copy_len = last.copy_len & 0x1FFFFFFu;
     const uint32_t lpp = g.r.last_processed_pos - last_copy_len;
@@ -367,24 +367,22 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   g.table = ws + D.table_off;
   g.nums = (uint16_t*)(ws + D.num_off);
   g.cmds = (Command*)(ws + D.cmds_off);
-  g.out = ws + D.out_off;
-  g.len = D.len;
+  g.descs = &D;
+  g.wsb = ws;
+  g.shard = 0;
   g.stream_offset = D.stream_offset;
-  g.final_op = D.final_op;
-  g.cmd_cap = D.cmd_cap;
   regs_load(g.r, S);
   for (int i = 0; i < 4; ++i) g.dc[i] = S->dist_cache[i];
   g.dict_lookups = S->dict_lookups;
   g.dict_matches = S->dict_matches;
-  g.blk_is_last = g.blk_force_flush = g.blk_bytes = g.blk_pos = 0;
-  g.want_stitch = g.want_extend = 0;
+  g.blk_flags = g.blk_bytes = g.blk_pos = 0;
   g.position = g.pos_end = g.store_end = g.insert_length = g.apply_random_heuristics = 0;
   g.sr_len = g.sr_dist = 0; g.sr_score = K_MIN_SCORE; g.sr_delta = 0; g.delayed = 0;
   g.st_first = g.st_count = 0; g.st_stride = 1;
   g.st_x = 0; g.st_x_valid = 0;
   g.n32.q[0] = g.n32.q[1] = g.n32.q[2] = g.n32.q[3] = 0;
   g.n32_pos = 0xFFFFFFFFu;
-  g.error = 0; g.have_mb = 0; g.done = 0;
+  g.status = 0;
   g.stat_searches = 0;
   g.pf_val = g.pf_acc = 0;
   g.role = 0;
@@ -473,14 +471,14 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     for (int i = 0; i < 4; ++i) S->dist_cache[i] = g.dc[i];
     S->dict_lookups = g.dict_lookups;
     S->dict_matches = g.dict_matches;
-    S->done = g.done;
-    S->mb_valid = g.have_mb;
-    if (g.error) S->error = g.error;
-    if (g.have_mb) {
+    S->done = (g.status & QST_DONE) ? 1u : 0u;
+    S->mb_valid = (g.status & QST_HAVE_MB) ? 1u : 0u;
+    if (g.status & QST_ERROR) S->error = 1;
+    if (g.status & QST_HAVE_MB) {
       S->mb_start = g.r.last_flush_pos;
       S->mb_bytes = g.r.input_pos - g.r.last_flush_pos;
-      S->mb_is_last = g.blk_is_last;
-      S->mb_force_flush = g.blk_force_flush;
+      S->mb_is_last = (g.blk_flags & QBLK_LAST) ? 1u : 0u;
+      S->mb_force_flush = (g.blk_flags & QBLK_FLUSH) ? 1u : 0u;
       S->mb_raw = 0;
     }
     S->stat_searches += g.stat_searches;
