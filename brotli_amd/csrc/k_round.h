@@ -253,18 +253,14 @@ DEV void init_shard_table(uint8_t* table, uint32_t nrec, uint32_t tid, uint32_t 
   // One record = 128 B = 8 x 16 B; thread t clears 16-byte piece t.  The
   // counter starts at 0xFFFF: dword 28 in k_parse.h's layout, the aux bytes of
   // entries 0 and 1 (bytes 7 and 15) in k_parse4.h's.
-  if (quad) {
-    // k_parse4.h trusts only the first (0xFFFF - num) ring slots of a record, so the
-    // counter bytes are all a fresh table needs: 16 of every 128 bytes are written, the
-    // rest keeps whatever an earlier job left there.
-    const uint32_t v[4] = {0, 0xFF000000u, 0, 0xFF000000u};
-    for (uint32_t r = tid; r < nrec; r += nthreads) __builtin_memcpy(table + (size_t)r * 128u, v, 16);
-    return;
-  }
   const uint32_t pieces = nrec * 8u;
   for (uint32_t p = tid; p < pieces; p += nthreads) {
     uint32_t v[4] = {0, 0, 0, 0};
-    if ((p & 7u) == 7u) v[0] = 0xFFFFu;
+    if (quad) {
+      if ((p & 7u) == 0u) { v[1] = 0xFF000000u; v[3] = 0xFF000000u; }
+    } else if ((p & 7u) == 7u) {
+      v[0] = 0xFFFFu;
+    }
     __builtin_memcpy(table + (size_t)p * 16u, v, 16);
   }
 }
