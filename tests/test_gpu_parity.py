@@ -257,3 +257,18 @@ def test_fast_path_full_size_properties(ctx, oracle, ref):
     m = 16 << 20
     nb2, _ = ctx.encode_fast_device(d_in, m, d_out, 22)
     assert d_out[:nb2 // 8].cpu().numpy().tobytes() == oracle.encode_fast(data[:m], 22)
+
+
+def test_parse4_wave_layouts_agree(ctx, oracle, monkeypatch):
+    """k_parse4's layouts — 4 / 2 / 1 shards per wave, with and without scout groups — are
+    chosen from the shard count; force each one on the same job (BROTLI_AMD_QGROUPS /
+    BROTLI_AMD_DUO are read at plan time) and compare with the oracle."""
+    from brotli_amd import hip
+    data = G.enwik_text((6 << 20) + 4321, seed=23, vocab=30000) + G.mixed_corpus(1 << 20)
+    shard = 96 << 10
+    want = oracle.encode_plan(data, 5, 22, shard)
+    for groups, duo in ((4, 1), (2, 0), (2, 1), (1, 0), (1, 1)):
+        monkeypatch.setenv("BROTLI_AMD_QGROUPS", str(groups))
+        monkeypatch.setenv("BROTLI_AMD_DUO", str(duo))
+        got, _ = ctx.encode_host(data, hip.make_params(5, 22, shard))
+        assert got == want, (groups, duo)
