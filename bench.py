@@ -312,6 +312,7 @@ def main():
                                   "bytes identical to the reference driven with the same plan" % (
                                       infos[-1]["nshards"], args.shard_kb),
                 "compressed_bytes": out_total, "ratio": round(total / out_total, 4),
+                "parse_ms_per_step": [round(i["ms_parse"], 1) for i in infos],
                 "stage_ms": {k: round(sum(i[k] for i in infos) / len(infos), 3) for k in
                              ("ms_total", "ms_init", "ms_parse", "ms_build", "ms_store", "ms_gather")},
             },
