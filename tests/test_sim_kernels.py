@@ -211,3 +211,56 @@ def test_fast_kernels_table_slots_are_reused(sim, oracle, monkeypatch):
     monkeypatch.setenv("SIM_FAST_SLOTS", "2")
     data = FAST["mixed"]
     assert sim.encode_fast(data, 16) == oracle.encode_fast(data, 16)
+
+
+# --- seeded fuzz: many small structured inputs through every kernel family ---------------------------
+
+def _fuzz_input(rng):
+    """Small inputs with the features that steer the encoder: repeats at assorted distances,
+    runs, dictionary words, incompressible stretches."""
+    words = [b"the ", b"and ", b"that ", b"with ", b"http://", b"</div>", b"function ", b"0000", b"\n\n", b"Time "]
+    out = bytearray()
+    target = int(rng.integers(1, 6000))
+    while len(out) < target:
+        k = int(rng.integers(0, 6))
+        if k == 0:
+            out += rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8).tobytes()
+        elif k == 1 and out:
+            d = int(rng.integers(1, len(out) + 1))
+            n = int(rng.integers(2, 70))
+            for _ in range(n):
+                out.append(out[-d])
+        elif k == 2:
+            out += bytes([int(rng.integers(32, 127))]) * int(rng.integers(1, 50))
+        elif k == 3:
+            out += words[int(rng.integers(0, len(words)))]
+        elif k == 4:
+            out += bytes(rng.integers(97, 123, int(rng.integers(1, 12)), dtype=np.uint8).tolist()) + b" "
+        else:
+            out += G.enwik_text(int(rng.integers(8, 200)), seed=int(rng.integers(0, 1 << 30)), vocab=300)
+    return bytes(out[:target])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_fuzz_small_inputs_all_kernels(sim, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(12):
+        data = _fuzz_input(rng)
+        shard = int(rng.integers(0, 3)) * int(rng.integers(300, 2500))
+        hint = (1 << 30) if rng.integers(0, 2) else 0          # H68 vs H58
+        want = sim.encode(data, size_hint=hint, shard_size=shard, flags=2) if hint else oracle.encode_plan(data, 5, 22, shard)
+        if hint:   # the oracle's plan driver derives the hint itself; pin the base kernel on its shard API
+            parts, off = [], 0
+            sh = shard or len(data)
+            while off < len(data):
+                m = min(sh, len(data) - off)
+                parts.append(oracle.encode_shard(data[off:off + m], 5, 22, hint, off, off + m == len(data)))
+                off += m
+            assert want == b"".join(parts)
+        rev = int(rng.integers(0, 2))
+        for flags in (2 | 32 | (1 << 8), 2 | 32 | (2 << 8), 2 | 4 | 32 | (2 << 8)):
+            assert sim.encode(data, size_hint=hint, shard_size=shard, reverse=rev, flags=flags) == want, (seed, len(data), shard, flags)
+        q = int(rng.integers(6, 10))
+        assert sim.encode(data, quality=q, lgwin=22, shard_size=shard) == oracle.encode_plan(data, q, 22, shard), (seed, q)
+        lgwin = int(rng.choice([10, 12, 16, 18, 22]))
+        assert sim.encode_fast(data, lgwin, None, rev) == oracle.encode_fast(data, lgwin), (seed, lgwin)
