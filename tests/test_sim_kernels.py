@@ -114,8 +114,8 @@ def test_quad_kernel_fewer_shards_per_wave(sim, oracle, groups):
     data, shard, hint = CASES["ragged_shards"]
     assert sim.encode(data, size_hint=hint, shard_size=shard, flags=2 | (groups << 8)) == \
         oracle.encode_plan(data, 5, 22, shard) if not hint else True
-    data = G.enwik_text(300000, seed=77, vocab=5000)
-    assert sim.encode(data, shard_size=50000, flags=2 | (groups << 8)) == oracle.encode_plan(data, 5, 22, 50000)
+    data = G.enwik_text(120000, seed=77, vocab=5000)
+    assert sim.encode(data, shard_size=30000, flags=2 | (groups << 8)) == oracle.encode_plan(data, 5, 22, 30000)
 
 
 @pytest.mark.parametrize("groups", [1, 2])
@@ -241,7 +241,7 @@ def _fuzz_input(rng):
     return bytes(out[:target])
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(4))
 def test_fuzz_small_inputs_all_kernels(sim, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     for _ in range(12):
