@@ -384,10 +384,50 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
                                         uint8_t** next_out, size_t* total_out) {
   if (!ensure_initialized(s)) return BROTLI_FALSE;
   if (op == OP_EMIT_METADATA) {
-    /* Metadata blocks share the partial last byte of the previous meta-block
-       (encode.c:1223-1249); that hand-off is not implemented on the device. */
-    if (verbose()) fprintf(stderr, "brotli_amd: BROTLI_OPERATION_EMIT_METADATA is not supported\n");
-    return BROTLI_FALSE;
+    /* ProcessMetadata / WriteMetadataHeader (encode.c:1223-1249, 1549-1617): the header
+       continues the partial last byte of the data before it.  At quality 1 that byte is
+       kept on the host (carry_*), so the block is assembled here; at the other qualities
+       the partial byte lives in the device-side shard state and this operation is not
+       offered. */
+    const size_t n = *available_in;
+    uint64_t bits;
+    uint32_t nbits;
+    uint8_t hdr[8];
+    size_t hb, i;
+    if (s->quality != 1) {
+      if (verbose()) fprintf(stderr, "brotli_amd: BROTLI_OPERATION_EMIT_METADATA needs quality 1\n");
+      return BROTLI_FALSE;
+    }
+    if (n > (1u << 24)) return BROTLI_FALSE;                        /* :1552 */
+    if (s->stream_state != ST_PROCESSING) return BROTLI_FALSE;      /* :1558-1561 */
+    if (!submit_fast(s, OP_PROCESS)) { s->failed = 1; return BROTLI_FALSE; }   /* data fed so far comes first */
+    bits = s->carry_value;
+    nbits = s->carry_bits;
+    /* ISLAST 0, MNIBBLES 11 (= 0 nibbles), reserved 0 */
+    bits |= (uint64_t)0x6u << nbits;
+    nbits += 4;
+    if (n == 0) {
+      nbits += 2;                                                   /* MSKIPBYTES 0 */
+    } else {
+      uint32_t lb = 1, nbytes;
+      if (n > 1) { uint32_t v = (uint32_t)n - 1; lb = 0; while (v) { ++lb; v >>= 1; } }
+      nbytes = (lb + 7) / 8;
+      bits |= (uint64_t)nbytes << nbits;
+      nbits += 2;
+      bits |= (uint64_t)(n - 1) << nbits;
+      nbits += 8 * nbytes;
+    }
+    hb = (nbits + 7) >> 3;
+    for (i = 0; i < hb; ++i) hdr[i] = (uint8_t)(bits >> (8 * i));
+    s->carry_bits = 0;
+    s->carry_value = 0;
+    if (!out_append(s, hdr, hb)) return BROTLI_FALSE;
+    if (n && !out_append(s, *next_in, n)) return BROTLI_FALSE;
+    *next_in += n;
+    *available_in = 0;
+    s->total_in += n;
+    push_output(s, available_out, next_out, total_out);
+    return BROTLI_TRUE;
   }
   if (op < 0 || op > 2) return BROTLI_FALSE;
   if (s->stream_state != ST_PROCESSING && *available_in != 0) return BROTLI_FALSE;   /* encode.c:1657 */

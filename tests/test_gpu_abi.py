@@ -258,3 +258,33 @@ def test_q1_reference_cli_on_our_library(tmp_path, stock):
     r = subprocess.run([cli, "-q", "1", "-w", "22", "-c", str(src)], capture_output=True, env=env, check=True)
     want, _ = drive(stock, data, _chunks(len(data), 1 << 19, 2), Q1)
     assert r.stdout == want
+
+
+def test_q1_emit_metadata_equals_reference(amd, stock):
+    """BROTLI_OPERATION_EMIT_METADATA at quality 1: the metadata header continues the partial
+    byte of the data before it (encode.c:1223-1249), also right at the start of the stream and
+    with an empty payload; the decoder skips the blocks."""
+    from refharness import Ref
+    text = G.enwik_text(700000, seed=43, vocab=20000)
+    meta = b"metadata payload \x00\x01\x02" * 11
+    data = text[:300000] + meta + text[300000:500000] + meta[:1] + text[500000:]
+    ops = [(300000, 0), (len(meta), 3), (200000, 1), (0, 3), (1, 3), (200000, 2)]
+    got, fin = drive(amd, data, ops, Q1)
+    want, _ = drive(stock, data, ops, Q1)
+    assert fin and got == want
+    assert Ref().decompress(got, len(text)) == text
+    ops = [(len(meta), 3), (300000, 2)]
+    data = meta + text[:300000]
+    got, fin = drive(amd, data, ops, Q1)
+    want, _ = drive(stock, data, ops, Q1)
+    assert fin and got == want
+    # not offered at the qualities whose partial byte lives on the device
+    st = amd.BrotliEncoderCreateInstance(None, None, None)
+    amd.BrotliEncoderSetParameter(st, 1, 5)
+    n = C.c_size_t(4)
+    buf = C.create_string_buffer(b"meta", 4)
+    nxt = C.c_void_p(C.addressof(buf))
+    ao = C.c_size_t(0)
+    no = C.c_void_p(0)
+    assert not amd.BrotliEncoderCompressStream(st, 3, C.byref(n), C.byref(nxt), C.byref(ao), C.byref(no), None)
+    amd.BrotliEncoderDestroyInstance(st)
