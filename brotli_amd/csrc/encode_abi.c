@@ -21,7 +21,7 @@
 #include "../../include/brotli_amd_hip.h"
 
 enum { OP_PROCESS = 0, OP_FLUSH = 1, OP_FINISH = 2, OP_EMIT_METADATA = 3 };
-enum { ST_PROCESSING = 0, ST_FLUSH_REQUESTED = 1, ST_FINISHED = 2 };
+enum { ST_PROCESSING = 0, ST_FLUSH_REQUESTED = 1, ST_FINISHED = 2, ST_METADATA = 3 };
 enum {  /* BrotliEncoderParameter, encode.h:160-265 */
   P_MODE = 0, P_QUALITY = 1, P_LGWIN = 2, P_LGBLOCK = 3, P_DISABLE_CTX = 4, P_SIZE_HINT = 5,
   P_LARGE_WINDOW = 6, P_NPOSTFIX = 7, P_NDIRECT = 8, P_STREAM_OFFSET = 9, P_BASE64_MODE = 10,
@@ -376,7 +376,8 @@ static void push_output(BrotliEncoderState* s, size_t* available_out, uint8_t** 
   }
   if (total_out) *total_out = (size_t)s->total_out;
   /* CheckFlushComplete, encode.c:1417-1423 */
-  if (s->stream_state == ST_FLUSH_REQUESTED && s->out_pos == s->out_len) s->stream_state = ST_PROCESSING;
+  if ((s->stream_state == ST_FLUSH_REQUESTED || s->stream_state == ST_METADATA) && s->out_pos == s->out_len)
+    s->stream_state = ST_PROCESSING;
 }
 
 BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* available_in,
@@ -399,6 +400,13 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
       return BROTLI_FALSE;
     }
     if (n > (1u << 24)) return BROTLI_FALSE;                        /* :1552 */
+    if (s->stream_state == ST_METADATA) {
+      /* the block is complete but not yet taken: the caller keeps calling with the same
+         operation and no input until the output is drained (:1641-1645, 1583-1589) */
+      if (n != 0) return BROTLI_FALSE;
+      push_output(s, available_out, next_out, total_out);
+      return BROTLI_TRUE;
+    }
     if (s->stream_state != ST_PROCESSING) return BROTLI_FALSE;      /* :1558-1561 */
     if (!submit_fast(s, OP_PROCESS)) { s->failed = 1; return BROTLI_FALSE; }   /* data fed so far comes first */
     bits = s->carry_value;
@@ -426,9 +434,11 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
     *next_in += n;
     *available_in = 0;
     s->total_in += n;
+    s->stream_state = ST_METADATA;
     push_output(s, available_out, next_out, total_out);
     return BROTLI_TRUE;
   }
+  if (s->stream_state == ST_METADATA) return BROTLI_FALSE;          /* :1652-1655 */
   if (op < 0 || op > 2) return BROTLI_FALSE;
   if (s->stream_state != ST_PROCESSING && *available_in != 0) return BROTLI_FALSE;   /* encode.c:1657 */
   if (s->stream_state == ST_PROCESSING) {
@@ -488,7 +498,8 @@ const uint8_t* BrotliEncoderTakeOutput(BrotliEncoderState* s, size_t* size) {
   if (n == 0) { *size = 0; return NULL; }
   s->out_pos += n;
   s->total_out += n;
-  if (s->stream_state == ST_FLUSH_REQUESTED && s->out_pos == s->out_len) s->stream_state = ST_PROCESSING;
+  if ((s->stream_state == ST_FLUSH_REQUESTED || s->stream_state == ST_METADATA) && s->out_pos == s->out_len)
+    s->stream_state = ST_PROCESSING;
   *size = n;
   return p;
 }
