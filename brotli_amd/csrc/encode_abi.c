@@ -395,8 +395,10 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
     uint32_t nbits;
     uint8_t hdr[8];
     size_t hb, i;
-    if (s->quality != 1) {
-      if (verbose()) fprintf(stderr, "brotli_amd: BROTLI_OPERATION_EMIT_METADATA needs quality 1\n");
+    const int single5 = s->quality == 5 && s->shard_bytes == 0;
+    if (s->quality != 1 && !single5) {
+      if (verbose()) fprintf(stderr, "brotli_amd: BROTLI_OPERATION_EMIT_METADATA needs quality 1 or an "
+                                     "unpartitioned quality-5 stream\n");
       return BROTLI_FALSE;
     }
     if (n > (1u << 24)) return BROTLI_FALSE;                        /* :1552 */
@@ -408,7 +410,31 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
       return BROTLI_TRUE;
     }
     if (s->stream_state != ST_PROCESSING) return BROTLI_FALSE;      /* :1558-1561 */
-    if (!submit_fast(s, OP_PROCESS)) { s->failed = 1; return BROTLI_FALSE; }   /* data fed so far comes first */
+    if (single5) {
+      /* the device stream flushes what it holds as a meta-block without the padding block
+         and hands over the open byte */
+      const uint8_t* o;
+      uint64_t on;
+      if (!s->hint_fixed) {                                        /* UpdateSizeHint(s, 0), :1647 */
+        s->eff_hint = s->total_in >= (1u << 30) ? (1u << 30) : (uint32_t)s->total_in;
+        s->hint_fixed = 1;
+      }
+      if (!s->stream && brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
+                                                 &s->stream) != BROTLI_AMD_OK) { s->failed = 1; return BROTLI_FALSE; }
+      if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_FLUSH_OPEN, &o, &on) != BROTLI_AMD_OK ||
+          brotli_amd_stream_take_partial(s->stream, &s->carry_bits, &s->carry_value) != BROTLI_AMD_OK) {
+        if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+        s->failed = 1;
+        return BROTLI_FALSE;
+      }
+      s->submitted += s->in_len;
+      s->in_len = 0;
+      s->header_written = 1;
+      if (!out_append(s, o, (size_t)on)) return BROTLI_FALSE;
+    } else if (!submit_fast(s, OP_PROCESS)) {                        /* data fed so far comes first */
+      s->failed = 1;
+      return BROTLI_FALSE;
+    }
     bits = s->carry_value;
     nbits = s->carry_bits;
     /* ISLAST 0, MNIBBLES 11 (= 0 nibbles), reserved 0 */

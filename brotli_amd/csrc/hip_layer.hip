@@ -732,11 +732,26 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
   BrotliAmdCtx* c = s->c;
   if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   if (s->finished) { fail(c, "stream already finished"); return BROTLI_AMD_ERROR; }
-  if (op < 0 || op > 2) { fail(c, "bad stream op"); return BROTLI_AMD_UNSUPPORTED; }
+  if (op < 0 || op > 3) { fail(c, "bad stream op"); return BROTLI_AMD_UNSUPPORTED; }
   if (!stream_run(s, data, len, op)) return BROTLI_AMD_ERROR;
   if (op == BROTLI_AMD_OP_FINISH) s->finished = true;
   *out = s->host_out.data();
   *out_len = s->host_out.size();
+  return BROTLI_AMD_OK;
+}
+
+int brotli_amd_stream_take_partial(BrotliAmdStream* s, uint32_t* nbits, uint32_t* value) {
+  BrotliAmdCtx* c = s->c;
+  *nbits = 0;
+  *value = 0;
+  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  uint32_t lb[2] = {0, 0};   // last_bytes, last_bytes_bits are adjacent in ShardState
+  static_assert(offsetof(ShardState, last_bytes_bits) == offsetof(ShardState, last_bytes) + 4, "layout");
+  if (hipMemcpy(lb, &s->d_state->last_bytes, 8, hipMemcpyDeviceToHost) != hipSuccess) { fail(c, "state read failed"); return BROTLI_AMD_ERROR; }
+  const uint32_t zero[2] = {0, 0};
+  if (hipMemcpy(&s->d_state->last_bytes, zero, 8, hipMemcpyHostToDevice) != hipSuccess) { fail(c, "state write failed"); return BROTLI_AMD_ERROR; }
+  *value = lb[0];
+  *nbits = lb[1];
   return BROTLI_AMD_OK;
 }
 

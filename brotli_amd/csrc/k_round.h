@@ -161,8 +161,12 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     // (encode.c:1700: EncodeData only when the block is full or op != PROCESS).
     if (remaining != 0 && avail == 0 && D.final_op == 0) { done = true; break; }
     bool is_last = avail == 0 && D.final_op == 2;
-    bool force_flush = avail == 0 && D.final_op == 1;
-    if (!is_last && r.flint == 0) { r.flint = -1; force_flush = true; }
+    // final_op 3: flush the pending input as a meta-block but leave the partial byte open
+    // (EncodeData(is_last 0, force_flush 1) of ProcessMetadata, encode.c:1569-1573: the
+    // padding block of InjectFlushOrPushOutput is not injected there)
+    bool force_flush = avail == 0 && (D.final_op == 1 || D.final_op == 3);
+    bool seal = avail == 0 && D.final_op == 1;
+    if (!is_last && r.flint == 0) { r.flint = -1; force_flush = true; seal = true; }
 
     // ---- EncodeData ----
     uint32_t bytes = r.input_pos - r.last_processed_pos;
@@ -195,7 +199,7 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     if (!is_last && r.input_pos == r.last_flush_pos) {
       // Flush with nothing new (encode.c:1175-1180): only the padding.
       r.last_processed_pos = r.input_pos;
-      if (force_flush) inject_flush_padding(r, out);
+      if (seal) inject_flush_padding(r, out);
       if (avail == 0) { done = true; break; }
       continue;
     }
@@ -213,13 +217,13 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
         emit_raw_metablock(w, c.data, r.last_flush_pos, mbytes, is_last);
       }
       after_metablock(r, c.dc, c.data, out, w, force_flush);
-      if (force_flush) inject_flush_padding(r, out);
+      if (seal) inject_flush_padding(r, out);
       if (is_last || avail == 0) { done = true; break; }
       continue;
     }
     have_mb = true;
     mb_is_last = is_last;
-    mb_force_flush = force_flush;
+    mb_force_flush = force_flush ? (seal ? 1u : 2u) : 0u;   // 2: flushed meta-block without the padding block
     break;
   }
 

@@ -1001,7 +1001,7 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     for (int i = 0; i < 4; ++i) r.saved_dc[i] = dc[i];
   }
   wave_mem_barrier();
-  if (force_flush) inject_flush_padding(r, out);
+  if (S->mb_force_flush == 1) inject_flush_padding(r, out);
   const bool done = is_last || (D.len - r.input_pos) == 0;
   wave_sync();
   if (lane == 0) {

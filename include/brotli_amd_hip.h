@@ -110,6 +110,8 @@ typedef struct BrotliAmdStream BrotliAmdStream;
 #define BROTLI_AMD_OP_PROCESS 0
 #define BROTLI_AMD_OP_FLUSH 1
 #define BROTLI_AMD_OP_FINISH 2
+#define BROTLI_AMD_OP_FLUSH_OPEN 3   /* flush the pending input as a meta-block, keep the partial last
+                                        byte pending (what EMIT_METADATA needs, encode.c:1569-1573) */
 int brotli_amd_stream_create(BrotliAmdCtx* ctx, int quality, int lgwin, uint32_t size_hint,
                              uint32_t stream_offset, BrotliAmdStream** stream);
 /* Appends `len` host bytes and applies `op`.  `*out` / `*out_len` receive the
@@ -117,6 +119,9 @@ int brotli_amd_stream_create(BrotliAmdCtx* ctx, int quality, int lgwin, uint32_t
    the stream. */
 int brotli_amd_stream_write(BrotliAmdStream* stream, const uint8_t* data, uint64_t len, int op,
                             const uint8_t** out, uint64_t* out_len);
+/* Hands the pending partial byte (s->last_bytes_ / last_bytes_bits_) to the caller and
+   clears it on the device: the caller continues the byte (metadata header). */
+int brotli_amd_stream_take_partial(BrotliAmdStream* stream, uint32_t* nbits, uint32_t* value);
 void brotli_amd_stream_destroy(BrotliAmdStream* stream);
 
 /* ---- quality 1: the two-pass fragment compressor (k_fast.h) -------------------

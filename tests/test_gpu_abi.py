@@ -278,9 +278,10 @@ def test_q1_emit_metadata_equals_reference(amd, stock):
     got, fin = drive(amd, data, ops, Q1)
     want, _ = drive(stock, data, ops, Q1)
     assert fin and got == want
-    # not offered at the qualities whose partial byte lives on the device
+    # not offered in a partition plan (the shards' partial bytes are sealed by the plan's flushes)
     st = amd.BrotliEncoderCreateInstance(None, None, None)
     amd.BrotliEncoderSetParameter(st, 1, 5)
+    amd.BrotliEncoderSetParameter(st, 0x4D490001, 65536)
     n = C.c_size_t(4)
     buf = C.create_string_buffer(b"meta", 4)
     nxt = C.c_void_p(C.addressof(buf))
@@ -288,3 +289,24 @@ def test_q1_emit_metadata_equals_reference(amd, stock):
     no = C.c_void_p(0)
     assert not amd.BrotliEncoderCompressStream(st, 3, C.byref(n), C.byref(nxt), C.byref(ao), C.byref(no), None)
     amd.BrotliEncoderDestroyInstance(st)
+
+
+def test_q5_single_stream_emit_metadata_equals_reference(amd, stock):
+    """EMIT_METADATA on the device-resident quality-5 stream: the pending input is flushed as a
+    meta-block without the padding block (encode.c:1569-1573) and the metadata header continues
+    its last byte; the hash table, ring positions and distance cache carry on afterwards."""
+    from refharness import Ref
+    text = G.enwik_text(460000, seed=47, vocab=20000)
+    meta = bytes(range(256)) * 3
+    for cut in (200000, 5000, 70000):
+        data = text[:cut] + meta + text[cut:300000] + text[300000:]
+        ops = [(cut, 0), (len(meta), 3), (300000 - cut, 1), (0, 3), (len(text) - 300000, 2)]
+        got, fin = drive(amd, data, ops)
+        want, _ = drive(stock, data, ops)
+        assert fin and got == want, cut
+        assert Ref().decompress(got, len(text)) == text
+    data = meta[:7] + text[:100000]
+    ops = [(7, 3), (100000, 2)]
+    got, fin = drive(amd, data, ops)
+    want, _ = drive(stock, data, ops)
+    assert fin and got == want
