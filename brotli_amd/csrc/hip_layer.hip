@@ -30,8 +30,10 @@ struct BrotliAmdCtx {
   uint8_t* d_ws = nullptr;
   uint64_t ws_cap = 0;
   // Hash tables live in their own allocation.
-  uint8_t* d_tables = nullptr;
-  uint64_t tables_cap = 0;
+  // Hash tables live in allocations of their own, at most TABLE_CHUNK bytes each (one
+  // 128 GiB hipMalloc for 4096 quality-9 tables fails where eight 16 GiB ones succeed).
+  std::vector<uint8_t*> d_table_chunks;
+  uint64_t chunk_shards = 0, chunk_shard_bytes = 0;
 
   ShardDesc* d_shards = nullptr;
   ShardState* d_states = nullptr;
@@ -106,21 +108,32 @@ bool ensure_log2(BrotliAmdCtx* c, uint32_t n) {
 // Points every shard at its table (own allocation, 128 B * 2^bucket_bits per
 // shard; cleared by k_init at the start of every job).
 bool prepare_tables(BrotliAmdCtx* c, JobPlan* plan) {
+  const uint64_t TABLE_CHUNK = 16ull << 30;
   const uint64_t tbytes = (uint64_t)plan->J.rec_bytes << plan->J.bucket_bits;
   const uint64_t nbytes = (plan->J.flags & JOB_FLAG_DEEP) ? ((uint64_t)2 << plan->J.bucket_bits) : 0;
+  const uint64_t per = tbytes + nbytes;            // records, then the counters of the same shard
   const uint64_t n = plan->shards.size();
-  const uint64_t need = (tbytes + nbytes) * n;
-  if (need > c->tables_cap) {
-    if (c->d_tables) HIP_OK(c, hipFree(c->d_tables));
-    c->d_tables = nullptr;
-    c->tables_cap = 0;
-    HIP_OK(c, hipMalloc((void**)&c->d_tables, need));
-    c->tables_cap = need;
+  uint64_t per_chunk = TABLE_CHUNK / per;
+  if (per_chunk < 1) per_chunk = 1;
+  if (per_chunk > n) per_chunk = n;
+  const uint64_t nchunks = (n + per_chunk - 1) / per_chunk;
+  const bool fits = c->chunk_shard_bytes == per && c->chunk_shards >= per_chunk &&
+                    c->d_table_chunks.size() >= nchunks;
+  if (!fits) {
+    for (uint8_t* p : c->d_table_chunks) if (p) HIP_OK(c, hipFree(p));
+    c->d_table_chunks.clear();
+    c->chunk_shards = per_chunk;
+    c->chunk_shard_bytes = per;
+    for (uint64_t k = 0; k < nchunks; ++k) {
+      uint8_t* p = nullptr;
+      HIP_OK(c, hipMalloc((void**)&p, per_chunk * per));
+      c->d_table_chunks.push_back(p);
+    }
   }
-  uint8_t* nums = c->d_tables + tbytes * n;   // counters of all shards behind the records
   for (uint64_t k = 0; k < n; ++k) {
-    plan->shards[k].table_off = (uint64_t)(c->d_tables - c->d_ws) + k * tbytes;   // ws + off (mod 2^64)
-    plan->shards[k].num_off = (uint64_t)(nums - c->d_ws) + k * nbytes;
+    uint8_t* base = c->d_table_chunks[k / c->chunk_shards] + (k % c->chunk_shards) * per;
+    plan->shards[k].table_off = (uint64_t)(base - c->d_ws);            // ws + off (mod 2^64)
+    plan->shards[k].num_off = (uint64_t)(base + tbytes - c->d_ws);
   }
   return true;
 }
@@ -310,10 +323,11 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_lut, c->d_dict, c->d_hash_words, c->d_hash_lengths, c->d_log2, c->d_T,
-                  c->d_ws, c->d_tables, c->d_shards, c->d_states, c->d_scan, c->d_counters,
+                  c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters,
                   c->d_stage_in, c->d_stage_out, c->d_ffrags, c->d_fblocks, c->d_fbstate,
                   c->d_ffstate, c->d_fresult};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (uint8_t* p : c->d_table_chunks) if (p) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
