@@ -271,27 +271,9 @@ static int submit_fast(BrotliEncoderState* s, int op) {
 /* Hands everything buffered to the device and applies `op` (1 flush, 2 finish). */
 static int submit(BrotliEncoderState* s, int op) {
   if (s->quality == 1) return submit_fast(s, op);
-  if (s->shard_bytes == 0 && s->quality != 5) {
-    /* The device-resident single-shard stream exists for the 16-slot hashers
-       only; deeper qualities take a single stream as one shard at FINISH. */
-    if (op != OP_FINISH || s->submitted != 0) {
-      if (verbose()) fprintf(stderr, "brotli_amd: FLUSH needs quality 5 or a partition plan\n");
-      return 0;
-    }
-    if (s->in_len == 0) {
-      uint32_t bits, nbits, v;
-      uint8_t b[2];
-      if (s->stream_offset != 0) { b[0] = 3; return out_append(s, b, 1); }
-      window_bits(s->lgwin, &bits, &nbits);
-      v = bits | (3u << nbits);
-      nbits += 2;
-      b[0] = (uint8_t)v;
-      b[1] = (uint8_t)(v >> 8);
-      return out_append(s, b, (nbits + 7) >> 3);
-    }
-  } else if (s->shard_bytes == 0) {
+  if (s->shard_bytes == 0) {
     /* One encoder instance: the persistent device stream reproduces the
-       reference for any op sequence. */
+       reference for any op sequence (qualities 6-9: up to the window size). */
     const uint8_t* out;
     uint64_t out_len;
     if (!s->stream) {
@@ -395,7 +377,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
     uint32_t nbits;
     uint8_t hdr[8];
     size_t hb, i;
-    const int single5 = s->quality == 5 && s->shard_bytes == 0;
+    const int single5 = s->quality >= 5 && s->quality <= 9 && s->shard_bytes == 0;
     if (s->quality != 1 && !single5) {
       if (verbose()) fprintf(stderr, "brotli_amd: BROTLI_OPERATION_EMIT_METADATA needs quality 1 or an "
                                      "unpartitioned quality-5 stream\n");

@@ -621,7 +621,8 @@ bool stream_init(BrotliAmdStream* s, uint32_t stream_offset) {
   D.stream_offset = (uint32_t)so;
   D.cmd_cap = (uint32_t)(mb / 2 + (mb >> J.lgblock) + 64);
   uint64_t off = 0;
-  D.table_off = off; off = plan_align(off + ((uint64_t)REC_BYTES << J.bucket_bits));
+  D.table_off = off; off = plan_align(off + ((uint64_t)J.rec_bytes << J.bucket_bits));
+  D.num_off = off;   off = plan_align(off + ((J.flags & JOB_FLAG_DEEP) ? ((uint64_t)2 << J.bucket_bits) : 0));
   D.cmds_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * sizeof(Command));
   D.lits_off = off;  off = plan_align(off + (mb + 8) * 2);
   D.dsym_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * 2);
@@ -652,6 +653,8 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
   BrotliAmdCtx* c = s->c;
   const JobParams& J = s->J;
   if (s->fed + len >= (3ull << 30)) return fail(c, "stream longer than 3 GiB is not supported");
+  if ((J.flags & JOB_FLAG_DEEP) && s->fed + len > J.max_backward_limit)   // k_parse_deep.h has no ring-wrap rules
+    return fail(c, "quality %d stream longer than the window (%u bytes) is not supported", J.quality, J.max_backward_limit);
   // input: the whole stream stays resident (positions are stream offsets)
   const uint64_t need_in = s->fed + len + BROTLI_AMD_INPUT_SLACK;
   if (need_in > s->in_cap) {
@@ -701,7 +704,10 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
   a.counters = s->d_counters;
   for (;;) {
     HIP_OK(c, hipMemsetAsync(s->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
-    hipLaunchKernelGGL(k_parse, dim3(1), dim3(64), 0, c->stream, a);
+    if (!(J.flags & JOB_FLAG_DEEP)) hipLaunchKernelGGL(k_parse, dim3(1), dim3(64), 0, c->stream, a);
+    else if (J.block_bits <= 6) hipLaunchKernelGGL(k_parse_deep<1>, dim3(1), dim3(64), 0, c->stream, a);
+    else if (J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(1), dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_parse_deep<4>, dim3(1), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_build, dim3(1), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_store, dim3(1), dim3(64), 0, c->stream, a);
     uint32_t counters[16];
@@ -728,11 +734,12 @@ int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t s
   if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   BrotliAmdStream* s = new BrotliAmdStream();
   s->c = c;
-  if (quality != 5 || !plan_params(quality, lgwin, size_hint, &s->J)) {   // k_parse.h: 16-slot buckets only
+  if (!plan_params(quality, lgwin, size_hint, &s->J)) {
     delete s;
     fail(c, "parameters outside the GPU path (quality %d lgwin %d)", quality, lgwin);
     return BROTLI_AMD_UNSUPPORTED;
   }
+  if (quality != 5) s->J.flags |= JOB_FLAG_DEEP;   // k_parse_deep.h; k_parse.h serves the 16-slot hashers
   s->J.log2_lut_size = s->J.max_metablock_size + 2;
   if (!stream_init(s, stream_offset)) { brotli_amd_stream_destroy(s); return BROTLI_AMD_ERROR; }
   *out = s;
