@@ -271,7 +271,11 @@ static int submit_fast(BrotliEncoderState* s, int op) {
 /* Hands everything buffered to the device and applies `op` (1 flush, 2 finish). */
 static int submit(BrotliEncoderState* s, int op) {
   if (s->quality == 1) return submit_fast(s, op);
-  if (s->shard_bytes == 0) {
+  if (s->shard_bytes == 0 && s->quality != 5 && op == OP_FINISH && s->submitted == 0 && !s->stream &&
+      s->in_len != 0) {
+    /* Qualities 6-9, everything in one FINISH: the same bytes come from a one-shard job
+       (falls through to the plan code below with shard size 0 = one shard). */
+  } else if (s->shard_bytes == 0) {
     /* One encoder instance: the persistent device stream reproduces the
        reference for any op sequence (qualities 6-9: up to the window size). */
     const uint8_t* out;

@@ -702,7 +702,8 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
   a.nshards = 1;
   a.init_blocks_per_shard = 1;
   a.counters = s->d_counters;
-  for (;;) {
+  for (uint64_t round = 0;; ++round) {
+    if (round > (s->fed >> 10) + 64) return fail(c, "stream rounds do not converge (device fault)");
     HIP_OK(c, hipMemsetAsync(s->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
     if (!(J.flags & JOB_FLAG_DEEP)) hipLaunchKernelGGL(k_parse, dim3(1), dim3(64), 0, c->stream, a);
     else if (J.block_bits <= 6) hipLaunchKernelGGL(k_parse_deep<1>, dim3(1), dim3(64), 0, c->stream, a);

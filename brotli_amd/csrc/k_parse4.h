@@ -57,6 +57,7 @@ extern unsigned long long g_sim_counts[16];
 #define QBLK_FLUSH 2u
 #define QBLK_STITCH 4u
 #define QBLK_EXTEND 8u
+#define QBLK_NOSEAL 16u     // flushed block without the padding block (final_op 3, see k_round.h)
 enum QState { Q_PRE = 0, Q_SETUP = 1, Q_SEARCH = 2, Q_LAZY = 3, Q_POST = 4, Q_DONE = 5 };
 
 // All fields are identical in the 16 lanes of a group.
@@ -522,12 +523,14 @@ DEV void q_driver_pre(const JobParams& J, QShard& g) {
     }
     if (remaining != 0 && avail == 0 && q_desc(g).final_op == 0) { g.status |= QST_DONE; g.state = Q_DONE; return; }
     bool is_last = avail == 0 && q_desc(g).final_op == 2;
-    bool force_flush = avail == 0 && q_desc(g).final_op == 1;
-    if (!is_last && r.flint == 0) { r.flint = -1; force_flush = true; }
+    bool force_flush = avail == 0 && (q_desc(g).final_op == 1 || q_desc(g).final_op == 3);
+    bool seal = avail == 0 && q_desc(g).final_op == 1;
+    if (!is_last && r.flint == 0) { r.flint = -1; force_flush = true; seal = true; }
     const uint32_t bytes = r.input_pos - r.last_processed_pos;
     const uint32_t pos = r.last_processed_pos;
     if (r.ncmds + bytes / 2u + 2u > q_desc(g).cmd_cap) { g.status |= QST_ERROR; g.state = Q_DONE; return; }
-    g.blk_flags = (is_last ? QBLK_LAST : 0u) | (force_flush ? QBLK_FLUSH : 0u);
+    g.blk_flags = (is_last ? QBLK_LAST : 0u) | (force_flush ? QBLK_FLUSH : 0u) |
+                  (force_flush && !seal ? QBLK_NOSEAL : 0u);
     g.blk_bytes = bytes;
     g.blk_pos = pos;
     g.pos_end = r.input_pos;
@@ -548,6 +551,9 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
     const uint32_t processed = r.input_pos - r.last_flush_pos;
     const bool next_fits = processed + block <= J.max_metablock_size;
     if (!is_last && !force_flush && next_fits && r.nlits < J.max_literals && r.ncmds < J.max_commands) {
+      // (a block without bytes and without an operation to carry out would come back here
+      // forever: an unknown final_op — fail instead of spinning)
+      if (g.blk_bytes == 0 && avail == 0) { g.status |= QST_ERROR | QST_DONE; g.state = Q_DONE; return; }
       r.last_processed_pos = r.input_pos;
       g.state = Q_PRE;
       return;
@@ -561,7 +567,7 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
   }
   if (!is_last && r.input_pos == r.last_flush_pos) {
     r.last_processed_pos = r.input_pos;
-    if (force_flush) q_flush_padding(g, writer);
+    if (force_flush && !(g.blk_flags & QBLK_NOSEAL)) q_flush_padding(g, writer);
     if (avail == 0) { g.status |= QST_DONE; g.state = Q_DONE; } else g.state = Q_PRE;
     return;
   }
@@ -606,7 +612,7 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
     r.ncmds = 0;
     r.nlits = 0;
     for (int i = 0; i < 4; ++i) r.saved_dc[i] = g.dc[i];
-    if (force_flush) q_flush_padding(g, writer);
+    if (force_flush && !(g.blk_flags & QBLK_NOSEAL)) q_flush_padding(g, writer);
     if (is_last || avail == 0) { g.status |= QST_DONE; g.state = Q_DONE; } else g.state = Q_PRE;
     return;
   }
@@ -914,7 +920,7 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
       S->mb_start = g.r.last_flush_pos;
       S->mb_bytes = g.r.input_pos - g.r.last_flush_pos;
       S->mb_is_last = (g.blk_flags & QBLK_LAST) ? 1u : 0u;
-      S->mb_force_flush = (g.blk_flags & QBLK_FLUSH) ? 1u : 0u;
+      S->mb_force_flush = (g.blk_flags & QBLK_FLUSH) ? ((g.blk_flags & QBLK_NOSEAL) ? 2u : 1u) : 0u;
       S->mb_raw = 0;
     }
     S->stat_searches += g.stat_searches;

@@ -478,7 +478,7 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
       S->mb_start = g.r.last_flush_pos;
       S->mb_bytes = g.r.input_pos - g.r.last_flush_pos;
       S->mb_is_last = (g.blk_flags & QBLK_LAST) ? 1u : 0u;
-      S->mb_force_flush = (g.blk_flags & QBLK_FLUSH) ? 1u : 0u;
+      S->mb_force_flush = (g.blk_flags & QBLK_FLUSH) ? ((g.blk_flags & QBLK_NOSEAL) ? 2u : 1u) : 0u;
       S->mb_raw = 0;
     }
     S->stat_searches += g.stat_searches;

@@ -186,6 +186,7 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
       const bool next_fits = processed + block <= J.max_metablock_size;
       if (!is_last && !force_flush && next_fits && r.nlits < J.max_literals &&
           r.ncmds < J.max_commands) {
+        if (bytes == 0 && avail == 0) { S->error = 2; return; }   // unknown final_op: fail, do not spin
         r.last_processed_pos = r.input_pos;
         continue;
       }

@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "timeout: per-test limit (pytest-timeout; ignored when the plugin is absent)")
     # Build the test-only checkers if they are missing (seconds).
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=False)

@@ -88,7 +88,7 @@ class Ref:
         L.BrotliEncoderDestroyInstance(st)
         return out.raw[:total.value]
 
-    def encode_calls(self, data, quality, lgwin, calls):
+    def encode_calls(self, data, quality, lgwin, calls, size_hint=0):
         """One instance driven with an explicit call sequence [(nbytes, op), ...];
         every call is repeated until its input is consumed and the output drained
         (what the CLI / bindings do)."""
@@ -96,6 +96,8 @@ class Ref:
         st = L.BrotliEncoderCreateInstance(None, None, None)
         assert L.BrotliEncoderSetParameter(st, PARAM_QUALITY, quality)
         assert L.BrotliEncoderSetParameter(st, PARAM_LGWIN, lgwin)
+        if size_hint:
+            assert L.BrotliEncoderSetParameter(st, PARAM_SIZE_HINT, size_hint)
         cap = 2 * len(data) + 1024 + 64 * len(calls)
         out = C.create_string_buffer(cap)
         inbuf = C.create_string_buffer(bytes(data), max(len(data), 1))
@@ -115,7 +117,9 @@ class Ref:
                 if avail_in.value == 0 and not L.BrotliEncoderHasMoreOutput(st):
                     break
         L.BrotliEncoderDestroyInstance(st)
-        return out.raw[:total.value]
+        # (metadata payloads are copied to next_out without being counted in total_out,
+        # encode.c:1590-1600: measure what actually left)
+        return out.raw[:cap - avail_out.value]
 
     def encode_plan(self, data, quality, lgwin, shard_size):
         n = len(data)

@@ -34,10 +34,26 @@ class Sim:
         self.L.sim_encode_fast.argtypes = [
             C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.POINTER(C.c_uint64), C.c_size_t,
             C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+        self.L.sim_stream.restype = C.c_long
+        self.L.sim_stream.argtypes = [
+            C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
+            C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
         self.L.sim_encode.restype = C.c_long
         self.L.sim_encode.argtypes = [
             C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
             C.c_size_t, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+
+    def stream(self, data, calls, quality=5, lgwin=22, size_hint=0, stream_offset=0, reverse=0):
+        """One encoder instance driven call by call on the simulator (k_parse / k_parse_deep +
+        k_build + k_store); `calls` = [(nbytes, op)], op 3 = EMIT_METADATA."""
+        sizes = (C.c_uint64 * len(calls))(*[c[0] for c in calls])
+        ops = (C.c_uint8 * len(calls))(*[c[1] for c in calls])
+        cap = 2 * len(data) + 4096 + 64 * len(calls)
+        out = C.create_string_buffer(cap)
+        n = self.L.sim_stream(TABLES.encode(), bytes(data), len(data), quality, lgwin, size_hint,
+                              stream_offset, sizes, ops, len(calls), reverse, out, cap)
+        assert n >= 0, n
+        return out.raw[:n]
 
     def encode_fast(self, data, lgwin=22, calls=None, reverse=0):
         """Quality 1 through the k_fast_* kernels; `calls` = [(nbytes, op), ...] ending

@@ -219,4 +219,113 @@ long sim_encode_fast(const char* tables_path, const uint8_t* in, size_t len, int
   return (long)result[0];
 }
 
+// One encoder instance fed call by call (the HIP layer's BrotliAmdStream, hip_layer.hip
+// stream_init / stream_run, restated for the simulator): qualities 5 (k_parse) and 6-9
+// (k_parse_deep).  Call k hands call_sizes[k] bytes of `in` with operation call_ops[k]
+// (0 PROCESS, 1 FLUSH, 2 FINISH, 3 EMIT_METADATA: those bytes are the metadata payload and
+// the header continues the stream's open byte, as encode_abi.c does).  Returns the number
+// of output bytes, negative on error (-5: the rounds did not converge).
+long sim_stream(const char* tables_path, const uint8_t* in, size_t len, int quality, int lgwin,
+                uint32_t size_hint, uint32_t stream_offset, const uint64_t* call_sizes,
+                const uint8_t* call_ops, size_t ncalls, int reverse, uint8_t* out, size_t out_cap) {
+  HostTables ht;
+  if (!host_tables_load(tables_path, &ht)) return -1;
+  JobParams J;
+  if (!plan_params(quality, lgwin, size_hint, &J)) return -2;
+  if (quality != 5) J.flags |= JOB_FLAG_DEEP;
+  const uint64_t mb = J.max_metablock_size;
+  J.log2_lut_size = (uint32_t)(mb + 2);
+  ShardDesc D;
+  memset(&D, 0, sizeof(D));
+  uint64_t so = stream_offset;
+  if (so > J.max_backward_limit) so = J.max_backward_limit;
+  D.stream_offset = (uint32_t)so;
+  D.cmd_cap = (uint32_t)(mb / 2 + (mb >> J.lgblock) + 64);
+  uint64_t off = 0;
+  D.table_off = off; off = plan_align(off + ((uint64_t)J.rec_bytes << J.bucket_bits));
+  D.num_off = off;   off = plan_align(off + ((J.flags & JOB_FLAG_DEEP) ? ((uint64_t)2 << J.bucket_bits) : 0));
+  D.cmds_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * sizeof(Command));
+  D.lits_off = off;  off = plan_align(off + (mb + 8) * 2);
+  D.dsym_off = off;  off = plan_align(off + (uint64_t)D.cmd_cap * 2);
+  D.mb_off = off;    off = plan_align(off + mb_work_bytes(mb));
+  D.scratch_off = off; off = plan_align(off + (mb / 256 + 64) * 8 + (2 * mb + 64) * 4);
+  D.out_off = off;
+  D.out_cap = 2 * (len + mb + (2ull << J.lgblock)) + 8192;
+  off = plan_align(off + D.out_cap);
+  std::vector<uint8_t> ws(off, 0xCD);
+  std::vector<uint8_t> input(len + 64, 0);
+  ShardState state;
+  std::vector<double> log2lut;
+  DeviceTables T;
+  host_tables_fill(ht, J.log2_lut_size, &log2lut, &T);
+  uint32_t counters[16] = {0};
+  JobArgs a;
+  a.J = J;
+  a.shards = &D;
+  a.states = &state;
+  a.T = &T;
+  a.input = input.data();
+  a.ws = ws.data();
+  a.nshards = 1;
+  a.init_blocks_per_shard = 64;
+  a.counters = counters;
+  run(k_init, a, 64, 256, 0);
+  size_t n_out = 0, pos = 0;
+  uint64_t fed = 0;
+  for (size_t k = 0; k < ncalls; ++k) {
+    const uint64_t n = call_sizes[k];
+    const int op = call_ops[k];
+    if (pos + n > len) return -2;
+    if (op != 3) { memcpy(input.data() + fed, in + pos, n); fed += n; }
+    if ((J.flags & JOB_FLAG_DEEP) && fed > J.max_backward_limit) return -6;
+    D.len = (uint32_t)fed;
+    D.final_op = (uint32_t)op;
+    state.done = 0;
+    state.out_bytes = 0;
+    int round = 0;
+    for (;; ++round) {
+      if (round > 4096) return -5;
+      memset(counters, 0, sizeof(counters));
+      if (!(J.flags & JOB_FLAG_DEEP)) run(k_parse, a, 1, 64, reverse);
+      else if (J.block_bits <= 6) run(k_parse_deep<1>, a, 1, 64, reverse);
+      else if (J.block_bits == 7) run(k_parse_deep<2>, a, 1, 64, reverse);
+      else run(k_parse_deep<4>, a, 1, 64, reverse);
+      run(k_build, a, 1, 64, reverse);
+      run(k_store, a, 1, 64, reverse);
+      if (counters[1]) return -3;
+      if (counters[0] == 0) break;
+    }
+    if (n_out + state.out_bytes > out_cap) return -4;
+    memcpy(out + n_out, ws.data() + D.out_off, state.out_bytes);
+    n_out += state.out_bytes;
+    if (op == 3) {
+      // WriteMetadataHeader (encode.c:1223-1249) over the open byte, then the payload
+      uint64_t bits = state.last_bytes;
+      uint32_t nbits = state.last_bytes_bits;
+      state.last_bytes = 0;
+      state.last_bytes_bits = 0;
+      bits |= (uint64_t)0x6u << nbits;
+      nbits += 4;
+      if (n == 0) {
+        nbits += 2;
+      } else {
+        uint32_t lb = 1;
+        if (n > 1) { uint32_t v = (uint32_t)n - 1; lb = 0; while (v) { ++lb; v >>= 1; } }
+        const uint32_t nbytes = (lb + 7) / 8;
+        bits |= (uint64_t)nbytes << nbits;
+        nbits += 2;
+        bits |= (uint64_t)(n - 1) << nbits;
+        nbits += 8 * nbytes;
+      }
+      const size_t hb = (nbits + 7) >> 3;
+      if (n_out + hb + n > out_cap) return -4;
+      for (size_t i = 0; i < hb; ++i) out[n_out++] = (uint8_t)(bits >> (8 * i));
+      memcpy(out + n_out, in + pos, n);
+      n_out += n;
+    }
+    pos += n;
+  }
+  return (long)n_out;
+}
+
 }  // extern "C"

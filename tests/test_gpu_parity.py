@@ -11,7 +11,9 @@ import pytest
 
 import gen_inputs as G
 
-pytestmark = pytest.mark.gpu
+# a kernel that never returns must not take the whole GPU tier with it: pytest-timeout's
+# thread method ends the run (a blocked HIP call cannot be interrupted by a signal)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread")]
 HERE = os.path.dirname(os.path.abspath(__file__))
 ALICE = open(os.path.join(HERE, "golden", "alice29.txt"), "rb").read()
 

@@ -11,7 +11,9 @@ import gen_inputs as G
 from test_gpu_abi import _bind, drive, _chunks, ROOT, ALICE
 import os
 
-pytestmark = pytest.mark.gpu
+# a kernel that never returns must not take the whole GPU tier with it: pytest-timeout's
+# thread method ends the run (a blocked HIP call cannot be interrupted by a signal)
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread")]
 
 
 @pytest.fixture(scope="module")

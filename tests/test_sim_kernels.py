@@ -264,3 +264,44 @@ def test_fuzz_small_inputs_all_kernels(sim, oracle, seed):
         assert sim.encode(data, quality=q, lgwin=22, shard_size=shard) == oracle.encode_plan(data, q, 22, shard), (seed, q)
         lgwin = int(rng.choice([10, 12, 16, 18, 22]))
         assert sim.encode_fast(data, lgwin, None, rev) == oracle.encode_fast(data, lgwin), (seed, lgwin)
+
+
+# --- one encoder instance fed call by call (the HIP layer's device-resident stream) -----------------
+
+def _stream_chunks(n, size, flush_every=0):
+    ops, off, i = [], 0, 0
+    while off < n:
+        m = min(size, n - off)
+        off += m
+        i += 1
+        ops.append((m, 2 if off == n else (1 if flush_every and i % flush_every == 0 else 0)))
+    return ops
+
+
+@pytest.mark.parametrize("quality,lgwin", [(5, 22), (6, 22), (9, 24)])
+def test_stream_call_sequences_equal_reference(sim, ref, quality, lgwin):
+    """k_parse (quality 5) / k_parse_deep (6-9) resumed call after call with the state the
+    previous call left: PROCESS feeds, FLUSHes, FINISH; metadata blocks continue the open byte
+    (final_op 3: flush without the padding block).  Checked against the reference library."""
+    text = G.enwik_text(150000, seed=53, vocab=20000)
+    meta = b"\x01\x02\x03" * 50
+    hint = 1 << 20
+    for data, calls in (
+            (text, _stream_chunks(len(text), 40000, 2)),
+            (text[:60000] + meta + text[60000:150000], [(60000, 0), (len(meta), 3), (90000, 2)]),
+            (text[:90000], [(30000, 1), (0, 3), (60000, 2)])):
+        want = ref.encode_calls(data, quality, lgwin, calls, size_hint=hint)
+        assert sim.stream(data, calls, quality, lgwin, size_hint=hint) == want, (quality, calls)
+
+
+def test_stream_unknown_operation_fails_instead_of_spinning(sim):
+    """A final_op the driver does not know must end in an error, not in an endless block loop
+    (the guard in q_driver_post / parse_round)."""
+    import ctypes as C
+    from simharness import TABLES
+    data = G.enwik_text(5000, seed=3, vocab=500)
+    for quality in (5, 9):
+        sizes = (C.c_uint64 * 1)(len(data))
+        ops = (C.c_uint8 * 1)(7)
+        out = C.create_string_buffer(20000)
+        assert sim.L.sim_stream(TABLES.encode(), data, len(data), quality, 22, 1 << 20, 0, sizes, ops, 1, 0, out, 20000) == -3
