@@ -458,7 +458,9 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
     /* UpdateSizeHint at the reference's first EncodeData (encode.c:1619-1632):
        when the first input block fills, or at the first op other than PROCESS. */
     if (!s->hint_fixed) {
-      const uint64_t threshold = s->stream_offset ? 2u : 65536u;   /* flint, lgblock 16 */
+      /* flint, or the input block size: lgblock 16, at quality 9 min(18, lgwin) (quality.h:75-93) */
+      const uint64_t threshold = s->stream_offset ? 2u :
+          (s->quality >= 9 && s->lgwin > 16) ? ((uint64_t)1 << (s->lgwin < 18 ? s->lgwin : 18)) : 65536u;
       const uint64_t seen = s->total_in + a;
       if (seen >= threshold || op != OP_PROCESS) {
         s->eff_hint = seen >= (1u << 30) ? (1u << 30) : (uint32_t)seen;
