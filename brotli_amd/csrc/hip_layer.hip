@@ -168,37 +168,10 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
     fail(c, "parameters outside the GPU path (quality %d lgwin %d)", p->quality, p->lgwin);
     return BROTLI_AMD_UNSUPPORTED;
   }
-  if (p->flags & BROTLI_AMD_FLAG_NO_PAIR) plan->J.flags |= JOB_FLAG_NO_PAIR;
-  if (p->flags & BROTLI_AMD_FLAG_FORCE_SLOW) plan->J.flags |= JOB_FLAG_FORCE_SLOW;
-  if (p->flags & BROTLI_AMD_FLAG_NO_HEADER) plan->J.flags |= JOB_FLAG_NO_HEADER;
-  // Four shards per wave (k_parse4.h) whenever no shard can wrap the ring or
-  // see a candidate beyond the window.
-  uint64_t longest = 0;
-  for (const ShardDesc& D : plan->shards) if (D.len > longest) longest = D.len;
-  if (plan->J.quality == 5) {
-    if (!(p->flags & BROTLI_AMD_FLAG_NO_QUAD) && longest <= plan->J.max_backward_limit) {
-      plan->J.flags |= JOB_FLAG_QUAD;
-      // Shards per wave: the kernel holds <= 128 VGPRs, i.e. 16 waves per CU stay resident.
-      // While every shard can have a wave (or half of one) to itself, lock-stepping four
-      // shards only makes each wait for the others' phases (measured, profiles/r01_k_*:
-      // 4096 shards of 256 KiB: 315 / 288 / 280 ms with 4 / 2 / 1 shards per wave).
-      const uint64_t resident = (uint64_t)c->num_cus * 16u;
-      int v = plan->shards.size() <= resident ? 1 : plan->shards.size() <= 2 * resident ? 2 : 4;
-      if (const char* e = getenv("BROTLI_AMD_QGROUPS")) v = atoi(e);   // experiment knob
-      if (v == 1 || v == 2) {
-        plan->J.flags |= (uint32_t)v << JOB_FLAG_GROUPS_SHIFT;
-        // the lanes a shard does not need for itself search one position ahead (k_parse4.h)
-        const char* d = getenv("BROTLI_AMD_DUO");
-        if (!d || atoi(d) != 0) plan->J.flags |= JOB_FLAG_DUO;
-      }
-    }
-  } else {
-    // deep-bucket qualities: shards must fit the window (no ring-wrap rules in k_parse_deep.h)
-    if (longest > plan->J.max_backward_limit) {
-      fail(c, "quality %d needs shards of at most %u bytes", plan->J.quality, plan->J.max_backward_limit);
-      return BROTLI_AMD_UNSUPPORTED;
-    }
-    plan->J.flags |= JOB_FLAG_DEEP;
+  uint32_t too_long = 0;
+  if (!plan_choose_kernels(plan, p->flags, c->num_cus, &too_long)) {
+    fail(c, "quality %d needs shards of at most %u bytes", plan->J.quality, too_long);
+    return BROTLI_AMD_UNSUPPORTED;
   }
   return BROTLI_AMD_OK;
 }

@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -108,6 +109,45 @@ static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_
   plan->ws_bytes = off;
   plan->in_bytes = len;
   plan->max_out_bytes = max_out;
+  return true;
+}
+
+// Which parse kernel a plan runs on and in which wave layout (api_flags: BROTLI_AMD_FLAG_*
+// of include/brotli_amd_hip.h: 1 NO_PAIR, 2 NO_QUAD, 4 FORCE_SLOW, 8 NO_HEADER).  Returns
+// false when a shard is too long for the kernel its quality needs (*limit = the bound).
+static inline bool plan_choose_kernels(JobPlan* plan, uint32_t api_flags, int num_cus, uint32_t* limit) {
+  if (api_flags & 1u) plan->J.flags |= JOB_FLAG_NO_PAIR;
+  if (api_flags & 4u) plan->J.flags |= JOB_FLAG_FORCE_SLOW;
+  if (api_flags & 8u) plan->J.flags |= JOB_FLAG_NO_HEADER;
+  // Four shards per wave (k_parse4.h) whenever no shard can wrap the ring or
+  // see a candidate beyond the window.
+  uint64_t longest = 0;
+  for (const ShardDesc& D : plan->shards) if (D.len > longest) longest = D.len;
+  if (plan->J.quality == 5) {
+    if (!(api_flags & 2u) && longest <= plan->J.max_backward_limit) {
+      plan->J.flags |= JOB_FLAG_QUAD;
+      // Shards per wave: the kernel holds <= 128 VGPRs, i.e. 16 waves per CU stay resident.
+      // While every shard can have a wave (or half of one) to itself, lock-stepping four
+      // shards only makes each wait for the others' phases (measured, profiles/r01_k_*:
+      // 4096 shards of 256 KiB: 315 / 288 / 280 ms with 4 / 2 / 1 shards per wave).
+      const uint64_t resident = (uint64_t)num_cus * 16u;
+      int v = plan->shards.size() <= resident ? 1 : plan->shards.size() <= 2 * resident ? 2 : 4;
+      if (const char* e = getenv("BROTLI_AMD_QGROUPS")) v = atoi(e);   // experiment knob
+      if (v == 1 || v == 2) {
+        plan->J.flags |= (uint32_t)v << JOB_FLAG_GROUPS_SHIFT;
+        // the lanes a shard does not need for itself search one position ahead (k_parse4.h)
+        const char* d = getenv("BROTLI_AMD_DUO");
+        if (!d || atoi(d) != 0) plan->J.flags |= JOB_FLAG_DUO;
+      }
+    }
+  } else {
+    // deep-bucket qualities: shards must fit the window (no ring-wrap rules in k_parse_deep.h)
+    if (longest > plan->J.max_backward_limit) {
+      *limit = plan->J.max_backward_limit;
+      return false;
+    }
+    plan->J.flags |= JOB_FLAG_DEEP;
+  }
   return true;
 }
 

@@ -1,0 +1,144 @@
+"""The drop-in boundary WITHOUT a GPU: brotli_amd/csrc/encode_abi.c built over the host SIMT
+simulator (tests/simt/sim_hip_layer.cc -> libbrotlienc_sim.so, test only) and driven with the
+reference's call sequences next to the reference library.  The kernels are the shipped
+headers; what this adds over tests/test_sim_kernels.py is the host side of the boundary:
+parameter latching, size-hint emulation, call lists and the pending partial byte at
+quality 1, flush / metadata hand-off, routing to plan / stream jobs."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import pytest
+
+import gen_inputs as G
+from refharness import ROOT, TABLES
+from test_gpu_abi import ALICE, ALICE_SHA, Q1, _bind, _chunks, drive
+
+SIM_ABI = os.path.join(ROOT, "tests", "simt", "libbrotlienc_sim.so")
+
+
+@pytest.fixture(scope="module")
+def simabi():
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "simt")], check=True)
+    os.environ["BROTLI_AMD_TABLES"] = TABLES
+    return _bind(SIM_ABI)
+
+
+@pytest.fixture(scope="module")
+def stock(ref):
+    return _bind(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
+
+
+TEXT = G.enwik_text(120000, seed=61, vocab=8000)
+
+
+def test_one_shot_alice_known_answer(simabi):
+    cap = simabi.BrotliEncoderMaxCompressedSize(len(ALICE))
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t(cap)
+    assert simabi.BrotliEncoderCompress(5, 22, 0, len(ALICE), ALICE, C.byref(n), out)
+    assert hashlib.sha256(out.raw[:n.value]).hexdigest() == ALICE_SHA
+    n = C.c_size_t(16)
+    assert simabi.BrotliEncoderCompress(5, 22, 0, 0, b"", C.byref(n), out) and out.raw[:n.value] == b"\x06"
+    n = C.c_size_t(1 << 20)
+    assert not simabi.BrotliEncoderCompress(11, 22, 0, len(ALICE), ALICE, C.byref(n), out) and n.value == 0
+
+
+@pytest.mark.parametrize("quality,lgwin", [(5, 22), (6, 22), (9, 24)])
+def test_single_stream_sequences_and_metadata(simabi, stock, quality, lgwin):
+    """One encoder instance: PROCESS / FLUSH / FINISH in assorted shapes, TakeOutput, metadata
+    blocks, size hint derived from the calls (no BROTLI_PARAM_SIZE_HINT)."""
+    params = ((1, quality), (2, lgwin))
+    data = TEXT[:90000]
+    for ops, take in ((_chunks(len(data), 2048, 2, 16), False), (_chunks(len(data), 30000, 2, 1), True),
+                      ([(0, 1)] + _chunks(len(data), 50000, 2), False), ([(len(data), 1), (0, 2)], False)):
+        want, fin_w = drive(stock, data, ops, params, take=take)
+        got, fin_g = drive(simabi, data, ops, params, take=take)
+        assert fin_w and fin_g and got == want, (quality, ops[:3])
+    meta = bytes(range(200))
+    d2 = data[:30000] + meta + data[30000:70000] + meta[:1] + data[70000:]
+    ops = [(30000, 0), (len(meta), 3), (40000, 1), (0, 3), (1, 3), (20000, 2)]
+    want, _ = drive(stock, d2, ops, params, out_chunk=4096)
+    got, fin = drive(simabi, d2, ops, params, out_chunk=4096)
+    assert fin and got == want
+    # one-shot wrapper (quality 6-9: a one-shard job instead of the stream)
+    outs = []
+    for L in (simabi, stock):
+        cap = L.BrotliEncoderMaxCompressedSize(len(data))
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t(cap)
+        assert L.BrotliEncoderCompress(quality, lgwin, 0, len(data), data, C.byref(n), out)
+        outs.append(out.raw[:n.value])
+    assert outs[0] == outs[1]
+
+
+def test_stream_offset_and_plan_parameters(simabi, stock, oracle):
+    data = ALICE[:100000]
+    ops = [(len(data), 1)]
+    want, _ = drive(stock, data, ops, params=((5, 300000), (9, 200000)))
+    got, _ = drive(simabi, data, ops, params=((5, 300000), (9, 200000)))
+    assert got == want
+    got, fin = drive(simabi, TEXT, [(len(TEXT), 2)], params=((5, len(TEXT)), (0x4D490001, 1 << 15)))
+    assert fin and got == oracle.encode_plan(TEXT, 5, 22, 1 << 15)
+    # a FLUSH ends the current shards, the next input starts new ones at its stream offset
+    ops = [(50000, 1), (70000, 2)]
+    got, fin = drive(simabi, TEXT, ops, params=((5, len(TEXT)), (0x4D490001, 1 << 15)))
+    parts, off = [], 0
+    for n_call, op in ops:
+        o2 = 0
+        while o2 < n_call:
+            m = min(1 << 15, n_call - o2)
+            parts.append(oracle.encode_shard(TEXT[off + o2:off + o2 + m], 5, 22, len(TEXT), off + o2,
+                                             op == 2 and o2 + m == n_call))
+            o2 += m
+        off += n_call
+    assert fin and got == b"".join(parts)
+
+
+def test_quality_1_call_patterns_and_metadata(simabi, stock):
+    data = TEXT + G.random_bytes(150000, seed=4) + TEXT[:80000]
+    for ops, take in ((_chunks(len(data), 1 << 17, 2), False), (_chunks(len(data), 65536, 2, 3), False),
+                      (_chunks(len(data), 100000, 2), True), ([(80000, 0)] * 4 + [(0, 2)], False),
+                      ([(0, 2)], False), ([(0, 1), (5, 1), (0, 1), (0, 2)], False)):
+        d = data[:sum(n for n, _ in ops)]
+        want, _ = drive(stock, d, ops, Q1, take=take)
+        got, fin = drive(simabi, d, ops, Q1, take=take)
+        assert fin and got == want, ops[:3]
+    meta = b"metadata payload \x00\x01\x02" * 11
+    d2 = data[:120000] + meta + data[120000:200000] + meta[:1] + data[200000:260000]
+    ops = [(120000, 0), (len(meta), 3), (80000, 1), (0, 3), (1, 3), (60000, 2)]
+    want, _ = drive(stock, d2, ops, Q1, out_chunk=8192)
+    got, fin = drive(simabi, d2, ops, Q1, out_chunk=8192)
+    assert fin and got == want
+    for lgwin in (16, 22):
+        outs = []
+        for L in (simabi, stock):
+            cap = L.BrotliEncoderMaxCompressedSize(len(data))
+            out = C.create_string_buffer(cap)
+            n = C.c_size_t(cap)
+            assert L.BrotliEncoderCompress(1, lgwin, 0, len(data), data, C.byref(n), out)
+            outs.append(out.raw[:n.value])
+        assert outs[0] == outs[1]
+
+
+def test_boundary_error_behaviour(simabi):
+    st = simabi.BrotliEncoderCreateInstance(None, None, None)
+    assert simabi.BrotliEncoderSetParameter(st, 1, 9) and simabi.BrotliEncoderSetParameter(st, 2, 20)
+    data = G.enwik_text((1 << 20) + 4096, seed=59, vocab=20000)     # past the quality-9 stream's window
+    buf = C.create_string_buffer(data, len(data))
+    n = C.c_size_t(len(data))
+    nxt = C.c_void_p(C.addressof(buf))
+    ao = C.c_size_t(0)
+    no = C.c_void_p(0)
+    assert not simabi.BrotliEncoderCompressStream(st, 2, C.byref(n), C.byref(nxt), C.byref(ao), C.byref(no), None)
+    assert not simabi.BrotliEncoderSetParameter(st, 1, 5)           # parameters are latched (encode.c:63)
+    simabi.BrotliEncoderDestroyInstance(st)
+    st = simabi.BrotliEncoderCreateInstance(None, None, None)
+    simabi.BrotliEncoderSetParameter(st, 1, 5)
+    simabi.BrotliEncoderSetParameter(st, 0x4D490001, 65536)
+    n = C.c_size_t(4)
+    b4 = C.create_string_buffer(b"meta", 4)
+    nxt = C.c_void_p(C.addressof(b4))
+    assert not simabi.BrotliEncoderCompressStream(st, 3, C.byref(n), C.byref(nxt), C.byref(ao), C.byref(no), None)
+    simabi.BrotliEncoderDestroyInstance(st)
