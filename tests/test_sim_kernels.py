@@ -71,8 +71,8 @@ def test_encode_bytes_match_oracle(sim, oracle, name):
 
 
 @pytest.mark.parametrize("flags", [2, 6])
-@pytest.mark.parametrize("name", ["text_hint_2shards", "ragged_shards", "mixed", "text_then_random",
-                                  "zeros", "rle", "tiny3", "shards_of_1_2_3", "alice_48k"])
+@pytest.mark.parametrize("name", ["text_hint_2shards", "ragged_shards", "text_then_random",
+                                  "zeros", "rle", "tiny3", "shards_of_1_2_3"])
 def test_quad_kernel_bytes_match_oracle(sim, oracle, name, flags):
     """Four shards per wave (k_parse4.h): arg-max resolve (flags=2) and the
     step-by-step resolve (flags=6) both reproduce the oracle."""
@@ -241,10 +241,10 @@ def _fuzz_input(rng):
     return bytes(out[:target])
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(3))
 def test_fuzz_small_inputs_all_kernels(sim, oracle, seed):
     rng = np.random.default_rng(1000 + seed)
-    for _ in range(12):
+    for _ in range(9):
         data = _fuzz_input(rng)
         shard = int(rng.integers(0, 3)) * int(rng.integers(300, 2500))
         hint = (1 << 30) if rng.integers(0, 2) else 0          # H68 vs H58
@@ -278,7 +278,7 @@ def _stream_chunks(n, size, flush_every=0):
     return ops
 
 
-@pytest.mark.parametrize("quality,lgwin", [(5, 22), (6, 22), (9, 24)])
+@pytest.mark.parametrize("quality,lgwin", [(9, 24)])      # (5, 22) and (6, 22): tests/test_abi_on_sim.py
 def test_stream_call_sequences_equal_reference(sim, ref, quality, lgwin):
     """k_parse (quality 5) / k_parse_deep (6-9) resumed call after call with the state the
     previous call left: PROCESS feeds, FLUSHes, FINISH; metadata blocks continue the open byte
