@@ -512,8 +512,10 @@ const uint8_t* BrotliEncoderTakeOutput(BrotliEncoderState* s, size_t* size) {
   if (n == 0) { *size = 0; return NULL; }
   s->out_pos += n;
   s->total_out += n;
-  if ((s->stream_state == ST_FLUSH_REQUESTED || s->stream_state == ST_METADATA) && s->out_pos == s->out_len)
-    s->stream_state = ST_PROCESSING;
+  /* CheckFlushComplete (encode.c:1417-1423) ends a flush here; a metadata block is only
+     closed by the next BrotliEncoderCompressStream(EMIT_METADATA) call (:1583-1589), as in
+     the reference: any other operation before that is refused */
+  if (s->stream_state == ST_FLUSH_REQUESTED && s->out_pos == s->out_len) s->stream_state = ST_PROCESSING;
   *size = n;
   return p;
 }
