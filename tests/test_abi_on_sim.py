@@ -142,3 +142,33 @@ def test_boundary_error_behaviour(simabi):
     nxt = C.c_void_p(C.addressof(b4))
     assert not simabi.BrotliEncoderCompressStream(st, 3, C.byref(n), C.byref(nxt), C.byref(ao), C.byref(no), None)
     simabi.BrotliEncoderDestroyInstance(st)
+
+
+def test_python_mirror_over_the_sim_library(simabi, stock, monkeypatch):
+    """brotli_amd.brotli (the mirror of python/brotli.py) bound to the simulator-backed library:
+    compress(), Compressor.process / flush / finish at qualities 1, 5 and 9, its errors."""
+    import brotli_amd.brotli as b
+    monkeypatch.setattr(b, "_LIB_PATH", SIM_ABI)
+    monkeypatch.setattr(b, "_lib", None)
+    data = TEXT[:60000]
+    for quality in (1, 5, 9):
+        got = b.compress(data, quality=quality, lgwin=22)
+        want, _ = drive(stock, data, [(len(data), 0), (0, 2)], ((1, quality), (2, 22)))      # process(string) + finish()
+        assert got == want, quality
+        c = b.Compressor(quality=quality, lgwin=22)
+        out, ops = b"", []
+        for i in range(0, len(data), 16384):
+            out += c.process(data[i:i + 16384])
+            ops.append((len(data[i:i + 16384]), 0))
+            if (i // 16384) % 2:
+                out += c.flush()
+                ops.append((0, 1))
+        out += c.finish()
+        ops.append((0, 2))
+        want, _ = drive(stock, data, ops, ((1, quality), (2, 22)))
+        assert out == want, quality
+        with pytest.raises(b.error):
+            c.process(b"more")
+    with pytest.raises(b.error):
+        b.compress(data, quality=11)          # outside the GPU path: fails loudly
+    monkeypatch.setattr(b, "_lib", None)
