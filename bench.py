@@ -38,19 +38,50 @@ ALGO_BYTES_PER_INPUT_BYTE = {5: 48.0, 6: 48.0, 7: 481.0, 8: 481.0, 9: 481.0}
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
-def cpu_baseline(data, quality, lgwin, shard_size, size_hint):
-    """The reference encoder (oracle/_ref/libbrotli_ref.so) driven with the SAME
-    partition plan by oracle/_ref/plan_bench (C, one POSIX thread per physical
-    core, one encoder instance per shard).  Falls back to the Python thread
-    pool over the oracle when the prebuilt reference is absent."""
+def host_cpu_info():
+    """CPU model, socket count and one logical CPU per physical core of socket 0 (BASELINE.md
+    section 3.3: the baseline runs pinned to the physical cores of ONE socket)."""
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    allowed = sorted(os.sched_getaffinity(0))
+    pk, seen, first_socket = {}, set(), []
+    for c in allowed:
+        base = "/sys/devices/system/cpu/cpu%d/topology/" % c
+        try:
+            p = int(open(base + "physical_package_id").read())
+            core = int(open(base + "core_id").read())
+        except (OSError, ValueError):
+            p, core = 0, c
+        pk.setdefault(p, 0)
+        pk[p] += 1
+        if (p, core) not in seen:
+            seen.add((p, core))
+            if p == min(pk):
+                first_socket.append(c)
+    s0 = min(pk) if pk else 0
+    first_socket = [c for c in first_socket]   # logical CPUs, one per physical core of socket s0
+    return {"model": model, "sockets": max(1, len(pk)), "logical_cpus": len(allowed),
+            "socket0_physical_cores": len(first_socket), "socket": s0}, first_socket
+
+
+def cpu_baseline(data, quality, lgwin, shard_size, size_hint, reps=5):
+    """The reference encoder (oracle/_ref/libbrotli_ref.so, built from /root/reference by
+    oracle/Makefile) driven by oracle/_ref/plan_bench (C, one pinned POSIX thread per physical
+    core of socket 0, one encoder instance per shard): (B2) the SAME partition plan as the GPU
+    run, median of `reps`, with the sha256 of the concatenated output; (B2') the reference at a
+    plan that suits the CPU (8 MiB shards); (B1) one instance on one core (what c/enc does by
+    itself).  Falls back to the Python thread pool over the oracle when the prebuilt reference
+    is absent."""
     import subprocess
     import tempfile
-    try:
-        import psutil
-        cores = psutil.cpu_count(logical=False) or os.cpu_count()
-    except Exception:
-        cores = os.cpu_count()
-    cores = max(1, min(cores, len(os.sched_getaffinity(0))))
+    info, cpus = host_cpu_info()
+    cores = max(1, len(cpus))
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so")
     drv = os.path.join(ROOT, "oracle", "_ref", "plan_bench")
     if os.path.exists(ref_so) and os.path.exists(drv):
@@ -59,31 +90,42 @@ def cpu_baseline(data, quality, lgwin, shard_size, size_hint):
         with open(path, "wb") as f:
             f.write(data)
         try:
-            def run(nbytes_path, threads, shard):
-                r = subprocess.run([drv, ref_so, nbytes_path, str(quality), str(lgwin), str(shard),
-                                    str(threads), str(size_hint)], capture_output=True, text=True,
-                                   check=True)
+            def run(threads, shard, nreps, pin):
+                cmd = [drv, ref_so, path, str(quality), str(lgwin), str(shard), str(threads),
+                       str(size_hint), str(nreps)]
+                if pin:
+                    cmd.append(",".join(str(c) for c in pin))
+                r = subprocess.run(cmd, capture_output=True, text=True, check=True)
                 return json.loads(r.stdout.strip().splitlines()[-1])
-            best = None
-            for _ in range(2):                       # first run warms the page cache
-                r = run(path, cores, shard_size)
-                if best is None or r["MBps"] > best["MBps"]:
-                    best = r
+            run(cores, shard_size, 1, cpus)                      # warm-up, discarded
+            same = run(cores, shard_size, reps, cpus)
+            big = 8 << 20
+            best = run(cores, big, 3, cpus) if len(data) >= 4 * big else None
             one = data[:min(len(data), 64 << 20)]
             with open(path, "wb") as f:
                 f.write(one)
-            single = run(path, 1, 0)                 # one instance, one core: what c/enc does alone
+            single = run(1, 0, 1, cpus[:1])                      # one instance, one core
         finally:
             os.unlink(path)
-        return {
-            "value": round(best["MBps"], 1), "unit": "MB/s", "cores": cores, "kind": "reference",
-            "sample": "the whole %d MiB input, same plan (%d shards of %d KiB), %d threads "
-                      "(oracle/plan_bench.c), %.2f s wall, ratio %.3f" % (
-                          len(data) >> 20, best["shards"], shard_size >> 10, cores, best["seconds"],
-                          best["bytes"] / max(1, best["out_bytes"])),
+        out = {
+            "value": round(same["MBps"], 1), "unit": "MB/s", "cores": cores, "kind": "reference",
+            "sample": "the whole %d MiB input, same plan (%d shards of %d KiB), %d threads pinned to the "
+                      "physical cores of socket %d (oracle/plan_bench.c), median of %d runs after one "
+                      "warm-up, %.3f s, ratio %.3f" % (
+                          len(data) >> 20, same["shards"], shard_size >> 10, cores, info["socket"], reps,
+                          same["seconds"], same["bytes"] / max(1, same["out_bytes"])),
+            "cpu": info, "seconds_all": same["seconds_all"], "sha256": same["sha256"],
+            "out_bytes": same["out_bytes"],
             "single_stream_1core_MBps": round(single["MBps"], 1),
+            "single_stream_ratio": round(single["bytes"] / max(1, single["out_bytes"]), 4),
             "single_stream_sample": "first %d MiB, one encoder instance, 1 thread" % (len(one) >> 20),
         }
+        if best:
+            out["reference_own_plan"] = {
+                "MBps": round(best["MBps"], 1), "shard_KiB": big >> 10, "shards": best["shards"],
+                "ratio": round(best["bytes"] / max(1, best["out_bytes"]), 4),
+                "note": "the reference at a plan that suits the CPU (tables cleared once per 8 MiB), same cores"}
+        return out
     from concurrent.futures import ThreadPoolExecutor
     from refharness import Oracle
     enc = Oracle()
@@ -333,7 +375,16 @@ def main():
                                            size_hint, min(i * shard, 1 << 30), (i + 1) * shard >= n)
                             for i in range(k))
             line["config"]["spot_check_first_shards_bit_exact"] = comp[:len(want)] == want
-            line["cpu_baseline"] = cpu_baseline(data, args.quality, args.lgwin, shard, size_hint)
+            import hashlib
+            line["config"]["gpu_output_sha256"] = hashlib.sha256(comp).hexdigest()
+            cb = cpu_baseline(data, args.quality, args.lgwin, shard, size_hint)
+            line["cpu_baseline"] = cb
+            # the reference encoded the WHOLE input with the same plan in this
+            # run; its concatenated output must be the GPU's, byte for byte
+            if "sha256" in cb:
+                line["config"]["parity_full_sha256_equal"] = (
+                    cb["sha256"] == line["config"]["gpu_output_sha256"] and cb["out_bytes"] == nbytes)
+            line["config"]["single_stream_ratio"] = cb.get("single_stream_ratio")
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -4,14 +4,17 @@
  * (oracle/_ref/libbrotli_ref.so, loaded with dlopen) using the same partition
  * plan as the GPU run — one independent encoder instance per shard
  * (BROTLI_PARAM_STREAM_OFFSET contract, c/include/brotli/encode.h:231-246) —
- * on T POSIX threads, and prints one JSON line with the wall time.
+ * on T POSIX threads (optionally pinned to a CPU list, BASELINE.md §3.3: one
+ * socket), `reps` times, and prints one JSON line: every wall time, the median,
+ * and the sha256 of the concatenated output (the bytes the GPU run must equal).
  *
  *   plan_bench <libbrotli_ref.so> <input file> <quality> <lgwin> <shard_size>
- *              <threads> [size_hint]
+ *              <threads> [size_hint [reps [cpu,cpu,...]]]
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -36,11 +39,74 @@ static int g_quality, g_lgwin;
 static uint32_t g_hint;
 static volatile size_t g_next;
 static uint64_t* g_sizes;
+static uint8_t** g_outs;      /* per-shard compressed bytes of the last repetition */
+static int g_cpus[1024], g_ncpus;
+
+/* ---- sha256 (FIPS 180-4), for the whole-output parity check --------------- */
+typedef struct { uint32_t h[8]; uint8_t buf[64]; uint64_t n; } Sha;
+static const uint32_t K256[64] = {
+  0x428a2f98,0x71374491,0xb5c0fbcf,0xe9b5dba5,0x3956c25b,0x59f111f1,0x923f82a4,0xab1c5ed5,
+  0xd807aa98,0x12835b01,0x243185be,0x550c7dc3,0x72be5d74,0x80deb1fe,0x9bdc06a7,0xc19bf174,
+  0xe49b69c1,0xefbe4786,0x0fc19dc6,0x240ca1cc,0x2de92c6f,0x4a7484aa,0x5cb0a9dc,0x76f988da,
+  0x983e5152,0xa831c66d,0xb00327c8,0xbf597fc7,0xc6e00bf3,0xd5a79147,0x06ca6351,0x14292967,
+  0x27b70a85,0x2e1b2138,0x4d2c6dfc,0x53380d13,0x650a7354,0x766a0abb,0x81c2c92e,0x92722c85,
+  0xa2bfe8a1,0xa81a664b,0xc24b8b70,0xc76c51a3,0xd192e819,0xd6990624,0xf40e3585,0x106aa070,
+  0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,0x682e6ff3,
+  0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2};
+#define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+static void sha_block(Sha* s, const uint8_t* p) {
+  uint32_t w[64], a[8], t1, t2;
+  int i;
+  for (i = 0; i < 16; ++i) w[i] = (uint32_t)p[4*i] << 24 | (uint32_t)p[4*i+1] << 16 | (uint32_t)p[4*i+2] << 8 | p[4*i+3];
+  for (i = 16; i < 64; ++i)
+    w[i] = w[i-16] + (ROR(w[i-15],7) ^ ROR(w[i-15],18) ^ (w[i-15] >> 3)) + w[i-7] +
+           (ROR(w[i-2],17) ^ ROR(w[i-2],19) ^ (w[i-2] >> 10));
+  memcpy(a, s->h, 32);
+  for (i = 0; i < 64; ++i) {
+    t1 = a[7] + (ROR(a[4],6) ^ ROR(a[4],11) ^ ROR(a[4],25)) + ((a[4] & a[5]) ^ (~a[4] & a[6])) + K256[i] + w[i];
+    t2 = (ROR(a[0],2) ^ ROR(a[0],13) ^ ROR(a[0],22)) + ((a[0] & a[1]) ^ (a[0] & a[2]) ^ (a[1] & a[2]));
+    a[7] = a[6]; a[6] = a[5]; a[5] = a[4]; a[4] = a[3] + t1; a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = t1 + t2;
+  }
+  for (i = 0; i < 8; ++i) s->h[i] += a[i];
+}
+static void sha_init(Sha* s) {
+  static const uint32_t h0[8] = {0x6a09e667,0xbb67ae85,0x3c6ef372,0xa54ff53a,0x510e527f,0x9b05688c,0x1f83d9ab,0x5be0cd19};
+  memcpy(s->h, h0, 32);
+  s->n = 0;
+}
+static void sha_update(Sha* s, const uint8_t* p, size_t n) {
+  size_t fill = (size_t)(s->n & 63);
+  s->n += n;
+  if (fill) {
+    size_t take = 64 - fill < n ? 64 - fill : n;
+    memcpy(s->buf + fill, p, take);
+    p += take; n -= take;
+    if (fill + take < 64) return;
+    sha_block(s, s->buf);
+  }
+  for (; n >= 64; p += 64, n -= 64) sha_block(s, p);
+  memcpy(s->buf, p, n);
+}
+static void sha_final(Sha* s, char hex[65]) {
+  uint64_t bits = s->n * 8;
+  uint8_t pad[72] = {0x80};
+  size_t fill = (size_t)(s->n & 63), npad = (fill < 56 ? 56 : 120) - fill;
+  int i;
+  for (i = 0; i < 8; ++i) pad[npad + i] = (uint8_t)(bits >> (56 - 8 * i));
+  sha_update(s, pad, npad + 8);
+  for (i = 0; i < 8; ++i) sprintf(hex + 8 * i, "%08x", s->h[i]);
+}
 
 static void* worker(void* arg) {
   uint8_t* out = NULL;
   size_t cap = 0;
-  (void)arg;
+  const long tid = (long)arg;
+  if (g_ncpus) {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    CPU_SET(g_cpus[tid % g_ncpus], &set);
+    pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+  }
   for (;;) {
     size_t k = __sync_fetch_and_add(&g_next, 1);
     size_t off, n, avail_in, avail_out, total = 0;
@@ -66,10 +132,18 @@ static void* worker(void* arg) {
       }
     } while (avail_in || HasMoreOutput(st));
     g_sizes[k] = total;
+    /* keep the bytes for the output hash (outside the hot loop of the encoder) */
+    g_outs[k] = (uint8_t*)realloc(g_outs[k], total ? total : 1);
+    memcpy(g_outs[k], out, total);
     Destroy(st);
   }
   free(out);
   return NULL;
+}
+
+static int cmp_double(const void* a, const void* b) {
+  const double x = *(const double*)a, y = *(const double*)b;
+  return x < y ? -1 : x > y;
 }
 
 int main(int argc, char** argv) {
@@ -77,11 +151,13 @@ int main(int argc, char** argv) {
   FILE* f;
   uint8_t* buf;
   pthread_t* th;
-  int threads, i;
+  int threads, i, reps, r;
   struct timespec t0, t1;
   uint64_t out_total = 0;
   size_t k;
-  double dt;
+  double times[64], sorted[64], median;
+  char hex[65];
+  Sha sha;
   if (argc < 7) { fprintf(stderr, "usage: see source\n"); return 1; }
   lib = dlopen(argv[1], RTLD_NOW);
   if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
@@ -104,20 +180,42 @@ int main(int argc, char** argv) {
   g_lgwin = atoi(argv[4]);
   g_shard = (size_t)strtoull(argv[5], NULL, 10);
   threads = atoi(argv[6]);
+  if (threads < 1) threads = 1;
   if (g_shard == 0 || g_shard > g_len) g_shard = g_len;
-  g_hint = argc > 7 ? (uint32_t)strtoul(argv[7], NULL, 10)
+  g_hint = argc > 7 && atol(argv[7]) > 0 ? (uint32_t)strtoul(argv[7], NULL, 10)
                     : (g_len >= (1u << 30) ? (1u << 30) : (uint32_t)g_len);
+  reps = argc > 8 ? atoi(argv[8]) : 1;
+  if (reps < 1) reps = 1;
+  if (reps > 64) reps = 64;
+  if (argc > 9) {
+    char* s = argv[9];
+    while (*s && g_ncpus < 1024) {
+      g_cpus[g_ncpus++] = (int)strtol(s, &s, 10);
+      if (*s == ',') ++s;
+    }
+  }
   g_nshards = (g_len + g_shard - 1) / g_shard;
   g_sizes = (uint64_t*)calloc(g_nshards, 8);
+  g_outs = (uint8_t**)calloc(g_nshards, sizeof(uint8_t*));
   th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
-  clock_gettime(CLOCK_MONOTONIC, &t0);
-  for (i = 0; i < threads; ++i) pthread_create(&th[i], NULL, worker, NULL);
-  for (i = 0; i < threads; ++i) pthread_join(th[i], NULL);
-  clock_gettime(CLOCK_MONOTONIC, &t1);
-  dt = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
-  for (k = 0; k < g_nshards; ++k) out_total += g_sizes[k];
-  printf("{\"bytes\": %zu, \"shards\": %zu, \"threads\": %d, \"seconds\": %.6f, \"MBps\": %.2f, "
-         "\"out_bytes\": %llu}\n", g_len, g_nshards, threads, dt, (double)g_len / 1e6 / dt,
-         (unsigned long long)out_total);
+  for (r = 0; r < reps; ++r) {
+    g_next = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (i = 0; i < threads; ++i) pthread_create(&th[i], NULL, worker, (void*)(long)i);
+    for (i = 0; i < threads; ++i) pthread_join(th[i], NULL);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    times[r] = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  }
+  memcpy(sorted, times, sizeof(double) * (size_t)reps);
+  qsort(sorted, (size_t)reps, sizeof(double), cmp_double);
+  median = (reps & 1) ? sorted[reps / 2] : 0.5 * (sorted[reps / 2 - 1] + sorted[reps / 2]);
+  sha_init(&sha);
+  for (k = 0; k < g_nshards; ++k) { out_total += g_sizes[k]; sha_update(&sha, g_outs[k], g_sizes[k]); }
+  sha_final(&sha, hex);
+  printf("{\"bytes\": %zu, \"shards\": %zu, \"threads\": %d, \"pinned_cpus\": %d, \"reps\": %d, "
+         "\"seconds\": %.6f, \"MBps\": %.2f, \"seconds_all\": [", g_len, g_nshards, threads, g_ncpus,
+         reps, median, (double)g_len / 1e6 / median);
+  for (r = 0; r < reps; ++r) printf("%s%.6f", r ? ", " : "", times[r]);
+  printf("], \"out_bytes\": %llu, \"sha256\": \"%s\"}\n", (unsigned long long)out_total, hex);
   return 0;
 }
