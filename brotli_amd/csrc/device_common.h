@@ -16,6 +16,18 @@ DEV uint32_t log2floor(uint32_t n) { return 31u - (uint32_t)dev_clz32(n); }
 DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
+// ---- wave scans -------------------------------------------------------------
+DEV uint32_t wave_incl_scan(uint32_t v) {
+  const int lane = wave_lane();
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = wave_shfl(x, (lane - d) & 63);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+
 // ---- hashing ---------------------------------------------------------------
 // H68: hash_longest_match64_simd_inc.h:26-32 (five bytes, 15-bit key + 8-bit
 // tag); H58: hash_longest_match_simd_inc.h:18-24 (four bytes,

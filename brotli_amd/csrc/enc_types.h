@@ -43,6 +43,7 @@ struct JobParams {
   uint32_t log2_lut_size;
   uint32_t flags;
   uint32_t rec_bytes;           // bytes of one bucket record (128 for 16 slots, 8 per slot otherwise)
+  uint32_t ix_slices;           // JOB_FLAG_INDEXED: position slices per shard of the index kernels (k_index.h)
 };
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
 #define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal
@@ -52,6 +53,8 @@ struct JobParams {
                                 //   shards per wave when the job is too small to fill the chip anyway
 #define JOB_FLAG_DUO 32u       // k_parse4 with <= 2 shards per wave: every shard gets a second 16-lane group that
                                //   searches the next position in the same step (k_parse4.h)
+#define JOB_FLAG_INDEXED 64u   // quality 5: match candidates come from a position index built by data-parallel
+                               //   kernels (k_index.h); the serial chain (k_chain.h) only selects
 #define JOB_FLAG_DEEP 16u      // one shard per wave, 32 .. 256 slots per bucket (k_parse_deep.h)
 
 // Per-shard description written by the host.
@@ -70,6 +73,7 @@ struct ShardDesc {
   uint64_t scratch_off;    // u32[...] bit offsets (store kernel)
   uint64_t out_off;        // shard output bytes
   uint64_t out_cap;
+  uint64_t ix_off;         // JOB_FLAG_INDEXED: the shard's index region (IxLayout, k_index.h)
 };
 
 // Persistent per-shard encoder state (c/enc/state.h:49-110 subset).
@@ -92,6 +96,8 @@ struct ShardState {
   uint64_t out_bytes;        // whole bytes already final in the shard output
   uint64_t stat_searches, stat_pairs, stat_b_used;
   uint64_t prof[12];         // -DQ_PROFILE: cycles per phase of k_parse4
+  uint32_t ix_frontier;      // k_chain.h: first position whose insertion has not been accounted for yet
+  uint32_t ix_slow;          // k_chain.h: searches that took the exact in-chain path (statistics)
 };
 
 // Constant tables uploaded once per context.

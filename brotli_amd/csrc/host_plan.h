@@ -13,6 +13,7 @@
 
 #include "enc_types.h"
 #include "mb_layout.h"
+#include "k_index_layout.h"
 
 struct JobPlan {
   JobParams J;
@@ -110,6 +111,27 @@ static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_
   plan->in_bytes = len;
   plan->max_out_bytes = max_out;
   return true;
+}
+
+// Gives every shard an index region (k_index.h) behind the rest of the workspace (simulator)
+// or leaves the placement to the caller (ix_in_ws false: the HIP layer keeps the regions in
+// allocations of their own and patches ix_off).  Returns the bytes one region needs.
+static inline uint64_t plan_add_index(JobPlan* plan, bool ix_in_ws) {
+  uint64_t longest = 0;
+  for (const ShardDesc& D : plan->shards) if (D.len > longest) longest = D.len;
+  uint32_t slices = (uint32_t)((longest + 8191) / 8192);    // ~128 rows of 64 positions per slice
+  if (slices < 1) slices = 1;
+  if (slices > 64) slices = 64;
+  plan->J.ix_slices = slices;
+  plan->J.flags |= JOB_FLAG_INDEXED;
+  IxLayout L;
+  ix_layout(longest, slices, &L);
+  if (ix_in_ws) {
+    uint64_t off = plan->ws_bytes;
+    for (ShardDesc& D : plan->shards) { D.ix_off = off; off = plan_align(off + L.bytes); }
+    plan->ws_bytes = off;
+  }
+  return L.bytes;
 }
 
 // Which parse kernel a plan runs on and in which wave layout (api_flags: BROTLI_AMD_FLAG_*

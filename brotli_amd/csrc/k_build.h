@@ -45,18 +45,6 @@ static __device__ const uint8_t k_ctx_maps[4][64] = {
      1, 1, 1, 1, 2, 2, 2, 2, 8, 4, 4, 4, 8, 7, 4, 4, 8, 0, 0, 0, 3, 3, 3, 3,
      5, 5, 10, 5, 5, 5, 10, 5, 6, 6, 6, 6, 6, 6, 6, 6}};
 
-// ---- wave scans -------------------------------------------------------------
-DEV uint32_t wave_incl_scan(uint32_t v) {
-  const int lane = wave_lane();
-  uint32_t x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t y = wave_shfl(x, (lane - d) & 63);
-    if (lane >= d) x += y;
-  }
-  return x;
-}
-
 // ---- entropy (summation order of the reference) ------------------------------
 // BitsEntropy of a[k] + g[k] (either pointer may be null), bit_cost.c:18-44.
 DEV double bits_entropy2(const uint32_t* a, const uint32_t* g, uint32_t n, const double* lut) {

@@ -1,0 +1,403 @@
+// brotli_amd/csrc/k_chain.h — the serial half of the quality-5 LZ77 parse on an
+// indexed job (JOB_FLAG_INDEXED, k_index.h): CreateBackwardReferences
+// (c/enc/backward_references_inc.h:10-242) and the EncodeData glue around it
+// (c/enc/encode.c:905-1173) for up to four shards per wave, 16 lanes each, with
+// NO hash table: the bucket part of every FindLongestMatch was evaluated for all
+// positions at once by ix_bucket; what is left for the dependency chain is
+//
+//   * the distance-cache candidates (they depend on the parse): the 16 lanes of a
+//     group probe the 4 cache entries at FOUR consecutive positions P .. P+3 in
+//     one memory round trip (lane t: position P + t/4, entry t%4);
+//   * the state machine (greedy / lazy decisions, literal spree, block glue),
+//     replicated per lane, which consumes those four results in order for as long
+//     as the position it wants next is the next one evaluated and the distance
+//     cache has not changed (a committed copy ends the step).  A typical command —
+//     match at P, lazy probe of P + 1 loses, commit — is one step;
+//   * book-keeping of which storable positions were NOT stored (k_index.h): a
+//     bitmap in HBM plus a Bloom filter of their bucket keys in LDS.  A search is
+//     taken from the index only if no unstored position can share its key, the
+//     index entry is decidable in isolation (IX_KIND_*), and the bucket winner does
+//     not depend on the byte gate (`unsure`, as in k_parse4.h).  Otherwise the
+//     group searches the position itself, exactly, from the (key, position)-sorted
+//     array: c_search_exact() reproduces the ring contents the reference would
+//     hold — the last 16 STORED predecessors of the key run, masked by the 16-bit
+//     counter — and resolves them like k_parse4.h does.  JOB_FLAG_FORCE_SLOW sends
+//     every search down that path, which pins the two against each other in tests.
+#ifndef BROTLI_AMD_CSRC_K_CHAIN_H_
+#define BROTLI_AMD_CSRC_K_CHAIN_H_
+
+#include "k_index.h"
+#include "k_parse4.h"
+
+#define C_GROUP_LDS_WORDS (IX_BLOOM_WORDS + 16u)   // Bloom filter + the 16 ring slots of c_search_exact
+#define C_LDS_WORDS (Q_GROUPS * C_GROUP_LDS_WORDS)
+
+struct CShard {
+  QShard g;
+  IxGeom geo;
+  const uint64_t* res;
+  const uint32_t* srt;
+  uint8_t* skip;
+  uint32_t frontier;     // every storable position below it is either stored or marked in `skip`
+  uint32_t nslow;
+};
+
+DEV bool c_bloom_hit(const uint32_t* bloom, uint32_t key) {
+  return (bloom[(key & 4095u) >> 5] >> (key & 31u)) & 1u;
+}
+
+// Marks the storable positions of [a, b) as not stored — except, for a literal spree
+// (stride > 1), the ones the spree did store: sfirst + i * stride.
+DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint32_t b,
+                      uint32_t sfirst, uint32_t stride, uint32_t* bloom) {
+  const int t = q_t();
+  uint32_t cur = a;
+  while (wave_any(act && cur < b)) {
+    const bool on = act && cur < b;
+    const uint32_t x = cur + (uint32_t)t;
+    bool sk = on && x < b && ix_storable(C.geo, x);
+    if (sk && stride > 1u && ((x - sfirst) % stride) == 0u) sk = false;
+    if (sk) {
+      const KeyTag kt = hash_pos(ld64(C.g.data + x), J.hasher_type, J.bucket_bits);
+      lds_atomic_or(&bloom[(kt.key & 4095u) >> 5], 1u << (kt.key & 31u));
+    }
+    const uint32_t m16 = q_mask16(wave_ballot(sk));
+    if (on && t == 0 && m16 != 0) {
+      uint8_t* p = C.skip + (cur >> 3);
+      st32(p, ld32(p) | (m16 << (cur & 7u)));
+    }
+    wave_sync();
+    if (on) cur += 16u;
+  }
+}
+
+// The parse stored [a, b) (a single position, a StoreRange, the stitch): everything
+// storable between the frontier and a was passed over.
+DEV void c_stored(const JobParams& J, CShard& C, bool act, uint32_t a, uint32_t b, uint32_t* bloom) {
+  if (wave_any(act && C.frontier < a)) c_mark_range(J, C, act && C.frontier < a, C.frontier, a, 0, 1, bloom);
+  if (act) C.frontier = b;
+}
+
+// Match length of data[a..] and data[b..] from offset `off` on (bytes before it are known to
+// be equal), limit = bytes available at a.
+DEV uint32_t c_extend_from(const uint8_t* data, uint32_t a, uint32_t b, uint32_t limit, uint32_t off) {
+  while (off + 8 <= limit) {
+    const uint64_t x = ld64(data + a + off) ^ ld64(data + b + off);
+    if (x) return off + ((uint32_t)dev_ctz64(x) >> 3);
+    off += 8;
+  }
+  while (off < limit && data[a + off] == data[b + off]) ++off;
+  return off;
+}
+
+// Exact FindLongestMatch (hash table part + distance cache, ..64_simd_inc.h:201-295) of
+// position P for the groups in `want`, from the sorted array.  The caller runs the
+// dictionary probe.
+DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P, uint32_t* scratch) {
+  QShard& g = C.g;
+  const int t = q_t();
+  const int ndist = J.ndist;
+  const uint32_t max_length = g.pos_end - P;
+  const uint32_t max_backward = umin(P, J.max_backward_limit);
+  const B32 cur32 = load_b32(g.data + (want ? P : 0u));
+  const uint32_t backward = q_dc_entry(g, t & 3);
+  const bool d_cand = want && t < ndist && (int32_t)backward > 0 && backward <= max_backward;
+  const uint32_t d_prev = P - backward;
+  const B32 pd = load_b32(g.data + (d_cand ? d_prev : 0u));
+  const KeyTag kt = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits);
+  const uint32_t hi = want ? (uint32_t)(C.res[P] >> 32) : 0u;
+  const int32_t sidx = (int32_t)(hi & 0xFFFFFFu);
+  const bool danger = (hi & IX_DANGER) != 0;
+  // the ring: the last 16 stored positions of the key run before P, newest first
+  uint32_t found = 0, j0 = 0;
+  bool exhausted = false;
+  while (wave_any(want && !exhausted && (found < 16u || danger))) {
+    const bool on = want && !exhausted && (found < 16u || danger);
+    const int32_t idx = sidx - 1 - (int32_t)(j0 + (uint32_t)t);
+    const bool ok = on && idx >= 0;
+    const uint32_t w0 = ok ? C.srt[idx] : 0u;
+    const uint32_t q = w0 & 0xFFFFFFu;
+    bool inrun = false, stored = false;
+    if (ok) {
+      inrun = hash_pos(ld64(g.data + q), J.hasher_type, J.bucket_bits).key == kt.key;
+      stored = inrun && !((C.skip[q >> 3] >> (q & 7u)) & 1u);
+    }
+    const uint32_t nr16 = q_mask16(wave_ballot(on && !inrun));
+    const uint32_t te = nr16 ? (uint32_t)dev_ctz32(nr16) : 16u;
+    stored = stored && (uint32_t)t < te;
+    const uint32_t s16 = q_mask16(wave_ballot(stored));
+    const uint32_t slot = found + (uint32_t)__builtin_popcount(s16 & ((1u << t) - 1u));
+    if (stored && slot < 16u) scratch[slot] = w0;
+    if (on) {
+      found += (uint32_t)__builtin_popcount(s16);
+      if (te < 16u) exhausted = true;
+      j0 += 16u;
+    }
+  }
+  wave_sync();
+  // slots the 16-bit counter leaves visible (:250-257): all 16 once it has seen 16 stores,
+  // and — only reachable after a wrap — count mod 65536 when that is below 16
+  uint32_t nvalid = umin(found, 16u);
+  if (danger) { const uint32_t n = found & 0xFFFFu; nvalid = n < 16u ? n : 16u; }
+  const uint32_t w0 = (uint32_t)t < nvalid ? scratch[t] : 0u;
+  const uint32_t b_prev = w0 & 0xFFFFFFu;
+  const bool b_cand = want && (uint32_t)t < nvalid && (w0 >> 24) == kt.tag && (P - b_prev) <= max_backward;
+  wave_sync();
+  uint32_t b_len = 0, d_len = 0;
+  {
+    B32 pb;
+    pb.q[0] = pb.q[1] = pb.q[2] = pb.q[3] = 0;
+    if (b_cand) pb = load_b32(g.data + b_prev);
+    const uint32_t md = common_prefix32(cur32, pd);
+    const uint32_t mb = common_prefix32(cur32, pb);
+    bool b_ext = false, d_ext = false;
+    if (b_cand) { b_len = umin(mb, max_length); b_ext = mb == 32u && max_length > 32u; }
+    if (d_cand) { d_len = umin(md, max_length); d_ext = md == 32u && max_length > 32u; }
+    if (wave_any(b_ext || d_ext)) {
+      if (b_ext) b_len = q_extend(g.data, P, b_prev, max_length);
+      if (d_ext) d_len = q_extend(g.data, P, d_prev, max_length);
+    }
+  }
+  const uint32_t b_score = 1920u + 135u * b_len - 30u * log2floor((P - b_prev) | 1u);
+  uint32_t d_score = 135u * d_len + 1935u;
+  if (t != 0) d_score -= 39u + ((0x1CA10u >> ((uint32_t)t & 0xEu)) & 0xEu);
+  const bool b_ok = b_cand && b_len >= 4u;
+  const bool d_ok = d_cand && (d_len >= 3u || (d_len == 2u && t < 2));
+  const uint32_t logical = (uint32_t)t;
+  const uint32_t d_key = d_ok ? (d_score << 5) | (31u - (uint32_t)t) : 0u;
+  const uint32_t b_key = b_ok ? (b_score << 5) | (27u - logical) : 0u;
+  const uint32_t d_best = q_max(d_key);
+  const uint32_t dc_score = d_best ? (d_best >> 5) : K_MIN_SCORE;
+  const uint32_t dc_len = q_max((d_key != 0 && d_key == d_best) ? d_len : 0u);
+  const uint32_t dc_len3 = dc_len < 3u ? 3u : dc_len;
+  const bool unsure = b_ok && b_score > dc_score && b_len <= dc_len3;
+  const bool slow = q_mask16(wave_ballot(unsure)) != 0 || ((J.flags & JOB_FLAG_FORCE_SLOW) != 0 && want);
+  const uint32_t best = q_max(b_key > d_key ? b_key : d_key);
+  const bool win_is_d = best != 0 && d_key == best;
+  const bool win_is_b = best != 0 && b_key == best;
+  QResult r;
+  r.len = q_max(win_is_d ? d_len : win_is_b ? b_len : 0u);
+  r.distance = q_max(win_is_d ? backward : win_is_b ? P - b_prev : 0u);
+  r.score = best >> 5;
+  r.delta = 0;
+  if (best == 0 || r.score <= K_MIN_SCORE) { r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; }
+  if (wave_any(slow)) {
+    const QResult s = q_resolve_slow(g, want, P, max_length, 0u, ndist, d_ok || d_cand, d_len, d_prev,
+                                     d_score, b_cand, b_len, b_prev, b_score);
+    if (slow) r = s;
+  }
+  return r;
+}
+
+// ---- the kernel body ---------------------------------------------------------------------
+DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* states,
+                     uint32_t nshards, const DeviceTables* T, const uint8_t* input, uint8_t* ws,
+                     uint32_t wave_index, uint32_t* lds) {
+  const int t = q_t();
+  const uint32_t gpw = q_groups_per_wave(J);
+  const uint32_t gi = (uint32_t)(wave_lane() >> 4);
+  const uint32_t shard = wave_index * gpw + gi;
+  const bool alive = gi < gpw && shard < nshards;
+  const bool writer = alive && t == 0;
+  const uint32_t htl = hasher_htl(J.hasher_type);
+  const ShardDesc& D = shards[alive ? shard : 0];
+  const ShardState* S0 = &states[alive ? shard : 0];
+  uint32_t* bloom = lds + gi * C_GROUP_LDS_WORDS;
+  uint32_t* scratch = bloom + IX_BLOOM_WORDS;
+  const int kpos = t >> 2, idc = t & 3;          // this lane's probe: position P0 + kpos, cache entry idc
+
+  CShard C;
+  QShard& g = C.g;
+  g.data = input + D.in_off;
+  g.table = nullptr;
+  g.nums = nullptr;
+  g.cmds = (Command*)(ws + D.cmds_off);
+  g.descs = shards;
+  g.wsb = ws;
+  g.shard = alive ? shard : 0u;
+  g.stream_offset = D.stream_offset;
+  regs_load(g.r, S0);
+  for (int i = 0; i < 4; ++i) g.dc[i] = S0->dist_cache[i];
+  g.dict_lookups = S0->dict_lookups;
+  g.dict_matches = S0->dict_matches;
+  g.blk_flags = g.blk_bytes = g.blk_pos = 0;
+  g.position = g.pos_end = g.store_end = g.insert_length = g.apply_random_heuristics = 0;
+  g.sr_len = g.sr_dist = 0; g.sr_score = K_MIN_SCORE; g.sr_delta = 0; g.delayed = 0;
+  g.st_first = g.st_count = 0; g.st_stride = 1;
+  g.st_x = 0; g.st_x_valid = 0;
+  g.n32.q[0] = g.n32.q[1] = g.n32.q[2] = g.n32.q[3] = 0;
+  g.n32_pos = 0xFFFFFFFFu;
+  g.status = 0;
+  g.stat_searches = 0;
+  g.role = 0;
+  g.pf_val = g.pf_acc = 0;
+  for (int i = 0; i < 12; ++i) g.prof[i] = 0;
+  g.state = (alive && !S0->done && !S0->mb_valid && !S0->error) ? Q_PRE : Q_DONE;
+  const bool participated = g.state != Q_DONE;
+  C.geo = ix_geom(J, D);
+  IxLayout L;
+  ix_layout(D.len, J.ix_slices, &L);
+  uint8_t* ixb = ws + D.ix_off;
+  C.res = (const uint64_t*)(ixb + L.res);
+  C.srt = (const uint32_t*)(ixb + L.srt);
+  C.skip = ixb + L.skip;
+  C.frontier = S0->ix_frontier;
+  C.nslow = 0;
+  {
+    const uint32_t* gb = (const uint32_t*)(ixb + L.bloom);
+    for (uint32_t i = (uint32_t)t; i < IX_BLOOM_WORDS; i += 16u) bloom[i] = participated ? gb[i] : 0u;
+  }
+  wave_sync();
+  const bool force_slow = (J.flags & JOB_FLAG_FORCE_SLOW) != 0;
+
+  while (wave_any(g.state != Q_DONE)) {
+    if (g.state == Q_PRE) q_driver_pre(J, g);
+    if (wave_any(g.state == Q_SETUP)) {
+      const bool su = g.state == Q_SETUP;
+      // StitchToPreviousBlock (..64_simd_inc.h:139-151) stores the last three positions of the
+      // previous block
+      if (wave_any(su && (g.blk_flags & QBLK_STITCH)))
+        c_stored(J, C, su && (g.blk_flags & QBLK_STITCH), g.blk_pos - 3u, g.blk_pos, bloom);
+      q_setup_extend(J, g, su);
+    }
+    // block finished? (loop guard of CreateBackwardReferences, :44 and :239-241)
+    if (g.state == Q_SEARCH && !(g.position + htl < g.pos_end)) {
+      g.insert_length += g.pos_end - g.position;
+      g.r.last_insert_len = g.insert_length;
+      g.state = Q_POST;
+    }
+    const bool want = g.state == Q_SEARCH || g.state == Q_LAZY;
+    if (wave_any(want)) {
+      const uint32_t P0 = g.position + (g.state == Q_LAZY ? 1u : 0u);
+      // positions passed over since the last store are known now; the Bloom filter must hold
+      // them before this step's searches consult it
+      if (wave_any(want && C.frontier < P0)) c_mark_range(J, C, want && C.frontier < P0, C.frontier, P0, 0, 1, bloom);
+      if (want) C.frontier = umax(C.frontier, P0);
+      wave_sync();
+
+      // ---- evaluation: lane (kpos, idc) ----
+      const uint32_t Pk = P0 + (uint32_t)kpos;
+      const bool ev = want && Pk + htl <= g.pos_end;
+      const uint32_t max_length = g.pos_end - Pk;
+      const B32 cur32 = load_b32(g.data + (ev ? Pk : 0u));
+      const uint32_t backward = q_dc_entry(g, idc);
+      const bool d_cand = ev && idc < J.ndist && (int32_t)backward > 0 && backward <= umin(Pk, J.max_backward_limit);
+      const B32 pd = load_b32(g.data + (d_cand ? Pk - backward : 0u));
+      const uint64_t rw = ev ? C.res[Pk] : 0ull;
+      uint32_t d_len = 0;
+      {
+        const uint32_t md = common_prefix32(cur32, pd);
+        bool d_ext = false;
+        if (d_cand) { d_len = umin(md, max_length); d_ext = md == 32u && max_length > 32u; }
+        if (wave_any(d_ext)) { if (d_ext) d_len = q_extend(g.data, Pk, Pk - backward, max_length); }
+      }
+      uint32_t d_score = 135u * d_len + 1935u;
+      if (idc != 0) d_score -= 39u + ((0x1CA10u >> ((uint32_t)idc & 0xEu)) & 0xEu);
+      const bool d_ok = d_cand && (d_len >= 3u || (d_len == 2u && idc < 2));
+      const uint32_t d_key = d_ok ? (d_score << 2) | (3u - (uint32_t)idc) : 0u;
+      uint32_t d_best = umax(d_key, wave_quad_xor(d_key, 1));
+      d_best = umax(d_best, wave_quad_xor(d_best, 2));
+      const uint32_t dc_score = d_best ? (d_best >> 2) : K_MIN_SCORE;
+      const bool d_win = d_key != 0 && d_key == d_best;
+      uint32_t dc_len = d_win ? d_len : 0u, dc_dist = d_win ? backward : 0u;
+      dc_len = umax(dc_len, wave_quad_xor(dc_len, 1)); dc_len = umax(dc_len, wave_quad_xor(dc_len, 2));
+      dc_dist = umax(dc_dist, wave_quad_xor(dc_dist, 1)); dc_dist = umax(dc_dist, wave_quad_xor(dc_dist, 2));
+      // the bucket part, from the index
+      const uint32_t rlo = (uint32_t)rw, rhi = (uint32_t)(rw >> 32);
+      const uint32_t kind = rlo >> 30;
+      uint32_t b_len = (rlo >> 24) & 63u;
+      const uint32_t b_dist = rlo & 0xFFFFFFu;
+      {
+        const bool b_long = ev && kind == IX_KIND_LONG;
+        if (wave_any(b_long)) { if (b_long) b_len = c_extend_from(g.data, Pk, Pk - b_dist, max_length, IX_CAP); }
+      }
+      const bool b_ok = ev && (kind == IX_KIND_EXACT || kind == IX_KIND_LONG);
+      const uint32_t b_score = b_ok ? 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u) : 0u;
+      const uint32_t keyP = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits).key;
+      const bool b_wins = b_ok && b_score > dc_score;
+      const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & IX_DANGER) != 0 || force_slow ||
+                                     c_bloom_hit(bloom, keyP) ||
+                                     (b_wins && b_len <= umax(dc_len, 3u)));
+      uint32_t e_len = 0, e_dist = 0, e_score = K_MIN_SCORE;
+      if (b_wins) { e_len = b_len; e_dist = b_dist; e_score = b_score; }
+      else if (d_best != 0) { e_len = dc_len; e_dist = dc_dist; e_score = dc_score; }
+      const uint32_t e_flags = e_score | (ev ? 0x80000000u : 0u) | (need_exact ? 0x40000000u : 0u);
+
+      // ---- consumption: the state machine takes P0, P0 + 1, ... while it may ----
+      bool go = want;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!wave_any(go)) break;
+        const uint32_t Pq = P0 + (uint32_t)k;
+        const uint32_t f = q_bcast(e_flags, 4 * k);
+        QResult cur;
+        cur.len = q_bcast(e_len, 4 * k);
+        cur.distance = q_bcast(e_dist, 4 * k);
+        cur.score = f & 0x3FFFFFFFu;
+        cur.delta = 0;
+        // does the state machine ask for exactly this position now?
+        bool take = go && (f & 0x80000000u) != 0;
+        if (take) {
+          if (g.state == Q_SEARCH) take = g.position == Pq && g.position + htl < g.pos_end;
+          else take = g.state == Q_LAZY && g.position + 1u == Pq;
+        }
+        go = take;
+        const bool exact = take && (f & 0x40000000u) != 0;
+        if (wave_any(exact)) {
+          const QResult s = c_search_exact(J, C, exact, Pq, scratch);
+          if (exact) { cur = s; ++C.nslow; }
+        }
+        if (take) C.frontier = Pq + 1u;          // FindLongestMatch stores the position it searched
+        // static dictionary when nothing was found (hash.h:179-202)
+        q_dict_search(J, T, g, take && cur.score == K_MIN_SCORE, Pq, g.pos_end - Pq, cur);
+        if (take) g.stat_searches++;
+        const bool commit = q_transition(J, g, take, cur, htl);
+        // what the transition stored: the copied range (StoreRange) or the literal spree
+        if (wave_any(take && g.st_count != 0)) {
+          const bool st = take && g.st_count != 0;
+          if (wave_any(st && g.st_stride == 1u))
+            c_stored(J, C, st && g.st_stride == 1u, g.st_first, g.st_first + g.st_count, bloom);
+          if (wave_any(st && g.st_stride != 1u)) {
+            const bool sp = st && g.st_stride != 1u;
+            c_stored(J, C, sp, g.st_first, g.st_first, bloom);
+            c_mark_range(J, C, sp, g.st_first, g.st_first + g.st_count * g.st_stride, g.st_first, g.st_stride, bloom);
+            if (sp) C.frontier = g.st_first + g.st_count * g.st_stride;
+          }
+          if (st) { g.st_count = 0; go = false; }
+        }
+        if (commit) go = false;                   // the distance cache changed: later probes are stale
+      }
+    }
+    if (g.state == Q_POST) q_driver_post(J, g, writer);
+  }
+
+  wave_sync();
+  if (participated) {
+    uint32_t* gb = (uint32_t*)(ixb + L.bloom);
+    for (uint32_t i = (uint32_t)t; i < IX_BLOOM_WORDS; i += 16u) gb[i] = bloom[i];
+  }
+  if (writer && participated) {
+    ShardState* S = &states[shard];
+    regs_save(g.r, S);
+    for (int i = 0; i < 4; ++i) S->dist_cache[i] = g.dc[i];
+    S->dict_lookups = g.dict_lookups;
+    S->dict_matches = g.dict_matches;
+    S->done = (g.status & QST_DONE) ? 1u : 0u;
+    S->mb_valid = (g.status & QST_HAVE_MB) ? 1u : 0u;
+    if (g.status & QST_ERROR) S->error = 1;
+    if (g.status & QST_HAVE_MB) {
+      S->mb_start = g.r.last_flush_pos;
+      S->mb_bytes = g.r.input_pos - g.r.last_flush_pos;
+      S->mb_is_last = (g.blk_flags & QBLK_LAST) ? 1u : 0u;
+      S->mb_force_flush = (g.blk_flags & QBLK_FLUSH) ? ((g.blk_flags & QBLK_NOSEAL) ? 2u : 1u) : 0u;
+      S->mb_raw = 0;
+    }
+    S->stat_searches += g.stat_searches;
+    S->stat_pairs += g.stat_searches;
+    S->ix_frontier = C.frontier;
+    S->ix_slow += C.nslow;
+  }
+  wave_sync();
+}
+
+#endif  // BROTLI_AMD_CSRC_K_CHAIN_H_

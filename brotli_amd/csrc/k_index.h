@@ -1,0 +1,354 @@
+// brotli_amd/csrc/k_index.h — the data-parallel half of the quality-5 LZ77 parse
+// (JOB_FLAG_INDEXED): a position index that answers "what would the 16-slot
+// tagged bucket of this position hold, and which of its entries is the best
+// match" for EVERY position of a shard at once, without a hash table.
+//
+// What the reference computes (c/enc/hash_longest_match64_simd_inc.h:114-302,
+// hash_longest_match_simd_inc.h for the 4-byte hasher): Store() puts positions
+// into the 16-slot ring of their bucket key in increasing position order, and
+// FindLongestMatch(P) looks at the (up to) 16 most recently stored positions of
+// P's key whose 8-bit tag equals P's.  Which positions get stored depends on
+// the parse, but only through a few, locally known exceptions (the position
+// after a chain of lazy matches, the clipped range of a run-length copy, the
+// literal spree, block tails — c/enc/backward_references_inc.h:122-236): on
+// ordinary data almost every position is stored.  So:
+//
+//   * F = the positions that CAN be stored (block structure only): x + HTL <=
+//     block end, or one of the three positions StitchToPreviousBlock adds;
+//   * the index is built for F: positions sorted by (key, position) — a
+//     two-level stable counting sort, 256 buckets by the top key bits
+//     (ix_count / ix_scan / ix_scatter) and the remaining key bits inside a
+//     bucket (ix_bucket);
+//   * ix_bucket then evaluates, for every searchable position P, the window of
+//     the <= 16 predecessors of P in its key run exactly as FindLongestMatch's
+//     bucket loop would (tag filter, first four bytes, match length, score, order
+//     of visit as the tie break) and stores the arg-max in res[P];
+//   * the serial chain (k_chain.h) walks CreateBackwardReferences with res[P]
+//     plus the distance-cache candidates it computes itself.  It keeps a bitmap
+//     of the positions of F it did NOT store and a Bloom filter of their keys;
+//     a search whose key may be affected, or whose result the index marked as
+//     not decidable in isolation, is redone exactly from the sorted array
+//     (`srt`), so the output never depends on how often the shortcut applied.
+//
+// Everything here is one 64-lane wave per workgroup, no inter-workgroup
+// communication inside a kernel; kernels hand over through HBM.
+#ifndef BROTLI_AMD_CSRC_K_INDEX_H_
+#define BROTLI_AMD_CSRC_K_INDEX_H_
+
+#include "device_common.h"
+#include "k_index_layout.h"
+
+// ---- block structure of a completely fed shard ------------------------------------
+// (BrotliEncoderCompressStream re-blocks the input to 1 << lgblock, encode.c:1666-1681;
+// a shard with a stream offset first emits its two "flint" bytes as a block of their own,
+// encode.c:1686-1694.)
+struct IxGeom { uint32_t n, first, lgblock, htl; };
+DEV IxGeom ix_geom(const JobParams& J, const ShardDesc& D) {
+  IxGeom g;
+  g.n = D.len;
+  g.first = D.stream_offset != 0 ? 2u : 0u;
+  g.lgblock = (uint32_t)J.lgblock;
+  g.htl = hasher_htl(J.hasher_type);
+  return g;
+}
+// End of the input block that contains x.
+DEV uint32_t ix_block_end(const IxGeom& g, uint32_t x) {
+  if (x < g.first) return umin(g.first, g.n);
+  const uint32_t e = g.first + ((((x - g.first) >> g.lgblock) + 1u) << g.lgblock);
+  return umin(e, g.n);
+}
+// Can position x ever be stored?  StoreRange stops at pos_end - HTL + 1
+// (backward_references_inc.h:41, 190-199), searches need x + HTL < pos_end (:44),
+// StitchToPreviousBlock adds the last three positions of a block when the next one
+// has >= HTL - 1 bytes and starts at >= 3 (..64_simd_inc.h:139-151).
+DEV bool ix_storable(const IxGeom& g, uint32_t x) {
+  if (x < g.first || x >= g.n) return false;
+  const uint32_t e = ix_block_end(g, x);
+  if (x + g.htl <= e) return true;
+  return x + 3u >= e && e >= 3u && g.n - e >= g.htl - 1u;
+}
+// Positions FindLongestMatch can be called for: the loop guard is x + HTL < pos_end (:44), the
+// lazy probe of x + 1 inside the loop has no guard of its own (:127-133).
+DEV bool ix_searchable(const IxGeom& g, uint32_t x) {
+  if (x < g.first || x >= g.n) return false;
+  return x + g.htl <= ix_block_end(g, x);
+}
+
+DEV IxEntry ix_load_entry(const uint8_t* p) {
+  IxEntry e;
+  __builtin_memcpy(&e, p, 16);
+  return e;
+}
+DEV void ix_store_entry(uint8_t* p, const IxEntry& e) { __builtin_memcpy(p, &e, 16); }
+
+// Lanes of the wave whose `v` (nbits wide) equals this lane's, among the lanes with `act`.
+DEV uint64_t ix_match_any(bool act, uint32_t v, int nbits) {
+  uint64_t same = wave_ballot(act);
+  for (int b = 0; b < nbits; ++b) {
+    const bool bit = (v >> b) & 1u;
+    const uint64_t m = wave_ballot(act && bit);
+    same &= bit ? m : ~m;
+  }
+  return act ? same : 0ull;
+}
+
+// ---- level 1: buckets by the top key bits ----------------------------------------------
+// Slice `w` of the shard: positions [w * per, (w + 1) * per), per a multiple of 64.
+DEV uint32_t ix_slice_len(uint32_t n, uint32_t slices) {
+  return (((n + slices - 1u) / slices) + 63u) & ~63u;
+}
+
+// grid = nshards * slices.  Counts the storable positions of the slice per bucket;
+// cnt[bucket * slices + w].  Also clears the slice's part of the unstored-position bitmap
+// and (slice 0) the Bloom filter.
+DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
+                  uint32_t w, uint32_t* lds_cnt) {
+  const int lane = wave_lane();
+  const IxGeom g = ix_geom(J, D);
+  IxLayout L;
+  ix_layout(g.n, J.ix_slices, &L);
+  uint8_t* base = ws + D.ix_off;
+  const uint8_t* data = input + D.in_off;
+  const uint32_t per = ix_slice_len(g.n, J.ix_slices);
+  const uint32_t lo = w * per, hi = umin(lo + per, g.n);
+  for (uint32_t b = (uint32_t)lane; b < IX_NB; b += 64u) lds_cnt[b] = 0;
+  wave_sync();
+  const int shift = J.bucket_bits - (int)IX_NB_LOG2;
+  for (uint32_t x0 = lo; x0 < hi; x0 += 64u) {
+    const uint32_t x = x0 + (uint32_t)lane;
+    if (x < hi && ix_storable(g, x)) {
+      const KeyTag kt = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits);
+      lds_atomic_add(&lds_cnt[kt.key >> shift], 1u);
+    }
+  }
+  wave_sync();
+  uint32_t* cnt = (uint32_t*)(base + L.cnt);
+  for (uint32_t b = (uint32_t)lane; b < IX_NB; b += 64u) cnt[b * J.ix_slices + w] = lds_cnt[b];
+  // bitmap bytes of this slice (per is a multiple of 64 positions = 8 bytes)
+  uint32_t* skip = (uint32_t*)(base + L.skip);
+  const uint32_t w_lo = lo / 32u, w_hi = (umin(lo + per, g.n + 128u) + 31u) / 32u;
+  for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) skip[i] = 0;
+  if (w == 0) {
+    uint32_t* bloom = (uint32_t*)(base + L.bloom);
+    for (uint32_t i = (uint32_t)lane; i < IX_BLOOM_WORDS; i += 64u) bloom[i] = 0;
+  }
+  wave_sync();
+}
+
+// grid = nshards.  Exclusive scan of cnt[] in (bucket, slice) order, in place;
+// cnt[IX_NB * slices] = number of storable positions of the shard.
+DEV void ix_scan(const JobParams& J, const ShardDesc& D, uint8_t* ws) {
+  const int lane = wave_lane();
+  IxLayout L;
+  ix_layout(D.len, J.ix_slices, &L);
+  uint32_t* cnt = (uint32_t*)(ws + D.ix_off + L.cnt);
+  const uint32_t total = IX_NB * J.ix_slices;
+  const uint32_t per = (total + 63u) / 64u;
+  const uint32_t lo = (uint32_t)lane * per, hi = umin(lo + per, total);
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; ++i) sum += cnt[i];
+  const uint32_t incl = wave_incl_scan(sum);
+  uint32_t run = incl - sum;
+  wave_sync();
+  for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = cnt[i]; cnt[i] = run; run += v; }
+  if (lane == 63) cnt[total] = incl;
+  wave_sync();
+}
+
+// grid = nshards * slices.  Stable scatter of the slice's entries to their buckets.
+DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
+                    uint32_t w, uint32_t* lds_off) {
+  const int lane = wave_lane();
+  const IxGeom g = ix_geom(J, D);
+  IxLayout L;
+  ix_layout(g.n, J.ix_slices, &L);
+  uint8_t* base = ws + D.ix_off;
+  const uint8_t* data = input + D.in_off;
+  const uint32_t* cnt = (const uint32_t*)(base + L.cnt);
+  uint8_t* ent = base + L.ent;
+  const uint32_t per = ix_slice_len(g.n, J.ix_slices);
+  const uint32_t lo = w * per, hi = umin(lo + per, g.n);
+  for (uint32_t b = (uint32_t)lane; b < IX_NB; b += 64u) lds_off[b] = cnt[b * J.ix_slices + w];
+  wave_sync();
+  const int shift = J.bucket_bits - (int)IX_NB_LOG2;
+  for (uint32_t x0 = lo; x0 < hi; x0 += 64u) {
+    const uint32_t x = x0 + (uint32_t)lane;
+    const bool act = x < hi && ix_storable(g, x);
+    IxEntry e;
+    e.w0 = e.w1 = 0; e.d = 0;
+    uint32_t b = 0;
+    if (act) {
+      e.d = ld64(data + x);
+      const KeyTag kt = hash_pos(e.d, J.hasher_type, J.bucket_bits);
+      e.w0 = x | (kt.tag << 24);
+      e.w1 = kt.key;
+      b = kt.key >> shift;
+    }
+    const uint64_t same = ix_match_any(act, b, (int)IX_NB_LOG2);
+    const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
+    const uint32_t total = (uint32_t)dev_popc64(same);
+    uint32_t at = 0;
+    if (act) at = lds_off[b];
+    wave_sync();
+    if (act && rank + 1u == total) lds_off[b] = at + total;
+    wave_sync();
+    if (act) ix_store_entry(ent + 16ull * (at + rank), e);
+  }
+  wave_sync();
+}
+
+// ---- level 2 + window search: one wave per (shard, bucket) -------------------------------
+struct IxBest { uint32_t key, len, dist; };   // key = score << 5 | (16 - j), j = 1 newest
+
+DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + 135u * len - 30u * log2floor(dist); }
+
+// Bytes the strings at data+p and data+q share from offset 8 on, up to `limit` (> 8) and at
+// most IX_CAP; the first 8 are known to be equal.
+DEV uint32_t ix_extend8(const uint8_t* data, uint32_t p, uint32_t q, uint32_t limit) {
+  const uint32_t cap = umin(limit, IX_CAP);
+  uint32_t off = 8;
+  while (off < cap) {
+    const uint64_t x = ld64(data + p + off) ^ ld64(data + q + off);
+    if (x) { off += (uint32_t)dev_ctz64(x) >> 3; break; }
+    off += 8;
+  }
+  return umin(off, cap);
+}
+
+// lds: [0, 128) bin counts / starts, [128, 256) cursors, then (16 + 64) staged entries (16 B each)
+#define IX_BUCKET_LDS_WORDS (256u + 80u * 4u)
+DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
+                   uint32_t bucket, uint32_t* lds) {
+  const int lane = wave_lane();
+  const IxGeom g = ix_geom(J, D);
+  IxLayout L;
+  ix_layout(g.n, J.ix_slices, &L);
+  uint8_t* base = ws + D.ix_off;
+  const uint8_t* data = input + D.in_off;
+  const uint32_t* cnt = (const uint32_t*)(base + L.cnt);
+  const uint8_t* ent = base + L.ent;
+  uint8_t* ent2 = base + L.ent2;
+  uint32_t* srt = (uint32_t*)(base + L.srt);
+  uint64_t* res = (uint64_t*)(base + L.res);
+  const uint32_t start = cnt[bucket * J.ix_slices];
+  const uint32_t end = cnt[(bucket + 1u) * J.ix_slices];   // (the last one reads the total)
+  const uint32_t m = end - start;
+  if (m == 0) return;
+  const int lowbits = J.bucket_bits - (int)IX_NB_LOG2;      // 6 or 7
+  const uint32_t nbins = 1u << lowbits, lowmask = nbins - 1u;
+  uint32_t* bins = lds;
+  uint32_t* cursor = lds + 128;
+  uint32_t* stage = lds + 256;
+  for (uint32_t b = (uint32_t)lane; b < 128u; b += 64u) bins[b] = 0;
+  wave_sync();
+  // A: histogram of the remaining key bits
+  for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+    const uint32_t i = r0 + (uint32_t)lane;
+    if (i < m) {
+      const IxEntry e = ix_load_entry(ent + 16ull * (start + i));
+      lds_atomic_add(&bins[e.w1 & lowmask], 1u);
+    }
+  }
+  wave_sync();
+  {
+    // exclusive scan of 128 bins: two per lane
+    const uint32_t a = bins[2 * lane], b = bins[2 * lane + 1];
+    const uint32_t incl = wave_incl_scan(a + b);
+    wave_sync();
+    bins[2 * lane] = incl - a - b;
+    bins[2 * lane + 1] = incl - b;
+    cursor[2 * lane] = incl - a - b;
+    cursor[2 * lane + 1] = incl - b;
+  }
+  wave_sync();
+  // B: stable scatter inside the bucket
+  for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+    const uint32_t i = r0 + (uint32_t)lane;
+    const bool act = i < m;
+    IxEntry e;
+    e.w0 = e.w1 = 0; e.d = 0;
+    if (act) e = ix_load_entry(ent + 16ull * (start + i));
+    const uint32_t kl = e.w1 & lowmask;
+    const uint64_t same = ix_match_any(act, kl, lowbits);
+    const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
+    const uint32_t total = (uint32_t)dev_popc64(same);
+    uint32_t at = 0;
+    if (act) at = cursor[kl];
+    wave_sync();
+    if (act && rank + 1u == total) cursor[kl] = at + total;
+    wave_sync();
+    if (act) ix_store_entry(ent2 + 16ull * (start + at + rank), e);
+  }
+  wave_sync();
+  // C: window search in sorted order.  stage[0..15] = the last 16 entries of the previous
+  // row, stage[16 + lane] = this row's.
+  for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+    const uint32_t i = r0 + (uint32_t)lane;
+    const bool act = i < m;
+    IxEntry e;
+    e.w0 = e.w1 = 0xFFFFFFFFu; e.d = 0;
+    if (act) e = ix_load_entry(ent2 + 16ull * (start + i));
+    __builtin_memcpy(&stage[4 * (16 + lane)], &e, 16);
+    wave_sync();
+    const uint32_t p = e.w0 & 0xFFFFFFu, tag = e.w0 >> 24, key = e.w1;
+    const uint32_t rank = act ? i - bins[key & lowmask] : 0u;      // same-key entries before this one
+    const bool danger = rank >= 65520u;
+    const bool search = act && ix_searchable(g, p);
+    const uint32_t max_length = search ? ix_block_end(g, p) - p : 0u;
+    uint32_t best = 0, best_len = 0, best_dist = 0;               // exact candidates
+    uint32_t longmask = 0;
+    const uint32_t nwin = umin(rank, 16u);
+    for (uint32_t j = 1; j <= 16u; ++j) {
+      IxEntry q;
+      __builtin_memcpy(&q, &stage[4 * (16 + lane - (int)j)], 16);
+      if (!(search && j <= nwin)) continue;
+      if ((q.w0 >> 24) != tag) continue;
+      const uint64_t x = q.d ^ e.d;
+      const uint32_t l8 = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
+      if (l8 < 4u) continue;                                      // first4 != current4
+      if (l8 == 8u && max_length > 8u) { longmask |= 1u << j; continue; }
+      const uint32_t len = umin(l8, max_length);
+      const uint32_t dist = p - (q.w0 & 0xFFFFFFu);
+      const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
+      if (k > best) { best = k; best_len = len; best_dist = dist; }
+    }
+    // candidates equal in the first 8 bytes: compare on in the input
+    uint32_t ncapped = 0, cap_key = 0, cap_dist = 0;
+    while (wave_ballot(longmask != 0) != 0) {
+      if (longmask != 0) {
+        const uint32_t j = (uint32_t)dev_ctz32(longmask);
+        longmask &= longmask - 1u;
+        IxEntry q;
+        __builtin_memcpy(&q, &stage[4 * (16 + lane - (int)j)], 16);
+        const uint32_t qp = q.w0 & 0xFFFFFFu;
+        const uint32_t len = ix_extend8(data, p, qp, max_length);
+        const uint32_t dist = p - qp;
+        const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
+        if (len == IX_CAP && max_length > IX_CAP) {
+          ++ncapped;
+          if (k > cap_key) { cap_key = k; cap_dist = dist; }
+        } else if (k > best) { best = k; best_len = len; best_dist = dist; }
+      }
+    }
+    if (act) {
+      srt[start + i] = e.w0;
+      uint32_t kind, len = 0, dist = 0;
+      if (!search) kind = IX_KIND_NONE;
+      else if (danger || ncapped >= 2u) kind = IX_KIND_SLOW;
+      else if (ncapped == 1u) {
+        // the long candidate's score can only grow with its real length
+        if (cap_key > best) { kind = IX_KIND_LONG; len = IX_CAP; dist = cap_dist; }
+        else kind = IX_KIND_SLOW;
+      } else if (best != 0) { kind = IX_KIND_EXACT; len = best_len; dist = best_dist; }
+      else kind = IX_KIND_NONE;
+      const uint32_t lo = (kind << 30) | (len << 24) | dist;
+      const uint32_t hi = (start + i) | (umin(rank, IX_RANK_CAP) << 24) | (danger ? IX_DANGER : 0u);
+      res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+    wave_sync();
+    if (lane >= 48) __builtin_memcpy(&stage[4 * (lane - 48)], &e, 16);   // the next row's look-back
+    wave_sync();
+  }
+}
+
+#endif  // BROTLI_AMD_CSRC_K_INDEX_H_

@@ -1,0 +1,44 @@
+// brotli_amd/csrc/k_index_layout.h — constants and the HBM layout of a shard's position
+// index (k_index.h), shared by the kernels and the host-side planner (host_plan.h).
+#ifndef BROTLI_AMD_CSRC_K_INDEX_LAYOUT_H_
+#define BROTLI_AMD_CSRC_K_INDEX_LAYOUT_H_
+
+#include <stdint.h>
+
+#if defined(__HIPCC__) || defined(BROTLI_AMD_SIMT_SIM)
+#define IX_HD __host__ __device__
+#else
+#define IX_HD
+#endif
+
+#define IX_NB_LOG2 8u
+#define IX_NB (1u << IX_NB_LOG2)              // first-level buckets (top key bits)
+#define IX_CAP 40u                            // bytes compared per candidate by ix_bucket
+#define IX_BLOOM_WORDS 128u                   // 4096-bit filter of the keys of unstored positions
+#define IX_KIND_NONE 0u
+#define IX_KIND_EXACT 1u                      // (len, distance) is the bucket loop's result
+#define IX_KIND_LONG 2u                       // one candidate matches >= IX_CAP bytes and wins however long it is
+#define IX_KIND_SLOW 3u                       // not decidable here: the chain searches this position itself
+#define IX_RANK_CAP 127u
+#define IX_DANGER 0x80000000u                 // the bucket counter may have wrapped (>= 65520 stores of one key)
+
+// Entry of the sort: w0 = position | tag << 24, w1 = bucket key, d = the 8 bytes at the position.
+struct IxEntry { uint32_t w0, w1; uint64_t d; };
+
+// Index region of one shard, offsets relative to ShardDesc::ix_off.
+struct IxLayout { uint64_t cnt, bloom, skip, srt, res, ent, ent2, bytes; };
+static inline IX_HD uint64_t ix_align(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
+static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, IxLayout* L) {
+  uint64_t off = 0;
+  L->cnt = off;   off = ix_align(off + 4ull * ((uint64_t)IX_NB * slices + 2));
+  L->bloom = off; off = ix_align(off + 4ull * IX_BLOOM_WORDS);
+  L->skip = off;  off = ix_align(off + n / 8 + 32);
+  L->srt = off;   off = ix_align(off + 4 * n + 16);
+  L->res = off;   off = ix_align(off + 8 * n + 16);
+  L->ent = off;   off = ix_align(off + 16 * n + 16);
+  L->ent2 = off;  off = ix_align(off + 16 * n + 16);
+  L->bytes = off;
+}
+
+
+#endif  // BROTLI_AMD_CSRC_K_INDEX_LAYOUT_H_

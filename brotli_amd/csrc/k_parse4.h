@@ -622,9 +622,8 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
 
 // ExtendLastCommand (encode.c:905-971) for the groups with want set; then the
 // CreateBackwardReferences prologue.
+DEV void q_setup_extend(const JobParams& J, QShard& g, bool want);
 DEV void q_setup_block(const JobParams& J, QShard& g, bool want, uint8_t* lds_dup) {
-  const int t = q_t();
-  const uint32_t htl = hasher_htl(J.hasher_type);
   // StitchToPreviousBlock (..64_simd_inc.h:139-151)
   if (want && (g.blk_flags & QBLK_STITCH)) {
     g.st_first = g.blk_pos - 3u;
@@ -632,6 +631,12 @@ DEV void q_setup_block(const JobParams& J, QShard& g, bool want, uint8_t* lds_du
     g.st_stride = 1;
   }
   q_drain_stores(J, g, lds_dup);
+  q_setup_extend(J, g, want);
+}
+// ExtendLastCommand + the CreateBackwardReferences prologue (shared with k_chain.h).
+DEV void q_setup_extend(const JobParams& J, QShard& g, bool want) {
+  const int t = q_t();
+  const uint32_t htl = hasher_htl(J.hasher_type);
   uint32_t bytes = g.blk_bytes, pos = g.blk_pos;
   bool ext = false;
   uint32_t cmd_dist = 0;

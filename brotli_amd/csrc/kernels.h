@@ -7,10 +7,15 @@
 #include "k_round.h"
 #include "k_parse4.h"
 #include "k_parse_deep.h"
+#include "k_index.h"
+#include "k_chain.h"
 
 // Register budgets (waves per SIMD the compiler must leave room for).
 #ifndef PARSE4_WAVES
 #define PARSE4_WAVES 4
+#endif
+#ifndef CHAIN_WAVES
+#define CHAIN_WAVES 4
 #endif
 #ifndef BUILD_WAVES
 #define BUILD_WAVES 4
@@ -70,6 +75,44 @@ __global__ void __launch_bounds__(64, PARSE4_WAVES) k_parse4(JobArgs a) {
   const uint32_t gi = (threadIdx.x >> 4) >> (duo ? 1 : 0);
   const uint32_t shard = blockIdx.x * gpw + gi;
   if ((threadIdx.x & (duo ? 31 : 15)) == 0 && gi < gpw && shard < a.nshards && a.states[shard].error)
+    glb_atomic_add(&a.counters[1], 1u);
+}
+
+// ---- indexed quality-5 parse (k_index.h, k_chain.h) ----------------------------------------
+// grid = nshards * ix_slices, block = 64
+__global__ void __launch_bounds__(64) k_ix_count(JobArgs a) {
+  __shared__ uint32_t lds_cnt[IX_NB];
+  const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
+  if (shard >= a.nshards) return;
+  ix_count(a.J, a.shards[shard], a.input, a.ws, w, lds_cnt);
+}
+// grid = nshards, block = 64
+__global__ void __launch_bounds__(64) k_ix_scan(JobArgs a) {
+  if (blockIdx.x >= a.nshards) return;
+  ix_scan(a.J, a.shards[blockIdx.x], a.ws);
+}
+// grid = nshards * ix_slices, block = 64
+__global__ void __launch_bounds__(64) k_ix_scatter(JobArgs a) {
+  __shared__ uint32_t lds_off[IX_NB];
+  const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
+  if (shard >= a.nshards) return;
+  ix_scatter(a.J, a.shards[shard], a.input, a.ws, w, lds_off);
+}
+// grid = nshards * IX_NB, block = 64: one wave per (shard, first-level bucket)
+__global__ void __launch_bounds__(64) k_ix_bucket(JobArgs a) {
+  __shared__ uint32_t lds_b[IX_BUCKET_LDS_WORDS];
+  const uint32_t shard = blockIdx.x / IX_NB, b = blockIdx.x % IX_NB;
+  if (shard >= a.nshards) return;
+  ix_bucket(a.J, a.shards[shard], a.input, a.ws, b, lds_b);
+}
+// grid = ceil(nshards / shards per wave), block = 64
+__global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain(JobArgs a) {
+  __shared__ uint32_t lds_c[C_LDS_WORDS];
+  chain_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c);
+  const uint32_t gpw = q_groups_per_wave(a.J);
+  const uint32_t gi = threadIdx.x >> 4;
+  const uint32_t shard = blockIdx.x * gpw + gi;
+  if ((threadIdx.x & 15) == 0 && gi < gpw && shard < a.nshards && a.states[shard].error)
     glb_atomic_add(&a.counters[1], 1u);
 }
 

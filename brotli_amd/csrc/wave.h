@@ -53,6 +53,8 @@ static inline void wave_equal_neighbours(uint32_t v, int n, int* prev, int* next
 }
 // Rotation inside rows of 16 lanes (DPP row_ror on the device).
 #define wave_row_ror(v, k) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), (wave_lane() & 48) | ((wave_lane() + (k)) & 15), WAVE_SITE))
+// Exchange inside quads of 4 lanes (DPP quad_perm on the device).
+#define wave_quad_xor(v, m) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), wave_lane() ^ (m), WAVE_SITE))
 
 #else  // ---- gfx950 ---------------------------------------------------------
 
@@ -126,6 +128,8 @@ __device__ __forceinline__ void wave_equal_neighbours(uint32_t v, int n, int* pr
 // Rotation inside rows of 16 lanes: one VALU v_mov_b32 with DPP row_ror:k, no
 // LDS crossbar round trip (ds_bpermute costs ~100 cycles of latency each).
 #define wave_row_ror(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x120 + (k), 0xF, 0xF, true))
+// Value of lane ^ m (m = 1 or 2) inside quads of 4 lanes: DPP quad_perm [1,0,3,2] / [2,3,0,1].
+#define wave_quad_xor(v, m) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (m) == 1 ? 0xB1 : 0x4E, 0xF, 0xF, true))
 
 #endif
 

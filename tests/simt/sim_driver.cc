@@ -22,6 +22,26 @@ void run(void (*fn)(JobArgs), const JobArgs& a, unsigned grid, unsigned block, i
   Launch l{fn, a};
   simt::launch(grid, block, tramp, &l, reverse);
 }
+// The index kernels of an indexed job (k_index.h), once per job.
+void run_index(const JobArgs& a, int reverse) {
+  run(k_ix_count, a, a.nshards * a.J.ix_slices, 64, reverse);
+  run(k_ix_scan, a, a.nshards, 64, reverse);
+  run(k_ix_scatter, a, a.nshards * a.J.ix_slices, 64, reverse);
+  run(k_ix_bucket, a, a.nshards * IX_NB, 64, reverse);
+}
+void run_parse_kernel(const JobArgs& a, int reverse) {
+  if (a.J.flags & JOB_FLAG_DEEP) {
+    if (a.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
+    else if (a.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
+    else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
+  } else if (a.J.flags & JOB_FLAG_INDEXED) {
+    run(k_chain, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
+  } else if (a.J.flags & JOB_FLAG_QUAD) {
+    run(k_parse4, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
+  } else {
+    run(k_parse, a, a.nshards, 64, reverse);
+  }
+}
 }  // namespace
 
 extern "C" {
@@ -39,7 +59,8 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   if (no_pair & 2) plan.J.flags |= JOB_FLAG_QUAD;
   if (no_pair & 4) plan.J.flags |= JOB_FLAG_FORCE_SLOW;
   plan.J.flags |= (uint32_t)(no_pair & ~7);   // other job flags pass through (DUO, GROUPS)
-  if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~JOB_FLAG_QUAD) | JOB_FLAG_DEEP;
+  if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~(JOB_FLAG_QUAD | JOB_FLAG_INDEXED)) | JOB_FLAG_DEEP;
+  if (plan.J.flags & JOB_FLAG_INDEXED) plan_add_index(&plan, true);
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);
   std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
@@ -59,12 +80,8 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   uint32_t counters[16] = {0};
   a.counters = counters;
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
-  if (plan.J.flags & JOB_FLAG_DEEP) {
-    if (plan.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
-    else if (plan.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
-    else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
-  } else if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
-  else run(k_parse, a, a.nshards, 64, reverse);
+  if (plan.J.flags & JOB_FLAG_INDEXED) run_index(a, reverse);
+  run_parse_kernel(a, reverse);
   if (getenv("SIM_COUNTS")) {
     fprintf(stderr, "sim counts: steps=%llu with_bucket_cand=%llu ext=%llu store_steps=%llu dict=%llu slow=%llu dup=%llu\n",
             g_sim_counts[0], g_sim_counts[1], g_sim_counts[2], g_sim_counts[3], g_sim_counts[4], g_sim_counts[5], g_sim_counts[6]);
@@ -97,7 +114,8 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   JobPlan plan;
   if (!plan_job(len, quality, lgwin, size_hint, shard_size, stream_base, is_last != 0, &plan)) return -2;
   plan.J.flags |= (uint32_t)flags;
-  if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~JOB_FLAG_QUAD) | JOB_FLAG_DEEP;
+  if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~(JOB_FLAG_QUAD | JOB_FLAG_INDEXED)) | JOB_FLAG_DEEP;
+  if (plan.J.flags & JOB_FLAG_INDEXED) plan_add_index(&plan, true);
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);
   std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
@@ -117,14 +135,10 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   uint32_t counters[16] = {0};
   a.counters = counters;
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
+  if (plan.J.flags & JOB_FLAG_INDEXED) run_index(a, reverse);
   for (int round = 0; round < 100000; ++round) {
     memset(counters, 0, sizeof(counters));
-    if (plan.J.flags & JOB_FLAG_DEEP) {
-      if (plan.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
-      else if (plan.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
-      else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
-    } else if (plan.J.flags & JOB_FLAG_QUAD) run(k_parse4, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
-    else run(k_parse, a, a.nshards, 64, reverse);
+    run_parse_kernel(a, reverse);
     run(k_build, a, a.nshards, 64, reverse);
     if (getenv("SIM_DEBUG")) {
       for (size_t k = 0; k < plan.shards.size(); ++k) {
@@ -147,6 +161,11 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
     run(k_store, a, a.nshards, 64, reverse);
     if (counters[1]) return -3;
     if (counters[0] == 0) break;
+  }
+  if (getenv("SIM_COUNTS") && (plan.J.flags & JOB_FLAG_INDEXED)) {
+    uint64_t se = 0, sl = 0;
+    for (const ShardState& S : states) { se += S.stat_searches; sl += S.ix_slow; }
+    fprintf(stderr, "indexed parse: %llu searches, %llu exact (in-chain) searches\n", (unsigned long long)se, (unsigned long long)sl);
   }
   size_t n = 0;
   for (size_t k = 0; k < plan.shards.size(); ++k) {
