@@ -356,7 +356,7 @@ def main():
                 "compressed_bytes": out_total, "ratio": round(total / out_total, 4),
                 "parse_ms_per_step": [round(i["ms_parse"], 1) for i in infos],
                 "stage_ms": {k: round(sum(i[k] for i in infos) / len(infos), 3) for k in
-                             ("ms_total", "ms_init", "ms_parse", "ms_build", "ms_store", "ms_gather")},
+                             ("ms_total", "ms_init", "ms_index", "ms_parse", "ms_build", "ms_store", "ms_gather")},
             },
             "roofline": {"bound": "hbm", "kernel": "k_parse4" if args.quality == 5 else "k_parse_deep", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),

@@ -34,6 +34,7 @@ struct BrotliAmdCtx {
   // 128 GiB hipMalloc for 4096 quality-9 tables fails where eight 16 GiB ones succeed).
   std::vector<uint8_t*> d_table_chunks;
   uint64_t chunk_shards = 0, chunk_shard_bytes = 0;
+  uint64_t ix_region_bytes = 0;     // indexed job being planned: bytes of one shard's index region
 
   ShardDesc* d_shards = nullptr;
   ShardState* d_states = nullptr;
@@ -51,6 +52,7 @@ struct BrotliAmdCtx {
   uint64_t* d_fresult = nullptr;
   uint64_t ffrag_cap = 0, fblock_cap = 0;
   hipEvent_t ev[8] = {};
+  hipEvent_t ev_ix = nullptr;
   std::string err;
 };
 
@@ -109,9 +111,11 @@ bool ensure_log2(BrotliAmdCtx* c, uint32_t n) {
 // shard; cleared by k_init at the start of every job).
 bool prepare_tables(BrotliAmdCtx* c, JobPlan* plan) {
   const uint64_t TABLE_CHUNK = 16ull << 30;
-  const uint64_t tbytes = (uint64_t)plan->J.rec_bytes << plan->J.bucket_bits;
+  const bool indexed = (plan->J.flags & JOB_FLAG_INDEXED) != 0;
+  const uint64_t tbytes = indexed ? c->ix_region_bytes : (uint64_t)plan->J.rec_bytes << plan->J.bucket_bits;
   const uint64_t nbytes = (plan->J.flags & JOB_FLAG_DEEP) ? ((uint64_t)2 << plan->J.bucket_bits) : 0;
   const uint64_t per = tbytes + nbytes;            // records, then the counters of the same shard
+                                                   // (indexed job: the shard's index region instead)
   const uint64_t n = plan->shards.size();
   uint64_t per_chunk = TABLE_CHUNK / per;
   if (per_chunk < 1) per_chunk = 1;
@@ -134,6 +138,7 @@ bool prepare_tables(BrotliAmdCtx* c, JobPlan* plan) {
     uint8_t* base = c->d_table_chunks[k / c->chunk_shards] + (k % c->chunk_shards) * per;
     plan->shards[k].table_off = (uint64_t)(base - c->d_ws);            // ws + off (mod 2^64)
     plan->shards[k].num_off = (uint64_t)(base + tbytes - c->d_ws);
+    if (indexed) plan->shards[k].ix_off = plan->shards[k].table_off;
   }
   return true;
 }
@@ -173,6 +178,22 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
     fail(c, "quality %d needs shards of at most %u bytes", plan->J.quality, too_long);
     return BROTLI_AMD_UNSUPPORTED;
   }
+  // Quality 5 on shards that fit the window: the position index + table-free chain.
+  c->ix_region_bytes = 0;
+  if ((plan->J.flags & JOB_FLAG_QUAD) && !(p->flags & BROTLI_AMD_FLAG_NO_INDEX)) {
+    const char* e = getenv("BROTLI_AMD_INDEXED");
+    if (!e || atoi(e) != 0) {
+      c->ix_region_bytes = plan_add_index(plan, /*ix_in_ws=*/false);
+      plan->J.flags &= ~(uint32_t)JOB_FLAG_DUO;
+      // shards per wave of k_chain: one 16-lane group per shard, as many waves as stay resident
+      const uint64_t resident = (uint64_t)c->num_cus * 4u * CHAIN_WAVES;
+      const uint64_t ns = plan->shards.size();
+      uint32_t v = ns <= resident ? 1u : ns <= 2 * resident ? 2u : 4u;
+      if (const char* g = getenv("BROTLI_AMD_CGROUPS")) v = (uint32_t)atoi(g);
+      plan->J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
+      if (v == 1 || v == 2) plan->J.flags |= v << JOB_FLAG_GROUPS_SHIFT;
+    }
+  }
   return BROTLI_AMD_OK;
 }
 
@@ -207,8 +228,19 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
 
   const uint32_t gpw = ((plan.J.flags >> JOB_FLAG_GROUPS_SHIFT) & 3u) ? ((plan.J.flags >> JOB_FLAG_GROUPS_SHIFT) & 3u) : 4u;
   float ms_parse = 0, ms_build = 0, ms_store = 0;
+  const bool indexed = (plan.J.flags & JOB_FLAG_INDEXED) != 0;
+  if (indexed) a.init_blocks_per_shard = ibs = 1;
   hipLaunchKernelGGL(k_init, dim3(nshards * ibs), dim3(256), 0, c->stream, a);
   HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
+  float ms_index = 0;
+  if (indexed) {
+    // the data-parallel half of the parse, once per job (k_index.h)
+    hipLaunchKernelGGL(k_ix_count, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_ix_scan, dim3(nshards), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_ix_scatter, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_ix_bucket, dim3(nshards * IX_NB), dim3(64), 0, c->stream, a);
+    HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
+  }
   uint32_t rounds = 0;
   for (;;) {
     HIP_OK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
@@ -217,7 +249,9 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       if (plan.J.block_bits <= 6) hipLaunchKernelGGL(k_parse_deep<1>, dim3(nshards), dim3(64), 0, c->stream, a);
       else if (plan.J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(nshards), dim3(64), 0, c->stream, a);
       else hipLaunchKernelGGL(k_parse_deep<4>, dim3(nshards), dim3(64), 0, c->stream, a);
-    } else if (plan.J.flags & JOB_FLAG_QUAD)
+    } else if (indexed)
+      hipLaunchKernelGGL(k_chain, dim3((nshards + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, a);
+    else if (plan.J.flags & JOB_FLAG_QUAD)
       hipLaunchKernelGGL(k_parse4, dim3((nshards + gpw - 1) / gpw), dim3(64), 0, c->stream, a);
     else
       hipLaunchKernelGGL(k_parse, dim3(nshards), dim3(64), 0, c->stream, a);
@@ -242,6 +276,8 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     float t;
     HIP_OK(c, hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
     info->ms_init = t;
+    if (indexed) { HIP_OK(c, hipEventElapsedTime(&ms_index, c->ev[1], c->ev_ix)); }
+    info->ms_index = ms_index;
     info->ms_parse = ms_parse;
     info->ms_build = ms_build;
     info->ms_store = ms_store;
@@ -282,6 +318,7 @@ int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** ou
     c->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIP_OK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_OK(c, hipEventCreate(&e));
+    HIP_OK(c, hipEventCreate(&c->ev_ix));
     if (!dev_upload(c, &c->d_lut, c->ht.context_lut, 2048)) return false;
     if (!dev_upload(c, &c->d_dict, c->ht.dict.data(), c->ht.dict.size())) return false;
     if (!dev_upload(c, &c->d_hash_words, c->ht.hash_words.data(), 32768 * 2)) return false;
@@ -302,6 +339,7 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (uint8_t* p : c->d_table_chunks) if (p) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->ev_ix) (void)hipEventDestroy(c->ev_ix);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -778,6 +816,7 @@ int brotli_amd_debug_parse(BrotliAmdCtx* c, const void* d_in, uint64_t len,
     const uint64_t m = st[k].ncmds;
     info->searches += st[k].stat_searches;
     info->search_steps += st[k].stat_pairs;
+    info->exact_searches += st[k].ix_slow;
     for (int i = 0; i < 12; ++i) info->prof[i] += st[k].prof[i];
     if (n + m <= cmd_cap && m) {
       if (hipMemcpy(dst + n, c->d_ws + plan.shards[k].cmds_off, m * sizeof(Command),

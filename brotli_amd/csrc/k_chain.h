@@ -29,7 +29,7 @@
 #include "k_index.h"
 #include "k_parse4.h"
 
-#define C_GROUP_LDS_WORDS (IX_BLOOM_WORDS + 16u)   // Bloom filter + the 16 ring slots of c_search_exact
+#define C_GROUP_LDS_WORDS (IX_BLOOM_WORDS + IX_SKIPTAB_WORDS + 16u)   // key bitmap, newest-unstored table, 16 ring slots
 #define C_LDS_WORDS (Q_GROUPS * C_GROUP_LDS_WORDS)
 
 struct CShard {
@@ -42,8 +42,20 @@ struct CShard {
   uint32_t nslow;
 };
 
-DEV bool c_bloom_hit(const uint32_t* bloom, uint32_t key) {
-  return (bloom[(key & 4095u) >> 5] >> (key & 31u)) & 1u;
+// Which keys have unstored positions, and does one of them sit in the window of a search?
+//   bloom[key >> 5] bit (key & 31): some storable position of this key was passed over;
+//   tab[key & 255] (behind the bitmap): {1, key >> 8 (7 bits), sorted index (24 bits)} of the
+//   NEWEST unstored position of the one key that owns the slot, 0 = empty, C_TAB_CONFLICT =
+//   several keys hit the slot (then the bitmap alone decides).
+// A search at sorted index s looks at the sorted indices s - 16 .. s - 1 of its key run
+// (k_index.h); an unstored position matters iff it is one of them, and if the newest one of
+// the key is not, no older one is.
+#define C_TAB_CONFLICT 0x7FFFFFFFu
+DEV bool c_bloom_hit(const uint32_t* bloom, uint32_t key, uint32_t sidx) {
+  if (!((bloom[key >> 5] >> (key & 31u)) & 1u)) return false;
+  const uint32_t e = bloom[IX_BLOOM_WORDS + (key & 255u)];
+  if (!(e & 0x80000000u) || ((e >> 24) & 127u) != (key >> 8)) return true;
+  return sidx - (e & 0xFFFFFFu) - 1u < 16u;
 }
 
 // Marks the storable positions of [a, b) as not stored — except, for a literal spree
@@ -57,11 +69,25 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
     const uint32_t x = cur + (uint32_t)t;
     bool sk = on && x < b && ix_storable(C.geo, x);
     if (sk && stride > 1u && ((x - sfirst) % stride) == 0u) sk = false;
+    uint32_t key = 0, entry = 0;
     if (sk) {
-      const KeyTag kt = hash_pos(ld64(C.g.data + x), J.hasher_type, J.bucket_bits);
-      lds_atomic_or(&bloom[(kt.key & 4095u) >> 5], 1u << (kt.key & 31u));
+      key = hash_pos(ld64(C.g.data + x), J.hasher_type, J.bucket_bits).key;
+      lds_atomic_or(&bloom[key >> 5], 1u << (key & 31u));
+      entry = 0x80000000u | ((key >> 8) << 24) | ((uint32_t)(C.res[x] >> 32) & 0xFFFFFFu);
     }
     const uint32_t m16 = q_mask16(wave_ballot(sk));
+    // the newest-unstored table, one lane at a time in position order
+    for (uint32_t left = m16; wave_any(left != 0); left &= left - 1u) {
+      if (left != 0 && (uint32_t)t == (uint32_t)dev_ctz32(left)) {
+        uint32_t* slot = &bloom[IX_BLOOM_WORDS + (key & 255u)];
+        const uint32_t e = *slot;
+        *slot = (e == 0 || ((e & 0x80000000u) && ((e ^ entry) >> 24) == 0)) ? entry : C_TAB_CONFLICT;
+      }
+      wave_sync();
+    }
+#if defined(BROTLI_AMD_SIMT_SIM)
+    if (on && t == 0 && m16 != 0) { g_sim_counts[13] += (unsigned)__builtin_popcount(m16); if (getenv("SIM_SKIPS")) fprintf(stderr, "skip [%u..] mask %x (range %u..%u stride %u)\n", cur, m16, a, b, stride); }
+#endif
     if (on && t == 0 && m16 != 0) {
       uint8_t* p = C.skip + (cur >> 3);
       st32(p, ld32(p) | (m16 << (cur & 7u)));
@@ -203,7 +229,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   const ShardDesc& D = shards[alive ? shard : 0];
   const ShardState* S0 = &states[alive ? shard : 0];
   uint32_t* bloom = lds + gi * C_GROUP_LDS_WORDS;
-  uint32_t* scratch = bloom + IX_BLOOM_WORDS;
+  uint32_t* scratch = bloom + IX_BLOOM_WORDS + IX_SKIPTAB_WORDS;
   const int kpos = t >> 2, idc = t & 3;          // this lane's probe: position P0 + kpos, cache entry idc
 
   CShard C;
@@ -245,12 +271,15 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   C.nslow = 0;
   {
     const uint32_t* gb = (const uint32_t*)(ixb + L.bloom);
-    for (uint32_t i = (uint32_t)t; i < IX_BLOOM_WORDS; i += 16u) bloom[i] = participated ? gb[i] : 0u;
+    for (uint32_t i = (uint32_t)t; i < IX_BLOOM_WORDS + IX_SKIPTAB_WORDS; i += 16u) bloom[i] = participated ? gb[i] : 0u;
   }
   wave_sync();
   const bool force_slow = (J.flags & JOB_FLAG_FORCE_SLOW) != 0;
 
+  uint32_t nsteps = 0;
   while (wave_any(g.state != Q_DONE)) {
+    SIM_COUNT(7, 1);                                   // chain steps (wave level)
+    uint64_t qt = QP_NOW();
     if (g.state == Q_PRE) q_driver_pre(J, g);
     if (wave_any(g.state == Q_SETUP)) {
       const bool su = g.state == Q_SETUP;
@@ -275,33 +304,45 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       if (want) C.frontier = umax(C.frontier, P0);
       wave_sync();
 
+      ++nsteps;
+      QP_ADD(g, 0, qt);
       // ---- evaluation: lane (kpos, idc) ----
       const uint32_t Pk = P0 + (uint32_t)kpos;
       const bool ev = want && Pk + htl <= g.pos_end;
       const uint32_t max_length = g.pos_end - Pk;
-      const B32 cur32 = load_b32(g.data + (ev ? Pk : 0u));
+      uint64_t cb[2], pb[2];
+      __builtin_memcpy(cb, g.data + (ev ? Pk : 0u), 16);
       const uint32_t backward = q_dc_entry(g, idc);
       const bool d_cand = ev && idc < J.ndist && (int32_t)backward > 0 && backward <= umin(Pk, J.max_backward_limit);
-      const B32 pd = load_b32(g.data + (d_cand ? Pk - backward : 0u));
+      __builtin_memcpy(pb, g.data + (d_cand ? Pk - backward : 0u), 16);
       const uint64_t rw = ev ? C.res[Pk] : 0ull;
       uint32_t d_len = 0;
       {
-        const uint32_t md = common_prefix32(cur32, pd);
+        const uint64_t x0 = cb[0] ^ pb[0], x1 = cb[1] ^ pb[1];
+        const uint32_t md = x0 ? ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 8u + ((uint32_t)dev_ctz64(x1) >> 3) : 16u;
         bool d_ext = false;
-        if (d_cand) { d_len = umin(md, max_length); d_ext = md == 32u && max_length > 32u; }
-        if (wave_any(d_ext)) { if (d_ext) d_len = q_extend(g.data, Pk, Pk - backward, max_length); }
+        if (d_cand) { d_len = umin(md, max_length); d_ext = md == 16u && max_length > 16u; }
+        if (wave_any(d_ext)) { if (d_ext) d_len = c_extend_from(g.data, Pk, Pk - backward, max_length, 16u); }
       }
-      uint32_t d_score = 135u * d_len + 1935u;
-      if (idc != 0) d_score -= 39u + ((0x1CA10u >> ((uint32_t)idc & 0xEu)) & 0xEu);
+#if defined(Q_PROFILE)
+      if (wave_any(d_len == 0xFFFFFFFFu || rw == 0x123456789ull)) g.pf_acc++;   // (profiling fence: loads consumed)
+#endif
+      QP_ADD(g, 1, qt);
+      // Distance-cache winner of the position (:201-240).  The score is 135 * len + 1935 - penalty(i)
+      // with penalties 0, 39, 43, 43 < 135: ordering by (len, earlier entry) is ordering by score
+      // with the reference's first-wins tie break, so one reduction of len << 2 | (3 - i) is enough.
       const bool d_ok = d_cand && (d_len >= 3u || (d_len == 2u && idc < 2));
-      const uint32_t d_key = d_ok ? (d_score << 2) | (3u - (uint32_t)idc) : 0u;
+      const uint32_t d_key = d_ok ? (d_len << 2) | (3u - (uint32_t)idc) : 0u;
       uint32_t d_best = umax(d_key, wave_quad_xor(d_key, 1));
       d_best = umax(d_best, wave_quad_xor(d_best, 2));
-      const uint32_t dc_score = d_best ? (d_best >> 2) : K_MIN_SCORE;
-      const bool d_win = d_key != 0 && d_key == d_best;
-      uint32_t dc_len = d_win ? d_len : 0u, dc_dist = d_win ? backward : 0u;
-      dc_len = umax(dc_len, wave_quad_xor(dc_len, 1)); dc_len = umax(dc_len, wave_quad_xor(dc_len, 2));
-      dc_dist = umax(dc_dist, wave_quad_xor(dc_dist, 1)); dc_dist = umax(dc_dist, wave_quad_xor(dc_dist, 2));
+      const uint32_t dc_len = d_best >> 2;
+      const uint32_t dc_i = 3u - (d_best & 3u);
+      const uint32_t dc_dist = q_dc_entry(g, (int)dc_i);
+      uint32_t dc_score = K_MIN_SCORE;
+      if (d_best != 0) {
+        dc_score = 135u * dc_len + 1935u;
+        if (dc_i != 0) dc_score -= 39u + ((0x1CA10u >> (dc_i & 0xEu)) & 0xEu);
+      }
       // the bucket part, from the index
       const uint32_t rlo = (uint32_t)rw, rhi = (uint32_t)(rw >> 32);
       const uint32_t kind = rlo >> 30;
@@ -313,68 +354,125 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       }
       const bool b_ok = ev && (kind == IX_KIND_EXACT || kind == IX_KIND_LONG);
       const uint32_t b_score = b_ok ? 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u) : 0u;
-      const uint32_t keyP = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits).key;
+      const uint32_t keyP = hash_pos(cb[0], J.hasher_type, J.bucket_bits).key;
       const bool b_wins = b_ok && b_score > dc_score;
       const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & IX_DANGER) != 0 || force_slow ||
-                                     c_bloom_hit(bloom, keyP) ||
+                                     c_bloom_hit(bloom, keyP, rhi & 0xFFFFFFu) ||
                                      (b_wins && b_len <= umax(dc_len, 3u)));
+#if defined(BROTLI_AMD_SIMT_SIM)
+      if (ev && idc == 0 && getenv("SIM_DBGPOS") && Pk == (uint32_t)atoi(getenv("SIM_DBGPOS")))
+        fprintf(stderr, "P %u key %x bit %u slot %x sidx %u kind %u blen %u bdist %u dc_len %u frontier %u\n", Pk, keyP,
+                (bloom[keyP >> 5] >> (keyP & 31)) & 1, bloom[IX_BLOOM_WORDS + (keyP & 255)], rhi & 0xFFFFFF, kind, b_len, b_dist, dc_len, C.frontier);
+      if (ev && idc == 0) {   // (statistics of the simulator runs: why positions go to the exact path)
+        if (kind == IX_KIND_SLOW) g_sim_counts[8]++;
+        else if (c_bloom_hit(bloom, keyP, rhi & 0xFFFFFFu)) g_sim_counts[9]++;
+        else if (b_wins && b_len <= umax(dc_len, 3u)) g_sim_counts[10]++;
+        if (kind == IX_KIND_LONG) g_sim_counts[11]++;
+        g_sim_counts[12]++;
+      }
+#endif
       uint32_t e_len = 0, e_dist = 0, e_score = K_MIN_SCORE;
       if (b_wins) { e_len = b_len; e_dist = b_dist; e_score = b_score; }
       else if (d_best != 0) { e_len = dc_len; e_dist = dc_dist; e_score = dc_score; }
       const uint32_t e_flags = e_score | (ev ? 0x80000000u : 0u) | (need_exact ? 0x40000000u : 0u);
+      uint32_t fl[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) fl[k] = q_bcast(e_flags, 4 * k);
 
-      // ---- consumption: the state machine takes P0, P0 + 1, ... while it may ----
-      bool go = want;
+      QP_ADD(g, 2, qt);
+      // ---- the common transitions, all four positions in registers (:44-164) ----
+      // SEARCH + hit -> LAZY; SEARCH + miss -> one more literal (only while neither the static
+      // dictionary nor the literal spree can come into play); LAZY -> stay lazy or commit.
+      uint32_t consumed = 0, sr_from = 7u;
+      bool commit = false, stop = !want;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        if (!wave_any(go)) break;
-        const uint32_t Pq = P0 + (uint32_t)k;
-        const uint32_t f = q_bcast(e_flags, 4 * k);
-        QResult cur;
-        cur.len = q_bcast(e_len, 4 * k);
-        cur.distance = q_bcast(e_dist, 4 * k);
-        cur.score = f & 0x3FFFFFFFu;
-        cur.delta = 0;
-        // does the state machine ask for exactly this position now?
-        bool take = go && (f & 0x80000000u) != 0;
-        if (take) {
-          if (g.state == Q_SEARCH) take = g.position == Pq && g.position + htl < g.pos_end;
-          else take = g.state == Q_LAZY && g.position + 1u == Pq;
-        }
-        go = take;
-        const bool exact = take && (f & 0x40000000u) != 0;
-        if (wave_any(exact)) {
-          const QResult s = c_search_exact(J, C, exact, Pq, scratch);
-          if (exact) { cur = s; ++C.nslow; }
-        }
-        if (take) C.frontier = Pq + 1u;          // FindLongestMatch stores the position it searched
-        // static dictionary when nothing was found (hash.h:179-202)
-        q_dict_search(J, T, g, take && cur.score == K_MIN_SCORE, Pq, g.pos_end - Pq, cur);
-        if (take) g.stat_searches++;
-        const bool commit = q_transition(J, g, take, cur, htl);
-        // what the transition stored: the copied range (StoreRange) or the literal spree
-        if (wave_any(take && g.st_count != 0)) {
-          const bool st = take && g.st_count != 0;
-          if (wave_any(st && g.st_stride == 1u))
-            c_stored(J, C, st && g.st_stride == 1u, g.st_first, g.st_first + g.st_count, bloom);
-          if (wave_any(st && g.st_stride != 1u)) {
-            const bool sp = st && g.st_stride != 1u;
-            c_stored(J, C, sp, g.st_first, g.st_first, bloom);
-            c_mark_range(J, C, sp, g.st_first, g.st_first + g.st_count * g.st_stride, g.st_first, g.st_stride, bloom);
-            if (sp) C.frontier = g.st_first + g.st_count * g.st_stride;
+        const uint32_t sk = fl[k] & 0x3FFFFFFFu;
+        const bool usable = (fl[k] >> 30) == 2u;                       // evaluated and decidable from the index
+        if (!stop && !usable) stop = true;
+        if (!stop) {
+          if (g.state == Q_SEARCH) {
+            if (!(g.position + htl < g.pos_end)) stop = true;
+            else if (sk > K_MIN_SCORE) {
+              g.sr_score = sk; sr_from = (uint32_t)k; g.delayed = 0; g.sr_delta = 0; g.state = Q_LAZY;
+              ++consumed;
+            } else if (g.dict_matches < (g.dict_lookups >> 7) && g.position + 1u <= g.apply_random_heuristics) {
+              ++g.insert_length; ++g.position; ++consumed;
+            } else stop = true;
+          } else if (sk == K_MIN_SCORE && !(g.dict_matches < (g.dict_lookups >> 7))) {
+            stop = true;   // Q_LAZY, nothing found: the static dictionary is asked next (generic path)
+          } else {         // Q_LAZY
+            ++consumed;
+            if (sk >= g.sr_score + 175u) {
+              ++g.position; ++g.insert_length;
+              g.sr_score = sk; sr_from = (uint32_t)k; g.sr_delta = 0;
+              if (!(++g.delayed < 4u && g.position + htl < g.pos_end)) { commit = true; stop = true; }
+            } else { commit = true; stop = true; }
           }
-          if (st) { g.st_count = 0; go = false; }
         }
-        if (commit) go = false;                   // the distance cache changed: later probes are stale
       }
+      QP_ADD(g, 3, qt);
+      if (want && consumed != 0) { C.frontier = P0 + consumed; g.stat_searches += consumed; }
+      // the pending match sits in the quad that evaluated it
+      if (wave_any(sr_from != 7u)) {
+        const int src = q_base() | (int)((sr_from & 3u) << 2);
+        const uint32_t l = wave_shfl(e_len, src), d = wave_shfl(e_dist, src);
+        if (sr_from != 7u) { g.sr_len = l; g.sr_dist = d; }
+      }
+      bool committed = commit;
+      if (wave_any(commit)) q_commit(J, g, commit, htl);
+
+      QP_ADD(g, 4, qt);
+      // ---- everything else, one position: exact search, dictionary, spree, block end ----
+      const bool gen = want && consumed == 0;
+      if (wave_any(gen)) {
+        QResult cur;
+        cur.len = q_bcast(e_len, 0);
+        cur.distance = q_bcast(e_dist, 0);
+        cur.score = fl[0] & 0x3FFFFFFFu;
+        cur.delta = 0;
+        bool take = gen && (fl[0] & 0x80000000u) != 0;
+        if (take) {
+          if (g.state == Q_SEARCH) take = g.position == P0 && g.position + htl < g.pos_end;
+          else take = g.state == Q_LAZY && g.position + 1u == P0;
+        }
+        if (gen && !take) { g.status |= QST_ERROR | QST_DONE; g.state = Q_DONE; }   // cannot happen: fail, do not spin
+        const bool exact = take && (fl[0] & 0x40000000u) != 0;
+        if (wave_any(exact)) {
+          const QResult sx = c_search_exact(J, C, exact, P0, scratch);
+          if (exact) { cur = sx; ++C.nslow; }
+        }
+        if (take) C.frontier = P0 + 1u;          // FindLongestMatch stores the position it searched
+        // static dictionary when nothing was found (hash.h:179-202)
+        q_dict_search(J, T, g, take && cur.score == K_MIN_SCORE, P0, g.pos_end - P0, cur);
+        if (take) g.stat_searches++;
+        committed = q_transition(J, g, take, cur, htl) || committed;
+      }
+      QP_ADD(g, 5, qt);
+      // what the step stored: the copied range (StoreRange) or the literal spree
+      if (wave_any(want && g.st_count != 0)) {
+        const bool st = want && g.st_count != 0;
+        if (wave_any(st && g.st_stride == 1u))
+          c_stored(J, C, st && g.st_stride == 1u, g.st_first, g.st_first + g.st_count, bloom);
+        if (wave_any(st && g.st_stride != 1u)) {
+          const bool sp = st && g.st_stride != 1u;
+          c_stored(J, C, sp, g.st_first, g.st_first, bloom);
+          c_mark_range(J, C, sp, g.st_first, g.st_first + g.st_count * g.st_stride, g.st_first, g.st_stride, bloom);
+          if (sp) C.frontier = g.st_first + g.st_count * g.st_stride;
+        }
+        if (st) g.st_count = 0;
+      }
+      (void)committed;
+      QP_ADD(g, 6, qt);
     }
     if (g.state == Q_POST) q_driver_post(J, g, writer);
+    QP_ADD(g, 7, qt);
   }
 
   wave_sync();
   if (participated) {
     uint32_t* gb = (uint32_t*)(ixb + L.bloom);
-    for (uint32_t i = (uint32_t)t; i < IX_BLOOM_WORDS; i += 16u) gb[i] = bloom[i];
+    for (uint32_t i = (uint32_t)t; i < IX_BLOOM_WORDS + IX_SKIPTAB_WORDS; i += 16u) gb[i] = bloom[i];
   }
   if (writer && participated) {
     ShardState* S = &states[shard];
@@ -393,7 +491,11 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       S->mb_raw = 0;
     }
     S->stat_searches += g.stat_searches;
-    S->stat_pairs += g.stat_searches;
+    S->stat_pairs += nsteps;
+    S->stat_b_used = g.pf_acc;
+#if defined(Q_PROFILE)
+    for (int i = 0; i < 12; ++i) S->prof[i] += g.prof[i];
+#endif
     S->ix_frontier = C.frontier;
     S->ix_slow += C.nslow;
   }

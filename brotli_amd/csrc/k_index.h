@@ -130,7 +130,7 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
   for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) skip[i] = 0;
   if (w == 0) {
     uint32_t* bloom = (uint32_t*)(base + L.bloom);
-    for (uint32_t i = (uint32_t)lane; i < IX_BLOOM_WORDS; i += 64u) bloom[i] = 0;
+    for (uint32_t i = (uint32_t)lane; i < IX_BLOOM_WORDS + IX_SKIPTAB_WORDS; i += 64u) bloom[i] = 0;
   }
   wave_sync();
 }
@@ -201,19 +201,6 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
 struct IxBest { uint32_t key, len, dist; };   // key = score << 5 | (16 - j), j = 1 newest
 
 DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + 135u * len - 30u * log2floor(dist); }
-
-// Bytes the strings at data+p and data+q share from offset 8 on, up to `limit` (> 8) and at
-// most IX_CAP; the first 8 are known to be equal.
-DEV uint32_t ix_extend8(const uint8_t* data, uint32_t p, uint32_t q, uint32_t limit) {
-  const uint32_t cap = umin(limit, IX_CAP);
-  uint32_t off = 8;
-  while (off < cap) {
-    const uint64_t x = ld64(data + p + off) ^ ld64(data + q + off);
-    if (x) { off += (uint32_t)dev_ctz64(x) >> 3; break; }
-    off += 8;
-  }
-  return umin(off, cap);
-}
 
 // lds: [0, 128) bin counts / starts, [128, 256) cursors, then (16 + 64) staged entries (16 B each)
 #define IX_BUCKET_LDS_WORDS (256u + 80u * 4u)
@@ -301,6 +288,10 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     for (uint32_t j = 1; j <= 16u; ++j) {
       IxEntry q;
       __builtin_memcpy(&q, &stage[4 * (16 + lane - (int)j)], 16);
+#if defined(BROTLI_AMD_SIMT_SIM)
+      if (getenv("SIM_DBGPOS") && act && p == (uint32_t)atoi(getenv("SIM_DBGPOS")))
+        fprintf(stderr, "ix p %u key %x tag %x rank %u search %d maxlen %u | j %u q %u qtag %x qkey %x\n", p, key, tag, rank, (int)search, max_length, j, q.w0 & 0xFFFFFF, q.w0 >> 24, q.w1);
+#endif
       if (!(search && j <= nwin)) continue;
       if ((q.w0 >> 24) != tag) continue;
       const uint64_t x = q.d ^ e.d;
@@ -312,22 +303,51 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
       if (k > best) { best = k; best_len = len; best_dist = dist; }
     }
-    // candidates equal in the first 8 bytes: compare on in the input
+    // candidates equal in the first 8 bytes: compare on in the input, four candidates per
+    // round trip (bytes 8..23 first; the few that are still equal fetch 24..39)
     uint32_t ncapped = 0, cap_key = 0, cap_dist = 0;
-    while (wave_ballot(longmask != 0) != 0) {
-      if (longmask != 0) {
-        const uint32_t j = (uint32_t)dev_ctz32(longmask);
-        longmask &= longmask - 1u;
-        IxEntry q;
-        __builtin_memcpy(&q, &stage[4 * (16 + lane - (int)j)], 16);
-        const uint32_t qp = q.w0 & 0xFFFFFFu;
-        const uint32_t len = ix_extend8(data, p, qp, max_length);
-        const uint32_t dist = p - qp;
-        const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
-        if (len == IX_CAP && max_length > IX_CAP) {
-          ++ncapped;
-          if (k > cap_key) { cap_key = k; cap_dist = dist; }
-        } else if (k > best) { best = k; best_len = len; best_dist = dist; }
+    if (wave_ballot(longmask != 0) != 0) {
+      uint64_t own[4] = {0, 0, 0, 0};
+      if (longmask != 0) __builtin_memcpy(own, data + p + 8u, 32);
+      while (wave_ballot(longmask != 0) != 0) {
+        uint32_t jj[4], qp[4], ln[4];
+        uint64_t c[4][2];
+        bool more = false;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          jj[u] = longmask != 0 ? (uint32_t)dev_ctz32(longmask) : 0u;
+          longmask &= longmask - 1u;
+          qp[u] = stage[4 * (16 + lane - (int)jj[u])] & 0xFFFFFFu;
+          c[u][0] = c[u][1] = 0;
+          if (jj[u] != 0) __builtin_memcpy(c[u], data + qp[u] + 8u, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint64_t x0 = c[u][0] ^ own[0], x1 = c[u][1] ^ own[1];
+          ln[u] = x0 ? 8u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 16u + ((uint32_t)dev_ctz64(x1) >> 3) : 24u;
+          if (jj[u] != 0 && ln[u] == 24u && max_length > 24u) more = true;
+        }
+        if (wave_ballot(more) != 0) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (jj[u] != 0 && ln[u] == 24u && max_length > 24u) {
+              __builtin_memcpy(c[u], data + qp[u] + 24u, 16);
+              const uint64_t x0 = c[u][0] ^ own[2], x1 = c[u][1] ^ own[3];
+              ln[u] = x0 ? 24u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 32u + ((uint32_t)dev_ctz64(x1) >> 3) : 40u;
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (jj[u] == 0) continue;
+          const uint32_t len = umin(ln[u], max_length);
+          const uint32_t dist = p - qp[u];
+          const uint32_t k = (ix_score(len, dist) << 5) | (16u - jj[u]);
+          if (len == IX_CAP && max_length > IX_CAP) {
+            ++ncapped;
+            if (k > cap_key) { cap_key = k; cap_dist = dist; }
+          } else if (k > best) { best = k; best_len = len; best_dist = dist; }
+        }
       }
     }
     if (act) {

@@ -14,7 +14,8 @@
 #define IX_NB_LOG2 8u
 #define IX_NB (1u << IX_NB_LOG2)              // first-level buckets (top key bits)
 #define IX_CAP 40u                            // bytes compared per candidate by ix_bucket
-#define IX_BLOOM_WORDS 128u                   // 4096-bit filter of the keys of unstored positions
+#define IX_BLOOM_WORDS 1024u                  // one bit per bucket key (<= 15 bits): keys of unstored positions
+#define IX_SKIPTAB_WORDS 256u                 // newest unstored position per key (direct mapped, k_chain.h)
 #define IX_KIND_NONE 0u
 #define IX_KIND_EXACT 1u                      // (len, distance) is the bucket loop's result
 #define IX_KIND_LONG 2u                       // one candidate matches >= IX_CAP bytes and wins however long it is
@@ -31,7 +32,7 @@ static inline IX_HD uint64_t ix_align(uint64_t x) { return (x + 255u) & ~(uint64
 static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, IxLayout* L) {
   uint64_t off = 0;
   L->cnt = off;   off = ix_align(off + 4ull * ((uint64_t)IX_NB * slices + 2));
-  L->bloom = off; off = ix_align(off + 4ull * IX_BLOOM_WORDS);
+  L->bloom = off; off = ix_align(off + 4ull * (IX_BLOOM_WORDS + IX_SKIPTAB_WORDS));
   L->skip = off;  off = ix_align(off + n / 8 + 32);
   L->srt = off;   off = ix_align(off + 4 * n + 16);
   L->res = off;   off = ix_align(off + 8 * n + 16);

@@ -694,6 +694,43 @@ DEV void q_setup_extend(const JobParams& J, QShard& g, bool want) {
   }
 }
 
+// Commits the pending match g.sr_* at g.position (:165-206): StoreRange bounds (left pending in
+// st_*), distance cache, command.  Shared with k_chain.h.
+DEV void q_commit(const JobParams& J, QShard& g, bool commit, uint32_t htl) {
+  const int t = q_t();
+  (void)t; (void)htl;
+  if (!commit) return;
+  g.state = Q_SEARCH;
+  // StoreRange bounds first, so that the bytes of the first insertion
+  // step (and the next search position's key) travel while the command
+  // is being built.
+  uint32_t range_start = g.position + 2u;
+  const uint32_t range_end = umin(g.position + g.sr_len, g.store_end);
+  if (g.sr_dist < (g.sr_len >> 2)) {
+    range_start = umin(range_end, umax(range_start, g.position + g.sr_len - (g.sr_dist << 2)));
+  }
+  if (range_start < range_end) {
+    g.st_first = range_start;
+    g.st_count = range_end - range_start;
+    g.st_stride = 1;
+#if defined(Q_EARLY_STX)
+    g.st_x = ld64(g.data + range_start + (uint32_t)t);
+    g.st_x_valid = 1;
+#endif
+  }
+  g.apply_random_heuristics = g.position + 2u * g.sr_len + J.spree_window;
+  const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit);
+  const uint32_t distance_code = compute_distance_code(g.sr_dist, dictionary_start, g.dc);
+  if (g.sr_dist <= dictionary_start && distance_code > 0) {
+    g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)g.sr_dist;
+  }
+  if (t == 0 && g.role == 0) g.cmds[g.r.ncmds] = make_command(g.insert_length, g.sr_len, g.sr_delta, distance_code);
+  ++g.r.ncmds;
+  g.r.nlits += g.insert_length;
+  g.insert_length = 0;
+  g.position += g.sr_len;
+}
+
 // One step of the CreateBackwardReferences state machine (:44-242) for the groups in
 // `act`, given the search result `cur` of the position they were waiting for.
 // Returns whether a command was committed (the copied range is then pending in st_*).
@@ -737,37 +774,7 @@ DEV bool q_transition(const JobParams& J, QShard& g, bool act, const QResult& cu
       if (++g.delayed < 4 && g.position + htl < g.pos_end) commit = false;
     }
   }
-  if (commit) {
-    g.state = Q_SEARCH;
-    // StoreRange bounds first, so that the bytes of the first insertion
-    // step (and the next search position's key) travel while the command
-    // is being built.
-    uint32_t range_start = g.position + 2u;
-    const uint32_t range_end = umin(g.position + g.sr_len, g.store_end);
-    if (g.sr_dist < (g.sr_len >> 2)) {
-      range_start = umin(range_end, umax(range_start, g.position + g.sr_len - (g.sr_dist << 2)));
-    }
-    if (range_start < range_end) {
-      g.st_first = range_start;
-      g.st_count = range_end - range_start;
-      g.st_stride = 1;
-#if defined(Q_EARLY_STX)
-      g.st_x = ld64(g.data + range_start + (uint32_t)t);
-      g.st_x_valid = 1;
-#endif
-    }
-    g.apply_random_heuristics = g.position + 2u * g.sr_len + J.spree_window;
-    const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit);
-    const uint32_t distance_code = compute_distance_code(g.sr_dist, dictionary_start, g.dc);
-    if (g.sr_dist <= dictionary_start && distance_code > 0) {
-      g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)g.sr_dist;
-    }
-    if (t == 0 && g.role == 0) g.cmds[g.r.ncmds] = make_command(g.insert_length, g.sr_len, g.sr_delta, distance_code);
-    ++g.r.ncmds;
-    g.r.nlits += g.insert_length;
-    g.insert_length = 0;
-    g.position += g.sr_len;
-  }
+  q_commit(J, g, commit, htl);
   return commit;
 }
 

@@ -44,7 +44,9 @@ __global__ void __launch_bounds__(256) k_init(JobArgs a) {
   const uint32_t b = blockIdx.x % a.init_blocks_per_shard;
   if (shard >= a.nshards) return;
   const ShardDesc& D = a.shards[shard];
-  if (a.J.flags & JOB_FLAG_DEEP) {
+  if (a.J.flags & JOB_FLAG_INDEXED) {
+    // no hash table: the index kernels clear what they use
+  } else if (a.J.flags & JOB_FLAG_DEEP) {
     // only the counters: 0xFFFF counting down (H68 / H58), 0 counting up (H5 / H6)
     uint32_t* nums = (uint32_t*)(a.ws + D.num_off);
     const uint32_t v = a.J.hasher_type >= 58 ? 0xFFFFFFFFu : 0u;
@@ -106,8 +108,13 @@ __global__ void __launch_bounds__(64) k_ix_bucket(JobArgs a) {
   ix_bucket(a.J, a.shards[shard], a.input, a.ws, b, lds_b);
 }
 // grid = ceil(nshards / shards per wave), block = 64
+// dynamic LDS: shards per wave * C_GROUP_LDS_WORDS * 4 bytes
 __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain(JobArgs a) {
+#if defined(BROTLI_AMD_SIMT_SIM)
   __shared__ uint32_t lds_c[C_LDS_WORDS];
+#else
+  extern __shared__ uint32_t lds_c[];
+#endif
   chain_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c);
   const uint32_t gpw = q_groups_per_wave(a.J);
   const uint32_t gi = threadIdx.x >> 4;

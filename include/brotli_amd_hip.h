@@ -61,6 +61,8 @@ typedef struct BrotliAmdJobParams {
 #define BROTLI_AMD_FLAG_NO_HEADER 8u  /* the stream header (window bits) has already been
                                          written by the caller (empty FLUSH at stream start,
                                          encode.c:1356-1415): the first shard starts byte aligned */
+#define BROTLI_AMD_FLAG_NO_INDEX 16u  /* quality 5: hash-table parse (k_parse4) instead of the position index
+                                         (k_index.h + k_chain.h) */
 
 typedef struct BrotliAmdJobInfo {
   uint64_t nshards;
@@ -71,9 +73,12 @@ typedef struct BrotliAmdJobInfo {
   uint32_t reserved;
   float ms_total;           /* HIP-event time of the whole job on the stream */
   float ms_init, ms_parse, ms_build, ms_store, ms_gather;
+  float ms_index;           /* indexed quality-5 job: the index kernels (k_index.h); ms_parse is the chain */
+  float reserved2;
   uint64_t searches;        /* FindLongestMatch calls (reference count) */
   uint64_t search_steps;    /* paired search steps actually executed */
   uint64_t commands;
+  uint64_t exact_searches;  /* indexed job: searches the chain had to redo itself (k_chain.h) */
   uint64_t prof[12];        /* debug_parse with a -DQ_PROFILE build: cycles per phase */
 } BrotliAmdJobInfo;
 

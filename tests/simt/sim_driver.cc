@@ -165,7 +165,10 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   if (getenv("SIM_COUNTS") && (plan.J.flags & JOB_FLAG_INDEXED)) {
     uint64_t se = 0, sl = 0;
     for (const ShardState& S : states) { se += S.stat_searches; sl += S.ix_slow; }
-    fprintf(stderr, "indexed parse: %llu searches, %llu exact (in-chain) searches\n", (unsigned long long)se, (unsigned long long)sl);
+    fprintf(stderr, "indexed parse: %llu searches, %llu exact (in-chain) searches; wave steps %llu; evaluated positions %llu: "
+            "index-undecidable %llu, bloom %llu, gate-dependent %llu, long %llu\n", (unsigned long long)se, (unsigned long long)sl,
+            g_sim_counts[7], g_sim_counts[12], g_sim_counts[8], g_sim_counts[9], g_sim_counts[10], g_sim_counts[11]);
+    memset(g_sim_counts, 0, sizeof(g_sim_counts));
   }
   size_t n = 0;
   for (size_t k = 0; k < plan.shards.size(); ++k) {

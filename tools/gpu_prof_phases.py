@@ -9,7 +9,10 @@ N = int(os.environ.get("PROBE_MB", "256")) << 20
 data = G.enwik_text(N)
 ctx = hip.Context(0)
 d = hip.to_device(data)
-names = ["record(after P bytes)", "ext+rest of cand", "resolve", "insert", "dict", "decide", "stores", "driver", "bytes at P", "dc strings", "bucket strings", "-"]
+if os.environ.get("PROBE_CHAIN"):
+    names = ["top/driver/marks", "loads -> dc len", "eval rest + bcast", "lean loop", "sr fetch + commit", "generic", "accounting", "post", "-", "-", "-", "-"]
+else:
+  names = ["record(after P bytes)", "ext+rest of cand", "resolve", "insert", "dict", "decide", "stores", "driver", "bytes at P", "dc strings", "bucket strings", "-"]
 for shard in [int(x) for x in os.environ.get("PROBE_SHARDS", "262144,65536").split(",")]:
     for rep in range(2):
         got, info = ctx.debug_parse(d, N, hip.make_params(5, 22, shard, 1 << 30))
