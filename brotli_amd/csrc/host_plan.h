@@ -123,9 +123,13 @@ static inline uint64_t plan_add_index(JobPlan* plan, bool ix_in_ws) {
   if (slices < 1) slices = 1;
   if (slices > 64) slices = 64;
   plan->J.ix_slices = slices;
+  uint32_t nb = IX_NB_MAX_LOG2 - 2u;                         // ~256 positions per bucket
+  while (nb < IX_NB_MAX_LOG2 && (longest >> nb) > 320u) ++nb;
+  if ((int)nb > plan->J.bucket_bits - 4) nb = (uint32_t)plan->J.bucket_bits - 4u;
+  plan->J.ix_nb_log2 = nb;
   plan->J.flags |= JOB_FLAG_INDEXED;
   IxLayout L;
-  ix_layout(longest, slices, &L);
+  ix_layout(longest, slices, nb, &L);
   if (ix_in_ws) {
     uint64_t off = plan->ws_bytes;
     for (ShardDesc& D : plan->shards) { D.ix_off = off; off = plan_align(off + L.bytes); }

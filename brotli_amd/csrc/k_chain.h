@@ -262,7 +262,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   const bool participated = g.state != Q_DONE;
   C.geo = ix_geom(J, D);
   IxLayout L;
-  ix_layout(D.len, J.ix_slices, &L);
+  ix_layout(D.len, J.ix_slices, J.ix_nb_log2, &L);
   uint8_t* ixb = ws + D.ix_off;
   C.res = (const uint64_t*)(ixb + L.res);
   C.srt = (const uint32_t*)(ixb + L.srt);
@@ -310,6 +310,24 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       const uint32_t Pk = P0 + (uint32_t)kpos;
       const bool ev = want && Pk + htl <= g.pos_end;
       const uint32_t max_length = g.pos_end - Pk;
+#if defined(C_PD32)
+      // 32-byte probes: a longer compare, fewer steps that need a second round trip
+      uint64_t cb[4], pb[4];
+      __builtin_memcpy(cb, g.data + (ev ? Pk : 0u), 32);
+      const uint32_t backward = q_dc_entry(g, idc);
+      const bool d_cand = ev && idc < J.ndist && (int32_t)backward > 0 && backward <= umin(Pk, J.max_backward_limit);
+      __builtin_memcpy(pb, g.data + (d_cand ? Pk - backward : 0u), 32);
+      const uint64_t rw = ev ? C.res[Pk] : 0ull;
+      uint32_t d_len = 0;
+      {
+        const uint64_t x0 = cb[0] ^ pb[0], x1 = cb[1] ^ pb[1], x2 = cb[2] ^ pb[2], x3 = cb[3] ^ pb[3];
+        const uint32_t md = x0 ? ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 8u + ((uint32_t)dev_ctz64(x1) >> 3)
+                          : x2 ? 16u + ((uint32_t)dev_ctz64(x2) >> 3) : x3 ? 24u + ((uint32_t)dev_ctz64(x3) >> 3) : 32u;
+        bool d_ext = false;
+        if (d_cand) { d_len = umin(md, max_length); d_ext = md == 32u && max_length > 32u; }
+        if (wave_any(d_ext)) { if (d_ext) d_len = c_extend_from(g.data, Pk, Pk - backward, max_length, 32u); }
+      }
+#else
       uint64_t cb[2], pb[2];
       __builtin_memcpy(cb, g.data + (ev ? Pk : 0u), 16);
       const uint32_t backward = q_dc_entry(g, idc);
@@ -324,6 +342,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
         if (d_cand) { d_len = umin(md, max_length); d_ext = md == 16u && max_length > 16u; }
         if (wave_any(d_ext)) { if (d_ext) d_len = c_extend_from(g.data, Pk, Pk - backward, max_length, 16u); }
       }
+#endif
 #if defined(Q_PROFILE)
       if (wave_any(d_len == 0xFFFFFFFFu || rw == 0x123456789ull)) g.pf_acc++;   // (profiling fence: loads consumed)
 #endif
@@ -387,6 +406,9 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       bool commit = false, stop = !want;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
+#if !defined(C_NOEARLY)
+        if (k >= 2 && !wave_any(!stop)) break;                         // (most commands end at the second position)
+#endif
         const uint32_t sk = fl[k] & 0x3FFFFFFFu;
         const bool usable = (fl[k] >> 30) == 2u;                       // evaluated and decidable from the index
         if (!stop && !usable) stop = true;

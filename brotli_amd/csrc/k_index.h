@@ -106,14 +106,15 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
   const int lane = wave_lane();
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
-  ix_layout(g.n, J.ix_slices, &L);
+  ix_layout(g.n, J.ix_slices, J.ix_nb_log2, &L);
   uint8_t* base = ws + D.ix_off;
   const uint8_t* data = input + D.in_off;
   const uint32_t per = ix_slice_len(g.n, J.ix_slices);
   const uint32_t lo = w * per, hi = umin(lo + per, g.n);
-  for (uint32_t b = (uint32_t)lane; b < IX_NB; b += 64u) lds_cnt[b] = 0;
+  const uint32_t nbk = 1u << J.ix_nb_log2;
+  for (uint32_t b = (uint32_t)lane; b < nbk; b += 64u) lds_cnt[b] = 0;
   wave_sync();
-  const int shift = J.bucket_bits - (int)IX_NB_LOG2;
+  const int shift = J.bucket_bits - (int)J.ix_nb_log2;
   for (uint32_t x0 = lo; x0 < hi; x0 += 64u) {
     const uint32_t x = x0 + (uint32_t)lane;
     if (x < hi && ix_storable(g, x)) {
@@ -123,7 +124,7 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
   }
   wave_sync();
   uint32_t* cnt = (uint32_t*)(base + L.cnt);
-  for (uint32_t b = (uint32_t)lane; b < IX_NB; b += 64u) cnt[b * J.ix_slices + w] = lds_cnt[b];
+  for (uint32_t b = (uint32_t)lane; b < nbk; b += 64u) cnt[b * J.ix_slices + w] = lds_cnt[b];
   // bitmap bytes of this slice (per is a multiple of 64 positions = 8 bytes)
   uint32_t* skip = (uint32_t*)(base + L.skip);
   const uint32_t w_lo = lo / 32u, w_hi = (umin(lo + per, g.n + 128u) + 31u) / 32u;
@@ -136,13 +137,13 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
 }
 
 // grid = nshards.  Exclusive scan of cnt[] in (bucket, slice) order, in place;
-// cnt[IX_NB * slices] = number of storable positions of the shard.
+// cnt[buckets * slices] = number of storable positions of the shard.
 DEV void ix_scan(const JobParams& J, const ShardDesc& D, uint8_t* ws) {
   const int lane = wave_lane();
   IxLayout L;
-  ix_layout(D.len, J.ix_slices, &L);
+  ix_layout(D.len, J.ix_slices, J.ix_nb_log2, &L);
   uint32_t* cnt = (uint32_t*)(ws + D.ix_off + L.cnt);
-  const uint32_t total = IX_NB * J.ix_slices;
+  const uint32_t total = J.ix_slices << J.ix_nb_log2;
   const uint32_t per = (total + 63u) / 64u;
   const uint32_t lo = (uint32_t)lane * per, hi = umin(lo + per, total);
   uint32_t sum = 0;
@@ -161,16 +162,16 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
   const int lane = wave_lane();
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
-  ix_layout(g.n, J.ix_slices, &L);
+  ix_layout(g.n, J.ix_slices, J.ix_nb_log2, &L);
   uint8_t* base = ws + D.ix_off;
   const uint8_t* data = input + D.in_off;
   const uint32_t* cnt = (const uint32_t*)(base + L.cnt);
   uint8_t* ent = base + L.ent;
   const uint32_t per = ix_slice_len(g.n, J.ix_slices);
   const uint32_t lo = w * per, hi = umin(lo + per, g.n);
-  for (uint32_t b = (uint32_t)lane; b < IX_NB; b += 64u) lds_off[b] = cnt[b * J.ix_slices + w];
+  for (uint32_t b = (uint32_t)lane; b < (1u << J.ix_nb_log2); b += 64u) lds_off[b] = cnt[b * J.ix_slices + w];
   wave_sync();
-  const int shift = J.bucket_bits - (int)IX_NB_LOG2;
+  const int shift = J.bucket_bits - (int)J.ix_nb_log2;
   for (uint32_t x0 = lo; x0 < hi; x0 += 64u) {
     const uint32_t x = x0 + (uint32_t)lane;
     const bool act = x < hi && ix_storable(g, x);
@@ -184,7 +185,7 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
       e.w1 = kt.key;
       b = kt.key >> shift;
     }
-    const uint64_t same = ix_match_any(act, b, (int)IX_NB_LOG2);
+    const uint64_t same = ix_match_any(act, b, (int)J.ix_nb_log2);
     const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
     const uint32_t total = (uint32_t)dev_popc64(same);
     uint32_t at = 0;
@@ -198,18 +199,112 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
 }
 
 // ---- level 2 + window search: one wave per (shard, bucket) -------------------------------
-struct IxBest { uint32_t key, len, dist; };   // key = score << 5 | (16 - j), j = 1 newest
-
 DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + 135u * len - 30u * log2floor(dist); }
 
-// lds: [0, 128) bin counts / starts, [128, 256) cursors, then (16 + 64) staged entries (16 B each)
-#define IX_BUCKET_LDS_WORDS (256u + 80u * 4u)
+// The bucket loop of FindLongestMatch (..64_simd_inc.h:246-292) for the entry `e` at index i of
+// its bucket, given the entries before it in (key, position) order: entry i - j sits 4 * j
+// words below `own` in LDS.  rank = same-key entries before e.  Writes srt[] and res[].
+DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool act, uint32_t rank,
+                   const uint32_t* own, uint32_t sidx, uint32_t* srt, uint64_t* res) {
+  const uint32_t p = e.w0 & 0xFFFFFFu, tag = e.w0 >> 24;
+  const bool danger = rank >= 65520u;
+  const bool search = act && ix_searchable(g, p);
+  const uint32_t max_length = search ? ix_block_end(g, p) - p : 0u;
+  uint32_t best = 0, best_len = 0, best_dist = 0;               // exact candidates
+  uint32_t longmask = 0;
+  const uint32_t nwin = search ? umin(rank, 16u) : 0u;
+  const uint32_t nmax = (uint32_t)wave_max_u32(nwin);
+  for (uint32_t j = 1; j <= nmax; ++j) {
+    if (j > nwin) continue;
+    IxEntry q;
+    __builtin_memcpy(&q, own - 4 * (int)j, 16);
+#if defined(BROTLI_AMD_SIMT_SIM)
+    if (getenv("SIM_DBGPOS") && act && p == (uint32_t)atoi(getenv("SIM_DBGPOS")))
+      fprintf(stderr, "ix p %u tag %x rank %u search %d maxlen %u | j %u q %u qtag %x qkey %x\n", p, tag, rank, (int)search, max_length, j, q.w0 & 0xFFFFFF, q.w0 >> 24, q.w1);
+#endif
+    if ((q.w0 >> 24) != tag) continue;
+    const uint64_t x = q.d ^ e.d;
+    const uint32_t l8 = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
+    if (l8 < 4u) continue;                                      // first4 != current4
+    if (l8 == 8u && max_length > 8u) { longmask |= 1u << j; continue; }
+    const uint32_t len = umin(l8, max_length);
+    const uint32_t dist = p - (q.w0 & 0xFFFFFFu);
+    const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
+    if (k > best) { best = k; best_len = len; best_dist = dist; }
+  }
+  // candidates equal in the first 8 bytes: compare on in the input, four candidates per
+  // round trip (bytes 8..23 first; the few that are still equal fetch 24..39)
+  uint32_t ncapped = 0, cap_key = 0, cap_dist = 0;
+  if (wave_ballot(longmask != 0) != 0) {
+    uint64_t mine[4] = {0, 0, 0, 0};
+    if (longmask != 0) __builtin_memcpy(mine, data + p + 8u, 32);
+    while (wave_ballot(longmask != 0) != 0) {
+      uint32_t jj[4], qp[4], ln[4];
+      uint64_t c[4][2];
+      bool more = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        jj[u] = longmask != 0 ? (uint32_t)dev_ctz32(longmask) : 0u;
+        longmask &= longmask - 1u;
+        qp[u] = own[-4 * (int)jj[u]] & 0xFFFFFFu;
+        c[u][0] = c[u][1] = 0;
+        if (jj[u] != 0) __builtin_memcpy(c[u], data + qp[u] + 8u, 16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t x0 = c[u][0] ^ mine[0], x1 = c[u][1] ^ mine[1];
+        ln[u] = x0 ? 8u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 16u + ((uint32_t)dev_ctz64(x1) >> 3) : 24u;
+        if (jj[u] != 0 && ln[u] == 24u && max_length > 24u) more = true;
+      }
+      if (wave_ballot(more) != 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (jj[u] != 0 && ln[u] == 24u && max_length > 24u) {
+            __builtin_memcpy(c[u], data + qp[u] + 24u, 16);
+            const uint64_t x0 = c[u][0] ^ mine[2], x1 = c[u][1] ^ mine[3];
+            ln[u] = x0 ? 24u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 32u + ((uint32_t)dev_ctz64(x1) >> 3) : 40u;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (jj[u] == 0) continue;
+        const uint32_t len = umin(ln[u], max_length);
+        const uint32_t dist = p - qp[u];
+        const uint32_t k = (ix_score(len, dist) << 5) | (16u - jj[u]);
+        if (len == IX_CAP && max_length > IX_CAP) {
+          ++ncapped;
+          if (k > cap_key) { cap_key = k; cap_dist = dist; }
+        } else if (k > best) { best = k; best_len = len; best_dist = dist; }
+      }
+    }
+  }
+  if (act) {
+    srt[sidx] = e.w0;
+    uint32_t kind, len = 0, dist = 0;
+    if (!search) kind = IX_KIND_NONE;
+    else if (danger || ncapped >= 2u) kind = IX_KIND_SLOW;
+    else if (ncapped == 1u) {
+      // the long candidate's score can only grow with its real length
+      if (cap_key > best) { kind = IX_KIND_LONG; len = IX_CAP; dist = cap_dist; }
+      else kind = IX_KIND_SLOW;
+    } else if (best != 0) { kind = IX_KIND_EXACT; len = best_len; dist = best_dist; }
+    else kind = IX_KIND_NONE;
+    const uint32_t lo = (kind << 30) | (len << 24) | dist;
+    const uint32_t hi = sidx | (umin(rank, IX_RANK_CAP) << 24) | (danger ? IX_DANGER : 0u);
+    res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
+  }
+}
+
+// lds: [0, 128) bin starts, [128, 256) cursors, then the sorted bucket (64 * IX_LROWS entries of
+// 16 B) — or, for a bigger bucket, the (16 + 64) staged entries of the row being searched
+#define IX_BUCKET_LDS_WORDS (256u + 64u * IX_LROWS * 4u)
 DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
                    uint32_t bucket, uint32_t* lds) {
   const int lane = wave_lane();
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
-  ix_layout(g.n, J.ix_slices, &L);
+  ix_layout(g.n, J.ix_slices, J.ix_nb_log2, &L);
   uint8_t* base = ws + D.ix_off;
   const uint8_t* data = input + D.in_off;
   const uint32_t* cnt = (const uint32_t*)(base + L.cnt);
@@ -221,14 +316,67 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   const uint32_t end = cnt[(bucket + 1u) * J.ix_slices];   // (the last one reads the total)
   const uint32_t m = end - start;
   if (m == 0) return;
-  const int lowbits = J.bucket_bits - (int)IX_NB_LOG2;      // 6 or 7
-  const uint32_t nbins = 1u << lowbits, lowmask = nbins - 1u;
+  const int lowbits = J.bucket_bits - (int)J.ix_nb_log2;    // 4 .. 7
+  const uint32_t lowmask = (1u << lowbits) - 1u;
   uint32_t* bins = lds;
   uint32_t* cursor = lds + 128;
-  uint32_t* stage = lds + 256;
+  uint32_t* sorted = lds + 256;
+  wave_sync();
   for (uint32_t b = (uint32_t)lane; b < 128u; b += 64u) bins[b] = 0;
   wave_sync();
-  // A: histogram of the remaining key bits
+  if (m <= 64u * IX_LROWS) {
+    // ---- the whole bucket in registers, then sorted into LDS ----
+    IxEntry row[IX_LROWS];
+#pragma unroll
+    for (uint32_t r = 0; r < IX_LROWS; ++r) {
+      const uint32_t i = r * 64u + (uint32_t)lane;
+      row[r].w0 = row[r].w1 = 0; row[r].d = 0;
+      if (i < m) row[r] = ix_load_entry(ent + 16ull * (start + i));
+    }
+#pragma unroll
+    for (uint32_t r = 0; r < IX_LROWS; ++r) {
+      if (r * 64u + (uint32_t)lane < m) lds_atomic_add(&bins[row[r].w1 & lowmask], 1u);
+    }
+    wave_sync();
+    {
+      const uint32_t a = bins[2 * lane], b = bins[2 * lane + 1];
+      const uint32_t incl = wave_incl_scan(a + b);
+      wave_sync();
+      bins[2 * lane] = incl - a - b;
+      bins[2 * lane + 1] = incl - b;
+      cursor[2 * lane] = incl - a - b;
+      cursor[2 * lane + 1] = incl - b;
+    }
+    wave_sync();
+#pragma unroll
+    for (uint32_t r = 0; r < IX_LROWS; ++r) {
+      if (r * 64u >= m) break;
+      const bool act = r * 64u + (uint32_t)lane < m;
+      const uint32_t kl = row[r].w1 & lowmask;
+      const uint64_t same = ix_match_any(act, kl, lowbits);
+      const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
+      const uint32_t total = (uint32_t)dev_popc64(same);
+      uint32_t at = 0;
+      if (act) at = cursor[kl];
+      wave_sync();
+      if (act && rank + 1u == total) cursor[kl] = at + total;
+      if (act) __builtin_memcpy(&sorted[4u * (at + rank)], &row[r], 16);
+      wave_sync();
+    }
+    for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+      const uint32_t i = r0 + (uint32_t)lane;
+      const bool act = i < m;
+      IxEntry e;
+      e.w0 = e.w1 = 0xFFFFFFFFu; e.d = 0;
+      if (act) __builtin_memcpy(&e, &sorted[4u * i], 16);
+      const uint32_t rank = act ? i - bins[e.w1 & lowmask] : 0u;
+      ix_window(g, data, e, act, rank, &sorted[4u * (act ? i : 0u)], start + i, srt, res);
+    }
+    wave_sync();
+    return;
+  }
+  // ---- a bigger bucket: sorted through HBM (ent -> ent2), searched row by row ----
+  uint32_t* stage = sorted;
   for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
     const uint32_t i = r0 + (uint32_t)lane;
     if (i < m) {
@@ -238,7 +386,6 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   }
   wave_sync();
   {
-    // exclusive scan of 128 bins: two per lane
     const uint32_t a = bins[2 * lane], b = bins[2 * lane + 1];
     const uint32_t incl = wave_incl_scan(a + b);
     wave_sync();
@@ -248,7 +395,6 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     cursor[2 * lane + 1] = incl - b;
   }
   wave_sync();
-  // B: stable scatter inside the bucket
   for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
     const uint32_t i = r0 + (uint32_t)lane;
     const bool act = i < m;
@@ -267,8 +413,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     if (act) ix_store_entry(ent2 + 16ull * (start + at + rank), e);
   }
   wave_sync();
-  // C: window search in sorted order.  stage[0..15] = the last 16 entries of the previous
-  // row, stage[16 + lane] = this row's.
+  // stage[0..15] = the last 16 entries of the previous row, stage[16 + lane] = this row's
   for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
     const uint32_t i = r0 + (uint32_t)lane;
     const bool act = i < m;
@@ -277,94 +422,8 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     if (act) e = ix_load_entry(ent2 + 16ull * (start + i));
     __builtin_memcpy(&stage[4 * (16 + lane)], &e, 16);
     wave_sync();
-    const uint32_t p = e.w0 & 0xFFFFFFu, tag = e.w0 >> 24, key = e.w1;
-    const uint32_t rank = act ? i - bins[key & lowmask] : 0u;      // same-key entries before this one
-    const bool danger = rank >= 65520u;
-    const bool search = act && ix_searchable(g, p);
-    const uint32_t max_length = search ? ix_block_end(g, p) - p : 0u;
-    uint32_t best = 0, best_len = 0, best_dist = 0;               // exact candidates
-    uint32_t longmask = 0;
-    const uint32_t nwin = umin(rank, 16u);
-    for (uint32_t j = 1; j <= 16u; ++j) {
-      IxEntry q;
-      __builtin_memcpy(&q, &stage[4 * (16 + lane - (int)j)], 16);
-#if defined(BROTLI_AMD_SIMT_SIM)
-      if (getenv("SIM_DBGPOS") && act && p == (uint32_t)atoi(getenv("SIM_DBGPOS")))
-        fprintf(stderr, "ix p %u key %x tag %x rank %u search %d maxlen %u | j %u q %u qtag %x qkey %x\n", p, key, tag, rank, (int)search, max_length, j, q.w0 & 0xFFFFFF, q.w0 >> 24, q.w1);
-#endif
-      if (!(search && j <= nwin)) continue;
-      if ((q.w0 >> 24) != tag) continue;
-      const uint64_t x = q.d ^ e.d;
-      const uint32_t l8 = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
-      if (l8 < 4u) continue;                                      // first4 != current4
-      if (l8 == 8u && max_length > 8u) { longmask |= 1u << j; continue; }
-      const uint32_t len = umin(l8, max_length);
-      const uint32_t dist = p - (q.w0 & 0xFFFFFFu);
-      const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
-      if (k > best) { best = k; best_len = len; best_dist = dist; }
-    }
-    // candidates equal in the first 8 bytes: compare on in the input, four candidates per
-    // round trip (bytes 8..23 first; the few that are still equal fetch 24..39)
-    uint32_t ncapped = 0, cap_key = 0, cap_dist = 0;
-    if (wave_ballot(longmask != 0) != 0) {
-      uint64_t own[4] = {0, 0, 0, 0};
-      if (longmask != 0) __builtin_memcpy(own, data + p + 8u, 32);
-      while (wave_ballot(longmask != 0) != 0) {
-        uint32_t jj[4], qp[4], ln[4];
-        uint64_t c[4][2];
-        bool more = false;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          jj[u] = longmask != 0 ? (uint32_t)dev_ctz32(longmask) : 0u;
-          longmask &= longmask - 1u;
-          qp[u] = stage[4 * (16 + lane - (int)jj[u])] & 0xFFFFFFu;
-          c[u][0] = c[u][1] = 0;
-          if (jj[u] != 0) __builtin_memcpy(c[u], data + qp[u] + 8u, 16);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const uint64_t x0 = c[u][0] ^ own[0], x1 = c[u][1] ^ own[1];
-          ln[u] = x0 ? 8u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 16u + ((uint32_t)dev_ctz64(x1) >> 3) : 24u;
-          if (jj[u] != 0 && ln[u] == 24u && max_length > 24u) more = true;
-        }
-        if (wave_ballot(more) != 0) {
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (jj[u] != 0 && ln[u] == 24u && max_length > 24u) {
-              __builtin_memcpy(c[u], data + qp[u] + 24u, 16);
-              const uint64_t x0 = c[u][0] ^ own[2], x1 = c[u][1] ^ own[3];
-              ln[u] = x0 ? 24u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 32u + ((uint32_t)dev_ctz64(x1) >> 3) : 40u;
-            }
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if (jj[u] == 0) continue;
-          const uint32_t len = umin(ln[u], max_length);
-          const uint32_t dist = p - qp[u];
-          const uint32_t k = (ix_score(len, dist) << 5) | (16u - jj[u]);
-          if (len == IX_CAP && max_length > IX_CAP) {
-            ++ncapped;
-            if (k > cap_key) { cap_key = k; cap_dist = dist; }
-          } else if (k > best) { best = k; best_len = len; best_dist = dist; }
-        }
-      }
-    }
-    if (act) {
-      srt[start + i] = e.w0;
-      uint32_t kind, len = 0, dist = 0;
-      if (!search) kind = IX_KIND_NONE;
-      else if (danger || ncapped >= 2u) kind = IX_KIND_SLOW;
-      else if (ncapped == 1u) {
-        // the long candidate's score can only grow with its real length
-        if (cap_key > best) { kind = IX_KIND_LONG; len = IX_CAP; dist = cap_dist; }
-        else kind = IX_KIND_SLOW;
-      } else if (best != 0) { kind = IX_KIND_EXACT; len = best_len; dist = best_dist; }
-      else kind = IX_KIND_NONE;
-      const uint32_t lo = (kind << 30) | (len << 24) | dist;
-      const uint32_t hi = (start + i) | (umin(rank, IX_RANK_CAP) << 24) | (danger ? IX_DANGER : 0u);
-      res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
-    }
+    const uint32_t rank = act ? i - bins[e.w1 & lowmask] : 0u;
+    ix_window(g, data, e, act, rank, &stage[4 * (16 + lane)], start + i, srt, res);
     wave_sync();
     if (lane >= 48) __builtin_memcpy(&stage[4 * (lane - 48)], &e, 16);   // the next row's look-back
     wave_sync();

@@ -11,8 +11,10 @@
 #define IX_HD
 #endif
 
-#define IX_NB_LOG2 8u
-#define IX_NB (1u << IX_NB_LOG2)              // first-level buckets (top key bits)
+#define IX_NB_MAX_LOG2 10u                    // first-level buckets by the top key bits: 2^8 .. 2^10 per shard
+#define IX_NB_MAX (1u << IX_NB_MAX_LOG2)      //   (JobParams::ix_nb_log2, chosen so that a bucket holds ~256 positions)
+#define IX_BPW 8u                             // buckets one wave of ix_bucket works through
+#define IX_LROWS 8u                           // a bucket of <= 64 * IX_LROWS entries is sorted and searched in LDS
 #define IX_CAP 40u                            // bytes compared per candidate by ix_bucket
 #define IX_BLOOM_WORDS 1024u                  // one bit per bucket key (<= 15 bits): keys of unstored positions
 #define IX_SKIPTAB_WORDS 256u                 // newest unstored position per key (direct mapped, k_chain.h)
@@ -29,9 +31,9 @@ struct IxEntry { uint32_t w0, w1; uint64_t d; };
 // Index region of one shard, offsets relative to ShardDesc::ix_off.
 struct IxLayout { uint64_t cnt, bloom, skip, srt, res, ent, ent2, bytes; };
 static inline IX_HD uint64_t ix_align(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
-static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, IxLayout* L) {
+static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, uint32_t nb_log2, IxLayout* L) {
   uint64_t off = 0;
-  L->cnt = off;   off = ix_align(off + 4ull * ((uint64_t)IX_NB * slices + 2));
+  L->cnt = off;   off = ix_align(off + 4ull * (((uint64_t)slices << nb_log2) + 2));
   L->bloom = off; off = ix_align(off + 4ull * (IX_BLOOM_WORDS + IX_SKIPTAB_WORDS));
   L->skip = off;  off = ix_align(off + n / 8 + 32);
   L->srt = off;   off = ix_align(off + 4 * n + 16);

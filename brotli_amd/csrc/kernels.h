@@ -17,6 +17,9 @@
 #ifndef CHAIN_WAVES
 #define CHAIN_WAVES 4
 #endif
+#ifndef IXB_WAVES
+#define IXB_WAVES 4
+#endif
 #ifndef BUILD_WAVES
 #define BUILD_WAVES 4
 #endif
@@ -83,7 +86,7 @@ __global__ void __launch_bounds__(64, PARSE4_WAVES) k_parse4(JobArgs a) {
 // ---- indexed quality-5 parse (k_index.h, k_chain.h) ----------------------------------------
 // grid = nshards * ix_slices, block = 64
 __global__ void __launch_bounds__(64) k_ix_count(JobArgs a) {
-  __shared__ uint32_t lds_cnt[IX_NB];
+  __shared__ uint32_t lds_cnt[IX_NB_MAX];
   const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
   if (shard >= a.nshards) return;
   ix_count(a.J, a.shards[shard], a.input, a.ws, w, lds_cnt);
@@ -95,19 +98,23 @@ __global__ void __launch_bounds__(64) k_ix_scan(JobArgs a) {
 }
 // grid = nshards * ix_slices, block = 64
 __global__ void __launch_bounds__(64) k_ix_scatter(JobArgs a) {
-  __shared__ uint32_t lds_off[IX_NB];
+  __shared__ uint32_t lds_off[IX_NB_MAX];
   const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
   if (shard >= a.nshards) return;
   ix_scatter(a.J, a.shards[shard], a.input, a.ws, w, lds_off);
 }
-// grid = nshards * IX_NB, block = 64: one wave per (shard, first-level bucket)
-__global__ void __launch_bounds__(64) k_ix_bucket(JobArgs a) {
+// grid = ceil(nshards / 8) * 8 * (buckets per shard / IX_BPW), block = 64: a wave works through
+// IX_BPW buckets.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md): all waves of a shard are
+// given the same b % 8, so the shard's input, entries and the res[] lines its buckets fill
+// together stay in ONE XCD's L2 instead of being written back partially by eight.
+__global__ void __launch_bounds__(64, IXB_WAVES) k_ix_bucket(JobArgs a) {
   __shared__ uint32_t lds_b[IX_BUCKET_LDS_WORDS];
-  const uint32_t shard = blockIdx.x / IX_NB, b = blockIdx.x % IX_NB;
+  const uint32_t per = (1u << a.J.ix_nb_log2) / IX_BPW;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  const uint32_t shard = (slot / per) * 8u + xcd, b0 = (slot % per) * IX_BPW;
   if (shard >= a.nshards) return;
-  ix_bucket(a.J, a.shards[shard], a.input, a.ws, b, lds_b);
+  for (uint32_t b = b0; b < b0 + IX_BPW; ++b) ix_bucket(a.J, a.shards[shard], a.input, a.ws, b, lds_b);
 }
-// grid = ceil(nshards / shards per wave), block = 64
 // dynamic LDS: shards per wave * C_GROUP_LDS_WORDS * 4 bytes
 __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain(JobArgs a) {
 #if defined(BROTLI_AMD_SIMT_SIM)

@@ -53,6 +53,13 @@ static inline void wave_equal_neighbours(uint32_t v, int n, int* prev, int* next
 }
 // Rotation inside rows of 16 lanes (DPP row_ror on the device).
 #define wave_row_ror(v, k) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), (wave_lane() & 48) | ((wave_lane() + (k)) & 15), WAVE_SITE))
+// Maximum of v over the wave (uniform result).
+static inline uint32_t wave_max_u32(uint32_t v) {
+  simt::rendezvous(v, 7002);
+  uint32_t m = 0;
+  for (int k = 0; k < 64; ++k) { const uint32_t x = (uint32_t)simt::peek((int)((threadIdx.x & ~63u) + k)); if (x > m) m = x; }
+  return m;
+}
 // Exchange inside quads of 4 lanes (DPP quad_perm on the device).
 #define wave_quad_xor(v, m) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), wave_lane() ^ (m), WAVE_SITE))
 
@@ -128,6 +135,18 @@ __device__ __forceinline__ void wave_equal_neighbours(uint32_t v, int n, int* pr
 // Rotation inside rows of 16 lanes: one VALU v_mov_b32 with DPP row_ror:k, no
 // LDS crossbar round trip (ds_bpermute costs ~100 cycles of latency each).
 #define wave_row_ror(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x120 + (k), 0xF, 0xF, true))
+// Maximum of v over the wave (uniform result): DPP row reductions + two readlanes.
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+  uint32_t o;
+  o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true); v = o > v ? o : v;   // row_ror:8
+  o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true); v = o > v ? o : v;   // row_ror:4
+  o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x122, 0xF, 0xF, true); v = o > v ? o : v;   // row_ror:2
+  o = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x121, 0xF, 0xF, true); v = o > v ? o : v;   // row_ror:1
+  const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+  const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+  const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+  return ab > cd ? ab : cd;
+}
 // Value of lane ^ m (m = 1 or 2) inside quads of 4 lanes: DPP quad_perm [1,0,3,2] / [2,3,0,1].
 #define wave_quad_xor(v, m) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (m) == 1 ? 0xB1 : 0x4E, 0xF, 0xF, true))
 
