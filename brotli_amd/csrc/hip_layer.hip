@@ -190,6 +190,10 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
       const uint64_t ns = plan->shards.size();
       uint32_t v = ns <= resident ? 1u : ns <= 2 * resident ? 2u : 4u;
       if (const char* g = getenv("BROTLI_AMD_CGROUPS")) v = (uint32_t)atoi(g);
+      {   // one shard per wave with wave-uniform state (default); BROTLI_AMD_WIDE=0: 16-lane groups
+        const char* w = getenv("BROTLI_AMD_WIDE");
+        if (!w || atoi(w) != 0) { plan->J.flags |= JOB_FLAG_WIDE; v = 1; }
+      }
       plan->J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
       if (v == 1 || v == 2) plan->J.flags |= v << JOB_FLAG_GROUPS_SHIFT;
     }
@@ -250,7 +254,10 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       else if (plan.J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(nshards), dim3(64), 0, c->stream, a);
       else hipLaunchKernelGGL(k_parse_deep<4>, dim3(nshards), dim3(64), 0, c->stream, a);
     } else if (indexed)
-      hipLaunchKernelGGL(k_chain, dim3((nshards + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, a);
+      if (plan.J.flags & JOB_FLAG_WIDE)
+        hipLaunchKernelGGL(k_chain<true>, dim3(nshards), dim3(64), C_GROUP_LDS_WORDS * 4u, c->stream, a);
+      else
+        hipLaunchKernelGGL(k_chain<false>, dim3((nshards + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, a);
     else if (plan.J.flags & JOB_FLAG_QUAD)
       hipLaunchKernelGGL(k_parse4, dim3((nshards + gpw - 1) / gpw), dim3(64), 0, c->stream, a);
     else

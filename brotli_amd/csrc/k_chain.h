@@ -215,22 +215,125 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   return r;
 }
 
+// One evaluation of the positions P0 .. P0 + NPOS - 1 (lane: position P0 + kpos, distance-cache
+// entry idc): distance-cache winner (:201-240) against the bucket result of the index, per quad.
+// e_flags = score | evaluated << 31 | needs-the-exact-search << 30.
+struct CEval { uint32_t e_flags, e_len, e_dist; };
+DEV CEval c_evaluate(const JobParams& J, CShard& C, bool want, uint32_t P0, int kpos, int idc,
+                     const uint32_t* bloom, bool force_slow, uint32_t htl) {
+  QShard& g = C.g;
+  const uint32_t Pk = P0 + (uint32_t)kpos;
+  const bool ev = want && Pk + htl <= g.pos_end;
+  const uint32_t max_length = g.pos_end - Pk;
+#if defined(C_PD32)
+  // 32-byte probes: a longer compare, fewer steps that need a second round trip
+  uint64_t cb[4], pb[4];
+  __builtin_memcpy(cb, g.data + (ev ? Pk : 0u), 32);
+  const uint32_t backward = q_dc_entry(g, idc);
+  const bool d_cand = ev && idc < J.ndist && (int32_t)backward > 0 && backward <= umin(Pk, J.max_backward_limit);
+  __builtin_memcpy(pb, g.data + (d_cand ? Pk - backward : 0u), 32);
+  const uint64_t rw = ev ? C.res[Pk] : 0ull;
+  uint32_t d_len = 0;
+  {
+    const uint64_t x0 = cb[0] ^ pb[0], x1 = cb[1] ^ pb[1], x2 = cb[2] ^ pb[2], x3 = cb[3] ^ pb[3];
+    const uint32_t md = x0 ? ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 8u + ((uint32_t)dev_ctz64(x1) >> 3)
+                      : x2 ? 16u + ((uint32_t)dev_ctz64(x2) >> 3) : x3 ? 24u + ((uint32_t)dev_ctz64(x3) >> 3) : 32u;
+    bool d_ext = false;
+    if (d_cand) { d_len = umin(md, max_length); d_ext = md == 32u && max_length > 32u; }
+    if (wave_any(d_ext)) { if (d_ext) d_len = c_extend_from(g.data, Pk, Pk - backward, max_length, 32u); }
+  }
+#else
+  uint64_t cb[2], pb[2];
+  __builtin_memcpy(cb, g.data + (ev ? Pk : 0u), 16);
+  const uint32_t backward = q_dc_entry(g, idc);
+  const bool d_cand = ev && idc < J.ndist && (int32_t)backward > 0 && backward <= umin(Pk, J.max_backward_limit);
+  __builtin_memcpy(pb, g.data + (d_cand ? Pk - backward : 0u), 16);
+  const uint64_t rw = ev ? C.res[Pk] : 0ull;
+  uint32_t d_len = 0;
+  {
+    const uint64_t x0 = cb[0] ^ pb[0], x1 = cb[1] ^ pb[1];
+    const uint32_t md = x0 ? ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 8u + ((uint32_t)dev_ctz64(x1) >> 3) : 16u;
+    bool d_ext = false;
+    if (d_cand) { d_len = umin(md, max_length); d_ext = md == 16u && max_length > 16u; }
+    if (wave_any(d_ext)) { if (d_ext) d_len = c_extend_from(g.data, Pk, Pk - backward, max_length, 16u); }
+  }
+#endif
+  // Distance-cache winner of the position (:201-240).  The score is 135 * len + 1935 - penalty(i)
+  // with penalties 0, 39, 43, 43 < 135: ordering by (len, earlier entry) is ordering by score
+  // with the reference's first-wins tie break, so one reduction of len << 2 | (3 - i) is enough.
+  const bool d_ok = d_cand && (d_len >= 3u || (d_len == 2u && idc < 2));
+  const uint32_t d_key = d_ok ? (d_len << 2) | (3u - (uint32_t)idc) : 0u;
+  uint32_t d_best = umax(d_key, wave_quad_xor(d_key, 1));
+  d_best = umax(d_best, wave_quad_xor(d_best, 2));
+  const uint32_t dc_len = d_best >> 2;
+  const uint32_t dc_i = 3u - (d_best & 3u);
+  const uint32_t dc_dist = q_dc_entry(g, (int)dc_i);
+  uint32_t dc_score = K_MIN_SCORE;
+  if (d_best != 0) {
+    dc_score = 135u * dc_len + 1935u;
+    if (dc_i != 0) dc_score -= 39u + ((0x1CA10u >> (dc_i & 0xEu)) & 0xEu);
+  }
+  // the bucket part, from the index
+  const uint32_t rlo = (uint32_t)rw, rhi = (uint32_t)(rw >> 32);
+  const uint32_t kind = rlo >> 30;
+  uint32_t b_len = (rlo >> 24) & 63u;
+  const uint32_t b_dist = rlo & 0xFFFFFFu;
+  {
+    const bool b_long = ev && kind == IX_KIND_LONG;
+    if (wave_any(b_long)) { if (b_long) b_len = c_extend_from(g.data, Pk, Pk - b_dist, max_length, IX_CAP); }
+  }
+  const bool b_ok = ev && (kind == IX_KIND_EXACT || kind == IX_KIND_LONG);
+  const uint32_t b_score = b_ok ? 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u) : 0u;
+  const uint32_t keyP = hash_pos(cb[0], J.hasher_type, J.bucket_bits).key;
+  const bool b_wins = b_ok && b_score > dc_score;
+  const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & IX_DANGER) != 0 || force_slow ||
+                                 c_bloom_hit(bloom, keyP, rhi & 0xFFFFFFu) ||
+                                 (b_wins && b_len <= umax(dc_len, 3u)));
+#if defined(BROTLI_AMD_SIMT_SIM)
+  if (ev && idc == 0 && getenv("SIM_DBGPOS") && Pk == (uint32_t)atoi(getenv("SIM_DBGPOS")))
+    fprintf(stderr, "P %u key %x bit %u slot %x sidx %u kind %u blen %u bdist %u dc_len %u frontier %u\n", Pk, keyP,
+            (bloom[keyP >> 5] >> (keyP & 31)) & 1, bloom[IX_BLOOM_WORDS + (keyP & 255)], rhi & 0xFFFFFF, kind, b_len, b_dist, dc_len, C.frontier);
+  if (ev && idc == 0) {   // (statistics of the simulator runs: why positions go to the exact path)
+    if (kind == IX_KIND_SLOW) g_sim_counts[8]++;
+    else if (c_bloom_hit(bloom, keyP, rhi & 0xFFFFFFu)) g_sim_counts[9]++;
+    else if (b_wins && b_len <= umax(dc_len, 3u)) g_sim_counts[10]++;
+    if (kind == IX_KIND_LONG) g_sim_counts[11]++;
+    g_sim_counts[12]++;
+  }
+#endif
+  uint32_t e_len = 0, e_dist = 0, e_score = K_MIN_SCORE;
+  if (b_wins) { e_len = b_len; e_dist = b_dist; e_score = b_score; }
+  else if (d_best != 0) { e_len = dc_len; e_dist = dc_dist; e_score = dc_score; }
+  const uint32_t e_flags = e_score | (ev ? 0x80000000u : 0u) | (need_exact ? 0x40000000u : 0u);
+
+  CEval r;
+  r.e_flags = e_flags; r.e_len = e_len; r.e_dist = e_dist;
+  return r;
+}
+
 // ---- the kernel body ---------------------------------------------------------------------
+// WIDE: the whole wave serves ONE shard.  The four 16-lane groups hold identical copies of the
+// state (so everything that is per group above — marking, exact search, dictionary, block glue —
+// just happens four times with the same result, idempotently), but each group evaluates its own
+// four positions: 16 positions of look-ahead per step, and — all state being wave-uniform — the
+// state machine compiles to scalar code and real branches.
+template <bool WIDE>
 DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* states,
                      uint32_t nshards, const DeviceTables* T, const uint8_t* input, uint8_t* ws,
                      uint32_t wave_index, uint32_t* lds) {
   const int t = q_t();
-  const uint32_t gpw = q_groups_per_wave(J);
-  const uint32_t gi = (uint32_t)(wave_lane() >> 4);
+  const uint32_t gpw = WIDE ? 1u : q_groups_per_wave(J);
+  const uint32_t gi = WIDE ? 0u : (uint32_t)(wave_lane() >> 4);
   const uint32_t shard = wave_index * gpw + gi;
   const bool alive = gi < gpw && shard < nshards;
-  const bool writer = alive && t == 0;
+  const bool writer = alive && (WIDE ? wave_lane() == 0 : t == 0);
+  constexpr int NPOS = WIDE ? 16 : 4;
   const uint32_t htl = hasher_htl(J.hasher_type);
   const ShardDesc& D = shards[alive ? shard : 0];
   const ShardState* S0 = &states[alive ? shard : 0];
   uint32_t* bloom = lds + gi * C_GROUP_LDS_WORDS;
   uint32_t* scratch = bloom + IX_BLOOM_WORDS + IX_SKIPTAB_WORDS;
-  const int kpos = t >> 2, idc = t & 3;          // this lane's probe: position P0 + kpos, cache entry idc
+  const int kpos = (WIDE ? wave_lane() : t) >> 2, idc = t & 3;   // this lane's probe: position P0 + kpos, cache entry idc
 
   CShard C;
   QShard& g = C.g;
@@ -280,6 +383,83 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   while (wave_any(g.state != Q_DONE)) {
     SIM_COUNT(7, 1);                                   // chain steps (wave level)
     uint64_t qt = QP_NOW();
+    if (WIDE) {
+      // All lanes hold the same state; reading it from lane 0 tells the compiler so: the
+      // state lives in scalar registers and the state machine branches for real.
+#define C_UNI(x) (x) = wave_bcast((x), 0)
+      C_UNI(g.state); C_UNI(g.status); C_UNI(g.position); C_UNI(g.pos_end); C_UNI(g.store_end);
+      C_UNI(g.insert_length); C_UNI(g.apply_random_heuristics);
+      C_UNI(g.sr_len); C_UNI(g.sr_dist); C_UNI(g.sr_score); g.sr_delta = (int32_t)wave_bcast((uint32_t)g.sr_delta, 0);
+      C_UNI(g.delayed); C_UNI(g.dict_lookups); C_UNI(g.dict_matches);
+      for (int i = 0; i < 4; ++i) g.dc[i] = (int32_t)wave_bcast((uint32_t)g.dc[i], 0);
+      C_UNI(g.blk_flags); C_UNI(g.blk_bytes); C_UNI(g.blk_pos);
+      C_UNI(g.r.input_pos); C_UNI(g.r.last_processed_pos); C_UNI(g.r.last_flush_pos);
+      C_UNI(g.r.last_insert_len); C_UNI(g.r.ncmds); C_UNI(g.r.nlits);
+      C_UNI(g.r.last_bytes); C_UNI(g.r.last_bytes_bits); g.r.flint = (int32_t)wave_bcast((uint32_t)g.r.flint, 0);
+      g.r.out_bytes = wave_bcast64(g.r.out_bytes, 0);
+      C_UNI(g.st_count); C_UNI(g.st_first); C_UNI(g.st_stride);
+      C_UNI(g.stat_searches); C_UNI(C.frontier); C_UNI(C.nslow); C_UNI(nsteps);
+#undef C_UNI
+    }
+    if (WIDE) {
+      // ---- the common path as a tight scalar loop (one shard per wave, uniform state) ----
+      // A step: evaluate 16 positions, walk the state machine over them with scalar code
+      // (readlane per position), commit at most one copy.  Anything else — block boundaries,
+      // positions the index cannot decide, unstored positions to account for, the static
+      // dictionary while its gate is open, the literal spree — leaves the loop; the generic step
+      // below handles exactly one such event and we come back.
+      for (;;) {
+        const bool lazy = g.state == Q_LAZY;
+        if (!(lazy || g.state == Q_SEARCH)) break;
+        if (!lazy && !(g.position + htl < g.pos_end)) break;
+        const uint32_t P0 = g.position + (lazy ? 1u : 0u);
+        if (C.frontier != P0 || g.st_count != 0) break;
+        if (!(g.dict_matches < (g.dict_lookups >> 7))) break;
+        const CEval ce = c_evaluate(J, C, true, P0, kpos, idc, bloom, force_slow, htl);
+        uint32_t k = 0, sr_k = 0xFFu;
+        bool commit = false;
+        while (k < (uint32_t)NPOS) {
+          const uint32_t f = wave_bcast(ce.e_flags, (int)(4u * k));
+          if ((f >> 30) != 2u) break;                            // not evaluated, or only the exact search knows
+          const uint32_t sk = f & 0x3FFFFFFFu;
+          if (g.state == Q_SEARCH) {
+            if (!(g.position + htl < g.pos_end)) break;
+            if (sk > K_MIN_SCORE) {
+              g.sr_score = sk; sr_k = k; g.delayed = 0; g.sr_delta = 0; g.state = Q_LAZY;
+            } else {
+              if (g.position + 1u > g.apply_random_heuristics) break;      // literal spree: generic
+              ++g.insert_length; ++g.position;
+            }
+            ++k;
+          } else {
+            if (sk == K_MIN_SCORE) { /* gate is closed (checked above): no dictionary probe */ }
+            ++k;
+            if (sk >= g.sr_score + 175u) {
+              ++g.position; ++g.insert_length;
+              g.sr_score = sk; sr_k = k - 1u; g.sr_delta = 0;
+              if (++g.delayed < 4u && g.position + htl < g.pos_end) continue;
+            }
+            commit = true;
+            break;
+          }
+        }
+        if (k == 0) break;
+        ++nsteps;
+        C.frontier = P0 + k;
+        g.stat_searches += k;
+        if (sr_k != 0xFFu) {
+          g.sr_len = wave_bcast(ce.e_len, (int)(4u * sr_k));
+          g.sr_dist = wave_bcast(ce.e_dist, (int)(4u * sr_k));
+        }
+        if (commit) {
+          q_commit(J, g, true, htl);
+          if (g.st_count != 0) {               // StoreRange: the copied positions are stored
+            c_stored(J, C, true, g.st_first, g.st_first + g.st_count, bloom);
+            g.st_count = 0;
+          }
+        }
+      }
+    }
     if (g.state == Q_PRE) q_driver_pre(J, g);
     if (wave_any(g.state == Q_SETUP)) {
       const bool su = g.state == Q_SETUP;
@@ -307,110 +487,22 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       ++nsteps;
       QP_ADD(g, 0, qt);
       // ---- evaluation: lane (kpos, idc) ----
-      const uint32_t Pk = P0 + (uint32_t)kpos;
-      const bool ev = want && Pk + htl <= g.pos_end;
-      const uint32_t max_length = g.pos_end - Pk;
-#if defined(C_PD32)
-      // 32-byte probes: a longer compare, fewer steps that need a second round trip
-      uint64_t cb[4], pb[4];
-      __builtin_memcpy(cb, g.data + (ev ? Pk : 0u), 32);
-      const uint32_t backward = q_dc_entry(g, idc);
-      const bool d_cand = ev && idc < J.ndist && (int32_t)backward > 0 && backward <= umin(Pk, J.max_backward_limit);
-      __builtin_memcpy(pb, g.data + (d_cand ? Pk - backward : 0u), 32);
-      const uint64_t rw = ev ? C.res[Pk] : 0ull;
-      uint32_t d_len = 0;
-      {
-        const uint64_t x0 = cb[0] ^ pb[0], x1 = cb[1] ^ pb[1], x2 = cb[2] ^ pb[2], x3 = cb[3] ^ pb[3];
-        const uint32_t md = x0 ? ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 8u + ((uint32_t)dev_ctz64(x1) >> 3)
-                          : x2 ? 16u + ((uint32_t)dev_ctz64(x2) >> 3) : x3 ? 24u + ((uint32_t)dev_ctz64(x3) >> 3) : 32u;
-        bool d_ext = false;
-        if (d_cand) { d_len = umin(md, max_length); d_ext = md == 32u && max_length > 32u; }
-        if (wave_any(d_ext)) { if (d_ext) d_len = c_extend_from(g.data, Pk, Pk - backward, max_length, 32u); }
-      }
-#else
-      uint64_t cb[2], pb[2];
-      __builtin_memcpy(cb, g.data + (ev ? Pk : 0u), 16);
-      const uint32_t backward = q_dc_entry(g, idc);
-      const bool d_cand = ev && idc < J.ndist && (int32_t)backward > 0 && backward <= umin(Pk, J.max_backward_limit);
-      __builtin_memcpy(pb, g.data + (d_cand ? Pk - backward : 0u), 16);
-      const uint64_t rw = ev ? C.res[Pk] : 0ull;
-      uint32_t d_len = 0;
-      {
-        const uint64_t x0 = cb[0] ^ pb[0], x1 = cb[1] ^ pb[1];
-        const uint32_t md = x0 ? ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 8u + ((uint32_t)dev_ctz64(x1) >> 3) : 16u;
-        bool d_ext = false;
-        if (d_cand) { d_len = umin(md, max_length); d_ext = md == 16u && max_length > 16u; }
-        if (wave_any(d_ext)) { if (d_ext) d_len = c_extend_from(g.data, Pk, Pk - backward, max_length, 16u); }
-      }
-#endif
-#if defined(Q_PROFILE)
-      if (wave_any(d_len == 0xFFFFFFFFu || rw == 0x123456789ull)) g.pf_acc++;   // (profiling fence: loads consumed)
-#endif
+      const CEval ce = c_evaluate(J, C, want, P0, kpos, idc, bloom, force_slow, htl);
+      const uint32_t e_flags = ce.e_flags, e_len = ce.e_len, e_dist = ce.e_dist;
       QP_ADD(g, 1, qt);
-      // Distance-cache winner of the position (:201-240).  The score is 135 * len + 1935 - penalty(i)
-      // with penalties 0, 39, 43, 43 < 135: ordering by (len, earlier entry) is ordering by score
-      // with the reference's first-wins tie break, so one reduction of len << 2 | (3 - i) is enough.
-      const bool d_ok = d_cand && (d_len >= 3u || (d_len == 2u && idc < 2));
-      const uint32_t d_key = d_ok ? (d_len << 2) | (3u - (uint32_t)idc) : 0u;
-      uint32_t d_best = umax(d_key, wave_quad_xor(d_key, 1));
-      d_best = umax(d_best, wave_quad_xor(d_best, 2));
-      const uint32_t dc_len = d_best >> 2;
-      const uint32_t dc_i = 3u - (d_best & 3u);
-      const uint32_t dc_dist = q_dc_entry(g, (int)dc_i);
-      uint32_t dc_score = K_MIN_SCORE;
-      if (d_best != 0) {
-        dc_score = 135u * dc_len + 1935u;
-        if (dc_i != 0) dc_score -= 39u + ((0x1CA10u >> (dc_i & 0xEu)) & 0xEu);
-      }
-      // the bucket part, from the index
-      const uint32_t rlo = (uint32_t)rw, rhi = (uint32_t)(rw >> 32);
-      const uint32_t kind = rlo >> 30;
-      uint32_t b_len = (rlo >> 24) & 63u;
-      const uint32_t b_dist = rlo & 0xFFFFFFu;
-      {
-        const bool b_long = ev && kind == IX_KIND_LONG;
-        if (wave_any(b_long)) { if (b_long) b_len = c_extend_from(g.data, Pk, Pk - b_dist, max_length, IX_CAP); }
-      }
-      const bool b_ok = ev && (kind == IX_KIND_EXACT || kind == IX_KIND_LONG);
-      const uint32_t b_score = b_ok ? 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u) : 0u;
-      const uint32_t keyP = hash_pos(cb[0], J.hasher_type, J.bucket_bits).key;
-      const bool b_wins = b_ok && b_score > dc_score;
-      const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & IX_DANGER) != 0 || force_slow ||
-                                     c_bloom_hit(bloom, keyP, rhi & 0xFFFFFFu) ||
-                                     (b_wins && b_len <= umax(dc_len, 3u)));
-#if defined(BROTLI_AMD_SIMT_SIM)
-      if (ev && idc == 0 && getenv("SIM_DBGPOS") && Pk == (uint32_t)atoi(getenv("SIM_DBGPOS")))
-        fprintf(stderr, "P %u key %x bit %u slot %x sidx %u kind %u blen %u bdist %u dc_len %u frontier %u\n", Pk, keyP,
-                (bloom[keyP >> 5] >> (keyP & 31)) & 1, bloom[IX_BLOOM_WORDS + (keyP & 255)], rhi & 0xFFFFFF, kind, b_len, b_dist, dc_len, C.frontier);
-      if (ev && idc == 0) {   // (statistics of the simulator runs: why positions go to the exact path)
-        if (kind == IX_KIND_SLOW) g_sim_counts[8]++;
-        else if (c_bloom_hit(bloom, keyP, rhi & 0xFFFFFFu)) g_sim_counts[9]++;
-        else if (b_wins && b_len <= umax(dc_len, 3u)) g_sim_counts[10]++;
-        if (kind == IX_KIND_LONG) g_sim_counts[11]++;
-        g_sim_counts[12]++;
-      }
-#endif
-      uint32_t e_len = 0, e_dist = 0, e_score = K_MIN_SCORE;
-      if (b_wins) { e_len = b_len; e_dist = b_dist; e_score = b_score; }
-      else if (d_best != 0) { e_len = dc_len; e_dist = dc_dist; e_score = dc_score; }
-      const uint32_t e_flags = e_score | (ev ? 0x80000000u : 0u) | (need_exact ? 0x40000000u : 0u);
-      uint32_t fl[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) fl[k] = q_bcast(e_flags, 4 * k);
-
       QP_ADD(g, 2, qt);
       // ---- the common transitions, all four positions in registers (:44-164) ----
       // SEARCH + hit -> LAZY; SEARCH + miss -> one more literal (only while neither the static
       // dictionary nor the literal spree can come into play); LAZY -> stay lazy or commit.
-      uint32_t consumed = 0, sr_from = 7u;
+      uint32_t consumed = 0, sr_from = 0xFFu;
       bool commit = false, stop = !want;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-#if !defined(C_NOEARLY)
+      uint32_t fl0 = 0;
+      for (int k = 0; k < NPOS; ++k) {
         if (k >= 2 && !wave_any(!stop)) break;                         // (most commands end at the second position)
-#endif
-        const uint32_t sk = fl[k] & 0x3FFFFFFFu;
-        const bool usable = (fl[k] >> 30) == 2u;                       // evaluated and decidable from the index
+        const uint32_t flk = WIDE ? wave_bcast(e_flags, 4 * k) : q_bcast(e_flags, 4 * k);
+        if (k == 0) fl0 = flk;
+        const uint32_t sk = flk & 0x3FFFFFFFu;
+        const bool usable = (flk >> 30) == 2u;                         // evaluated and decidable from the index
         if (!stop && !usable) stop = true;
         if (!stop) {
           if (g.state == Q_SEARCH) {
@@ -436,10 +528,16 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       QP_ADD(g, 3, qt);
       if (want && consumed != 0) { C.frontier = P0 + consumed; g.stat_searches += consumed; }
       // the pending match sits in the quad that evaluated it
-      if (wave_any(sr_from != 7u)) {
-        const int src = q_base() | (int)((sr_from & 3u) << 2);
-        const uint32_t l = wave_shfl(e_len, src), d = wave_shfl(e_dist, src);
-        if (sr_from != 7u) { g.sr_len = l; g.sr_dist = d; }
+      if (wave_any(sr_from != 0xFFu)) {
+        uint32_t l, d;
+        if (WIDE) {
+          const int src = (int)((sr_from & 15u) << 2);
+          l = wave_bcast(e_len, src); d = wave_bcast(e_dist, src);
+        } else {
+          const int src = q_base() | (int)((sr_from & 3u) << 2);
+          l = wave_shfl(e_len, src); d = wave_shfl(e_dist, src);
+        }
+        if (sr_from != 0xFFu) { g.sr_len = l; g.sr_dist = d; }
       }
       bool committed = commit;
       if (wave_any(commit)) q_commit(J, g, commit, htl);
@@ -449,17 +547,17 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       const bool gen = want && consumed == 0;
       if (wave_any(gen)) {
         QResult cur;
-        cur.len = q_bcast(e_len, 0);
-        cur.distance = q_bcast(e_dist, 0);
-        cur.score = fl[0] & 0x3FFFFFFFu;
+        cur.len = WIDE ? wave_bcast(e_len, 0) : q_bcast(e_len, 0);
+        cur.distance = WIDE ? wave_bcast(e_dist, 0) : q_bcast(e_dist, 0);
+        cur.score = fl0 & 0x3FFFFFFFu;
         cur.delta = 0;
-        bool take = gen && (fl[0] & 0x80000000u) != 0;
+        bool take = gen && (fl0 & 0x80000000u) != 0;
         if (take) {
           if (g.state == Q_SEARCH) take = g.position == P0 && g.position + htl < g.pos_end;
           else take = g.state == Q_LAZY && g.position + 1u == P0;
         }
         if (gen && !take) { g.status |= QST_ERROR | QST_DONE; g.state = Q_DONE; }   // cannot happen: fail, do not spin
-        const bool exact = take && (fl[0] & 0x40000000u) != 0;
+        const bool exact = take && (fl0 & 0x40000000u) != 0;
         if (wave_any(exact)) {
           const QResult sx = c_search_exact(J, C, exact, P0, scratch);
           if (exact) { cur = sx; ++C.nslow; }
