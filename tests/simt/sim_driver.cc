@@ -167,8 +167,10 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
     uint64_t se = 0, sl = 0;
     for (const ShardState& S : states) { se += S.stat_searches; sl += S.ix_slow; }
     fprintf(stderr, "indexed parse: %llu searches, %llu exact (in-chain) searches; wave steps %llu; evaluated positions %llu: "
-            "index-undecidable %llu, bloom %llu, gate-dependent %llu, long %llu\n", (unsigned long long)se, (unsigned long long)sl,
-            g_sim_counts[7], g_sim_counts[12], g_sim_counts[8], g_sim_counts[9], g_sim_counts[10], g_sim_counts[11]);
+            "index-undecidable %llu, bloom %llu, gate-dependent %llu, long %llu; fast-loop steps %llu\n", (unsigned long long)se, (unsigned long long)sl,
+            g_sim_counts[7], g_sim_counts[12], g_sim_counts[8], g_sim_counts[9], g_sim_counts[10], g_sim_counts[11], g_sim_counts[14]);
+    fprintf(stderr, "fast loop stopped at its first position: long cache candidate %llu, long/undecidable index %llu, tainted key %llu, gate-dependent %llu, not evaluated %llu\n",
+            g_sim_counts[1], g_sim_counts[2], g_sim_counts[3], g_sim_counts[4], g_sim_counts[5]);
     memset(g_sim_counts, 0, sizeof(g_sim_counts));
   }
   size_t n = 0;

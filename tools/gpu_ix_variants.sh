@@ -7,6 +7,6 @@ run() {  # name, env...
 }
 timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -2
 run wide8
-for v in ww4 ww5; do run $v BROTLI_AMD_HIP_LIB=$PWD/build/var/lib_$v.so; done
-BENCH_ARGS="--shard-kb 256" run ww4_256k BROTLI_AMD_HIP_LIB=$PWD/build/var/lib_ww4.so
-BENCH_ARGS="--shard-kb 512" run ww4_512k BROTLI_AMD_HIP_LIB=$PWD/build/var/lib_ww4.so
+for v in ww5 ww6; do run $v BROTLI_AMD_HIP_LIB=$PWD/build/var/lib_$v.so; done
+BENCH_ARGS="--shard-kb 256" run wide8_256k
+BENCH_ARGS="--shard-kb 512" run wide8_512k
