@@ -17,6 +17,10 @@ struct Command {
   uint16_t cmd_prefix;
   uint16_t dist_prefix;  // low 10 bits: distance symbol; high 6: #extra bits
 };
+// A command the serial chain (k_chain.h) left unencoded: cmd_prefix = CMD_RAW, dist_extra = the
+// distance CODE (backward_references.c:87-109); k_cmd_encode fills in the prefix fields for 64
+// commands at a time before the meta-block is built.
+#define CMD_RAW 0xFFFFu
 
 // Hash-table record, one per bucket key: everything one FindLongestMatch /
 // Store touches for a key sits in ONE 128-byte line (the reference keeps

@@ -190,9 +190,9 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
       const uint64_t ns = plan->shards.size();
       uint32_t v = ns <= resident ? 1u : ns <= 2 * resident ? 2u : 4u;
       if (const char* g = getenv("BROTLI_AMD_CGROUPS")) v = (uint32_t)atoi(g);
-      {   // one shard per wave with wave-uniform state (default); BROTLI_AMD_WIDE=0: 16-lane groups
+      {   // BROTLI_AMD_WIDE=1: one shard per wave with wave-uniform state (experiment)
         const char* w = getenv("BROTLI_AMD_WIDE");
-        if (!w || atoi(w) != 0) { plan->J.flags |= JOB_FLAG_WIDE; v = 1; }
+        if (w && atoi(w) != 0) { plan->J.flags |= JOB_FLAG_WIDE; v = 1; }
       }
       plan->J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
       if (v == 1 || v == 2) plan->J.flags |= v << JOB_FLAG_GROUPS_SHIFT;
@@ -262,6 +262,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       hipLaunchKernelGGL(k_parse4, dim3((nshards + gpw - 1) / gpw), dim3(64), 0, c->stream, a);
     else
       hipLaunchKernelGGL(k_parse, dim3(nshards), dim3(64), 0, c->stream, a);
+    if (indexed) hipLaunchKernelGGL(k_cmd_encode, dim3(nshards * CE_SPLIT), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev[3], c->stream));
     if (stages & STAGE_BUILD) hipLaunchKernelGGL(k_build, dim3(nshards), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev[4], c->stream));

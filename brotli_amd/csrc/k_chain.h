@@ -14,10 +14,12 @@
 //     cache has not changed (a committed copy ends the step).  A typical command —
 //     match at P, lazy probe of P + 1 loses, commit — is one step;
 //   * book-keeping of which storable positions were NOT stored (k_index.h): a
-//     bitmap in HBM plus a Bloom filter of their bucket keys in LDS.  A search is
-//     taken from the index only if no unstored position can share its key, the
-//     index entry is decidable in isolation (IX_KIND_*), and the bucket winner does
-//     not depend on the byte gate (`unsure`, as in k_parse4.h).  Otherwise the
+//     bitmap in HBM, and a taint bit in res[] of the (at most 16) positions that
+//     follow an unstored one in its key run — exactly the searches whose bucket
+//     window it would have been part of.  A search is taken from the index only if
+//     its position is not tainted, the index entry is decidable in isolation
+//     (IX_KIND_*), and the bucket winner does not depend on the byte gate
+//     (`unsure`, as in k_parse4.h).  Otherwise the
 //     group searches the position itself, exactly, from the (key, position)-sorted
 //     array: c_search_exact() reproduces the ring contents the reference would
 //     hold — the last 16 STORED predecessors of the key run, masked by the 16-bit
@@ -29,62 +31,47 @@
 #include "k_index.h"
 #include "k_parse4.h"
 
-#define C_GROUP_LDS_WORDS (IX_BLOOM_WORDS + IX_SKIPTAB_WORDS + 16u)   // key bitmap, newest-unstored table, 16 ring slots
+#define C_GROUP_LDS_WORDS 16u                                          // 16 ring slots of c_search_exact
 #define C_LDS_WORDS (Q_GROUPS * C_GROUP_LDS_WORDS)
 
 struct CShard {
   QShard g;
   IxGeom geo;
-  const uint64_t* res;
+  uint64_t* res;
   const uint32_t* srt;
   uint8_t* skip;
   uint32_t frontier;     // every storable position below it is either stored or marked in `skip`
   uint32_t nslow;
 };
 
-// Which keys have unstored positions, and does one of them sit in the window of a search?
-//   bloom[key >> 5] bit (key & 31): some storable position of this key was passed over;
-//   tab[key & 255] (behind the bitmap): {1, key >> 8 (7 bits), sorted index (24 bits)} of the
-//   NEWEST unstored position of the one key that owns the slot, 0 = empty, C_TAB_CONFLICT =
-//   several keys hit the slot (then the bitmap alone decides).
-// A search at sorted index s looks at the sorted indices s - 16 .. s - 1 of its key run
-// (k_index.h); an unstored position matters iff it is one of them, and if the newest one of
-// the key is not, no older one is.
-#define C_TAB_CONFLICT 0x7FFFFFFFu
-DEV bool c_bloom_hit(const uint32_t* bloom, uint32_t key, uint32_t sidx) {
-  if (!((bloom[key >> 5] >> (key & 31u)) & 1u)) return false;
-  const uint32_t e = bloom[IX_BLOOM_WORDS + (key & 255u)];
-  if (!(e & 0x80000000u) || ((e >> 24) & 127u) != (key >> 8)) return true;
-  return sidx - (e & 0xFFFFFFu) - 1u < 16u;
-}
+DEV uint32_t c_res_hi(const CShard& C, uint32_t x) { return ((const uint32_t*)(C.res + x))[1]; }
 
 // Marks the storable positions of [a, b) as not stored — except, for a literal spree
-// (stride > 1), the ones the spree did store: sfirst + i * stride.
+// (stride > 1), the ones the spree did store: sfirst + i * stride.  An unstored position x is
+// missing from the bucket window of the (at most 16) positions that follow it in its key run:
+// their index results no longer hold, so they get IX_TAINT (the chain searches them itself,
+// from `srt` and this bitmap).  All of it is this group's own memory: plain loads and stores.
 DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint32_t b,
-                      uint32_t sfirst, uint32_t stride, uint32_t* bloom) {
+                      uint32_t sfirst, uint32_t stride) {
   const int t = q_t();
+  (void)J;
   uint32_t cur = a;
   while (wave_any(act && cur < b)) {
     const bool on = act && cur < b;
     const uint32_t x = cur + (uint32_t)t;
     bool sk = on && x < b && ix_storable(C.geo, x);
     if (sk && stride > 1u && ((x - sfirst) % stride) == 0u) sk = false;
-    uint32_t key = 0, entry = 0;
-    if (sk) {
-      key = hash_pos(ld64(C.g.data + x), J.hasher_type, J.bucket_bits).key;
-      lds_atomic_or(&bloom[key >> 5], 1u << (key & 31u));
-      entry = 0x80000000u | ((key >> 8) << 24) | ((uint32_t)(C.res[x] >> 32) & 0xFFFFFFu);
+    const uint32_t hi = sk ? c_res_hi(C, x) : 0u;
+    const uint32_t s = hi & 0xFFFFFFu, ns = sk ? (hi >> IX_NSUCC_SHIFT) & 31u : 0u;
+    const uint32_t nmax = wave_max_u32(ns);
+    for (uint32_t j = 1; j <= nmax; ++j) {
+      if (j <= ns) {
+        const uint32_t p = C.srt[s + j] & 0xFFFFFFu;
+        uint32_t* w = (uint32_t*)(C.res + p) + 1;
+        *w = *w | IX_TAINT;      // (lanes that hit the same word write the same bit)
+      }
     }
     const uint32_t m16 = q_mask16(wave_ballot(sk));
-    // the newest-unstored table, one lane at a time in position order
-    for (uint32_t left = m16; wave_any(left != 0); left &= left - 1u) {
-      if (left != 0 && (uint32_t)t == (uint32_t)dev_ctz32(left)) {
-        uint32_t* slot = &bloom[IX_BLOOM_WORDS + (key & 255u)];
-        const uint32_t e = *slot;
-        *slot = (e == 0 || ((e & 0x80000000u) && ((e ^ entry) >> 24) == 0)) ? entry : C_TAB_CONFLICT;
-      }
-      wave_sync();
-    }
 #if defined(BROTLI_AMD_SIMT_SIM)
     if (on && t == 0 && m16 != 0) { g_sim_counts[13] += (unsigned)__builtin_popcount(m16); if (getenv("SIM_SKIPS")) fprintf(stderr, "skip [%u..] mask %x (range %u..%u stride %u)\n", cur, m16, a, b, stride); }
 #endif
@@ -99,8 +86,8 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
 
 // The parse stored [a, b) (a single position, a StoreRange, the stitch): everything
 // storable between the frontier and a was passed over.
-DEV void c_stored(const JobParams& J, CShard& C, bool act, uint32_t a, uint32_t b, uint32_t* bloom) {
-  if (wave_any(act && C.frontier < a)) c_mark_range(J, C, act && C.frontier < a, C.frontier, a, 0, 1, bloom);
+DEV void c_stored(const JobParams& J, CShard& C, bool act, uint32_t a, uint32_t b) {
+  if (wave_any(act && C.frontier < a)) c_mark_range(J, C, act && C.frontier < a, C.frontier, a, 0, 1);
   if (act) C.frontier = b;
 }
 
@@ -212,6 +199,11 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
                                      d_score, b_cand, b_len, b_prev, b_score);
     if (slow) r = s;
   }
+#if defined(BROTLI_AMD_SIMT_SIM)
+  if (getenv("SIM_DBGPOS") && want && (!getenv("SIM_DBGSHARD") || g.shard == (uint32_t)atoi(getenv("SIM_DBGSHARD"))) && P == (uint32_t)atoi(getenv("SIM_DBGPOS")))
+    fprintf(stderr, "EXACT P %u t %d found %u nvalid %u b_cand %d b_prev %u b_len %u b_score %u d_cand %d d_len %u d_score %u -> len %u dist %u score %u slow %d sidx %d\n",
+            P, t, found, nvalid, (int)b_cand, b_prev, b_len, b_score, (int)d_cand, d_len, d_score, r.len, r.distance, r.score, (int)slow, sidx);
+#endif
   return r;
 }
 
@@ -220,7 +212,7 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
 // e_flags = score | evaluated << 31 | needs-the-exact-search << 30.
 struct CEval { uint32_t e_flags, e_len, e_dist; };
 DEV CEval c_evaluate(const JobParams& J, CShard& C, bool want, uint32_t P0, int kpos, int idc,
-                     const uint32_t* bloom, bool force_slow, uint32_t htl) {
+                     bool force_slow, uint32_t htl) {
   QShard& g = C.g;
   const uint32_t Pk = P0 + (uint32_t)kpos;
   const bool ev = want && Pk + htl <= g.pos_end;
@@ -284,18 +276,13 @@ DEV CEval c_evaluate(const JobParams& J, CShard& C, bool want, uint32_t P0, int 
   }
   const bool b_ok = ev && (kind == IX_KIND_EXACT || kind == IX_KIND_LONG);
   const uint32_t b_score = b_ok ? 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u) : 0u;
-  const uint32_t keyP = hash_pos(cb[0], J.hasher_type, J.bucket_bits).key;
   const bool b_wins = b_ok && b_score > dc_score;
-  const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & IX_DANGER) != 0 || force_slow ||
-                                 c_bloom_hit(bloom, keyP, rhi & 0xFFFFFFu) ||
+  const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & (IX_DANGER | IX_TAINT)) != 0 || force_slow ||
                                  (b_wins && b_len <= umax(dc_len, 3u)));
 #if defined(BROTLI_AMD_SIMT_SIM)
-  if (ev && idc == 0 && getenv("SIM_DBGPOS") && Pk == (uint32_t)atoi(getenv("SIM_DBGPOS")))
-    fprintf(stderr, "P %u key %x bit %u slot %x sidx %u kind %u blen %u bdist %u dc_len %u frontier %u\n", Pk, keyP,
-            (bloom[keyP >> 5] >> (keyP & 31)) & 1, bloom[IX_BLOOM_WORDS + (keyP & 255)], rhi & 0xFFFFFF, kind, b_len, b_dist, dc_len, C.frontier);
   if (ev && idc == 0) {   // (statistics of the simulator runs: why positions go to the exact path)
     if (kind == IX_KIND_SLOW) g_sim_counts[8]++;
-    else if (c_bloom_hit(bloom, keyP, rhi & 0xFFFFFFu)) g_sim_counts[9]++;
+    else if (rhi & IX_TAINT) g_sim_counts[9]++;
     else if (b_wins && b_len <= umax(dc_len, 3u)) g_sim_counts[10]++;
     if (kind == IX_KIND_LONG) g_sim_counts[11]++;
     g_sim_counts[12]++;
@@ -321,7 +308,7 @@ DEV CEval c_evaluate(const JobParams& J, CShard& C, bool want, uint32_t P0, int 
 // open and the literal spree leave the loop: the generic step of chain_round handles exactly
 // one such event and comes back here.
 template <int HT>
-DEV void c_fast_loop(const JobParams& J, CShard& C, const uint32_t* bloom, int kpos, int idc,
+DEV void c_fast_loop(const JobParams& J, CShard& C, int kpos, int idc,
                      bool force_slow, uint32_t& nsteps) {
   QShard& g = C.g;
   constexpr uint32_t htl = HT == 68 ? 8u : 4u;
@@ -379,10 +366,7 @@ DEV void c_fast_loop(const JobParams& J, CShard& C, const uint32_t* bloom, int k
     const uint32_t kind = rlo >> 30, b_len = (rlo >> 24) & 63u, b_dist = rlo & 0xFFFFFFu;
     const bool b_ok = kind == IX_KIND_EXACT;
     const uint32_t b_score = 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u);
-    uint32_t key;
-    if (HT == 68) key = (uint32_t)((cb[0] * (0x1FE35A7BD3579BD3ull << 24)) >> (64 - 15));
-    else key = ((uint32_t)cb[0] * 0x1E35A7BDu) >> (32 - J.bucket_bits);
-    const bool tainted = c_bloom_hit(bloom, key, rhi & 0xFFFFFFu);
+    const bool tainted = (rhi & IX_TAINT) != 0;
     const bool b_wins = b_ok && b_score > dc_score;
     const bool need = kind >= IX_KIND_LONG || (rhi & IX_DANGER) != 0 || tainted || (d_key >> 31) != 0 ||
                       force_slow || (b_wins && b_len <= umax(dc_len, 3u));
@@ -446,7 +430,7 @@ DEV void c_fast_loop(const JobParams& J, CShard& C, const uint32_t* bloom, int k
         if (frontier == range_start) frontier = range_end;
         else {                                                 // positions passed over: mark them
           C.frontier = frontier;
-          c_stored(J, C, true, range_start, range_end, const_cast<uint32_t*>(bloom));
+          c_stored(J, C, true, range_start, range_end);
           frontier = wave_bcast(C.frontier, 0);
         }
       }
@@ -475,6 +459,232 @@ DEV void c_fast_loop(const JobParams& J, CShard& C, const uint32_t* bloom, int k
   nsteps += steps;
 }
 
+// ---- the common path of a 16-lane group: one whole command per step, no loops --------------
+// (up to four shards per wave.)  Lane t of a group evaluates position pos + t completely: the
+// four distance-cache candidates (16 bytes each; a longer one sends the position to the exact
+// search) against the bucket result of the index.  With the 16 results in the lanes, what
+// CreateBackwardReferences does next (:44-206) is bit arithmetic on three ballots:
+//   literals   = positions before the first one with a match (bounded by the literal spree);
+//   lazy chain = how many of the following positions beat their predecessor by >= 175 (at most 4);
+// then ONE commit per step — distance code, distance cache, command — so every VALU instruction
+// of a step advances four encoders by a whole command.  Positions the index cannot decide are
+// searched exactly (c_search_exact) when they come first; block boundaries, the literal spree,
+// the static dictionary and a lazy chain that runs into an undecidable position leave the loop
+// for the generic step of chain_round.  Needs pos + 64 <= pos_end, so that every position of the
+// step is searchable and no match of <= 16 compared bytes is cut by the block end.
+struct C16 { uint32_t w[4]; };
+DEV C16 c_load16(const uint8_t* p) { C16 r; __builtin_memcpy(&r, p, 16); return r; }
+// Common prefix of two 16-byte strings in bytes (0 .. 16): straight-line, 16 VALU instructions.
+// ffbl gives 0xFFFFFFFF for an all-equal word, so the minimum falls through to the next word.
+DEV uint32_t c_prefix16(const C16& a, const C16& b) {
+  uint32_t n = umin(dev_ffbl32(a.w[3] ^ b.w[3]), 32u);
+  n = umin(dev_ffbl32(a.w[2] ^ b.w[2]), n + 32u);
+  n = umin(dev_ffbl32(a.w[1] ^ b.w[1]), n + 32u);
+  n = umin(dev_ffbl32(a.w[0] ^ b.w[0]), n + 32u);
+  return n >> 3;
+}
+
+// dc[i] for a lane-varying i: three selects, no branches.
+// (Values, not a pointer to the cache: a select between loads would be turned into a load from a
+// selected address and pin the whole shard state in scratch memory.)
+DEV uint32_t c_dc_pick(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3, uint32_t i) {
+  uint32_t d = d0;
+  d = i == 1u ? d1 : d;
+  d = i == 2u ? d2 : d;
+  d = i == 3u ? d3 : d;
+  return d;
+}
+// ComputeDistanceCode (backward_references.c:87-109) as a chain of selects, last rule first.
+DEV uint32_t c_distance_code(uint32_t distance, uint32_t max_distance, uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
+  const uint32_t o0 = distance + 3u - d0, o1 = distance + 3u - d1;
+  uint32_t c = distance + 15u;
+  uint32_t k = distance == d3 ? 3u : c;
+  k = distance == d2 ? 2u : k;
+  k = o1 < 7u ? (0xFDB1ACEu >> (4u * (o1 & 7u))) & 0xFu : k;
+  k = o0 < 7u ? (0x9750468u >> (4u * (o0 & 7u))) & 0xFu : k;
+  k = distance == d1 ? 1u : k;
+  k = distance == d0 ? 0u : k;
+  return distance <= max_distance ? k : c;
+}
+
+DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool alive, uint32_t* scratch, uint32_t& nsteps) {
+  QShard& g = C.g;
+  const int t = q_t();
+  const uint32_t limit = J.max_backward_limit;
+  const bool force_slow = (J.flags & JOB_FLAG_FORCE_SLOW) != 0;
+  for (;;) {
+    {
+      // positions passed over since the last store are known now (see chain_round) — but not at
+      // the end of a block: the next block's stitch still stores its last three positions
+      const bool lag = alive && g.state == Q_SEARCH && g.st_count == 0 && C.frontier < g.position &&
+                       g.position + 64u <= g.pos_end;
+      if (wave_any(lag)) c_mark_range(J, C, lag, C.frontier, g.position, 0, 1);
+      if (lag) C.frontier = g.position;
+    }
+    const bool can = alive && g.state == Q_SEARCH && g.st_count == 0 && C.frontier == g.position &&
+                     g.position + 64u <= g.pos_end;
+    if (wave_any(alive && g.state != Q_DONE && !can) || !wave_any(can)) break;
+    ++nsteps;
+    SIM_COUNT(14, 1);
+    uint64_t ft = QP_NOW();
+    const uint32_t pos = g.position;
+    const uint32_t Pk = pos + (uint32_t)t;
+    // ---- evaluation of position Pk ----
+    const C16 cb = c_load16(g.data + (can ? Pk : 0u));
+    const uint64_t rw = C.res[can ? Pk : 0u];
+    C16 pb[4];
+    const uint32_t maxb = umin(Pk, limit);
+    const uint32_t dcs[4] = {(uint32_t)g.dc[0], (uint32_t)g.dc[1], (uint32_t)g.dc[2], (uint32_t)g.dc[3]};
+    bool d_cand[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t dcv = dcs[i];
+      d_cand[i] = can && (dcv - 1u) < maxb;                   // 0 < distance <= max_backward
+      pb[i] = c_load16(g.data + (d_cand[i] ? Pk - dcv : 0u));
+    }
+    // (len, earlier entry) orders the cache candidates like their scores do (see c_evaluate)
+    uint32_t d_key = 0;
+    bool d_long = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t md = c_prefix16(cb, pb[i]);
+      const bool ok = d_cand[i] && md >= (i < 2 ? 2u : 3u);
+      d_long = d_long || (d_cand[i] && md == 16u);
+      d_key = umax(d_key, ok ? (md << 2) | (3u - (uint32_t)i) : 0u);
+    }
+    const uint32_t dc_len = (d_key >> 2) & 31u, dc_i = 3u - (d_key & 3u);
+    const uint32_t dc_dist = c_dc_pick(dcs[0], dcs[1], dcs[2], dcs[3], dc_i);
+    uint32_t dc_score = 135u * dc_len + 1935u - (dc_i == 0u ? 0u : dc_i == 1u ? 39u : 43u);
+    dc_score = d_key != 0 ? dc_score : K_MIN_SCORE;
+    const uint32_t rlo = (uint32_t)rw, rhi = (uint32_t)(rw >> 32);
+    const uint32_t kind = rlo >> 30, b_len = (rlo >> 24) & 63u, b_dist = rlo & 0xFFFFFFu;
+    const uint32_t b_score = 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u);
+    const bool b_wins = kind == IX_KIND_EXACT && b_score > dc_score;
+    const bool need = kind >= IX_KIND_LONG || (rhi & (IX_DANGER | IX_TAINT)) != 0 || d_long || force_slow ||
+                      (b_wins && b_len <= umax(dc_len, 3u));
+    uint32_t sc = b_wins ? b_score : dc_score;
+    uint32_t ln = b_wins ? b_len : dc_len;
+    uint32_t ds = b_wins ? b_dist : dc_dist;
+    uint32_t use16 = q_mask16(wave_ballot(can && !need));
+    QP_ADD(g, 8, ft);
+    // ---- an undecidable first position: the exact search, then on with its result ----
+    bool dead = false;                                          // this step cannot move the group
+    {
+      const bool fix = can && (use16 & 1u) == 0u;
+      if (wave_any(fix)) {
+        const QResult r = c_search_exact(J, C, fix, pos, scratch);
+        if (fix) {
+          ++C.nslow;
+          if (t == 0) { sc = r.score; ln = r.len; ds = r.distance; }
+          use16 |= 1u;
+        }
+      }
+    }
+    uint32_t hit16 = q_mask16(wave_ballot(sc > K_MIN_SCORE));
+    // ---- nothing found at the first position while the static dictionary is being consulted
+    // (hash.h:179-202): probe it here.  A dictionary match starts the lazy evaluation, which the
+    // generic step carries on with (it may ask the dictionary again at the next position).
+    bool gate_closed = g.dict_matches < (g.dict_lookups >> 7);
+    bool dict0 = false;                                         // the dictionary was asked about position 0, in vain
+    {
+      const bool dq = can && !gate_closed && (hit16 & 1u) == 0u;
+      if (wave_any(dq)) {
+        QResult r;
+        r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; r.delta = 0;
+        q_dict_search(J, T, g, dq, pos, g.pos_end - pos, r);
+        if (dq) {
+          if (r.score > K_MIN_SCORE) {
+            g.sr_len = r.len; g.sr_dist = r.distance; g.sr_score = r.score; g.sr_delta = r.delta;
+            g.delayed = 0;
+            g.state = Q_LAZY;
+            g.stat_searches++;
+            C.frontier = pos + 1u;
+            dead = true;
+          } else dict0 = true;
+        }
+      }
+    }
+    QP_ADD(g, 9, ft);
+    // lane t: does position t + 1 beat position t by the lazy-matching margin (:139)?
+    const uint32_t sc_next = wave_row_ror(sc, 15);              // lane t reads lane (t + 1) & 15 of its group
+    const uint32_t adv16 = q_mask16(wave_ballot(t < 15 && sc_next >= sc + 175u));
+    const uint32_t U = (uint32_t)dev_ctz32(~use16 | 0x10000u);                  // usable prefix
+    const uint32_t m = (uint32_t)dev_ctz32(hit16 | 0x10000u);                   // first match
+    // literals allowed before the spree check trips (:208) / the dictionary has to be asked
+    const uint32_t room = g.apply_random_heuristics >= pos ? g.apply_random_heuristics - pos : 0u;
+    const uint32_t missmax = gate_closed ? room : dict0 ? umin(room, 1u) : 0u;
+    const uint32_t tt = umin((uint32_t)dev_ctz32(~(adv16 >> (m & 15u)) | 0x10u), 4u);   // positions the match is delayed by
+    const uint32_t last = m + umin(tt + 1u, 4u);                                // last position probed
+    // while the static dictionary is being consulted, a probe that finds nothing asks it:
+    // only probes with a match are decidable here
+    const uint32_t probes = (0x3FFFFu >> (17u - umin(last, 16u))) & ~(0x1FFFFu >> (16u - umin(m, 16u)));   // bits m + 1 .. last
+    const bool have = can && !dead && m < 16u && m <= missmax && last < U &&
+                      (gate_closed || (hit16 & probes) == probes);
+    const uint32_t L = umin(umin(m, U), missmax);               // literals this step may consume without a match
+    if (can && !dead && !have && L != 0u) {
+      g.position = pos + L;
+      g.insert_length += L;
+      g.stat_searches += L;
+      C.frontier = pos + L;
+    }
+    if (can && !have && (dead || L == 0u)) { g.status |= 0x80000000u; }         // needs the generic step
+#if defined(BROTLI_AMD_SIMT_SIM)
+    if (can && t == 0) {
+      if (have) g_sim_counts[0]++;                       // steps with a commit
+      else if (dead) g_sim_counts[2]++;                  // dictionary match: lazy evaluation handed to the generic step
+      else if (L != 0u) g_sim_counts[1]++;               // literal-only steps
+      else if (m < 16u && m < U && m <= missmax && last >= U) g_sim_counts[3]++;   // lazy chain runs into an undecidable position
+      else if (m < 16u && m < U && m <= missmax) g_sim_counts[4]++;                // lazy probe without a match, dictionary gate open
+      else if (missmax == 0u) g_sim_counts[5]++;         // spree / dictionary gate at the first position
+      else g_sim_counts[6]++;
+    }
+#endif
+    QP_ADD(g, 10, ft);
+    if (wave_any(have)) {
+      // ---- one commit (:165-206) ----
+      const uint32_t f = m + tt;
+      const int src = q_base() | (int)(f & 15u);
+      const uint32_t sr_len = wave_shfl(ln, src), sr_dist = wave_shfl(ds, src);
+      if (have && sr_len < 2u) { g.status |= QST_ERROR | QST_DONE; g.state = Q_DONE; }   // cannot happen: fail, do not spin
+      const uint32_t pc = pos + f;                              // the copy starts here
+      const uint32_t ins = g.insert_length + f;
+      const uint32_t newpos = pc + sr_len;
+      uint32_t range_start = pc + 2u;
+      const uint32_t range_end = umin(newpos, g.store_end);
+      if (sr_dist < (sr_len >> 2)) range_start = umin(range_end, umax(range_start, newpos - (sr_dist << 2)));
+      const bool ranged = range_start < range_end;
+      if (have) C.frontier = pos + last + 1u;                   // searched positions are stored (:293-295)
+      const bool gap1 = have && ranged && C.frontier != range_start;
+      if (wave_any(gap1)) c_mark_range(J, C, gap1, C.frontier, range_start, 0, 1);
+      if (have && ranged) C.frontier = range_end;
+      const bool gap2 = have && C.frontier < newpos;
+      if (wave_any(gap2)) c_mark_range(J, C, gap2, C.frontier, newpos, 0, 1);
+      if (have) {
+        C.frontier = umax(C.frontier, newpos);
+        const uint32_t dictionary_start = umin(pc + g.stream_offset, limit);
+        const uint32_t code = c_distance_code(sr_dist, dictionary_start, dcs[0], dcs[1], dcs[2], dcs[3]);
+        if (sr_dist <= dictionary_start && code > 0u) {
+          g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)sr_dist;
+        }
+        if (t == 0) {
+          Command c;
+          c.insert_len = ins; c.copy_len = sr_len; c.dist_extra = code; c.cmd_prefix = CMD_RAW; c.dist_prefix = 0;
+          g.cmds[g.r.ncmds] = c;
+        }
+        ++g.r.ncmds;
+        g.r.nlits += ins;
+        g.insert_length = 0;
+        g.apply_random_heuristics = pc + 2u * sr_len + J.spree_window;
+        g.position = newpos;
+        g.stat_searches += last + 1u;
+      }
+    }
+    QP_ADD(g, 11, ft);
+    if (wave_any((g.status & 0x80000000u) != 0)) break;
+  }
+  g.status &= 0x7FFFFFFFu;
+}
+
 // ---- the kernel body ---------------------------------------------------------------------
 // WIDE: the whole wave serves ONE shard.  The four 16-lane groups hold identical copies of the
 // state (so everything that is per group above — marking, exact search, dictionary, block glue —
@@ -495,8 +705,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   const uint32_t htl = hasher_htl(J.hasher_type);
   const ShardDesc& D = shards[alive ? shard : 0];
   const ShardState* S0 = &states[alive ? shard : 0];
-  uint32_t* bloom = lds + gi * C_GROUP_LDS_WORDS;
-  uint32_t* scratch = bloom + IX_BLOOM_WORDS + IX_SKIPTAB_WORDS;
+  uint32_t* scratch = lds + gi * C_GROUP_LDS_WORDS;
   const int kpos = (WIDE ? wave_lane() : t) >> 2, idc = t & 3;   // this lane's probe: position P0 + kpos, cache entry idc
 
   CShard C;
@@ -531,16 +740,11 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   IxLayout L;
   ix_layout(D.len, J.ix_slices, J.ix_nb_log2, &L);
   uint8_t* ixb = ws + D.ix_off;
-  C.res = (const uint64_t*)(ixb + L.res);
+  C.res = (uint64_t*)(ixb + L.res);
   C.srt = (const uint32_t*)(ixb + L.srt);
   C.skip = ixb + L.skip;
   C.frontier = S0->ix_frontier;
   C.nslow = 0;
-  {
-    const uint32_t* gb = (const uint32_t*)(ixb + L.bloom);
-    for (uint32_t i = (uint32_t)t; i < IX_BLOOM_WORDS + IX_SKIPTAB_WORDS; i += 16u) bloom[i] = participated ? gb[i] : 0u;
-  }
-  wave_sync();
   const bool force_slow = (J.flags & JOB_FLAG_FORCE_SLOW) != 0;
 
   uint32_t nsteps = 0;
@@ -566,16 +770,21 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
 #undef C_UNI
     }
     if (WIDE) {
-      if (J.hasher_type == 68) c_fast_loop<68>(J, C, bloom, kpos, idc, force_slow, nsteps);
-      else c_fast_loop<58>(J, C, bloom, kpos, idc, force_slow, nsteps);
+      if (J.hasher_type == 68) c_fast_loop<68>(J, C, kpos, idc, force_slow, nsteps);
+      else c_fast_loop<58>(J, C, kpos, idc, force_slow, nsteps);
     }
+#if defined(BROTLI_AMD_SIMT_SIM)
+    if (!WIDE && !getenv("SIM_NOFAST")) c_group_fast(J, T, C, alive, scratch, nsteps);
+#else
+    if (!WIDE) c_group_fast(J, T, C, alive, scratch, nsteps);
+#endif
     if (g.state == Q_PRE) q_driver_pre(J, g);
     if (wave_any(g.state == Q_SETUP)) {
       const bool su = g.state == Q_SETUP;
       // StitchToPreviousBlock (..64_simd_inc.h:139-151) stores the last three positions of the
       // previous block
       if (wave_any(su && (g.blk_flags & QBLK_STITCH)))
-        c_stored(J, C, su && (g.blk_flags & QBLK_STITCH), g.blk_pos - 3u, g.blk_pos, bloom);
+        c_stored(J, C, su && (g.blk_flags & QBLK_STITCH), g.blk_pos - 3u, g.blk_pos);
       q_setup_extend(J, g, su);
     }
     // block finished? (loop guard of CreateBackwardReferences, :44 and :239-241)
@@ -589,14 +798,14 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       const uint32_t P0 = g.position + (g.state == Q_LAZY ? 1u : 0u);
       // positions passed over since the last store are known now; the Bloom filter must hold
       // them before this step's searches consult it
-      if (wave_any(want && C.frontier < P0)) c_mark_range(J, C, want && C.frontier < P0, C.frontier, P0, 0, 1, bloom);
+      if (wave_any(want && C.frontier < P0)) c_mark_range(J, C, want && C.frontier < P0, C.frontier, P0, 0, 1);
       if (want) C.frontier = umax(C.frontier, P0);
       wave_sync();
 
       ++nsteps;
       QP_ADD(g, 0, qt);
       // ---- evaluation: lane (kpos, idc) ----
-      const CEval ce = c_evaluate(J, C, want, P0, kpos, idc, bloom, force_slow, htl);
+      const CEval ce = c_evaluate(J, C, want, P0, kpos, idc, force_slow, htl);
       const uint32_t e_flags = ce.e_flags, e_len = ce.e_len, e_dist = ce.e_dist;
       QP_ADD(g, 1, qt);
       QP_ADD(g, 2, qt);
@@ -682,11 +891,11 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       if (wave_any(want && g.st_count != 0)) {
         const bool st = want && g.st_count != 0;
         if (wave_any(st && g.st_stride == 1u))
-          c_stored(J, C, st && g.st_stride == 1u, g.st_first, g.st_first + g.st_count, bloom);
+          c_stored(J, C, st && g.st_stride == 1u, g.st_first, g.st_first + g.st_count);
         if (wave_any(st && g.st_stride != 1u)) {
           const bool sp = st && g.st_stride != 1u;
-          c_stored(J, C, sp, g.st_first, g.st_first, bloom);
-          c_mark_range(J, C, sp, g.st_first, g.st_first + g.st_count * g.st_stride, g.st_first, g.st_stride, bloom);
+          c_stored(J, C, sp, g.st_first, g.st_first);
+          c_mark_range(J, C, sp, g.st_first, g.st_first + g.st_count * g.st_stride, g.st_first, g.st_stride);
           if (sp) C.frontier = g.st_first + g.st_count * g.st_stride;
         }
         if (st) g.st_count = 0;
@@ -699,10 +908,6 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   }
 
   wave_sync();
-  if (participated) {
-    uint32_t* gb = (uint32_t*)(ixb + L.bloom);
-    for (uint32_t i = (uint32_t)t; i < IX_BLOOM_WORDS + IX_SKIPTAB_WORDS; i += 16u) gb[i] = bloom[i];
-  }
   if (writer && participated) {
     ShardState* S = &states[shard];
     regs_save(g.r, S);

@@ -99,8 +99,7 @@ DEV uint32_t ix_slice_len(uint32_t n, uint32_t slices) {
 }
 
 // grid = nshards * slices.  Counts the storable positions of the slice per bucket;
-// cnt[bucket * slices + w].  Also clears the slice's part of the unstored-position bitmap
-// and (slice 0) the Bloom filter.
+// cnt[bucket * slices + w].  Also clears the slice's part of the unstored-position bitmap.
 DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
                   uint32_t w, uint32_t* lds_cnt) {
   const int lane = wave_lane();
@@ -129,10 +128,6 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
   uint32_t* skip = (uint32_t*)(base + L.skip);
   const uint32_t w_lo = lo / 32u, w_hi = (umin(lo + per, g.n + 128u) + 31u) / 32u;
   for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) skip[i] = 0;
-  if (w == 0) {
-    uint32_t* bloom = (uint32_t*)(base + L.bloom);
-    for (uint32_t i = (uint32_t)lane; i < IX_BLOOM_WORDS + IX_SKIPTAB_WORDS; i += 64u) bloom[i] = 0;
-  }
   wave_sync();
 }
 
@@ -204,7 +199,7 @@ DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + 135u * len -
 // The bucket loop of FindLongestMatch (..64_simd_inc.h:246-292) for the entry `e` at index i of
 // its bucket, given the entries before it in (key, position) order: entry i - j sits 4 * j
 // words below `own` in LDS.  rank = same-key entries before e.  Writes srt[] and res[].
-DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool act, uint32_t rank,
+DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool act, uint32_t rank, uint32_t nsucc,
                    const uint32_t* own, uint32_t sidx, uint32_t* srt, uint64_t* res) {
   const uint32_t p = e.w0 & 0xFFFFFFu, tag = e.w0 >> 24;
   const bool danger = rank >= 65520u;
@@ -291,7 +286,7 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
     } else if (best != 0) { kind = IX_KIND_EXACT; len = best_len; dist = best_dist; }
     else kind = IX_KIND_NONE;
     const uint32_t lo = (kind << 30) | (len << 24) | dist;
-    const uint32_t hi = sidx | (umin(rank, IX_RANK_CAP) << 24) | (danger ? IX_DANGER : 0u);
+    const uint32_t hi = sidx | (umin(nsucc, 16u) << IX_NSUCC_SHIFT) | (danger ? IX_DANGER : 0u);
     res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
   }
 }
@@ -369,8 +364,10 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       IxEntry e;
       e.w0 = e.w1 = 0xFFFFFFFFu; e.d = 0;
       if (act) __builtin_memcpy(&e, &sorted[4u * i], 16);
-      const uint32_t rank = act ? i - bins[e.w1 & lowmask] : 0u;
-      ix_window(g, data, e, act, rank, &sorted[4u * (act ? i : 0u)], start + i, srt, res);
+      const uint32_t kl = e.w1 & lowmask;
+      const uint32_t rank = act ? i - bins[kl] : 0u;
+      const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
+      ix_window(g, data, e, act, rank, nsucc, &sorted[4u * (act ? i : 0u)], start + i, srt, res);
     }
     wave_sync();
     return;
@@ -422,8 +419,10 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     if (act) e = ix_load_entry(ent2 + 16ull * (start + i));
     __builtin_memcpy(&stage[4 * (16 + lane)], &e, 16);
     wave_sync();
-    const uint32_t rank = act ? i - bins[e.w1 & lowmask] : 0u;
-    ix_window(g, data, e, act, rank, &stage[4 * (16 + lane)], start + i, srt, res);
+    const uint32_t kl = e.w1 & lowmask;
+    const uint32_t rank = act ? i - bins[kl] : 0u;
+    const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;
+    ix_window(g, data, e, act, rank, nsucc, &stage[4 * (16 + lane)], start + i, srt, res);
     wave_sync();
     if (lane >= 48) __builtin_memcpy(&stage[4 * (lane - 48)], &e, 16);   // the next row's look-back
     wave_sync();

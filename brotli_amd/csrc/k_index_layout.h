@@ -16,25 +16,25 @@
 #define IX_BPW 8u                             // buckets one wave of ix_bucket works through
 #define IX_LROWS 8u                           // a bucket of <= 64 * IX_LROWS entries is sorted and searched in LDS
 #define IX_CAP 40u                            // bytes compared per candidate by ix_bucket
-#define IX_BLOOM_WORDS 1024u                  // one bit per bucket key (<= 15 bits): keys of unstored positions
-#define IX_SKIPTAB_WORDS 256u                 // newest unstored position per key (direct mapped, k_chain.h)
 #define IX_KIND_NONE 0u
 #define IX_KIND_EXACT 1u                      // (len, distance) is the bucket loop's result
 #define IX_KIND_LONG 2u                       // one candidate matches >= IX_CAP bytes and wins however long it is
 #define IX_KIND_SLOW 3u                       // not decidable here: the chain searches this position itself
-#define IX_RANK_CAP 127u
+// res[p], high word: sorted index (24 bits) | successors of p in its key run, capped at 16 (5 bits) << 24 | flags
+#define IX_NSUCC_SHIFT 24u
+#define IX_TAINT 0x20000000u                  // set by the chain: one of the 16 predecessors of p in its key run was NOT
+                                              //   stored by the parse, so the index result of p does not hold (k_chain.h)
 #define IX_DANGER 0x80000000u                 // the bucket counter may have wrapped (>= 65520 stores of one key)
 
 // Entry of the sort: w0 = position | tag << 24, w1 = bucket key, d = the 8 bytes at the position.
 struct IxEntry { uint32_t w0, w1; uint64_t d; };
 
 // Index region of one shard, offsets relative to ShardDesc::ix_off.
-struct IxLayout { uint64_t cnt, bloom, skip, srt, res, ent, ent2, bytes; };
+struct IxLayout { uint64_t cnt, skip, srt, res, ent, ent2, bytes; };
 static inline IX_HD uint64_t ix_align(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
 static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, uint32_t nb_log2, IxLayout* L) {
   uint64_t off = 0;
   L->cnt = off;   off = ix_align(off + 4ull * (((uint64_t)slices << nb_log2) + 2));
-  L->bloom = off; off = ix_align(off + 4ull * (IX_BLOOM_WORDS + IX_SKIPTAB_WORDS));
   L->skip = off;  off = ix_align(off + n / 8 + 32);
   L->srt = off;   off = ix_align(off + 4 * n + 16);
   L->res = off;   off = ix_align(off + 8 * n + 16);

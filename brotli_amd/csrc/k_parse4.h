@@ -652,7 +652,9 @@ DEV void q_setup_extend(const JobParams& J, QShard& g, bool want) {
     cmd_dist = (uint32_t)g.dc[0];
     uint32_t distance_code;
     const uint32_t dcode = last.dist_prefix & 0x3FFu;
-    if (dcode < 16) {
+    if (last.cmd_prefix == CMD_RAW) {
+      distance_code = last.dist_extra;
+    } else if (dcode < 16) {
       distance_code = dcode;
     } else {
       const uint32_t nbits = last.dist_prefix >> 10;
@@ -678,6 +680,7 @@ DEV void q_setup_extend(const JobParams& J, QShard& g, bool want) {
     }
   }
   if (try_ext && last.insert_len != 0xFFFFFFFFu) {
+    if (last.cmd_prefix != CMD_RAW)
     last.cmd_prefix = (uint16_t)combine_length_codes(insert_length_code(last.insert_len),
         copy_length_code((uint32_t)((int)(last.copy_len & 0x1FFFFFFu) + (int)(last.copy_len >> 25))),
         (last.dist_prefix & 0x3FF) == 0);

@@ -15,7 +15,7 @@
 #define PARSE4_WAVES 4
 #endif
 #ifndef CHAIN_WAVES
-#define CHAIN_WAVES 4
+#define CHAIN_WAVES 3
 #endif
 #ifndef IXB_WAVES
 #define IXB_WAVES 4
@@ -132,6 +132,23 @@ __global__ void __launch_bounds__(64, WIDE ? CHAINW_WAVES : CHAIN_WAVES) k_chain
   const uint32_t shard = blockIdx.x * gpw + gi;
   if ((threadIdx.x & (WIDE ? 63 : 15)) == 0 && gi < gpw && shard < a.nshards && a.states[shard].error)
     glb_atomic_add(&a.counters[1], 1u);
+}
+
+// grid = nshards * CE_SPLIT, block = 64: prefix fields of the commands the chain left raw
+// (CMD_RAW, enc_types.h), 64 commands per wave step.
+#define CE_SPLIT 8u
+__global__ void __launch_bounds__(64) k_cmd_encode(JobArgs a) {
+  const uint32_t shard = blockIdx.x / CE_SPLIT, w = blockIdx.x % CE_SPLIT;
+  if (shard >= a.nshards) return;
+  const uint32_t n = a.states[shard].ncmds;
+  Command* cmds = (Command*)(a.ws + a.shards[shard].cmds_off);
+  for (uint32_t i = w * 64u + threadIdx.x; i < n; i += 64u * CE_SPLIT) {
+    const Command c = cmds[i];
+    if (c.cmd_prefix != CMD_RAW) continue;
+    const uint32_t m = c.copy_len >> 25;
+    const int32_t delta = (int8_t)((uint8_t)(m | ((m & 0x40) << 1)));
+    cmds[i] = make_command(c.insert_len, c.copy_len & 0x1FFFFFFu, delta, c.dist_extra);
+  }
 }
 
 // grid = nshards, block = 64: one shard per wave, E = slots / 64 entries per lane.

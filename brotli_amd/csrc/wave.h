@@ -28,6 +28,8 @@ static inline int dev_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 static inline int dev_ctz32(uint32_t x) { return __builtin_ctz(x); }
 static inline int dev_clz32(uint32_t x) { return __builtin_clz(x); }
 static inline int dev_popc64(uint64_t x) { return __builtin_popcountll(x); }
+// Index of the lowest set bit, 0xFFFFFFFF for 0 (v_ffbl_b32 on the device).
+static inline uint32_t dev_ffbl32(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 0xFFFFFFFFu; }
 template <class T> static inline T lds_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T lds_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
 static inline uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
@@ -51,8 +53,9 @@ static inline void wave_equal_neighbours(uint32_t v, int n, int* prev, int* next
   }
   *prev = p; *next = x;
 }
-// Rotation inside rows of 16 lanes (DPP row_ror on the device).
-#define wave_row_ror(v, k) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), (wave_lane() & 48) | ((wave_lane() + (k)) & 15), WAVE_SITE))
+// Rotation inside rows of 16 lanes (DPP row_ror on the device: lane i reads lane (i - k) & 15 of
+// its row, measured with tools/dpp_probe.hip).
+#define wave_row_ror(v, k) ((uint32_t)simt_shfl64((uint64_t)(uint32_t)(v), (wave_lane() & 48) | ((wave_lane() - (k)) & 15), WAVE_SITE))
 // Maximum of v over the wave (uniform result).
 static inline uint32_t wave_max_u32(uint32_t v) {
   simt::rendezvous(v, 7002);
@@ -111,6 +114,12 @@ __device__ __forceinline__ int dev_ctz64(uint64_t x) { return __builtin_ctzll(x)
 __device__ __forceinline__ int dev_ctz32(uint32_t x) { return __builtin_ctz(x); }
 __device__ __forceinline__ int dev_clz32(uint32_t x) { return __builtin_clz(x); }
 __device__ __forceinline__ int dev_popc64(uint64_t x) { return __builtin_popcountll(x); }
+// Index of the lowest set bit, 0xFFFFFFFF for 0: one v_ffbl_b32, no select around it.
+__device__ __forceinline__ uint32_t dev_ffbl32(uint32_t x) {
+  uint32_t r;
+  asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
 template <class T> __device__ __forceinline__ T lds_atomic_add(T* p, T v) { return atomicAdd(p, v); }
 template <class T> __device__ __forceinline__ T lds_atomic_or(T* p, T v) { return atomicOr(p, v); }
 // Device-scope OR on a global dword (executed at the L2; result optional).
@@ -132,8 +141,8 @@ __device__ __forceinline__ void wave_equal_neighbours(uint32_t v, int n, int* pr
   }
   *prev = p; *next = x;
 }
-// Rotation inside rows of 16 lanes: one VALU v_mov_b32 with DPP row_ror:k, no
-// LDS crossbar round trip (ds_bpermute costs ~100 cycles of latency each).
+// Rotation inside rows of 16 lanes: one VALU v_mov_b32 with DPP row_ror:k (lane i reads lane
+// (i - k) & 15 of its row), no LDS crossbar round trip (ds_bpermute costs ~100 cycles of latency each).
 #define wave_row_ror(v, k) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x120 + (k), 0xF, 0xF, true))
 // Maximum of v over the wave (uniform result): DPP row reductions + two readlanes.
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {

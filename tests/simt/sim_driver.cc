@@ -37,6 +37,7 @@ void run_parse_kernel(const JobArgs& a, int reverse) {
   } else if (a.J.flags & JOB_FLAG_INDEXED) {
     if (a.J.flags & JOB_FLAG_WIDE) run(k_chain<true>, a, a.nshards, 64, reverse);
     else run(k_chain<false>, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
+    run(k_cmd_encode, a, a.nshards * CE_SPLIT, 64, reverse);
   } else if (a.J.flags & JOB_FLAG_QUAD) {
     run(k_parse4, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
   } else {
@@ -169,8 +170,8 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
     fprintf(stderr, "indexed parse: %llu searches, %llu exact (in-chain) searches; wave steps %llu; evaluated positions %llu: "
             "index-undecidable %llu, bloom %llu, gate-dependent %llu, long %llu; fast-loop steps %llu\n", (unsigned long long)se, (unsigned long long)sl,
             g_sim_counts[7], g_sim_counts[12], g_sim_counts[8], g_sim_counts[9], g_sim_counts[10], g_sim_counts[11], g_sim_counts[14]);
-    fprintf(stderr, "fast loop stopped at its first position: long cache candidate %llu, long/undecidable index %llu, tainted key %llu, gate-dependent %llu, not evaluated %llu\n",
-            g_sim_counts[1], g_sim_counts[2], g_sim_counts[3], g_sim_counts[4], g_sim_counts[5]);
+    fprintf(stderr, "group fast steps: commit %llu, literals only %llu | stuck: dictionary after exact %llu, lazy chain into undecidable %llu, empty probe with open gate %llu, spree or gate at first %llu, other %llu\n",
+            g_sim_counts[0], g_sim_counts[1], g_sim_counts[2], g_sim_counts[3], g_sim_counts[4], g_sim_counts[5], g_sim_counts[6]);
     memset(g_sim_counts, 0, sizeof(g_sim_counts));
   }
   size_t n = 0;

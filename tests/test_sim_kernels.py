@@ -139,6 +139,74 @@ def test_quad_kernel_scout_groups_forced_slow_resolve(sim, oracle):
     assert sim.encode(data, shard_size=50000, flags=2 | 4 | 32 | (2 << 8)) == oracle.encode_plan(data, 5, 22, 50000)
 
 
+# ---- indexed quality-5 parse (k_index.h + k_chain.h): JOB_FLAG_INDEXED = 64, JOB_FLAG_WIDE = 128 ----
+IX_LAYOUTS = {
+    "groups4": 2 | 64,                      # four shards per wave, 16 lanes each (the product default for many shards)
+    "groups2": 2 | 64 | (2 << 8),
+    "groups1": 2 | 64 | (1 << 8),
+    "wide": 2 | 64 | 128 | (1 << 8),        # one shard per wave, wave-uniform state
+}
+
+
+@pytest.mark.parametrize("layout", list(IX_LAYOUTS))
+@pytest.mark.parametrize("name", list(CASES))
+def test_indexed_parse_bytes_match_oracle(sim, oracle, name, layout):
+    """The position index + table-free chain reproduce the oracle on every case of the table
+    kernels, in every wave layout, with lanes scheduled in either order."""
+    data, hint, shard = CASES[name]
+    want = _oracle_plan(oracle, data, hint, shard)
+    for reverse in (0, 1):
+        assert sim.encode(data, 5, 22, hint, shard, reverse=reverse, flags=IX_LAYOUTS[layout]) == want
+
+
+@pytest.mark.parametrize("layout", ["groups4", "groups1", "wide"])
+@pytest.mark.parametrize("name", ["alice_48k", "text_hint_2shards", "mixed", "rle", "runs", "shards_of_1_2_3"])
+def test_indexed_parse_forced_exact_search(sim, oracle, name, layout):
+    """JOB_FLAG_FORCE_SLOW: every search goes through c_search_exact (the sorted array + the
+    bitmap of unstored positions) and the step-by-step resolve."""
+    data, hint, shard = CASES[name]
+    assert sim.encode(data, 5, 22, hint, shard, flags=IX_LAYOUTS[layout] | 4) == _oracle_plan(oracle, data, hint, shard)
+
+
+def test_indexed_parse_english_text_dictionary_gate_open(sim, oracle):
+    """alice29.txt keeps the static-dictionary gate open (hash.h:179-202): misses and empty
+    lazy probes must leave the group fast path."""
+    want = oracle.encode_plan(ALICE, 5, 22, 40000)
+    for layout in ("groups4", "groups1", "wide"):
+        assert sim.encode(ALICE, 5, 22, 0, 40000, flags=IX_LAYOUTS[layout]) == want, layout
+
+
+def test_indexed_parse_long_shards_h68(sim, oracle):
+    """Two 160 KiB shards with the 5-byte hasher: buckets fill up (16 slots), long copies."""
+    data = G.enwik_text(320 << 10, seed=21, vocab=4000) 
+    want = _oracle_plan(oracle, data, 1 << 30, 160 << 10)
+    for layout in ("groups4", "wide"):
+        assert sim.encode(data, 5, 22, 1 << 30, 160 << 10, flags=IX_LAYOUTS[layout]) == want, layout
+
+
+def test_indexed_parse_copy_ends_at_block_end(sim, oracle):
+    """Regression: a copy that ends exactly at the end of an input block; the next block's
+    stitch (..64_simd_inc.h:139-151) still stores the last three positions of the block."""
+    data = G.enwik_text(4 << 20, seed=11, vocab=20000)[2 << 18:3 << 18]
+    want = oracle.encode_shard(data, 5, 22, 4 << 20, 2 << 18, False)
+    assert sim.encode(data, 5, 22, 4 << 20, 0, stream_base=2 << 18, is_last=False, flags=IX_LAYOUTS["groups1"]) == want
+
+
+@pytest.mark.parametrize("seed", range(3))
+def test_indexed_parse_fuzz(sim, oracle, seed):
+    rng = np.random.default_rng(4000 + seed)
+    for _ in range(6):
+        data = _fuzz_input(rng)
+        shard = int(rng.integers(0, 3)) * int(rng.integers(300, 2500))
+        hint = (1 << 30) if rng.integers(0, 2) else 0          # H68 vs H58
+        want = _oracle_plan(oracle, data, hint, shard)
+        rev = int(rng.integers(0, 2))
+        for layout in IX_LAYOUTS:
+            assert sim.encode(data, size_hint=hint, shard_size=shard, reverse=rev, flags=IX_LAYOUTS[layout]) == want, \
+                (seed, len(data), shard, hint, layout)
+        assert sim.encode(data, size_hint=hint, shard_size=shard, reverse=rev, flags=IX_LAYOUTS["groups4"] | 4) == want
+
+
 def test_quad_kernel_many_shards_reverse(sim, oracle):
     """7 shards over 2 waves (one group idle), lanes scheduled high-to-low."""
     data = G.enwik_text(70000, seed=13, vocab=3000)

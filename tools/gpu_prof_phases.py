@@ -10,7 +10,7 @@ data = G.enwik_text(N)
 ctx = hip.Context(0)
 d = hip.to_device(data)
 if os.environ.get("PROBE_CHAIN"):
-    names = ["top/driver/marks", "loads -> dc len", "eval rest + bcast", "lean loop", "sr fetch + commit", "generic", "accounting", "post", "FAST loads->dc len", "FAST eval rest", "FAST scalar walk", "FAST commit"]
+    names = ["top/driver/marks", "loads -> dc len", "eval rest + bcast", "lean loop", "sr fetch + commit", "generic", "accounting", "post", "FAST loads+eval", "FAST exact fix", "FAST group logic", "FAST commit+marks"]
 else:
   names = ["record(after P bytes)", "ext+rest of cand", "resolve", "insert", "dict", "decide", "stores", "driver", "bytes at P", "dc strings", "bucket strings", "-"]
 for shard in [int(x) for x in os.environ.get("PROBE_SHARDS", "262144,65536").split(",")]:
