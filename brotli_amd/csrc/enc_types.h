@@ -49,6 +49,7 @@ struct JobParams {
   uint32_t rec_bytes;           // bytes of one bucket record (128 for 16 slots, 8 per slot otherwise)
   uint32_t ix_slices;           // JOB_FLAG_INDEXED: position slices per shard of the index kernels (k_index.h)
   uint32_t ix_nb_log2;          //   and log2 of the first-level buckets per shard
+  uint32_t ix_bpw;              //   buckets one wave of k_ix_bucket works through (a power of two)
 };
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
 #define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal

@@ -184,6 +184,10 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
     const char* e = getenv("BROTLI_AMD_INDEXED");
     if (!e || atoi(e) != 0) {
       c->ix_region_bytes = plan_add_index(plan, /*ix_in_ws=*/false);
+      if (const char* b = getenv("BROTLI_AMD_IX_BPW")) {          // experiment knob: 1, 2, 4, 8
+        const uint32_t v = (uint32_t)atoi(b);
+        if (v == 1 || v == 2 || v == 4 || v == 8) plan->J.ix_bpw = v;
+      }
       plan->J.flags &= ~(uint32_t)JOB_FLAG_DUO;
       // shards per wave of k_chain: one 16-lane group per shard, as many waves as stay resident
       const uint64_t resident = (uint64_t)c->num_cus * 4u * CHAIN_WAVES;
@@ -242,8 +246,17 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     hipLaunchKernelGGL(k_ix_count, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_scan, dim3(nshards), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_scatter, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_ix_bucket, dim3(((nshards + 7u) / 8u) * 8u * ((1u << plan.J.ix_nb_log2) / IX_BPW)), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_ix_bucket, dim3(((nshards + 7u) / 8u) * 8u * ((1u << plan.J.ix_nb_log2) / plan.J.ix_bpw)), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
+    if (getenv("BROTLI_AMD_INDEX_ONLY")) {   // timing experiments: stop after the index kernels
+      HIP_OK(c, hipStreamSynchronize(c->stream));
+      if (info) { HIP_OK(c, hipEventElapsedTime(&ms_index, c->ev[1], c->ev_ix)); info->ms_index = ms_index; }
+      if (states_out) {
+        states_out->resize(nshards);
+        HIP_OK(c, hipMemcpy(states_out->data(), c->d_states, nshards * sizeof(ShardState), hipMemcpyDeviceToHost));
+      }
+      return true;
+    }
   }
   uint32_t rounds = 0;
   for (;;) {

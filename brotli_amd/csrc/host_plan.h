@@ -127,6 +127,10 @@ static inline uint64_t plan_add_index(JobPlan* plan, bool ix_in_ws) {
   while (nb < IX_NB_MAX_LOG2 && (longest >> nb) > 320u) ++nb;
   if ((int)nb > plan->J.bucket_bits - 4) nb = (uint32_t)plan->J.bucket_bits - 4u;
   plan->J.ix_nb_log2 = nb;
+  // Few buckets per wave = many waves per shard: the waves of one shard run on one XCD
+  // (kernels.h), and with ~2 shards in flight per XCD the res[] lines its buckets fill stay in
+  // that L2 until they are complete (measured: profiles/r02_d_*).
+  plan->J.ix_bpw = longest <= (160u << 10) ? 2u : 4u;
   plan->J.flags |= JOB_FLAG_INDEXED;
   IxLayout L;
   ix_layout(longest, slices, nb, &L);

@@ -16,9 +16,10 @@
 //   * F = the positions that CAN be stored (block structure only): x + HTL <=
 //     block end, or one of the three positions StitchToPreviousBlock adds;
 //   * the index is built for F: positions sorted by (key, position) — a
-//     two-level stable counting sort, 256 buckets by the top key bits
-//     (ix_count / ix_scan / ix_scatter) and the remaining key bits inside a
-//     bucket (ix_bucket);
+//     two-level stable counting sort, 256 .. 1024 buckets by the top key bits
+//     (ix_count / ix_scan / ix_scatter: 4 bytes per position through HBM) and the
+//     remaining key bits inside a bucket (ix_bucket, which fetches the 16 bytes at
+//     each position from the shard's input — L2 resident — once);
 //   * ix_bucket then evaluates, for every searchable position P, the window of
 //     the <= 16 predecessors of P in its key run exactly as FindLongestMatch's
 //     bucket loop would (tag filter, first four bytes, match length, score, order
@@ -74,12 +75,13 @@ DEV bool ix_searchable(const IxGeom& g, uint32_t x) {
   return x + g.htl <= ix_block_end(g, x);
 }
 
-DEV IxEntry ix_load_entry(const uint8_t* p) {
-  IxEntry e;
-  __builtin_memcpy(&e, p, 16);
-  return e;
+// The 16 bytes at the entry's position and its full bucket key (w1).
+DEV void ix_fetch(const JobParams& J, const uint8_t* data, IxEntry& e) {
+  uint64_t b[2];
+  __builtin_memcpy(b, data + (e.w0 & 0xFFFFFFu), 16);
+  e.d = b[0]; e.d2 = b[1];
+  e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key;
 }
-DEV void ix_store_entry(uint8_t* p, const IxEntry& e) { __builtin_memcpy(p, &e, 16); }
 
 // Lanes of the wave whose `v` (nbits wide) equals this lane's, among the lanes with `act`.
 DEV uint64_t ix_match_any(bool act, uint32_t v, int nbits) {
@@ -170,14 +172,10 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
   for (uint32_t x0 = lo; x0 < hi; x0 += 64u) {
     const uint32_t x = x0 + (uint32_t)lane;
     const bool act = x < hi && ix_storable(g, x);
-    IxEntry e;
-    e.w0 = e.w1 = 0; e.d = 0;
-    uint32_t b = 0;
+    uint32_t w0 = 0, b = 0;
     if (act) {
-      e.d = ld64(data + x);
-      const KeyTag kt = hash_pos(e.d, J.hasher_type, J.bucket_bits);
-      e.w0 = x | (kt.tag << 24);
-      e.w1 = kt.key;
+      const KeyTag kt = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits);
+      w0 = x | (kt.tag << 24);
       b = kt.key >> shift;
     }
     const uint64_t same = ix_match_any(act, b, (int)J.ix_nb_log2);
@@ -188,7 +186,7 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
     wave_sync();
     if (act && rank + 1u == total) lds_off[b] = at + total;
     wave_sync();
-    if (act) ix_store_entry(ent + 16ull * (at + rank), e);
+    if (act) ((uint32_t*)ent)[at + rank] = w0;
   }
   wave_sync();
 }
@@ -196,43 +194,51 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
 // ---- level 2 + window search: one wave per (shard, bucket) -------------------------------
 DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + 135u * len - 30u * log2floor(dist); }
 
-// The bucket loop of FindLongestMatch (..64_simd_inc.h:246-292) for the entry `e` at index i of
-// its bucket, given the entries before it in (key, position) order: entry i - j sits 4 * j
-// words below `own` in LDS.  rank = same-key entries before e.  Writes srt[] and res[].
+// The bucket loop of FindLongestMatch (..64_simd_inc.h:246-292) for the entry at index li of the
+// LDS arrays (w0 / bytes 0..7 / bytes 8..15, in (key, position) order): the entries before it sit
+// at li - 1, li - 2, ...  rank = same-key entries before it, nsucc = same-key entries after it.
+// Matches of up to 16 bytes are decided from LDS alone; longer ones compare on in the input.
+// Writes srt[] and res[].
+struct IxLds { const uint32_t* w0; const uint64_t* d; const uint64_t* d2; };
 DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool act, uint32_t rank, uint32_t nsucc,
-                   const uint32_t* own, uint32_t sidx, uint32_t* srt, uint64_t* res) {
+                   const IxLds& S, uint32_t li, uint32_t sidx, uint32_t* srt, uint64_t* res) {
   const uint32_t p = e.w0 & 0xFFFFFFu, tag = e.w0 >> 24;
   const bool danger = rank >= 65520u;
   const bool search = act && ix_searchable(g, p);
   const uint32_t max_length = search ? ix_block_end(g, p) - p : 0u;
   uint32_t best = 0, best_len = 0, best_dist = 0;               // exact candidates
   uint32_t longmask = 0;
+#if defined(IX_NOWIN)       // (timing experiments only: results are wrong)
+  const uint32_t nwin = 0u;
+#else
   const uint32_t nwin = search ? umin(rank, 16u) : 0u;
+#endif
   const uint32_t nmax = (uint32_t)wave_max_u32(nwin);
   for (uint32_t j = 1; j <= nmax; ++j) {
     if (j > nwin) continue;
-    IxEntry q;
-    __builtin_memcpy(&q, own - 4 * (int)j, 16);
-#if defined(BROTLI_AMD_SIMT_SIM)
-    if (getenv("SIM_DBGPOS") && act && p == (uint32_t)atoi(getenv("SIM_DBGPOS")))
-      fprintf(stderr, "ix p %u tag %x rank %u search %d maxlen %u | j %u q %u qtag %x qkey %x\n", p, tag, rank, (int)search, max_length, j, q.w0 & 0xFFFFFF, q.w0 >> 24, q.w1);
+    const uint32_t qw = S.w0[li - j];
+    if ((qw >> 24) != tag) continue;
+    const uint64_t x = S.d[li - j] ^ e.d;
+    uint32_t l = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
+    if (l < 4u) continue;                                       // first4 != current4
+    if (l == 8u) {
+      const uint64_t x2 = S.d2[li - j] ^ e.d2;
+      l = x2 ? 8u + ((uint32_t)dev_ctz64(x2) >> 3) : 16u;
+#if !defined(IX_NOLONG)     // (timing experiments only: results are wrong)
+      if (l == 16u && max_length > 16u) { longmask |= 1u << j; continue; }
 #endif
-    if ((q.w0 >> 24) != tag) continue;
-    const uint64_t x = q.d ^ e.d;
-    const uint32_t l8 = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
-    if (l8 < 4u) continue;                                      // first4 != current4
-    if (l8 == 8u && max_length > 8u) { longmask |= 1u << j; continue; }
-    const uint32_t len = umin(l8, max_length);
-    const uint32_t dist = p - (q.w0 & 0xFFFFFFu);
+    }
+    const uint32_t len = umin(l, max_length);
+    const uint32_t dist = p - (qw & 0xFFFFFFu);
     const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
     if (k > best) { best = k; best_len = len; best_dist = dist; }
   }
-  // candidates equal in the first 8 bytes: compare on in the input, four candidates per
-  // round trip (bytes 8..23 first; the few that are still equal fetch 24..39)
+  // candidates equal in the first 16 bytes: compare on in the input, four candidates per
+  // round trip (bytes 16..31 first; the few that are still equal fetch 32..39)
   uint32_t ncapped = 0, cap_key = 0, cap_dist = 0;
   if (wave_ballot(longmask != 0) != 0) {
-    uint64_t mine[4] = {0, 0, 0, 0};
-    if (longmask != 0) __builtin_memcpy(mine, data + p + 8u, 32);
+    uint64_t mine[3] = {0, 0, 0};
+    if (longmask != 0) __builtin_memcpy(mine, data + p + 16u, 24);
     while (wave_ballot(longmask != 0) != 0) {
       uint32_t jj[4], qp[4], ln[4];
       uint64_t c[4][2];
@@ -241,23 +247,22 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
       for (int u = 0; u < 4; ++u) {
         jj[u] = longmask != 0 ? (uint32_t)dev_ctz32(longmask) : 0u;
         longmask &= longmask - 1u;
-        qp[u] = own[-4 * (int)jj[u]] & 0xFFFFFFu;
+        qp[u] = S.w0[li - jj[u]] & 0xFFFFFFu;
         c[u][0] = c[u][1] = 0;
-        if (jj[u] != 0) __builtin_memcpy(c[u], data + qp[u] + 8u, 16);
+        if (jj[u] != 0) __builtin_memcpy(c[u], data + qp[u] + 16u, 16);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const uint64_t x0 = c[u][0] ^ mine[0], x1 = c[u][1] ^ mine[1];
-        ln[u] = x0 ? 8u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 16u + ((uint32_t)dev_ctz64(x1) >> 3) : 24u;
-        if (jj[u] != 0 && ln[u] == 24u && max_length > 24u) more = true;
+        ln[u] = x0 ? 16u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 24u + ((uint32_t)dev_ctz64(x1) >> 3) : 32u;
+        if (jj[u] != 0 && ln[u] == 32u && max_length > 32u) more = true;
       }
       if (wave_ballot(more) != 0) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          if (jj[u] != 0 && ln[u] == 24u && max_length > 24u) {
-            __builtin_memcpy(c[u], data + qp[u] + 24u, 16);
-            const uint64_t x0 = c[u][0] ^ mine[2], x1 = c[u][1] ^ mine[3];
-            ln[u] = x0 ? 24u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 32u + ((uint32_t)dev_ctz64(x1) >> 3) : 40u;
+          if (jj[u] != 0 && ln[u] == 32u && max_length > 32u) {
+            const uint64_t x0 = ld64(data + qp[u] + 32u) ^ mine[2];
+            ln[u] = x0 ? 32u + ((uint32_t)dev_ctz64(x0) >> 3) : 40u;
           }
         }
       }
@@ -291,9 +296,13 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
   }
 }
 
-// lds: [0, 128) bin starts, [128, 256) cursors, then the sorted bucket (64 * IX_LROWS entries of
-// 16 B) — or, for a bigger bucket, the (16 + 64) staged entries of the row being searched
-#define IX_BUCKET_LDS_WORDS (256u + 64u * IX_LROWS * 4u)
+// lds (words): [0, 128) bin starts, [128, 256) cursors, then w0[N], bytes 0..7 [N] (2 words each),
+// bytes 8..15 [N], N = 64 * IX_LROWS entries of the sorted bucket — or, for a bigger bucket, the
+// (16 + 64) staged entries of the row being searched
+#define IX_BUCKET_LDS_WORDS (256u + 64u * IX_LROWS * 5u)
+DEV void ix_lds_put(uint32_t* w0S, uint64_t* dS, uint64_t* d2S, uint32_t i, const IxEntry& e) {
+  w0S[i] = e.w0; dS[i] = e.d; d2S[i] = e.d2;
+}
 DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
                    uint32_t bucket, uint32_t* lds) {
   const int lane = wave_lane();
@@ -303,8 +312,8 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   uint8_t* base = ws + D.ix_off;
   const uint8_t* data = input + D.in_off;
   const uint32_t* cnt = (const uint32_t*)(base + L.cnt);
-  const uint8_t* ent = base + L.ent;
-  uint8_t* ent2 = base + L.ent2;
+  const uint32_t* ent = (const uint32_t*)(base + L.ent);
+  uint32_t* ent2 = (uint32_t*)(base + L.ent2);
   uint32_t* srt = (uint32_t*)(base + L.srt);
   uint64_t* res = (uint64_t*)(base + L.res);
   const uint32_t start = cnt[bucket * J.ix_slices];
@@ -315,22 +324,31 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   const uint32_t lowmask = (1u << lowbits) - 1u;
   uint32_t* bins = lds;
   uint32_t* cursor = lds + 128;
-  uint32_t* sorted = lds + 256;
+  const uint32_t NL = 64u * IX_LROWS;
+  uint32_t* w0S = lds + 256;
+  uint64_t* dS = (uint64_t*)(lds + 256 + NL);
+  uint64_t* d2S = (uint64_t*)(lds + 256 + 3u * NL);
+  IxLds S;
+  S.w0 = w0S; S.d = dS; S.d2 = d2S;
   wave_sync();
   for (uint32_t b = (uint32_t)lane; b < 128u; b += 64u) bins[b] = 0;
   wave_sync();
-  if (m <= 64u * IX_LROWS) {
+  if (m <= NL) {
     // ---- the whole bucket in registers, then sorted into LDS ----
     IxEntry row[IX_LROWS];
 #pragma unroll
     for (uint32_t r = 0; r < IX_LROWS; ++r) {
       const uint32_t i = r * 64u + (uint32_t)lane;
-      row[r].w0 = row[r].w1 = 0; row[r].d = 0;
-      if (i < m) row[r] = ix_load_entry(ent + 16ull * (start + i));
+      row[r].w0 = row[r].w1 = 0; row[r].d = row[r].d2 = 0;
+      if (i < m) row[r].w0 = ent[start + i];
     }
 #pragma unroll
     for (uint32_t r = 0; r < IX_LROWS; ++r) {
-      if (r * 64u + (uint32_t)lane < m) lds_atomic_add(&bins[row[r].w1 & lowmask], 1u);
+      if (r * 64u >= m) break;
+      if (r * 64u + (uint32_t)lane < m) {
+        ix_fetch(J, data, row[r]);
+        lds_atomic_add(&bins[row[r].w1 & lowmask], 1u);
+      }
     }
     wave_sync();
     {
@@ -355,29 +373,30 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       if (act) at = cursor[kl];
       wave_sync();
       if (act && rank + 1u == total) cursor[kl] = at + total;
-      if (act) __builtin_memcpy(&sorted[4u * (at + rank)], &row[r], 16);
+      if (act) ix_lds_put(w0S, dS, d2S, at + rank, row[r]);
       wave_sync();
     }
     for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
       const uint32_t i = r0 + (uint32_t)lane;
       const bool act = i < m;
       IxEntry e;
-      e.w0 = e.w1 = 0xFFFFFFFFu; e.d = 0;
-      if (act) __builtin_memcpy(&e, &sorted[4u * i], 16);
+      e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
+      if (act) { e.w0 = w0S[i]; e.d = dS[i]; e.d2 = d2S[i]; e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key; }
       const uint32_t kl = e.w1 & lowmask;
       const uint32_t rank = act ? i - bins[kl] : 0u;
       const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
-      ix_window(g, data, e, act, rank, nsucc, &sorted[4u * (act ? i : 0u)], start + i, srt, res);
+      ix_window(g, data, e, act, rank, nsucc, S, act ? i : 0u, start + i, srt, res);
     }
     wave_sync();
     return;
   }
   // ---- a bigger bucket: sorted through HBM (ent -> ent2), searched row by row ----
-  uint32_t* stage = sorted;
   for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
     const uint32_t i = r0 + (uint32_t)lane;
     if (i < m) {
-      const IxEntry e = ix_load_entry(ent + 16ull * (start + i));
+      IxEntry e;
+      e.w0 = ent[start + i];
+      ix_fetch(J, data, e);
       lds_atomic_add(&bins[e.w1 & lowmask], 1u);
     }
   }
@@ -396,8 +415,8 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     const uint32_t i = r0 + (uint32_t)lane;
     const bool act = i < m;
     IxEntry e;
-    e.w0 = e.w1 = 0; e.d = 0;
-    if (act) e = ix_load_entry(ent + 16ull * (start + i));
+    e.w0 = e.w1 = 0; e.d = e.d2 = 0;
+    if (act) { e.w0 = ent[start + i]; ix_fetch(J, data, e); }
     const uint32_t kl = e.w1 & lowmask;
     const uint64_t same = ix_match_any(act, kl, lowbits);
     const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
@@ -407,24 +426,24 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     wave_sync();
     if (act && rank + 1u == total) cursor[kl] = at + total;
     wave_sync();
-    if (act) ix_store_entry(ent2 + 16ull * (start + at + rank), e);
+    if (act) ent2[start + at + rank] = e.w0;
   }
   wave_sync();
-  // stage[0..15] = the last 16 entries of the previous row, stage[16 + lane] = this row's
+  // staged entries 0..15 = the last 16 entries of the previous row, 16 + lane = this row's
   for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
     const uint32_t i = r0 + (uint32_t)lane;
     const bool act = i < m;
     IxEntry e;
-    e.w0 = e.w1 = 0xFFFFFFFFu; e.d = 0;
-    if (act) e = ix_load_entry(ent2 + 16ull * (start + i));
-    __builtin_memcpy(&stage[4 * (16 + lane)], &e, 16);
+    e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
+    if (act) { e.w0 = ent2[start + i]; ix_fetch(J, data, e); }
+    ix_lds_put(w0S, dS, d2S, 16u + (uint32_t)lane, e);
     wave_sync();
     const uint32_t kl = e.w1 & lowmask;
     const uint32_t rank = act ? i - bins[kl] : 0u;
     const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;
-    ix_window(g, data, e, act, rank, nsucc, &stage[4 * (16 + lane)], start + i, srt, res);
+    ix_window(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res);
     wave_sync();
-    if (lane >= 48) __builtin_memcpy(&stage[4 * (lane - 48)], &e, 16);   // the next row's look-back
+    if (lane >= 48) ix_lds_put(w0S, dS, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
     wave_sync();
   }
 }

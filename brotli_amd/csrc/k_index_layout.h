@@ -13,7 +13,6 @@
 
 #define IX_NB_MAX_LOG2 10u                    // first-level buckets by the top key bits: 2^8 .. 2^10 per shard
 #define IX_NB_MAX (1u << IX_NB_MAX_LOG2)      //   (JobParams::ix_nb_log2, chosen so that a bucket holds ~256 positions)
-#define IX_BPW 8u                             // buckets one wave of ix_bucket works through
 #define IX_LROWS 8u                           // a bucket of <= 64 * IX_LROWS entries is sorted and searched in LDS
 #define IX_CAP 40u                            // bytes compared per candidate by ix_bucket
 #define IX_KIND_NONE 0u
@@ -26,8 +25,10 @@
                                               //   stored by the parse, so the index result of p does not hold (k_chain.h)
 #define IX_DANGER 0x80000000u                 // the bucket counter may have wrapped (>= 65520 stores of one key)
 
-// Entry of the sort: w0 = position | tag << 24, w1 = bucket key, d = the 8 bytes at the position.
-struct IxEntry { uint32_t w0, w1; uint64_t d; };
+// Entry of the sort as it travels through HBM: position | tag << 24 (4 bytes).  The bucket pass
+// re-reads the 16 bytes at the position from the shard's input (which sits in the L2) and keeps
+// {w0, key, bytes 0..7, bytes 8..15} per entry in registers / LDS.
+struct IxEntry { uint32_t w0, w1; uint64_t d, d2; };
 
 // Index region of one shard, offsets relative to ShardDesc::ix_off.
 struct IxLayout { uint64_t cnt, skip, srt, res, ent, ent2, bytes; };
@@ -38,8 +39,8 @@ static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, uint32_t nb_log2
   L->skip = off;  off = ix_align(off + n / 8 + 32);
   L->srt = off;   off = ix_align(off + 4 * n + 16);
   L->res = off;   off = ix_align(off + 8 * n + 16);
-  L->ent = off;   off = ix_align(off + 16 * n + 16);
-  L->ent2 = off;  off = ix_align(off + 16 * n + 16);
+  L->ent = off;   off = ix_align(off + 4 * n + 16);
+  L->ent2 = off;  off = ix_align(off + 4 * n + 16);
   L->bytes = off;
 }
 

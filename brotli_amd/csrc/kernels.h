@@ -106,17 +106,17 @@ __global__ void __launch_bounds__(64) k_ix_scatter(JobArgs a) {
   if (shard >= a.nshards) return;
   ix_scatter(a.J, a.shards[shard], a.input, a.ws, w, lds_off);
 }
-// grid = ceil(nshards / 8) * 8 * (buckets per shard / IX_BPW), block = 64: a wave works through
-// IX_BPW buckets.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md): all waves of a shard are
+// grid = ceil(nshards / 8) * 8 * (buckets per shard / ix_bpw), block = 64: a wave works through
+// ix_bpw buckets.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md): all waves of a shard are
 // given the same b % 8, so the shard's input, entries and the res[] lines its buckets fill
 // together stay in ONE XCD's L2 instead of being written back partially by eight.
 __global__ void __launch_bounds__(64, IXB_WAVES) k_ix_bucket(JobArgs a) {
   __shared__ uint32_t lds_b[IX_BUCKET_LDS_WORDS];
-  const uint32_t per = (1u << a.J.ix_nb_log2) / IX_BPW;
+  const uint32_t per = (1u << a.J.ix_nb_log2) / a.J.ix_bpw;
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t shard = (slot / per) * 8u + xcd, b0 = (slot % per) * IX_BPW;
+  const uint32_t shard = (slot / per) * 8u + xcd, b0 = (slot % per) * a.J.ix_bpw;
   if (shard >= a.nshards) return;
-  for (uint32_t b = b0; b < b0 + IX_BPW; ++b) ix_bucket(a.J, a.shards[shard], a.input, a.ws, b, lds_b);
+  for (uint32_t b = b0; b < b0 + a.J.ix_bpw; ++b) ix_bucket(a.J, a.shards[shard], a.input, a.ws, b, lds_b);
 }
 // dynamic LDS: shards per wave * C_GROUP_LDS_WORDS * 4 bytes
 template <bool WIDE>

@@ -27,7 +27,7 @@ void run_index(const JobArgs& a, int reverse) {
   run(k_ix_count, a, a.nshards * a.J.ix_slices, 64, reverse);
   run(k_ix_scan, a, a.nshards, 64, reverse);
   run(k_ix_scatter, a, a.nshards * a.J.ix_slices, 64, reverse);
-  run(k_ix_bucket, a, ((a.nshards + 7u) / 8u) * 8u * ((1u << a.J.ix_nb_log2) / IX_BPW), 64, reverse);
+  run(k_ix_bucket, a, ((a.nshards + 7u) / 8u) * 8u * ((1u << a.J.ix_nb_log2) / a.J.ix_bpw), 64, reverse);
 }
 void run_parse_kernel(const JobArgs& a, int reverse) {
   if (a.J.flags & JOB_FLAG_DEEP) {
