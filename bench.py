@@ -14,8 +14,12 @@ encode.h:231-246) and the ranks concatenate the compressed pieces with one
 RCCL all-gather of sizes + one of (padded) payloads inside the timed region.
 
 Rank 0 prints ONE JSON line (driver contract) with two extra objects:
-  roofline     — k_parse (the dominant kernel): algorithmic bytes per launch
-                 (DESIGN.md §5: A5 = 48 B per input byte) / its HIP-event time;
+  roofline     — the dominant kernel (quality 5: k_ix_bucket, the sort inside the
+                 index buckets + the window search of every position): its
+                 algorithmic HBM bytes per launch (17 B per input
+                 byte) / its HIP-event time, measured live on the library's
+                 stream; `parse_path` beside it prices the whole LZ77 parse
+                 (index kernels + chain) at SURVEY.md §8(d)'s 48 B per input byte;
   cpu_baseline — the reference encoder (oracle/_ref, built from /root/reference
                  by oracle/Makefile) with the SAME partition plan on the host
                  cores of this box, on a bounded sample (N = 1 only).
@@ -35,6 +39,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # SURVEY.md §8(d) models: q5 / H68 48 B per input byte; q9 / H6 0.47 KiB.
 ALGO_BYTES_PER_INPUT_BYTE = {5: 48.0, 6: 48.0, 7: 481.0, 8: 481.0, 9: 481.0}
+# k_ix_bucket per position (= per input byte): entry 4 B in, the input byte itself 1 B in (the 16-byte
+# gathers hit the L2), srt 4 B + res 8 B out
+IX_BUCKET_BYTES_PER_INPUT_BYTE = 17.0
+HBM_ACHIEVABLE_GBS = 6300.0        # what a copy kernel reaches
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
@@ -144,6 +152,40 @@ def cpu_baseline(data, quality, lgwin, shard_size, size_hint, reps=5):
     return {"value": round(len(sample) / 1e6 / dt, 1), "unit": "MB/s", "cores": cores, "kind": "port",
             "sample": "first %d MiB, same plan, %d Python threads over oracle/liboracle.so, %.1f s; "
                       "ratio %.3f" % (len(sample) >> 20, cores, dt, len(sample) / max(1, out_bytes))}
+
+
+def end_to_end_abi(data, quality, lgwin, shard_kb, want_bytes, want_sha):
+    """host buffer -> BrotliEncoderCompress of the drop-in library
+    (libbrotlienc_amd.so, partition plan from BROTLI_AMD_SHARD_KB) -> host buffer, PCIe included.
+    Never the reported `value`."""
+    import hashlib
+    lib_path = os.path.join(ROOT, "brotli_amd", "lib", "libbrotlienc_amd.so")
+    if not os.path.exists(lib_path):
+        return None
+    os.environ["BROTLI_AMD_SHARD_KB"] = str(shard_kb)
+    L = C.CDLL(lib_path)
+    L.BrotliEncoderMaxCompressedSize.restype = C.c_size_t
+    L.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
+    L.BrotliEncoderCompress.restype = C.c_int
+    L.BrotliEncoderCompress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_char_p,
+                                        C.POINTER(C.c_size_t), C.c_char_p]
+    cap = L.BrotliEncoderMaxCompressedSize(len(data))
+    out = C.create_string_buffer(cap)
+    times, n_out = [], 0
+    for _ in range(3):
+        sz = C.c_size_t(cap)
+        t0 = time.perf_counter()
+        ok = L.BrotliEncoderCompress(quality, lgwin, 0, len(data), data, C.byref(sz), out)
+        times.append(time.perf_counter() - t0)
+        if not ok:
+            return {"error": "BrotliEncoderCompress returned BROTLI_FALSE"}
+        n_out = sz.value
+    dt = sorted(times)[len(times) // 2]
+    return {"MBps": round(len(data) / 1e6 / dt, 1), "seconds_all": [round(t, 4) for t in times],
+            "out_bytes": n_out, "bytes_equal_device_path": n_out == want_bytes and
+            hashlib.sha256(out.raw[:n_out]).hexdigest() == want_sha,
+            "note": "one BrotliEncoderCompress call on a pageable host buffer, BROTLI_AMD_SHARD_KB=%d, "
+                    "median of 3 (the first includes context creation)" % shard_kb}
 
 
 def main_q1(args):
@@ -330,16 +372,19 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = total / 1e6 / (dt / args.steps)
-        ms_parse = sum(i["ms_parse"] for i in infos) / len(infos)
+        def avg(k):
+            return sum(i.get(k, 0.0) for i in infos) / len(infos)
+        ms_parse, ms_index, ms_ixb = avg("ms_parse"), avg("ms_index"), avg("ms_ix_bucket")
         algo = ALGO_BYTES_PER_INPUT_BYTE[args.quality]
-        achieved = algo * n / (ms_parse / 1e3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            t = json.load(open(prof))
-            key = "%d/%d" % (args.size_mb, args.shard_kb)
-            if key in t:
-                traffic = t[key]["hbm_bytes_per_launch"]
+        indexed = args.quality == 5 and ms_ixb > 0
+        if indexed and ms_ixb >= ms_parse:
+            kernel, k_ms, k_bytes = "k_ix_bucket", ms_ixb, IX_BUCKET_BYTES_PER_INPUT_BYTE
+        else:
+            kernel = "k_chain" if indexed else ("k_parse4" if args.quality == 5 else "k_parse_deep")
+            k_ms, k_bytes = ms_parse, (algo if not indexed else 9.0 + 16.0 * 0.4)
+        achieved = k_bytes * n / (k_ms / 1e3) / 1e9
+        path_ms = ms_index + ms_parse
+        path = algo * n / (path_ms / 1e3) / 1e9
         line = {
             "metric": "encode MB/s at quality %d, lgwin %d, 1 GiB input; bit-exact vs c/enc" % (
                 args.quality, args.lgwin),
@@ -354,16 +399,23 @@ def main():
                                   "bytes identical to the reference driven with the same plan" % (
                                       infos[-1]["nshards"], args.shard_kb),
                 "compressed_bytes": out_total, "ratio": round(total / out_total, 4),
-                "parse_ms_per_step": [round(i["ms_parse"], 1) for i in infos],
-                "stage_ms": {k: round(sum(i[k] for i in infos) / len(infos), 3) for k in
-                             ("ms_total", "ms_init", "ms_index", "ms_parse", "ms_build", "ms_store", "ms_gather")},
+                "parse_ms_per_step": [round(i["ms_index"] + i["ms_parse"], 1) for i in infos],
+                "stage_ms": {k: round(avg(k), 3) for k in
+                             ("ms_total", "ms_init", "ms_index", "ms_ix_bucket", "ms_parse", "ms_build", "ms_store", "ms_gather")},
             },
-            "roofline": {"bound": "hbm", "kernel": "k_parse4" if args.quality == 5 else "k_parse_deep", "achieved": round(achieved, 1),
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": traffic,
-                         "note": "algorithmic bytes = %.0f B per input byte x %d bytes per launch; "
-                                 "kernel time %.3f ms (HIP events on the library's stream); the kernel "
-                                 "is latency bound (dependent random accesses), not bandwidth bound (DESIGN.md)" % (algo, n, ms_parse)},
+                         "frac_of_achievable_6300": round(achieved / HBM_ACHIEVABLE_GBS, 5),
+                         "traffic": None, "traffic_source": "not measured in this run (PMC passes: profiles/)",
+                         "parse_path": {"kernels": "k_ix_count + k_ix_scan + k_ix_scatter + k_ix_bucket + k_chain + k_cmd_encode"
+                                        if indexed else kernel,
+                                        "ms": round(path_ms, 3), "achieved": round(path, 1),
+                                        "frac": round(path / HBM_PEAK_GBS, 5),
+                                        "model": "SURVEY.md 8(d): %.0f B per input byte for the whole LZ77 parse" % algo},
+                         "note": "%s: algorithmic bytes = %.1f B per input byte x %d bytes per launch; kernel "
+                                 "time %.3f ms (HIP events on the library's stream).  The parse is bound by "
+                                 "instruction issue and dependent accesses, not by bandwidth (DESIGN.md 5)" % (
+                                     kernel, k_bytes, n, k_ms)},
         }
         if world == 1 and not args.no_cpu_baseline:
             # spot check of the bytes against the oracle on the first shards, then the baseline
@@ -385,6 +437,8 @@ def main():
                 line["config"]["parity_full_sha256_equal"] = (
                     cb["sha256"] == line["config"]["gpu_output_sha256"] and cb["out_bytes"] == nbytes)
             line["config"]["single_stream_ratio"] = cb.get("single_stream_ratio")
+            line["config"]["end_to_end_abi"] = end_to_end_abi(data, args.quality, args.lgwin, args.shard_kb, nbytes,
+                                                             line["config"]["gpu_output_sha256"])
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -61,7 +61,6 @@ struct JobParams {
                                //   searches the next position in the same step (k_parse4.h)
 #define JOB_FLAG_INDEXED 64u   // quality 5: match candidates come from a position index built by data-parallel
                                //   kernels (k_index.h); the serial chain (k_chain.h) only selects
-#define JOB_FLAG_WIDE 128u     // k_chain: one shard per wave, 16 positions of look-ahead, wave-uniform state
 #define JOB_FLAG_DEEP 16u      // one shard per wave, 32 .. 256 slots per bucket (k_parse_deep.h)
 
 // Per-shard description written by the host.

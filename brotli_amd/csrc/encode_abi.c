@@ -13,6 +13,7 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -100,6 +101,33 @@ static void tables_path(char* out, size_t cap) {
   snprintf(out, cap, "brotli_tables.bin");
 }
 
+/* Device contexts are expensive (HIP context, tables, a workspace sized for the largest job so
+   far): an encoder instance borrows one from a small process-wide pool and hands it back when it
+   is destroyed, so a program that compresses many buffers pays for the set-up once. */
+#define CTX_POOL 8
+static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
+static struct { BrotliAmdCtx* ctx; int device; } g_pool[CTX_POOL];
+
+static BrotliAmdCtx* pool_take(int device) {
+  BrotliAmdCtx* c = NULL;
+  int i;
+  pthread_mutex_lock(&g_pool_lock);
+  for (i = 0; i < CTX_POOL; ++i) {
+    if (g_pool[i].ctx && g_pool[i].device == device) { c = g_pool[i].ctx; g_pool[i].ctx = NULL; break; }
+  }
+  pthread_mutex_unlock(&g_pool_lock);
+  return c;
+}
+static void pool_give(BrotliAmdCtx* c, int device) {
+  int i;
+  pthread_mutex_lock(&g_pool_lock);
+  for (i = 0; i < CTX_POOL; ++i) {
+    if (!g_pool[i].ctx) { g_pool[i].ctx = c; g_pool[i].device = device; c = NULL; break; }
+  }
+  pthread_mutex_unlock(&g_pool_lock);
+  if (c) brotli_amd_ctx_destroy(c);
+}
+
 BrotliEncoderState* BrotliEncoderCreateInstance(brotli_amd_alloc_func alloc_func,
                                                 brotli_amd_free_func free_func, void* opaque) {
   BrotliEncoderState* s;
@@ -124,7 +152,10 @@ BrotliEncoderState* BrotliEncoderCreateInstance(brotli_amd_alloc_func alloc_func
 void BrotliEncoderDestroyInstance(BrotliEncoderState* s) {
   if (!s) return;
   if (s->stream) brotli_amd_stream_destroy(s->stream);
-  if (s->ctx) brotli_amd_ctx_destroy(s->ctx);
+  if (s->ctx) {
+    if (s->failed) brotli_amd_ctx_destroy(s->ctx);   /* whatever went wrong, do not pass it on */
+    else pool_give(s->ctx, s->device);
+  }
   st_free(s, s->in_buf);
   st_free(s, s->out_buf);
   st_free(s, s->calls);
@@ -193,7 +224,8 @@ static int ensure_initialized(BrotliEncoderState* s) {
     return 0;
   }
   tables_path(path, sizeof(path));
-  if (brotli_amd_ctx_create(s->device, path, &s->ctx) != BROTLI_AMD_OK) {
+  s->ctx = pool_take(s->device);
+  if (!s->ctx && brotli_amd_ctx_create(s->device, path, &s->ctx) != BROTLI_AMD_OK) {
     s->failed = 1;
     if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
     return 0;
@@ -275,13 +307,17 @@ static int submit(BrotliEncoderState* s, int op) {
       s->in_len != 0) {
     /* Qualities 6-9, everything in one FINISH: the same bytes come from a one-shard job
        (falls through to the plan code below with shard size 0 = one shard). */
-  } else if (s->shard_bytes == 0) {
+  } else if (s->shard_bytes == 0 && !(s->in_len == 0 && s->submitted == 0 && !s->stream)) {
     /* One encoder instance: the persistent device stream reproduces the
-       reference for any op sequence (qualities 6-9: up to the window size). */
+       reference for any op sequence (qualities 6-9: up to the window size).
+       (An operation before the first data byte is answered on the host, below: the reference has
+       not chosen its hasher yet either — UpdateSizeHint, encode.c:1619-1632, keeps a hint of 0
+       open — so the device stream is only created once there is data to size it by.) */
     const uint8_t* out;
     uint64_t out_len;
     if (!s->stream) {
       if (brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
+                                   s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u,
                                    &s->stream) != BROTLI_AMD_OK) {
         if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
         return 0;
@@ -401,22 +437,30 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
          and hands over the open byte */
       const uint8_t* o;
       uint64_t on;
-      if (!s->hint_fixed) {                                        /* UpdateSizeHint(s, 0), :1647 */
+      if (!s->hint_fixed && s->total_in != 0) {                    /* UpdateSizeHint(s, 0), :1647: a hint of 0 stays open */
         s->eff_hint = s->total_in >= (1u << 30) ? (1u << 30) : (uint32_t)s->total_in;
         s->hint_fixed = 1;
       }
-      if (!s->stream && brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
-                                                 &s->stream) != BROTLI_AMD_OK) { s->failed = 1; return BROTLI_FALSE; }
-      if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_FLUSH_OPEN, &o, &on) != BROTLI_AMD_OK ||
-          brotli_amd_stream_take_partial(s->stream, &s->carry_bits, &s->carry_value) != BROTLI_AMD_OK) {
-        if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
-        s->failed = 1;
-        return BROTLI_FALSE;
+      if (!s->stream && s->in_len == 0 && s->submitted == 0) {
+        /* metadata before the first data byte: the stream header is still pending and goes out
+           in front of the metadata block; the device stream will start without it */
+        if (!s->header_written && s->stream_offset == 0) window_bits(s->lgwin, &s->carry_value, &s->carry_bits);
+        s->header_written = 2;
+      } else {
+        if (!s->stream && brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
+                                                   s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u,
+                                                   &s->stream) != BROTLI_AMD_OK) { s->failed = 1; return BROTLI_FALSE; }
+        if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_FLUSH_OPEN, &o, &on) != BROTLI_AMD_OK ||
+            brotli_amd_stream_take_partial(s->stream, &s->carry_bits, &s->carry_value) != BROTLI_AMD_OK) {
+          if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+          s->failed = 1;
+          return BROTLI_FALSE;
+        }
+        s->submitted += s->in_len;
+        s->in_len = 0;
+        s->header_written = 1;
+        if (!out_append(s, o, (size_t)on)) return BROTLI_FALSE;
       }
-      s->submitted += s->in_len;
-      s->in_len = 0;
-      s->header_written = 1;
-      if (!out_append(s, o, (size_t)on)) return BROTLI_FALSE;
     } else if (!submit_fast(s, OP_PROCESS)) {                        /* data fed so far comes first */
       s->failed = 1;
       return BROTLI_FALSE;
@@ -462,7 +506,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
       const uint64_t threshold = s->stream_offset ? 2u :
           (s->quality >= 9 && s->lgwin > 16) ? ((uint64_t)1 << (s->lgwin < 18 ? s->lgwin : 18)) : 65536u;
       const uint64_t seen = s->total_in + a;
-      if (seen >= threshold || op != OP_PROCESS) {
+      if ((seen >= threshold || op != OP_PROCESS) && seen != 0) {   /* a hint of 0 stays open (:1620) */
         s->eff_hint = seen >= (1u << 30) ? (1u << 30) : (uint32_t)seen;
         s->hint_fixed = 1;
       }
@@ -520,37 +564,41 @@ const uint8_t* BrotliEncoderTakeOutput(BrotliEncoderState* s, size_t* size) {
   return p;
 }
 
+/* Worst case of the raw fallback stream below (the bound the reference publishes,
+   c/include/brotli/encode.h:388-404): two header bytes, one 4-byte meta-block header per 16 KiB
+   started... the reference prices 4 bytes for every complete 16 KiB, plus 3 + 1 closing bytes. */
 size_t BrotliEncoderMaxCompressedSize(size_t input_size) {
-  /* encode.c:1251-1258 */
-  size_t num_large_blocks = input_size >> 14;
-  size_t overhead = 2 + (4 * num_large_blocks) + 3 + 1;
-  size_t result = input_size + overhead;
+  size_t bound;
   if (input_size == 0) return 2;
-  return (result < input_size) ? 0 : result;
+  bound = input_size + 4 * (input_size >> 14) + 6;
+  return bound < input_size ? 0 : bound;                      /* overflow: no bound exists */
 }
 
-/* encode.c:1264-1294 */
+/* The whole input as stored meta-blocks (RFC 7932 section 9.2: ISLAST 0, MNIBBLES, MLEN - 1,
+   ISUNCOMPRESSED 1, byte aligned payload) behind a lgwin 24 header, closed by an empty last
+   meta-block: the bytes BrotliEncoderCompress falls back to when compression does not pay
+   (same stream as c/enc/encode.c:1264-1294). */
 static size_t make_uncompressed_stream(const uint8_t* input, size_t input_size, uint8_t* output) {
-  size_t size = input_size, result = 0, offset = 0;
-  if (input_size == 0) { output[0] = 6; return 1; }
-  output[result++] = 0x21;
-  output[result++] = 0x03;
-  while (size > 0) {
-    uint32_t nibbles = 0, chunk_size, bits;
-    chunk_size = (size > (1u << 24)) ? (1u << 24) : (uint32_t)size;
-    if (chunk_size > (1u << 16)) nibbles = (chunk_size > (1u << 20)) ? 2 : 1;
-    bits = (nibbles << 1) | ((chunk_size - 1) << 3) | (1u << (19 + 4 * nibbles));
-    output[result++] = (uint8_t)bits;
-    output[result++] = (uint8_t)(bits >> 8);
-    output[result++] = (uint8_t)(bits >> 16);
-    if (nibbles == 2) output[result++] = (uint8_t)(bits >> 24);
-    memcpy(&output[result], &input[offset], chunk_size);
-    result += chunk_size;
-    offset += chunk_size;
-    size -= chunk_size;
+  uint8_t* w = output;
+  size_t left = input_size;
+  if (input_size == 0) { *w = 0x06; return 1; }                /* WBITS 16, ISLAST, ISEMPTY */
+  *w++ = 0x21;                                                  /* WBITS = 24 (0100001b) + ... */
+  *w++ = 0x03;                                                  /* ... an empty metadata block pads the byte */
+  while (left != 0) {
+    const uint32_t mlen = left > (1u << 24) ? (1u << 24) : (uint32_t)left;
+    const uint32_t nib = mlen > (1u << 20) ? 6u : mlen > (1u << 16) ? 5u : 4u;   /* nibbles of MLEN - 1 */
+    /* bit 0 ISLAST = 0 | bits 1-2 MNIBBLES - 4 | MLEN - 1 | ISUNCOMPRESSED */
+    const uint32_t head = ((nib - 4u) << 1) | ((mlen - 1u) << 3) | (1u << (3u + 4u * nib));
+    const uint32_t head_bytes = nib == 6u ? 4u : 3u;
+    uint32_t i;
+    for (i = 0; i < head_bytes; ++i) *w++ = (uint8_t)(head >> (8u * i));
+    memcpy(w, input, mlen);
+    w += mlen;
+    input += mlen;
+    left -= mlen;
   }
-  output[result++] = 3;
-  return result;
+  *w++ = 0x03;                                                  /* ISLAST, ISEMPTY */
+  return (size_t)(w - output);
 }
 
 BROTLI_BOOL BrotliEncoderCompress(int quality, int lgwin, int mode, size_t input_size,
@@ -593,6 +641,19 @@ BROTLI_BOOL BrotliEncoderCompress(int quality, int lgwin, int mode, size_t input
 }
 
 uint32_t BrotliEncoderVersion(void) { return 0x1002000; }   /* 1.2.0, c/common/version.h */
+
+/* encode.h:531: the reference reports host memory; here the encoder state lives on the device, so
+   this is the HOST side of one instance (staging of input and output) — the device workspace is
+   sized by brotli_amd_max_output / DESIGN.md section 3 and is not host memory. */
+size_t BrotliEncoderEstimatePeakMemoryUsage(int quality, int lgwin, size_t input_size) {
+  (void)quality; (void)lgwin;
+  return 2 * input_size + BrotliEncoderMaxCompressedSize(input_size) + (1u << 16);
+}
+/* encode.h:534: 0 = "not a valid dictionary" — prepared dictionaries are outside the GPU path. */
+size_t BrotliEncoderGetPreparedDictionarySize(const BrotliEncoderPreparedDictionary* dictionary) {
+  (void)dictionary;
+  return 0;
+}
 
 BrotliEncoderPreparedDictionary* BrotliEncoderPrepareDictionary(
     int type, size_t data_size, const uint8_t* data, int quality,

@@ -52,7 +52,7 @@ struct BrotliAmdCtx {
   uint64_t* d_fresult = nullptr;
   uint64_t ffrag_cap = 0, fblock_cap = 0;
   hipEvent_t ev[8] = {};
-  hipEvent_t ev_ix = nullptr;
+  hipEvent_t ev_ix = nullptr, ev_ixb = nullptr;
   std::string err;
 };
 
@@ -192,18 +192,29 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
       // shards per wave of k_chain: one 16-lane group per shard, as many waves as stay resident
       const uint64_t resident = (uint64_t)c->num_cus * 4u * CHAIN_WAVES;
       const uint64_t ns = plan->shards.size();
-      uint32_t v = ns <= resident ? 1u : ns <= 2 * resident ? 2u : 4u;
+      // measured (profiles/r02_b/c): the step is bound by instruction issue, so four shards per
+      // wave win as soon as there are enough shards to give every SIMD a wave
+      (void)resident;
+      uint32_t v = ns >= 1024 ? 4u : ns >= 512 ? 2u : 1u;
       if (const char* g = getenv("BROTLI_AMD_CGROUPS")) v = (uint32_t)atoi(g);
-      {   // BROTLI_AMD_WIDE=1: one shard per wave with wave-uniform state (experiment)
-        const char* w = getenv("BROTLI_AMD_WIDE");
-        if (w && atoi(w) != 0) { plan->J.flags |= JOB_FLAG_WIDE; v = 1; }
-      }
       plan->J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
       if (v == 1 || v == 2) plan->J.flags |= v << JOB_FLAG_GROUPS_SHIFT;
     }
   }
   return BROTLI_AMD_OK;
 }
+
+// Every extern "C" entry runs on the context's device and leaves the caller's current device
+// as it found it (a host application may be driving another GPU from the same thread).
+struct DeviceScope {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceScope(int device) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(device) == hipSuccess;
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 
 enum { STAGE_PARSE = 1, STAGE_BUILD = 2, STAGE_STORE = 4, STAGE_ALL = 7 };
 
@@ -246,6 +257,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     hipLaunchKernelGGL(k_ix_count, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_scan, dim3(nshards), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_scatter, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
+    HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
     hipLaunchKernelGGL(k_ix_bucket, dim3(((nshards + 7u) / 8u) * 8u * ((1u << plan.J.ix_nb_log2) / plan.J.ix_bpw)), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
     if (getenv("BROTLI_AMD_INDEX_ONLY")) {   // timing experiments: stop after the index kernels
@@ -267,10 +279,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       else if (plan.J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(nshards), dim3(64), 0, c->stream, a);
       else hipLaunchKernelGGL(k_parse_deep<4>, dim3(nshards), dim3(64), 0, c->stream, a);
     } else if (indexed)
-      if (plan.J.flags & JOB_FLAG_WIDE)
-        hipLaunchKernelGGL(k_chain<true>, dim3(nshards), dim3(64), C_GROUP_LDS_WORDS * 4u, c->stream, a);
-      else
-        hipLaunchKernelGGL(k_chain<false>, dim3((nshards + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, a);
+      hipLaunchKernelGGL(k_chain, dim3((nshards + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, a);
     else if (plan.J.flags & JOB_FLAG_QUAD)
       hipLaunchKernelGGL(k_parse4, dim3((nshards + gpw - 1) / gpw), dim3(64), 0, c->stream, a);
     else
@@ -297,7 +306,11 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     float t;
     HIP_OK(c, hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
     info->ms_init = t;
-    if (indexed) { HIP_OK(c, hipEventElapsedTime(&ms_index, c->ev[1], c->ev_ix)); }
+    info->ms_ix_bucket = 0;
+    if (indexed) {
+      HIP_OK(c, hipEventElapsedTime(&ms_index, c->ev[1], c->ev_ix));
+      HIP_OK(c, hipEventElapsedTime(&info->ms_ix_bucket, c->ev_ixb, c->ev_ix));
+    }
     info->ms_index = ms_index;
     info->ms_parse = ms_parse;
     info->ms_build = ms_build;
@@ -331,7 +344,8 @@ int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** ou
     int n = 0;
     HIP_OK(c, hipGetDeviceCount(&n));
     if (device < 0 || device >= n) return fail(c, "no HIP device %d (count %d)", device, n);
-    HIP_OK(c, hipSetDevice(device));
+    DeviceScope dev(device);
+    if (!dev.ok) return fail(c, "hipSetDevice(%d) failed", device);
     hipDeviceProp_t prop;
     HIP_OK(c, hipGetDeviceProperties(&prop, device));
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -340,6 +354,7 @@ int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** ou
     HIP_OK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto& e : c->ev) HIP_OK(c, hipEventCreate(&e));
     HIP_OK(c, hipEventCreate(&c->ev_ix));
+    HIP_OK(c, hipEventCreate(&c->ev_ixb));
     if (!dev_upload(c, &c->d_lut, c->ht.context_lut, 2048)) return false;
     if (!dev_upload(c, &c->d_dict, c->ht.dict.data(), c->ht.dict.size())) return false;
     if (!dev_upload(c, &c->d_hash_words, c->ht.hash_words.data(), 32768 * 2)) return false;
@@ -351,7 +366,7 @@ int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** ou
 
 void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->device);
+  DeviceScope dev(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_lut, c->d_dict, c->d_hash_words, c->d_hash_lengths, c->d_log2, c->d_T,
                   c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters,
@@ -361,6 +376,7 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   for (uint8_t* p : c->d_table_chunks) if (p) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->ev_ix) (void)hipEventDestroy(c->ev_ix);
+  if (c->ev_ixb) (void)hipEventDestroy(c->ev_ixb);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -383,7 +399,8 @@ int brotli_amd_encode_device(BrotliAmdCtx* c, const void* d_in, uint64_t len,
   if (!info) info = &local;
   memset(info, 0, sizeof(*info));
   *out_size = 0;
-  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   JobPlan plan;
   int rc = plan_from_params(c, len, p, &plan);
   if (rc != BROTLI_AMD_OK) return rc;
@@ -442,7 +459,8 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
                            const BrotliAmdJobParams* p, uint8_t* out, uint64_t out_cap,
                            uint64_t* out_size, BrotliAmdJobInfo* info) {
   *out_size = 0;
-  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   const uint64_t max_out = brotli_amd_max_output(len, p);
   if (max_out == 0) { fail(c, "parameters outside the GPU path"); return BROTLI_AMD_UNSUPPORTED; }
   auto stage = [&]() -> bool {
@@ -491,7 +509,8 @@ int brotli_amd_encode_fast_device(BrotliAmdCtx* c, const void* d_in, uint64_t le
   if (!info) info = &local;
   memset(info, 0, sizeof(*info));
   *out_bits = 0;
-  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   if (p->carry_bits > 15) { fail(c, "carry_bits > 15"); return BROTLI_AMD_UNSUPPORTED; }
   FastPlan plan;
   if (!plan_fast(len, p->lgwin, call_sizes, (size_t)ncalls, &plan)) {
@@ -584,7 +603,8 @@ int brotli_amd_encode_fast_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len
                                 const BrotliAmdFastParams* p, uint8_t* out, uint64_t out_cap,
                                 uint64_t* out_bits, BrotliAmdJobInfo* info) {
   *out_bits = 0;
-  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   const uint64_t max_out = brotli_amd_fast_max_output(len, ncalls, p->lgwin);
   if (max_out == 0) { fail(c, "quality 1: lgwin %d", p->lgwin); return BROTLI_AMD_UNSUPPORTED; }
   auto stage = [&]() -> bool {
@@ -762,9 +782,10 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
 extern "C" {
 
 int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t size_hint,
-                             uint32_t stream_offset, BrotliAmdStream** out) {
+                             uint32_t stream_offset, uint32_t flags, BrotliAmdStream** out) {
   *out = nullptr;
-  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   BrotliAmdStream* s = new BrotliAmdStream();
   s->c = c;
   if (!plan_params(quality, lgwin, size_hint, &s->J)) {
@@ -773,6 +794,7 @@ int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t s
     return BROTLI_AMD_UNSUPPORTED;
   }
   if (quality != 5) s->J.flags |= JOB_FLAG_DEEP;   // k_parse_deep.h; k_parse.h serves the 16-slot hashers
+  if (flags & BROTLI_AMD_FLAG_NO_HEADER) s->J.flags |= JOB_FLAG_NO_HEADER;
   s->J.log2_lut_size = s->J.max_metablock_size + 2;
   if (!stream_init(s, stream_offset)) { brotli_amd_stream_destroy(s); return BROTLI_AMD_ERROR; }
   *out = s;
@@ -784,7 +806,8 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
   *out = nullptr;
   *out_len = 0;
   BrotliAmdCtx* c = s->c;
-  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   if (s->finished) { fail(c, "stream already finished"); return BROTLI_AMD_ERROR; }
   if (op < 0 || op > 3) { fail(c, "bad stream op"); return BROTLI_AMD_UNSUPPORTED; }
   if (!stream_run(s, data, len, op)) return BROTLI_AMD_ERROR;
@@ -798,7 +821,8 @@ int brotli_amd_stream_take_partial(BrotliAmdStream* s, uint32_t* nbits, uint32_t
   BrotliAmdCtx* c = s->c;
   *nbits = 0;
   *value = 0;
-  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   uint32_t lb[2] = {0, 0};   // last_bytes, last_bytes_bits are adjacent in ShardState
   static_assert(offsetof(ShardState, last_bytes_bits) == offsetof(ShardState, last_bytes) + 4, "layout");
   if (hipMemcpy(lb, &s->d_state->last_bytes, 8, hipMemcpyDeviceToHost) != hipSuccess) { fail(c, "state read failed"); return BROTLI_AMD_ERROR; }
@@ -811,7 +835,7 @@ int brotli_amd_stream_take_partial(BrotliAmdStream* s, uint32_t* nbits, uint32_t
 
 void brotli_amd_stream_destroy(BrotliAmdStream* s) {
   if (!s) return;
-  (void)hipSetDevice(s->c->device);
+  DeviceScope dev(s->c->device);
   (void)hipStreamSynchronize(s->c->stream);
   void* ptrs[] = {s->d_in, s->d_ws, s->d_out, s->d_desc, s->d_state, s->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -825,7 +849,8 @@ int brotli_amd_debug_parse(BrotliAmdCtx* c, const void* d_in, uint64_t len,
   if (!info) info = &local;
   memset(info, 0, sizeof(*info));
   *ncmds = 0;
-  if (hipSetDevice(c->device) != hipSuccess) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   JobPlan plan;
   int rc = plan_from_params(c, len, p, &plan);
   if (rc != BROTLI_AMD_OK) return rc;

@@ -298,167 +298,6 @@ DEV CEval c_evaluate(const JobParams& J, CShard& C, bool want, uint32_t P0, int 
   return r;
 }
 
-// ---- WIDE: the common path as a tight, hand-scheduled loop ---------------------------------
-// One shard per wave, all state wave-uniform (scalar registers).  A step: the 64 lanes evaluate
-// 16 positions x 4 distance-cache entries with straight-line vector code (no loops: a position
-// whose answer would need one — a cache candidate or an index candidate longer than the bytes
-// at hand — is simply flagged for the generic step); then scalar code walks the state machine
-// over the positions (one v_readlane each) and commits at most one copy.  Block boundaries,
-// flagged positions, unstored positions to account for, the static dictionary while its gate is
-// open and the literal spree leave the loop: the generic step of chain_round handles exactly
-// one such event and comes back here.
-template <int HT>
-DEV void c_fast_loop(const JobParams& J, CShard& C, int kpos, int idc,
-                     bool force_slow, uint32_t& nsteps) {
-  QShard& g = C.g;
-  constexpr uint32_t htl = HT == 68 ? 8u : 4u;
-  if (!(g.state == Q_SEARCH || g.state == Q_LAZY)) return;
-  if (g.st_count != 0) return;
-  if (!(g.dict_matches < (g.dict_lookups >> 7))) return;      // the dictionary gate is open: generic path
-  uint32_t pos = g.position, ins = g.insert_length, arh = g.apply_random_heuristics;
-  const uint32_t pend = g.pos_end, store_end = g.store_end, limit = J.max_backward_limit;
-  uint32_t lazy = g.state == Q_LAZY ? 1u : 0u;
-  uint32_t sr_score = g.sr_score, sr_len = g.sr_len, sr_dist = g.sr_dist, delayed = g.delayed;
-  int32_t sr_delta = g.sr_delta;
-  int32_t dcl[4] = {g.dc[0], g.dc[1], g.dc[2], g.dc[3]};
-  uint32_t ncmds = g.r.ncmds, nlits = g.r.nlits, frontier = C.frontier, searches = 0, steps = 0;
-  const uint8_t* data = g.data;
-  const bool i1 = idc == 1, i2 = idc == 2, i3 = idc == 3;
-  const uint32_t pen = idc == 0 ? 0u : 39u + ((0x1CA10u >> ((uint32_t)idc & 0xEu)) & 0xEu);
-  (void)pen;
-  for (;;) {
-    if (!lazy && !(pos + htl < pend)) break;
-    const uint32_t P0 = pos + lazy;
-    if (frontier != P0) break;
-    uint64_t ft = QP_NOW();
-    // ---- evaluation, lane (kpos, idc) ----
-    const uint32_t Pk = P0 + (uint32_t)kpos;
-    const bool ev = Pk + htl <= pend;
-    const uint32_t maxlen = pend - Pk;
-    const uint32_t dcv = (uint32_t)(i3 ? dcl[3] : i2 ? dcl[2] : i1 ? dcl[1] : dcl[0]);
-    const bool d_cand = ev && (dcv - 1u) < umin(Pk, limit);
-    uint64_t cb[2], pb[2];
-    __builtin_memcpy(cb, data + (ev ? Pk : 0u), 16);
-    __builtin_memcpy(pb, data + (d_cand ? Pk - dcv : 0u), 16);
-    const uint64_t rw = C.res[ev ? Pk : 0u];
-    const uint64_t x0 = cb[0] ^ pb[0], x1 = cb[1] ^ pb[1];
-    const uint32_t l0 = x0 ? ((uint32_t)dev_ctz64(x0) >> 3) : 8u;
-    const uint32_t l1 = x1 ? ((uint32_t)dev_ctz64(x1) >> 3) : 8u;
-    const uint32_t md = l0 < 8u ? l0 : 8u + l1;
-    const uint32_t d_len = umin(md, maxlen);
-#if defined(Q_PROFILE)
-    if (wave_any(d_len == 0xFFFFFFFFu || rw == 0x123456789ull)) g.pf_acc++;   // (profiling fence: loads consumed)
-#endif
-    QP_ADD(g, 8, ft);
-    const bool d_long = d_cand && md == 16u && maxlen > 16u;
-    const bool d_ok = d_cand && (d_len >= 3u || (d_len == 2u && idc < 2));
-    // (len, earlier entry) orders the cache candidates like their scores do (see c_evaluate);
-    // bit 31 carries "some candidate of this position is longer than the 16 bytes compared"
-    uint32_t d_key = (d_ok ? (d_len << 2) | (3u - (uint32_t)idc) : 0u) | (d_long ? 0x80000000u : 0u);
-    d_key = umax(d_key, wave_quad_xor(d_key, 1));
-    d_key = umax(d_key, wave_quad_xor(d_key, 2));
-    const uint32_t dc_len = (d_key >> 2) & 0x1FFFFFFFu;
-    const uint32_t dc_i = 3u - (d_key & 3u);
-    const uint32_t dc_dist = (uint32_t)(dc_i == 3u ? dcl[3] : dc_i == 2u ? dcl[2] : dc_i == 1u ? dcl[1] : dcl[0]);
-    const uint32_t dc_pen = dc_i == 0u ? 0u : dc_i == 1u ? 39u : 43u;
-    const uint32_t dc_score = (d_key & 0x7FFFFFFFu) != 0 ? 135u * dc_len + 1935u - dc_pen : K_MIN_SCORE;
-    const uint32_t rlo = (uint32_t)rw, rhi = (uint32_t)(rw >> 32);
-    const uint32_t kind = rlo >> 30, b_len = (rlo >> 24) & 63u, b_dist = rlo & 0xFFFFFFu;
-    const bool b_ok = kind == IX_KIND_EXACT;
-    const uint32_t b_score = 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u);
-    const bool tainted = (rhi & IX_TAINT) != 0;
-    const bool b_wins = b_ok && b_score > dc_score;
-    const bool need = kind >= IX_KIND_LONG || (rhi & IX_DANGER) != 0 || tainted || (d_key >> 31) != 0 ||
-                      force_slow || (b_wins && b_len <= umax(dc_len, 3u));
-    const uint32_t e_score = b_wins ? b_score : dc_score;
-    const uint32_t e_len = b_wins ? b_len : dc_len;
-    const uint32_t e_dist = b_wins ? b_dist : dc_dist;
-    const uint32_t e_flags = e_score | (ev ? 0x80000000u : 0u) | (need ? 0x40000000u : 0u);
-#if defined(Q_PROFILE)
-    if (wave_any(e_flags == 0x12345u)) g.pf_acc++;
-#endif
-    QP_ADD(g, 9, ft);
-    // ---- the state machine over the evaluated positions (:44-164), scalar ----
-    uint32_t k = 0, sr_k = 0xFFu;
-    bool commit = false;
-    while (k < 16u) {
-      const uint32_t f = wave_bcast(e_flags, (int)(4u * k));
-#if defined(BROTLI_AMD_SIMT_SIM)
-      if ((f >> 30) == 3u && k == 0 && wave_lane() == 0) {   // (why the fast loop stops at its first position)
-        const uint32_t dk = d_key, kd = kind; const bool tn = tainted, un = (b_wins && b_len <= umax(dc_len, 3u));
-        g_sim_counts[1] += (dk >> 31) ? 1 : 0; g_sim_counts[2] += kd >= 2 ? 1 : 0; g_sim_counts[3] += tn ? 1 : 0; g_sim_counts[4] += un ? 1 : 0;
-      }
-      if ((f >> 30) != 2u && (f >> 30) != 3u && k == 0 && wave_lane() == 0) g_sim_counts[5]++;
-#endif
-      if ((f >> 30) != 2u) break;                              // not evaluated, or not decidable here
-      const uint32_t sk = f & 0x3FFFFFFFu;
-      if (!lazy) {
-        if (!(pos + htl < pend)) break;
-        if (sk > K_MIN_SCORE) { sr_score = sk; sr_k = k; delayed = 0; sr_delta = 0; lazy = 1u; }
-        else {
-          if (pos + 1u > arh) break;                           // literal spree
-          ++ins; ++pos;
-        }
-        ++k;
-      } else {
-        ++k;
-        if (sk >= sr_score + 175u) {
-          ++pos; ++ins;
-          sr_score = sk; sr_k = k - 1u; sr_delta = 0;
-          if (++delayed < 4u && pos + htl < pend) continue;
-        }
-        commit = true;
-        break;
-      }
-    }
-    QP_ADD(g, 10, ft);
-    if (k == 0) break;
-    ++steps;
-    SIM_COUNT(14, 1);
-    frontier = P0 + k;
-    searches += k;
-    if (sr_k != 0xFFu) {
-      sr_len = wave_bcast(e_len, (int)(4u * sr_k));
-      sr_dist = wave_bcast(e_dist, (int)(4u * sr_k));
-    }
-    if (commit) {
-      // :165-206
-      uint32_t range_start = pos + 2u;
-      const uint32_t range_end = umin(pos + sr_len, store_end);
-      if (sr_dist < (sr_len >> 2)) range_start = umin(range_end, umax(range_start, pos + sr_len - (sr_dist << 2)));
-      if (range_start < range_end) {
-        if (frontier == range_start) frontier = range_end;
-        else {                                                 // positions passed over: mark them
-          C.frontier = frontier;
-          c_stored(J, C, true, range_start, range_end);
-          frontier = wave_bcast(C.frontier, 0);
-        }
-      }
-      arh = pos + 2u * sr_len + J.spree_window;
-      const uint32_t dictionary_start = umin(pos + g.stream_offset, limit);
-      const uint32_t distance_code = compute_distance_code(sr_dist, dictionary_start, dcl);
-      if (sr_dist <= dictionary_start && distance_code > 0) {
-        dcl[3] = dcl[2]; dcl[2] = dcl[1]; dcl[1] = dcl[0]; dcl[0] = (int32_t)sr_dist;
-      }
-      if (wave_lane() == 0) g.cmds[ncmds] = make_command(ins, sr_len, sr_delta, distance_code);
-      ++ncmds;
-      nlits += ins;
-      ins = 0;
-      pos += sr_len;
-      lazy = 0;
-    }
-    QP_ADD(g, 11, ft);
-  }
-  g.position = pos; g.insert_length = ins; g.apply_random_heuristics = arh;
-  g.state = lazy ? Q_LAZY : Q_SEARCH;
-  g.sr_score = sr_score; g.sr_len = sr_len; g.sr_dist = sr_dist; g.delayed = delayed; g.sr_delta = sr_delta;
-  for (int i = 0; i < 4; ++i) g.dc[i] = dcl[i];
-  g.r.ncmds = ncmds; g.r.nlits = nlits;
-  C.frontier = frontier;
-  g.stat_searches += searches;
-  nsteps += steps;
-}
-
 // ---- the common path of a 16-lane group: one whole command per step, no loops --------------
 // (up to four shards per wave.)  Lane t of a group evaluates position pos + t completely: the
 // four distance-cache candidates (16 bytes each; a longer one sends the position to the exact
@@ -686,27 +525,22 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
 }
 
 // ---- the kernel body ---------------------------------------------------------------------
-// WIDE: the whole wave serves ONE shard.  The four 16-lane groups hold identical copies of the
-// state (so everything that is per group above — marking, exact search, dictionary, block glue —
-// just happens four times with the same result, idempotently), but each group evaluates its own
-// four positions: 16 positions of look-ahead per step, and — all state being wave-uniform — the
-// state machine compiles to scalar code and real branches.
-template <bool WIDE>
+// Up to four shards per wave (q_groups_per_wave): group gi of wave w serves shard w * gpw + gi.
 DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* states,
                      uint32_t nshards, const DeviceTables* T, const uint8_t* input, uint8_t* ws,
                      uint32_t wave_index, uint32_t* lds) {
   const int t = q_t();
-  const uint32_t gpw = WIDE ? 1u : q_groups_per_wave(J);
-  const uint32_t gi = WIDE ? 0u : (uint32_t)(wave_lane() >> 4);
+  const uint32_t gpw = q_groups_per_wave(J);
+  const uint32_t gi = (uint32_t)(wave_lane() >> 4);
   const uint32_t shard = wave_index * gpw + gi;
   const bool alive = gi < gpw && shard < nshards;
-  const bool writer = alive && (WIDE ? wave_lane() == 0 : t == 0);
-  constexpr int NPOS = WIDE ? 16 : 4;
+  const bool writer = alive && t == 0;
+  constexpr int NPOS = 4;
   const uint32_t htl = hasher_htl(J.hasher_type);
   const ShardDesc& D = shards[alive ? shard : 0];
   const ShardState* S0 = &states[alive ? shard : 0];
   uint32_t* scratch = lds + gi * C_GROUP_LDS_WORDS;
-  const int kpos = (WIDE ? wave_lane() : t) >> 2, idc = t & 3;   // this lane's probe: position P0 + kpos, cache entry idc
+  const int kpos = t >> 2, idc = t & 3;   // this lane's probe: position P0 + kpos, cache entry idc
 
   CShard C;
   QShard& g = C.g;
@@ -751,32 +585,10 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   while (wave_any(g.state != Q_DONE)) {
     SIM_COUNT(7, 1);                                   // chain steps (wave level)
     uint64_t qt = QP_NOW();
-    if (WIDE) {
-      // All lanes hold the same state; reading it from lane 0 tells the compiler so: the
-      // state lives in scalar registers and the state machine branches for real.
-#define C_UNI(x) (x) = wave_bcast((x), 0)
-      C_UNI(g.state); C_UNI(g.status); C_UNI(g.position); C_UNI(g.pos_end); C_UNI(g.store_end);
-      C_UNI(g.insert_length); C_UNI(g.apply_random_heuristics);
-      C_UNI(g.sr_len); C_UNI(g.sr_dist); C_UNI(g.sr_score); g.sr_delta = (int32_t)wave_bcast((uint32_t)g.sr_delta, 0);
-      C_UNI(g.delayed); C_UNI(g.dict_lookups); C_UNI(g.dict_matches);
-      for (int i = 0; i < 4; ++i) g.dc[i] = (int32_t)wave_bcast((uint32_t)g.dc[i], 0);
-      C_UNI(g.blk_flags); C_UNI(g.blk_bytes); C_UNI(g.blk_pos);
-      C_UNI(g.r.input_pos); C_UNI(g.r.last_processed_pos); C_UNI(g.r.last_flush_pos);
-      C_UNI(g.r.last_insert_len); C_UNI(g.r.ncmds); C_UNI(g.r.nlits);
-      C_UNI(g.r.last_bytes); C_UNI(g.r.last_bytes_bits); g.r.flint = (int32_t)wave_bcast((uint32_t)g.r.flint, 0);
-      g.r.out_bytes = wave_bcast64(g.r.out_bytes, 0);
-      C_UNI(g.st_count); C_UNI(g.st_first); C_UNI(g.st_stride);
-      C_UNI(g.stat_searches); C_UNI(C.frontier); C_UNI(C.nslow); C_UNI(nsteps);
-#undef C_UNI
-    }
-    if (WIDE) {
-      if (J.hasher_type == 68) c_fast_loop<68>(J, C, kpos, idc, force_slow, nsteps);
-      else c_fast_loop<58>(J, C, kpos, idc, force_slow, nsteps);
-    }
 #if defined(BROTLI_AMD_SIMT_SIM)
-    if (!WIDE && !getenv("SIM_NOFAST")) c_group_fast(J, T, C, alive, scratch, nsteps);
+    if (!getenv("SIM_NOFAST")) c_group_fast(J, T, C, alive, scratch, nsteps);   // (test knob: generic steps only)
 #else
-    if (!WIDE) c_group_fast(J, T, C, alive, scratch, nsteps);
+    c_group_fast(J, T, C, alive, scratch, nsteps);
 #endif
     if (g.state == Q_PRE) q_driver_pre(J, g);
     if (wave_any(g.state == Q_SETUP)) {
@@ -817,7 +629,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       uint32_t fl0 = 0;
       for (int k = 0; k < NPOS; ++k) {
         if (k >= 2 && !wave_any(!stop)) break;                         // (most commands end at the second position)
-        const uint32_t flk = WIDE ? wave_bcast(e_flags, 4 * k) : q_bcast(e_flags, 4 * k);
+        const uint32_t flk = q_bcast(e_flags, 4 * k);
         if (k == 0) fl0 = flk;
         const uint32_t sk = flk & 0x3FFFFFFFu;
         const bool usable = (flk >> 30) == 2u;                         // evaluated and decidable from the index
@@ -847,14 +659,8 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       if (want && consumed != 0) { C.frontier = P0 + consumed; g.stat_searches += consumed; }
       // the pending match sits in the quad that evaluated it
       if (wave_any(sr_from != 0xFFu)) {
-        uint32_t l, d;
-        if (WIDE) {
-          const int src = (int)((sr_from & 15u) << 2);
-          l = wave_bcast(e_len, src); d = wave_bcast(e_dist, src);
-        } else {
-          const int src = q_base() | (int)((sr_from & 3u) << 2);
-          l = wave_shfl(e_len, src); d = wave_shfl(e_dist, src);
-        }
+        const int src = q_base() | (int)((sr_from & 3u) << 2);
+        const uint32_t l = wave_shfl(e_len, src), d = wave_shfl(e_dist, src);
         if (sr_from != 0xFFu) { g.sr_len = l; g.sr_dist = d; }
       }
       bool committed = commit;
@@ -865,8 +671,8 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       const bool gen = want && consumed == 0;
       if (wave_any(gen)) {
         QResult cur;
-        cur.len = WIDE ? wave_bcast(e_len, 0) : q_bcast(e_len, 0);
-        cur.distance = WIDE ? wave_bcast(e_dist, 0) : q_bcast(e_dist, 0);
+        cur.len = q_bcast(e_len, 0);
+        cur.distance = q_bcast(e_dist, 0);
         cur.score = fl0 & 0x3FFFFFFFu;
         cur.delta = 0;
         bool take = gen && (fl0 & 0x80000000u) != 0;

@@ -20,9 +20,6 @@
 #ifndef IXB_WAVES
 #define IXB_WAVES 4
 #endif
-#ifndef CHAINW_WAVES
-#define CHAINW_WAVES 8
-#endif
 #ifndef BUILD_WAVES
 #define BUILD_WAVES 4
 #endif
@@ -118,19 +115,18 @@ __global__ void __launch_bounds__(64, IXB_WAVES) k_ix_bucket(JobArgs a) {
   if (shard >= a.nshards) return;
   for (uint32_t b = b0; b < b0 + a.J.ix_bpw; ++b) ix_bucket(a.J, a.shards[shard], a.input, a.ws, b, lds_b);
 }
-// dynamic LDS: shards per wave * C_GROUP_LDS_WORDS * 4 bytes
-template <bool WIDE>
-__global__ void __launch_bounds__(64, WIDE ? CHAINW_WAVES : CHAIN_WAVES) k_chain(JobArgs a) {
+// grid = ceil(nshards / shards per wave), block = 64; dynamic LDS: shards per wave * C_GROUP_LDS_WORDS * 4 bytes
+__global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain(JobArgs a) {
 #if defined(BROTLI_AMD_SIMT_SIM)
   __shared__ uint32_t lds_c[C_LDS_WORDS];
 #else
   extern __shared__ uint32_t lds_c[];
 #endif
-  chain_round<WIDE>(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c);
-  const uint32_t gpw = WIDE ? 1u : q_groups_per_wave(a.J);
-  const uint32_t gi = WIDE ? 0u : threadIdx.x >> 4;
+  chain_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c);
+  const uint32_t gpw = q_groups_per_wave(a.J);
+  const uint32_t gi = threadIdx.x >> 4;
   const uint32_t shard = blockIdx.x * gpw + gi;
-  if ((threadIdx.x & (WIDE ? 63 : 15)) == 0 && gi < gpw && shard < a.nshards && a.states[shard].error)
+  if ((threadIdx.x & 15) == 0 && gi < gpw && shard < a.nshards && a.states[shard].error)
     glb_atomic_add(&a.counters[1], 1u);
 }
 

@@ -33,13 +33,13 @@ class JobInfo(C.Structure):
                 ("ms_init", C.c_float), ("ms_parse", C.c_float),
                 ("ms_build", C.c_float), ("ms_store", C.c_float),
                 ("ms_gather", C.c_float), ("ms_index", C.c_float),
-                ("reserved2", C.c_float), ("searches", C.c_uint64),
+                ("ms_ix_bucket", C.c_float), ("searches", C.c_uint64),
                 ("search_steps", C.c_uint64), ("commands", C.c_uint64),
                 ("exact_searches", C.c_uint64),
                 ("prof", C.c_uint64 * 12)]
 
     def as_dict(self):
-        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "reserved2", "prof")}
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "prof")}
         d["prof"] = list(self.prof)
         return d
 

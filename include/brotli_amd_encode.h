@@ -76,6 +76,11 @@ BROTLI_BOOL BrotliEncoderHasMoreOutput(BrotliEncoderState* state);
 const uint8_t* BrotliEncoderTakeOutput(BrotliEncoderState* state, size_t* size);
 /* encode.h:542  BrotliEncoderVersion */
 uint32_t BrotliEncoderVersion(void);
+/* encode.h:531  BrotliEncoderEstimatePeakMemoryUsage (host memory of one instance; the encoder
+   state itself is device memory) */
+size_t BrotliEncoderEstimatePeakMemoryUsage(int quality, int lgwin, size_t input_size);
+/* encode.h:534  BrotliEncoderGetPreparedDictionarySize: always 0 ("not valid") */
+size_t BrotliEncoderGetPreparedDictionarySize(const BrotliEncoderPreparedDictionary* dictionary);
 /* encode.h:342 / 348 / 361: prepared dictionaries are outside the GPU path; the
    symbols exist, PrepareDictionary returns NULL and Attach returns BROTLI_FALSE. */
 BrotliEncoderPreparedDictionary* BrotliEncoderPrepareDictionary(

@@ -74,7 +74,7 @@ typedef struct BrotliAmdJobInfo {
   float ms_total;           /* HIP-event time of the whole job on the stream */
   float ms_init, ms_parse, ms_build, ms_store, ms_gather;
   float ms_index;           /* indexed quality-5 job: the index kernels (k_index.h); ms_parse is the chain */
-  float reserved2;
+  float ms_ix_bucket;       /* of ms_index: k_ix_bucket alone (sort inside the buckets + window search of every position) */
   uint64_t searches;        /* FindLongestMatch calls (reference count) */
   uint64_t search_steps;    /* paired search steps actually executed */
   uint64_t commands;
@@ -117,8 +117,11 @@ typedef struct BrotliAmdStream BrotliAmdStream;
 #define BROTLI_AMD_OP_FINISH 2
 #define BROTLI_AMD_OP_FLUSH_OPEN 3   /* flush the pending input as a meta-block, keep the partial last
                                         byte pending (what EMIT_METADATA needs, encode.c:1569-1573) */
+/* `flags`: BROTLI_AMD_FLAG_NO_HEADER when the stream header has left the encoder already (an empty
+   FLUSH or a metadata block came before the first data, encode.c:1356-1415): the stream then starts
+   byte aligned without the window bits. */
 int brotli_amd_stream_create(BrotliAmdCtx* ctx, int quality, int lgwin, uint32_t size_hint,
-                             uint32_t stream_offset, BrotliAmdStream** stream);
+                             uint32_t stream_offset, uint32_t flags, BrotliAmdStream** stream);
 /* Appends `len` host bytes and applies `op`.  `*out` / `*out_len` receive the
    bytes produced by this call; the pointer stays valid until the next call on
    the stream. */

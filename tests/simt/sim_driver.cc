@@ -35,8 +35,7 @@ void run_parse_kernel(const JobArgs& a, int reverse) {
     else if (a.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
     else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
   } else if (a.J.flags & JOB_FLAG_INDEXED) {
-    if (a.J.flags & JOB_FLAG_WIDE) run(k_chain<true>, a, a.nshards, 64, reverse);
-    else run(k_chain<false>, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
+    run(k_chain, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
     run(k_cmd_encode, a, a.nshards * CE_SPLIT, 64, reverse);
   } else if (a.J.flags & JOB_FLAG_QUAD) {
     run(k_parse4, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);

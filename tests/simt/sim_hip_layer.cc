@@ -137,13 +137,14 @@ int brotli_amd_encode_fast_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len
 
 // ---- the incremental stream (hip_layer.hip stream_init / stream_run on the simulator) ----
 int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t size_hint, uint32_t stream_offset,
-                             BrotliAmdStream** out) {
+                             uint32_t flags, BrotliAmdStream** out) {
   *out = nullptr;
   BrotliAmdStream* s = new BrotliAmdStream();
   s->c = c;
   if (!plan_params(quality, lgwin, size_hint, &s->J)) { delete s; return set_err(c, "parameters outside the GPU path", BROTLI_AMD_UNSUPPORTED); }
   JobParams& J = s->J;
   if (quality != 5) J.flags |= JOB_FLAG_DEEP;
+  if (flags & BROTLI_AMD_FLAG_NO_HEADER) J.flags |= JOB_FLAG_NO_HEADER;
   const uint64_t mb = J.max_metablock_size;
   J.log2_lut_size = (uint32_t)(mb + 2);
   ShardDesc& D = s->D;

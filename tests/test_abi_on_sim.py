@@ -73,6 +73,19 @@ def test_single_stream_sequences_and_metadata(simabi, stock, quality, lgwin):
     assert outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("first_op", [1, 3])
+def test_empty_first_operation_leaves_the_size_hint_open(simabi, stock, first_op):
+    """An empty FLUSH / EMIT_METADATA before the first data byte must not pin the size hint to 0
+    (UpdateSizeHint, encode.c:1619-1632): with >= 1 MiB of data behind it the reference still
+    picks the large hasher (H68) at quality 5."""
+    data = G.enwik_text((1 << 20) + 50000, seed=62, vocab=20000)
+    params = ((1, 5), (2, 22))
+    for ops in ([(0, first_op), (len(data), 2)], [(0, first_op), (0, 1), (70000, 0), (len(data) - 70000, 2)]):
+        want, fin_w = drive(stock, data, ops, params)
+        got, fin_g = drive(simabi, data, ops, params)
+        assert fin_w and fin_g and got == want, ops
+
+
 def test_stream_offset_and_plan_parameters(simabi, stock, oracle):
     data = ALICE[:100000]
     ops = [(len(data), 1)]

@@ -139,12 +139,11 @@ def test_quad_kernel_scout_groups_forced_slow_resolve(sim, oracle):
     assert sim.encode(data, shard_size=50000, flags=2 | 4 | 32 | (2 << 8)) == oracle.encode_plan(data, 5, 22, 50000)
 
 
-# ---- indexed quality-5 parse (k_index.h + k_chain.h): JOB_FLAG_INDEXED = 64, JOB_FLAG_WIDE = 128 ----
+# ---- indexed quality-5 parse (k_index.h + k_chain.h): JOB_FLAG_INDEXED = 64 ----
 IX_LAYOUTS = {
     "groups4": 2 | 64,                      # four shards per wave, 16 lanes each (the product default for many shards)
     "groups2": 2 | 64 | (2 << 8),
     "groups1": 2 | 64 | (1 << 8),
-    "wide": 2 | 64 | 128 | (1 << 8),        # one shard per wave, wave-uniform state
 }
 
 
@@ -159,7 +158,7 @@ def test_indexed_parse_bytes_match_oracle(sim, oracle, name, layout):
         assert sim.encode(data, 5, 22, hint, shard, reverse=reverse, flags=IX_LAYOUTS[layout]) == want
 
 
-@pytest.mark.parametrize("layout", ["groups4", "groups1", "wide"])
+@pytest.mark.parametrize("layout", ["groups4", "groups2", "groups1"])
 @pytest.mark.parametrize("name", ["alice_48k", "text_hint_2shards", "mixed", "rle", "runs", "shards_of_1_2_3"])
 def test_indexed_parse_forced_exact_search(sim, oracle, name, layout):
     """JOB_FLAG_FORCE_SLOW: every search goes through c_search_exact (the sorted array + the
@@ -172,7 +171,7 @@ def test_indexed_parse_english_text_dictionary_gate_open(sim, oracle):
     """alice29.txt keeps the static-dictionary gate open (hash.h:179-202): misses and empty
     lazy probes must leave the group fast path."""
     want = oracle.encode_plan(ALICE, 5, 22, 40000)
-    for layout in ("groups4", "groups1", "wide"):
+    for layout in ("groups4", "groups2", "groups1"):
         assert sim.encode(ALICE, 5, 22, 0, 40000, flags=IX_LAYOUTS[layout]) == want, layout
 
 
@@ -180,7 +179,7 @@ def test_indexed_parse_long_shards_h68(sim, oracle):
     """Two 160 KiB shards with the 5-byte hasher: buckets fill up (16 slots), long copies."""
     data = G.enwik_text(320 << 10, seed=21, vocab=4000) 
     want = _oracle_plan(oracle, data, 1 << 30, 160 << 10)
-    for layout in ("groups4", "wide"):
+    for layout in ("groups4", "groups1"):
         assert sim.encode(data, 5, 22, 1 << 30, 160 << 10, flags=IX_LAYOUTS[layout]) == want, layout
 
 
