@@ -483,78 +483,60 @@ DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
   wave_sync();
 }
 
-// ---- BrotliOptimizeHuffmanCountsForRle (entropy_encode.c:241-370) ----------------
-// One lane per histogram; `good` is that lane's private flag array.
-DEV void optimize_counts_for_rle(uint32_t length, uint32_t* counts, uint8_t* good) {
-  uint32_t nonzero_count = 0, i;
-  const uint32_t streak_limit = 1240;
-  for (i = 0; i < length; i++) if (counts[i]) ++nonzero_count;
-  if (nonzero_count < 16) return;
-  while (length != 0 && counts[length - 1] == 0) --length;
-  if (length == 0) return;
-  {
-    uint32_t nonzeros = 0, smallest_nonzero = 1u << 30;
-    for (i = 0; i < length; ++i) {
-      if (counts[i] != 0) {
-        ++nonzeros;
-        if (smallest_nonzero > counts[i]) smallest_nonzero = counts[i];
-      }
-    }
-    if (nonzeros < 5) return;
-    if (smallest_nonzero < 4) {
-      const uint32_t zeros = length - nonzeros;
-      if (zeros < 6) {
-        for (i = 1; i < length - 1; ++i) {
-          if (counts[i - 1] != 0 && counts[i] == 0 && counts[i + 1] != 0) counts[i] = 1;
-        }
-      }
-    }
-    if (nonzeros < 28) return;
+// ---- histogram smoothing before the prefix codes are built ------------------------------
+// What BrotliOptimizeHuffmanCountsForRle (entropy_encode.c:241-370) does to a histogram, said in
+// terms of runs and segments (one lane per histogram; `sticky` is that lane's flag array):
+//   * nothing for fewer than 16 used symbols; the tail of unused symbols never takes part;
+//   * when some symbol is rarer than 4 and fewer than 6 symbols inside are unused, an unused
+//     symbol between two used ones counts as seen once;
+//   * nothing more for fewer than 28 used symbols;
+//   * long runs of one value (>= 5 zeros, >= 7 equal non-zeros) are "sticky": they already
+//     run-length code well and stay as they are, each of their elements a segment of its own;
+//   * the rest is cut, left to right, into segments whose members stay within 1240 / 256 of the
+//     segment's running mean (seeded by the mean of the first three values + 420 / 256, and
+//     given 120 / 256 of slack when the fourth member joins); a segment of four or more — or of
+//     three zeros — is flattened to its rounded mean (at least 1 unless all were 0).
+// The reference's mix of 32-bit products and 64-bit sums is kept: the sums wrap the same way.
+DEV void smooth_histogram_for_rle(uint32_t length, uint32_t* counts, uint8_t* sticky) {
+  uint32_t used = 0, rarest = 1u << 30;
+  for (uint32_t i = 0; i < length; ++i) {
+    if (counts[i] != 0) { ++used; rarest = umin(rarest, counts[i]); }
   }
-  for (i = 0; i < length; ++i) good[i] = 0;
-  {
-    uint32_t symbol = counts[0], step = 0;
-    for (i = 0; i <= length; ++i) {
-      if (i == length || counts[i] != symbol) {
-        if ((symbol == 0 && step >= 5) || (symbol != 0 && step >= 7)) {
-          for (uint32_t k = 0; k < step; ++k) good[i - k - 1] = 1;
-        }
-        step = 1;
-        if (i != length) symbol = counts[i];
-      } else {
-        ++step;
-      }
+  if (used < 16u) return;
+  while (counts[length - 1u] == 0) --length;                 // (used != 0: this stops)
+  if (rarest < 4u && length - used < 6u) {
+    // (a filled slot never makes its neighbour fillable: that one would have to be unused too)
+    for (uint32_t i = 1; i + 1u < length; ++i) {
+      if (counts[i] == 0 && counts[i - 1u] != 0 && counts[i + 1u] != 0) counts[i] = 1;
     }
   }
-  // The reference mixes uint32_t products with size_t (64-bit, wrapping)
-  // accumulators; the same widths are kept here.
-  uint64_t stride = 0, sum = 0;
-  uint64_t limit = (uint64_t)(256u * (counts[0] + counts[1] + counts[2]) / 3u + 420u);
-  for (i = 0; i <= length; ++i) {
-    if (i == length || good[i] || (i != 0 && good[i - 1]) ||
-        ((uint64_t)(256u * counts[i]) - limit + streak_limit) >= 2ull * streak_limit) {
-      if (stride >= 4 || (stride >= 3 && sum == 0)) {
-        uint64_t count = (sum + stride / 2) / stride;
-        if (count == 0) count = 1;
-        if (sum == 0) count = 0;
-        for (uint64_t k = 0; k < stride; ++k) counts[i - k - 1] = (uint32_t)count;
-      }
-      stride = 0;
-      sum = 0;
-      if (i + 2 < length) {
-        limit = (uint64_t)(256u * (counts[i] + counts[i + 1] + counts[i + 2]) / 3u + 420u);
-      } else if (i < length) {
-        limit = (uint64_t)(256u * counts[i]);
-      } else {
-        limit = 0;
-      }
+  if (used < 28u) return;
+  for (uint32_t a = 0; a < length;) {
+    uint32_t b = a + 1u;
+    while (b < length && counts[b] == counts[a]) ++b;
+    const uint8_t keep = (b - a >= (counts[a] == 0 ? 5u : 7u)) ? 1 : 0;
+    for (uint32_t i = a; i < b; ++i) sticky[i] = keep;
+    a = b;
+  }
+  for (uint32_t start = 0; start < length;) {
+    uint64_t members = 0, sum = 0, mean256;
+    if (start + 2u < length) mean256 = (uint64_t)(256u * (counts[start] + counts[start + 1u] + counts[start + 2u]) / 3u + 420u);
+    else mean256 = (uint64_t)(256u * counts[start]);
+    uint32_t end = start;
+    do {
+      ++members;
+      sum += counts[end];
+      if (members >= 4u) mean256 = (256u * sum + members / 2u) / members + (members == 4u ? 120u : 0u);
+      ++end;
+    } while (end < length && !sticky[end] && !sticky[end - 1u] &&
+             (uint64_t)(256u * counts[end]) - mean256 + 1240u < 2480u);
+    if (members >= 4u || (members == 3u && sum == 0)) {
+      uint64_t flat = (sum + members / 2u) / members;
+      if (flat == 0) flat = 1;
+      if (sum == 0) flat = 0;
+      for (uint32_t i = start; i < end; ++i) counts[i] = (uint32_t)flat;
     }
-    ++stride;
-    if (i != length) {
-      sum += counts[i];
-      if (stride >= 4) limit = (256 * sum + stride / 2) / stride;
-      if (stride == 4) limit += 120;
-    }
+    start = end;
   }
 }
 
@@ -629,7 +611,7 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
         const uint32_t nb = umin(per, nh[c] - h0);
         for (uint32_t k = (uint32_t)lane; k < nb * A; k += 64) b.lds[k] = G[(size_t)h0 * A + k];
         wave_sync();
-        if ((uint32_t)lane < nb) optimize_counts_for_rle(A, b.lds + (uint32_t)lane * A, flags + (uint32_t)lane * A);
+        if ((uint32_t)lane < nb) smooth_histogram_for_rle(A, b.lds + (uint32_t)lane * A, flags + (uint32_t)lane * A);
         wave_sync();
         for (uint32_t k = (uint32_t)lane; k < nb * A; k += 64) G[(size_t)h0 * A + k] = b.lds[k];
         wave_sync();

@@ -372,170 +372,6 @@ DEV void fast_parse_fragment(const FastArgs& a, uint32_t f, uint32_t* table, uin
   }
 }
 
-// ---- the fast prefix-code writer (brotli_bit_stream.c:399-573), one lane -----------------
-DEV void sort_nodes_by_count(HNode* items, uint32_t n) {
-  // SortHuffmanTreeItems (entropy_encode.h:82-115) with the count-only comparator
-  // (:399-402): not a total order, so the gap sequence is part of the result.
-  if (n < 13) {
-    for (uint32_t i = 1; i < n; ++i) {
-      const HNode tmp = items[i];
-      uint32_t k = i, j = i - 1;
-      while (tmp.total_count < items[j].total_count) {
-        items[k] = items[j];
-        k = j;
-        if (!j--) break;
-      }
-      items[k] = tmp;
-    }
-  } else {
-    const uint32_t gaps[6] = {132, 57, 23, 10, 4, 1};
-    for (int g = n < 57 ? 2 : 0; g < 6; ++g) {
-      const uint32_t gap = gaps[g];
-      for (uint32_t i = gap; i < n; ++i) {
-        uint32_t j = i;
-        const HNode tmp = items[i];
-        for (; j >= gap && tmp.total_count < items[j - gap].total_count; j -= gap) items[j] = items[j - gap];
-        items[j] = tmp;
-      }
-    }
-  }
-}
-
-// Static code-length code of the fast writer (entropy_encode_static.h:20-22, 82-90):
-// symbols 0..12, 16, 17 have 4 bits, 13 and 14 have 5; canonical, bit-reversed.
-DEV void fast_cl_code(uint32_t sym, uint32_t* nbits, uint32_t* bits) {
-  uint32_t code, n;
-  if (sym <= 12) { code = sym; n = 4; }
-  else if (sym >= 16) { code = 13u + (sym - 16u); n = 4; }
-  else { code = 30u + (sym - 13u); n = 5; }
-  *nbits = n;
-  *bits = dev_bitrev32(code) >> (32u - n);
-}
-// `reps` zero code lengths as code-17 runs (kZeroRepsBits / kZeroRepsDepth,
-// generated by the rule of entropy_encode.c:203-239 instead of tabulated).
-DEV void fast_put_zero_reps(BitWriter& w, uint32_t reps) {
-  uint32_t n4, b4;
-  if (reps == 11) { fast_cl_code(0, &n4, &b4); bw_put(w, n4, b4); --reps; }
-  if (reps < 3) {
-    fast_cl_code(0, &n4, &b4);
-    for (uint32_t i = 0; i < reps; ++i) bw_put(w, n4, b4);
-    return;
-  }
-  uint32_t ex[8];
-  uint32_t n = 0;
-  reps -= 3;
-  for (;;) {
-    ex[n++] = reps & 7u;
-    reps >>= 3;
-    if (reps == 0) break;
-    --reps;
-  }
-  fast_cl_code(17, &n4, &b4);
-  while (n) { --n; bw_put(w, n4 + 3u, b4 | (ex[n] << n4)); }
-}
-// `reps + 3` repeats of the previous non-zero length as code-16 runs (kNonZeroReps*).
-DEV void fast_put_nonzero_reps(BitWriter& w, uint32_t reps) {
-  uint32_t ex[8];
-  uint32_t n = 0, n4, b4;
-  for (;;) {
-    ex[n++] = reps & 3u;
-    reps >>= 2;
-    if (reps == 0) break;
-    --reps;
-  }
-  fast_cl_code(16, &n4, &b4);
-  while (n) { --n; bw_put(w, n4 + 2u, b4 | (ex[n] << n4)); }
-}
-
-DEV void fast_build_and_store_tree(HNode* tree, const uint32_t* histogram, uint32_t histogram_total,
-                                   uint32_t max_bits, uint8_t* depth, uint16_t* bits, BitWriter& w) {
-  uint32_t count = 0, symbols[4] = {0, 0, 0, 0}, length = 0, total = histogram_total;
-  while (total != 0) {
-    if (histogram[length]) {
-      if (count < 4) symbols[count] = length;
-      ++count;
-      total -= histogram[length];
-    }
-    ++length;
-  }
-  if (count <= 1) {
-    bw_put(w, 4, 1);
-    bw_put(w, max_bits, symbols[0]);
-    depth[symbols[0]] = 0;
-    bits[symbols[0]] = 0;
-    return;
-  }
-  for (uint32_t i = 0; i < length; ++i) depth[i] = 0;
-  HNode sentinel;
-  sentinel.total_count = 0xFFFFFFFFu;
-  sentinel.left = -1;
-  sentinel.right_or_value = -1;
-  for (uint32_t count_limit = 1;; count_limit *= 2) {
-    uint32_t n = 0;
-    for (uint32_t l = length; l != 0;) {
-      --l;
-      if (histogram[l]) {
-        HNode t;
-        t.total_count = histogram[l] >= count_limit ? histogram[l] : count_limit;
-        t.left = -1;
-        t.right_or_value = (int16_t)l;
-        tree[n++] = t;
-      }
-    }
-    sort_nodes_by_count(tree, n);
-    tree[n] = sentinel;
-    tree[n + 1] = sentinel;
-    uint32_t i = 0, j = n + 1;
-    for (uint32_t k = n - 1; k > 0; --k) {
-      uint32_t left, right;
-      if (tree[i].total_count <= tree[j].total_count) { left = i; ++i; } else { left = j; ++j; }
-      if (tree[i].total_count <= tree[j].total_count) { right = i; ++i; } else { right = j; ++j; }
-      const uint32_t end = 2 * n - k;
-      HNode t;
-      t.total_count = tree[left].total_count + tree[right].total_count;
-      t.left = (int16_t)left;
-      t.right_or_value = (int16_t)right;
-      tree[end] = t;
-      tree[end + 1] = sentinel;
-    }
-    if (set_depth((int)(2 * n - 1), tree, depth, 14)) break;
-  }
-  convert_bit_depths_to_symbols(depth, length, bits);
-  if (count <= 4) {
-    bw_put(w, 2, 1);
-    bw_put(w, 2, count - 1);
-    for (uint32_t i = 0; i < count; i++) {
-      for (uint32_t j = i + 1; j < count; j++) {
-        if (depth[symbols[j]] < depth[symbols[i]]) { const uint32_t t = symbols[j]; symbols[j] = symbols[i]; symbols[i] = t; }
-      }
-    }
-    for (uint32_t i = 0; i < count; ++i) bw_put(w, max_bits, symbols[i]);
-    if (count == 4) bw_put(w, 1, depth[symbols[0]] == 1 ? 1 : 0);
-  } else {
-    uint32_t previous_value = 8;
-    bw_put(w, 40, (0xFFull << 32) | 0x55555554ull);   // StoreStaticCodeLengthCode
-    for (uint32_t i = 0; i < length;) {
-      const uint32_t value = depth[i];
-      uint32_t reps = 1;
-      for (uint32_t k = i + 1; k < length && depth[k] == value; ++k) ++reps;
-      i += reps;
-      if (value == 0) {
-        fast_put_zero_reps(w, reps);
-      } else {
-        uint32_t n4, b4;
-        fast_cl_code(value, &n4, &b4);
-        if (previous_value != value) { bw_put(w, n4, b4); --reps; }
-        if (reps < 3) {
-          while (reps != 0) { reps--; bw_put(w, n4, b4); }
-        } else {
-          fast_put_nonzero_reps(w, reps - 3);
-        }
-        previous_value = value;
-      }
-    }
-  }
-}
-
 // Order in which BuildAndStoreCommandPrefixCode (:56-104) lines the 64 command codes
 // of the working alphabet up for canonical code assignment.
 static __device__ const uint8_t k_fast_order[64] = {
@@ -543,22 +379,22 @@ static __device__ const uint8_t k_fast_order[64] = {
     0, 1, 2, 3, 4, 5, 6, 7, 48, 49, 50, 51, 52, 53, 54, 55, 8, 9, 10, 11, 12, 13, 14, 15,
     56, 57, 58, 59, 60, 61, 62, 63, 16, 17, 18, 19, 20, 21, 22, 23};
 
-// LDS of one k_fast_store wave (dwords)
+// LDS of one k_fast_store wave (dwords).  The prefix-code builder's work area (k_prefix.h) and
+// the output window of the command stream are never in use at the same time.
 #define FAST_WIN_DW 1024u
 #define FS_HIST 0u                       // u32[256] literal histogram
 #define FS_CHIST 256u                    // u32[128] command histogram
-#define FS_TREE 384u                     // HNode[2 * 256 + 2]
-#define FS_HT (FS_TREE + 2u * 514u)      // u8[704] + u8[704] serialised code lengths
-#define FS_TMPD (FS_HT + 352u)           // u8[704]
-#define FS_LDEPTH (FS_TMPD + 176u)       // u8[256]
+#define FS_LDEPTH 384u                   // u8[256]
 #define FS_LBITS (FS_LDEPTH + 64u)       // u16[256]
 #define FS_CDEPTH (FS_LBITS + 128u)      // u8[128]
 #define FS_CBITS (FS_CDEPTH + 32u)       // u16[128]
-#define FS_START (FS_CBITS + 64u)        // u32[65]
+#define FS_TMP8 (FS_CBITS + 64u)         // u8[64] + u16[64]: codes of the permuted command alphabet
+#define FS_START (FS_TMP8 + 48u)         // u32[65]
 #define FS_BASE (FS_START + 65u)         // u32[64]
 #define FS_FLAG (FS_BASE + 64u)          // u32[3]
-#define FS_WIN (FS_FLAG + 3u)            // u32[FAST_WIN_DW + 4]
-#define FAST_STORE_LDS_WORDS (FS_WIN + FAST_WIN_DW + 4u)
+#define FS_WIN (FS_FLAG + 3u)            // u32[FAST_WIN_DW + 4] | the prefix-code work area
+#define FS_PFX FS_WIN
+#define FAST_STORE_LDS_WORDS (FS_WIN + (PFX_LDS_WORDS > FAST_WIN_DW + 4u ? PFX_LDS_WORDS : FAST_WIN_DW + 4u))
 
 // One block after the parse: ShouldCompress (:524-544), then StoreCommands (:461-522)
 // into the block's scratch as a bit string that starts at bit 0.
@@ -576,9 +412,7 @@ DEV void fast_store_block(const FastArgs& a, uint32_t bidx, uint32_t* lds) {
 
   uint32_t* hist = lds + FS_HIST;
   uint32_t* chist = lds + FS_CHIST;
-  HNode* tree = (HNode*)(lds + FS_TREE);
-  uint8_t* ht = (uint8_t*)(lds + FS_HT);
-  uint8_t* tmp_depth = (uint8_t*)(lds + FS_TMPD);
+  uint32_t* P = lds + FS_PFX;
   uint8_t* ldepth = (uint8_t*)(lds + FS_LDEPTH);
   uint16_t* lbits = (uint16_t*)(lds + FS_LBITS);
   uint8_t* cdepth = (uint8_t*)(lds + FS_CDEPTH);
@@ -615,59 +449,68 @@ DEV void fast_store_block(const FastArgs& a, uint32_t bidx, uint32_t* lds) {
   // ---- histograms
   for (uint32_t k = (uint32_t)lane; k < nlits; k += 64) lds_atomic_add(&hist[lits[k]], 1u);
   for (uint32_t k = (uint32_t)lane; k < ncmds; k += 64) lds_atomic_add(&chist[cmds[k] & 0xFFu], 1u);
-  // tmp_depth, ldepth, lbits, cdepth, cbits are contiguous
-  for (uint32_t j = (uint32_t)lane; j < FS_START - FS_TMPD; j += 64) (lds + FS_TMPD)[j] = 0;
+  // ldepth, lbits, cdepth, cbits are contiguous
+  for (uint32_t j = (uint32_t)lane; j < FS_START - FS_LDEPTH; j += 64) (lds + FS_LDEPTH)[j] = 0;
   wave_sync();
-  // ---- header and the three prefix codes, lane 0
-  uint64_t bit_cmds = 0;
-  if (lane == 0) {
-    BitWriter w;
-    bw_init(w, scr, 0, 0);
-    {
-      // BrotliStoreMetaBlockHeader (:216-232) + "no block splits, no contexts" (:586-588)
-      const uint32_t nibbles = len <= (1u << 16) ? 4u : (len <= (1u << 20) ? 5u : 6u);
-      bw_put(w, 1, 0);
-      bw_put(w, 2, nibbles - 4);
-      bw_put(w, nibbles * 4, len - 1);
-      bw_put(w, 1, 0);
-      bw_put(w, 13, 0);
-    }
-    fast_build_and_store_tree(tree, hist, nlits, 8, ldepth, lbits, w);
-    chist[1] += 1;
-    chist[2] += 1;
-    chist[64] += 1;
-    chist[84] += 1;
-    // BuildAndStoreCommandPrefixCode (:56-104)
-    create_huffman_tree(chist, 64, 15, tree, cdepth);
-    create_huffman_tree(chist + 64, 64, 14, tree, cdepth + 64);
-    {
-      uint8_t d64[64];
-      uint16_t b64[64];
-      for (int i = 0; i < 64; ++i) { d64[i] = cdepth[k_fast_order[i]]; b64[i] = 0; }
-      convert_bit_depths_to_symbols(d64, 64, b64);
-      for (int i = 0; i < 64; ++i) cbits_[k_fast_order[i]] = b64[i];
-      convert_bit_depths_to_symbols(cdepth + 64, 64, cbits_ + 64);
-    }
-    for (int i = 0; i < 8; ++i) {
-      tmp_depth[i] = cdepth[24 + i];
-      tmp_depth[64 + i] = cdepth[32 + i];
-      tmp_depth[128 + i] = cdepth[40 + i];
-      tmp_depth[192 + i] = cdepth[48 + i];
-      tmp_depth[384 + i] = cdepth[56 + i];
-    }
-    for (int i = 0; i < 8; ++i) {
-      tmp_depth[128 + 8 * i] = cdepth[i];
-      tmp_depth[256 + 8 * i] = cdepth[8 + i];
-      tmp_depth[448 + 8 * i] = cdepth[16 + i];
-    }
-    store_huffman_tree(tmp_depth, 704, tree, ht, ht + 704, w);
-    store_huffman_tree(cdepth + 64, 64, tree, ht, ht + 704, w);
-    bit_cmds = bw_bitpos(w);
-    bw_flush_bytes(w);
-    if (w.nacc) w.out[w.byte_pos] = (uint8_t)w.acc;
+  // ---- header and the three prefix codes, the whole wave on each (k_prefix.h) ----
+  uint32_t* bitbuf = P + PFX_BITBUF;       // (<= 256 used symbols per code here: the sort keys stay below it)
+  uint32_t hbits = 0;
+  for (uint32_t j = (uint32_t)lane; j < 128u; j += 64) bitbuf[j] = 0;
+  wave_sync();
+  {
+    // BrotliStoreMetaBlockHeader (:216-232) + "no block splits, no contexts" (:586-588):
+    // ISLAST 0, MNIBBLES, MLEN - 1, ISUNCOMPRESSED 0, thirteen zero bits
+    const uint32_t nibbles = len <= (1u << 16) ? 4u : (len <= (1u << 20) ? 5u : 6u);
+    uint32_t nb = 0, val = 0;
+    if (lane == 0) { nb = 3; val = (nibbles - 4u) << 1; }
+    else if (lane == 1) { nb = nibbles * 4u; val = len - 1u; }
+    else if (lane == 2) { nb = 14; val = 0; }
+    pfx_put_lanes(bitbuf, hbits, nb, val);
   }
+  pfx_build_and_append<true>(hist, 256u, 8u, P, ldepth, lbits, bitbuf, hbits, false);
+  if (lane == 0) { chist[1] += 1; chist[2] += 1; chist[64] += 1; chist[84] += 1; }
   wave_sync();
-  bit_cmds = wave_bcast64(bit_cmds, 0);
+  {
+    // BuildAndStoreCommandPrefixCode (:56-104): lengths of the two halves of the working
+    // alphabet, codes assigned with the first half lined up in k_fast_order
+    uint8_t* len8 = (uint8_t*)(P + PFX_LEN);
+    uint8_t* t8 = (uint8_t*)(lds + FS_TMP8);
+    uint16_t* t16 = (uint16_t*)(lds + FS_TMP8 + 16u);
+    pfx_code_lengths<false>(chist, 64u, 15u, P);
+    if (lane < 64) cdepth[lane] = len8[lane];
+    wave_sync();
+    pfx_code_lengths<false>(chist + 64, 64u, 14u, P);
+    if (lane < 64) cdepth[64 + lane] = len8[lane];
+    wave_sync();
+    pfx_assign_codes(64u, P, cdepth + 64, cbits_ + 64);          // (len8 still holds the second half)
+    if (lane < 64) len8[lane] = cdepth[k_fast_order[lane]];
+    wave_sync();
+    pfx_assign_codes(64u, P, t8, t16);
+    if (lane < 64) cbits_[k_fast_order[lane]] = t16[lane];
+    wave_sync();
+    // the 704-symbol insert-and-copy alphabet the working alphabet stands for (:79-98)
+    for (uint32_t j = (uint32_t)lane; j < 704u / 4u; j += 64) ((uint32_t*)len8)[j] = 0;
+    wave_sync();
+    if (lane < 40) {
+      const uint32_t i = (uint32_t)lane & 7u, blk = (uint32_t)lane >> 3;      // cdepth[24 + 8 * blk + i]
+      const uint32_t at = blk == 4u ? 384u : 64u * blk;
+      len8[at + i] = cdepth[24 + lane];
+    }
+    wave_sync();                                   // (slot 128 is written again below, and that write stands)
+    if (lane >= 40 && lane < 64) {
+      const uint32_t i = ((uint32_t)lane - 40u) & 7u, blk = ((uint32_t)lane - 40u) >> 3;   // cdepth[8 * blk + i]
+      const uint32_t at = blk == 0u ? 128u : blk == 1u ? 256u : 448u;
+      len8[at + 8u * i] = cdepth[8u * blk + i];
+    }
+    wave_sync();
+    pfx_store_complex<false>(704u, P, bitbuf, hbits);
+    if (lane < 64) len8[lane] = cdepth[64 + lane];
+    wave_sync();
+    pfx_store_complex<false>(64u, P, bitbuf, hbits);
+  }
+  const uint64_t bit_cmds = hbits;
+  for (uint32_t j = (uint32_t)lane; j < (hbits + 31u) / 32u; j += 64) st32(scr + 4u * j, bitbuf[j]);
+  wave_sync();
 
   // ---- (a) running sum of literal bits: lsum[k] = bits of literals [0, k)
   {

@@ -13,9 +13,10 @@
 //
 // Design: the reference writes one bit field after another.  Here
 //  * every prefix code of the meta-block (literal / command / distance
-//    histograms, block-type and block-length codes, context-map codes) is an
-//    independent job: one lane builds the tree, assigns the canonical codes
-//    and serialises the code into a private 512-byte buffer;
+//    histograms, block-type and block-length codes, context-map codes) is a
+//    job the whole wave works through (k_prefix.h: LDS sort of the leaves,
+//    two-queue merge, depths by pointer jumping, canonical codes and the
+//    run-length coded description by ballots and scans) into a 512-byte buffer;
 //  * the header is then assembled in order, splicing those buffers with
 //    wave-wide shifted copies;
 //  * the command stream is emitted 64 commands at a time: each lane sizes its
@@ -29,6 +30,7 @@
 
 #include "k_build.h"
 #include "k_round.h"
+#include "k_prefix.h"
 
 // Optional phase timing (-DS_PROFILE): cycles per phase into ShardState::prof[].
 #if defined(S_PROFILE) && !defined(BROTLI_AMD_SIMT_SIM)
@@ -97,312 +99,9 @@ DEV void sink_varlen_uint8(BitSink& s, uint32_t n) {   // StoreVarLenUint8
 }
 
 #define STORE_WIN_DW 2048u   // LDS output window of the command stream (64 Kbit)
-
-// ---- prefix-code construction (one lane) ---------------------------------------
-struct HNode { uint32_t total_count; int16_t left; int16_t right_or_value; };
-
-DEV bool hnode_less(const HNode& a, const HNode& b) {
-  if (a.total_count != b.total_count) return a.total_count < b.total_count;
-  return a.right_or_value > b.right_or_value;
-}
-
-// BrotliSetDepth, entropy_encode.c:20-42.
-DEV bool set_depth(int p0, const HNode* pool, uint8_t* depth, int max_depth) {
-  int stack[16];
-  int level = 0;
-  int p = p0;
-  stack[0] = -1;
-  for (;;) {
-    if (pool[p].left >= 0) {
-      level++;
-      if (level > max_depth) return false;
-      stack[level] = pool[p].right_or_value;
-      p = pool[p].left;
-      continue;
-    } else {
-      depth[pool[p].right_or_value] = (uint8_t)level;
-    }
-    while (level >= 0 && stack[level] == -1) level--;
-    if (level < 0) return true;
-    p = stack[level];
-    stack[level] = -1;
-  }
-}
-
-// The comparator is a total order (count, then symbol), so any sort yields the
-// reference's sequence; a shell sort with the reference's gaps is used.
-DEV void sort_nodes(HNode* items, uint32_t n) {
-  if (n < 13) {
-    for (uint32_t i = 1; i < n; ++i) {
-      const HNode tmp = items[i];
-      uint32_t k = i, j = i - 1;
-      while (hnode_less(tmp, items[j])) {
-        items[k] = items[j];
-        k = j;
-        if (!j--) break;
-      }
-      items[k] = tmp;
-    }
-  } else {
-    const uint32_t gaps[6] = {132, 57, 23, 10, 4, 1};
-    for (int g = n < 57 ? 2 : 0; g < 6; ++g) {
-      const uint32_t gap = gaps[g];
-      for (uint32_t i = gap; i < n; ++i) {
-        uint32_t j = i;
-        const HNode tmp = items[i];
-        for (; j >= gap && hnode_less(tmp, items[j - gap]); j -= gap) items[j] = items[j - gap];
-        items[j] = tmp;
-      }
-    }
-  }
-}
-
-// BrotliCreateHuffmanTree, entropy_encode.c:68-147.
-DEV void create_huffman_tree(const uint32_t* data, uint32_t length, int tree_limit,
-                             HNode* tree, uint8_t* depth) {
-  HNode sentinel;
-  sentinel.total_count = 0xFFFFFFFFu;
-  sentinel.left = -1;
-  sentinel.right_or_value = -1;
-  for (uint32_t count_limit = 1;; count_limit *= 2) {
-    uint32_t n = 0;
-    for (uint32_t i = length; i != 0;) {
-      --i;
-      if (data[i]) {
-        HNode t;
-        t.total_count = data[i] > count_limit ? data[i] : count_limit;
-        t.left = -1;
-        t.right_or_value = (int16_t)i;
-        tree[n++] = t;
-      }
-    }
-    if (n == 1) {
-      depth[tree[0].right_or_value] = 1;
-      break;
-    }
-    sort_nodes(tree, n);
-    tree[n] = sentinel;
-    tree[n + 1] = sentinel;
-    uint32_t i = 0, j = n + 1;
-    for (uint32_t k = n - 1; k != 0; --k) {
-      uint32_t left, right;
-      if (tree[i].total_count <= tree[j].total_count) { left = i; ++i; } else { left = j; ++j; }
-      if (tree[i].total_count <= tree[j].total_count) { right = i; ++i; } else { right = j; ++j; }
-      const uint32_t j_end = 2 * n - k;
-      HNode t;
-      t.total_count = tree[left].total_count + tree[right].total_count;
-      t.left = (int16_t)left;
-      t.right_or_value = (int16_t)right;
-      tree[j_end] = t;
-      tree[j_end + 1] = sentinel;
-    }
-    if (set_depth((int)(2 * n - 1), tree, depth, tree_limit)) break;
-  }
-}
-
-DEV void reverse_u8(uint8_t* v, uint32_t start, uint32_t end) {
-  --end;
-  while (start < end) {
-    const uint8_t t = v[start];
-    v[start] = v[end];
-    v[end] = t;
-    ++start;
-    --end;
-  }
-}
-// entropy_encode.c:160-239
-DEV void write_tree_reps(uint8_t prev, uint8_t value, uint32_t reps, uint32_t* n,
-                         uint8_t* tree, uint8_t* extra) {
-  if (prev != value) { tree[*n] = value; extra[*n] = 0; ++*n; --reps; }
-  if (reps == 7) { tree[*n] = value; extra[*n] = 0; ++*n; --reps; }
-  if (reps < 3) {
-    for (uint32_t i = 0; i < reps; ++i) { tree[*n] = value; extra[*n] = 0; ++*n; }
-  } else {
-    const uint32_t start = *n;
-    reps -= 3;
-    for (;;) {
-      tree[*n] = 16; extra[*n] = (uint8_t)(reps & 3); ++*n;
-      reps >>= 2;
-      if (reps == 0) break;
-      --reps;
-    }
-    reverse_u8(tree, start, *n);
-    reverse_u8(extra, start, *n);
-  }
-}
-DEV void write_tree_reps_zeros(uint32_t reps, uint32_t* n, uint8_t* tree, uint8_t* extra) {
-  if (reps == 11) { tree[*n] = 0; extra[*n] = 0; ++*n; --reps; }
-  if (reps < 3) {
-    for (uint32_t i = 0; i < reps; ++i) { tree[*n] = 0; extra[*n] = 0; ++*n; }
-  } else {
-    const uint32_t start = *n;
-    reps -= 3;
-    for (;;) {
-      tree[*n] = 17; extra[*n] = (uint8_t)(reps & 7); ++*n;
-      reps >>= 3;
-      if (reps == 0) break;
-      --reps;
-    }
-    reverse_u8(tree, start, *n);
-    reverse_u8(extra, start, *n);
-  }
-}
-// BrotliWriteHuffmanTree, entropy_encode.c:372-452.
-DEV void write_huffman_tree(const uint8_t* depth, uint32_t length, uint32_t* tree_size,
-                            uint8_t* tree, uint8_t* extra) {
-  uint8_t previous_value = 8;
-  bool rle_nz = false, rle_z = false;
-  uint32_t new_length = length;
-  for (uint32_t i = 0; i < length; ++i) {
-    if (depth[length - i - 1] == 0) --new_length; else break;
-  }
-  if (length > 50) {
-    uint32_t total_z = 0, total_nz = 0, cnt_z = 1, cnt_nz = 1;
-    for (uint32_t i = 0; i < new_length;) {
-      const uint8_t value = depth[i];
-      uint32_t reps = 1;
-      for (uint32_t k = i + 1; k < new_length && depth[k] == value; ++k) ++reps;
-      if (reps >= 3 && value == 0) { total_z += reps; ++cnt_z; }
-      if (reps >= 4 && value != 0) { total_nz += reps; ++cnt_nz; }
-      i += reps;
-    }
-    rle_nz = total_nz > cnt_nz * 2;
-    rle_z = total_z > cnt_z * 2;
-  }
-  for (uint32_t i = 0; i < new_length;) {
-    const uint8_t value = depth[i];
-    uint32_t reps = 1;
-    if ((value != 0 && rle_nz) || (value == 0 && rle_z)) {
-      for (uint32_t k = i + 1; k < new_length && depth[k] == value; ++k) ++reps;
-    }
-    if (value == 0) {
-      write_tree_reps_zeros(reps, tree_size, tree, extra);
-    } else {
-      write_tree_reps(previous_value, value, reps, tree_size, tree, extra);
-      previous_value = value;
-    }
-    i += reps;
-  }
-}
-
-// BrotliConvertBitDepthsToSymbols, entropy_encode.c:454-497.
-DEV uint16_t reverse_bits16(uint32_t num_bits, uint32_t bits) {
-  uint32_t r = dev_bitrev32(bits) >> (32u - num_bits);
-  return (uint16_t)r;
-}
-DEV void convert_bit_depths_to_symbols(const uint8_t* depth, uint32_t len, uint16_t* bits) {
-  uint16_t bl_count[16];
-  uint16_t next_code[16];
-  for (int i = 0; i < 16; ++i) bl_count[i] = 0;
-  for (uint32_t i = 0; i < len; ++i) ++bl_count[depth[i]];
-  bl_count[0] = 0;
-  next_code[0] = 0;
-  int code = 0;
-  for (int i = 1; i < 16; ++i) {
-    code = (code + bl_count[i - 1]) << 1;
-    next_code[i] = (uint16_t)code;
-  }
-  for (uint32_t i = 0; i < len; ++i) {
-    if (depth[i]) bits[i] = reverse_bits16(depth[i], next_code[depth[i]]++);
-  }
-}
-
-// BrotliStoreHuffmanTree, brotli_bit_stream.c:163-345.
-DEV void store_huffman_tree(const uint8_t* depths, uint32_t num, HNode* tree,
-                            uint8_t* huffman_tree, uint8_t* extra_bits, BitWriter& w) {
-  const uint8_t kStorageOrder[18] = {1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15};
-  const uint8_t kSym[6] = {0, 7, 3, 2, 1, 15};
-  const uint8_t kLen[6] = {2, 4, 3, 2, 2, 4};
-  uint32_t huffman_tree_size = 0;
-  uint8_t cl_depth[18];
-  uint16_t cl_bits[18];
-  uint32_t histogram[18];
-  for (int i = 0; i < 18; ++i) { cl_depth[i] = 0; cl_bits[i] = 0; histogram[i] = 0; }
-  write_huffman_tree(depths, num, &huffman_tree_size, huffman_tree, extra_bits);
-  for (uint32_t i = 0; i < huffman_tree_size; ++i) ++histogram[huffman_tree[i]];
-  int num_codes = 0;
-  uint32_t code = 0;
-  for (uint32_t i = 0; i < 18; ++i) {
-    if (histogram[i]) {
-      if (num_codes == 0) { code = i; num_codes = 1; }
-      else if (num_codes == 1) { num_codes = 2; break; }
-    }
-  }
-  create_huffman_tree(histogram, 18, 5, tree, cl_depth);
-  convert_bit_depths_to_symbols(cl_depth, 18, cl_bits);
-  {
-    uint32_t skip_some = 0, codes_to_store = 18;
-    if (num_codes > 1) {
-      for (; codes_to_store > 0; --codes_to_store) {
-        if (cl_depth[kStorageOrder[codes_to_store - 1]] != 0) break;
-      }
-    }
-    if (cl_depth[kStorageOrder[0]] == 0 && cl_depth[kStorageOrder[1]] == 0) {
-      skip_some = 2;
-      if (cl_depth[kStorageOrder[2]] == 0) skip_some = 3;
-    }
-    bw_put(w, 2, skip_some);
-    for (uint32_t i = skip_some; i < codes_to_store; ++i) {
-      const uint32_t l = cl_depth[kStorageOrder[i]];
-      bw_put(w, kLen[l], kSym[l]);
-    }
-  }
-  if (num_codes == 1) cl_depth[code] = 0;
-  for (uint32_t i = 0; i < huffman_tree_size; ++i) {
-    const uint32_t v = huffman_tree[i];
-    bw_put(w, cl_depth[v], cl_bits[v]);
-    if (v == 16) bw_put(w, 2, extra_bits[i]);
-    else if (v == 17) bw_put(w, 3, extra_bits[i]);
-  }
-}
-
-// BuildAndStoreHuffmanTree, brotli_bit_stream.c:242-279, 349-397.  Returns the
-// number of bits written to `buf`.
-DEV uint32_t build_and_store_huffman_tree(const uint32_t* histogram, uint32_t histogram_length,
-                                          uint32_t alphabet_size, uint8_t* scratch,
-                                          uint8_t* depth, uint16_t* bits, uint8_t* buf) {
-  HNode* tree = (HNode*)scratch;
-  uint8_t* huffman_tree = scratch + 8u * (2u * 704u + 2u);
-  uint8_t* extra_bits = huffman_tree + 704u;
-  BitWriter w;
-  bw_init(w, buf, 0, 0);
-  uint32_t count = 0, s4[4] = {0, 0, 0, 0}, max_bits = 0;
-  for (uint32_t i = 0; i < histogram_length; i++) {
-    if (histogram[i]) {
-      if (count < 4) s4[count] = i; else if (count > 4) break;
-      count++;
-    }
-  }
-  for (uint32_t c = alphabet_size - 1; c; c >>= 1) ++max_bits;
-  if (count <= 1) {
-    bw_put(w, 4, 1);
-    bw_put(w, max_bits, s4[0]);
-    depth[s4[0]] = 0;
-    bits[s4[0]] = 0;
-  } else {
-    for (uint32_t i = 0; i < histogram_length; ++i) depth[i] = 0;
-    create_huffman_tree(histogram, histogram_length, 15, tree, depth);
-    convert_bit_depths_to_symbols(depth, histogram_length, bits);
-    if (count <= 4) {
-      bw_put(w, 2, 1);
-      bw_put(w, 2, count - 1);
-      for (uint32_t i = 0; i < count; i++) {
-        for (uint32_t j = i + 1; j < count; j++) {
-          if (depth[s4[j]] < depth[s4[i]]) { const uint32_t t = s4[j]; s4[j] = s4[i]; s4[i] = t; }
-        }
-      }
-      for (uint32_t i = 0; i < count; ++i) bw_put(w, max_bits, s4[i]);
-      if (count == 4) bw_put(w, 1, depth[s4[0]] == 1 ? 1 : 0);
-    } else {
-      store_huffman_tree(depth, histogram_length, tree, huffman_tree, extra_bits, w);
-    }
-  }
-  const uint32_t nbits = (uint32_t)bw_bitpos(w);
-  // flush the accumulator (whole bytes, then the partial byte)
-  bw_flush_bytes(w);
-  if (w.nacc) w.out[w.byte_pos] = (uint8_t)w.acc;
-  return nbits;
-}
+// LDS of the kernel: the window + 132 words of step bookkeeping — or, before the command stream
+// starts, the work area of the prefix-code builder (k_prefix.h)
+#define STORE_LDS_WORDS (PFX_LDS_WORDS > 132u + STORE_WIN_DW + 4u ? PFX_LDS_WORDS : 132u + STORE_WIN_DW + 4u)
 
 // ---- block-split bookkeeping ------------------------------------------------------
 // brotli_bit_stream.c:34-46 and the block-length prefix table of
@@ -648,15 +347,14 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     wave_sync();
 
     SP_ADD(S, 1, spt);
-    // ---- phase 1: every prefix code, one lane per job ----
+    // ---- phase 1: every prefix code, one after the other, the whole wave on each ----
     // job ids: 0-2 block types, 3-5 block lengths, 6 literal context map,
     // 7 distance context map, then literal / command / distance histograms.
     const uint32_t njobs = 8 + nhist[0] + nhist[1] + nhist[2];
     uint8_t* tree_bufs = s.mb + s.L.tree_bufs;
     uint32_t* job_nbits = (uint32_t*)(s.mb + s.L.jobs);
-    uint8_t* scratch = s.mb + s.L.lane_scratch + (size_t)lane * MB_LANE_SCRATCH_BYTES;
     const uint32_t lit_cmap_alpha = s.nc > 1 ? nhist[0] + cmap_max_prefix : nhist[0] + 5u;
-    for (uint32_t j = (uint32_t)lane; j < njobs; j += 64) {
+    for (uint32_t j = 0; j < njobs; ++j) {
       const uint32_t* histo = nullptr;
       uint8_t* depth = nullptr;
       uint16_t* bits = nullptr;
@@ -686,10 +384,10 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
       }
       uint32_t nb = 0;
       if (!skip) {
-        nb = build_and_store_huffman_tree(histo, length, length, scratch, depth, bits,
-                                          tree_bufs + (size_t)j * MB_TREE_BUF_BYTES);
+        nb = pfx_build_and_store(histo, length, length, lds_store, depth, bits,
+                                 tree_bufs + (size_t)j * MB_TREE_BUF_BYTES);
       }
-      job_nbits[j] = nb;
+      if (lane == 0) job_nbits[j] = nb;
     }
     wave_sync();
 

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(64, BUILD_WAVES) k_build(JobArgs a) {
 __global__ void __launch_bounds__(64, STORE_WAVES) k_store(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
-  __shared__ uint32_t lds_store[132 + STORE_WIN_DW + 4];
+  __shared__ uint32_t lds_store[STORE_LDS_WORDS];
   store_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds_store);
   if (threadIdx.x == 0) {
     if (a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
