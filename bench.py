@@ -293,6 +293,9 @@ def main():
     ap.add_argument("--quality", type=int, default=5)
     ap.add_argument("--lgwin", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["text", "silesia"], default="text",
+                    help="text: BASELINE configs[1] (enwik-style); silesia: configs[3] (Silesia-style mix, "
+                         "size-mb MiB per GPU: 8 GiB on 8 GPUs)")
     ap.add_argument("--data", choices=["text", "random"], default="text", help="quality 1 only")
     ap.add_argument("--feed-kb", type=int, default=0, help="quality 1 only: KiB per CompressStream call (0 = one call)")
     args = ap.parse_args()
@@ -324,7 +327,7 @@ def main():
     shard = args.shard_kb << 10
     total = n * world
     size_hint = min(total, 1 << 30)
-    data = G.enwik_text(n, seed=G.SEED + rank)
+    data = G.enwik_text(n, seed=G.SEED + rank) if args.workload == "text" else G.mixed_corpus(n, seed=G.SEED + rank)
     d_in = hip.to_device(data, local_rank)
     ctx = hip.Context(local_rank)
     params = hip.make_params(args.quality, args.lgwin, shard, size_hint, stream_base=rank * n,
@@ -338,15 +341,23 @@ def main():
         torch.cuda.synchronize(dev)
 
     gathered = None
+    stream = None
 
     def step():
-        nonlocal gathered
-        nbytes, info = ctx.encode_device(d_in, n, params, d_out)
+        nonlocal gathered, stream
+        got = {}
+
+        def encode_local():
+            got["nbytes"], got["info"] = ctx.encode_device(d_in, n, params, d_out)
+            return d_out, got["nbytes"]
         if dist is not None:
-            # C1: one all-gather of the sizes, one of the padded payloads.
-            from brotli_amd.dist import gather_stream
-            gathered, _, _ = gather_stream(d_out, nbytes, scratch=gathered)
-        return nbytes, info
+            # C1: one all-gather of the sizes, one of the padded payloads, padding stripped —
+            # all of it inside the timed region (brotli_amd/dist.py, shared with the gloo test)
+            from brotli_amd.dist import sharded_step
+            stream, _, gathered = sharded_step(encode_local, scratch=gathered)
+        else:
+            encode_local()
+        return got["nbytes"], got["info"]
 
     for _ in range(args.warmup):
         step()
@@ -359,10 +370,13 @@ def main():
         infos.append(info)
     barrier()
     dt = time.perf_counter() - t0
+    stream_check = None
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        from brotli_amd.dist import same_stream_on_all_ranks
+        stream_check = same_stream_on_all_ranks(stream)
         tot_out = torch.tensor([nbytes], dtype=torch.int64, device=dev)
         dist.all_reduce(tot_out)
         out_total = int(tot_out.item())
@@ -392,13 +406,18 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {
-                "workload": "%d MiB synthetic enwik-style text per GPU (tests/gen_inputs.enwik_text, "
+                "workload": "%d MiB synthetic %s per GPU (tests/gen_inputs.%s, "
                             "seed %d+rank), quality %d, lgwin %d, %d x MI355X" % (
-                                args.size_mb, G.SEED, args.quality, args.lgwin, world),
+                                args.size_mb, "enwik-style text" if args.workload == "text" else "Silesia-style mix",
+                                "enwik_text" if args.workload == "text" else "mixed_corpus",
+                                G.SEED, args.quality, args.lgwin, world),
                 "partition_plan": "%d shards of %d KiB per GPU (STREAM_OFFSET contract); "
                                   "bytes identical to the reference driven with the same plan" % (
                                       infos[-1]["nshards"], args.shard_kb),
                 "compressed_bytes": out_total, "ratio": round(total / out_total, 4),
+                "gathered_stream": None if stream_check is None else {
+                    "sha256": stream_check[1], "equal_on_all_ranks": stream_check[0],
+                    "bytes": int(stream.numel()), "concatenation_inside_timed_region": True},
                 "parse_ms_per_step": [round(i["ms_index"] + i["ms_parse"], 1) for i in infos],
                 "stage_ms": {k: round(avg(k), 3) for k in
                              ("ms_total", "ms_init", "ms_index", "ms_ix_bucket", "ms_parse", "ms_build", "ms_store", "ms_gather")},

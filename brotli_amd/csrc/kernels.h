@@ -24,7 +24,7 @@
 #define BUILD_WAVES 4
 #endif
 #ifndef STORE_WAVES
-#define STORE_WAVES 4
+#define STORE_WAVES 3
 #endif
 #include "k_build.h"
 #include "k_store.h"

@@ -42,3 +42,26 @@ def compact(buffer, sizes, pad):
     """Removes the padding: the final contiguous stream (uint8 tensor)."""
     parts = [buffer[r * pad:r * pad + int(n)] for r, n in enumerate(sizes.tolist())]
     return torch.cat(parts)
+
+
+def sharded_step(encode_local, group=None, scratch=None):
+    """One step of the N-rank job, the same code for bench.py (RCCL, device tensors) and the gloo
+    test (CPU tensors): encode this rank's piece, all-gather, strip the padding.  The pieces of
+    one stream compress to within a few per cent of each other, so the padded gather moves hardly
+    more than the stream itself; an exact-size gather would cost `world` broadcasts instead of one
+    collective.  encode_local() -> (uint8 tensor, nbytes).  Returns (stream, sizes, gather buffer)."""
+    local, nbytes = encode_local()
+    buf, sizes, pad = gather_stream(local, nbytes, group=group, scratch=scratch)
+    return compact(buf, sizes, pad), sizes, buf
+
+
+def same_stream_on_all_ranks(stream, group=None):
+    """sha256 of the concatenated stream, all-gathered: True iff every rank holds rank 0's bytes."""
+    import hashlib
+    world = dist.get_world_size(group)
+    digest = hashlib.sha256(stream.detach().cpu().numpy().tobytes()).digest()
+    mine = torch.frombuffer(bytearray(digest), dtype=torch.uint8).to(stream.device)
+    allh = torch.zeros(world * 32, dtype=torch.uint8, device=stream.device)
+    dist.all_gather_into_tensor(allh, mine, group=group)
+    allh = allh.cpu().view(world, 32)
+    return bool((allh == allh[0]).all().item()), digest.hex()

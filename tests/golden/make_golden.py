@@ -29,6 +29,32 @@ CASES = [
 ]
 
 
+# quality 1 (the two-pass fragment compressor): (input, lgwin, KiB per CompressStream call; 0 = one FINISH call)
+Q1_CASES = [
+    ({"kind": "file", "name": "alice29.txt"}, 22, 0),
+    ({"kind": "text", "size": 1 << 20, "seed": 11}, 22, 0),
+    ({"kind": "text", "size": (1 << 20) + 3, "seed": 3}, 18, 0),
+    ({"kind": "text", "size": 3 << 20, "seed": 7}, 22, 512),          # the CLI's feed pattern, with the empty FINISH
+    ({"kind": "mixed", "size": 2 << 20, "seed": 9}, 20, 0),
+    ({"kind": "random", "size": 1 << 18, "seed": 1}, 22, 64),
+    ({"kind": "repeat", "unit": "abcdefgh", "size": 333333}, 16, 0),
+]
+
+
+def q1_calls(n, feed_kb):
+    """[(nbytes, op)]: one FINISH call, or feed_kb KiB per PROCESS call and FINISH with the last
+    one — as an extra empty call when n is a multiple of the feed (c/tools/brotli.c:1419-1463)."""
+    if not feed_kb:
+        return [(n, 2)]
+    feed = feed_kb << 10
+    calls = [(min(feed, n - o), 0) for o in range(0, n, feed)]
+    if n % feed == 0:
+        calls.append((0, 2))
+    else:
+        calls[-1] = (calls[-1][0], 2)
+    return calls
+
+
 def main():
     ref = Ref()
     cases = []
@@ -40,8 +66,16 @@ def main():
                       "shard_size": shard, "size": len(out),
                       "sha256": hashlib.sha256(out).hexdigest()})
         print(cases[-1])
+    q1 = []
+    for spec, w, feed_kb in Q1_CASES:
+        data = G.make(spec)
+        out = ref.encode_calls(data, 1, w, q1_calls(len(data), feed_kb))
+        assert ref.decompress(out, len(data)) == data
+        q1.append({"input": spec, "quality": 1, "lgwin": w, "feed_kb": feed_kb, "size": len(out),
+                   "sha256": hashlib.sha256(out).hexdigest()})
+        print(q1[-1])
     json.dump({"generator": "oracle/_ref (google/brotli c/enc, gcc x86-64)",
-               "cases": cases}, open(os.path.join(HERE, "golden.json"), "w"),
+               "cases": cases, "quality1_cases": q1}, open(os.path.join(HERE, "golden.json"), "w"),
               indent=1)
 
 

@@ -1,7 +1,7 @@
-"""N > 1 path on CPU: two gloo ranks, each holding the compressed piece of its
-half of a stream (pieces come from the oracle here — the test exercises the
-rank parameters and the all-gather concatenation of brotli_amd.dist, which is
-what bench.py --gpus N runs over RCCL)."""
+"""N > 1 path on CPU: two gloo ranks run brotli_amd.dist.sharded_step — the very function
+bench.py --gpus N runs over RCCL — with the oracle standing in for the device encoder
+(no GPU here): rank parameters, all-gather, padding removal, and the sha256 agreement
+check bench.py reports."""
 import os
 import sys
 
@@ -21,7 +21,7 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import gen_inputs as G
-    from brotli_amd.dist import compact, gather_stream, rank_params
+    from brotli_amd.dist import rank_params, same_stream_on_all_ranks, sharded_step
     from refharness import Oracle
     o = Oracle()
     piece, shard = 300000, 1 << 16
@@ -36,17 +36,23 @@ def _worker(rank, world, port, q):
                                     is_last and off + m == piece))
         off += m
     comp = b"".join(parts)
-    local = torch.zeros(len(comp) + 4096, dtype=torch.uint8)
-    local[:len(comp)] = torch.frombuffer(bytearray(comp), dtype=torch.uint8)
-    buf, sizes, pad = gather_stream(local, len(comp))
-    stream = compact(buf, sizes, pad).numpy().tobytes()
+
+    def encode_local():
+        local = torch.zeros(len(comp) + 4096, dtype=torch.uint8)
+        local[:len(comp)] = torch.frombuffer(bytearray(comp), dtype=torch.uint8)
+        return local, len(comp)
+    scratch = None
+    for _ in range(2):      # (the second step reuses the gather buffer, as bench.py's steps do)
+        stream_t, sizes, scratch = sharded_step(encode_local, scratch=scratch)
+    same, _ = same_stream_on_all_ranks(stream_t)
+    stream = stream_t.numpy().tobytes()
     # every rank holds the same, complete stream
     want_parts, off = [], 0
     while off < total:
         m = min(shard, total - off, piece - off % piece)
         want_parts.append(o.encode_shard(data[off:off + m], 5, 22, hint, off, off + m == total))
         off += m
-    ok = stream == b"".join(want_parts)
+    ok = same and stream == b"".join(want_parts) and int(sizes.sum().item()) == len(stream)
     q.put((rank, ok, len(stream)))
     dist.barrier()
     dist.destroy_process_group()

@@ -5,6 +5,7 @@ bit-exact — and, at BASELINE.json sizes, through size-independent properties
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -100,6 +101,20 @@ def test_golden_vectors(ctx):
         assert hashlib.sha256(got).hexdigest() == case["sha256"], case
         n += 1
     assert n > 0
+
+
+def test_golden_vectors_quality1(ctx):
+    """Quality-1 fixtures from the reference library (one-shot and CLI-style feeds)."""
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_golden import q1_calls
+    gold = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    assert gold["quality1_cases"]
+    for case in gold["quality1_cases"]:
+        data = G.make(case["input"])
+        calls = q1_calls(len(data), case["feed_kb"])
+        got, nbits, _ = ctx.encode_fast_host(data, case["lgwin"], [c[0] for c in calls])
+        assert nbits == 8 * len(got) and len(got) == case["size"], case
+        assert hashlib.sha256(got).hexdigest() == case["sha256"], case
 
 
 @pytest.mark.parametrize("lgwin", [18, 20, 24])
