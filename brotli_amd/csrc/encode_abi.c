@@ -384,6 +384,64 @@ static int submit(BrotliEncoderState* s, int op) {
   return 1;
 }
 
+/* PROCESS with a lot of input waiting (BROTLI_AMD_FEED_KB): hand it to the device now, so that host memory stays
+   bounded and output starts to flow (the reference emits during PROCESS too, encode.c:1665-1722).
+   Plan mode: the complete shards that are waiting — shard boundaries sit at multiples of the shard
+   size from the last flush either way, so the bytes do not depend on when a shard is submitted.
+   One encoder instance: the device stream takes input with BROTLI_AMD_OP_PROCESS. */
+static size_t feed_threshold(const BrotliEncoderState* s) {
+  const char* e = getenv("BROTLI_AMD_FEED_KB");       /* default: 256 MiB of shards / 4 MiB of one stream */
+  size_t kb = e ? (size_t)strtoull(e, NULL, 10) : (s->shard_bytes ? (256u << 10) : (4u << 10));
+  if (kb == 0) kb = 1;
+  return kb << 10;
+}
+static int forward_pending_input(BrotliEncoderState* s) {
+  if (s->quality == 1 || !s->hint_fixed || s->in_len < feed_threshold(s)) return 1;
+  if (s->shard_bytes == 0) {
+    const uint8_t* out;
+    uint64_t out_len;
+    if (!s->stream && brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
+                                               s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u,
+                                               &s->stream) != BROTLI_AMD_OK) return 0;
+    if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_PROCESS, &out, &out_len) != BROTLI_AMD_OK) {
+      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      return 0;
+    }
+    s->submitted += s->in_len;
+    s->in_len = 0;
+    s->header_written = 1;
+    return out_append(s, out, (size_t)out_len);
+  } else {
+    BrotliAmdJobParams p;
+    BrotliAmdJobInfo info;
+    uint64_t cap, n = 0;
+    const size_t whole = (s->in_len / s->shard_bytes) * s->shard_bytes;
+    if (whole == 0) return 1;
+    memset(&p, 0, sizeof(p));
+    p.quality = s->quality;
+    p.lgwin = s->lgwin;
+    p.size_hint = s->eff_hint;
+    p.shard_size = s->shard_bytes;
+    p.stream_base = (uint64_t)s->stream_offset + s->submitted;
+    p.is_last = 0;
+    if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
+    cap = brotli_amd_max_output(whole, &p);
+    if (cap == 0) return 0;
+    if (s->out_pos == s->out_len) s->out_pos = s->out_len = 0;
+    if (!grow(s, &s->out_buf, &s->out_cap, s->out_len, s->out_len + cap)) return 0;
+    if (brotli_amd_encode_host(s->ctx, s->in_buf, whole, &p, s->out_buf + s->out_len, cap, &n, &info) != BROTLI_AMD_OK) {
+      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      return 0;
+    }
+    s->out_len += (size_t)n;
+    s->submitted += whole;
+    memmove(s->in_buf, s->in_buf + whole, s->in_len - whole);
+    s->in_len -= whole;
+    s->header_written = 1;
+    return 1;
+  }
+}
+
 static void push_output(BrotliEncoderState* s, size_t* available_out, uint8_t** next_out,
                         size_t* total_out) {
   size_t n = s->out_len - s->out_pos;
@@ -537,6 +595,9 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
     if (op != OP_PROCESS) {
       if (!submit(s, op)) { s->failed = 1; return BROTLI_FALSE; }
       s->stream_state = op == OP_FINISH ? ST_FINISHED : ST_FLUSH_REQUESTED;
+    } else if (!forward_pending_input(s)) {
+      s->failed = 1;
+      return BROTLI_FALSE;
     }
   }
   push_output(s, available_out, next_out, total_out);

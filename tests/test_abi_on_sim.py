@@ -109,6 +109,29 @@ def test_stream_offset_and_plan_parameters(simabi, stock, oracle):
     assert fin and got == b"".join(parts)
 
 
+def test_process_calls_reach_the_device_before_the_final_operation(simabi, stock, oracle, monkeypatch):
+    """PROCESS forwards what is waiting once it passes BROTLI_AMD_FEED_KB (bounded host memory,
+    output during PROCESS, encode.c:1665-1722): the bytes are those of the same calls without
+    forwarding — the reference's for one instance, the plan's for a partition plan."""
+    monkeypatch.setenv("BROTLI_AMD_FEED_KB", "150")
+    data = G.enwik_text(423457, seed=63, vocab=20000)
+    ops = _chunks(len(data), 70000, 2)
+    # one encoder instance (quality 5): forwarded to the device stream with OP_PROCESS
+    want, _ = drive(stock, data, ops, ((1, 5), (2, 22)))
+    got, fin = drive(simabi, data, ops, ((1, 5), (2, 22)), out_chunk=1 << 15)
+    assert fin and got == want
+    # partition plan of 64 KiB shards: complete shards leave during PROCESS
+    shard = 1 << 16
+    got, fin = drive(simabi, data, ops, ((1, 5), (2, 22), (0x4D490001, shard)))
+    parts, off = [], 0
+    # (the size hint is what the calls had shown when the first input block filled: the first call)
+    while off < len(data):
+        m = min(shard, len(data) - off)
+        parts.append(oracle.encode_shard(data[off:off + m], 5, 22, 70000, off, off + m == len(data)))
+        off += m
+    assert fin and got == b"".join(parts)
+
+
 def test_quality_1_call_patterns_and_metadata(simabi, stock):
     data = TEXT + G.random_bytes(150000, seed=4) + TEXT[:80000]
     for ops, take in ((_chunks(len(data), 1 << 17, 2), False), (_chunks(len(data), 65536, 2, 3), False),
