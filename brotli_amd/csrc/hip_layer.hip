@@ -256,7 +256,8 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     // the data-parallel half of the parse, once per job (k_index.h)
     hipLaunchKernelGGL(k_ix_count, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_scan, dim3(nshards), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_ix_scatter, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_ix_scatter, dim3(nshards * plan.J.ix_slices), dim3(64),
+                       (IX_CHUNK + (3u << plan.J.ix_nb_log2)) * 4u, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
     hipLaunchKernelGGL(k_ix_bucket, dim3(((nshards + 7u) / 8u) * 8u * ((1u << plan.J.ix_nb_log2) / plan.J.ix_bpw)), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));

@@ -154,41 +154,133 @@ DEV void ix_scan(const JobParams& J, const ShardDesc& D, uint8_t* ws) {
 }
 
 // grid = nshards * slices.  Stable scatter of the slice's entries to their buckets.
+// A row of 64 consecutive positions lands in ~64 different buckets: written straight to HBM that
+// is one 4-byte transaction per entry (measured: 1 G transactions bound the kernel at 16 ms per
+// GiB).  So the slice goes through LDS in chunks of IX_CHUNK positions: counted, scanned and
+// counting-sorted by bucket inside the chunk (entries packed as chunk-relative position | tag |
+// bucket), then copied out index by index — neighbours in LDS are neighbours in their bucket's
+// range, and a bucket's share of a chunk leaves as one contiguous piece.
+#define IX_CHUNK 2048u
+#define IX_CHUNK_RANKED 48u   // up to this many entries of a chunk in one bucket are ranked by counting
+#define IX_SCATTER_LDS_WORDS (IX_CHUNK + 3u * IX_NB_MAX)
 DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
-                    uint32_t w, uint32_t* lds_off) {
-  const int lane = wave_lane();
+                    uint32_t w, uint32_t* lds) {
+  const uint32_t lane = (uint32_t)wave_lane();
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
   ix_layout(g.n, J.ix_slices, J.ix_nb_log2, &L);
   uint8_t* base = ws + D.ix_off;
   const uint8_t* data = input + D.in_off;
   const uint32_t* cnt = (const uint32_t*)(base + L.cnt);
-  uint8_t* ent = base + L.ent;
+  uint32_t* ent = (uint32_t*)(base + L.ent);
   const uint32_t per = ix_slice_len(g.n, J.ix_slices);
   const uint32_t lo = w * per, hi = umin(lo + per, g.n);
-  for (uint32_t b = (uint32_t)lane; b < (1u << J.ix_nb_log2); b += 64u) lds_off[b] = cnt[b * J.ix_slices + w];
+  const uint32_t nbk = 1u << J.ix_nb_log2;
+  uint32_t* sorted = lds;                       // [IX_CHUNK] packed entries in bucket order
+  uint32_t* start = lds + IX_CHUNK;             // [nbk] first LDS index of a bucket in this chunk (counts first)
+  uint32_t* cur = start + nbk;                  // [nbk] next free LDS index of a bucket
+  uint32_t* glob = cur + nbk;                   // [nbk] next free entry of a bucket in HBM
+  for (uint32_t b = lane; b < nbk; b += 64u) { glob[b] = cnt[b * J.ix_slices + w]; start[b] = 0; }
   wave_sync();
   const int shift = J.bucket_bits - (int)J.ix_nb_log2;
-  for (uint32_t x0 = lo; x0 < hi; x0 += 64u) {
-    const uint32_t x = x0 + (uint32_t)lane;
-    const bool act = x < hi && ix_storable(g, x);
-    uint32_t w0 = 0, b = 0;
-    if (act) {
-      const KeyTag kt = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits);
-      w0 = x | (kt.tag << 24);
-      b = kt.key >> shift;
+  for (uint32_t c0 = lo; c0 < hi; c0 += IX_CHUNK) {
+    const uint32_t c1 = umin(c0 + IX_CHUNK, hi);
+    uint32_t pk[IX_CHUNK / 64u];
+    // (1) hash, count
+#pragma unroll
+    for (uint32_t r = 0; r < IX_CHUNK / 64u; ++r) {
+      const uint32_t x = c0 + r * 64u + lane;
+      pk[r] = 0xFFFFFFFFu;
+      if (x < c1 && ix_storable(g, x)) {
+        const KeyTag kt = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits);
+        const uint32_t b = kt.key >> shift;
+        pk[r] = (x - c0) | (kt.tag << 11) | (b << 19);
+        lds_atomic_add(&start[b], 1u);
+      }
     }
-    const uint64_t same = ix_match_any(act, b, (int)J.ix_nb_log2);
-    const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
-    const uint32_t total = (uint32_t)dev_popc64(same);
-    uint32_t at = 0;
-    if (act) at = lds_off[b];
     wave_sync();
-    if (act && rank + 1u == total) lds_off[b] = at + total;
+    // (2) counts -> first indices (nbk <= 1024: up to 16 consecutive buckets per lane)
+    uint32_t total, biggest = 0;
+    {
+      const uint32_t per_lane = (nbk + 63u) / 64u;
+      uint32_t sum = 0;
+      for (uint32_t k = 0; k < per_lane; ++k) {
+        const uint32_t b = lane * per_lane + k;
+        if (b < nbk) { sum += start[b]; biggest = umax(biggest, start[b]); }
+      }
+      biggest = wave_max_u32(biggest);
+      const uint32_t incl = wave_incl_scan(sum);
+      uint32_t run = incl - sum;
+      total = wave_bcast(incl, 63);
+      wave_sync();
+      for (uint32_t k = 0; k < per_lane; ++k) {
+        const uint32_t b = lane * per_lane + k;
+        if (b >= nbk) break;
+        const uint32_t v = start[b];
+        start[b] = run; cur[b] = run;
+        run += v;
+      }
+    }
     wave_sync();
-    if (act) ((uint32_t*)ent)[at + rank] = w0;
+    if (biggest <= IX_CHUNK_RANKED) {
+      // (3) common case, every bucket holds only a handful of the chunk's entries: slots by LDS
+      // atomics (no row waits for the one before), then (4) out — straight if the runs came
+      // out in position order, else every entry finds its place by counting the entries of its
+      // bucket's run that come before it
+#pragma unroll
+      for (uint32_t r = 0; r < IX_CHUNK / 64u; ++r) {
+        if (pk[r] != 0xFFFFFFFFu) sorted[lds_atomic_add(&cur[pk[r] >> 19], 1u)] = pk[r];
+      }
+      wave_sync();
+      // The LDS unit serves the lanes of one atomic in lane order and a wave's atomics in
+      // program order, which already IS position order — but nothing promises the former, so it
+      // is checked (one look at the left neighbour) and only a chunk that fails is ranked.
+      bool ascending = true;
+      for (uint32_t i = lane; i < total; i += 64u) {
+        const uint32_t e = sorted[i];
+        if (i != start[e >> 19]) ascending = ascending && (sorted[i - 1u] & 2047u) < (e & 2047u);
+      }
+      if (!wave_ballot(!ascending)) {
+        for (uint32_t i = lane; i < total; i += 64u) {
+          const uint32_t e = sorted[i], b = e >> 19;
+          ent[glob[b] + (i - start[b])] = (c0 + (e & 2047u)) | (((e >> 11) & 255u) << 24);
+        }
+      } else {
+        for (uint32_t i = lane; i < total; i += 64u) {
+          const uint32_t e = sorted[i], b = e >> 19;
+          const uint32_t s0 = start[b], s1 = cur[b];
+          uint32_t before = 0;
+          for (uint32_t j = s0; j < s1; ++j) before += (sorted[j] & 2047u) < (e & 2047u) ? 1u : 0u;
+          ent[glob[b] + before] = (c0 + (e & 2047u)) | (((e >> 11) & 255u) << 24);
+        }
+      }
+    } else {
+      // (3') a crowded bucket (runs, zeros): rows strictly in position order, ranks by match-any
+#pragma unroll
+      for (uint32_t r = 0; r < IX_CHUNK / 64u; ++r) {
+        if (c0 + r * 64u >= c1) break;
+        const bool act = pk[r] != 0xFFFFFFFFu;
+        const uint32_t b = act ? pk[r] >> 19 : 0u;
+        const uint64_t same = ix_match_any(act, b, (int)J.ix_nb_log2);
+        const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
+        const uint32_t group = (uint32_t)dev_popc64(same);
+        uint32_t at = 0;
+        if (act) at = cur[b];
+        wave_sync();
+        if (act && rank + 1u == group) cur[b] = at + group;
+        if (act) sorted[at + rank] = pk[r];
+        wave_sync();
+      }
+      // (4') out: LDS index i of bucket b goes to glob[b] + (i - start[b])
+      for (uint32_t i = lane; i < total; i += 64u) {
+        const uint32_t e = sorted[i], b = e >> 19;
+        ent[glob[b] + (i - start[b])] = (c0 + (e & 2047u)) | (((e >> 11) & 255u) << 24);
+      }
+    }
+    wave_sync();
+    for (uint32_t b = lane; b < nbk; b += 64u) { glob[b] += cur[b] - start[b]; start[b] = 0; }
+    wave_sync();
   }
-  wave_sync();
 }
 
 // ---- level 2 + window search: one wave per (shard, bucket) -------------------------------

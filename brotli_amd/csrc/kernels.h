@@ -98,10 +98,14 @@ __global__ void __launch_bounds__(64) k_ix_scan(JobArgs a) {
 }
 // grid = nshards * ix_slices, block = 64
 __global__ void __launch_bounds__(64) k_ix_scatter(JobArgs a) {
-  __shared__ uint32_t lds_off[IX_NB_MAX];
+#if defined(BROTLI_AMD_SIMT_SIM)
+  __shared__ uint32_t lds_sc[IX_SCATTER_LDS_WORDS];
+#else
+  extern __shared__ uint32_t lds_sc[];            // (IX_CHUNK + 3 << ix_nb_log2) dwords
+#endif
   const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
   if (shard >= a.nshards) return;
-  ix_scatter(a.J, a.shards[shard], a.input, a.ws, w, lds_off);
+  ix_scatter(a.J, a.shards[shard], a.input, a.ws, w, lds_sc);
 }
 // grid = ceil(nshards / 8) * 8 * (buckets per shard / ix_bpw), block = 64: a wave works through
 // ix_bpw buckets.  Workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md): all waves of a shard are
