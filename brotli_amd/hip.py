@@ -142,6 +142,7 @@ class Context:
         """d_in: uint8 cuda tensor with >= n + INPUT_SLACK elements; d_out:
         uint8 cuda tensor.  Returns (out_bytes, info dict)."""
         assert d_in.is_cuda and d_in.numel() >= n + INPUT_SLACK
+        _wait_for_torch(d_in)
         info = JobInfo()
         out_size = C.c_uint64(0)
         rc = self.L.brotli_amd_encode_device(
@@ -180,6 +181,7 @@ class Context:
         bytes); returns (out_bits, info).  `carry` = (bits, value) pending at the
         start of the output, default: the stream header."""
         assert d_in.is_cuda and d_in.numel() >= n + INPUT_SLACK
+        _wait_for_torch(d_in)
         sizes, ncalls, p = self._fast_args(n, lgwin, call_sizes, is_last, carry)
         info = JobInfo()
         out_bits = C.c_uint64(0)
@@ -213,6 +215,14 @@ class Context:
                                            C.byref(info))
         self._check(rc, "brotli_amd_debug_parse")
         return arr[:ncmds.value], info.as_dict()
+
+
+def _wait_for_torch(t):
+    """The library works on a HIP stream of its own (non-blocking: it does not order itself
+    behind torch's streams) and returns when its work is done.  Whatever torch still has in
+    flight for the input — a fill, a copy — has to land first."""
+    import torch
+    torch.cuda.current_stream(t.device).synchronize()
 
 
 def to_device(data, device=0):

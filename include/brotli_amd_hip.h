@@ -94,7 +94,10 @@ uint64_t brotli_amd_max_output(uint64_t len, const BrotliAmdJobParams* p);
 /* Encodes d_in[0,len) (device memory, BROTLI_AMD_INPUT_SLACK readable past
    the end) into d_out (device memory, out_cap bytes): the concatenation of
    the shards' outputs in order.  d_shard_sizes (device, may be NULL) receives
-   nshards u64 compressed sizes.  Synchronous on return. */
+   nshards u64 compressed sizes.  Synchronous on return.  The work runs on a stream of the
+   context's own, created non-blocking: it is NOT ordered behind work the caller has in flight
+   on other streams — whatever produces d_in must have completed (brotli_amd/hip.py
+   synchronises torch's current stream before every call). */
 int brotli_amd_encode_device(BrotliAmdCtx* ctx, const void* d_in, uint64_t len,
                              const BrotliAmdJobParams* p, void* d_out,
                              uint64_t out_cap, uint64_t* out_size,
