@@ -706,8 +706,6 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
   BrotliAmdCtx* c = s->c;
   const JobParams& J = s->J;
   if (s->fed + len >= (3ull << 30)) return fail(c, "stream longer than 3 GiB is not supported");
-  if ((J.flags & JOB_FLAG_DEEP) && s->fed + len > J.max_backward_limit)   // k_parse_deep.h has no ring-wrap rules
-    return fail(c, "quality %d stream longer than the window (%u bytes) is not supported", J.quality, J.max_backward_limit);
   // input: the whole stream stays resident (positions are stream offsets)
   const uint64_t need_in = s->fed + len + BROTLI_AMD_INPUT_SLACK;
   if (need_in > s->in_cap) {

@@ -171,11 +171,9 @@ static inline bool plan_choose_kernels(JobPlan* plan, uint32_t api_flags, int nu
       }
     }
   } else {
-    // deep-bucket qualities: shards must fit the window (no ring-wrap rules in k_parse_deep.h)
-    if (longest > plan->J.max_backward_limit) {
-      *limit = plan->J.max_backward_limit;
-      return false;
-    }
+    // deep-bucket qualities: one shard per wave (k_parse_deep.h); shards longer than the window
+    // follow the ring-end and stale-byte rules there
+    (void)longest; (void)limit;
     plan->J.flags |= JOB_FLAG_DEEP;
   }
   return true;

@@ -384,7 +384,13 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
     else kind = IX_KIND_NONE;
     const uint32_t lo = (kind << 30) | (len << 24) | dist;
     const uint32_t hi = sidx | (umin(nsucc, 16u) << IX_NSUCC_SHIFT) | (danger ? IX_DANGER : 0u);
+#if defined(IX_NORES)        // (timing experiments only: results are wrong)
+    if (lo == 0x12345u) res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
+#elif defined(IX_RES_SORTED) // (timing experiments only)
+    res[sidx] = (uint64_t)lo | ((uint64_t)hi << 32);
+#else
     res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
+#endif
   }
 }
 

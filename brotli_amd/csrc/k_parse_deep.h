@@ -124,6 +124,15 @@ DEV void d_drain_stores(const JobParams& J, const DeepGeom& G, QShard& g, uint8_
   }
 }
 
+// Byte the reference reads at ring index x & mask for x <= pos_end: the data below pos_end; at
+// pos_end the zero bytes behind the block on the first lap (encode.c:879-893) or, once the ring
+// has been lapped, the byte of the lap before (c/enc/ringbuffer.h:103-159).
+DEV uint32_t d_ring_byte(const JobParams& J, const QShard& g, uint32_t x) {
+  if (x < g.pos_end) return g.data[x];
+  if (g.pos_end <= J.ring_mask) return 0u;
+  return g.data[x - (J.ring_mask + 1u)];
+}
+
 // ---- FindLongestMatch -----------------------------------------------------------------
 // Step-by-step emulation (..64_inc.h:157-277 / ..64_simd_inc.h:170-302).
 template <int E>
@@ -138,7 +147,10 @@ DEV QResult d_resolve_slow(const JobParams& J, const DeepGeom& G, const QShard& 
     const bool ok = d_from(d_cand ? 1u : 0u, i) != 0;
     const uint32_t len_i = d_from(d_len, i), prev_i = d_from(d_prev, i), score_i = d_from(d_score, i);
     if (!ok) continue;
-    if (q_ring_byte(g, P + best_len) != q_ring_byte(g, prev_i + best_len)) continue;
+    // candidates are not followed across the physical end of the ring (..64_inc.h:187-195)
+    if ((P & J.ring_mask) + best_len > J.ring_mask) break;
+    if ((prev_i & J.ring_mask) + best_len > J.ring_mask) continue;
+    if (d_ring_byte(J, g, P + best_len) != d_ring_byte(J, g, prev_i + best_len)) continue;
     if (!(len_i >= 3 || (len_i == 2 && i < 2))) continue;
     if (!(r.score < score_i)) continue;
     best_len = len_i;
@@ -158,9 +170,11 @@ DEV QResult d_resolve_slow(const JobParams& J, const DeepGeom& G, const QShard& 
       if ((uint32_t)k == e) { ok = o; len_j = l; prev_j = p; score_j = sc; }
     }
     if (!ok) continue;
+    if ((P & J.ring_mask) + best_len > J.ring_mask) break;                    // (:243-249)
+    if ((prev_j & J.ring_mask) + best_len > J.ring_mask) continue;
     bool pass = true;
     for (uint32_t k = best_len - 3; k <= best_len; ++k) {
-      if (q_ring_byte(g, P + k) != q_ring_byte(g, prev_j + k)) { pass = false; break; }
+      if (d_ring_byte(J, g, P + k) != d_ring_byte(J, g, prev_j + k)) { pass = false; break; }
     }
     if (!pass) continue;
     if (len_j < 4) continue;
@@ -259,6 +273,17 @@ DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* 
     if (ok && b_score[k] > dc_score && b_len[k] <= dc_len3) unsure = true;
     const uint32_t key = ok ? (b_score[k] << 9) | (511u - b_logical[k]) : 0u;
     if (key > my_key) { my_key = key; my_len = b_len[k]; my_dist = P - b_prev[k]; }
+  }
+  {
+    // a candidate that sits within a match length of the physical end of the ring may be skipped
+    // by the reference (it does not follow matches across that end): rare, resolved step by step
+    uint32_t longest = d_cand ? d_len : 0u;
+#pragma unroll
+    for (int k = 0; k < E; ++k) if (b_cand[k]) longest = umax(longest, b_len[k]);
+    longest = umax(d_max(longest), 3u);
+    if (d_cand && (d_prev & J.ring_mask) + longest > J.ring_mask) unsure = true;
+#pragma unroll
+    for (int k = 0; k < E; ++k) if (b_cand[k] && (b_prev[k] & J.ring_mask) + longest > J.ring_mask) unsure = true;
   }
   const bool force_slow = (J.flags & JOB_FLAG_FORCE_SLOW) != 0;
   const bool slow = wave_any(unsure) || force_slow;

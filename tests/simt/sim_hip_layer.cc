@@ -187,8 +187,6 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
   const JobParams& J = s->J;
   if (s->finished) return set_err(c, "stream already finished", BROTLI_AMD_ERROR);
   if (op < 0 || op > 3) return set_err(c, "bad stream op", BROTLI_AMD_UNSUPPORTED);
-  if ((J.flags & JOB_FLAG_DEEP) && s->fed + len > J.max_backward_limit)
-    return set_err(c, "stream longer than the window", BROTLI_AMD_ERROR);
   s->input.resize(s->fed + len + 64);
   if (len) memcpy(s->input.data() + s->fed, data, len);
   memset(s->input.data() + s->fed + len, 0, 64);

@@ -158,10 +158,23 @@ def test_quality_1_call_patterns_and_metadata(simabi, stock):
         assert outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("quality,lgwin", [(6, 17), (9, 17)])
+def test_deep_stream_longer_than_its_window(simabi, stock, quality, lgwin):
+    """Qualities 6-9 on one stream several windows long: candidates age out of the window, the
+    ring is lapped (stale byte behind a block end), matches are not followed across the physical
+    end of the ring (hash_longest_match64_inc.h:187-195, 243-249)."""
+    data = G.enwik_text(430000, seed=71, vocab=6000)
+    params = ((1, quality), (2, lgwin))
+    for ops in ([(len(data), 2)], _chunks(len(data), 150000, 2, 2)):
+        want, _ = drive(stock, data, ops, params)
+        got, fin = drive(simabi, data, ops, params)
+        assert fin and got == want, (quality, lgwin, len(ops))
+
+
 def test_boundary_error_behaviour(simabi):
     st = simabi.BrotliEncoderCreateInstance(None, None, None)
-    assert simabi.BrotliEncoderSetParameter(st, 1, 9) and simabi.BrotliEncoderSetParameter(st, 2, 20)
-    data = G.enwik_text((1 << 20) + 4096, seed=59, vocab=20000)     # past the quality-9 stream's window
+    assert simabi.BrotliEncoderSetParameter(st, 1, 11) and simabi.BrotliEncoderSetParameter(st, 2, 20)
+    data = G.enwik_text(5000, seed=59, vocab=2000)                  # quality 11: outside the GPU path
     buf = C.create_string_buffer(data, len(data))
     n = C.c_size_t(len(data))
     nxt = C.c_void_p(C.addressof(buf))
