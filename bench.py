@@ -397,6 +397,14 @@ def main():
             kernel = "k_chain" if indexed else ("k_parse4" if args.quality == 5 else "k_parse_deep")
             k_ms, k_bytes = ms_parse, (algo if not indexed else 9.0 + 16.0 * 0.4)
         achieved = k_bytes * n / (k_ms / 1e3) / 1e9
+        # HBM bytes of the dominant kernel: NOT measured by this run — a constant from PMC passes of a
+        # separate run of the same command (profiles/traffic.json names its source), null otherwise
+        traffic, traffic_source = None, "not measured (no PMC pass on record for this configuration)"
+        prof = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(prof) and args.workload == "text":
+            t = json.load(open(prof)).get("%d/%d" % (args.size_mb, args.shard_kb))
+            if t and t.get("kernel") == kernel:
+                traffic, traffic_source = t["hbm_bytes_per_launch"], "model input, not this run: " + t["source"]
         path_ms = ms_index + ms_parse
         path = algo * n / (path_ms / 1e3) / 1e9
         line = {
@@ -425,7 +433,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "frac_of_achievable_6300": round(achieved / HBM_ACHIEVABLE_GBS, 5),
-                         "traffic": None, "traffic_source": "not measured in this run (PMC passes: profiles/)",
+                         "traffic": traffic, "traffic_source": traffic_source,
                          "parse_path": {"kernels": "k_ix_count + k_ix_scan + k_ix_scatter + k_ix_bucket + k_chain + k_cmd_encode"
                                         if indexed else kernel,
                                         "ms": round(path_ms, 3), "achieved": round(path, 1),
