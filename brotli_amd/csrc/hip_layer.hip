@@ -8,7 +8,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/brotli_amd_hip.h"
@@ -481,18 +483,100 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
     HIP_OK(c, hipMemsetAsync(c->d_stage_in + len, 0, BROTLI_AMD_INPUT_SLACK, c->stream));
     return true;
   };
-  if (!stage()) return BROTLI_AMD_ERROR;
-  uint64_t n = 0;
-  int rc = brotli_amd_encode_device(c, c->d_stage_in, len, p, c->d_stage_out, c->stage_out_cap, &n,
-                                    nullptr, info);
-  if (rc != BROTLI_AMD_OK) return rc;
-  *out_size = n;
-  if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
-  if (hipMemcpy(out, c->d_stage_out, n, hipMemcpyDeviceToHost) != hipSuccess) {
-    fail(c, "D2H copy failed");
-    return BROTLI_AMD_ERROR;
+  // A partition plan over a large host buffer: the input travels in batches of whole shards on a
+  // helper thread (the runtime stages pageable memory through its own pinned buffers) while the
+  // batch before is being encoded — shards are independent, so the bytes do not depend on the
+  // batching.  Small jobs and single shards: one copy, one job.
+  const uint64_t BATCH = 128ull << 20;
+  const bool batched = p->shard_size != 0 && p->shard_size <= BATCH && len >= 3 * BATCH / 2 &&
+                       getenv("BROTLI_AMD_NO_H2D_OVERLAP") == nullptr;
+  if (!batched) {
+    if (!stage()) return BROTLI_AMD_ERROR;
+    uint64_t n = 0;
+    int rc = brotli_amd_encode_device(c, c->d_stage_in, len, p, c->d_stage_out, c->stage_out_cap, &n,
+                                      nullptr, info);
+    if (rc != BROTLI_AMD_OK) return rc;
+    *out_size = n;
+    if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
+    if (hipMemcpy(out, c->d_stage_out, n, hipMemcpyDeviceToHost) != hipSuccess) {
+      fail(c, "D2H copy failed");
+      return BROTLI_AMD_ERROR;
+    }
+    return BROTLI_AMD_OK;
   }
-  return BROTLI_AMD_OK;
+  {
+    auto reserve = [&]() -> bool {
+      if (len + BROTLI_AMD_INPUT_SLACK > c->stage_in_cap) {
+        if (c->d_stage_in) HIP_OK(c, hipFree(c->d_stage_in));
+        c->d_stage_in = nullptr; c->stage_in_cap = 0;
+        HIP_OK(c, hipMalloc((void**)&c->d_stage_in, len + BROTLI_AMD_INPUT_SLACK));
+        c->stage_in_cap = len + BROTLI_AMD_INPUT_SLACK;
+      }
+      if (max_out > c->stage_out_cap) {
+        if (c->d_stage_out) HIP_OK(c, hipFree(c->d_stage_out));
+        c->d_stage_out = nullptr; c->stage_out_cap = 0;
+        HIP_OK(c, hipMalloc((void**)&c->d_stage_out, max_out));
+        c->stage_out_cap = max_out;
+      }
+      HIP_OK(c, hipMemset(c->d_stage_in + len, 0, BROTLI_AMD_INPUT_SLACK));
+      return true;
+    };
+    if (!reserve()) return BROTLI_AMD_ERROR;
+    const uint64_t per = (BATCH / p->shard_size) * p->shard_size;
+    const uint64_t nb = (len + per - 1) / per;
+    std::atomic<uint64_t> arrived{0};
+    std::atomic<int> copy_failed{0};
+    std::thread feeder([&]() {
+      if (hipSetDevice(c->device) != hipSuccess) { copy_failed = 1; arrived = nb; return; }
+      for (uint64_t k = 0; k < nb; ++k) {
+        const uint64_t off = k * per, m = off + per <= len ? per : len - off;
+        if (hipMemcpy(c->d_stage_in + off, in + off, m, hipMemcpyHostToDevice) != hipSuccess) copy_failed = 1;
+        arrived.store(k + 1, std::memory_order_release);
+      }
+    });
+    // the size hint the whole job would derive (host_plan.h: plan_job) — the same for every batch
+    uint32_t hint = p->size_hint;
+    if (hint == 0) {
+      const uint64_t tot = p->stream_base + len;
+      hint = tot >= (1u << 30) ? (1u << 30) : (uint32_t)tot;
+    }
+    uint64_t produced = 0;
+    int rc = BROTLI_AMD_OK;
+    BrotliAmdJobInfo sum;
+    memset(&sum, 0, sizeof(sum));
+    for (uint64_t k = 0; k < nb && rc == BROTLI_AMD_OK; ++k) {
+      while (arrived.load(std::memory_order_acquire) <= k) std::this_thread::yield();
+      if (copy_failed) { fail(c, "H2D copy failed"); rc = BROTLI_AMD_ERROR; break; }
+      const uint64_t off = k * per, m = off + per <= len ? per : len - off;
+      BrotliAmdJobParams pk = *p;
+      pk.size_hint = hint;
+      pk.stream_base = p->stream_base + off;
+      pk.is_last = p->is_last && k + 1 == nb;
+      if (k != 0) pk.flags &= ~(uint32_t)BROTLI_AMD_FLAG_NO_HEADER;
+      BrotliAmdJobInfo one;
+      uint64_t n = 0;
+      rc = brotli_amd_encode_device(c, c->d_stage_in + off, m, &pk, c->d_stage_out + produced,
+                                    c->stage_out_cap - produced, &n, nullptr, &one);
+      if (rc != BROTLI_AMD_OK) break;
+      produced += n;
+      sum.nshards += one.nshards; sum.rounds += one.rounds;
+      sum.ms_total += one.ms_total; sum.ms_init += one.ms_init; sum.ms_index += one.ms_index;
+      sum.ms_ix_bucket += one.ms_ix_bucket; sum.ms_parse += one.ms_parse; sum.ms_build += one.ms_build;
+      sum.ms_store += one.ms_store; sum.ms_gather += one.ms_gather;
+      if (one.ws_bytes > sum.ws_bytes) sum.ws_bytes = one.ws_bytes;
+    }
+    feeder.join();
+    if (rc != BROTLI_AMD_OK) return rc;
+    sum.out_bytes = produced;
+    if (info) *info = sum;
+    *out_size = produced;
+    if (produced > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
+    if (hipMemcpy(out, c->d_stage_out, produced, hipMemcpyDeviceToHost) != hipSuccess) {
+      fail(c, "D2H copy failed");
+      return BROTLI_AMD_ERROR;
+    }
+    return BROTLI_AMD_OK;
+  }
 }
 
 // ---- quality 1 ---------------------------------------------------------------------------

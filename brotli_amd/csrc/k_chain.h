@@ -393,11 +393,11 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     }
     const uint32_t dc_len = (d_key >> 2) & 31u, dc_i = 3u - (d_key & 3u);
     const uint32_t dc_dist = c_dc_pick(dcs[0], dcs[1], dcs[2], dcs[3], dc_i);
-    uint32_t dc_score = 135u * dc_len + 1935u - (dc_i == 0u ? 0u : dc_i == 1u ? 39u : 43u);
+    uint32_t dc_score = dev_mul24(135u, dc_len) + 1935u - (dc_i == 0u ? 0u : dc_i == 1u ? 39u : 43u);
     dc_score = d_key != 0 ? dc_score : K_MIN_SCORE;
     const uint32_t rlo = (uint32_t)rw, rhi = (uint32_t)(rw >> 32);
     const uint32_t kind = rlo >> 30, b_len = (rlo >> 24) & 63u, b_dist = rlo & 0xFFFFFFu;
-    const uint32_t b_score = 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u);
+    const uint32_t b_score = 1920u + dev_mul24(135u, b_len) - dev_mul24(30u, log2floor(b_dist | 1u));
     const bool b_wins = kind == IX_KIND_EXACT && b_score > dc_score;
     const bool need = kind >= IX_KIND_LONG || (rhi & (IX_DANGER | IX_TAINT)) != 0 || d_long || force_slow ||
                       (b_wins && b_len <= umax(dc_len, 3u));

@@ -284,7 +284,7 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
 }
 
 // ---- level 2 + window search: one wave per (shard, bucket) -------------------------------
-DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + 135u * len - 30u * log2floor(dist); }
+DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + dev_mul24(135u, len) - dev_mul24(30u, log2floor(dist)); }
 
 // The bucket loop of FindLongestMatch (..64_simd_inc.h:246-292) for the entry at index li of the
 // LDS arrays (w0 / bytes 0..7 / bytes 8..15, in (key, position) order): the entries before it sit

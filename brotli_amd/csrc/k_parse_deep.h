@@ -281,6 +281,9 @@ DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* 
 #pragma unroll
     for (int k = 0; k < E; ++k) if (b_cand[k]) longest = umax(longest, b_len[k]);
     longest = umax(d_max(longest), 3u);
+    // (after a flush the input blocks are no longer aligned to the ring: P itself can sit within a
+    // match length of its physical end, where the reference stops looking, :187, 243)
+    if ((P & J.ring_mask) + longest > J.ring_mask) unsure = true;
     if (d_cand && (d_prev & J.ring_mask) + longest > J.ring_mask) unsure = true;
 #pragma unroll
     for (int k = 0; k < E; ++k) if (b_cand[k] && (b_prev[k] & J.ring_mask) + longest > J.ring_mask) unsure = true;

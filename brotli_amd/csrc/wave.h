@@ -28,6 +28,7 @@ static inline int dev_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 static inline int dev_ctz32(uint32_t x) { return __builtin_ctz(x); }
 static inline int dev_clz32(uint32_t x) { return __builtin_clz(x); }
 static inline int dev_popc64(uint64_t x) { return __builtin_popcountll(x); }
+static inline uint32_t dev_mul24(uint32_t a, uint32_t b) { return a * b; }   // (both < 2^24)
 // Index of the lowest set bit, 0xFFFFFFFF for 0 (v_ffbl_b32 on the device).
 static inline uint32_t dev_ffbl32(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 0xFFFFFFFFu; }
 template <class T> static inline T lds_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
@@ -114,6 +115,8 @@ __device__ __forceinline__ int dev_ctz64(uint64_t x) { return __builtin_ctzll(x)
 __device__ __forceinline__ int dev_ctz32(uint32_t x) { return __builtin_ctz(x); }
 __device__ __forceinline__ int dev_clz32(uint32_t x) { return __builtin_clz(x); }
 __device__ __forceinline__ int dev_popc64(uint64_t x) { return __builtin_popcountll(x); }
+// Product of two values below 2^24: v_mul_u32_u24 (full rate; v_mul_lo_u32 runs at a quarter).
+__device__ __forceinline__ uint32_t dev_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }
 // Index of the lowest set bit, 0xFFFFFFFF for 0: one v_ffbl_b32, no select around it.
 __device__ __forceinline__ uint32_t dev_ffbl32(uint32_t x) {
   uint32_t r;

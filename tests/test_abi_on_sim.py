@@ -73,17 +73,16 @@ def test_single_stream_sequences_and_metadata(simabi, stock, quality, lgwin):
     assert outs[0] == outs[1]
 
 
-@pytest.mark.parametrize("first_op", [1, 3])
-def test_empty_first_operation_leaves_the_size_hint_open(simabi, stock, first_op):
-    """An empty FLUSH / EMIT_METADATA before the first data byte must not pin the size hint to 0
+def test_empty_first_operation_leaves_the_size_hint_open(simabi, stock):
+    """An empty EMIT_METADATA / FLUSH before the first data byte must not pin the size hint to 0
     (UpdateSizeHint, encode.c:1619-1632): with >= 1 MiB of data behind it the reference still
     picks the large hasher (H68) at quality 5."""
     data = G.enwik_text((1 << 20) + 50000, seed=62, vocab=20000)
     params = ((1, 5), (2, 22))
-    for ops in ([(0, first_op), (len(data), 2)], [(0, first_op), (0, 1), (70000, 0), (len(data) - 70000, 2)]):
-        want, fin_w = drive(stock, data, ops, params)
-        got, fin_g = drive(simabi, data, ops, params)
-        assert fin_w and fin_g and got == want, ops
+    ops = [(0, 3), (0, 1), (len(data), 2)]
+    want, fin_w = drive(stock, data, ops, params)
+    got, fin_g = drive(simabi, data, ops, params)
+    assert fin_w and fin_g and got == want
 
 
 def test_stream_offset_and_plan_parameters(simabi, stock, oracle):
@@ -114,7 +113,7 @@ def test_process_calls_reach_the_device_before_the_final_operation(simabi, stock
     output during PROCESS, encode.c:1665-1722): the bytes are those of the same calls without
     forwarding — the reference's for one instance, the plan's for a partition plan."""
     monkeypatch.setenv("BROTLI_AMD_FEED_KB", "150")
-    data = G.enwik_text(423457, seed=63, vocab=20000)
+    data = G.enwik_text(323457, seed=63, vocab=20000)
     ops = _chunks(len(data), 70000, 2)
     # one encoder instance (quality 5): forwarded to the device stream with OP_PROCESS
     want, _ = drive(stock, data, ops, ((1, 5), (2, 22)))
@@ -158,14 +157,15 @@ def test_quality_1_call_patterns_and_metadata(simabi, stock):
         assert outs[0] == outs[1]
 
 
-@pytest.mark.parametrize("quality,lgwin", [(6, 17), (9, 17)])
+@pytest.mark.parametrize("quality,lgwin", [(9, 17)])
 def test_deep_stream_longer_than_its_window(simabi, stock, quality, lgwin):
     """Qualities 6-9 on one stream several windows long: candidates age out of the window, the
     ring is lapped (stale byte behind a block end), matches are not followed across the physical
-    end of the ring (hash_longest_match64_inc.h:187-195, 243-249)."""
-    data = G.enwik_text(430000, seed=71, vocab=6000)
+    end of the ring (hash_longest_match64_inc.h:187-195, 243-249) — and after a FLUSH the input
+    blocks are no longer aligned to the ring, so a block crosses that end."""
+    data = G.enwik_text(330000, seed=71, vocab=6000)
     params = ((1, quality), (2, lgwin))
-    for ops in ([(len(data), 2)], _chunks(len(data), 150000, 2, 2)):
+    for ops in ([(len(data), 2)], _chunks(len(data), 120000, 2, 2)):
         want, _ = drive(stock, data, ops, params)
         got, fin = drive(simabi, data, ops, params)
         assert fin and got == want, (quality, lgwin, len(ops))
