@@ -55,8 +55,76 @@ struct BrotliAmdCtx {
   uint64_t ffrag_cap = 0, fblock_cap = 0;
   hipEvent_t ev[8] = {};
   hipEvent_t ev_ix = nullptr, ev_ixb = nullptr;
+  // host <-> device copies of encode_host: copy lanes, each a stream and two pinned chunks
+  struct CopyLane { hipStream_t s = nullptr; uint8_t* pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; };
+  std::vector<CopyLane> lanes;
   std::string err;
 };
+
+// A large copy between a pageable host buffer and device memory: the runtime's own path stages
+// through one pinned buffer on the calling thread (about 5 GB/s on the MI355X host, whatever the
+// number of callers); here T threads each move every T-th chunk through pinned chunks of their own
+// — the host-side memcpy of one chunk overlaps the DMA of the other.  Blocking.
+static const uint64_t PIN_CHUNK = 8ull << 20;
+static bool big_copy(BrotliAmdCtx* c, uint8_t* dst, const uint8_t* src, uint64_t len, bool to_device) {
+  if (len == 0) return true;
+  if (len < 2 * PIN_CHUNK || getenv("BROTLI_AMD_PLAIN_COPY") != nullptr)
+    return hipMemcpy(dst, src, len, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) == hipSuccess;
+  if (c->lanes.empty()) {
+    int T = 4;
+    if (const char* e = getenv("BROTLI_AMD_COPY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 16) T = v; }
+    std::vector<BrotliAmdCtx::CopyLane> lanes((size_t)T);
+    bool ok = true;
+    for (auto& l : lanes) {
+      ok = ok && hipStreamCreateWithFlags(&l.s, hipStreamNonBlocking) == hipSuccess;
+      for (int k = 0; k < 2; ++k) {
+        ok = ok && hipHostMalloc((void**)&l.pin[k], PIN_CHUNK, hipHostMallocDefault) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&l.ev[k], hipEventDisableTiming) == hipSuccess;
+      }
+    }
+    if (!ok) {
+      for (auto& l : lanes) {
+        for (int k = 0; k < 2; ++k) { if (l.pin[k]) (void)hipHostFree(l.pin[k]); if (l.ev[k]) (void)hipEventDestroy(l.ev[k]); }
+        if (l.s) (void)hipStreamDestroy(l.s);
+      }
+      (void)hipGetLastError();
+      return hipMemcpy(dst, src, len, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    c->lanes.swap(lanes);
+  }
+  const uint64_t T = c->lanes.size(), nchunks = (len + PIN_CHUNK - 1) / PIN_CHUNK;
+  std::atomic<int> failed{0};
+  std::vector<std::thread> th;
+  for (uint64_t j = 0; j < T; ++j) {
+    th.emplace_back([&, j]() {
+      BrotliAmdCtx::CopyLane& l = c->lanes[j];
+      if (hipSetDevice(c->device) != hipSuccess) { failed = 1; return; }
+      uint64_t it = 0, prev_off = 0, prev_m = 0;
+      for (uint64_t i = j; i < nchunks; i += T, ++it) {
+        const uint64_t off = i * PIN_CHUNK, m = off + PIN_CHUNK <= len ? PIN_CHUNK : len - off;
+        const int k = (int)(it & 1u);
+        if (to_device) {
+          if (it >= 2 && hipEventSynchronize(l.ev[k]) != hipSuccess) failed = 1;
+          memcpy(l.pin[k], src + off, m);
+          if (hipMemcpyAsync(dst + off, l.pin[k], m, hipMemcpyHostToDevice, l.s) != hipSuccess) failed = 1;
+          if (hipEventRecord(l.ev[k], l.s) != hipSuccess) failed = 1;
+        } else {
+          if (hipMemcpyAsync(l.pin[k], src + off, m, hipMemcpyDeviceToHost, l.s) != hipSuccess) failed = 1;
+          if (hipEventRecord(l.ev[k], l.s) != hipSuccess) failed = 1;
+          if (it >= 1) {
+            if (hipEventSynchronize(l.ev[k ^ 1]) != hipSuccess) failed = 1;
+            memcpy(dst + prev_off, l.pin[k ^ 1], prev_m);
+          }
+          prev_off = off; prev_m = m;
+        }
+      }
+      if (hipStreamSynchronize(l.s) != hipSuccess) failed = 1;
+      if (!to_device && it >= 1) memcpy(dst + prev_off, l.pin[(it - 1) & 1u], prev_m);
+    });
+  }
+  for (auto& t : th) t.join();
+  return failed == 0;
+}
 
 namespace {
 
@@ -380,6 +448,10 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->ev_ix) (void)hipEventDestroy(c->ev_ix);
   if (c->ev_ixb) (void)hipEventDestroy(c->ev_ixb);
+  for (auto& l : c->lanes) {
+    for (int k = 0; k < 2; ++k) { if (l.pin[k]) (void)hipHostFree(l.pin[k]); if (l.ev[k]) (void)hipEventDestroy(l.ev[k]); }
+    if (l.s) (void)hipStreamDestroy(l.s);
+  }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -479,104 +551,24 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
       HIP_OK(c, hipMalloc((void**)&c->d_stage_out, max_out));
       c->stage_out_cap = max_out;
     }
-    HIP_OK(c, hipMemcpyAsync(c->d_stage_in, in, len, hipMemcpyHostToDevice, c->stream));
+    if (!big_copy(c, c->d_stage_in, in, len, true)) { fail(c, "H2D copy failed"); return false; }
     HIP_OK(c, hipMemsetAsync(c->d_stage_in + len, 0, BROTLI_AMD_INPUT_SLACK, c->stream));
     return true;
   };
-  // A partition plan over a large host buffer: the input travels in batches of whole shards on a
-  // helper thread (the runtime stages pageable memory through its own pinned buffers) while the
-  // batch before is being encoded — shards are independent, so the bytes do not depend on the
-  // batching.  Small jobs and single shards: one copy, one job.
-  const uint64_t BATCH = 128ull << 20;
-  const bool batched = p->shard_size != 0 && p->shard_size <= BATCH && len >= 3 * BATCH / 2 &&
-                       getenv("BROTLI_AMD_NO_H2D_OVERLAP") == nullptr;
-  if (!batched) {
-    if (!stage()) return BROTLI_AMD_ERROR;
-    uint64_t n = 0;
-    int rc = brotli_amd_encode_device(c, c->d_stage_in, len, p, c->d_stage_out, c->stage_out_cap, &n,
-                                      nullptr, info);
-    if (rc != BROTLI_AMD_OK) return rc;
-    *out_size = n;
-    if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
-    if (hipMemcpy(out, c->d_stage_out, n, hipMemcpyDeviceToHost) != hipSuccess) {
-      fail(c, "D2H copy failed");
-      return BROTLI_AMD_ERROR;
-    }
-    return BROTLI_AMD_OK;
+  // (Encoding a plan in batches while the next batch travels was measured and dropped: the chain
+  // kernel takes as long for 1024 shards as for 8192, so every batch pays the whole latency.)
+  if (!stage()) return BROTLI_AMD_ERROR;
+  uint64_t n = 0;
+  int rc = brotli_amd_encode_device(c, c->d_stage_in, len, p, c->d_stage_out, c->stage_out_cap, &n,
+                                    nullptr, info);
+  if (rc != BROTLI_AMD_OK) return rc;
+  *out_size = n;
+  if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
+  if (!big_copy(c, out, c->d_stage_out, n, false)) {
+    fail(c, "D2H copy failed");
+    return BROTLI_AMD_ERROR;
   }
-  {
-    auto reserve = [&]() -> bool {
-      if (len + BROTLI_AMD_INPUT_SLACK > c->stage_in_cap) {
-        if (c->d_stage_in) HIP_OK(c, hipFree(c->d_stage_in));
-        c->d_stage_in = nullptr; c->stage_in_cap = 0;
-        HIP_OK(c, hipMalloc((void**)&c->d_stage_in, len + BROTLI_AMD_INPUT_SLACK));
-        c->stage_in_cap = len + BROTLI_AMD_INPUT_SLACK;
-      }
-      if (max_out > c->stage_out_cap) {
-        if (c->d_stage_out) HIP_OK(c, hipFree(c->d_stage_out));
-        c->d_stage_out = nullptr; c->stage_out_cap = 0;
-        HIP_OK(c, hipMalloc((void**)&c->d_stage_out, max_out));
-        c->stage_out_cap = max_out;
-      }
-      HIP_OK(c, hipMemset(c->d_stage_in + len, 0, BROTLI_AMD_INPUT_SLACK));
-      return true;
-    };
-    if (!reserve()) return BROTLI_AMD_ERROR;
-    const uint64_t per = (BATCH / p->shard_size) * p->shard_size;
-    const uint64_t nb = (len + per - 1) / per;
-    std::atomic<uint64_t> arrived{0};
-    std::atomic<int> copy_failed{0};
-    std::thread feeder([&]() {
-      if (hipSetDevice(c->device) != hipSuccess) { copy_failed = 1; arrived = nb; return; }
-      for (uint64_t k = 0; k < nb; ++k) {
-        const uint64_t off = k * per, m = off + per <= len ? per : len - off;
-        if (hipMemcpy(c->d_stage_in + off, in + off, m, hipMemcpyHostToDevice) != hipSuccess) copy_failed = 1;
-        arrived.store(k + 1, std::memory_order_release);
-      }
-    });
-    // the size hint the whole job would derive (host_plan.h: plan_job) — the same for every batch
-    uint32_t hint = p->size_hint;
-    if (hint == 0) {
-      const uint64_t tot = p->stream_base + len;
-      hint = tot >= (1u << 30) ? (1u << 30) : (uint32_t)tot;
-    }
-    uint64_t produced = 0;
-    int rc = BROTLI_AMD_OK;
-    BrotliAmdJobInfo sum;
-    memset(&sum, 0, sizeof(sum));
-    for (uint64_t k = 0; k < nb && rc == BROTLI_AMD_OK; ++k) {
-      while (arrived.load(std::memory_order_acquire) <= k) std::this_thread::yield();
-      if (copy_failed) { fail(c, "H2D copy failed"); rc = BROTLI_AMD_ERROR; break; }
-      const uint64_t off = k * per, m = off + per <= len ? per : len - off;
-      BrotliAmdJobParams pk = *p;
-      pk.size_hint = hint;
-      pk.stream_base = p->stream_base + off;
-      pk.is_last = p->is_last && k + 1 == nb;
-      if (k != 0) pk.flags &= ~(uint32_t)BROTLI_AMD_FLAG_NO_HEADER;
-      BrotliAmdJobInfo one;
-      uint64_t n = 0;
-      rc = brotli_amd_encode_device(c, c->d_stage_in + off, m, &pk, c->d_stage_out + produced,
-                                    c->stage_out_cap - produced, &n, nullptr, &one);
-      if (rc != BROTLI_AMD_OK) break;
-      produced += n;
-      sum.nshards += one.nshards; sum.rounds += one.rounds;
-      sum.ms_total += one.ms_total; sum.ms_init += one.ms_init; sum.ms_index += one.ms_index;
-      sum.ms_ix_bucket += one.ms_ix_bucket; sum.ms_parse += one.ms_parse; sum.ms_build += one.ms_build;
-      sum.ms_store += one.ms_store; sum.ms_gather += one.ms_gather;
-      if (one.ws_bytes > sum.ws_bytes) sum.ws_bytes = one.ws_bytes;
-    }
-    feeder.join();
-    if (rc != BROTLI_AMD_OK) return rc;
-    sum.out_bytes = produced;
-    if (info) *info = sum;
-    *out_size = produced;
-    if (produced > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
-    if (hipMemcpy(out, c->d_stage_out, produced, hipMemcpyDeviceToHost) != hipSuccess) {
-      fail(c, "D2H copy failed");
-      return BROTLI_AMD_ERROR;
-    }
-    return BROTLI_AMD_OK;
-  }
+  return BROTLI_AMD_OK;
 }
 
 // ---- quality 1 ---------------------------------------------------------------------------
@@ -705,7 +697,7 @@ int brotli_amd_encode_fast_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len
       HIP_OK(c, hipMalloc((void**)&c->d_stage_out, max_out));
       c->stage_out_cap = max_out;
     }
-    if (len) HIP_OK(c, hipMemcpyAsync(c->d_stage_in, in, len, hipMemcpyHostToDevice, c->stream));
+    if (len && !big_copy(c, c->d_stage_in, in, len, true)) return fail(c, "H2D copy failed");
     HIP_OK(c, hipMemsetAsync(c->d_stage_in + len, 0, BROTLI_AMD_INPUT_SLACK, c->stream));
     return true;
   };
@@ -717,7 +709,7 @@ int brotli_amd_encode_fast_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len
   const uint64_t n = (nbits + 7) / 8;
   *out_bits = nbits;
   if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
-  if (n && hipMemcpy(out, c->d_stage_out, n, hipMemcpyDeviceToHost) != hipSuccess) {
+  if (n && !big_copy(c, out, c->d_stage_out, n, false)) {
     fail(c, "D2H copy failed");
     return BROTLI_AMD_ERROR;
   }

@@ -31,7 +31,7 @@
 #include "k_index.h"
 #include "k_parse4.h"
 
-#define C_GROUP_LDS_WORDS 16u                                          // 16 ring slots of c_search_exact
+#define C_GROUP_LDS_WORDS 20u                                          // 16 ring slots of c_search_exact + its carried store count
 #define C_LDS_WORDS (Q_GROUPS * C_GROUP_LDS_WORDS)
 
 struct CShard {
@@ -121,11 +121,20 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   const uint32_t hi = want ? (uint32_t)(C.res[P] >> 32) : 0u;
   const int32_t sidx = (int32_t)(hi & 0xFFFFFFu);
   const bool danger = (hi & IX_DANGER) != 0;
-  // the ring: the last 16 stored positions of the key run before P, newest first
+  // the ring: the last 16 stored positions of the key run before P, newest first.  Past rank
+  // 65520 the 16-bit store counter of the reference may have wrapped (:250-257), and the number
+  // of stores of the whole run decides what is visible: counted once, then carried in the
+  // group's LDS words 16..18 (key, index the count reaches, count) — what lies below a searched
+  // position never changes — so that a run of 100 000 zeros is not walked again by every search.
+  const uint32_t c_key = scratch[16], c_sidx = scratch[17], c_cnt = scratch[18];
+  const bool carried = danger && c_key == kt.key && (int32_t)c_sidx <= sidx;
+  const int32_t count_from = carried ? (int32_t)c_sidx : 0;
+  uint32_t total = carried ? c_cnt : 0u;
+  bool counted = !danger;
   uint32_t found = 0, j0 = 0;
   bool exhausted = false;
-  while (wave_any(want && !exhausted && (found < 16u || danger))) {
-    const bool on = want && !exhausted && (found < 16u || danger);
+  while (wave_any(want && !exhausted && (found < 16u || !counted))) {
+    const bool on = want && !exhausted && (found < 16u || !counted);
     const int32_t idx = sidx - 1 - (int32_t)(j0 + (uint32_t)t);
     const bool ok = on && idx >= 0;
     const uint32_t w0 = ok ? C.srt[idx] : 0u;
@@ -139,19 +148,23 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
     const uint32_t te = nr16 ? (uint32_t)dev_ctz32(nr16) : 16u;
     stored = stored && (uint32_t)t < te;
     const uint32_t s16 = q_mask16(wave_ballot(stored));
+    const uint32_t n16 = q_mask16(wave_ballot(stored && idx >= count_from));
     const uint32_t slot = found + (uint32_t)__builtin_popcount(s16 & ((1u << t) - 1u));
     if (stored && slot < 16u) scratch[slot] = w0;
     if (on) {
       found += (uint32_t)__builtin_popcount(s16);
+      total += (uint32_t)__builtin_popcount(n16);
       if (te < 16u) exhausted = true;
       j0 += 16u;
+      if (sidx - (int32_t)j0 <= count_from) counted = true;     // everything from count_from up is in
     }
   }
   wave_sync();
+  if (want && danger && t == 0) { scratch[16] = kt.key; scratch[17] = (uint32_t)sidx; scratch[18] = total; }
   // slots the 16-bit counter leaves visible (:250-257): all 16 once it has seen 16 stores,
   // and — only reachable after a wrap — count mod 65536 when that is below 16
   uint32_t nvalid = umin(found, 16u);
-  if (danger) { const uint32_t n = found & 0xFFFFu; nvalid = n < 16u ? n : 16u; }
+  if (danger) { const uint32_t n = total & 0xFFFFu; nvalid = n < 16u ? n : 16u; }
   const uint32_t w0 = (uint32_t)t < nvalid ? scratch[t] : 0u;
   const uint32_t b_prev = w0 & 0xFFFFFFu;
   const bool b_cand = want && (uint32_t)t < nvalid && (w0 >> 24) == kt.tag && (P - b_prev) <= max_backward;
@@ -540,6 +553,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   const ShardDesc& D = shards[alive ? shard : 0];
   const ShardState* S0 = &states[alive ? shard : 0];
   uint32_t* scratch = lds + gi * C_GROUP_LDS_WORDS;
+  if (t == 0) scratch[16] = 0xFFFFFFFFu;               // no carried store count yet (c_search_exact)
   const int kpos = t >> 2, idc = t & 3;   // this lane's probe: position P0 + kpos, cache entry idc
 
   CShard C;

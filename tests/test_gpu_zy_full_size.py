@@ -70,6 +70,27 @@ def test_1gib_text_q5_lgwin22_128k_plan_sha256(ctx, text1g):
     assert want["out_bytes"] == nb and want["sha256"] == got
 
 
+def test_256mib_mixed_corpus_q5_128k_plan_sha256_and_time(ctx):
+    """BASELINE configs[3] stand-in (tests/gen_inputs.mixed_corpus: text, markup, source, rows,
+    floats, gradients, sparse zeros, noise in 1 MiB members): same bytes as the reference, and
+    no member type may throw the serial chain off its pace — the sparse-zero shards (one key run
+    longer than the reference's 16-bit store counter) once took 16 s."""
+    import torch
+    from brotli_amd import hip
+    n, shard = 256 << 20, 1 << 17
+    data = G.mixed_corpus(n)
+    p = hip.make_params(5, 22, shard)
+    d_in = hip.to_device(data)
+    d_out = torch.empty(ctx.max_output(n, p), dtype=torch.uint8, device="cuda:0")
+    nb, info = ctx.encode_device(d_in, n, p, d_out)
+    nb, info = ctx.encode_device(d_in, n, p, d_out)
+    got = hashlib.sha256(d_out[:nb].cpu().numpy().tobytes()).hexdigest()
+    del d_out, d_in
+    want = _reference(data, 5, 22, shard, n, _threads())
+    assert want["out_bytes"] == nb and want["sha256"] == got
+    assert info["ms_total"] < 1000.0, info
+
+
 def test_1gib_text_q9_lgwin24_512k_plan_sha256(ctx, text1g):
     """BASELINE configs[4] at the plan bench.py --quality 9 runs (512 KiB shards)."""
     import torch

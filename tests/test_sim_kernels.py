@@ -192,6 +192,26 @@ def test_indexed_parse_copy_ends_at_block_end(sim, oracle):
     assert sim.encode(data, 5, 22, 4 << 20, 0, stream_base=2 << 18, is_last=False, flags=IX_LAYOUTS["groups1"]) == want
 
 
+def test_indexed_parse_key_run_past_the_16_bit_store_counter(sim, oracle):
+    """Sparse zeros: one key run of > 65520 positions, so the wrap of the reference's 16-bit
+    store counter (..64_simd_inc.h:250-257) is in reach and every search there is an exact one;
+    the number of stores of the run is carried from search to search (c_search_exact) — without
+    that this shard takes minutes here and seconds on the GPU.  The second input stores more
+    than 65536 positions of the run: the counter does wrap."""
+    import time
+    rng = np.random.default_rng(7)
+    z = np.zeros(140000, dtype=np.uint8)
+    pos = rng.integers(0, z.size, size=z.size // 50)
+    z[pos] = rng.integers(1, 256, size=pos.size)
+    t0 = time.time()
+    assert sim.encode(z.tobytes(), 5, 22, 1 << 30, 0, flags=IX_LAYOUTS["groups4"]) == _oracle_plan(oracle, z.tobytes(), 1 << 30, 0)
+    assert time.time() - t0 < 60
+    z = np.zeros(260000, dtype=np.uint8)
+    pos = rng.integers(0, z.size, size=z.size // 6)
+    z[pos] = rng.integers(1, 4, size=pos.size)
+    assert sim.encode(z.tobytes(), 5, 22, 0, 0, flags=IX_LAYOUTS["groups1"]) == _oracle_plan(oracle, z.tobytes(), 0, 0)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_indexed_parse_fuzz(sim, oracle, seed):
     rng = np.random.default_rng(4000 + seed)
