@@ -47,6 +47,10 @@ struct BrotliEncoderStateStruct {
   size_t in_len, in_cap;
   uint64_t total_in, submitted;
   /* produced, not yet taken */
+  /* one FLUSH / FINISH call that brings its whole input and has room for the output: the job
+     reads the caller's input and writes the caller's output (no staging copies on the host) */
+  uint8_t* direct_out;
+  size_t direct_cap, direct_n;
   uint8_t* out_buf;
   size_t out_len, out_pos, out_cap;
   uint64_t total_out;
@@ -370,6 +374,23 @@ static int submit(BrotliEncoderState* s, int op) {
     cap = brotli_amd_max_output(s->in_len, &p);
     if (cap == 0) return 0;
     if (s->out_pos == s->out_len) s->out_pos = s->out_len = 0;
+    if (s->direct_out && s->out_len == 0) {
+      /* straight into the caller's buffer; if the result does not fit (the caller offered less
+         than the worst case), once more through the instance's own buffer */
+      const int rc = brotli_amd_encode_host(s->ctx, s->in_buf, s->in_len, &p, s->direct_out, s->direct_cap, &n, &info);
+      if (rc == BROTLI_AMD_OK) {
+        s->direct_n = (size_t)n;
+        s->submitted += s->in_len;
+        s->in_len = 0;
+        s->header_written = 1;
+        return 1;
+      }
+      if (rc != BROTLI_AMD_OVERFLOW) {
+        if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+        return 0;
+      }
+      n = 0;
+    }
     if (!grow(s, &s->out_buf, &s->out_cap, s->out_len, s->out_len + cap)) return 0;
     if (brotli_amd_encode_host(s->ctx, s->in_buf, s->in_len, &p, s->out_buf + s->out_len, cap, &n,
                                &info) != BROTLI_AMD_OK) {
@@ -583,6 +604,36 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
         s->calls_cap = nc;
       }
       s->calls[s->ncalls++] = a;
+    }
+    if (a && op != OP_PROCESS && s->in_len == 0 && a >= ((size_t)1 << 16) && s->quality != 1 &&
+        (s->shard_bytes != 0 || (s->quality != 5 && op == OP_FINISH && s->submitted == 0 && !s->stream))) {
+      /* A job (partition plan, or the one-shard job of qualities 6-9) whose whole input arrives
+         with the FLUSH / FINISH: it reads the caller's buffer, and writes the caller's output
+         buffer when nothing is waiting in front of it. */
+      uint8_t* const own = s->in_buf;
+      int ok;
+      s->in_buf = (uint8_t*)(uintptr_t)*next_in;
+      s->in_len = a;
+      s->total_in += a;
+      s->direct_out = (available_out && next_out && s->out_pos == s->out_len) ? *next_out : NULL;
+      s->direct_cap = s->direct_out ? *available_out : 0;
+      s->direct_n = 0;
+      ok = submit(s, op);
+      s->in_buf = own;
+      s->in_len = 0;
+      s->direct_out = NULL;
+      if (!ok) { s->failed = 1; return BROTLI_FALSE; }
+      *next_in += a;
+      *available_in = 0;
+      if (s->direct_n) {
+        *next_out += s->direct_n;
+        *available_out -= s->direct_n;
+        s->total_out += s->direct_n;
+        s->direct_n = 0;
+      }
+      s->stream_state = op == OP_FINISH ? ST_FINISHED : ST_FLUSH_REQUESTED;
+      push_output(s, available_out, next_out, total_out);
+      return BROTLI_TRUE;
     }
     if (a) {
       if (!grow(s, &s->in_buf, &s->in_cap, s->in_len, s->in_len + a)) return BROTLI_FALSE;

@@ -93,8 +93,9 @@ typedef struct Enc {
   uint32_t size_hint;
   size_t stream_offset;
   /* hasher (c/enc/quality.h:172-223) */
-  int hasher_type; /* 5, 6, 58, 68 */
+  int hasher_type; /* 5, 6, 58, 68; 2, 3, 4, 54 (HashLongestMatchQuickly) */
   int bucket_bits, block_bits, ndist;
+  int sweep_bits, hash_len, use_dictionary; /* the quickly family (hash.h:251-279, 329-338) */
   int hasher_setup, hasher_prepared;
   uint16_t* num;
   uint8_t* tags;
@@ -223,9 +224,17 @@ static uint32_t WrapPosition(uint64_t position) {
 static const uint32_t kHashMul32 = 0x1E35A7BD;
 static const uint64_t kHashMul64 = 0x1FE35A7BD3579BD3ull;
 
+static int HasherQuick(const Enc* s) { return s->hasher_type < 5 || s->hasher_type == 54; }
 static int HasherTagged(const Enc* s) { return s->hasher_type >= 58; }
 static int Hasher64(const Enc* s) { return s->hasher_type == 6 || s->hasher_type == 68; }
-static size_t HashTypeLength(const Enc* s) { return Hasher64(s) ? 8 : 4; }
+/* HashTypeLength == StoreLookahead: 8 for the 64-bit and the quickly hashers
+   (hash_longest_match_quickly_inc.h:17-18) */
+static size_t HashTypeLength(const Enc* s) { return (Hasher64(s) || HasherQuick(s)) ? 8 : 4; }
+/* HashBytes of the quickly family, hash_longest_match_quickly_inc.h:23-29 */
+static uint32_t QuickKey(const Enc* s, const uint8_t* p) {
+  const uint64_t h = (Load64(p) << (64 - 8 * s->hash_len)) * kHashMul64;
+  return (uint32_t)(h >> (64 - s->bucket_bits));
+}
 
 /* Returns key | tag<<32 (tag only for H58/H68).
    H68: hash_longest_match64_simd_inc.h:26-32; H58: ..._simd_inc.h:18-24;
@@ -248,6 +257,17 @@ static uint64_t HashKeyTag(const Enc* s, const uint8_t* p) {
    is 6, c/common/platform.h:666-668). */
 static int ChooseHasher(Enc* s) {
   int q = s->quality;
+  if (q >= 2 && q <= 4 && s->lgwin >= 10 && s->lgwin <= 24) {
+    /* quality.h:176-179 and the template parameters of hash.h:251-279, 329-338 */
+    s->hasher_type = (q == 4 && s->size_hint >= (1u << 20)) ? 54 : q;
+    s->bucket_bits = s->hasher_type == 54 ? 20 : s->hasher_type == 4 ? 17 : 16;
+    s->sweep_bits = s->hasher_type == 2 ? 0 : s->hasher_type == 3 ? 1 : 2;
+    s->hash_len = s->hasher_type == 54 ? 7 : 5;
+    s->use_dictionary = s->hasher_type == 2 || s->hasher_type == 4;
+    s->block_bits = 0;
+    s->ndist = 4;
+    return 1;
+  }
   if (q < 5 || q > 9 || s->lgwin <= 16 || s->lgwin > 24) return 0;
   if (s->size_hint >= (1u << 20) && s->lgwin >= 19) {
     s->hasher_type = q <= 6 ? 68 : 6;
@@ -266,6 +286,22 @@ static int ChooseHasher(Enc* s) {
    branch initialises exactly the keys that can be touched, so a full fill is
    equivalent. */
 static void HasherSetup(Enc* s) {
+  if (HasherQuick(s)) {
+    /* Prepare, hash_longest_match_quickly_inc.h:49-77: all zero (the sparse branch clears exactly
+       the slots that can be touched) */
+    const size_t nb = (size_t)1 << s->bucket_bits;
+    if (!s->hasher_setup) {
+      s->buckets = (uint32_t*)malloc(nb * 4);
+      s->dict_lookups = s->dict_matches = 0;
+      s->hasher_setup = 1;
+      s->hasher_prepared = 0;
+    }
+    if (!s->hasher_prepared) {
+      memset(s->buckets, 0, nb * 4);
+      s->hasher_prepared = 1;
+    }
+    return;
+  }
   if (!s->hasher_setup) {
     size_t nb = (size_t)1 << s->bucket_bits, bs = (size_t)1 << s->block_bits;
     s->num = (uint16_t*)malloc(nb * 2);
@@ -285,7 +321,15 @@ static void HasherSetup(Enc* s) {
 
 /* Store, ..64_simd_inc.h:114-128 / ..64_inc.h:105-115 */
 static void HStore(Enc* s, size_t ix) {
-  uint64_t kt = HashKeyTag(s, &s->rb[ix & s->rb_mask]);
+  uint64_t kt;
+  if (HasherQuick(s)) {
+    /* hash_longest_match_quickly_inc.h:93-104: the slot is wiggled by bits 3.. of the position */
+    const uint32_t key = QuickKey(s, &s->rb[ix & s->rb_mask]);
+    const uint32_t off = (uint32_t)ix & (((1u << s->sweep_bits) - 1u) << 3);
+    s->buckets[(key + off) & ((1u << s->bucket_bits) - 1u)] = (uint32_t)ix;
+    return;
+  }
+  kt = HashKeyTag(s, &s->rb[ix & s->rb_mask]);
   size_t key = (size_t)(kt & 0xFFFFFFFFu);
   uint32_t bmask = (1u << s->block_bits) - 1;
   size_t off = (s->num[key] & bmask) + (key << s->block_bits);
@@ -326,9 +370,10 @@ static void SearchInStaticDictionary(Enc* s, const uint8_t* data,
     size_t max_length, size_t max_backward, size_t max_distance,
     SearchResult* out) {
   size_t key, i;
+  const size_t nprobes = HasherQuick(s) ? 1 : 2;   /* `shallow`, hash.h:187 */
   if (s->dict_matches < (s->dict_lookups >> 7)) return;
   key = ((uint32_t)(Load32(data) * kHashMul32) >> (32 - 14)) << 1;
-  for (i = 0; i < 2; ++i, ++key) {
+  for (i = 0; i < nprobes; ++i, ++key) {
     size_t len = g_hash_lengths[key];
     s->dict_lookups++;
     if (len != 0) {
@@ -355,6 +400,83 @@ static void SearchInStaticDictionary(Enc* s, const uint8_t* data,
   }
 }
 
+/* FindLongestMatch of the quickly family, hash_longest_match_quickly_inc.h:141-262: the last
+   distance, then the bucket sweep in slot order; a candidate is looked at only if it agrees with
+   the input at offset best_len (so the outcome depends on the order), out->len comes in from the
+   caller (backward_references_inc.h:127-128). */
+static void FindLongestMatchQuick(Enc* s, size_t cur_ix, size_t max_length,
+    size_t max_backward, size_t dictionary_distance, size_t max_distance,
+    SearchResult* out) {
+  const uint8_t* data = s->rb;
+  const size_t mask = s->rb_mask;
+  const size_t cur_ix_masked = cur_ix & mask;
+  const size_t best_len_in = out->len;
+  const uint32_t bucket_mask = (1u << s->bucket_bits) - 1u;
+  const uint32_t sweep = 1u << s->sweep_bits;
+  int compare_char = data[cur_ix_masked + best_len_in];
+  const uint32_t key = QuickKey(s, &data[cur_ix_masked]);
+  const size_t min_score = out->score;
+  size_t best_score = out->score;
+  size_t best_len = best_len_in;
+  const size_t cached_backward = (size_t)s->dist_cache[0];
+  size_t prev_ix = cur_ix - cached_backward;
+  uint32_t i;
+  out->len_code_delta = 0;
+  if (prev_ix < cur_ix && cached_backward <= max_backward) {
+    prev_ix &= (uint32_t)mask;
+    if (compare_char == data[prev_ix + best_len]) {
+      const size_t len = FindMatchLength(&data[prev_ix], &data[cur_ix_masked], max_length);
+      if (len >= 4) {
+        const size_t score = ScoreLast(len);
+        if (best_score < score) {
+          out->len = len; out->distance = cached_backward; out->score = score;
+          if (sweep == 1) { s->buckets[key] = (uint32_t)cur_ix; return; }
+          best_len = len; best_score = score;
+          compare_char = data[cur_ix_masked + len];
+        }
+      }
+    }
+  }
+  if (sweep == 1) {
+    size_t backward, len;
+    prev_ix = s->buckets[key];
+    s->buckets[key] = (uint32_t)cur_ix;
+    backward = cur_ix - prev_ix;
+    prev_ix &= (uint32_t)mask;
+    if (compare_char != data[prev_ix + best_len_in]) return;
+    if (backward == 0 || backward > max_backward) return;
+    len = FindMatchLength(&data[prev_ix], &data[cur_ix_masked], max_length);
+    if (len >= 4) {
+      const size_t score = ScoreNormal(len, backward);
+      if (best_score < score) { out->len = len; out->distance = backward; out->score = score; return; }
+    }
+  } else {
+    for (i = 0; i < sweep; ++i) {
+      size_t backward, len;
+      prev_ix = s->buckets[(key + (i << 3)) & bucket_mask];
+      backward = cur_ix - prev_ix;
+      prev_ix &= (uint32_t)mask;
+      if (compare_char != data[prev_ix + best_len]) continue;
+      if (backward == 0 || backward > max_backward) continue;
+      len = FindMatchLength(&data[prev_ix], &data[cur_ix_masked], max_length);
+      if (len >= 4) {
+        const size_t score = ScoreNormal(len, backward);
+        if (best_score < score) {
+          best_len = len; best_score = score;
+          compare_char = data[cur_ix_masked + len];
+          out->len = len; out->score = score; out->distance = backward;
+        }
+      }
+    }
+  }
+  if (s->use_dictionary && min_score == out->score) {
+    SearchInStaticDictionary(s, &data[cur_ix_masked], max_length, dictionary_distance, max_distance, out);
+  }
+  if (sweep != 1) {
+    s->buckets[(key + ((uint32_t)cur_ix & ((sweep - 1u) << 3))) & bucket_mask] = (uint32_t)cur_ix;
+  }
+}
+
 /* FindLongestMatch for all four hashers: ..64_simd_inc.h:170-302,
    .._simd_inc.h:140-277, ..64_inc.h:157-277, .._inc.h. */
 static void FindLongestMatch(Enc* s, size_t cur_ix, size_t max_length,
@@ -372,6 +494,10 @@ static void FindLongestMatch(Enc* s, size_t cur_ix, size_t max_length,
   uint32_t* bucket = &s->buckets[key << s->block_bits];
   const int is64 = Hasher64(s);
   size_t i;
+  if (HasherQuick(s)) {
+    FindLongestMatchQuick(s, cur_ix, max_length, max_backward, dictionary_distance, max_distance, out);
+    return;
+  }
   out->len = 0;
   out->len_code_delta = 0;
   for (i = 0; i < (size_t)s->ndist; ++i) {
@@ -607,7 +733,7 @@ static void CreateBackwardReferences(Enc* s, size_t num_bytes, size_t position) 
       --max_length;
       for (;; --max_length) {
         SearchResult sr2;
-        sr2.len = 0; /* quality >= 5, :127-128 */
+        sr2.len = s->quality < 5 ? (sr.len - 1 < max_length ? sr.len - 1 : max_length) : 0; /* :127-128 */
         sr2.len_code_delta = 0; sr2.distance = 0; sr2.score = kMinScore;
         max_distance = position + 1 < max_backward_limit ? position + 1 : max_backward_limit;
         dictionary_start = position + 1 + position_offset < max_backward_limit ?
@@ -1610,6 +1736,103 @@ static void StoreUncompressedMetaBlock(int is_final, const uint8_t* input, size_
 /* WriteMetaBlockInternal (encode.c:498-614) for 4 <= quality < 10:
    greedy builder (metablock.c:708-839), BrotliOptimizeHistograms
    (metablock.c:841-859), BrotliStoreMetaBlock (brotli_bit_stream.c:947-1114). */
+static void BuildAndStoreHuffmanTreeFast(HTree* tree, const uint32_t* histogram,
+    size_t histogram_total, size_t max_bits, uint8_t* depth, uint16_t* bits,
+    size_t* ix, uint8_t* storage);
+static void ConvertBitDepthsToSymbols(const uint8_t* depth, size_t len, uint16_t* bits);
+static void FastStaticInit(void);
+
+/* Qualities 2 and 3: one prefix code per category, no block splitting.
+   BrotliStoreMetaBlockTrivial (brotli_bit_stream.c:1196-1240, quality 3) and
+   BrotliStoreMetaBlockFast (:1242-1314, quality 2: count-only trees; up to 128 commands the
+   command and distance codes are the static ones of entropy_encode_static.h — 448 command
+   symbols of 9 bits + 256 of 11, 64 distance symbols of 6 bits, canonical — whose serialised
+   forms are the constants of :524-541). */
+static void WriteMetaBlockSimple(Enc* s, size_t bytes, int is_last, size_t* ix, uint8_t* storage) {
+  const uint8_t* data = s->rb;
+  const size_t mask = s->rb_mask;
+  size_t pos = (size_t)s->last_flush_pos, i;
+  uint32_t lit_histo[256], cmd_histo[704], dist_histo[140];
+  uint8_t lit_depth[256], cmd_depth[704], dist_depth[140];
+  uint16_t lit_bits[256], cmd_bits[704], dist_bits[140];
+  size_t nlit = 0, ncmd = 0, ndist = 0;
+  HTree* tree = (HTree*)malloc(sizeof(HTree) * (2 * 704 + 1));
+  { /* StoreCompressedMetaBlockHeader :120-143 */
+    size_t lg = (bytes == 1) ? 1 : Log2Floor((uint32_t)(bytes - 1)) + 1;
+    size_t mnibbles = (lg < 16 ? 16 : (lg + 3)) / 4;
+    WriteBits(1, (uint64_t)is_last, ix, storage);
+    if (is_last) WriteBits(1, 0, ix, storage);
+    WriteBits(2, mnibbles - 4, ix, storage);
+    WriteBits(mnibbles * 4, bytes - 1, ix, storage);
+    if (!is_last) WriteBits(1, 0, ix, storage);
+  }
+  WriteBits(13, 0, ix, storage);
+  FastStaticInit();
+  memset(lit_histo, 0, sizeof(lit_histo));
+  memset(cmd_histo, 0, sizeof(cmd_histo));
+  memset(dist_histo, 0, sizeof(dist_histo));
+  memset(lit_depth, 0, sizeof(lit_depth));
+  memset(cmd_depth, 0, sizeof(cmd_depth));
+  memset(dist_depth, 0, sizeof(dist_depth));
+  memset(lit_bits, 0, sizeof(lit_bits));
+  memset(cmd_bits, 0, sizeof(cmd_bits));
+  memset(dist_bits, 0, sizeof(dist_bits));
+  for (i = 0; i < s->ncmds; ++i) { /* BuildHistograms :1152-1172 */
+    const Cmd c = s->cmds[i];
+    size_t j;
+    ++cmd_histo[c.cmd_prefix]; ++ncmd;
+    for (j = c.insert_len; j != 0; --j) { ++lit_histo[data[pos & mask]]; ++nlit; ++pos; }
+    pos += CmdCopyLen(&c);
+    if (CmdCopyLen(&c) && c.cmd_prefix >= 128) { ++dist_histo[c.dist_prefix & 0x3FF]; ++ndist; }
+  }
+  if (s->quality == 3) {
+    BuildAndStoreHuffmanTree(lit_histo, 256, 256, tree, lit_depth, lit_bits, ix, storage);
+    BuildAndStoreHuffmanTree(cmd_histo, 704, 704, tree, cmd_depth, cmd_bits, ix, storage);
+    BuildAndStoreHuffmanTree(dist_histo, 140, 64, tree, dist_depth, dist_bits, ix, storage);
+  } else if (s->ncmds <= 128) {
+    BuildAndStoreHuffmanTreeFast(tree, lit_histo, nlit, 8, lit_depth, lit_bits, ix, storage);
+    for (i = 0; i < 704; ++i) cmd_depth[i] = i < 448 ? 9 : 11;
+    for (i = 0; i < 64; ++i) dist_depth[i] = 6;
+    ConvertBitDepthsToSymbols(cmd_depth, 704, cmd_bits);
+    ConvertBitDepthsToSymbols(dist_depth, 64, dist_bits);
+    WriteBits(56, ((uint64_t)0x926244u << 32) | 0x16307003u, ix, storage);
+    WriteBits(3, 0, ix, storage);
+    WriteBits(28, 0x0369DC03u, ix, storage);
+  } else {
+    BuildAndStoreHuffmanTreeFast(tree, lit_histo, nlit, 8, lit_depth, lit_bits, ix, storage);
+    BuildAndStoreHuffmanTreeFast(tree, cmd_histo, ncmd, 10, cmd_depth, cmd_bits, ix, storage);
+    BuildAndStoreHuffmanTreeFast(tree, dist_histo, ndist, 6 /* Log2Floor(64 - 1) + 1 */, dist_depth, dist_bits, ix, storage);
+  }
+  free(tree);
+  pos = (size_t)s->last_flush_pos;
+  for (i = 0; i < s->ncmds; ++i) { /* StoreDataWithHuffmanCodes :1174-1207 */
+    const Cmd c = s->cmds[i];
+    size_t j;
+    WriteBits(cmd_depth[c.cmd_prefix], cmd_bits[c.cmd_prefix], ix, storage);
+    {
+      uint32_t copylen_code = CmdCopyLenCode(&c);
+      uint16_t inscode = InsertLengthCode(c.insert_len);
+      uint16_t copycode = CopyLengthCode(copylen_code);
+      uint32_t insnumextra = kInsExtra[inscode];
+      uint64_t insextraval = c.insert_len - kInsBase[inscode];
+      uint64_t copyextraval = copylen_code - kCopyBase[copycode];
+      WriteBits(insnumextra + kCopyExtra[copycode], (copyextraval << insnumextra) | insextraval, ix, storage);
+    }
+    for (j = c.insert_len; j != 0; --j) {
+      const uint8_t literal = data[pos & mask];
+      WriteBits(lit_depth[literal], lit_bits[literal], ix, storage);
+      ++pos;
+    }
+    pos += CmdCopyLen(&c);
+    if (CmdCopyLen(&c) && c.cmd_prefix >= 128) {
+      const size_t dist_code = c.dist_prefix & 0x3FF;
+      WriteBits(dist_depth[dist_code], dist_bits[dist_code], ix, storage);
+      WriteBits(c.dist_prefix >> 10, c.dist_extra, ix, storage);
+    }
+  }
+  if (is_last) { *ix = (*ix + 7u) & ~(size_t)7u; storage[*ix >> 3] = 0; }
+}
+
 static void WriteMetaBlock(Enc* s, size_t bytes, int is_last, size_t* ix, uint8_t* storage) {
   const uint8_t* data = s->rb;
   const size_t mask = s->rb_mask;
@@ -1644,6 +1867,17 @@ static void WriteMetaBlock(Enc* s, size_t bytes, int is_last, size_t* ix, uint8_
   }
   last_bytes = (uint16_t)((storage[1] << 8) | storage[0]);
   last_bytes_bits = (uint8_t)(*ix);
+  if (s->quality < 4) { /* encode.c:543-555 */
+    WriteMetaBlockSimple(s, bytes, is_last, ix, storage);
+    if (bytes + 4 < (*ix >> 3)) {
+      memcpy(s->dist_cache, s->saved_dist_cache, 4 * sizeof(int));
+      storage[0] = (uint8_t)last_bytes;
+      storage[1] = (uint8_t)(last_bytes >> 8);
+      *ix = last_bytes_bits;
+      StoreUncompressedMetaBlock(is_last, data, (size_t)last_flush_pos, mask, bytes, ix, storage);
+    }
+    return;
+  }
 
   DecideOverLiteralContextModeling(data, (size_t)last_flush_pos, bytes, mask,
       s->quality, s->size_hint, &num_contexts, &static_map);
@@ -1896,7 +2130,9 @@ static int EncodeData(Enc* s, int is_last, int force_flush) {
     const size_t max_literals = max_length / 8, max_commands = max_length / 8;
     const size_t processed_bytes = (size_t)(s->input_pos - s->last_flush_pos);
     const int next_fits = processed_bytes + ((size_t)1 << s->lgblock) <= max_length;
-    if (!is_last && !force_flush && next_fits && s->nlits < max_literals && s->ncmds < max_commands) {
+    /* no block splitting: flush once 0x2FFF symbols have gathered (encode.c:1150-1153) */
+    const int should_flush = s->quality < 4 && s->nlits + s->ncmds >= 0x2FFF;
+    if (!is_last && !force_flush && !should_flush && next_fits && s->nlits < max_literals && s->ncmds < max_commands) {
       if (UpdateLastProcessedPos(s)) s->hasher_prepared = 0;
       return 1;
     }
@@ -1949,7 +2185,7 @@ size_t oracle_encode_shard(const uint8_t* in, size_t len, int quality, int lgwin
   memcpy(s->saved_dist_cache, s->dist_cache, sizeof(s->saved_dist_cache));
   /* EnsureInitialized, encode.c:642-700 */
   s->flint = -2;
-  s->lgblock = 16;
+  s->lgblock = quality < 4 ? 14 : 16;   /* ComputeLgBlock, quality.h:75-93 */
   if (quality >= 9 && lgwin > 16) s->lgblock = lgwin < 18 ? lgwin : 18;
   if (stream_offset != 0) {
     s->flint = 2;
