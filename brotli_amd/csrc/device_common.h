@@ -36,7 +36,7 @@ DEV uint32_t wave_incl_scan(uint32_t v) {
 struct KeyTag { uint32_t key, tag, tag2; };
 
 // Bytes a hasher reads per position (HashTypeLength == StoreLookahead).
-DEV uint32_t hasher_htl(int hasher_type) { return (hasher_type == 68 || hasher_type == 6) ? 8u : 4u; }
+DEV uint32_t hasher_htl(int hasher_type) { return (hasher_type == 68 || hasher_type == 6 || hasher_type < 5 || hasher_type == 54) ? 8u : 4u; }
 
 DEV KeyTag hash_pos(uint64_t x, int hasher_type, int bucket_bits) {
   KeyTag r;

@@ -38,7 +38,7 @@ struct Command {
 struct JobParams {
   int32_t quality, lgwin, lgblock;
   uint32_t size_hint;
-  int32_t hasher_type;  // 68 (5-byte hash, 15-bit key) or 58 (4-byte hash)
+  int32_t hasher_type;  // 68 / 58 (tagged 16-slot buckets), 6 / 5 (deep buckets), 2 / 3 / 4 / 54 (quickly family)
   int32_t bucket_bits, block_bits, ndist;
   uint32_t ring_mask;           // (1 << (1 + max(lgwin, lgblock))) - 1
   uint32_t max_backward_limit;  // (1 << lgwin) - 16
@@ -50,6 +50,7 @@ struct JobParams {
   uint32_t ix_slices;           // JOB_FLAG_INDEXED: position slices per shard of the index kernels (k_index.h)
   uint32_t ix_nb_log2;          //   and log2 of the first-level buckets per shard
   uint32_t ix_bpw;              //   buckets one wave of k_ix_bucket works through (a power of two)
+  uint32_t flush_symbols;       // qualities 2 - 3: a meta-block is cut once literals + commands reach this (encode.c:1150-1153); 0 = never
 };
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
 #define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal
@@ -61,6 +62,8 @@ struct JobParams {
                                //   searches the next position in the same step (k_parse4.h)
 #define JOB_FLAG_INDEXED 64u   // quality 5: match candidates come from a position index built by data-parallel
                                //   kernels (k_index.h); the serial chain (k_chain.h) only selects
+#define JOB_FLAG_QUICK 128u    // with JOB_FLAG_DEEP: qualities 2 - 4, the HashLongestMatchQuickly family (k_parse_quick.h);
+                               //   block_bits carries BUCKET_SWEEP_BITS
 #define JOB_FLAG_DEEP 16u      // one shard per wave, 32 .. 256 slots per bucket (k_parse_deep.h)
 
 // Per-shard description written by the host.

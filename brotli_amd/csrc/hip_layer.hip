@@ -183,7 +183,7 @@ bool prepare_tables(BrotliAmdCtx* c, JobPlan* plan) {
   const uint64_t TABLE_CHUNK = 16ull << 30;
   const bool indexed = (plan->J.flags & JOB_FLAG_INDEXED) != 0;
   const uint64_t tbytes = indexed ? c->ix_region_bytes : (uint64_t)plan->J.rec_bytes << plan->J.bucket_bits;
-  const uint64_t nbytes = (plan->J.flags & JOB_FLAG_DEEP) ? ((uint64_t)2 << plan->J.bucket_bits) : 0;
+  const uint64_t nbytes = ((plan->J.flags & (JOB_FLAG_DEEP | JOB_FLAG_QUICK)) == JOB_FLAG_DEEP) ? ((uint64_t)2 << plan->J.bucket_bits) : 0;
   const uint64_t per = tbytes + nbytes;            // records, then the counters of the same shard
                                                    // (indexed job: the shard's index region instead)
   const uint64_t n = plan->shards.size();
@@ -345,7 +345,9 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
   for (;;) {
     HIP_OK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
     HIP_OK(c, hipEventRecord(c->ev[2], c->stream));
-    if (plan.J.flags & JOB_FLAG_DEEP) {
+    if (plan.J.flags & JOB_FLAG_QUICK) {
+      hipLaunchKernelGGL(k_parse_quick, dim3(nshards), dim3(64), 0, c->stream, a);
+    } else if (plan.J.flags & JOB_FLAG_DEEP) {
       if (plan.J.block_bits <= 6) hipLaunchKernelGGL(k_parse_deep<1>, dim3(nshards), dim3(64), 0, c->stream, a);
       else if (plan.J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(nshards), dim3(64), 0, c->stream, a);
       else hipLaunchKernelGGL(k_parse_deep<4>, dim3(nshards), dim3(64), 0, c->stream, a);
@@ -832,7 +834,8 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
   for (uint64_t round = 0;; ++round) {
     if (round > (s->fed >> 10) + 64) return fail(c, "stream rounds do not converge (device fault)");
     HIP_OK(c, hipMemsetAsync(s->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
-    if (!(J.flags & JOB_FLAG_DEEP)) hipLaunchKernelGGL(k_parse, dim3(1), dim3(64), 0, c->stream, a);
+    if (J.flags & JOB_FLAG_QUICK) hipLaunchKernelGGL(k_parse_quick, dim3(1), dim3(64), 0, c->stream, a);
+    else if (!(J.flags & JOB_FLAG_DEEP)) hipLaunchKernelGGL(k_parse, dim3(1), dim3(64), 0, c->stream, a);
     else if (J.block_bits <= 6) hipLaunchKernelGGL(k_parse_deep<1>, dim3(1), dim3(64), 0, c->stream, a);
     else if (J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(1), dim3(64), 0, c->stream, a);
     else hipLaunchKernelGGL(k_parse_deep<4>, dim3(1), dim3(64), 0, c->stream, a);

@@ -30,23 +30,35 @@ static inline uint64_t plan_align(uint64_t x) { return (x + 255u) & ~(uint64_t)2
 // parameter combinations this library does not implement on the GPU.
 static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobParams* J) {
   memset(J, 0, sizeof(*J));
-  if (quality < 5 || quality > 9) return false;      // q0-4 / q10-11: other algorithms
-  if (lgwin < 17 || lgwin > 24) return false;        // H40-42 / large window: out of scope
+  if (quality < 2 || quality > 9) return false;      // q0-1: k_fast.h; q10-11: other algorithms
+  if (lgwin > 24) return false;                      // large window: out of scope
+  if (quality >= 5 ? lgwin < 17 : lgwin < 10) return false;   // H40-42 (q5-9 at lgwin <= 16): out of scope
   J->quality = quality;
   J->lgwin = lgwin;
-  J->lgblock = 16;                                   // ComputeLgBlock, quality.h:75-92
+  J->lgblock = quality < 4 ? 14 : 16;                // ComputeLgBlock, quality.h:75-92
   if (quality >= 9) J->lgblock = lgwin < 18 ? lgwin : 18;
   J->size_hint = size_hint;
-  if (size_hint >= (1u << 20) && lgwin >= 19) {      // ChooseHasher, quality.h:186-204
+  if (quality < 5) {
+    // the quickly family: quality.h:176-179, template parameters hash.h:251-279, 329-338
+    J->hasher_type = (quality == 4 && size_hint >= (1u << 20)) ? 54 : quality;
+    J->bucket_bits = J->hasher_type == 54 ? 20 : J->hasher_type == 4 ? 17 : 16;
+    J->block_bits = J->hasher_type == 2 ? 0 : J->hasher_type == 3 ? 1 : 2;   // BUCKET_SWEEP_BITS
+    J->ndist = 4;
+    J->rec_bytes = 4;
+    J->flush_symbols = quality < 4 ? 0x2FFFu : 0u;   // MAX_NUM_DELAYED_SYMBOLS, quality.h:33
+    J->flags |= JOB_FLAG_DEEP | JOB_FLAG_QUICK;
+  } else if (size_hint >= (1u << 20) && lgwin >= 19) {      // ChooseHasher, quality.h:186-204
     J->hasher_type = quality <= 6 ? 68 : 6;
     J->bucket_bits = 15;
   } else {
     J->hasher_type = quality <= 6 ? 58 : 5;
     J->bucket_bits = quality < 7 ? 14 : 15;
   }
-  J->block_bits = quality - 1;
-  J->ndist = quality < 7 ? 4 : quality < 9 ? 10 : 16;
-  J->rec_bytes = quality == 5 ? REC_BYTES : (8u << J->block_bits);
+  if (quality >= 5) {
+    J->block_bits = quality - 1;
+    J->ndist = quality < 7 ? 4 : quality < 9 ? 10 : 16;
+    J->rec_bytes = quality == 5 ? REC_BYTES : (8u << J->block_bits);
+  }
   const int rb_bits = 1 + (lgwin > J->lgblock ? lgwin : J->lgblock);
   J->ring_mask = (1u << rb_bits) - 1u;
   J->max_backward_limit = (1u << lgwin) - 16u;

@@ -309,6 +309,9 @@ DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
   uint16_t* blkmap = (uint16_t*)(b.mb + b.L.blkmap[CAT]);
   uint32_t* G = (uint32_t*)(b.mb + b.L.histos[CAT]);
   uint32_t* cur = b.lds;
+  // qualities 2 - 3 do not split (BrotliStoreMetaBlockTrivial / Fast, brotli_bit_stream.c:1196-1314):
+  // everything lands in the one block the final decision opens
+  const bool single = b.J->quality < 4;
 
   for (uint32_t k = (uint32_t)lane; k < nc * ROW; k += 64) cur[k] = 0;
   wave_sync();
@@ -469,7 +472,7 @@ DEV void run_splitter(BuildCtx& b, uint32_t nsym) {
     wave_sync();
     block_size += n;
     ++chunk_hi;
-    if (block_size == target) finish(false);
+    if (!single && block_size == target) finish(false);
   }
   finish(true);
 
@@ -593,6 +596,7 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   run_splitter<2>(b, ndist);
   BP_ADD(S, 4, bpt);
 
+  if (J.quality < 4) { wave_sync(); BP_ADD(S, 5, bpt); return; }   // encode.c:587: from quality 4 on
   // BrotliOptimizeHistograms: one lane per histogram, but on LDS copies (the
   // smoothing is a serial scan with data-dependent rewrites: ~5 passes of
   // dependent accesses per entry).  Batches of as many histograms as fit the

@@ -301,8 +301,9 @@ DEV void q_dict_search(const JobParams& J, const DeviceTables* T, QShard& g, boo
   const bool go = want && !(g.dict_matches < (g.dict_lookups >> 7));
   if (!wave_any(go)) return;
   SIM_COUNT(4, 1);                                     // dictionary probes (wave level)
+  const int nprobes = (J.hasher_type < 5 || J.hasher_type == 54) ? 1 : 2;   // `shallow`, hash.h:187
   uint32_t matchlen = 0, wlen = 0, widx = 0;
-  if (go && t < 2) {
+  if (go && t < nprobes) {
     const uint32_t key = (((ld32(g.data + P) * 0x1E35A7BDu) >> (32 - 14)) << 1) + (uint32_t)t;
     wlen = T->dict_hash_lengths[key];
     widx = T->dict_hash_words[key];
@@ -312,7 +313,7 @@ DEV void q_dict_search(const JobParams& J, const DeviceTables* T, QShard& g, boo
     }
   }
   const uint32_t dictionary_start = umin(P + g.stream_offset, J.max_backward_limit);
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < nprobes; ++i) {
     const uint32_t len = q_from(wlen, i), word_idx = q_from(widx, i), ml = q_from(matchlen, i);
     if (!go) continue;
     g.dict_lookups++;
@@ -550,7 +551,9 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
   {
     const uint32_t processed = r.input_pos - r.last_flush_pos;
     const bool next_fits = processed + block <= J.max_metablock_size;
-    if (!is_last && !force_flush && next_fits && r.nlits < J.max_literals && r.ncmds < J.max_commands) {
+    // without block splitting a meta-block is cut as soon as enough symbols have gathered (:1150-1153)
+    const bool should_flush = J.flush_symbols != 0u && r.nlits + r.ncmds >= J.flush_symbols;
+    if (!is_last && !force_flush && !should_flush && next_fits && r.nlits < J.max_literals && r.ncmds < J.max_commands) {
       // (a block without bytes and without an operation to carry out would come back here
       // forever: an unknown final_op — fail instead of spinning)
       if (g.blk_bytes == 0 && avail == 0) { g.status |= QST_ERROR | QST_DONE; g.state = Q_DONE; return; }

@@ -504,13 +504,15 @@ DEV void pfx_build_and_append(const uint32_t* histo, uint32_t n, uint32_t max_bi
 }
 
 // The store kernel's job: one code into its own 512-byte buffer `buf`; returns its bits.
+// (Q1: the count-only builder — quality 2's BrotliStoreMetaBlockFast uses it for all three codes.)
+template <bool Q1 = false>
 DEV uint32_t pfx_build_and_store(const uint32_t* histo, uint32_t n, uint32_t alphabet_size, uint32_t* P,
                                  uint8_t* depth8, uint16_t* bits16, uint8_t* buf) {
   const uint32_t lane = (uint32_t)wave_lane();
   uint32_t* bitbuf = P + PFX_BITBUF;
   uint32_t max_bits = 0, bitpos = 0;
   for (uint32_t c = alphabet_size - 1u; c != 0; c >>= 1) ++max_bits;
-  pfx_build_and_append<false>(histo, n, max_bits, P, depth8, bits16, bitbuf, bitpos, true);
+  pfx_build_and_append<Q1>(histo, n, max_bits, P, depth8, bits16, bitbuf, bitpos, true);
   for (uint32_t i = lane; i < (bitpos + 31u) / 32u; i += 64u) st32(buf + 4u * i, bitbuf[i]);
   wave_sync();
   return bitpos;

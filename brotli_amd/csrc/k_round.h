@@ -280,10 +280,12 @@ DEV void init_shard_state(const JobParams& J, const ShardDesc& D, ShardState* S)
     s.flint = -2;
     s.dist_cache[0] = 4; s.dist_cache[1] = 11; s.dist_cache[2] = 15; s.dist_cache[3] = 16;
     for (int i = 0; i < 4; ++i) s.saved_dist_cache[i] = s.dist_cache[i];
-    // EncodeWindowBits, encode.c:191-211 (lgwin 17..24, no large window)
+    // EncodeWindowBits, encode.c:191-211 (lgwin 10..24, no large window)
     if (J.flags & JOB_FLAG_NO_HEADER) { s.last_bytes = 0; s.last_bytes_bits = 0; }
+    else if (J.lgwin == 16) { s.last_bytes = 0; s.last_bytes_bits = 1; }
     else if (J.lgwin == 17) { s.last_bytes = 1; s.last_bytes_bits = 7; }
-    else { s.last_bytes = (uint32_t)(((J.lgwin - 17) << 1) | 1); s.last_bytes_bits = 4; }
+    else if (J.lgwin > 17) { s.last_bytes = (uint32_t)(((J.lgwin - 17) << 1) | 1); s.last_bytes_bits = 4; }
+    else { s.last_bytes = (uint32_t)(((J.lgwin - 8) << 4) | 1); s.last_bytes_bits = 7; }
   }
   *S = s;
 }

@@ -383,7 +383,29 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
         length = alpha[c];
       }
       uint32_t nb = 0;
-      if (!skip) {
+      if (!skip && J.quality == 2 && j >= 8) {
+        // BrotliStoreMetaBlockFast (brotli_bit_stream.c:1242-1314): count-only trees; up to 128
+        // commands the command and distance codes are the static ones (entropy_encode_static.h:
+        // 448 command symbols of 9 bits + 256 of 11, 64 distance symbols of 6 bits, canonical,
+        // bits reversed; their serialised forms are the constants of :524-541)
+        uint8_t* buf = tree_bufs + (size_t)j * MB_TREE_BUF_BYTES;
+        if (j == 8 || ncmds > 128u) {
+          nb = pfx_build_and_store<true>(histo, length, length, lds_store, depth, bits, buf);
+        } else if (j == 9) {
+          for (uint32_t i = (uint32_t)lane; i < 704u; i += 64) {
+            const uint32_t code = i < 448u ? i : 1792u + (i - 448u), nbits = i < 448u ? 9u : 11u;
+            depth[i] = (uint8_t)nbits;
+            bits[i] = (uint16_t)(dev_bitrev32(code) >> (32u - nbits));
+          }
+          if (lane == 0) { st32(buf, 0x16307003u); st32(buf + 4, 0x00926244u); }
+          nb = 59;
+        } else {
+          if (lane < 64) { depth[lane] = 6; bits[lane] = (uint16_t)(dev_bitrev32((uint32_t)lane) >> 26); }
+          if (lane == 0) st32(buf, 0x0369DC03u);
+          nb = 28;
+        }
+        wave_sync();
+      } else if (!skip) {
         nb = pfx_build_and_store(histo, length, length, lds_store, depth, bits,
                                  tree_bufs + (size_t)j * MB_TREE_BUF_BYTES);
       }
@@ -442,7 +464,8 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     }
     sink_put(sink, 2, 0);   // NPOSTFIX
     sink_put(sink, 4, 0);   // NDIRECT >> NPOSTFIX
-    for (uint32_t i = 0; i < ntypes[0]; ++i) sink_put(sink, 2, 2);   // CONTEXT_UTF8
+    // CONTEXT_UTF8 (encode.c:486-496); the writers of qualities 2 - 3 leave the field zero ("13 zero bits")
+    for (uint32_t i = 0; i < ntypes[0]; ++i) sink_put(sink, 2, J.quality < 4 ? 0 : 2);
     if (s.nc == 1) {
       // StoreTrivialContextMap(num literal histograms, 6 context bits)
       sink_varlen_uint8(sink, nhist[0] - 1u);

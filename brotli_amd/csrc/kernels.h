@@ -7,6 +7,7 @@
 #include "k_round.h"
 #include "k_parse4.h"
 #include "k_parse_deep.h"
+#include "k_parse_quick.h"
 #include "k_index.h"
 #include "k_chain.h"
 
@@ -49,6 +50,11 @@ __global__ void __launch_bounds__(256) k_init(JobArgs a) {
   const ShardDesc& D = a.shards[shard];
   if (a.J.flags & JOB_FLAG_INDEXED) {
     // no hash table: the index kernels clear what they use
+  } else if (a.J.flags & JOB_FLAG_QUICK) {
+    // Prepare, hash_longest_match_quickly_inc.h:49-77: every slot holds position 0
+    uint32_t* table = (uint32_t*)(a.ws + D.table_off);
+    for (uint32_t p = b * blockDim.x + threadIdx.x; p < (1u << a.J.bucket_bits);
+         p += a.init_blocks_per_shard * blockDim.x) table[p] = 0u;
   } else if (a.J.flags & JOB_FLAG_DEEP) {
     // only the counters: 0xFFFF counting down (H68 / H58), 0 counting up (H5 / H6)
     uint32_t* nums = (uint32_t*)(a.ws + D.num_off);
@@ -158,6 +164,14 @@ __global__ void __launch_bounds__(64, 2) k_parse_deep(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
   parse_deep_round<E>(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds_dup);
+  if (threadIdx.x == 0 && a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
+}
+
+// grid = nshards, block = 64: one shard per wave (qualities 2 - 4).
+__global__ void __launch_bounds__(64) k_parse_quick(JobArgs a) {
+  const uint32_t shard = blockIdx.x;
+  if (shard >= a.nshards) return;
+  parse_quick_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
   if (threadIdx.x == 0 && a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
 }
 

@@ -26,6 +26,17 @@ CASES = [
     ({"kind": "repeat", "unit": "abcdefgh", "size": 333333}, 5, 22, 100000),
     ({"kind": "text", "size": 1 << 20, "seed": 11}, 9, 24, 0),
     ({"kind": "text", "size": 1 << 20, "seed": 11}, 7, 22, 1 << 18),
+    # qualities 2 - 4: the quickly hashers (H54 at quality 4 from a MiB on), trivial / fast writers
+    ({"kind": "file", "name": "alice29.txt"}, 2, 22, 0),
+    ({"kind": "file", "name": "alice29.txt"}, 3, 22, 0),
+    ({"kind": "file", "name": "alice29.txt"}, 4, 22, 0),
+    ({"kind": "file", "name": "alice29.txt"}, 4, 16, 65536),
+    ({"kind": "text", "size": 1 << 20, "seed": 11}, 2, 22, 1 << 18),
+    ({"kind": "text", "size": 1 << 20, "seed": 11}, 3, 18, 0),
+    ({"kind": "text", "size": 1 << 20, "seed": 11}, 4, 22, 1 << 17),
+    ({"kind": "mixed", "size": 2 << 20, "seed": 9}, 4, 24, 1 << 19),
+    ({"kind": "mixed", "size": 1 << 20, "seed": 9}, 2, 10, 0),
+    ({"kind": "random", "size": 1 << 18, "seed": 1}, 3, 22, 1 << 16),
 ]
 
 

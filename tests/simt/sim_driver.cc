@@ -30,7 +30,9 @@ void run_index(const JobArgs& a, int reverse) {
   run(k_ix_bucket, a, ((a.nshards + 7u) / 8u) * 8u * ((1u << a.J.ix_nb_log2) / a.J.ix_bpw), 64, reverse);
 }
 void run_parse_kernel(const JobArgs& a, int reverse) {
-  if (a.J.flags & JOB_FLAG_DEEP) {
+  if (a.J.flags & JOB_FLAG_QUICK) {
+    run(k_parse_quick, a, a.nshards, 64, reverse);
+  } else if (a.J.flags & JOB_FLAG_DEEP) {
     if (a.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
     else if (a.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
     else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
@@ -302,7 +304,6 @@ long sim_stream(const char* tables_path, const uint8_t* in, size_t len, int qual
     const int op = call_ops[k];
     if (pos + n > len) return -2;
     if (op != 3) { memcpy(input.data() + fed, in + pos, n); fed += n; }
-    if ((J.flags & JOB_FLAG_DEEP) && fed > J.max_backward_limit) return -6;
     D.len = (uint32_t)fed;
     D.final_op = (uint32_t)op;
     state.done = 0;
@@ -311,7 +312,8 @@ long sim_stream(const char* tables_path, const uint8_t* in, size_t len, int qual
     for (;; ++round) {
       if (round > 4096) return -5;
       memset(counters, 0, sizeof(counters));
-      if (!(J.flags & JOB_FLAG_DEEP)) run(k_parse, a, 1, 64, reverse);
+      if (J.flags & JOB_FLAG_QUICK) run(k_parse_quick, a, 1, 64, reverse);
+      else if (!(J.flags & JOB_FLAG_DEEP)) run(k_parse, a, 1, 64, reverse);
       else if (J.block_bits <= 6) run(k_parse_deep<1>, a, 1, 64, reverse);
       else if (J.block_bits == 7) run(k_parse_deep<2>, a, 1, 64, reverse);
       else run(k_parse_deep<4>, a, 1, 64, reverse);

@@ -55,7 +55,9 @@ long run_plan_on_sim(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* in, size_t l
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
   for (int round = 0; round < 100000; ++round) {
     memset(counters, 0, sizeof(counters));
-    if (plan.J.flags & JOB_FLAG_DEEP) {
+    if (plan.J.flags & JOB_FLAG_QUICK) {
+      run(k_parse_quick, a, a.nshards, 64, 0);
+    } else if (plan.J.flags & JOB_FLAG_DEEP) {
       if (plan.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, 0);
       else if (plan.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, 0);
       else run(k_parse_deep<4>, a, a.nshards, 64, 0);
@@ -213,7 +215,8 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
   for (uint64_t round = 0;; ++round) {
     if (round > (s->fed >> 10) + 64) return set_err(c, "stream rounds do not converge (device fault)", BROTLI_AMD_ERROR);
     memset(s->counters, 0, sizeof(s->counters));
-    if (!(J.flags & JOB_FLAG_DEEP)) run(k_parse, a, 1, 64, 0);
+    if (J.flags & JOB_FLAG_QUICK) run(k_parse_quick, a, 1, 64, 0);
+    else if (!(J.flags & JOB_FLAG_DEEP)) run(k_parse, a, 1, 64, 0);
     else if (J.block_bits <= 6) run(k_parse_deep<1>, a, 1, 64, 0);
     else if (J.block_bits == 7) run(k_parse_deep<2>, a, 1, 64, 0);
     else run(k_parse_deep<4>, a, 1, 64, 0);

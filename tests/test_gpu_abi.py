@@ -116,7 +116,7 @@ def test_one_shot_empty_and_small_buffer(amd):
     assert not amd.BrotliEncoderCompress(5, 22, 0, len(ALICE), ALICE, C.byref(n), out)
 
 
-@pytest.mark.parametrize("quality,lgwin", [(6, 22), (9, 24)])
+@pytest.mark.parametrize("quality,lgwin", [(6, 22), (9, 24), (2, 22), (3, 22), (4, 22), (4, 16), (2, 10)])
 def test_one_shot_deep_quality_equals_reference(amd, stock, quality, lgwin):
     data = G.enwik_text(1 << 20, seed=29, vocab=10000)
     outs = []
@@ -127,6 +127,25 @@ def test_one_shot_deep_quality_equals_reference(amd, stock, quality, lgwin):
         assert L.BrotliEncoderCompress(quality, lgwin, 0, len(data), data, C.byref(n), out)
         outs.append(out.raw[:n.value])
     assert outs[0] == outs[1]
+
+
+@pytest.mark.parametrize("quality,lgwin", [(2, 22), (3, 18), (4, 22)])
+def test_stream_sequences_at_qualities_2_to_4_equal_reference(amd, stock, quality, lgwin):
+    """One encoder instance (the device stream over k_parse_quick) driven with PROCESS / FLUSH /
+    FINISH shapes, TakeOutput and a metadata block, against the stock library."""
+    data = G.enwik_text(400000, seed=31, vocab=10000)
+    params = ((1, quality), (2, lgwin))
+    for ops, take in ((_chunks(len(data), 50000, 2), False), (_chunks(len(data), 30000, 2, 3), True),
+                      ([(0, 1)] + _chunks(len(data), 150000, 2), False)):
+        want, fin_w = drive(stock, data, ops, params, take=take)
+        got, fin_g = drive(amd, data, ops, params, take=take)
+        assert fin_w and fin_g and got == want, (quality, ops[:3])
+    meta = bytes(range(100))
+    d2 = data[:100000] + meta + data[100000:300000]
+    ops = [(100000, 0), (len(meta), 3), (200000, 2)]
+    want, _ = drive(stock, d2, ops, params)
+    got, fin = drive(amd, d2, ops, params)
+    assert fin and got == want
 
 
 def test_unsupported_quality_fails_loudly(amd):

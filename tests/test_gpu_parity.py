@@ -91,7 +91,7 @@ def test_golden_vectors(ctx):
     gold = json.load(open(os.path.join(HERE, "golden", "golden.json")))
     n = 0
     for case in gold["cases"]:
-        if case["quality"] not in range(5, 10) or case["lgwin"] not in range(17, 25):
+        if case["quality"] not in range(2, 10) or case["lgwin"] not in range(17 if case["quality"] >= 5 else 10, 25):
             continue
         data = G.make(case["input"])
         if len(data) == 0:
@@ -129,6 +129,26 @@ def test_other_windows(ctx, oracle, lgwin):
         parts.append(oracle.encode_shard(data[off:off + m], 5, lgwin, n, off, off + m == n))
         off += m
     assert got == b"".join(parts)
+
+
+@pytest.mark.parametrize("quality,lgwin,shard", [(2, 22, 1 << 17), (2, 18, 0), (3, 22, 1 << 18), (3, 16, 0), (4, 22, 1 << 17),
+                                                 (4, 24, 0), (4, 10, 100000), (2, 10, 0)])
+@pytest.mark.parametrize("name", ["text", "mixed", "text_rand_text", "zeros", "tiny"])
+def test_qualities_2_to_4_equal_oracle(ctx, oracle, name, quality, lgwin, shard):
+    """k_parse_quick.h (H2 / H3 / H4 / H54) with the single-block build and the trivial / fast
+    meta-block writers: partition plans and single streams, windows from 10 to 24 bits."""
+    from brotli_amd import hip
+    data = {"text": TEXT4M[:(2 << 20) + 777], "mixed": G.mixed_corpus(2 << 20),
+            "text_rand_text": TEXT4M[:200000] + G.random_bytes(150000) + TEXT4M[:100000],
+            "zeros": bytes(300000), "tiny": b"hello hello hello hello"}[name]
+    if len(data) < 1000 and shard:
+        pytest.skip("one shard")
+    got, info = ctx.encode_host(data, hip.make_params(quality, lgwin, shard))
+    n = len(data)
+    s = shard or n
+    want = b"".join(oracle.encode_shard(data[o:o + s], quality, lgwin, min(n, 1 << 30), o, o + s >= n)
+                    for o in range(0, n, s))
+    assert got == want
 
 
 @pytest.mark.parametrize("quality,lgwin,shard", [(6, 22, 1 << 18), (7, 22, 1 << 18), (8, 20, 1 << 17),
@@ -177,7 +197,7 @@ def test_unsupported_parameters_fail_loudly(ctx):
     with pytest.raises(hip.BrotliAmdError):
         ctx.encode_host(b"hello world", hip.make_params(11, 22, 0))
     with pytest.raises(hip.BrotliAmdError):
-        ctx.encode_host(b"hello world", hip.make_params(3, 22, 0))
+        ctx.encode_host(b"hello world", hip.make_params(10, 22, 0))
     with pytest.raises(hip.BrotliAmdError):
         ctx.encode_host(b"hello world", hip.make_params(5, 30, 0))
 

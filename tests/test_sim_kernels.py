@@ -366,6 +366,58 @@ def _stream_chunks(n, size, flush_every=0):
     return ops
 
 
+# ---- qualities 2 - 4 (k_parse_quick.h; single-block / count-only tree modes of k_build / k_store) ----
+def _plan_q(oracle, data, quality, lgwin, hint, shard):
+    n = len(data)
+    shard = shard or n
+    parts, off = [], 0
+    while off < n:
+        m = min(shard, n - off)
+        parts.append(oracle.encode_shard(data[off:off + m], quality, lgwin, hint or n, min(off, 1 << 30), off + m == n))
+        off += m
+    return b"".join(parts)
+
+
+QUICK_TEXT = G.enwik_text(140000, seed=4, vocab=20000)
+QUICK_CASES = {
+    "text": QUICK_TEXT,
+    "mixed": G.mixed_corpus(120000),
+    "random": G.random_bytes(40000, seed=1),
+    "zeros": bytes(100000),
+    "rle": (b"abcdefgh" * 20000)[:111111],
+    "text_rand": QUICK_TEXT[:50000] + G.random_bytes(30000, seed=2) + QUICK_TEXT[:40000],
+    "x64": b"x" * 64,
+    "t3": b"xyz",
+    "t9": b"123456789",
+    "hello": b"hello hello hello hello",       # quality 2 with <= 128 commands: the static command / distance codes
+}
+
+
+@pytest.mark.parametrize("name", list(QUICK_CASES))
+@pytest.mark.parametrize("quality", [2, 3, 4])
+def test_quick_hashers_bytes_match_oracle(sim, oracle, name, quality):
+    """H2 / H3 / H4 (H54 once a MiB is announced), the lazy probe seeded with the length to beat,
+    16 KiB input blocks and the early cut at qualities 2 - 3, one prefix code per category
+    (count-only trees or the static codes at quality 2): one stream, shards with STREAM_OFFSET,
+    windows below the shard length (10, 16 bits) and the largest one."""
+    data = QUICK_CASES[name]
+    for lgwin, hint, shard in ((22, 0, 0), (18, 1 << 30, 50000), (16, 0, 0), (10, 0, 0), (24, 1 << 30, 0)):
+        if shard and len(data) < 1000:
+            continue
+        want = _plan_q(oracle, data, quality, lgwin, hint, shard)
+        assert sim.encode(data, quality, lgwin, hint or len(data), shard) == want, (lgwin, hint, shard)
+
+
+@pytest.mark.parametrize("quality,lgwin", [(2, 22), (3, 18), (4, 22), (4, 16)])
+def test_quick_stream_call_sequences_equal_reference(sim, ref, quality, lgwin):
+    """One encoder instance at qualities 2 - 4 resumed call after call (PROCESS, FLUSH, FINISH)."""
+    text = G.enwik_text(120000, seed=54, vocab=20000)
+    for hint in (1 << 20, 0):
+        for calls in (_stream_chunks(len(text), 30000), _stream_chunks(len(text), 17000, 3)):
+            want = ref.encode_calls(text, quality, lgwin, calls, size_hint=hint)
+            assert sim.stream(text, calls, quality, lgwin, size_hint=hint) == want, (quality, hint, calls[:3])
+
+
 @pytest.mark.parametrize("quality,lgwin", [(9, 24)])      # (5, 22) and (6, 22): tests/test_abi_on_sim.py
 def test_stream_call_sequences_equal_reference(sim, ref, quality, lgwin):
     """k_parse (quality 5) / k_parse_deep (6-9) resumed call after call with the state the
