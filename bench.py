@@ -38,7 +38,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 # SURVEY.md §8(d) models: q5 / H68 48 B per input byte; q9 / H6 0.47 KiB.
-ALGO_BYTES_PER_INPUT_BYTE = {5: 48.0, 6: 48.0, 7: 481.0, 8: 481.0, 9: 481.0}
+# (qualities 2 - 4: one 4-byte slot written per stored position, 1 << sweep_bits slots and as many 32-byte
+#  candidate reads per searched position, about every third position searched)
+ALGO_BYTES_PER_INPUT_BYTE = {2: 20.0, 3: 32.0, 4: 56.0, 5: 48.0, 6: 48.0, 7: 481.0, 8: 481.0, 9: 481.0}
 # k_ix_bucket per position (= per input byte): entry 4 B in, the input byte itself 1 B in (the 16-byte
 # gathers hit the L2), srt 4 B + res 8 B out
 IX_BUCKET_BYTES_PER_INPUT_BYTE = 17.0
@@ -394,7 +396,7 @@ def main():
         if indexed and ms_ixb >= ms_parse:
             kernel, k_ms, k_bytes = "k_ix_bucket", ms_ixb, IX_BUCKET_BYTES_PER_INPUT_BYTE
         else:
-            kernel = "k_chain" if indexed else ("k_parse4" if args.quality == 5 else "k_parse_deep")
+            kernel = "k_chain" if indexed else ("k_parse4" if args.quality == 5 else "k_parse_quick" if args.quality < 5 else "k_parse_deep")
             k_ms, k_bytes = ms_parse, (algo if not indexed else 9.0 + 16.0 * 0.4)
         achieved = k_bytes * n / (k_ms / 1e3) / 1e9
         # HBM bytes of the dominant kernel: NOT measured by this run — a constant from PMC passes of a

@@ -18,7 +18,8 @@
 // decide, so the outcome is not an arg-max: the walk is replayed here step by step, uniformly,
 // reading the deciding byte from the candidate's mask (or, beyond 32 bytes, from memory).
 // Insertions are positions in increasing order over the whole shard, so a StoreRange is one
-// atomic max per position, 64 positions at a time.
+// atomic max per position, 64 positions at a time; the searches read the table through the L2
+// (where the atomics land), which keeps a wave's accesses to a slot in order without fences.
 #ifndef BROTLI_AMD_CSRC_K_PARSE_QUICK_H_
 #define BROTLI_AMD_CSRC_K_PARSE_QUICK_H_
 
@@ -61,7 +62,7 @@ DEV void k_drain_stores(const JobParams& J, const QuickGeom& G, QShard& g) {
       glb_atomic_max(&table[quick_slot(G, quick_key(G, ld64(g.data + pos)), pos)], pos);
     }
   }
-  wave_mem_barrier();
+  wave_sync();     // (the table is read through the L2 as well: no fence, the wave's accesses to a word stay in order)
   g.st_count = 0;
 }
 
@@ -90,7 +91,7 @@ DEV QResult k_search(const JobParams& J, const QuickGeom& G, const DeviceTables*
     valid = g.dc[0] > 0 && backward <= P && backward <= max_backward;     // prev_ix < cur_ix (:159)
     prev = P - backward;
   } else if ((uint32_t)lane <= G.sweep) {
-    prev = table[(key + (((uint32_t)lane - 1u) << 3)) & G.mask];
+    prev = glb_load_l2(&table[(key + (((uint32_t)lane - 1u) << 3)) & G.mask]);
     backward = P - prev;
     valid = backward != 0u && backward <= max_backward;
   }
@@ -156,7 +157,7 @@ DEV QResult k_search(const JobParams& J, const QuickGeom& G, const DeviceTables*
     wave_sync();
     if (lane == 0) table[quick_slot(G, key, P)] = P;
   }
-  wave_mem_barrier();
+  wave_sync();
   return out;
 }
 

@@ -36,6 +36,7 @@ template <class T> static inline T lds_atomic_or(T* p, T v) { T o = *p; *p = o |
 static inline uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 static inline uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t glb_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
+static inline uint32_t glb_load_l2(const uint32_t* p) { return *p; }
 static inline uint32_t dev_bitrev32(uint32_t x) {
   x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
   x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
@@ -130,6 +131,10 @@ template <class T> __device__ __forceinline__ T lds_atomic_or(T* p, T v) { retur
 __device__ __forceinline__ uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 __device__ __forceinline__ uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
 __device__ __forceinline__ uint32_t glb_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
+// A load served by the L2 (not the CU's L1): sees this wave's earlier atomics on the same word.
+__device__ __forceinline__ uint32_t glb_load_l2(const uint32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint32_t dev_bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
 // Lanes [0, n) hold v: prev = highest lane below this one with the same v (-1 if

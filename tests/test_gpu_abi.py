@@ -72,6 +72,7 @@ def drive(L, data, ops, params=(), out_chunk=1 << 16, take=False):
                 next_out = C.c_void_p(C.addressof(out))
             assert L.BrotliEncoderCompressStream(st, op, C.byref(avail_in), C.byref(next_in),
                                                  C.byref(avail_out), C.byref(next_out), None)
+            took = 0
             if take:
                 while True:
                     sz = C.c_size_t(0)
@@ -79,9 +80,14 @@ def drive(L, data, ops, params=(), out_chunk=1 << 16, take=False):
                     if not sz.value:
                         break
                     res += C.string_at(p, sz.value)
+                    took += sz.value
             else:
                 res += out.raw[:out_chunk - avail_out.value]
-            if avail_in.value == 0 and not L.BrotliEncoderHasMoreOutput(st):
+            # TakeOutput style: the reference does not encode while output is waiting (encode.c:
+            # 1694-1697), so a call that handed something over may have left its operation
+            # unfinished (at qualities 2 - 3 meta-blocks leave in the middle of a call): the
+            # caller repeats the operation until a call yields nothing
+            if avail_in.value == 0 and not L.BrotliEncoderHasMoreOutput(st) and took == 0:
                 break
     fin = bool(L.BrotliEncoderIsFinished(st))
     L.BrotliEncoderDestroyInstance(st)
