@@ -96,6 +96,16 @@ typedef struct Enc {
   int hasher_type; /* 5, 6, 58, 68; 2, 3, 4, 54 (HashLongestMatchQuickly) */
   int bucket_bits, block_bits, ndist;
   int sweep_bits, hash_len, use_dictionary; /* the quickly family (hash.h:251-279, 329-338) */
+  /* the forgetful-chain family H40 / H41 / H42 (hash.h:296-326): addr / head per bucket, a tiny
+     hash per 16-bit position, chain nodes in banks of recycled slots */
+  int num_banks, bank_bits;
+  size_t max_hops;
+  uint32_t* fc_addr;
+  uint16_t* fc_head;
+  uint8_t* fc_tiny;
+  uint16_t* fc_free;
+  uint16_t* fc_delta;
+  uint16_t* fc_next;
   int hasher_setup, hasher_prepared;
   uint16_t* num;
   uint8_t* tags;
@@ -225,6 +235,7 @@ static const uint32_t kHashMul32 = 0x1E35A7BD;
 static const uint64_t kHashMul64 = 0x1FE35A7BD3579BD3ull;
 
 static int HasherQuick(const Enc* s) { return s->hasher_type < 5 || s->hasher_type == 54; }
+static int HasherChain(const Enc* s) { return s->hasher_type >= 40 && s->hasher_type <= 42; }
 static int HasherTagged(const Enc* s) { return s->hasher_type >= 58; }
 static int Hasher64(const Enc* s) { return s->hasher_type == 6 || s->hasher_type == 68; }
 /* HashTypeLength == StoreLookahead: 8 for the 64-bit and the quickly hashers
@@ -268,7 +279,19 @@ static int ChooseHasher(Enc* s) {
     s->ndist = 4;
     return 1;
   }
-  if (q < 5 || q > 9 || s->lgwin <= 16 || s->lgwin > 24) return 0;
+  if (q < 5 || q > 9 || s->lgwin < 10 || s->lgwin > 24) return 0;
+  if (s->lgwin <= 16) {
+    /* quality.h:180-181; hash.h:296-326 (15-bit buckets; one bank of 65536 slots, 512 banks of 512
+       at quality 9); max_hops: hash_forgetful_chain_inc.h:87 */
+    s->hasher_type = q < 7 ? 40 : q < 9 ? 41 : 42;
+    s->bucket_bits = 15;
+    s->block_bits = 0;
+    s->ndist = q < 7 ? 4 : q < 9 ? 10 : 16;
+    s->num_banks = q < 9 ? 1 : 512;
+    s->bank_bits = q < 9 ? 16 : 9;
+    s->max_hops = (size_t)(q > 6 ? 7u : 8u) << (q - 4);
+    return 1;
+  }
   if (s->size_hint >= (1u << 20) && s->lgwin >= 19) {
     s->hasher_type = q <= 6 ? 68 : 6;
     s->bucket_bits = 15;
@@ -286,6 +309,30 @@ static int ChooseHasher(Enc* s) {
    branch initialises exactly the keys that can be touched, so a full fill is
    equivalent. */
 static void HasherSetup(Enc* s) {
+  if (HasherChain(s)) {
+    /* Prepare, hash_forgetful_chain_inc.h:90-118 (the partial branch touches exactly the buckets
+       that can be reached) */
+    const size_t nb = (size_t)1 << s->bucket_bits;
+    if (!s->hasher_setup) {
+      s->fc_addr = (uint32_t*)malloc(nb * 4);
+      s->fc_head = (uint16_t*)malloc(nb * 2);
+      s->fc_tiny = (uint8_t*)malloc(65536);
+      s->fc_free = (uint16_t*)malloc((size_t)s->num_banks * 2);
+      s->fc_delta = (uint16_t*)calloc((size_t)s->num_banks << s->bank_bits, 2);
+      s->fc_next = (uint16_t*)calloc((size_t)s->num_banks << s->bank_bits, 2);
+      s->dict_lookups = s->dict_matches = 0;
+      s->hasher_setup = 1;
+      s->hasher_prepared = 0;
+    }
+    if (!s->hasher_prepared) {
+      memset(s->fc_addr, 0xCC, nb * 4);
+      memset(s->fc_head, 0, nb * 2);
+      memset(s->fc_tiny, 0, 65536);
+      memset(s->fc_free, 0, (size_t)s->num_banks * 2);
+      s->hasher_prepared = 1;
+    }
+    return;
+  }
   if (HasherQuick(s)) {
     /* Prepare, hash_longest_match_quickly_inc.h:49-77: all zero (the sparse branch clears exactly
        the slots that can be touched) */
@@ -322,6 +369,21 @@ static void HasherSetup(Enc* s) {
 /* Store, ..64_simd_inc.h:114-128 / ..64_inc.h:105-115 */
 static void HStore(Enc* s, size_t ix) {
   uint64_t kt;
+  if (HasherChain(s)) {
+    /* hash_forgetful_chain_inc.h:133-149: the node goes to the next slot of the key's bank,
+       whatever lived there is forgotten */
+    const uint32_t key = (uint32_t)(Load32(&s->rb[ix & s->rb_mask]) * kHashMul32) >> (32 - 15);
+    const size_t bank = key & (uint32_t)(s->num_banks - 1);
+    const size_t idx = (size_t)(s->fc_free[bank]++ & ((1u << s->bank_bits) - 1u)) + (bank << s->bank_bits);
+    size_t delta = ix - s->fc_addr[key];
+    s->fc_tiny[(uint16_t)ix] = (uint8_t)key;
+    if (delta > 0xFFFF) delta = 0xFFFF;
+    s->fc_delta[idx] = (uint16_t)delta;
+    s->fc_next[idx] = s->fc_head[key];
+    s->fc_addr[key] = (uint32_t)ix;
+    s->fc_head[key] = (uint16_t)(idx & ((1u << s->bank_bits) - 1u));
+    return;
+  }
   if (HasherQuick(s)) {
     /* hash_longest_match_quickly_inc.h:93-104: the slot is wiggled by bits 3.. of the position */
     const uint32_t key = QuickKey(s, &s->rb[ix & s->rb_mask]);
@@ -477,6 +539,76 @@ static void FindLongestMatchQuick(Enc* s, size_t cur_ix, size_t max_length,
   }
 }
 
+/* FindLongestMatch of the forgetful-chain family, hash_forgetful_chain_inc.h:190-298. */
+static void FindLongestMatchChain(Enc* s, size_t cur_ix, size_t max_length,
+    size_t max_backward, size_t dictionary_distance, size_t max_distance,
+    SearchResult* out) {
+  const uint8_t* data = s->rb;
+  const size_t mask = s->rb_mask;
+  const size_t cur_ix_masked = cur_ix & mask;
+  const size_t min_score = out->score;
+  size_t best_score = out->score;
+  size_t best_len = out->len;
+  const uint32_t key = (uint32_t)(Load32(&data[cur_ix_masked]) * kHashMul32) >> (32 - 15);
+  const uint8_t tiny_hash = (uint8_t)key;
+  size_t i;
+  out->len = 0;
+  out->len_code_delta = 0;
+  for (i = 0; i < (size_t)s->ndist; ++i) {
+    const size_t backward = (size_t)s->dist_cache[i];
+    size_t prev_ix = cur_ix - backward;
+    if (i > 0 && s->fc_tiny[(uint16_t)prev_ix] != tiny_hash) continue;
+    if (prev_ix >= cur_ix || backward > max_backward) continue;
+    prev_ix &= mask;
+    {
+      const size_t len = FindMatchLength(&data[prev_ix], &data[cur_ix_masked], max_length);
+      if (len >= 2) {
+        size_t score = ScoreLast(len);
+        if (best_score < score) {
+          if (i != 0) score -= PenaltyLast(i);
+          if (best_score < score) {
+            best_score = score; best_len = len;
+            out->len = len; out->distance = backward; out->score = score;
+          }
+        }
+      }
+    }
+  }
+  if (best_len < 3) best_len = 3;
+  {
+    const size_t bank = key & (uint32_t)(s->num_banks - 1);
+    size_t backward = 0;
+    size_t hops = s->max_hops;
+    size_t delta = cur_ix - s->fc_addr[key];
+    size_t slot = s->fc_head[key];
+    while (hops--) {
+      size_t prev_ix;
+      const size_t last = slot + (bank << s->bank_bits);
+      backward += delta;
+      if (backward > max_backward) break;
+      prev_ix = (cur_ix - backward) & mask;
+      slot = s->fc_next[last];
+      delta = s->fc_delta[last];
+      if (cur_ix_masked + best_len > mask || prev_ix + best_len > mask ||
+          Load32(&data[cur_ix_masked + best_len - 3]) != Load32(&data[prev_ix + best_len - 3])) continue;
+      {
+        const size_t len = FindMatchLength(&data[prev_ix], &data[cur_ix_masked], max_length);
+        if (len >= 4) {
+          const size_t score = ScoreNormal(len, backward);
+          if (best_score < score) {
+            best_score = score; best_len = len;
+            out->len = len; out->distance = backward; out->score = score;
+          }
+        }
+      }
+    }
+    HStore(s, cur_ix);
+  }
+  if (out->score == min_score) {
+    SearchInStaticDictionary(s, &data[cur_ix_masked], max_length, dictionary_distance, max_distance, out);
+  }
+}
+
 /* FindLongestMatch for all four hashers: ..64_simd_inc.h:170-302,
    .._simd_inc.h:140-277, ..64_inc.h:157-277, .._inc.h. */
 static void FindLongestMatch(Enc* s, size_t cur_ix, size_t max_length,
@@ -496,6 +628,10 @@ static void FindLongestMatch(Enc* s, size_t cur_ix, size_t max_length,
   size_t i;
   if (HasherQuick(s)) {
     FindLongestMatchQuick(s, cur_ix, max_length, max_backward, dictionary_distance, max_distance, out);
+    return;
+  }
+  if (HasherChain(s)) {
+    FindLongestMatchChain(s, cur_ix, max_length, max_backward, dictionary_distance, max_distance, out);
     return;
   }
   out->len = 0;
@@ -2261,6 +2397,7 @@ size_t oracle_encode_shard(const uint8_t* in, size_t len, int quality, int lgwin
     break;
   }
   free(s->rb_data); free(s->num); free(s->tags); free(s->buckets); free(s->cmds);
+  free(s->fc_addr); free(s->fc_head); free(s->fc_tiny); free(s->fc_free); free(s->fc_delta); free(s->fc_next);
   if (s->overflow) return 0;
   return s->out_len;
 }
