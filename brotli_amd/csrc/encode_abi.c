@@ -207,15 +207,15 @@ static int ensure_initialized(BrotliEncoderState* s) {
   if (s->quality > 11) s->quality = 11;
   if (s->lgwin < 10) s->lgwin = 10;
   if (s->lgwin > 24 && !s->large_window) s->lgwin = 24;
-  /* What the kernels implement: qualities 2..4 (H2 / H3 / H4 / H54, any window of
-     10..24 bits) and 5..9 (H68 / H58 / H6 / H5, windows of 17..24 bits), default block size, default distance parameters, no base64 regions,
+  /* What the kernels implement: qualities 2..4 (H2 / H3 / H4 / H54) and 5..9 (H68 / H58 / H6 / H5; H40 / H41 / H42 at
+     windows of 10..16 bits), default block size, default distance parameters, no base64 regions,
      literal context modelling on, the x86-64 default hashers. */
   if (s->quality == 1) {
     /* The two-pass fragment compressor ignores mode, block size, distance
        parameters, context modelling, size hint and hasher selection
        (encode.c:1660-1664 branches before any of them is read). */
     if (s->large_window || s->shard_bytes != 0) s->failed = 1;
-  } else if (s->quality < 2 || s->quality > 9 || (s->quality >= 5 && s->lgwin < 17) || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
+  } else if (s->quality < 2 || s->quality > 9 || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
       s->mode == 2 /* FONT: non-zero distance parameters, encode.c:616-640 */ ||
       s->npostfix != 0 || s->ndirect != 0 || s->base64_mode != 0 || s->disable_ctx != 0 ||
       s->simd_hasher != 0 /* ENABLE / DISABLE change the hasher choice at q5-q7 */) {

@@ -32,11 +32,11 @@ static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobPa
   memset(J, 0, sizeof(*J));
   if (quality < 2 || quality > 9) return false;      // q0-1: k_fast.h; q10-11: other algorithms
   if (lgwin > 24) return false;                      // large window: out of scope
-  if (quality >= 5 ? lgwin < 17 : lgwin < 10) return false;   // H40-42 (q5-9 at lgwin <= 16): out of scope
+  if (lgwin < 10) return false;
   J->quality = quality;
   J->lgwin = lgwin;
   J->lgblock = quality < 4 ? 14 : 16;                // ComputeLgBlock, quality.h:75-92
-  if (quality >= 9) J->lgblock = lgwin < 18 ? lgwin : 18;
+  if (quality >= 9 && lgwin > 16) J->lgblock = lgwin < 18 ? lgwin : 18;
   J->size_hint = size_hint;
   if (quality < 5) {
     // the quickly family: quality.h:176-179, template parameters hash.h:251-279, 329-338
@@ -47,6 +47,15 @@ static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobPa
     J->rec_bytes = 4;
     J->flush_symbols = quality < 4 ? 0x2FFFu : 0u;   // MAX_NUM_DELAYED_SYMBOLS, quality.h:33
     J->flags |= JOB_FLAG_DEEP | JOB_FLAG_QUICK;
+  } else if (lgwin <= 16) {
+    // the forgetful-chain family: quality.h:180-181, hash.h:296-326; table region = addr + head +
+    // tiny hash + free-slot counters + the banks (k_parse_quick.h: FcGeom)
+    J->hasher_type = quality < 7 ? 40 : quality < 9 ? 41 : 42;
+    J->bucket_bits = 15;
+    J->block_bits = 0;
+    J->ndist = quality < 7 ? 4 : quality < 9 ? 10 : 16;
+    J->rec_bytes = quality < 9 ? 17u : 41u;            // (263168 + 4 * 65536 | 4 * 512 * 512) / 32768, rounded up
+    J->flags |= JOB_FLAG_DEEP | JOB_FLAG_QUICK;
   } else if (size_hint >= (1u << 20) && lgwin >= 19) {      // ChooseHasher, quality.h:186-204
     J->hasher_type = quality <= 6 ? 68 : 6;
     J->bucket_bits = 15;
@@ -54,7 +63,7 @@ static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobPa
     J->hasher_type = quality <= 6 ? 58 : 5;
     J->bucket_bits = quality < 7 ? 14 : 15;
   }
-  if (quality >= 5) {
+  if (quality >= 5 && lgwin > 16) {
     J->block_bits = quality - 1;
     J->ndist = quality < 7 ? 4 : quality < 9 ? 10 : 16;
     J->rec_bytes = quality == 5 ? REC_BYTES : (8u << J->block_bits);

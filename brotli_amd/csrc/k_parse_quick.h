@@ -20,6 +20,10 @@
 // Insertions are positions in increasing order over the whole shard, so a StoreRange is one
 // atomic max per position, 64 positions at a time; the searches read the table through the L2
 // (where the atomics land), which keeps a wave's accesses to a slot in order without fences.
+//
+// The same kernel serves qualities 5 - 9 at windows of 10 - 16 bits: the forgetful-chain hashers
+// H40 / H41 / H42 (c/enc/hash_forgetful_chain_inc.h, parameters c/enc/hash.h:296-326,
+// c/enc/quality.h:180-181) — see the fc_* functions below.
 #ifndef BROTLI_AMD_CSRC_K_PARSE_QUICK_H_
 #define BROTLI_AMD_CSRC_K_PARSE_QUICK_H_
 
@@ -161,6 +165,145 @@ DEV QResult k_search(const JobParams& J, const QuickGeom& G, const DeviceTables*
   return out;
 }
 
+// ---- the forgetful-chain family (H40 / H41 / H42) ------------------------------------------
+// Per shard, in the table region: addr u32[32768] (position of the newest node of a bucket,
+// 0xCCCCCCCC = none), head u16[32768] (its slot), tiny u8[65536] (low byte of the key of the
+// position with these low 16 bits), free u16[banks], then the banks: {delta u16, next u16} per
+// slot.  A node is stored into the next slot of its key's bank, whatever lived there is forgotten
+// — chains may run into each other's tails, and the walk follows whatever it finds, exactly as the
+// reference's does (:133-149, 249-287).  Everything here is a chain of dependent reads and
+// writes: one lane's worth of work done uniformly by the wave.
+struct FcGeom {
+  uint32_t* addr;
+  uint16_t* head;
+  uint8_t* tiny;
+  uint16_t* free_idx;
+  uint32_t* slots;       // delta | next << 16
+  uint32_t bank_mask, bank_bits, max_hops;
+};
+DEV uint32_t fc_table_bytes_before_slots() { return 32768u * 4u + 32768u * 2u + 65536u + 1024u; }
+DEV FcGeom fc_geom(const JobParams& J, const QShard& g) {
+  FcGeom F;
+  F.addr = (uint32_t*)g.table;
+  F.head = (uint16_t*)(g.table + 32768u * 4u);
+  F.tiny = g.table + 32768u * 6u;
+  F.free_idx = (uint16_t*)(g.table + 32768u * 6u + 65536u);
+  F.slots = (uint32_t*)(g.table + fc_table_bytes_before_slots());
+  F.bank_bits = J.hasher_type == 42 ? 9u : 16u;
+  F.bank_mask = J.hasher_type == 42 ? 511u : 0u;
+  F.max_hops = (J.quality > 6 ? 7u : 8u) << (J.quality - 4);      // :87
+  return F;
+}
+DEV uint32_t fc_key(const uint8_t* p) { return (ld32(p) * 0x1E35A7BDu) >> (32 - 15); }
+
+// Store (:133-149) of position ix, every lane the same (plain loads and stores of one wave to
+// one address stay in order).
+DEV void fc_store(const FcGeom& F, const QShard& g, uint32_t ix) {
+  const int lane = wave_lane();
+  const uint32_t key = fc_key(g.data + ix);
+  const uint32_t bank = key & F.bank_mask;
+  const uint32_t idx = (uint32_t)F.free_idx[bank] & ((1u << F.bank_bits) - 1u);
+  uint32_t delta = ix - F.addr[key];
+  if (delta > 0xFFFFu) delta = 0xFFFFu;
+  const uint32_t node = delta | ((uint32_t)F.head[key] << 16);
+  wave_sync();
+  if (lane == 0) {
+    F.free_idx[bank] = (uint16_t)(F.free_idx[bank] + 1u);
+    F.tiny[ix & 0xFFFFu] = (uint8_t)key;
+    F.slots[(bank << F.bank_bits) + idx] = node;
+    F.addr[key] = ix;
+    F.head[key] = (uint16_t)idx;
+  }
+  wave_sync();
+}
+
+DEV void fc_drain_stores(const FcGeom& F, QShard& g) {
+  for (uint32_t i = 0; i < g.st_count; ++i) fc_store(F, g, g.st_first + i * g.st_stride);
+  g.st_count = 0;
+}
+
+// FindMatchLengthWithLimit, uniform
+DEV uint32_t fc_match_len(const uint8_t* data, uint32_t a, uint32_t b, uint32_t limit) {
+  uint32_t off = 0;
+  while (off + 8 <= limit) {
+    const uint64_t x = ld64(data + a + off) ^ ld64(data + b + off);
+    if (x) return off + ((uint32_t)dev_ctz64(x) >> 3);
+    off += 8;
+  }
+  while (off < limit && data[a + off] == data[b + off]) ++off;
+  return off;
+}
+
+// FindLongestMatch (:190-298)
+DEV QResult fc_search(const JobParams& J, const FcGeom& F, const DeviceTables* T, QShard& g, uint32_t P) {
+  const int lane = wave_lane();
+  const uint32_t max_length = g.pos_end - P;
+  const uint32_t max_backward = umin(P, J.max_backward_limit);
+  const uint32_t key = fc_key(g.data + P);
+  const uint32_t tiny_hash = key & 0xFFu;
+  QResult out;
+  out.len = 0; out.distance = 0; out.score = K_MIN_SCORE; out.delta = 0;
+  uint32_t best_len = 0;
+  {
+    // the distance cache: one candidate per lane, the best adjusted score wins, the earlier entry
+    // on a tie (each is accepted only if it beats what came before, :232-243)
+    uint32_t k = 0, len = 0, backward = 0;
+    if (lane < J.ndist) {
+      backward = d_dc_entry(g, lane);
+      const uint32_t prev = P - backward;
+      bool ok = (int32_t)backward > 0 && backward <= P && backward <= max_backward;
+      if (lane > 0 && F.tiny[prev & 0xFFFFu] != tiny_hash) ok = false;      // (:219, before the range test: same outcome)
+      if (ok) {
+        len = fc_match_len(g.data, prev, P, max_length);
+        if (len >= 2u) {
+          uint32_t score = 135u * len + 1935u;
+          if (lane != 0) score -= 39u + ((0x1CA10u >> ((uint32_t)lane & 0xEu)) & 0xEu);
+          if (score > K_MIN_SCORE) k = (score << 5) | (31u - (uint32_t)lane);
+        }
+      }
+    }
+    const uint32_t best = d_max(k);
+    if (best != 0) {
+      const int src = 31 - (int)(best & 31u);
+      out.score = best >> 5;
+      out.len = wave_shfl(len, src);
+      out.distance = wave_shfl(backward, src);
+      best_len = out.len;
+    }
+  }
+  if (best_len < 3u) best_len = 3u;
+  {
+    const uint32_t ring_mask = J.ring_mask;
+    const uint32_t cur_masked = P & ring_mask;
+    const uint32_t bank = key & F.bank_mask;
+    uint32_t backward = 0, hops = F.max_hops;
+    uint32_t delta = P - F.addr[key];
+    uint32_t slot = F.head[key];
+    while (hops--) {
+      backward += delta;
+      if (backward > max_backward || backward < delta) break;       // (second test: the 64-bit sum of the reference cannot wrap)
+      const uint32_t prev = P - backward;
+      const uint32_t node = F.slots[(bank << F.bank_bits) + slot];
+      slot = node >> 16;
+      delta = node & 0xFFFFu;
+      if (cur_masked + best_len > ring_mask || (prev & ring_mask) + best_len > ring_mask) continue;
+      // the four bytes ending at offset best_len (:262-266); the input's last one may be the byte
+      // behind the block
+      uint32_t a = ld32(g.data + P + best_len - 3u), b = ld32(g.data + prev + best_len - 3u);
+      if (best_len == max_length) a = (a & 0x00FFFFFFu) | (d_ring_byte(J, g, P + best_len) << 24);
+      if (a != b) continue;
+      const uint32_t len = fc_match_len(g.data, prev, P, max_length);
+      if (len >= 4u) {
+        const uint32_t score = 1920u + 135u * len - 30u * log2floor(backward);
+        if (out.score < score) { out.score = score; out.len = len; out.distance = backward; best_len = len; }
+      }
+    }
+    fc_store(F, g, P);
+  }
+  if (out.score == K_MIN_SCORE) q_dict_search(J, T, g, true, P, max_length, out);
+  return out;
+}
+
 DEV void k_setup_block(const JobParams& J, const QuickGeom& G, QShard& g) {
   const int lane = wave_lane();
   const uint32_t htl = hasher_htl(J.hasher_type);
@@ -169,7 +312,7 @@ DEV void k_setup_block(const JobParams& J, const QuickGeom& G, QShard& g) {
     g.st_count = 3;
     g.st_stride = 1;
   }
-  k_drain_stores(J, G, g);
+  if (J.hasher_type >= 40) fc_drain_stores(fc_geom(J, g), g); else k_drain_stores(J, G, g);
   uint32_t bytes = g.blk_bytes, pos = g.blk_pos;
   if (g.blk_flags & QBLK_EXTEND) {                     // ExtendLastCommand, encode.c:905-971
     Command last = g.cmds[g.r.ncmds - 1];
@@ -249,6 +392,8 @@ DEV void parse_quick_round(const JobParams& J, const ShardDesc& D, ShardState* S
   g.pf_val = g.pf_acc = 0;
   g.role = 0;
   g.state = Q_PRE;
+  const bool chain = J.hasher_type >= 40;             // H40 / H41 / H42
+  const FcGeom F = fc_geom(J, g);
 
   while (g.state != Q_DONE) {       // all state is wave-uniform here
     if (g.state == Q_PRE) q_driver_pre(J, g);
@@ -263,7 +408,7 @@ DEV void parse_quick_round(const JobParams& J, const ShardDesc& D, ShardState* S
       const uint32_t P = g.position + (lazy ? 1u : 0u);
       // the lazy probe only looks for something longer than what it has (:127-128)
       const uint32_t len_in = lazy ? umin(g.sr_len - 1u, g.pos_end - P) : 0u;
-      const QResult cur = k_search(J, G, T, g, P, len_in);
+      const QResult cur = chain ? fc_search(J, F, T, g, P) : k_search(J, G, T, g, P, len_in);
       g.stat_searches++;
       bool commit = false;
       if (!lazy) {
@@ -325,7 +470,7 @@ DEV void parse_quick_round(const JobParams& J, const ShardDesc& D, ShardState* S
         g.insert_length = 0;
         g.position += g.sr_len;
       }
-      k_drain_stores(J, G, g);
+      if (chain) fc_drain_stores(F, g); else k_drain_stores(J, G, g);
     }
     if (g.state == Q_POST) q_driver_post(J, g, writer);
   }

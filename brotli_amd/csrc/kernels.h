@@ -50,6 +50,13 @@ __global__ void __launch_bounds__(256) k_init(JobArgs a) {
   const ShardDesc& D = a.shards[shard];
   if (a.J.flags & JOB_FLAG_INDEXED) {
     // no hash table: the index kernels clear what they use
+  } else if ((a.J.flags & JOB_FLAG_QUICK) && a.J.hasher_type >= 40) {
+    // Prepare, hash_forgetful_chain_inc.h:90-118: addr = 0xCCCCCCCC, head / tiny hash / free-slot
+    // counters = 0 (the banks are only ever read behind a node that was written)
+    uint32_t* w = (uint32_t*)(a.ws + D.table_off);
+    const uint32_t n_addr = 32768u, n_rest = (32768u * 2u + 65536u + 1024u) / 4u;
+    for (uint32_t p = b * blockDim.x + threadIdx.x; p < n_addr + n_rest;
+         p += a.init_blocks_per_shard * blockDim.x) w[p] = p < n_addr ? 0xCCCCCCCCu : 0u;
   } else if (a.J.flags & JOB_FLAG_QUICK) {
     // Prepare, hash_longest_match_quickly_inc.h:49-77: every slot holds position 0
     uint32_t* table = (uint32_t*)(a.ws + D.table_off);

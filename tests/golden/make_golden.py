@@ -37,6 +37,12 @@ CASES = [
     ({"kind": "mixed", "size": 2 << 20, "seed": 9}, 4, 24, 1 << 19),
     ({"kind": "mixed", "size": 1 << 20, "seed": 9}, 2, 10, 0),
     ({"kind": "random", "size": 1 << 18, "seed": 1}, 3, 22, 1 << 16),
+    # qualities 5 - 9 at windows of 10 - 16 bits: the forgetful-chain hashers H40 / H41 / H42
+    ({"kind": "file", "name": "alice29.txt"}, 5, 16, 0),
+    ({"kind": "file", "name": "alice29.txt"}, 9, 10, 0),
+    ({"kind": "text", "size": 1 << 20, "seed": 11}, 6, 16, 1 << 17),
+    ({"kind": "text", "size": 1 << 20, "seed": 11}, 7, 14, 0),
+    ({"kind": "mixed", "size": 1 << 20, "seed": 9}, 9, 16, 1 << 18),
 ]
 
 

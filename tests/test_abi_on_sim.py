@@ -45,7 +45,7 @@ def test_one_shot_alice_known_answer(simabi):
     assert not simabi.BrotliEncoderCompress(11, 22, 0, len(ALICE), ALICE, C.byref(n), out) and n.value == 0
 
 
-@pytest.mark.parametrize("quality,lgwin", [(5, 22), (6, 22), (9, 24), (4, 22), (3, 16), (2, 18)])
+@pytest.mark.parametrize("quality,lgwin", [(5, 22), (6, 22), (9, 24), (4, 22), (3, 16), (2, 18), (5, 14), (9, 16)])
 def test_single_stream_sequences_and_metadata(simabi, stock, quality, lgwin):
     """One encoder instance: PROCESS / FLUSH / FINISH in assorted shapes, TakeOutput, metadata
     blocks, size hint derived from the calls (no BROTLI_PARAM_SIZE_HINT)."""

@@ -122,7 +122,7 @@ def test_one_shot_empty_and_small_buffer(amd):
     assert not amd.BrotliEncoderCompress(5, 22, 0, len(ALICE), ALICE, C.byref(n), out)
 
 
-@pytest.mark.parametrize("quality,lgwin", [(6, 22), (9, 24), (2, 22), (3, 22), (4, 22), (4, 16), (2, 10)])
+@pytest.mark.parametrize("quality,lgwin", [(6, 22), (9, 24), (2, 22), (3, 22), (4, 22), (4, 16), (2, 10), (5, 16), (7, 12), (9, 10)])
 def test_one_shot_deep_quality_equals_reference(amd, stock, quality, lgwin):
     data = G.enwik_text(1 << 20, seed=29, vocab=10000)
     outs = []

@@ -91,7 +91,7 @@ def test_golden_vectors(ctx):
     gold = json.load(open(os.path.join(HERE, "golden", "golden.json")))
     n = 0
     for case in gold["cases"]:
-        if case["quality"] not in range(2, 10) or case["lgwin"] not in range(17 if case["quality"] >= 5 else 10, 25):
+        if case["quality"] not in range(2, 10) or case["lgwin"] not in range(10, 25):
             continue
         data = G.make(case["input"])
         if len(data) == 0:
@@ -143,6 +143,23 @@ def test_qualities_2_to_4_equal_oracle(ctx, oracle, name, quality, lgwin, shard)
             "zeros": bytes(300000), "tiny": b"hello hello hello hello"}[name]
     if len(data) < 1000 and shard:
         pytest.skip("one shard")
+    got, info = ctx.encode_host(data, hip.make_params(quality, lgwin, shard))
+    n = len(data)
+    s = shard or n
+    want = b"".join(oracle.encode_shard(data[o:o + s], quality, lgwin, min(n, 1 << 30), o, o + s >= n)
+                    for o in range(0, n, s))
+    assert got == want
+
+
+@pytest.mark.parametrize("quality,lgwin,shard", [(5, 16, 1 << 17), (5, 10, 0), (6, 14, 0), (7, 16, 100000), (8, 12, 0),
+                                                 (9, 16, 0), (9, 10, 1 << 16)])
+@pytest.mark.parametrize("name", ["text", "mixed", "text_rand_text", "zeros"])
+def test_small_windows_equal_oracle(ctx, oracle, name, quality, lgwin, shard):
+    """Qualities 5 - 9 at lgwin 10 - 16: the forgetful-chain hashers H40 / H41 / H42."""
+    from brotli_amd import hip
+    data = {"text": TEXT4M[:(1 << 20) + 777], "mixed": G.mixed_corpus(1 << 20),
+            "text_rand_text": TEXT4M[:200000] + G.random_bytes(150000) + TEXT4M[:100000],
+            "zeros": bytes(300000)}[name]
     got, info = ctx.encode_host(data, hip.make_params(quality, lgwin, shard))
     n = len(data)
     s = shard or n

@@ -418,6 +418,38 @@ def test_quick_stream_call_sequences_equal_reference(sim, ref, quality, lgwin):
             assert sim.stream(text, calls, quality, lgwin, size_hint=hint) == want, (quality, hint, calls[:3])
 
 
+FC_TEXT = G.enwik_text(200000, seed=5, vocab=20000)
+FC_CASES = {
+    "text_laps_ring": FC_TEXT,                          # 200 KB through a 128 KiB ring
+    "mixed": G.mixed_corpus(150000),
+    "text_rand": FC_TEXT[:60000] + G.random_bytes(30000, seed=2) + FC_TEXT[:40000],
+    "rle": (b"abcdefgh" * 20000)[:111111],
+    "zeros": bytes(100000),
+    "t9": b"123456789",
+}
+
+
+@pytest.mark.parametrize("name", list(FC_CASES))
+@pytest.mark.parametrize("quality,lgwin,shard", [(5, 16, 0), (6, 10, 0), (7, 14, 70000), (8, 12, 0), (9, 16, 0), (9, 10, 50000)])
+def test_forgetful_chain_hashers_bytes_match_oracle(sim, oracle, name, quality, lgwin, shard):
+    """Qualities 5 - 9 at windows of 10 - 16 bits: H40 / H41 / H42 in k_parse_quick.h (chains
+    through banks of recycled slots, tiny-hash filter on 4 / 10 / 16 distance-cache entries,
+    ring-end rules of the chain walk), one stream and shards."""
+    data = FC_CASES[name]
+    if shard and len(data) < 1000:
+        pytest.skip("one shard")
+    want = _plan_q(oracle, data, quality, lgwin, 1 << 30 if shard else 0, shard)
+    assert sim.encode(data, quality, lgwin, (1 << 30) if shard else len(data), shard) == want
+
+
+@pytest.mark.parametrize("quality,lgwin", [(5, 16), (9, 12)])
+def test_forgetful_chain_stream_call_sequences_equal_reference(sim, ref, quality, lgwin):
+    text = G.enwik_text(150000, seed=55, vocab=20000)
+    for calls in (_stream_chunks(len(text), 40000), _stream_chunks(len(text), 23000, 2)):
+        want = ref.encode_calls(text, quality, lgwin, calls, size_hint=0)
+        assert sim.stream(text, calls, quality, lgwin, size_hint=0) == want, (quality, calls[:3])
+
+
 @pytest.mark.parametrize("quality,lgwin", [(9, 24)])      # (5, 22) and (6, 22): tests/test_abi_on_sim.py
 def test_stream_call_sequences_equal_reference(sim, ref, quality, lgwin):
     """k_parse (quality 5) / k_parse_deep (6-9) resumed call after call with the state the
