@@ -312,7 +312,7 @@ DEV void k_setup_block(const JobParams& J, const QuickGeom& G, QShard& g) {
     g.st_count = 3;
     g.st_stride = 1;
   }
-  if (J.hasher_type >= 40) fc_drain_stores(fc_geom(J, g), g); else k_drain_stores(J, G, g);
+  if (J.hasher_type >= 40 && J.hasher_type <= 42) fc_drain_stores(fc_geom(J, g), g); else k_drain_stores(J, G, g);
   uint32_t bytes = g.blk_bytes, pos = g.blk_pos;
   if (g.blk_flags & QBLK_EXTEND) {                     // ExtendLastCommand, encode.c:905-971
     Command last = g.cmds[g.r.ncmds - 1];
@@ -392,7 +392,7 @@ DEV void parse_quick_round(const JobParams& J, const ShardDesc& D, ShardState* S
   g.pf_val = g.pf_acc = 0;
   g.role = 0;
   g.state = Q_PRE;
-  const bool chain = J.hasher_type >= 40;             // H40 / H41 / H42
+  const bool chain = J.hasher_type >= 40 && J.hasher_type <= 42;             // H40 / H41 / H42
   const FcGeom F = fc_geom(J, g);
 
   while (g.state != Q_DONE) {       // all state is wave-uniform here

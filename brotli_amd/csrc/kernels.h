@@ -50,7 +50,7 @@ __global__ void __launch_bounds__(256) k_init(JobArgs a) {
   const ShardDesc& D = a.shards[shard];
   if (a.J.flags & JOB_FLAG_INDEXED) {
     // no hash table: the index kernels clear what they use
-  } else if ((a.J.flags & JOB_FLAG_QUICK) && a.J.hasher_type >= 40) {
+  } else if ((a.J.flags & JOB_FLAG_QUICK) && a.J.hasher_type >= 40 && a.J.hasher_type <= 42) {
     // Prepare, hash_forgetful_chain_inc.h:90-118: addr = 0xCCCCCCCC, head / tiny hash / free-slot
     // counters = 0 (the banks are only ever read behind a node that was written)
     uint32_t* w = (uint32_t*)(a.ws + D.table_off);

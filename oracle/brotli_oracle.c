@@ -840,6 +840,206 @@ static uint32_t CmdCopyLenCode(const Cmd* c) {
 
 /* c/enc/backward_references_inc.h:10-242 (base64 mode and compound
    dictionaries are off: encode.h:69, ENABLE_COMPOUND_DICTIONARY 0). */
+
+/* ------------------------------------------------------------------------ */
+/* Attached (compound) dictionaries: raw LZ77 prefixes prepared by
+   BrotliEncoderPrepareDictionary(BROTLI_SHARED_DICTIONARY_RAW) and attached with
+   BrotliEncoderAttachPreparedDictionary (c/enc/encode.c:1756-1880).            */
+
+typedef struct {
+  uint32_t source_size, bucket_bits, slot_bits, hash_bits, num_items;
+  uint32_t* slot_offsets;   /* [1 << slot_bits] */
+  uint16_t* heads;          /* [1 << bucket_bits] */
+  uint32_t* items;          /* [num_items], bit 31 ends a chain */
+  const uint8_t* source;
+} PDict;
+
+static struct {
+  size_t num_chunks, total_size;
+  PDict chunks[16];
+  size_t chunk_offsets[17];
+} g_cd;
+
+static const uint64_t kPDictMul = 0x1FE35A7BD3579BD3ull; /* compound_dictionary.h:31-32 */
+
+/* c/enc/compound_dictionary.c:13-153 (CreatePreparedDictionaryWithParams) with the parameters
+   of CreatePreparedDictionary (:155-173). */
+static int PDictCreate(PDict* d, const uint8_t* source, size_t source_size) {
+  uint32_t bucket_bits = 17, slot_bits = 7;
+  const uint32_t hash_bits = 40;
+  const uint16_t bucket_limit = 32;
+  size_t volume = (size_t)16 << bucket_bits;
+  uint32_t num_slots, num_buckets, hash_shift, slot_mask, i, total_items = 0;
+  uint64_t hash_mask;
+  uint16_t* num;
+  uint32_t *bucket_heads, *next_bucket, *slot_size, *slot_limit;
+  while (volume < source_size && bucket_bits < 22) { bucket_bits++; slot_bits++; volume <<= 1; }
+  num_slots = 1u << slot_bits;
+  num_buckets = 1u << bucket_bits;
+  hash_shift = 64u - bucket_bits;
+  hash_mask = (~(uint64_t)0) >> (64 - hash_bits);
+  slot_mask = num_slots - 1;
+  slot_size = (uint32_t*)calloc(num_slots, 4);
+  slot_limit = (uint32_t*)calloc(num_slots, 4);
+  num = (uint16_t*)calloc(num_buckets, 2);
+  bucket_heads = (uint32_t*)calloc(num_buckets, 4);
+  next_bucket = (uint32_t*)calloc(source_size + 1, 4);
+  for (i = 0; (size_t)i + 7 < source_size; ++i) {
+    const uint64_t h = (Load64(&source[i]) & hash_mask) * kPDictMul;
+    const uint32_t key = (uint32_t)(h >> hash_shift);
+    uint16_t count = num[key];
+    next_bucket[i] = count == 0 ? (uint32_t)-1 : bucket_heads[key];
+    bucket_heads[key] = i;
+    count++;
+    if (count > bucket_limit) count = bucket_limit;
+    num[key] = count;
+  }
+  for (i = 0; i < num_slots; ++i) {
+    slot_limit[i] = bucket_limit;
+    for (;;) {
+      uint32_t limit = slot_limit[i], count = 0;
+      size_t j;
+      int overflow = 0;
+      for (j = i; j < num_buckets; j += num_slots) {
+        uint32_t size = num[j];
+        if (count >= 0xFFFF) { overflow = 1; break; }
+        if (size > limit) size = limit;
+        count += size;
+      }
+      if (!overflow) { slot_size[i] = count; total_items += count; break; }
+      slot_limit[i]--;
+    }
+  }
+  d->source_size = (uint32_t)source_size;
+  d->bucket_bits = bucket_bits;
+  d->slot_bits = slot_bits;
+  d->hash_bits = hash_bits;
+  d->num_items = total_items;
+  d->slot_offsets = (uint32_t*)calloc(num_slots, 4);
+  d->heads = (uint16_t*)calloc(num_buckets, 2);
+  d->items = (uint32_t*)calloc(total_items + 1, 4);
+  d->source = source;
+  total_items = 0;
+  for (i = 0; i < num_slots; ++i) {
+    d->slot_offsets[i] = total_items;
+    total_items += slot_size[i];
+    slot_size[i] = 0;
+  }
+  for (i = 0; i < num_buckets; ++i) {
+    uint32_t slot = i & slot_mask, count = num[i], pos;
+    size_t j, cursor = slot_size[slot];
+    if (count > slot_limit[slot]) count = slot_limit[slot];
+    if (count == 0) { d->heads[i] = 0xFFFF; continue; }
+    d->heads[i] = (uint16_t)cursor;
+    cursor += d->slot_offsets[slot];
+    slot_size[slot] += count;
+    pos = bucket_heads[i];
+    for (j = 0; j < count; j++) { d->items[cursor++] = pos; pos = next_bucket[pos]; }
+    d->items[cursor - 1] |= 0x80000000u;
+  }
+  free(slot_size); free(slot_limit); free(num); free(bucket_heads); free(next_bucket);
+  return 1;
+}
+
+/* AttachPreparedDictionary, compound_dictionary.c:182-211; n == 0 detaches everything.  The
+   sources must stay alive while encodes run (the "lean" form references them). */
+int oracle_set_dictionary(const uint8_t* const* sources, const size_t* sizes, size_t n) {
+  size_t i;
+  for (i = 0; i < g_cd.num_chunks; ++i) {
+    free(g_cd.chunks[i].slot_offsets); free(g_cd.chunks[i].heads); free(g_cd.chunks[i].items);
+  }
+  memset(&g_cd, 0, sizeof(g_cd));
+  if (n > 15) return 0;
+  for (i = 0; i < n; ++i) {
+    if (sizes[i] > (size_t)0x7FFFFFFF - g_cd.total_size) return 0;   /* SHARED_BROTLI_MAX_RAW_DICT_SIZE */
+    PDictCreate(&g_cd.chunks[i], sources[i], sizes[i]);
+    g_cd.total_size += sizes[i];
+    g_cd.chunk_offsets[i + 1] = g_cd.total_size;
+    g_cd.num_chunks++;
+  }
+  return 1;
+}
+
+/* The hashers that have a compound-dictionary variant (backward_references.c:194-243, 256-282);
+   H2 and H54 fall through to the plain variant, where only `gap` applies. */
+static int HasherLooksUpCompound(int t) {
+  return t == 3 || t == 4 || t == 5 || t == 6 || t == 40 || t == 41 || t == 42 || t == 58 || t == 68;
+}
+
+/* FindCompoundDictionaryMatch, c/enc/hash.h:526-634 */
+static void FindCompoundDictionaryMatch(const PDict* self, const uint8_t* data, size_t ring_buffer_mask,
+    const int* distance_cache, size_t cur_ix, size_t max_length, size_t distance_offset,
+    size_t max_distance, SearchResult* out) {
+  const uint32_t source_size = self->source_size;
+  const size_t boundary = distance_offset - source_size;
+  const uint32_t hash_shift = 64u - self->bucket_bits;
+  const uint32_t slot_mask = (~(uint32_t)0) >> (32 - self->slot_bits);
+  const uint64_t hash_mask = (~(uint64_t)0) >> (64 - self->hash_bits);
+  const uint8_t* source = self->source;
+  const size_t cur_ix_masked = cur_ix & ring_buffer_mask;
+  size_t best_score = out->score, best_len = out->len, i;
+  const uint64_t h = (Load64(&data[cur_ix_masked]) & hash_mask) * kPDictMul;
+  const uint32_t key = (uint32_t)(h >> hash_shift);
+  const uint32_t slot = key & slot_mask;
+  const uint32_t head = self->heads[key];
+  const uint32_t* chain = &self->items[self->slot_offsets[slot] + head];
+  uint32_t item = head == 0xFFFF ? 1 : 0;
+  for (i = 0; i < 4; ++i) {
+    const size_t distance = (size_t)distance_cache[i];
+    size_t offset, limit, len;
+    if (distance <= boundary || distance > distance_offset) continue;
+    offset = distance_offset - distance;
+    limit = source_size - offset;
+    limit = limit > max_length ? max_length : limit;
+    len = FindMatchLength(&source[offset], &data[cur_ix_masked], limit);
+    if (len >= 2) {
+      size_t score = ScoreLast(len);
+      if (best_score < score) {
+        if (i != 0) score -= PenaltyLast(i);
+        if (best_score < score) {
+          best_score = score;
+          if (len > best_len) best_len = len;
+          out->len = len; out->len_code_delta = 0; out->distance = distance; out->score = best_score;
+        }
+      }
+    }
+  }
+  if (best_len < 3) best_len = 3;
+  while (item == 0) {
+    size_t offset, distance, limit;
+    item = *chain++;
+    offset = item & 0x7FFFFFFF;
+    item &= 0x80000000u;
+    distance = distance_offset - offset;
+    limit = source_size - offset;
+    limit = limit > max_length ? max_length : limit;
+    if (distance > max_distance) continue;
+    if (cur_ix_masked + best_len > ring_buffer_mask || best_len >= limit ||
+        Load32(&data[cur_ix_masked + best_len - 3]) != Load32(&source[offset + best_len - 3])) continue;
+    {
+      const size_t len = FindMatchLength(&source[offset], &data[cur_ix_masked], limit);
+      if (len >= 4) {
+        size_t score = ScoreNormal(len, distance);
+        if (best_score < score) {
+          best_score = score; best_len = len;
+          out->len = best_len; out->len_code_delta = 0; out->distance = distance; out->score = best_score;
+        }
+      }
+    }
+  }
+}
+
+/* LookupCompoundDictionaryMatch, c/enc/hash.h:703-717 */
+static void LookupCompoundDictionaryMatch(Enc* s, size_t cur_ix, size_t max_length,
+    size_t max_ring_buffer_distance, size_t max_distance, SearchResult* sr) {
+  size_t base_offset = max_ring_buffer_distance + 1 + g_cd.total_size - 1, d;
+  if (!HasherLooksUpCompound(s->hasher_type)) return;
+  for (d = 0; d < g_cd.num_chunks; ++d) {
+    FindCompoundDictionaryMatch(&g_cd.chunks[d], s->rb, s->rb_mask, s->dist_cache, cur_ix, max_length,
+        base_offset - g_cd.chunk_offsets[d], max_distance, sr);
+  }
+}
+
 static void CreateBackwardReferences(Enc* s, size_t num_bytes, size_t position) {
   const size_t max_backward_limit = ((size_t)1 << s->lgwin) - 16;
   const size_t position_offset = s->stream_offset;
@@ -854,6 +1054,7 @@ static void CreateBackwardReferences(Enc* s, size_t num_bytes, size_t position) 
   const size_t kMinScore = SCORE_BASE + 100;
   const size_t dist_max_distance = 0x3FFFFFC; /* metablock.c:190-191 */
   int* dc = s->dist_cache;
+  const size_t gap = g_cd.total_size;   /* backward_references_inc.h:31 */
   PrepareDistanceCache(dc, s->ndist);
   while (position + htl < pos_end) {
     size_t max_length = pos_end - position;
@@ -862,8 +1063,10 @@ static void CreateBackwardReferences(Enc* s, size_t num_bytes, size_t position) 
         position + position_offset : max_backward_limit;
     SearchResult sr;
     sr.len = 0; sr.len_code_delta = 0; sr.distance = 0; sr.score = kMinScore;
-    FindLongestMatch(s, position, max_length, max_distance, dictionary_start,
+    FindLongestMatch(s, position, max_length, max_distance, dictionary_start + gap,
                      dist_max_distance, &sr);
+    if (g_cd.num_chunks) LookupCompoundDictionaryMatch(s, position, max_length, dictionary_start,
+                                                       dist_max_distance, &sr);
     if (sr.score > kMinScore) {
       int delayed = 0;
       --max_length;
@@ -875,7 +1078,9 @@ static void CreateBackwardReferences(Enc* s, size_t num_bytes, size_t position) 
         dictionary_start = position + 1 + position_offset < max_backward_limit ?
             position + 1 + position_offset : max_backward_limit;
         FindLongestMatch(s, position + 1, max_length, max_distance,
-                         dictionary_start, dist_max_distance, &sr2);
+                         dictionary_start + gap, dist_max_distance, &sr2);
+        if (g_cd.num_chunks) LookupCompoundDictionaryMatch(s, position + 1, max_length, dictionary_start,
+                                                           dist_max_distance, &sr2);
         if (sr2.score >= sr.score + 175) {
           ++position; ++insert_length; sr = sr2;
           if (++delayed < 4 && position + htl < pos_end) continue;
@@ -886,8 +1091,8 @@ static void CreateBackwardReferences(Enc* s, size_t num_bytes, size_t position) 
       dictionary_start = position + position_offset < max_backward_limit ?
           position + position_offset : max_backward_limit;
       {
-        size_t distance_code = ComputeDistanceCode(sr.distance, dictionary_start, dc);
-        if (sr.distance <= dictionary_start && distance_code > 0) {
+        size_t distance_code = ComputeDistanceCode(sr.distance, dictionary_start + gap, dc);
+        if (sr.distance <= dictionary_start + gap && distance_code > 0) {
           dc[3] = dc[2]; dc[2] = dc[1]; dc[1] = dc[0]; dc[0] = (int)sr.distance;
           PrepareDistanceCache(dc, s->ndist);
         }
@@ -2203,6 +2408,30 @@ static void ExtendLastCommand(Enc* s, uint32_t* bytes, uint32_t* wrapped_pos) {
         last->copy_len++;
         (*bytes)--;
         (*wrapped_pos)++;
+      }
+    } else if ((cmd_dist - max_distance - 1) < g_cd.total_size && last_copy_len < cmd_dist - max_distance) {
+      /* encode.c:930-961: the copy continues inside the attached dictionary, chunk after chunk */
+      size_t address = g_cd.total_size - (size_t)(cmd_dist - max_distance) + (size_t)last_copy_len;
+      size_t br_index = 0, br_offset, chunk_length;
+      const uint8_t* chunk;
+      while (address >= g_cd.chunk_offsets[br_index + 1]) br_index++;
+      br_offset = address - g_cd.chunk_offsets[br_index];
+      chunk = g_cd.chunks[br_index].source;
+      chunk_length = g_cd.chunk_offsets[br_index + 1] - g_cd.chunk_offsets[br_index];
+      while (*bytes != 0 && data[*wrapped_pos & mask] == chunk[br_offset]) {
+        last->copy_len++;
+        (*bytes)--;
+        (*wrapped_pos)++;
+        if (++br_offset == chunk_length) {
+          br_index++;
+          br_offset = 0;
+          if (br_index != g_cd.num_chunks) {
+            chunk = g_cd.chunks[br_index].source;
+            chunk_length = g_cd.chunk_offsets[br_index + 1] - g_cd.chunk_offsets[br_index];
+          } else {
+            break;
+          }
+        }
       }
     }
     last->cmd_prefix = CombineLengthCodes(InsertLengthCode(last->insert_len),

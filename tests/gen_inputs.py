@@ -140,3 +140,24 @@ def make(spec):
     if kind == "repeat":
         return (spec["unit"].encode() * (spec["size"] // len(spec["unit"]) + 1))[:spec["size"]]
     raise ValueError(kind)
+
+
+def dictionary_case(nbytes, dict_bytes, nchunks=1, seed=SEED):
+    """Input + raw dictionaries for the attached-dictionary tests: text whose
+    vocabulary the dictionary shares, with pieces of the dictionary pasted in every ~2 KB, and the
+    dictionary cut into `nchunks` chunks (attached in order)."""
+    import random
+    rng = random.Random(seed)
+    base = bytes(enwik_text(nbytes + dict_bytes, seed=seed, vocab=3000))
+    d = base[:dict_bytes]
+    body = bytearray(base[dict_bytes:dict_bytes + nbytes])
+    for _ in range(nbytes // 2000 + 1):
+        ln = rng.randrange(8, 300)
+        a = rng.randrange(0, max(1, dict_bytes - ln))
+        b = rng.randrange(0, max(1, nbytes - ln))
+        piece = d[a:a + ln]
+        body[b:b + len(piece)] = piece
+    body = bytes(body[:nbytes])
+    k = max(1, dict_bytes // nchunks)
+    chunks = [d[i * k:(i + 1) * k] for i in range(nchunks - 1)] + [d[(nchunks - 1) * k:]]
+    return body, chunks

@@ -45,6 +45,11 @@ class Ref:
             C.POINTER(C.c_size_t), C.c_char_p]
         L.BrotliEncoderMaxCompressedSize.restype = C.c_size_t
         L.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
+        L.BrotliEncoderPrepareDictionary.restype = C.c_void_p
+        L.BrotliEncoderPrepareDictionary.argtypes = [C.c_int, C.c_size_t, C.c_char_p, C.c_int,
+                                                     C.c_void_p, C.c_void_p, C.c_void_p]
+        L.BrotliEncoderDestroyPreparedDictionary.argtypes = [C.c_void_p]
+        L.BrotliEncoderAttachPreparedDictionary.argtypes = [C.c_void_p, C.c_void_p]
         if hasattr(L, "BrotliDecoderDecompress"):
             L.BrotliDecoderDecompress.argtypes = [
                 C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.c_char_p]
@@ -88,16 +93,24 @@ class Ref:
         L.BrotliEncoderDestroyInstance(st)
         return out.raw[:total.value]
 
-    def encode_calls(self, data, quality, lgwin, calls, size_hint=0):
+    def encode_calls(self, data, quality, lgwin, calls, size_hint=0, dictionaries=()):
         """One instance driven with an explicit call sequence [(nbytes, op), ...];
         every call is repeated until its input is consumed and the output drained
-        (what the CLI / bindings do)."""
+        (what the CLI / bindings do).  `dictionaries`: raw LZ77 prefixes prepared and
+        attached in order before the first call (encode.h:318-363)."""
         L = self.L
         st = L.BrotliEncoderCreateInstance(None, None, None)
         assert L.BrotliEncoderSetParameter(st, PARAM_QUALITY, quality)
         assert L.BrotliEncoderSetParameter(st, PARAM_LGWIN, lgwin)
         if size_hint:
             assert L.BrotliEncoderSetParameter(st, PARAM_SIZE_HINT, size_hint)
+        keep = [C.create_string_buffer(bytes(d), max(len(d), 1)) for d in dictionaries]
+        prepared = []
+        for d, buf in zip(dictionaries, keep):
+            pd = L.BrotliEncoderPrepareDictionary(0, len(d), buf, 11, None, None, None)
+            assert pd
+            assert L.BrotliEncoderAttachPreparedDictionary(st, pd)
+            prepared.append(pd)
         cap = 2 * len(data) + 1024 + 64 * len(calls)
         out = C.create_string_buffer(cap)
         inbuf = C.create_string_buffer(bytes(data), max(len(data), 1))
@@ -117,6 +130,8 @@ class Ref:
                 if avail_in.value == 0 and not L.BrotliEncoderHasMoreOutput(st):
                     break
         L.BrotliEncoderDestroyInstance(st)
+        for pd in prepared:
+            L.BrotliEncoderDestroyPreparedDictionary(pd)
         # (metadata payloads are copied to next_out without being counted in total_out,
         # encode.c:1590-1600: measure what actually left)
         return out.raw[:cap - avail_out.value]
@@ -137,6 +152,32 @@ class Ref:
                 off + m == n))
             off += m
         return b"".join(parts)
+
+    def decompress_with(self, comp, max_out, dictionaries):
+        """Streaming decoder with raw dictionaries attached (c/include/brotli/decode.h
+        BrotliDecoderAttachDictionary)."""
+        L = self.L
+        L.BrotliDecoderCreateInstance.restype = C.c_void_p
+        L.BrotliDecoderCreateInstance.argtypes = [C.c_void_p] * 3
+        L.BrotliDecoderDestroyInstance.argtypes = [C.c_void_p]
+        L.BrotliDecoderAttachDictionary.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_char_p]
+        L.BrotliDecoderDecompressStream.argtypes = [
+            C.c_void_p, C.POINTER(C.c_size_t), C.POINTER(C.c_void_p),
+            C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        st = L.BrotliDecoderCreateInstance(None, None, None)
+        keep = [C.create_string_buffer(bytes(d), max(len(d), 1)) for d in dictionaries]
+        for d, buf in zip(dictionaries, keep):
+            assert L.BrotliDecoderAttachDictionary(st, 0, len(d), buf)
+        out = C.create_string_buffer(max(max_out, 1))
+        inbuf = C.create_string_buffer(bytes(comp), max(len(comp), 1))
+        avail_in, next_in = C.c_size_t(len(comp)), C.c_void_p(C.addressof(inbuf))
+        avail_out, next_out = C.c_size_t(max_out), C.c_void_p(C.addressof(out))
+        total = C.c_size_t(0)
+        r = L.BrotliDecoderDecompressStream(st, C.byref(avail_in), C.byref(next_in),
+                                            C.byref(avail_out), C.byref(next_out), C.byref(total))
+        L.BrotliDecoderDestroyInstance(st)
+        assert r == 1, "decoder rejected stream (result %d)" % r
+        return out.raw[:max_out - avail_out.value]
 
     def decompress(self, comp, max_out):
         out = C.create_string_buffer(max(max_out, 1))
@@ -164,6 +205,18 @@ class Oracle:
         L.oracle_encode_plan.argtypes = [
             C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_size_t, C.c_char_p,
             C.c_size_t, C.POINTER(C.c_uint64)]
+
+        L.oracle_set_dictionary.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t]
+        self._dict_keep = None
+
+    def set_dictionary(self, dictionaries=()):
+        """Attach raw dictionaries to every encoder instance created from now on; () detaches."""
+        n = len(dictionaries)
+        bufs = [C.create_string_buffer(bytes(d), max(len(d), 1)) for d in dictionaries]
+        ptrs = (C.c_char_p * max(n, 1))(*[C.cast(b, C.c_char_p) for b in bufs])
+        sizes = (C.c_size_t * max(n, 1))(*[len(d) for d in dictionaries])
+        assert self.L.oracle_set_dictionary(ptrs, sizes, n) == 1
+        self._dict_keep = bufs
 
     def encode_fast(self, data, lgwin=22, calls=None):
         """Quality 1; `calls` = [(nbytes, op), ...], default one FINISH call."""

@@ -70,6 +70,40 @@ def test_small_windows_forgetful_chain_match_reference(ref, oracle, name, qualit
         assert oracle.encode_plan(data, quality, lgwin, 100000) == ref.encode_plan(data, quality, lgwin, 100000)
 
 
+@pytest.mark.parametrize("nbytes,dict_bytes,nchunks", [(50000, 20000, 1), (300000, 300000, 3), (3000, 100000, 1),
+                                                       (70000, 9, 1)])
+@pytest.mark.parametrize("quality,lgwin", [(5, 22), (5, 18), (6, 22), (9, 24), (7, 17), (3, 22), (4, 18), (2, 22),
+                                           (5, 16), (7, 14), (9, 12)])
+def test_attached_dictionaries_match_reference(ref, oracle, quality, lgwin, nbytes, dict_bytes, nchunks):
+    """BrotliEncoderPrepareDictionary(RAW) + AttachPreparedDictionary (encode.h:318-363): the lookup
+    after every FindLongestMatch (hash.h:526-717), `gap` in the distance code and the static-dictionary
+    distances, ExtendLastCommand into the dictionary; H2 only gets the gap (no compound variant)."""
+    data, chunks = G.dictionary_case(nbytes, dict_bytes, nchunks, seed=quality * 100 + lgwin)
+    want = ref.encode_calls(data, quality, lgwin, [(len(data), 2)], dictionaries=chunks)
+    oracle.set_dictionary(chunks)
+    try:
+        got = oracle.encode_shard(data, quality, lgwin, 0, 0, True)
+    finally:
+        oracle.set_dictionary(())
+    assert got == want
+    if quality != 2 and dict_bytes > 1000:
+        assert len(want) < len(ref.compress(data, quality, lgwin))
+    assert ref.decompress_with(want, len(data), chunks) == data
+
+
+def test_attached_dictionary_large_hint_h54_and_h68(ref, oracle):
+    """Past 1 MiB: H54 at quality 4 (plain variant, gap only), H68 at quality 5."""
+    data, chunks = G.dictionary_case((1 << 20) + 50000, 150000, 2, seed=77)
+    for quality in (4, 5):
+        want = ref.encode_calls(data, quality, 22, [(len(data), 2)], dictionaries=chunks)
+        oracle.set_dictionary(chunks)
+        try:
+            got = oracle.encode_shard(data, quality, 22, 0, 0, True)
+        finally:
+            oracle.set_dictionary(())
+        assert got == want
+
+
 @pytest.mark.parametrize("name", ["text1m", "mixed1m", "rle", "text_rand"])
 @pytest.mark.parametrize("shard", [1 << 18, 100000, 65536, 70000])
 def test_mode_p_matches_reference(ref, oracle, name, shard):
