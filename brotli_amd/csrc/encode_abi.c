@@ -20,6 +20,7 @@
 
 #include "../../include/brotli_amd_encode.h"
 #include "../../include/brotli_amd_hip.h"
+#include "dict_index.h"
 
 enum { OP_PROCESS = 0, OP_FLUSH = 1, OP_FINISH = 2, OP_EMIT_METADATA = 3 };
 enum { ST_PROCESSING = 0, ST_FLUSH_REQUESTED = 1, ST_FINISHED = 2, ST_METADATA = 3 };
@@ -64,6 +65,10 @@ struct BrotliEncoderStateStruct {
   uint32_t carry_bits, carry_value;
   BrotliAmdCtx* ctx;
   BrotliAmdStream* stream;
+  /* attached raw dictionaries in attach order (params.dictionary.compound, encode.c:1828-1850) */
+  const DictIndex* dicts[15];
+  uint32_t ndicts;
+  uint64_t dict_total;
 };
 
 static void* st_alloc(BrotliEncoderState* s, size_t n) {
@@ -259,6 +264,28 @@ static int out_append(BrotliEncoderState* s, const uint8_t* p, size_t n) {
   return 1;
 }
 
+/* The device stream of one encoder instance, with the dictionaries attached so far. */
+static int push_dictionaries(BrotliEncoderState* s) {
+  BrotliAmdDictChunk ch[15];
+  uint32_t i;
+  for (i = 0; i < s->ndicts; ++i) {
+    ch[i].source = s->dicts[i]->source;
+    ch[i].starts = s->dicts[i]->starts;
+    ch[i].items = s->dicts[i]->items;
+    ch[i].source_size = s->dicts[i]->source_size;
+    ch[i].bucket_bits = s->dicts[i]->bucket_bits;
+  }
+  return brotli_amd_stream_attach_dictionary(s->stream, ch, s->ndicts) == BROTLI_AMD_OK;
+}
+static int open_stream(BrotliEncoderState* s) {
+  if (s->stream) return 1;
+  if (brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
+                               s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u,
+                               &s->stream) != BROTLI_AMD_OK) return 0;
+  if (s->ndicts && !push_dictionaries(s)) return 0;
+  return 1;
+}
+
 /* Quality 1: the calls buffered since the last flush become one device job; the
    bytes completed so far leave, the partial byte stays pending (encode.c:1521-1535). */
 static int submit_fast(BrotliEncoderState* s, int op) {
@@ -308,7 +335,7 @@ static int submit_fast(BrotliEncoderState* s, int op) {
 static int submit(BrotliEncoderState* s, int op) {
   if (s->quality == 1) return submit_fast(s, op);
   if (s->shard_bytes == 0 && s->quality != 5 && op == OP_FINISH && s->submitted == 0 && !s->stream &&
-      s->in_len != 0) {
+      s->in_len != 0 && s->ndicts == 0) {
     /* Qualities 6-9, everything in one FINISH: the same bytes come from a one-shard job
        (falls through to the plan code below with shard size 0 = one shard). */
   } else if (s->shard_bytes == 0 && !(s->in_len == 0 && s->submitted == 0 && !s->stream)) {
@@ -319,13 +346,9 @@ static int submit(BrotliEncoderState* s, int op) {
        open — so the device stream is only created once there is data to size it by.) */
     const uint8_t* out;
     uint64_t out_len;
-    if (!s->stream) {
-      if (brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
-                                   s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u,
-                                   &s->stream) != BROTLI_AMD_OK) {
-        if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
-        return 0;
-      }
+    if (!open_stream(s)) {
+      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      return 0;
     }
     if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, op, &out, &out_len) != BROTLI_AMD_OK) {
       if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
@@ -421,9 +444,7 @@ static int forward_pending_input(BrotliEncoderState* s) {
   if (s->shard_bytes == 0) {
     const uint8_t* out;
     uint64_t out_len;
-    if (!s->stream && brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
-                                               s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u,
-                                               &s->stream) != BROTLI_AMD_OK) return 0;
+    if (!open_stream(s)) return 0;
     if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_PROCESS, &out, &out_len) != BROTLI_AMD_OK) {
       if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
       return 0;
@@ -526,9 +547,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
         if (!s->header_written && s->stream_offset == 0) window_bits(s->lgwin, &s->carry_value, &s->carry_bits);
         s->header_written = 2;
       } else {
-        if (!s->stream && brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
-                                                   s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u,
-                                                   &s->stream) != BROTLI_AMD_OK) { s->failed = 1; return BROTLI_FALSE; }
+        if (!open_stream(s)) { s->failed = 1; return BROTLI_FALSE; }
         if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_FLUSH_OPEN, &o, &on) != BROTLI_AMD_OK ||
             brotli_amd_stream_take_partial(s->stream, &s->carry_bits, &s->carry_value) != BROTLI_AMD_OK) {
           if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
@@ -762,23 +781,68 @@ size_t BrotliEncoderEstimatePeakMemoryUsage(int quality, int lgwin, size_t input
   (void)quality; (void)lgwin;
   return 2 * input_size + BrotliEncoderMaxCompressedSize(input_size) + (1u << 16);
 }
-/* encode.h:534: 0 = "not a valid dictionary" — prepared dictionaries are outside the GPU path. */
+/* encode.h:534-542: bytes this library holds for the prepared dictionary (the index; the raw bytes
+   stay the caller's), 0 for anything that is not one of ours. */
 size_t BrotliEncoderGetPreparedDictionarySize(const BrotliEncoderPreparedDictionary* dictionary) {
-  (void)dictionary;
-  return 0;
+  const DictIndex* d = (const DictIndex*)dictionary;
+  if (!d || d->magic != DICT_INDEX_MAGIC) return 0;
+  return sizeof(*d) + (((size_t)1 << d->bucket_bits) + 1) * 4 + ((size_t)d->num_items + 1) * 4;
 }
 
+/* encode.h:318-346, encode.c:1756-1799.  Only BROTLI_SHARED_DICTIONARY_RAW (0): an LZ77 prefix.  The
+   serialized form (1) is an experimental build option of the reference and answers NULL there too.
+   The index is built on the host (dict_index.h) — once per dictionary, off the hot path — and goes
+   to the device with the encoder instance it is attached to. */
 BrotliEncoderPreparedDictionary* BrotliEncoderPrepareDictionary(
     int type, size_t data_size, const uint8_t* data, int quality,
     brotli_amd_alloc_func alloc_func, brotli_amd_free_func free_func, void* opaque) {
-  (void)type; (void)data_size; (void)data; (void)quality; (void)alloc_func; (void)free_func; (void)opaque;
-  return NULL;
+  DictIndex* d;
+  (void)quality;
+  if (type != 0 || data_size > DICT_INDEX_MAX_RAW) return NULL;
+  if ((alloc_func == NULL) != (free_func == NULL)) return NULL;
+  d = (DictIndex*)(alloc_func ? alloc_func(opaque, sizeof(*d)) : malloc(sizeof(*d)));
+  if (!d) return NULL;
+  memset(d, 0, sizeof(*d));
+  d->alloc = alloc_func;
+  d->free_ = free_func;
+  d->opaque = opaque;
+  if (!dict_index_build(d, data, data_size)) {
+    if (free_func) free_func(opaque, d); else free(d);
+    return NULL;
+  }
+  return (BrotliEncoderPreparedDictionary*)d;
 }
+
 void BrotliEncoderDestroyPreparedDictionary(BrotliEncoderPreparedDictionary* dictionary) {
-  (void)dictionary;
+  DictIndex* d = (DictIndex*)dictionary;
+  brotli_amd_free_func free_func;
+  void* opaque;
+  if (!d || d->magic != DICT_INDEX_MAGIC) return;     /* encode.c:1806-1809: only what Prepare made */
+  free_func = d->free_;
+  opaque = d->opaque;
+  dict_index_release(d);
+  if (free_func) free_func(opaque, d); else free(d);
 }
+
+/* encode.c:1828-1850 + AttachPreparedDictionary (compound_dictionary.c:182-211): at most 15 chunks,
+   2^31 - 1 bytes in total; allowed at any time for raw dictionaries, it then takes effect with the
+   next input block.  Qualities 0 / 1 accept and ignore dictionaries (their compressors never look at
+   params.dictionary).  A partition plan (BROTLI_AMD_SHARD_KB) has no dictionary path: refused. */
 BROTLI_BOOL BrotliEncoderAttachPreparedDictionary(BrotliEncoderState* state,
                                                   const BrotliEncoderPreparedDictionary* dictionary) {
-  (void)state; (void)dictionary;
-  return BROTLI_FALSE;
+  const DictIndex* d = (const DictIndex*)dictionary;
+  if (!state || !d || d->magic != DICT_INDEX_MAGIC) return BROTLI_FALSE;
+  if (state->ndicts == 15) return BROTLI_FALSE;
+  if (d->source_size > DICT_INDEX_MAX_RAW - state->dict_total) return BROTLI_FALSE;
+  if (state->shard_bytes != 0) {
+    if (verbose()) fprintf(stderr, "brotli_amd: dictionaries cannot be attached to a partition plan\n");
+    return BROTLI_FALSE;
+  }
+  state->dicts[state->ndicts++] = d;
+  state->dict_total += d->source_size;
+  if (state->stream && !push_dictionaries(state)) {
+    state->failed = 1;
+    return BROTLI_FALSE;
+  }
+  return BROTLI_TRUE;
 }

@@ -736,6 +736,9 @@ struct BrotliAmdStream {
   uint64_t fed = 0;
   bool finished = false;
   std::vector<uint8_t> host_out;
+  // attached dictionaries (k_dict.h): the device copies of the chunks and of the CompoundDict
+  std::vector<void*> dict_allocs;
+  CompoundDict* d_cd = nullptr;
 };
 
 namespace {
@@ -831,6 +834,7 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
   a.nshards = 1;
   a.init_blocks_per_shard = 1;
   a.counters = s->d_counters;
+  a.cd = s->d_cd;
   for (uint64_t round = 0;; ++round) {
     if (round > (s->fed >> 10) + 64) return fail(c, "stream rounds do not converge (device fault)");
     HIP_OK(c, hipMemsetAsync(s->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
@@ -895,6 +899,51 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
   return BROTLI_AMD_OK;
 }
 
+int brotli_amd_stream_attach_dictionary(BrotliAmdStream* s, const BrotliAmdDictChunk* chunks, uint32_t nchunks) {
+  BrotliAmdCtx* c = s->c;
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  if (nchunks > DICT_MAX_CHUNKS) { fail(c, "more than 15 dictionary chunks"); return BROTLI_AMD_UNSUPPORTED; }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { fail(c, "stream sync failed"); return BROTLI_AMD_ERROR; }
+  for (void* p : s->dict_allocs) (void)hipFree(p);
+  s->dict_allocs.clear();
+  s->d_cd = nullptr;
+  if (nchunks == 0) return BROTLI_AMD_OK;
+  CompoundDict cd;
+  memset(&cd, 0, sizeof(cd));
+  auto upload = [&](const void* src, uint64_t bytes, uint64_t slack) -> void* {
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes + slack + 16) != hipSuccess) return nullptr;
+    s->dict_allocs.push_back(d);
+    if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (slack && hipMemset((uint8_t*)d + bytes, 0, slack) != hipSuccess) return nullptr;
+    return d;
+  };
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < nchunks; ++k) {
+    const BrotliAmdDictChunk& h = chunks[k];
+    if (h.bucket_bits < 17 || h.bucket_bits > 22 || total + h.source_size > 0x7FFFFFFFull) {
+      fail(c, "bad dictionary chunk");
+      return BROTLI_AMD_UNSUPPORTED;
+    }
+    const uint64_t nkeys = 1ull << h.bucket_bits;
+    DictChunk& g = cd.chunks[k];
+    g.source = (const uint8_t*)upload(h.source, h.source_size, DICT_SOURCE_SLACK);
+    g.starts = (const uint32_t*)upload(h.starts, (nkeys + 1) * 4, 0);
+    g.items = (const uint32_t*)upload(h.items, (uint64_t)h.starts[nkeys] * 4, 0);
+    if (!g.source || !g.starts || !g.items) { fail(c, "dictionary upload failed"); return BROTLI_AMD_ERROR; }
+    g.source_size = h.source_size;
+    g.bucket_bits = h.bucket_bits;
+    g.offset = (uint32_t)total;
+    total += h.source_size;
+  }
+  cd.num_chunks = nchunks;
+  cd.total_size = (uint32_t)total;
+  s->d_cd = (CompoundDict*)upload(&cd, sizeof(cd), 0);
+  if (!s->d_cd) { fail(c, "dictionary upload failed"); return BROTLI_AMD_ERROR; }
+  return BROTLI_AMD_OK;
+}
+
 int brotli_amd_stream_take_partial(BrotliAmdStream* s, uint32_t* nbits, uint32_t* value) {
   BrotliAmdCtx* c = s->c;
   *nbits = 0;
@@ -917,6 +966,7 @@ void brotli_amd_stream_destroy(BrotliAmdStream* s) {
   (void)hipStreamSynchronize(s->c->stream);
   void* ptrs[] = {s->d_in, s->d_ws, s->d_out, s->d_desc, s->d_state, s->d_counters};
   for (void* p : ptrs) if (p) (void)hipFree(p);
+  for (void* p : s->dict_allocs) (void)hipFree(p);
   delete s;
 }
 

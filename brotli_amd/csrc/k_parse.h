@@ -33,13 +33,10 @@
 #define BROTLI_AMD_CSRC_K_PARSE_H_
 
 #include "device_common.h"
+#include "k_dict.h"
 
 #define K_MIN_SCORE (1920u + 100u)   // BROTLI_SCORE_BASE + 100, hash.h:102-105
-
-struct SearchResult {
-  uint32_t len, distance, score;
-  int32_t len_code_delta;
-};
+#define K_DIST_MAX_DISTANCE 0x3FFFFFCu   // params->dist.max_distance at NPOSTFIX = NDIRECT = 0
 
 struct ParseCtx {
   const uint8_t* data;      // shard byte 0
@@ -53,6 +50,9 @@ struct ParseCtx {
   uint32_t dict_lookups, dict_matches;
   int32_t dc[4];
   bool pair_enabled;
+  const CompoundDict* cd;   // attached dictionaries (k_dict.h), nullptr = none
+  uint32_t gap;             // their total size: shifts the static dictionary and the distance-code
+                            // limit (backward_references_inc.h:31, 114, 173)
 };
 
 // Byte the reference would read at ring index (x & mask) for x <= pos_end:
@@ -366,10 +366,10 @@ DEV SearchResult search_pair(ParseCtx& c, uint32_t posA, PendingB& B) {
     }
   }
   insert_searched(c, posA, keyA, tagA, tag2A, numA);
-  if (ra.score == K_MIN_SCORE) {
-    const uint32_t dictionary_start = umin(posA + c.stream_offset, c.max_backward_limit);
-    dict_search(c, posA, c.pos_end - posA, dictionary_start, ra);
-  }
+  const uint32_t dictionary_start = umin(posA + c.stream_offset, c.max_backward_limit);
+  if (ra.score == K_MIN_SCORE) dict_search(c, posA, c.pos_end - posA, dictionary_start + c.gap, ra);
+  if (c.cd) compound_lookup(c.cd, c.data + posA, posA & c.ring_mask, c.ring_mask, c.dc, c.pos_end - posA,
+                            dictionary_start, K_DIST_MAX_DISTANCE, ra);
   return ra;
 }
 
@@ -377,10 +377,10 @@ DEV SearchResult search_pair(ParseCtx& c, uint32_t posA, PendingB& B) {
 DEV SearchResult finalize_b(ParseCtx& c, PendingB& B) {
   SearchResult r = B.sr;
   insert_searched(c, B.pos, B.key, B.tag, B.tag2, B.num);
-  if (r.score == K_MIN_SCORE) {
-    const uint32_t dictionary_start = umin(B.pos + c.stream_offset, c.max_backward_limit);
-    dict_search(c, B.pos, c.pos_end - B.pos, dictionary_start, r);
-  }
+  const uint32_t dictionary_start = umin(B.pos + c.stream_offset, c.max_backward_limit);
+  if (r.score == K_MIN_SCORE) dict_search(c, B.pos, c.pos_end - B.pos, dictionary_start + c.gap, r);
+  if (c.cd) compound_lookup(c.cd, c.data + B.pos, B.pos & c.ring_mask, c.ring_mask, c.dc, c.pos_end - B.pos,
+                            dictionary_start, K_DIST_MAX_DISTANCE, r);
   B.valid = false;
   return r;
 }
@@ -474,7 +474,7 @@ DEV void parse_block(ParseCtx& c, uint32_t position, uint32_t num_bytes,
     B.valid = false;
     apply_random_heuristics = position + 2u * sr.len + spree_window;
     {
-      const uint32_t dictionary_start = umin(position + c.stream_offset, c.max_backward_limit);
+      const uint32_t dictionary_start = umin(position + c.stream_offset, c.max_backward_limit) + c.gap;
       const uint32_t distance_code = compute_distance_code(sr.distance, dictionary_start, c.dc);
       if (sr.distance <= dictionary_start && distance_code > 0) {
         c.dc[3] = c.dc[2]; c.dc[2] = c.dc[1]; c.dc[1] = c.dc[0]; c.dc[0] = (int32_t)sr.distance;
@@ -504,7 +504,7 @@ DEV void parse_block(ParseCtx& c, uint32_t position, uint32_t num_bytes,
   last_insert_len = insert_length;
 }
 
-// ExtendLastCommand, encode.c:905-971 (no compound dictionary).
+// ExtendLastCommand, encode.c:905-971.
 DEV void extend_last_command(const ParseCtx& c, Command* cmds, uint32_t ncmds,
                              uint32_t last_processed_pos, int lgwin, int32_t dc0,
                              uint32_t& bytes, uint32_t& pos) {
@@ -540,6 +540,11 @@ DEV void extend_last_command(const ParseCtx& c, Command* cmds, uint32_t ncmds,
       pos += run;
       if (run < 64u || bytes == 0) break;
     }
+  } else if (c.cd && cmd_dist > max_distance) {
+    const uint32_t gained = compound_extend(c.cd, c.data + pos, bytes, cmd_dist, max_distance, last_copy_len);
+    last.copy_len += gained;
+    bytes -= gained;
+    pos += gained;
   }
   last.cmd_prefix = (uint16_t)combine_length_codes(insert_length_code(last.insert_len),
       copy_length_code((uint32_t)((int)(last.copy_len & 0x1FFFFFFu) + (int)(last.copy_len >> 25))),

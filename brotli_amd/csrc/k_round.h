@@ -113,7 +113,7 @@ DEV void inject_flush_padding(RoundRegs& r, uint8_t* out) {
 // Runs the shard until a meta-block is ready for the build/store kernels
 // (S->mb_valid = 1) or the shard is complete (S->done = 1).
 DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
-                     const DeviceTables* T, const uint8_t* input, uint8_t* ws) {
+                     const DeviceTables* T, const uint8_t* input, uint8_t* ws, const CompoundDict* cd = nullptr) {
   const int lane = wave_lane();
   if (S->done || S->mb_valid || S->error) return;
 
@@ -133,6 +133,8 @@ DEV void parse_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   c.dict_lookups = S->dict_lookups;
   c.dict_matches = S->dict_matches;
   c.pair_enabled = (J.flags & JOB_FLAG_NO_PAIR) == 0;
+  c.cd = cd;
+  c.gap = cd ? cd->total_size : 0u;
   for (int i = 0; i < 4; ++i) c.dc[i] = S->dist_cache[i];
 
   RoundRegs r;

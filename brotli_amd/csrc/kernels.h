@@ -40,6 +40,7 @@ struct JobArgs {
   uint32_t nshards;
   uint32_t init_blocks_per_shard;
   uint32_t* counters;   // [0] shards with work left after this round, [1] faults
+  const CompoundDict* cd = nullptr;   // attached dictionaries of a single stream (k_dict.h)
 };
 
 // grid = nshards * init_blocks_per_shard, block = 256
@@ -80,7 +81,7 @@ __global__ void __launch_bounds__(256) k_init(JobArgs a) {
 __global__ void __launch_bounds__(64) k_parse(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
-  parse_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
+  parse_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, a.cd);
   if (threadIdx.x == 0 && a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
 }
 

@@ -79,10 +79,16 @@ uint32_t BrotliEncoderVersion(void);
 /* encode.h:531  BrotliEncoderEstimatePeakMemoryUsage (host memory of one instance; the encoder
    state itself is device memory) */
 size_t BrotliEncoderEstimatePeakMemoryUsage(int quality, int lgwin, size_t input_size);
-/* encode.h:534  BrotliEncoderGetPreparedDictionarySize: always 0 ("not valid") */
+/* encode.h:534  BrotliEncoderGetPreparedDictionarySize: host bytes of the index this library built
+   (the raw dictionary bytes stay the caller's), 0 = not a dictionary of this library */
 size_t BrotliEncoderGetPreparedDictionarySize(const BrotliEncoderPreparedDictionary* dictionary);
-/* encode.h:342 / 348 / 361: prepared dictionaries are outside the GPU path; the
-   symbols exist, PrepareDictionary returns NULL and Attach returns BROTLI_FALSE. */
+/* encode.h:342 / 348 / 361 (c/enc/encode.c:1756-1880, c/enc/compound_dictionary.c): raw LZ77-prefix
+   dictionaries (type BROTLI_SHARED_DICTIONARY_RAW = 0), up to 15 per encoder instance.  The caller
+   keeps the dictionary bytes alive while a prepared dictionary exists, and the prepared dictionary
+   alive while an encoder uses it — as with the reference.  Any other type returns NULL (the
+   reference's serialized form is an experimental build option).  Attached dictionaries are looked
+   up on the device by the single-stream path at qualities 2 - 9; qualities 0 - 1 ignore them; an
+   instance driven by a partition plan (BROTLI_AMD_SHARD_KB) refuses Attach. */
 BrotliEncoderPreparedDictionary* BrotliEncoderPrepareDictionary(
     int type, size_t data_size, const uint8_t* data, int quality,
     brotli_amd_alloc_func alloc_func, brotli_amd_free_func free_func, void* opaque);

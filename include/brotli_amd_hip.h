@@ -130,6 +130,24 @@ int brotli_amd_stream_create(BrotliAmdCtx* ctx, int quality, int lgwin, uint32_t
    the stream. */
 int brotli_amd_stream_write(BrotliAmdStream* stream, const uint8_t* data, uint64_t len, int op,
                             const uint8_t** out, uint64_t* out_len);
+/* Attached dictionaries of the stream (BrotliEncoderAttachPreparedDictionary, c/enc/encode.c:1828-1880,
+   raw LZ77 prefixes only): chunk d is its bytes plus the index the device lookup walks —
+   starts[key] .. starts[key + 1] are the positions (newest first, at most 32) whose eight bytes hash
+   to `key` (brotli_amd/csrc/dict_index.h builds it; brotli_amd/csrc/k_dict.h reads it).  All
+   pointers are host memory; everything is copied to the device by the call.  The call REPLACES the
+   stream's dictionary list (pass all chunks attached so far, in attach order, at most 15); it takes
+   effect with the next input block, as in the reference.  Every hasher that has a dictionary variant
+   in the reference looks the chunks up (H3 - H6, H40 - H42, H58, H68); H2 and H54 only shift their
+   distances by the dictionary size (backward_references.c:194-243, 256-282). */
+typedef struct BrotliAmdDictChunk {
+  const uint8_t* source;
+  const uint32_t* starts;
+  const uint32_t* items;
+  uint32_t source_size;
+  uint32_t bucket_bits;
+} BrotliAmdDictChunk;
+int brotli_amd_stream_attach_dictionary(BrotliAmdStream* stream, const BrotliAmdDictChunk* chunks,
+                                        uint32_t nchunks);
 /* Hands the pending partial byte (s->last_bytes_ / last_bytes_bits_) to the caller and
    clears it on the device: the caller continues the byte (metadata header). */
 int brotli_amd_stream_take_partial(BrotliAmdStream* stream, uint32_t* nbits, uint32_t* value);

@@ -27,6 +27,10 @@ struct BrotliAmdStream {
   uint32_t counters[16];
   uint64_t fed = 0;
   bool finished = false;
+  std::vector<std::vector<uint8_t>> dict_src;
+  std::vector<std::vector<uint32_t>> dict_starts, dict_items;
+  CompoundDict cd;
+  bool have_cd = false;
 };
 
 namespace {
@@ -212,6 +216,7 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
   a.nshards = 1;
   a.init_blocks_per_shard = 1;
   a.counters = s->counters;
+  a.cd = s->have_cd ? &s->cd : nullptr;
   for (uint64_t round = 0;; ++round) {
     if (round > (s->fed >> 10) + 64) return set_err(c, "stream rounds do not converge (device fault)", BROTLI_AMD_ERROR);
     memset(s->counters, 0, sizeof(s->counters));
@@ -230,6 +235,36 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
   if (op == BROTLI_AMD_OP_FINISH) s->finished = true;
   *out = s->host_out.data();
   *out_len = s->host_out.size();
+  return BROTLI_AMD_OK;
+}
+
+int brotli_amd_stream_attach_dictionary(BrotliAmdStream* s, const BrotliAmdDictChunk* chunks, uint32_t nchunks) {
+  if (nchunks > DICT_MAX_CHUNKS) return set_err(s->c, "more than 15 dictionary chunks", BROTLI_AMD_UNSUPPORTED);
+  s->dict_src.assign(nchunks, {});
+  s->dict_starts.assign(nchunks, {});
+  s->dict_items.assign(nchunks, {});
+  memset(&s->cd, 0, sizeof(s->cd));
+  uint32_t total = 0;
+  for (uint32_t k = 0; k < nchunks; ++k) {
+    const BrotliAmdDictChunk& h = chunks[k];
+    const size_t nkeys = (size_t)1 << h.bucket_bits;
+    s->dict_src[k].assign(h.source, h.source + h.source_size);
+    s->dict_src[k].resize(h.source_size + DICT_SOURCE_SLACK, 0);
+    s->dict_starts[k].assign(h.starts, h.starts + nkeys + 1);
+    s->dict_items[k].assign(h.items, h.items + h.starts[nkeys]);
+    s->dict_items[k].push_back(0);
+    DictChunk& g = s->cd.chunks[k];
+    g.source = s->dict_src[k].data();
+    g.starts = s->dict_starts[k].data();
+    g.items = s->dict_items[k].data();
+    g.source_size = h.source_size;
+    g.bucket_bits = h.bucket_bits;
+    g.offset = total;
+    total += h.source_size;
+  }
+  s->cd.num_chunks = nchunks;
+  s->cd.total_size = total;
+  s->have_cd = nchunks != 0;
   return BROTLI_AMD_OK;
 }
 

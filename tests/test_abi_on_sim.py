@@ -73,6 +73,28 @@ def test_single_stream_sequences_and_metadata(simabi, stock, quality, lgwin):
     assert outs[0] == outs[1]
 
 
+@pytest.mark.parametrize("quality,lgwin,nbytes,dict_bytes,nchunks", [
+    (5, 22, 90000, 40000, 1), (5, 18, 150000, 120000, 3), (5, 22, 3000, 100000, 2), (5, 20, 70000, 9, 1)])
+def test_attached_dictionaries(simabi, stock, ref, quality, lgwin, nbytes, dict_bytes, nchunks):
+    """BrotliEncoderPrepareDictionary(RAW) + AttachPreparedDictionary next to the reference: the
+    index built by dict_index.h, the device lookup (k_dict.h) after every search, the gap in the
+    distance codes, ExtendLastCommand into the dictionary; one call, assorted call shapes, and a
+    dictionary attached in the middle of the stream."""
+    data, chunks = G.dictionary_case(nbytes, dict_bytes, nchunks, seed=quality * 100 + lgwin + nchunks)
+    params = ((1, quality), (2, lgwin))
+    n = len(data)
+    shapes = [([(n, 2)], False, 0), (_chunks(n, 17000, 2, 2), True, 0), ([(n // 3, 1), (n - n // 3, 2)], False, 1)]
+    for ops, take, at in shapes:
+        want, fin_w = drive(stock, data, ops, params, take=take, dictionaries=chunks, attach_before_op=at)
+        got, fin_g = drive(simabi, data, ops, params, take=take, dictionaries=chunks, attach_before_op=at)
+        assert fin_w and fin_g and got == want, (quality, lgwin, ops[:3], at)
+    want, _ = drive(stock, data, [(n, 2)], params, dictionaries=chunks)
+    assert ref.decompress_with(want, n, chunks) == data
+    if dict_bytes > 1000:
+        plain, _ = drive(stock, data, [(n, 2)], params)
+        assert len(want) < len(plain)
+
+
 def test_empty_first_operation_leaves_the_size_hint_open(simabi, stock):
     """An empty EMIT_METADATA / FLUSH before the first data byte must not pin the size hint to 0
     (UpdateSizeHint, encode.c:1619-1632): with >= 1 MiB of data behind it the reference still

@@ -37,6 +37,14 @@ def _bind(path):
                                         C.POINTER(C.c_size_t), C.c_char_p]
     L.BrotliEncoderMaxCompressedSize.restype = C.c_size_t
     L.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
+    L.BrotliEncoderPrepareDictionary.restype = C.c_void_p
+    L.BrotliEncoderPrepareDictionary.argtypes = [C.c_int, C.c_size_t, C.c_char_p, C.c_int,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p]
+    L.BrotliEncoderDestroyPreparedDictionary.argtypes = [C.c_void_p]
+    L.BrotliEncoderAttachPreparedDictionary.argtypes = [C.c_void_p, C.c_void_p]
+    if hasattr(L, "BrotliEncoderGetPreparedDictionarySize"):   # (not in the test build of the reference)
+        L.BrotliEncoderGetPreparedDictionarySize.restype = C.c_size_t
+        L.BrotliEncoderGetPreparedDictionarySize.argtypes = [C.c_void_p]
     return L
 
 
@@ -50,16 +58,30 @@ def stock(ref):
     return _bind(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
 
 
-def drive(L, data, ops, params=(), out_chunk=1 << 16, take=False):
-    """ops: list of (nbytes, op).  Returns all output bytes."""
+def drive(L, data, ops, params=(), out_chunk=1 << 16, take=False, dictionaries=(), attach_before_op=0):
+    """ops: list of (nbytes, op).  Returns all output bytes.  `dictionaries`: raw LZ77 prefixes,
+    prepared and attached in order (encode.h:318-363) right before operation `attach_before_op`."""
     st = L.BrotliEncoderCreateInstance(None, None, None)
     for k, v in ((1, 5), (2, 22)) + tuple(params):
         assert L.BrotliEncoderSetParameter(st, k, v)
+    keep = [C.create_string_buffer(bytes(d), max(len(d), 1)) for d in dictionaries]
+    prepared = []
+
+    def attach():
+        for d, b in zip(dictionaries, keep):
+            pd = L.BrotliEncoderPrepareDictionary(0, len(d), b, 11, None, None, None)
+            assert pd
+            if hasattr(L, "BrotliEncoderGetPreparedDictionarySize"):
+                assert L.BrotliEncoderGetPreparedDictionarySize(pd) > 0
+            assert L.BrotliEncoderAttachPreparedDictionary(st, pd)
+            prepared.append(pd)
     buf = C.create_string_buffer(bytes(data), len(data))
     out = C.create_string_buffer(out_chunk)
     res = bytearray()
     off = 0
-    for n, op in ops:
+    for k_op, (n, op) in enumerate(ops):
+        if k_op == attach_before_op:
+            attach()
         avail_in = C.c_size_t(n)
         next_in = C.c_void_p(C.addressof(buf) + off)
         off += n
@@ -91,6 +113,8 @@ def drive(L, data, ops, params=(), out_chunk=1 << 16, take=False):
                 break
     fin = bool(L.BrotliEncoderIsFinished(st))
     L.BrotliEncoderDestroyInstance(st)
+    for pd in prepared:
+        L.BrotliEncoderDestroyPreparedDictionary(pd)
     return bytes(res), fin
 
 
