@@ -106,6 +106,9 @@ struct QShard {
   // loads alive
   uint32_t pf_val, pf_acc;
   uint64_t prof[12];
+  // attached dictionaries (k_dict.h): only the one-shard-per-wave stream kernels set them
+  const CompoundDict* cd = nullptr;
+  uint32_t gap = 0;        // their total size (backward_references_inc.h:31)
 };
 
 DEV const ShardDesc& q_desc(const QShard& g) { return g.descs[g.shard]; }
@@ -312,7 +315,7 @@ DEV void q_dict_search(const JobParams& J, const DeviceTables* T, QShard& g, boo
       while (matchlen < wlen && g.data[P + matchlen] == w[matchlen]) ++matchlen;
     }
   }
-  const uint32_t dictionary_start = umin(P + g.stream_offset, J.max_backward_limit);
+  const uint32_t dictionary_start = umin(P + g.stream_offset, J.max_backward_limit) + g.gap;
   for (int i = 0; i < nprobes; ++i) {
     const uint32_t len = q_from(wlen, i), word_idx = q_from(widx, i), ml = q_from(matchlen, i);
     if (!go) continue;
@@ -332,6 +335,26 @@ DEV void q_dict_search(const JobParams& J, const DeviceTables* T, QShard& g, boo
     out.score = score;
     g.dict_matches++;
   }
+}
+
+// One shard per wave (k_parse_deep.h, k_parse_quick.h): the attached-dictionary lookup that follows
+// FindLongestMatch (backward_references_inc.h:115-119, 147-152) and the dictionary branch of
+// ExtendLastCommand (encode.c:930-961).
+DEV void q_compound_lookup(const JobParams& J, const QShard& g, uint32_t P, uint32_t max_length, QResult& r) {
+  if (!g.cd) return;
+  SearchResult sr;
+  sr.len = r.len; sr.distance = r.distance; sr.score = r.score; sr.len_code_delta = r.delta;
+  compound_lookup(g.cd, g.data + P, P & J.ring_mask, J.ring_mask, g.dc, max_length,
+                  umin(P + g.stream_offset, J.max_backward_limit), K_DIST_MAX_DISTANCE, sr);
+  r.len = sr.len; r.distance = sr.distance; r.score = sr.score; r.delta = sr.len_code_delta;
+}
+DEV void q_compound_extend(const QShard& g, Command& last, uint32_t cmd_dist, uint32_t max_distance,
+                           uint32_t& bytes, uint32_t& pos) {
+  if (!g.cd || cmd_dist <= max_distance) return;
+  const uint32_t gained = compound_extend(g.cd, g.data + pos, bytes, cmd_dist, max_distance, last.copy_len & 0x1FFFFFFu);
+  last.copy_len += gained;
+  bytes -= gained;
+  pos += gained;
 }
 
 // What the insertion of the searched position needs from its search (per lane).

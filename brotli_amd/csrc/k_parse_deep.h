@@ -321,6 +321,7 @@ DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* 
   }
   wave_sync();
   q_dict_search(J, T, g, r.score == K_MIN_SCORE, P, max_length, r);
+  q_compound_lookup(J, g, P, max_length, r);
   return r;
 }
 
@@ -364,6 +365,8 @@ DEV void d_setup_block(const JobParams& J, const DeepGeom& G, QShard& g, uint8_t
           pos += run;
           if (run < 64u || bytes == 0) break;
         }
+      } else {
+        q_compound_extend(g, last, cmd_dist, max_distance, bytes, pos);
       }
       last.cmd_prefix = (uint16_t)combine_length_codes(insert_length_code(last.insert_len),
           copy_length_code((uint32_t)((int)(last.copy_len & 0x1FFFFFFu) + (int)(last.copy_len >> 25))),
@@ -383,7 +386,7 @@ DEV void d_setup_block(const JobParams& J, const DeepGeom& G, QShard& g, uint8_t
 // ---- the kernel body: one shard per wave ------------------------------------------------
 template <int E>
 DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S, const DeviceTables* T,
-                          const uint8_t* input, uint8_t* ws, uint8_t* lds_dup) {
+                          const uint8_t* input, uint8_t* ws, uint8_t* lds_dup, const CompoundDict* cd = nullptr) {
   const int lane = wave_lane();
   const bool writer = lane == 0;
   const uint32_t htl = hasher_htl(J.hasher_type);
@@ -399,6 +402,8 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   g.wsb = ws;
   g.shard = 0;
   g.stream_offset = D.stream_offset;
+  g.cd = cd;
+  g.gap = cd ? cd->total_size : 0u;
   regs_load(g.r, S);
   for (int i = 0; i < 4; ++i) g.dc[i] = S->dist_cache[i];
   g.dict_lookups = S->dict_lookups;
@@ -477,7 +482,7 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
           g.st_stride = 1;
         }
         g.apply_random_heuristics = g.position + 2u * g.sr_len + J.spree_window;
-        const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit);
+        const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit) + g.gap;
         const uint32_t distance_code = compute_distance_code(g.sr_dist, dictionary_start, g.dc);
         if (g.sr_dist <= dictionary_start && distance_code > 0) {
           g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)g.sr_dist;

@@ -342,6 +342,8 @@ DEV void k_setup_block(const JobParams& J, const QuickGeom& G, QShard& g) {
           pos += run;
           if (run < 64u || bytes == 0) break;
         }
+      } else {
+        q_compound_extend(g, last, cmd_dist, max_distance, bytes, pos);
       }
       last.cmd_prefix = (uint16_t)combine_length_codes(insert_length_code(last.insert_len),
           copy_length_code((uint32_t)((int)(last.copy_len & 0x1FFFFFFu) + (int)(last.copy_len >> 25))),
@@ -360,7 +362,7 @@ DEV void k_setup_block(const JobParams& J, const QuickGeom& G, QShard& g) {
 
 // ---- the kernel body: one shard per wave ------------------------------------------------
 DEV void parse_quick_round(const JobParams& J, const ShardDesc& D, ShardState* S, const DeviceTables* T,
-                           const uint8_t* input, uint8_t* ws) {
+                           const uint8_t* input, uint8_t* ws, const CompoundDict* cd = nullptr) {
   const int lane = wave_lane();
   const bool writer = lane == 0;
   const uint32_t htl = hasher_htl(J.hasher_type);
@@ -376,6 +378,8 @@ DEV void parse_quick_round(const JobParams& J, const ShardDesc& D, ShardState* S
   g.wsb = ws;
   g.shard = 0;
   g.stream_offset = D.stream_offset;
+  g.cd = cd;
+  g.gap = cd ? cd->total_size : 0u;
   regs_load(g.r, S);
   for (int i = 0; i < 4; ++i) g.dc[i] = S->dist_cache[i];
   g.dict_lookups = S->dict_lookups;
@@ -408,7 +412,9 @@ DEV void parse_quick_round(const JobParams& J, const ShardDesc& D, ShardState* S
       const uint32_t P = g.position + (lazy ? 1u : 0u);
       // the lazy probe only looks for something longer than what it has (:127-128)
       const uint32_t len_in = lazy ? umin(g.sr_len - 1u, g.pos_end - P) : 0u;
-      const QResult cur = chain ? fc_search(J, F, T, g, P) : k_search(J, G, T, g, P, len_in);
+      QResult cur = chain ? fc_search(J, F, T, g, P) : k_search(J, G, T, g, P, len_in);
+      // attached dictionaries: H2 and H54 have no dictionary variant (backward_references.c:194-243)
+      if (g.cd && J.hasher_type != 2 && J.hasher_type != 54) q_compound_lookup(J, g, P, g.pos_end - P, cur);
       g.stat_searches++;
       bool commit = false;
       if (!lazy) {
@@ -459,7 +465,7 @@ DEV void parse_quick_round(const JobParams& J, const ShardDesc& D, ShardState* S
           g.st_stride = 1;
         }
         g.apply_random_heuristics = g.position + 2u * g.sr_len + J.spree_window;
-        const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit);
+        const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit) + g.gap;
         const uint32_t distance_code = compute_distance_code(g.sr_dist, dictionary_start, g.dc);
         if (g.sr_dist <= dictionary_start && distance_code > 0) {
           g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)g.sr_dist;

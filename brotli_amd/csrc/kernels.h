@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(64, 2) k_parse_deep(JobArgs a) {
   __shared__ uint8_t lds_dup[D_DUP_SLOTS];
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
-  parse_deep_round<E>(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds_dup);
+  parse_deep_round<E>(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, lds_dup, a.cd);
   if (threadIdx.x == 0 && a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
 }
 
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(64, 2) k_parse_deep(JobArgs a) {
 __global__ void __launch_bounds__(64) k_parse_quick(JobArgs a) {
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
-  parse_quick_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws);
+  parse_quick_round(a.J, a.shards[shard], &a.states[shard], a.T, a.input, a.ws, a.cd);
   if (threadIdx.x == 0 && a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
 }
 

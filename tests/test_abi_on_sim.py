@@ -73,26 +73,68 @@ def test_single_stream_sequences_and_metadata(simabi, stock, quality, lgwin):
     assert outs[0] == outs[1]
 
 
-@pytest.mark.parametrize("quality,lgwin,nbytes,dict_bytes,nchunks", [
-    (5, 22, 90000, 40000, 1), (5, 18, 150000, 120000, 3), (5, 22, 3000, 100000, 2), (5, 20, 70000, 9, 1)])
-def test_attached_dictionaries(simabi, stock, ref, quality, lgwin, nbytes, dict_bytes, nchunks):
+@pytest.mark.parametrize("quality,lgwin,nbytes,dict_bytes,nchunks,shapes", [
+    (5, 18, 100000, 90000, 3, 3), (5, 22, 3000, 100000, 2, 3), (5, 20, 40000, 9, 1, 1),
+    (6, 22, 60000, 30000, 2, 2), (9, 24, 60000, 30000, 1, 2), (4, 18, 60000, 30000, 2, 2), (3, 22, 60000, 30000, 1, 2),
+    (2, 22, 60000, 30000, 1, 1), (5, 16, 60000, 30000, 2, 2), (9, 12, 60000, 30000, 1, 2)])
+def test_attached_dictionaries(simabi, stock, ref, quality, lgwin, nbytes, dict_bytes, nchunks, shapes):
     """BrotliEncoderPrepareDictionary(RAW) + AttachPreparedDictionary next to the reference: the
-    index built by dict_index.h, the device lookup (k_dict.h) after every search, the gap in the
-    distance codes, ExtendLastCommand into the dictionary; one call, assorted call shapes, and a
-    dictionary attached in the middle of the stream."""
+    index built by dict_index.h, the device lookup (k_dict.h) after every search in k_parse /
+    k_parse_deep / k_parse_quick, the gap in the distance codes, ExtendLastCommand into the
+    dictionary; one call, a dictionary attached in the middle of the stream, PROCESS / FLUSH with
+    TakeOutput."""
     data, chunks = G.dictionary_case(nbytes, dict_bytes, nchunks, seed=quality * 100 + lgwin + nchunks)
     params = ((1, quality), (2, lgwin))
     n = len(data)
-    shapes = [([(n, 2)], False, 0), (_chunks(n, 17000, 2, 2), True, 0), ([(n // 3, 1), (n - n // 3, 2)], False, 1)]
-    for ops, take, at in shapes:
+    all_shapes = [([(n, 2)], False, 0), ([(n // 3, 1), (n - n // 3, 2)], False, 1), (_chunks(n, 17000, 2, 2), True, 0)]
+    for ops, take, at in all_shapes[:shapes]:
         want, fin_w = drive(stock, data, ops, params, take=take, dictionaries=chunks, attach_before_op=at)
         got, fin_g = drive(simabi, data, ops, params, take=take, dictionaries=chunks, attach_before_op=at)
         assert fin_w and fin_g and got == want, (quality, lgwin, ops[:3], at)
     want, _ = drive(stock, data, [(n, 2)], params, dictionaries=chunks)
     assert ref.decompress_with(want, n, chunks) == data
-    if dict_bytes > 1000:
+    if dict_bytes > 1000 and quality != 2:
         plain, _ = drive(stock, data, [(n, 2)], params)
         assert len(want) < len(plain)
+
+
+def test_dictionary_api_edges_and_cli(simabi, tmp_path):
+    """Not-a-dictionary handles, the 15-chunk limit, a partition plan, quality 1 (ignores them);
+    `brotli -D FILE` of the reference CLI over this library (the simulator build) next to the
+    stock CLI."""
+    L = simabi
+    assert L.BrotliEncoderPrepareDictionary(1, 4, b"abcd", 11, None, None, None) is None
+    assert L.BrotliEncoderGetPreparedDictionarySize(None) == 0
+    d = C.create_string_buffer(b"hello hello hello hello", 23)
+    pd = L.BrotliEncoderPrepareDictionary(0, 23, d, 11, None, None, None)
+    assert pd and L.BrotliEncoderGetPreparedDictionarySize(pd) > (1 << 17) * 4
+    st = L.BrotliEncoderCreateInstance(None, None, None)
+    for _ in range(15):
+        assert L.BrotliEncoderAttachPreparedDictionary(st, pd)
+    assert not L.BrotliEncoderAttachPreparedDictionary(st, pd)
+    assert not L.BrotliEncoderAttachPreparedDictionary(st, None)
+    L.BrotliEncoderDestroyInstance(st)
+    st = L.BrotliEncoderCreateInstance(None, None, None)
+    assert L.BrotliEncoderSetParameter(st, 0x4D490001, 1 << 17)
+    assert not L.BrotliEncoderAttachPreparedDictionary(st, pd)
+    L.BrotliEncoderDestroyInstance(st)
+    L.BrotliEncoderDestroyPreparedDictionary(pd)
+    data, chunks = G.dictionary_case(30000, 20000, 1, seed=5)
+    with_d, fin = drive(L, data, [(len(data), 2)], Q1, dictionaries=chunks)
+    without, _ = drive(L, data, [(len(data), 2)], Q1)
+    assert fin and with_d == without
+    cli, cli_ref = (os.path.join(ROOT, "oracle", "_ref", n) for n in ("brotli_cli_amd", "brotli_cli_ref"))
+    if not (os.path.exists(cli) and os.path.exists(cli_ref)):
+        pytest.skip("oracle/_ref/brotli_cli_amd / brotli_cli_ref not built")
+    os.symlink(SIM_ABI, tmp_path / "libbrotlienc.so.1")
+    env = dict(os.environ, LD_LIBRARY_PATH=str(tmp_path), BROTLI_AMD_TABLES=TABLES)
+    data, chunks = G.dictionary_case(60000, 50000, 1, seed=91)
+    (tmp_path / "input.bin").write_bytes(data)
+    (tmp_path / "dictionary.bin").write_bytes(chunks[0])
+    args = ["-q", "5", "-w", "22", "-D", str(tmp_path / "dictionary.bin"), "-c", str(tmp_path / "input.bin")]
+    got = subprocess.run([cli] + args, capture_output=True, env=env, check=True).stdout
+    want = subprocess.run([cli_ref] + args, capture_output=True, check=True).stdout
+    assert got == want
 
 
 def test_empty_first_operation_leaves_the_size_hint_open(simabi, stock):

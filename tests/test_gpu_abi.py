@@ -246,6 +246,86 @@ def test_reference_cli_on_our_library():
     assert d.stdout == ALICE
 
 
+# --- attached dictionaries ----------------------------------------------------
+
+@pytest.mark.parametrize("quality,lgwin", [(5, 22), (5, 18), (6, 22), (7, 20), (9, 24), (4, 22), (3, 18), (2, 22),
+                                           (5, 16), (7, 14), (9, 12)])
+def test_attached_dictionaries_equal_reference(amd, stock, ref, quality, lgwin):
+    """BrotliEncoderPrepareDictionary(RAW) + AttachPreparedDictionary on both libraries (encode.h:
+    318-363): one FINISH call, PROCESS / FLUSH shapes with TakeOutput, a dictionary of three chunks,
+    a dictionary attached in the middle of the stream, a tiny input against a large dictionary."""
+    params = ((1, quality), (2, lgwin))
+    for nbytes, dict_bytes, nchunks in ((200000, 80000, 1), (300000, 250000, 3), (3000, 100000, 2)):
+        data, chunks = G.dictionary_case(nbytes, dict_bytes, nchunks, seed=quality * 100 + lgwin + nchunks)
+        n = len(data)
+        for ops, take, at in (([(n, 2)], False, 0), (_chunks(n, 37000, 2, 2), True, 0),
+                              ([(n // 3, 1), (n - n // 3, 2)], False, 1)):
+            want, fin_w = drive(stock, data, ops, params, take=take, dictionaries=chunks, attach_before_op=at)
+            got, fin_g = drive(amd, data, ops, params, take=take, dictionaries=chunks, attach_before_op=at)
+            assert fin_w and fin_g and got == want, (quality, lgwin, nbytes, ops[:3], at)
+        want, _ = drive(stock, data, [(n, 2)], params, dictionaries=chunks)
+        assert ref.decompress_with(want, n, chunks) == data
+        if quality != 2:
+            plain, _ = drive(stock, data, [(n, 2)], params)
+            assert len(want) < len(plain)
+
+
+def test_attached_dictionary_past_one_mebibyte(amd, stock):
+    """H68 at quality 5 and H54 at quality 4 (chosen once a MiB is announced); H54 has no dictionary
+    variant in the reference and only shifts its distances."""
+    data, chunks = G.dictionary_case((1 << 20) + 50000, 150000, 2, seed=77)
+    for quality in (5, 4):
+        params = ((1, quality), (2, 22))
+        want, fin_w = drive(stock, data, [(len(data), 2)], params, dictionaries=chunks)
+        got, fin_g = drive(amd, data, [(len(data), 2)], params, dictionaries=chunks)
+        assert fin_w and fin_g and got == want, quality
+
+
+def test_dictionary_api_edges(amd):
+    """Not-a-dictionary handles, the 15-chunk limit, a partition plan, quality 1 (ignores them)."""
+    assert amd.BrotliEncoderPrepareDictionary(1, 4, b"abcd", 11, None, None, None) is None   # serialized: not built
+    assert amd.BrotliEncoderGetPreparedDictionarySize(None) == 0
+    d = C.create_string_buffer(b"hello hello hello hello", 23)
+    pd = amd.BrotliEncoderPrepareDictionary(0, 23, d, 11, None, None, None)
+    assert pd and amd.BrotliEncoderGetPreparedDictionarySize(pd) > (1 << 17) * 4
+    st = amd.BrotliEncoderCreateInstance(None, None, None)
+    for _ in range(15):
+        assert amd.BrotliEncoderAttachPreparedDictionary(st, pd)
+    assert not amd.BrotliEncoderAttachPreparedDictionary(st, pd)          # SHARED_BROTLI_MAX_COMPOUND_DICTS
+    assert not amd.BrotliEncoderAttachPreparedDictionary(st, None)
+    amd.BrotliEncoderDestroyInstance(st)
+    st = amd.BrotliEncoderCreateInstance(None, None, None)
+    assert amd.BrotliEncoderSetParameter(st, 0x4D490001, 1 << 17)
+    assert not amd.BrotliEncoderAttachPreparedDictionary(st, pd)          # partition plan: refused
+    amd.BrotliEncoderDestroyInstance(st)
+    amd.BrotliEncoderDestroyPreparedDictionary(pd)
+    data, chunks = G.dictionary_case(100000, 50000, 1, seed=5)
+    with_d, fin = drive(amd, data, [(len(data), 2)], Q1, dictionaries=chunks)
+    without, _ = drive(amd, data, [(len(data), 2)], Q1)
+    assert fin and with_d == without
+
+
+def test_reference_cli_with_dictionary_on_our_library(tmp_path):
+    """`brotli -D FILE` (c/tools/brotli.c: PrepareDictionary + AttachPreparedDictionary) linked against
+    our library writes what the stock build writes, and the stock decoder restores the input."""
+    cli, cli_ref = (os.path.join(ROOT, "oracle", "_ref", n) for n in ("brotli_cli_amd", "brotli_cli_ref"))
+    if not (os.path.exists(cli) and os.path.exists(cli_ref)):
+        pytest.skip("oracle/_ref/brotli_cli_amd / brotli_cli_ref not built")
+    dropin = os.path.join(LIBDIR, "dropin")
+    env = dict(os.environ, LD_LIBRARY_PATH=dropin + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    data, chunks = G.dictionary_case(400000, 200000, 1, seed=91)
+    src, dic = tmp_path / "input.bin", tmp_path / "dictionary.bin"
+    src.write_bytes(data)
+    dic.write_bytes(chunks[0])
+    for q in ("5", "9", "3"):
+        args = ["-q", q, "-w", "22", "-D", str(dic), "-c", str(src)]
+        got = subprocess.run([cli] + args, capture_output=True, env=env, check=True).stdout
+        want = subprocess.run([cli_ref] + args, capture_output=True, check=True).stdout
+        assert got == want, q
+        back = subprocess.run([cli_ref, "-d", "-D", str(dic), "-c"], input=got, capture_output=True, check=True).stdout
+        assert back == data
+
+
 # --- quality 1 (BrotliEncoderCompressStreamFast / two-pass fragments, SURVEY.md §8 row q1) ----------
 
 Q1 = ((1, 1),)      # BROTLI_PARAM_QUALITY = 1; `drive` sets quality 5 first, the later value wins
