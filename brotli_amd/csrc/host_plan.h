@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <string>
 #include <vector>
 
 #include "enc_types.h"
@@ -319,5 +320,34 @@ static inline void host_tables_fill(const HostTables& h, uint32_t log2_n,
   memcpy(T->dict_offsets_by_length, h.offsets_by_length, sizeof(T->dict_offsets_by_length));
   memcpy(T->dict_size_bits_by_length, h.size_bits_by_length, sizeof(T->dict_size_bits_by_length));
 }
+
+// ---- decoder side: the word transforms (brotli_amd/data/brotli_transforms.bin, tools/gen_transforms.c)
+struct HostTransforms {
+  std::vector<uint8_t> records;   // n x 8 bytes (DecTransform, k_decode.h)
+  std::vector<uint8_t> text;
+  uint32_t n = 0;
+};
+static inline bool host_transforms_load(const char* tables_path, HostTransforms* t) {
+  // sits next to the tables blob
+  std::string path(tables_path);
+  const size_t slash = path.find_last_of('/');
+  path = (slash == std::string::npos ? std::string() : path.substr(0, slash + 1)) + "brotli_transforms.bin";
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  char magic[4];
+  uint32_t ver = 0, n = 0, ts = 0;
+  bool ok = fread(magic, 1, 4, f) == 4 && !memcmp(magic, "BRTT", 4) && fread(&ver, 4, 1, f) == 1 && ver == 1 &&
+            fread(&n, 4, 1, f) == 1 && fread(&ts, 4, 1, f) == 1 && n == 121 && ts < 4096;
+  if (ok) {
+    t->records.resize((size_t)n * 8);
+    t->text.resize(ts + 64, 0);
+    ok = fread(t->records.data(), 8, n, f) == n && fread(t->text.data(), 1, ts, f) == ts;
+    t->n = n;
+  }
+  fclose(f);
+  return ok;
+}
+// Dwords of arena one piece needs at most (k_decode.h): 256 literal + 256 command + 256 distance codes.
+static inline uint32_t dec_arena_words_max() { return 4416u + 3u * 176u + 256u * (144u + 368u + 16u + 260u) + 64u; }
 
 #endif  // BROTLI_AMD_CSRC_HOST_PLAN_H_

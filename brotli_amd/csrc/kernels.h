@@ -285,4 +285,13 @@ __global__ void __launch_bounds__(256) k_fast_emit(FastArgs a) {
   if (blockIdx.x < a.nblocks) fast_emit_block(a, blockIdx.x, threadIdx.x, blockDim.x);
 }
 
+// ---- decoder (k_decode.h) -----------------------------------------------------------------
+#include "k_decode.h"
+
+// grid = npieces, block = 64: one piece per wave
+__global__ void __launch_bounds__(64) k_decode(DecArgs a) {
+  __shared__ uint32_t lds_dec[DEC_LDS_WORDS];
+  if (blockIdx.x < a.npieces) decode_piece(a, blockIdx.x, lds_dec);
+}
+
 #endif  // BROTLI_AMD_CSRC_KERNELS_H_

@@ -355,4 +355,47 @@ long sim_stream(const char* tables_path, const uint8_t* in, size_t len, int qual
   return (long)n_out;
 }
 
+// The decoder kernel (k_decode.h) over `npieces` pieces: pieces[k] = {in_off, in_len, out_off, out_cap, flags |
+// lgwin << 32}; results[k] = {out_bytes, in_bits, error | finished << 32, lgwin | metablocks << 32}.
+long sim_decode(const char* tables_path, const uint8_t* in, size_t in_len, const uint64_t* pieces, size_t npieces,
+                uint32_t arena_words, int reverse, uint8_t* out, size_t out_cap, uint64_t* results) {
+  HostTables ht;
+  HostTransforms tr;
+  if (!host_tables_load(tables_path, &ht) || !host_transforms_load(tables_path, &tr)) return -1;
+  std::vector<double> lut;
+  DeviceTables T;
+  host_tables_fill(ht, 16, &lut, &T);
+  std::vector<uint8_t> input(in_len + 64, 0);
+  memcpy(input.data(), in, in_len);
+  std::vector<DecPiece> P(npieces);
+  for (size_t k = 0; k < npieces; ++k) {
+    P[k].in_off = pieces[5 * k]; P[k].in_len = pieces[5 * k + 1]; P[k].out_off = pieces[5 * k + 2];
+    P[k].out_cap = pieces[5 * k + 3]; P[k].flags = (uint32_t)pieces[5 * k + 4]; P[k].lgwin = (uint32_t)(pieces[5 * k + 4] >> 32);
+    if (P[k].in_off + P[k].in_len > in_len || P[k].out_off + P[k].out_cap > out_cap) return -2;
+  }
+  if (arena_words == 0) arena_words = dec_arena_words_max();
+  std::vector<DecResult> R(npieces);
+  std::vector<uint32_t> arena((size_t)npieces * arena_words, 0xCDCDCDCDu);
+  DecArgs a;
+  a.pieces = P.data();
+  a.results = R.data();
+  a.T = &T;
+  a.transforms = (const DecTransform*)tr.records.data();
+  a.transform_text = tr.text.data();
+  a.input = input.data();
+  a.out = out;
+  a.arena = arena.data();
+  a.arena_words = arena_words;
+  a.npieces = (uint32_t)npieces;
+  struct DLaunch { DecArgs a; } l{a};
+  simt::launch((unsigned)npieces, 64, [](void* p) { k_decode(((DLaunch*)p)->a); }, &l, reverse);
+  for (size_t k = 0; k < npieces; ++k) {
+    results[4 * k] = R[k].out_bytes;
+    results[4 * k + 1] = R[k].in_bits;
+    results[4 * k + 2] = R[k].error | ((uint64_t)R[k].finished << 32);
+    results[4 * k + 3] = R[k].lgwin | ((uint64_t)R[k].metablocks << 32);
+  }
+  return 0;
+}
+
 }  // extern "C"
