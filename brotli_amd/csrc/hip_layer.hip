@@ -55,6 +55,16 @@ struct BrotliAmdCtx {
   uint64_t ffrag_cap = 0, fblock_cap = 0;
   hipEvent_t ev[8] = {};
   hipEvent_t ev_ix = nullptr, ev_ixb = nullptr;
+  // decoder (k_decode.h): word transforms, per-piece arenas, piece descriptors / results
+  HostTransforms htr;
+  std::string tables_path;
+  DecTransform* d_transforms = nullptr;
+  uint8_t* d_transform_text = nullptr;
+  uint32_t* d_dec_arena = nullptr;
+  uint64_t dec_arena_cap = 0;        // dwords
+  DecPiece* d_dec_pieces = nullptr;
+  DecResult* d_dec_results = nullptr;
+  uint64_t dec_piece_cap = 0;
   // host <-> device copies of encode_host: copy lanes, each a stream and two pinned chunks
   struct CopyLane { hipStream_t s = nullptr; uint8_t* pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; };
   std::vector<CopyLane> lanes;
@@ -409,6 +419,7 @@ int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** ou
   BrotliAmdCtx* c = new BrotliAmdCtx();
   *out = c;   // returned even on failure so the caller can read the error
   c->device = device;
+  c->tables_path = tables_path;
   if (!host_tables_load(tables_path, &c->ht)) {
     fail(c, "cannot load format tables from %s", tables_path);
     return BROTLI_AMD_ERROR;
@@ -444,7 +455,8 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   void* ptrs[] = {c->d_lut, c->d_dict, c->d_hash_words, c->d_hash_lengths, c->d_log2, c->d_T,
                   c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters,
                   c->d_stage_in, c->d_stage_out, c->d_ffrags, c->d_fblocks, c->d_fbstate,
-                  c->d_ffstate, c->d_fresult};
+                  c->d_ffstate, c->d_fresult, c->d_transforms, c->d_transform_text, c->d_dec_arena,
+                  c->d_dec_pieces, c->d_dec_results};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (uint8_t* p : c->d_table_chunks) if (p) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -968,6 +980,111 @@ void brotli_amd_stream_destroy(BrotliAmdStream* s) {
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (void* p : s->dict_allocs) (void)hipFree(p);
   delete s;
+}
+
+// ---- decoder ---------------------------------------------------------------------------------
+static_assert(sizeof(BrotliAmdDecodePiece) == sizeof(DecPiece) && sizeof(BrotliAmdDecodeResult) == sizeof(DecResult),
+              "the C ABI structs are the kernel's");
+static_assert(sizeof(DecTransform) == 8, "transform records are 8 bytes");
+
+int brotli_amd_decode_device(BrotliAmdCtx* c, const void* d_in, uint64_t in_len,
+                             const BrotliAmdDecodePiece* pieces, uint64_t npieces, void* d_out,
+                             uint64_t out_cap, BrotliAmdDecodeResult* results, float* ms) {
+  if (ms) *ms = 0.f;
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  if (npieces == 0) return BROTLI_AMD_OK;
+  if (npieces > (1u << 22)) { fail(c, "too many pieces"); return BROTLI_AMD_UNSUPPORTED; }
+  for (uint64_t k = 0; k < npieces; ++k) {
+    const BrotliAmdDecodePiece& p = pieces[k];
+    if (p.in_off + p.in_len > in_len || p.out_off + p.out_cap > out_cap ||
+        (!(p.flags & BROTLI_AMD_PIECE_HEADER) && (p.lgwin < 10 || p.lgwin > 24))) {
+      fail(c, "piece %llu does not fit its buffers", (unsigned long long)k);
+      return BROTLI_AMD_UNSUPPORTED;
+    }
+  }
+  auto body = [&]() -> bool {
+    if (!c->d_transforms) {
+      if (!host_transforms_load(c->tables_path.c_str(), &c->htr)) return fail(c, "cannot load brotli_transforms.bin next to %s", c->tables_path.c_str());
+      if (!dev_upload(c, &c->d_transforms, c->htr.records.data(), c->htr.records.size())) return false;
+      if (!dev_upload(c, &c->d_transform_text, c->htr.text.data(), c->htr.text.size())) return false;
+    }
+    // arena per piece: everything a meta-block can ask for while the job is small, 48 Ki dwords (the
+    // encoder kernels' streams need a fraction of that) once thousands of pieces share the memory
+    const uint32_t full = dec_arena_words_max();
+    uint64_t words = full;
+    if (npieces * (uint64_t)full * 4u > (8ull << 30)) words = 48u << 10;
+    if (npieces * words > c->dec_arena_cap) {
+      if (c->d_dec_arena) HIP_OK(c, hipFree(c->d_dec_arena));
+      c->d_dec_arena = nullptr;
+      c->dec_arena_cap = 0;
+      HIP_OK(c, hipMalloc((void**)&c->d_dec_arena, npieces * words * 4u));
+      c->dec_arena_cap = npieces * words;
+    }
+    if (npieces > c->dec_piece_cap) {
+      if (c->d_dec_pieces) HIP_OK(c, hipFree(c->d_dec_pieces));
+      if (c->d_dec_results) HIP_OK(c, hipFree(c->d_dec_results));
+      c->d_dec_pieces = nullptr;
+      c->d_dec_results = nullptr;
+      c->dec_piece_cap = 0;
+      HIP_OK(c, hipMalloc((void**)&c->d_dec_pieces, npieces * sizeof(DecPiece)));
+      HIP_OK(c, hipMalloc((void**)&c->d_dec_results, npieces * sizeof(DecResult)));
+      c->dec_piece_cap = npieces;
+    }
+    HIP_OK(c, hipMemcpyAsync(c->d_dec_pieces, pieces, npieces * sizeof(DecPiece), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(c, hipMemsetAsync(c->d_dec_results, 0xFF, npieces * sizeof(DecResult), c->stream));
+    DecArgs a;
+    a.pieces = c->d_dec_pieces;
+    a.results = c->d_dec_results;
+    a.T = c->d_T;
+    a.transforms = c->d_transforms;
+    a.transform_text = c->d_transform_text;
+    a.input = (const uint8_t*)d_in;
+    a.out = (uint8_t*)d_out;
+    a.arena = c->d_dec_arena;
+    a.arena_words = (uint32_t)words;
+    a.npieces = (uint32_t)npieces;
+    HIP_OK(c, hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(k_decode, dim3((uint32_t)npieces), dim3(64), 0, c->stream, a);
+    HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
+    HIP_OK(c, hipMemcpyAsync(results, c->d_dec_results, npieces * sizeof(DecResult), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    HIP_OK(c, hipGetLastError());
+    if (ms) HIP_OK(c, hipEventElapsedTime(ms, c->ev[0], c->ev[1]));
+    return true;
+  };
+  if (!body()) return BROTLI_AMD_ERROR;
+  for (uint64_t k = 0; k < npieces; ++k) {
+    if (results[k].error) {
+      fail(c, "piece %llu: decoder error %u", (unsigned long long)k, results[k].error);
+      return BROTLI_AMD_DEVICE_FAULT;
+    }
+  }
+  return BROTLI_AMD_OK;
+}
+
+int brotli_amd_decode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t in_len,
+                           const BrotliAmdDecodePiece* pieces, uint64_t npieces, uint8_t* out,
+                           uint64_t out_cap, BrotliAmdDecodeResult* results, float* ms) {
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  uint8_t *d_in = nullptr, *d_out = nullptr;
+  int rc = BROTLI_AMD_ERROR;
+  auto body = [&]() -> bool {
+    HIP_OK(c, hipMalloc((void**)&d_in, in_len + BROTLI_AMD_DECODE_SLACK));
+    HIP_OK(c, hipMalloc((void**)&d_out, out_cap + 64));
+    if (in_len) HIP_OK(c, hipMemcpy(d_in, in, in_len, hipMemcpyHostToDevice));
+    HIP_OK(c, hipMemset(d_in + in_len, 0, BROTLI_AMD_DECODE_SLACK));
+    rc = brotli_amd_decode_device(c, d_in, in_len, pieces, npieces, d_out, out_cap, results, ms);
+    if (rc == BROTLI_AMD_OK || rc == BROTLI_AMD_DEVICE_FAULT) {
+      if (out_cap) HIP_OK(c, hipMemcpy(out, d_out, out_cap, hipMemcpyDeviceToHost));
+    }
+    return true;
+  };
+  const bool ok = body();
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  return ok ? rc : BROTLI_AMD_ERROR;
 }
 
 int brotli_amd_debug_parse(BrotliAmdCtx* c, const void* d_in, uint64_t len,

@@ -104,6 +104,10 @@ DEV uint32_t br_read(BitRd& b, uint32_t k) {   // k <= 32
   return v;
 }
 DEV uint64_t br_bitpos(const BitRd& b) { return (uint64_t)(b.p - b.base) * 8u - b.n; }
+// The reader has loaded past the end of the input (the buffer has BROTLI_AMD_INPUT_SLACK readable bytes
+// behind it): checked inside every loop whose length the stream dictates, so that a damaged stream ends
+// as DEC_ERR_INPUT instead of walking through memory.
+DEV bool br_overrun(const BitRd& b, uint64_t in_len) { return (uint64_t)(b.p - b.base) > in_len + 8u; }
 DEV void br_align(BitRd& b) { const uint32_t r = b.n & 7u; b.acc >>= r; b.n -= r; }
 // byte position after alignment; re-seats the reader there
 DEV void br_seek(BitRd& b, uint64_t byte_pos) { b.p = b.base + byte_pos; b.acc = 0; b.n = 0; }
@@ -306,13 +310,14 @@ DEV void dec_switch_block(BitRd& b, DecBlocks& k, const uint32_t* trees) {
 }
 
 // Context map (section 7.3): `size` entries of tree indices below `ntrees`, into map[].
-DEV bool dec_read_context_map(BitRd& b, uint32_t size, uint32_t ntrees, uint8_t* map, uint32_t* scratch_tree,
-                              uint32_t* lds) {
+DEV bool dec_read_context_map(BitRd& b, uint64_t in_len, uint32_t size, uint32_t ntrees, uint8_t* map,
+                              uint32_t* scratch_tree, uint32_t* lds) {
   const int lane = wave_lane();
   const uint32_t rlemax = br_read(b, 1) ? br_read(b, 4) + 1u : 0u;
   if (!dec_read_tree(b, ntrees + rlemax, scratch_tree, lds)) return false;
   uint32_t i = 0;
   while (i < size) {
+    if (br_overrun(b, in_len)) return false;
     const uint32_t s = dec_symbol(b, scratch_tree);
     if (s == 0u) {
       if (lane == 0) map[i] = 0;
@@ -492,13 +497,13 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
     const uint32_t ntrees_l = dec_read_count256(b);
     uint32_t* scratch_tree = arena + DEC_A_TREES;     // the context maps' own codes: read before the trees land here
     if (ntrees_l >= 2u) {
-      if (!dec_read_context_map(b, 64u * blk[0].ntypes, ntrees_l, cmap_l, scratch_tree, lds)) { error = DEC_ERR_CONTEXT_MAP; break; }
+      if (!dec_read_context_map(b, P.in_len, 64u * blk[0].ntypes, ntrees_l, cmap_l, scratch_tree, lds)) { error = DEC_ERR_CONTEXT_MAP; break; }
     } else {
       for (uint32_t i = (uint32_t)lane; i < 64u * blk[0].ntypes; i += 64u) cmap_l[i] = 0;
     }
     const uint32_t ntrees_d = dec_read_count256(b);
     if (ntrees_d >= 2u) {
-      if (!dec_read_context_map(b, 4u * blk[2].ntypes, ntrees_d, cmap_d, scratch_tree, lds)) { error = DEC_ERR_CONTEXT_MAP; break; }
+      if (!dec_read_context_map(b, P.in_len, 4u * blk[2].ntypes, ntrees_d, cmap_d, scratch_tree, lds)) { error = DEC_ERR_CONTEXT_MAP; break; }
     } else {
       for (uint32_t i = (uint32_t)lane; i < 4u * blk[2].ntypes; i += 64u) cmap_d[i] = 0;
     }
@@ -510,9 +515,10 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
       error = DEC_ERR_ARENA;
       break;
     }
-    for (uint32_t t = 0; t < ntrees_l && ok; ++t) ok = dec_read_tree(b, 256u, trees_l + t * stride_l, lds);
-    for (uint32_t t = 0; t < blk[1].ntypes && ok; ++t) ok = dec_read_tree(b, 704u, trees_i + t * stride_i, lds);
-    for (uint32_t t = 0; t < ntrees_d && ok; ++t) ok = dec_read_tree(b, alphabet_d, trees_d + t * stride_d, lds);
+    // (one prefix code is at most ~1.6 KB of input: BROTLI_AMD_DECODE_SLACK covers the last one of a damaged stream)
+    for (uint32_t t = 0; t < ntrees_l && ok; ++t) ok = !br_overrun(b, P.in_len) && dec_read_tree(b, 256u, trees_l + t * stride_l, lds);
+    for (uint32_t t = 0; t < blk[1].ntypes && ok; ++t) ok = !br_overrun(b, P.in_len) && dec_read_tree(b, 704u, trees_i + t * stride_i, lds);
+    for (uint32_t t = 0; t < ntrees_d && ok; ++t) ok = !br_overrun(b, P.in_len) && dec_read_tree(b, alphabet_d, trees_d + t * stride_d, lds);
     if (!ok) { error = DEC_ERR_PREFIX_CODE; break; }
     // every cmap entry must name a tree that exists
     {
@@ -534,7 +540,7 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
     const uint32_t* bt_i = bt_l + DEC_BT_STRIDE;
     const uint32_t* bt_d = bt_i + DEC_BT_STRIDE;
     while (pos < mb_end && !error) {
-      if (br_bitpos(b) > P.in_len * 8u) { error = DEC_ERR_INPUT; break; }
+      if (br_overrun(b, P.in_len)) { error = DEC_ERR_INPUT; break; }
       if (blk[1].left == 0u) dec_switch_block(b, blk[1], bt_i);
       --blk[1].left;
       const uint32_t cmd = dec_symbol(b, trees_i + blk[1].type * stride_i);
@@ -571,6 +577,7 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
       if (pos + insert_len > mb_end) { error = DEC_ERR_OVERRUN; break; }
       // literals
       for (uint32_t k = 0; k < insert_len; ++k) {
+        if (br_overrun(b, P.in_len)) { error = DEC_ERR_INPUT; break; }
         if (blk[0].left == 0u) dec_switch_block(b, blk[0], bt_l);
         --blk[0].left;
         const uint32_t mode = modes[blk[0].type];
@@ -583,7 +590,7 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
         p2 = p1;
         p1 = lit;
       }
-      if (pos >= mb_end) break;
+      if (error || pos >= mb_end) break;
       // distance
       uint32_t distance;
       uint32_t dcode = 0;

@@ -60,6 +60,32 @@ CMD_DTYPE = np.dtype([("insert_len", "<u4"), ("copy_len", "<u4"),
                       ("dist_prefix", "<u2")])
 
 
+class DecodePiece(C.Structure):
+    _fields_ = [("in_off", C.c_uint64), ("in_len", C.c_uint64), ("out_off", C.c_uint64),
+                ("out_cap", C.c_uint64), ("flags", C.c_uint32), ("lgwin", C.c_uint32)]
+
+
+class DecodeResult(C.Structure):
+    _fields_ = [("out_bytes", C.c_uint64), ("in_bits", C.c_uint64), ("error", C.c_uint32),
+                ("finished", C.c_uint32), ("lgwin", C.c_uint32), ("metablocks", C.c_uint32)]
+
+
+PIECE_HEADER, PIECE_ISOLATED = 1, 2
+DECODE_SLACK = 4096
+
+
+def plan_pieces(shard_sizes, total, shard_size, lgwin):
+    """The pieces of a partition plan's output: compressed sizes per shard (as
+    brotli_amd_encode_device reports them), decoded size of the stream, bytes per shard."""
+    pieces, off = [], 0
+    for k, n in enumerate(shard_sizes):
+        out_off = k * shard_size
+        pieces.append((off, int(n), out_off, min(shard_size, total - out_off),
+                       PIECE_HEADER if k == 0 else PIECE_ISOLATED, lgwin))
+        off += int(n)
+    return pieces
+
+
 class BrotliAmdError(RuntimeError):
     pass
 
@@ -90,6 +116,12 @@ def load_library(path=LIB_PATH):
     L.brotli_amd_encode_fast_host.argtypes = [
         C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_uint64,
         C.POINTER(FastParams), C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(JobInfo)]
+    L.brotli_amd_decode_device.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(DecodePiece), C.c_uint64, C.c_void_p,
+        C.c_uint64, C.POINTER(DecodeResult), C.POINTER(C.c_float)]
+    L.brotli_amd_decode_host.argtypes = [
+        C.c_void_p, C.c_char_p, C.c_uint64, C.POINTER(DecodePiece), C.c_uint64, C.c_void_p,
+        C.c_uint64, C.POINTER(DecodeResult), C.POINTER(C.c_float)]
     L.brotli_amd_debug_parse.argtypes = [
         C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(JobParams), C.c_void_p,
         C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(JobInfo)]
@@ -204,6 +236,39 @@ class Context:
                                                 C.byref(p), out, cap, C.byref(out_bits), C.byref(info))
         self._check(rc, "brotli_amd_encode_fast_host")
         return out.raw[:(out_bits.value + 7) // 8], int(out_bits.value), info.as_dict()
+
+    # -- decoder (k_decode.h): round trips on the device -------------------------
+    @staticmethod
+    def _pieces(pieces, n_in, n_out):
+        if pieces is None:
+            pieces = [(0, n_in, 0, n_out, PIECE_HEADER, 0)]
+        arr = (DecodePiece * len(pieces))(*[DecodePiece(*p) for p in pieces])
+        return arr, (DecodeResult * len(pieces))()
+
+    def decode_device(self, d_in, n_in, d_out, n_out, pieces=None, check=True):
+        """d_in: uint8 cuda tensor with >= n_in + DECODE_SLACK elements; d_out: uint8 cuda tensor of
+        >= n_out.  `pieces`: [(in_off, in_len, out_off, out_cap, flags, lgwin)], default one stream.
+        Returns (results, kernel ms); results[k] = (out_bytes, error, finished)."""
+        assert d_in.is_cuda and d_in.numel() >= n_in + DECODE_SLACK and d_out.numel() >= n_out
+        _wait_for_torch(d_in)
+        arr, res = self._pieces(pieces, n_in, n_out)
+        ms = C.c_float(0)
+        rc = self.L.brotli_amd_decode_device(self.h, d_in.data_ptr(), n_in, arr, len(arr),
+                                             d_out.data_ptr(), n_out, res, C.byref(ms))
+        if check or rc not in (OK, DEVICE_FAULT):
+            self._check(rc, "brotli_amd_decode_device")
+        return [(int(r.out_bytes), int(r.error), int(r.finished)) for r in res], float(ms.value)
+
+    def decode_host(self, comp, n_out, pieces=None, check=True):
+        comp = bytes(comp)
+        arr, res = self._pieces(pieces, len(comp), n_out)
+        out = C.create_string_buffer(max(n_out, 1))
+        ms = C.c_float(0)
+        rc = self.L.brotli_amd_decode_host(self.h, comp, len(comp), arr, len(arr), out, n_out, res,
+                                           C.byref(ms))
+        if check or rc not in (OK, DEVICE_FAULT):
+            self._check(rc, "brotli_amd_decode_host")
+        return out.raw[:n_out], [(int(r.out_bytes), int(r.error), int(r.finished)) for r in res]
 
     def debug_parse(self, d_in, n, params):
         cap = n // 2 + 64 * (1 + (n // max(1, params.shard_size or n)))

@@ -181,6 +181,48 @@ int brotli_amd_encode_fast_host(BrotliAmdCtx* ctx, const uint8_t* in, uint64_t l
                                 uint64_t out_cap, uint64_t* out_bits,
                                 BrotliAmdJobInfo* info);
 
+/* ---- decoder on the device (k_decode.h) -----------------------------
+   What it is for: round trips of what the encoder produced, at rate, with the data staying in HBM
+   (tests, bench.py's round-trip check).  It decodes any RFC 7932 stream (no large window); the
+   counterpart in the reference is BrotliDecoderDecompress (c/dec/decode.c), a serial state machine.
+   The unit of work is a PIECE, decoded by one wave: a whole stream, or one shard of a partition
+   plan — shard k of the encoder's output starts at the sum of the compressed sizes before it
+   (brotli_amd_encode_device's d_shard_sizes), decodes to stream offset k * shard_size, and only
+   shard 0 carries the stream header.  Pieces of one call decode concurrently. */
+typedef struct BrotliAmdDecodePiece {
+  uint64_t in_off, in_len;   /* the piece's compressed bytes inside the input buffer */
+  uint64_t out_off;          /* where its bytes go in the output buffer == its offset in the stream */
+  uint64_t out_cap;          /* room there (the shard size; the whole capacity for one stream) */
+  uint32_t flags;            /* BROTLI_AMD_PIECE_* */
+  uint32_t lgwin;            /* the stream's window, for pieces without BROTLI_AMD_PIECE_HEADER */
+} BrotliAmdDecodePiece;
+#define BROTLI_AMD_PIECE_HEADER 1u     /* starts with the stream header (window bits) */
+#define BROTLI_AMD_PIECE_ISOLATED 2u   /* a shard of a plan: a copy reaching before the piece is an error */
+typedef struct BrotliAmdDecodeResult {
+  uint64_t out_bytes;
+  uint64_t in_bits;          /* bits consumed */
+  uint32_t error;            /* 0 = ok; 1 header, 2 prefix code, 3 context map, 4 distance, 5 dictionary,
+                                6 output overrun, 7 input overrun, 8 arena (too many prefix codes for the
+                                per-piece workspace), 9 unsupported (large window) */
+  uint32_t finished;         /* the ISLAST meta-block was decoded */
+  uint32_t lgwin;
+  uint32_t metablocks;
+} BrotliAmdDecodeResult;
+/* Device input buffers of the decoder must stay readable this many bytes past their end (a damaged
+   stream is noticed at most one prefix code late). */
+#define BROTLI_AMD_DECODE_SLACK 4096
+/* d_in / d_out: device memory.  pieces / results: host arrays of npieces entries.  Returns
+   BROTLI_AMD_OK when the kernel ran (look at results[k].error per piece), BROTLI_AMD_DEVICE_FAULT if
+   any piece reported an error, BROTLI_AMD_ERROR for HIP failures.  *ms (may be NULL): HIP-event time
+   of the kernel. */
+int brotli_amd_decode_device(BrotliAmdCtx* ctx, const void* d_in, uint64_t in_len,
+                             const BrotliAmdDecodePiece* pieces, uint64_t npieces, void* d_out,
+                             uint64_t out_cap, BrotliAmdDecodeResult* results, float* ms);
+/* Same with host buffers. */
+int brotli_amd_decode_host(BrotliAmdCtx* ctx, const uint8_t* in, uint64_t in_len,
+                           const BrotliAmdDecodePiece* pieces, uint64_t npieces, uint8_t* out,
+                           uint64_t out_cap, BrotliAmdDecodeResult* results, float* ms);
+
 /* Parity tap used by tests/: runs table init + the LZ77 parse only and copies
    the command list of the first meta-block of every shard (16-byte records,
    c/enc/command.h:106-116 field order) to host memory. */

@@ -38,10 +38,31 @@ class Sim:
         self.L.sim_stream.argtypes = [
             C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32, C.c_uint32,
             C.POINTER(C.c_uint64), C.POINTER(C.c_uint8), C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]
+        self.L.sim_decode.restype = C.c_long
+        self.L.sim_decode.argtypes = [
+            C.c_char_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64), C.c_size_t, C.c_uint32, C.c_int,
+            C.c_char_p, C.c_size_t, C.POINTER(C.c_uint64)]
         self.L.sim_encode.restype = C.c_long
         self.L.sim_encode.argtypes = [
             C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
             C.c_size_t, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+
+    def decode(self, comp, n_out, pieces=None, arena_words=0, reverse=0):
+        """k_decode on the simulator.  pieces = [(in_off, in_len, out_off, out_cap, flags, lgwin)],
+        default: one whole stream.  Returns (bytes, [(out_bytes, in_bits, error, finished)])."""
+        if pieces is None:
+            pieces = [(0, len(comp), 0, n_out, 1, 0)]
+        arr = (C.c_uint64 * (5 * len(pieces)))()
+        for k, (io, il, oo, oc, fl, lw) in enumerate(pieces):
+            arr[5 * k:5 * k + 5] = [io, il, oo, oc, fl | (lw << 32)]
+        out = C.create_string_buffer(n_out + 64)
+        res = (C.c_uint64 * (4 * len(pieces)))()
+        comp = bytes(comp)
+        rc = self.L.sim_decode(TABLES.encode(), comp, len(comp), arr, len(pieces), arena_words, reverse,
+                               out, n_out, res)
+        assert rc == 0, rc
+        return out.raw[:n_out], [(res[4 * k], res[4 * k + 1], res[4 * k + 2] & 0xFFFFFFFF, res[4 * k + 2] >> 32)
+                                 for k in range(len(pieces))]
 
     def stream(self, data, calls, quality=5, lgwin=22, size_hint=0, stream_offset=0, reverse=0):
         """One encoder instance driven call by call on the simulator (k_parse / k_parse_deep +
