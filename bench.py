@@ -446,6 +446,27 @@ def main():
                                  "instruction issue and dependent accesses, not by bandwidth (DESIGN.md 5)" % (
                                      kernel, k_bytes, n, k_ms)},
         }
+        if world == 1:
+            # round trip on the device, outside the timed region: the shards of the plan decode as
+            # independent pieces (k_decode.h, one wave per shard) and must give back the input
+            try:
+                nsh = -(-n // shard)
+                d_sizes = torch.zeros(nsh, dtype=torch.int64, device=dev)
+                nb2, _ = ctx.encode_device(d_in, n, params, d_out, d_sizes)
+                sizes = d_sizes.cpu().tolist()
+                if nb2 + hip.DECODE_SLACK <= d_out.numel() and sum(sizes) == nb2:
+                    d_back = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+                    pieces = hip.plan_pieces(sizes, n, shard, args.lgwin)
+                    res, dec_ms = ctx.decode_device(d_out, nb2, d_back, n, pieces, check=False)
+                    errs = [r[1] for r in res if r[1]]
+                    same = bool(torch.equal(d_back[:n], d_in[:n]))
+                    line["config"]["device_round_trip"] = {
+                        "equal_to_input": same and not errs and res[-1][2] == 1, "pieces": len(pieces),
+                        "piece_errors": len(errs), "decode_ms": round(dec_ms, 3),
+                        "decode_GBps_of_output": round(n / 1e9 / (dec_ms / 1e3), 2) if dec_ms > 0 else None}
+                    del d_back
+            except Exception as e:   # the encoder's line must not depend on the decoder
+                line["config"]["device_round_trip"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_cpu_baseline:
             # spot check of the bytes against the oracle on the first shards, then the baseline
             from refharness import Oracle

@@ -9,6 +9,34 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, ROOT)
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (-m "not gpu") is simulator work, several hundred independent cases: when
+    pytest-xdist is there and the caller did not choose (-n, -p no:xdist, BROTLI_AMD_TESTS_SERIAL=1)
+    it is spread over the cores.  The GPU suite stays in one process (one device, large buffers).
+
+    xdist WORKERS run this hook too (xdist/remote.py calls pytest_cmdline_main in every worker): a
+    worker that asked for workers of its own would multiply without end, so the hook stands down
+    in anything that is, or descends from, a distributed run — three independent signs of that."""
+    if os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput"):
+        return None
+    if os.environ.get("BROTLI_AMD_PYTEST_PARENT") or os.environ.get("BROTLI_AMD_TESTS_SERIAL"):
+        return None
+    if "not gpu" not in (config.option.markexpr or ""):
+        return None
+    if not config.pluginmanager.hasplugin("xdist") or getattr(config.option, "numprocesses", None) is not None:
+        return None
+    if getattr(config.option, "collectonly", False) or getattr(config.option, "usepdb", False):
+        return None
+    os.environ["BROTLI_AMD_PYTEST_PARENT"] = str(os.getpid())     # inherited by every worker
+    # the checkers are built once, here, not by eight workers at the same time
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "oracle")], check=False)
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "simt")], check=False)
+    config.option.numprocesses = max(1, min(8, os.cpu_count() or 1))
+    config.option.dist = "load"
+    return None
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "timeout: per-test limit (pytest-timeout; ignored when the plugin is absent)")
