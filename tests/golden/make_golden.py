@@ -58,6 +58,20 @@ Q1_CASES = [
 ]
 
 
+# attached dictionaries (BrotliEncoderPrepareDictionary(RAW) + AttachPreparedDictionary), one FINISH call:
+# (gen_inputs.dictionary_case arguments, quality, lgwin)
+DICT_CASES = [
+    ({"nbytes": 200000, "dict_bytes": 80000, "nchunks": 1, "seed": 41}, 5, 22),
+    ({"nbytes": 300000, "dict_bytes": 250000, "nchunks": 3, "seed": 42}, 5, 18),
+    ({"nbytes": 3000, "dict_bytes": 100000, "nchunks": 2, "seed": 43}, 5, 22),
+    ({"nbytes": 200000, "dict_bytes": 80000, "nchunks": 2, "seed": 44}, 9, 24),
+    ({"nbytes": 200000, "dict_bytes": 80000, "nchunks": 1, "seed": 45}, 7, 14),
+    ({"nbytes": 200000, "dict_bytes": 80000, "nchunks": 1, "seed": 46}, 3, 22),
+    ({"nbytes": 200000, "dict_bytes": 80000, "nchunks": 2, "seed": 47}, 4, 18),
+    ({"nbytes": (1 << 20) + 50000, "dict_bytes": 150000, "nchunks": 2, "seed": 48}, 5, 22),   # H68
+]
+
+
 def q1_calls(n, feed_kb):
     """[(nbytes, op)]: one FINISH call, or feed_kb KiB per PROCESS call and FINISH with the last
     one — as an extra empty call when n is a multiple of the feed (c/tools/brotli.c:1419-1463)."""
@@ -91,9 +105,17 @@ def main():
         q1.append({"input": spec, "quality": 1, "lgwin": w, "feed_kb": feed_kb, "size": len(out),
                    "sha256": hashlib.sha256(out).hexdigest()})
         print(q1[-1])
+    dc = []
+    for spec, q, w in DICT_CASES:
+        data, chunks = G.dictionary_case(**spec)
+        out = ref.encode_calls(data, q, w, [(len(data), 2)], dictionaries=chunks)
+        assert ref.decompress_with(out, len(data), chunks) == data
+        dc.append({"input": spec, "quality": q, "lgwin": w, "size": len(out),
+                   "sha256": hashlib.sha256(out).hexdigest()})
+        print(dc[-1])
     json.dump({"generator": "oracle/_ref (google/brotli c/enc, gcc x86-64)",
-               "cases": cases, "quality1_cases": q1}, open(os.path.join(HERE, "golden.json"), "w"),
-              indent=1)
+               "cases": cases, "quality1_cases": q1, "dictionary_cases": dc},
+              open(os.path.join(HERE, "golden.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":

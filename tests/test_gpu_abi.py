@@ -270,6 +270,17 @@ def test_attached_dictionaries_equal_reference(amd, stock, ref, quality, lgwin):
             assert len(want) < len(plain)
 
 
+def test_golden_vectors_dictionaries(amd):
+    """tests/golden/golden.json `dictionary_cases`: sha256 of the reference's output, generated in the
+    build container by tests/golden/make_golden.py (the fixture travels, the reference tree does not)."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+    for case in gold["dictionary_cases"]:
+        data, chunks = G.dictionary_case(**case["input"])
+        got, fin = drive(amd, data, [(len(data), 2)], ((1, case["quality"]), (2, case["lgwin"])), dictionaries=chunks)
+        assert fin and len(got) == case["size"] and hashlib.sha256(got).hexdigest() == case["sha256"], case
+
+
 def test_attached_dictionary_past_one_mebibyte(amd, stock):
     """H68 at quality 5 and H54 at quality 4 (chosen once a MiB is announced); H54 has no dictionary
     variant in the reference and only shifts its distances."""

@@ -150,6 +150,18 @@ def test_golden_vectors(oracle):
         assert hashlib.sha256(out).hexdigest() == case["sha256"], case
 
 
+def test_golden_vectors_dictionaries(oracle):
+    gold = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    for case in gold["dictionary_cases"]:
+        data, chunks = G.dictionary_case(**case["input"])
+        oracle.set_dictionary(chunks)
+        try:
+            out = oracle.encode_shard(data, case["quality"], case["lgwin"], 0, 0, True)
+        finally:
+            oracle.set_dictionary(())
+        assert len(out) == case["size"] and hashlib.sha256(out).hexdigest() == case["sha256"], case
+
+
 def test_golden_vectors_quality1(oracle):
     """The quality-1 fixtures (one-shot and CLI-style feeds) of tests/golden/golden.json."""
     sys.path.insert(0, os.path.join(HERE, "golden"))
