@@ -323,6 +323,11 @@ def test_reference_cli_with_dictionary_on_our_library(tmp_path):
     if not (os.path.exists(cli) and os.path.exists(cli_ref)):
         pytest.skip("oracle/_ref/brotli_cli_amd / brotli_cli_ref not built")
     dropin = os.path.join(LIBDIR, "dropin")
+    os.makedirs(dropin, exist_ok=True)
+    for name, target in (("libbrotlienc.so.1", "../libbrotlienc_amd.so"),
+                         ("libbrotli_amd_hip.so", "../libbrotli_amd_hip.so")):
+        if not os.path.lexists(os.path.join(dropin, name)):
+            os.symlink(target, os.path.join(dropin, name))
     env = dict(os.environ, LD_LIBRARY_PATH=dropin + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
     data, chunks = G.dictionary_case(400000, 200000, 1, seed=91)
     src, dic = tmp_path / "input.bin", tmp_path / "dictionary.bin"
