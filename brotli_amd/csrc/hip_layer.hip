@@ -1044,8 +1044,14 @@ int brotli_amd_decode_device(BrotliAmdCtx* c, const void* d_in, uint64_t in_len,
     a.arena = c->d_dec_arena;
     a.arena_words = (uint32_t)words;
     a.npieces = (uint32_t)npieces;
+    // measurement switches (tools/gpu_decode_variants.py): BROTLI_AMD_DECODE_VARIANT = waves per SIMD (4 / 8),
+    // + 16 = no LDS cache
+    const int variant = getenv("BROTLI_AMD_DECODE_VARIANT") ? atoi(getenv("BROTLI_AMD_DECODE_VARIANT")) : DECODE_WAVES;
+    a.flags = (variant & 16) ? DEC_ARG_NO_LDS_CACHE : 0u;
+    a.pad = 0;
     HIP_OK(c, hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(k_decode, dim3((uint32_t)npieces), dim3(64), 0, c->stream, a);
+    if ((variant & 15) == 8) hipLaunchKernelGGL(k_decode<8>, dim3((uint32_t)npieces), dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_decode<4>, dim3((uint32_t)npieces), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
     HIP_OK(c, hipMemcpyAsync(results, c->d_dec_results, npieces * sizeof(DecResult), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(c, hipStreamSynchronize(c->stream));

@@ -68,12 +68,25 @@ struct DecArgs {
   uint32_t* arena;                   // npieces * arena_words
   uint32_t arena_words;
   uint32_t npieces;
+  uint32_t flags;                    // DEC_ARG_*
+  uint32_t pad;
 };
+#define DEC_ARG_NO_LDS_CACHE 1u      // measurement only: every table read goes to the arena in HBM / L2
 
 // LDS of one wave (dwords)
 #define DEC_LDS_LENS 0u            // u8 lens[768]
 #define DEC_LDS_CLTREE 192u        // code-length code: 16 + 9
-#define DEC_LDS_WORDS 224u
+// what the inner loops touch once per symbol, kept next to the wave: the context LUT of the current
+// literal block type's mode, its row of the context map, and the headers of the first prefix codes
+#define DEC_LDS_LUT 224u           // u8 [512]
+#define DEC_LDS_CMAP 352u          // u8 [64]
+#define DEC_LDS_HDR_L 368u         // 16 codes x 16 dwords
+#define DEC_LDS_HDR_D 624u         // 16 x 16
+#define DEC_LDS_HDR_I 880u         // 4 x 16
+#define DEC_LDS_WORDS 944u
+#define DEC_HDR_CACHE_L 16u
+#define DEC_HDR_CACHE_D 16u
+#define DEC_HDR_CACHE_I 4u
 
 // arena layout of one piece (dwords)
 #define DEC_A_CMAP_L 0u            // u8 [64 * 256]
@@ -113,10 +126,13 @@ DEV void br_align(BitRd& b) { const uint32_t r = b.n & 7u; b.acc >>= r; b.n -= r
 DEV void br_seek(BitRd& b, uint64_t byte_pos) { b.p = b.base + byte_pos; b.acc = 0; b.n = 0; }
 
 // ---- prefix codes -------------------------------------------------------------------------------
-DEV uint32_t dec_symbol(BitRd& b, const uint32_t* tree) {
+// `hdr`: the 16 header dwords (LDS copy or the arena), `sorted`: the symbols in the arena.
+DEV uint32_t dec_symbol_at(BitRd& b, const uint32_t* hdr, const uint16_t* sorted);
+DEV uint32_t dec_symbol(BitRd& b, const uint32_t* tree) { return dec_symbol_at(b, tree, (const uint16_t*)(tree + 16)); }
+DEV uint32_t dec_symbol_at(BitRd& b, const uint32_t* hdr, const uint16_t* sorted) {
   const int lane = wave_lane();
   if (b.n < 15u) br_fill(b);
-  const uint32_t h = tree[lane & 15];
+  const uint32_t h = hdr[lane & 15];
   const uint32_t h0 = wave_bcast(h, 0);
   if (h0 & 0x80000000u) return h0 & 0xFFFFu;
   const uint32_t v = dev_bitrev32((uint32_t)b.acc) >> 17;
@@ -126,7 +142,7 @@ DEV uint32_t dec_symbol(BitRd& b, const uint32_t* tree) {
   const uint32_t idx = ((hl >> 16) + (v >> (15 - L))) & 0xFFFFu;
   b.acc >>= L;
   b.n -= (uint32_t)L;
-  return ((const uint16_t*)(tree + 16))[idx];
+  return sorted[idx];
 }
 
 // Canonical code from lens[0 .. n) (u8 in LDS): header + sorted symbols.  Returns false if the
@@ -528,6 +544,35 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
       if (wave_ballot(bad)) { error = DEC_ERR_CONTEXT_MAP; break; }
     }
 
+    // the per-symbol tables of this meta-block, next to the wave
+    const bool cache = !(a.flags & DEC_ARG_NO_LDS_CACHE);
+    uint8_t* lds_lut = (uint8_t*)(lds + DEC_LDS_LUT);
+    uint8_t* lds_cmap = (uint8_t*)(lds + DEC_LDS_CMAP);
+    uint32_t cached_mode = 0xFFFFFFFFu;
+    if (cache) {
+      for (uint32_t i = (uint32_t)lane; i < umin(ntrees_l, DEC_HDR_CACHE_L) * 16u; i += 64u)
+        lds[DEC_LDS_HDR_L + i] = trees_l[(i >> 4) * stride_l + (i & 15u)];
+      for (uint32_t i = (uint32_t)lane; i < umin(ntrees_d, DEC_HDR_CACHE_D) * 16u; i += 64u)
+        lds[DEC_LDS_HDR_D + i] = trees_d[(i >> 4) * stride_d + (i & 15u)];
+      for (uint32_t i = (uint32_t)lane; i < umin(blk[1].ntypes, DEC_HDR_CACHE_I) * 16u; i += 64u)
+        lds[DEC_LDS_HDR_I + i] = trees_i[(i >> 4) * stride_i + (i & 15u)];
+    }
+    // (re)loads what depends on the literal block type: the LUT of its context mode, its context-map row
+    auto literal_block_tables = [&]() {
+      if (!cache) return;
+      const uint32_t mode = modes[blk[0].type];
+      if (mode != cached_mode) {
+        const uint32_t* src = (const uint32_t*)(lut_all + (mode << 9));
+        lds[DEC_LDS_LUT + (uint32_t)lane] = src[lane];
+        lds[DEC_LDS_LUT + 64u + (uint32_t)lane] = src[64 + lane];
+        cached_mode = mode;
+      }
+      if (lane < 16) lds[DEC_LDS_CMAP + (uint32_t)lane] = ((const uint32_t*)(cmap_l + (blk[0].type << 6)))[lane];
+      wave_sync();
+    };
+    literal_block_tables();
+    wave_sync();
+
     // ---- commands (section 5, 10) ----
     const uint64_t mb_end = pos + mlen;
     uint32_t p1 = 0, p2 = 0;                    // the two bytes before pos
@@ -543,7 +588,9 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
       if (br_overrun(b, P.in_len)) { error = DEC_ERR_INPUT; break; }
       if (blk[1].left == 0u) dec_switch_block(b, blk[1], bt_i);
       --blk[1].left;
-      const uint32_t cmd = dec_symbol(b, trees_i + blk[1].type * stride_i);
+      const uint32_t* tree_i = trees_i + blk[1].type * stride_i;
+      const uint32_t cmd = dec_symbol_at(b, cache && blk[1].type < DEC_HDR_CACHE_I ? lds + DEC_LDS_HDR_I + blk[1].type * 16u : tree_i,
+                                         (const uint16_t*)(tree_i + 16));
       // insert-and-copy code -> insert code, copy code (section 5): cells of 64 symbols
       const uint32_t cell = cmd >> 6;
       uint32_t icode, ccode;
@@ -578,13 +625,18 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
       // literals
       for (uint32_t k = 0; k < insert_len; ++k) {
         if (br_overrun(b, P.in_len)) { error = DEC_ERR_INPUT; break; }
-        if (blk[0].left == 0u) dec_switch_block(b, blk[0], bt_l);
+        if (blk[0].left == 0u) { dec_switch_block(b, blk[0], bt_l); literal_block_tables(); }
         --blk[0].left;
-        const uint32_t mode = modes[blk[0].type];
-        const uint8_t* lut = lut_all + (mode << 9);
-        const uint32_t ctx = lut[p1] | lut[256u + p2];
-        const uint32_t tree = cmap_l[(blk[0].type << 6) + ctx];
-        const uint32_t lit = dec_symbol(b, trees_l + tree * stride_l);
+        uint32_t tree;
+        if (cache) {
+          tree = lds_cmap[lds_lut[p1] | lds_lut[256u + p2]];
+        } else {
+          const uint8_t* lut = lut_all + ((uint32_t)modes[blk[0].type] << 9);
+          tree = cmap_l[(blk[0].type << 6) + (lut[p1] | lut[256u + p2])];
+        }
+        const uint32_t* tree_l = trees_l + tree * stride_l;
+        const uint32_t lit = dec_symbol_at(b, cache && tree < DEC_HDR_CACHE_L ? lds + DEC_LDS_HDR_L + tree * 16u : tree_l,
+                                           (const uint16_t*)(tree_l + 16));
         if (lane == 0) out[pos] = (uint8_t)lit;
         ++pos;
         p2 = p1;
@@ -599,7 +651,9 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
         --blk[2].left;
         const uint32_t dctx = copy_len > 4u ? 3u : copy_len - 2u;
         const uint32_t tree = cmap_d[(blk[2].type << 2) + dctx];
-        dcode = dec_symbol(b, trees_d + tree * stride_d);
+        const uint32_t* tree_d = trees_d + tree * stride_d;
+        dcode = dec_symbol_at(b, cache && tree < DEC_HDR_CACHE_D ? lds + DEC_LDS_HDR_D + tree * 16u : tree_d,
+                              (const uint16_t*)(tree_d + 16));
       }
       if (dcode < 16u) {
         // 0..3: the ring; 4..9: last -1 +1 -2 +2 -3 +3; 10..15: second last likewise

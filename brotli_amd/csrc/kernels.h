@@ -288,8 +288,13 @@ __global__ void __launch_bounds__(256) k_fast_emit(FastArgs a) {
 // ---- decoder (k_decode.h) -----------------------------------------------------------------
 #include "k_decode.h"
 
-// grid = npieces, block = 64: one piece per wave
-__global__ void __launch_bounds__(64) k_decode(DecArgs a) {
+// grid = npieces, block = 64: one piece per wave.  W = waves per SIMD the register budget leaves room for
+// (4: everything in registers; 8: all 8192 pieces of a 1 GiB / 128 KiB plan resident at once, some scratch).
+#ifndef DECODE_WAVES
+#define DECODE_WAVES 4
+#endif
+template <int W>
+__global__ void __launch_bounds__(64, W) k_decode(DecArgs a) {
   __shared__ uint32_t lds_dec[DEC_LDS_WORDS];
   if (blockIdx.x < a.npieces) decode_piece(a, blockIdx.x, lds_dec);
 }

@@ -359,6 +359,7 @@ long sim_stream(const char* tables_path, const uint8_t* in, size_t len, int qual
 // lgwin << 32}; results[k] = {out_bytes, in_bits, error | finished << 32, lgwin | metablocks << 32}.
 long sim_decode(const char* tables_path, const uint8_t* in, size_t in_len, const uint64_t* pieces, size_t npieces,
                 uint32_t arena_words, int reverse, uint8_t* out, size_t out_cap, uint64_t* results) {
+  // `reverse`: bit 0 = lane scheduling order of the simulator, bit 1 = DEC_ARG_NO_LDS_CACHE
   HostTables ht;
   HostTransforms tr;
   if (!host_tables_load(tables_path, &ht) || !host_transforms_load(tables_path, &tr)) return -1;
@@ -387,8 +388,10 @@ long sim_decode(const char* tables_path, const uint8_t* in, size_t in_len, const
   a.arena = arena.data();
   a.arena_words = arena_words;
   a.npieces = (uint32_t)npieces;
+  a.flags = (reverse & 2) ? DEC_ARG_NO_LDS_CACHE : 0u;
+  a.pad = 0;
   struct DLaunch { DecArgs a; } l{a};
-  simt::launch((unsigned)npieces, 64, [](void* p) { k_decode(((DLaunch*)p)->a); }, &l, reverse);
+  simt::launch((unsigned)npieces, 64, [](void* p) { k_decode<4>(((DLaunch*)p)->a); }, &l, reverse & 1);
   for (size_t k = 0; k < npieces; ++k) {
     results[4 * k] = R[k].out_bytes;
     results[4 * k + 1] = R[k].in_bits;

@@ -10,8 +10,12 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900, method="thread")]
 
 @pytest.fixture(scope="module")
 def ctx():
+    import torch
+    torch.cuda.init()       # same initialisation order as bench.py and test_gpu_parity.py: torch first
     from brotli_amd import hip
-    return hip.Context(0)
+    c = hip.Context(0)
+    yield c
+    c.close()
 
 
 def test_decodes_reference_streams(ctx, ref):

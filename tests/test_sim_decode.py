@@ -35,7 +35,8 @@ def test_decodes_reference_streams_at_every_quality(sim, ref, name):
         if quality >= 10 and len(data) > 70001:
             continue
         comp = ref.compress(data, quality, lgwin)
-        out, res = sim.decode(comp, len(data), reverse=quality & 1)
+        # (lane order of the simulator both ways; every third case without the LDS copies of the tables)
+        out, res = sim.decode(comp, len(data), reverse=(quality & 1) | (2 if quality % 3 == 0 else 0))
         n, bits, err, fin = res[0]
         assert (err, fin, n) == (0, 1, len(data)) and out == data, (name, quality, lgwin)
         assert (bits + 7) // 8 == len(comp)
