@@ -102,12 +102,14 @@ struct BitRd {
   uint64_t acc;
   uint32_t n;              // valid bits in acc
   const uint8_t* base;
+  uint64_t ahead;          // the eight bytes at p, requested when p was set: a refill never waits for memory
 };
-DEV void br_init(BitRd& b, const uint8_t* in) { b.p = b.base = in; b.acc = 0; b.n = 0; }
+DEV void br_init(BitRd& b, const uint8_t* in) { b.p = b.base = in; b.acc = 0; b.n = 0; b.ahead = ld64(in); }
 DEV void br_fill(BitRd& b) {            // n >= 56 afterwards
-  b.acc |= ld64(b.p) << b.n;
+  b.acc |= b.ahead << b.n;
   b.p += (63u - b.n) >> 3;
   b.n |= 56u;
+  b.ahead = ld64(b.p);
 }
 DEV uint32_t br_read(BitRd& b, uint32_t k) {   // k <= 32
   if (b.n < k) br_fill(b);
@@ -123,7 +125,7 @@ DEV uint64_t br_bitpos(const BitRd& b) { return (uint64_t)(b.p - b.base) * 8u - 
 DEV bool br_overrun(const BitRd& b, uint64_t in_len) { return (uint64_t)(b.p - b.base) > in_len + 8u; }
 DEV void br_align(BitRd& b) { const uint32_t r = b.n & 7u; b.acc >>= r; b.n -= r; }
 // byte position after alignment; re-seats the reader there
-DEV void br_seek(BitRd& b, uint64_t byte_pos) { b.p = b.base + byte_pos; b.acc = 0; b.n = 0; }
+DEV void br_seek(BitRd& b, uint64_t byte_pos) { b.p = b.base + byte_pos; b.acc = 0; b.n = 0; b.ahead = ld64(b.p); }
 
 // ---- prefix codes -------------------------------------------------------------------------------
 // `hdr`: the 16 header dwords (LDS copy or the arena), `sorted`: the symbols in the arena.
@@ -635,6 +637,8 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
           tree = cmap_l[(blk[0].type << 6) + (lut[p1] | lut[256u + p2])];
         }
         const uint32_t* tree_l = trees_l + tree * stride_l;
+        // (the symbols themselves in LDS as well — 256 B per code — was measured: no gain, the loop is bound by
+        // instruction issue, not by this load; profiles/r02_x_*)
         const uint32_t lit = dec_symbol_at(b, cache && tree < DEC_HDR_CACHE_L ? lds + DEC_LDS_HDR_L + tree * 16u : tree_l,
                                            (const uint16_t*)(tree_l + 16));
         if (lane == 0) out[pos] = (uint8_t)lit;
