@@ -8,9 +8,10 @@ C ABI library brotli_amd/lib/libbrotlienc_amd.so.
 
 Names, argument meaning and error behaviour follow the reference module:
 `brotli.error` is raised where the reference raises it (invalid parameters,
-use after finish(), failed compression).  There is no decoder here (the
-reference's `decompress` is out of scope) and no CPU encoder: parameters outside
-the GPU path raise `brotli.error`.
+use after finish(), failed compression).  There is no CPU encoder: parameters
+outside the GPU path raise `brotli.error`.  `decompress` (python/brotli.py:56-73)
+runs the device decoder (brotli_amd/csrc/k_decode.h) through the HIP layer: one
+stream = one wave, meant for round trips and checks, not for throughput.
 
 Extension: `shard_size=<bytes>` (module-level `compress` and `Compressor`)
 selects a partition plan; 0 = single stream, bytes
@@ -146,6 +147,37 @@ class Compressor(object):
     def finish(self):
         """Ends the stream; the object cannot be used afterwards."""
         return self._stream(b"", _OP_FINISH)
+
+
+_dec_ctx = None
+
+
+def decompress(string):
+    """python/brotli.py:56-73: the decoded bytes of one complete Brotli stream; `brotli.error` if the
+    stream is damaged or incomplete.  Device decoder (k_decode.h); the output size is not known in
+    advance, so the buffer is grown until the stream fits."""
+    global _dec_ctx
+    from . import hip
+    data = bytes(string)
+    with _lib_lock:
+        if _dec_ctx is None:
+            try:
+                _dec_ctx = hip.Context(int(os.environ.get("BROTLI_AMD_DEVICE", "0")))
+            except hip.BrotliAmdError as e:
+                raise error(str(e))
+        cap = max(1 << 16, 6 * len(data))
+        while True:
+            out, res, bits = _dec_ctx.decode_host(data, cap, check=False, with_bits=True)
+            n, err, finished = res[0]
+            if err == 6 and cap < (1 << 31):      # output overrun: more room
+                cap *= 4
+                continue
+            if err != 0 or not finished:
+                raise error("BrotliDecoderDecompress failed (device decoder error %d%s)" % (
+                    err, "" if finished or err else ", stream incomplete"))
+            if (bits[0] + 7) // 8 != len(data):          # python/_brotli.c:917: input left over is an error
+                raise error("BrotliDecoderDecompress failed (data after the end of the stream)")
+            return out[:n]
 
 
 def compress(string, mode=MODE_GENERIC, quality=11, lgwin=22, lgblock=0, shard_size=0):

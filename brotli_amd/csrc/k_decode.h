@@ -123,7 +123,14 @@ DEV uint64_t br_bitpos(const BitRd& b) { return (uint64_t)(b.p - b.base) * 8u - 
 // behind it): checked inside every loop whose length the stream dictates, so that a damaged stream ends
 // as DEC_ERR_INPUT instead of walking through memory.
 DEV bool br_overrun(const BitRd& b, uint64_t in_len) { return (uint64_t)(b.p - b.base) > in_len + 8u; }
-DEV void br_align(BitRd& b) { const uint32_t r = b.n & 7u; b.acc >>= r; b.n -= r; }
+// Drops the rest of the current byte and returns it: padding bits, which the format wants zero.
+DEV uint32_t br_align(BitRd& b) {
+  const uint32_t r = b.n & 7u;
+  const uint32_t v = (uint32_t)b.acc & ((1u << r) - 1u);
+  b.acc >>= r;
+  b.n -= r;
+  return v;
+}
 // byte position after alignment; re-seats the reader there
 DEV void br_seek(BitRd& b, uint64_t byte_pos) { b.p = b.base + byte_pos; b.acc = 0; b.n = 0; b.ahead = ld64(b.p); }
 
@@ -467,7 +474,7 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
         if (nbytes > 1u && (skip >> (8u * (nbytes - 1u))) == 0u) { error = DEC_ERR_HEADER; break; }
         skip += 1u;
       }
-      br_align(b);
+      if (br_align(b) != 0u) { error = DEC_ERR_HEADER; break; }
       br_seek(b, (br_bitpos(b) >> 3) + skip);
       if (is_last) finished = 1;
       continue;
@@ -479,7 +486,7 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
     mlen += 1u;
     if (pos + mlen > P.out_cap) { error = DEC_ERR_OVERRUN; break; }
     if (!is_last && br_read(b, 1)) {                                  // uncompressed
-      br_align(b);
+      if (br_align(b) != 0u) { error = DEC_ERR_HEADER; break; }
       const uint64_t from = br_bitpos(b) >> 3;
       if (from + mlen > P.in_len) { error = DEC_ERR_INPUT; break; }
       const uint8_t* src = b.base + from;
@@ -716,6 +723,10 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
     if (is_last) finished = 1;
   }
   if (!error && br_bitpos(b) > P.in_len * 8u) error = DEC_ERR_INPUT;
+  if (!error && finished) {                      // the last byte is padded with zeros (section 9.1 / 9.3)
+    if (b.n < 8u) br_fill(b);
+    if (br_align(b) != 0u) error = DEC_ERR_HEADER;
+  }
   wave_sync();
   if (lane == 0) {
     DecResult r;

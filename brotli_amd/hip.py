@@ -259,7 +259,9 @@ class Context:
             self._check(rc, "brotli_amd_decode_device")
         return [(int(r.out_bytes), int(r.error), int(r.finished)) for r in res], float(ms.value)
 
-    def decode_host(self, comp, n_out, pieces=None, check=True):
+    def decode_host(self, comp, n_out, pieces=None, check=True, with_bits=False):
+        """Host buffers.  Returns (bytes, results) — and the bits every piece consumed with
+        `with_bits` (a stream that ends before its input does has trailing data)."""
         comp = bytes(comp)
         arr, res = self._pieces(pieces, len(comp), n_out)
         out = C.create_string_buffer(max(n_out, 1))
@@ -268,7 +270,10 @@ class Context:
                                            C.byref(ms))
         if check or rc not in (OK, DEVICE_FAULT):
             self._check(rc, "brotli_amd_decode_host")
-        return out.raw[:n_out], [(int(r.out_bytes), int(r.error), int(r.finished)) for r in res]
+        results = [(int(r.out_bytes), int(r.error), int(r.finished)) for r in res]
+        if with_bits:
+            return out.raw[:n_out], results, [int(r.in_bits) for r in res]
+        return out.raw[:n_out], results
 
     def debug_parse(self, d_in, n, params):
         cap = n // 2 + 64 * (1 + (n // max(1, params.shard_size or n)))

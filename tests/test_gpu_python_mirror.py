@@ -65,6 +65,20 @@ def test_multiple_process_and_flush(brotli, stock, ref, name):
     assert ref.decompress(out, len(data)) == data
 
 
+def test_decompress_round_trip_and_errors(brotli, ref):
+    """python/tests/decompress_test.py in small: decompress(compress(x)) == x for the module's own
+    output and for the stock encoder's, a damaged or cut stream raises brotli.error."""
+    for name, data in INPUTS.items():
+        data = bytes(data)
+        assert brotli.decompress(brotli.compress(data, quality=5)) == data, name
+        assert brotli.decompress(ref.compress(data, 11, 22)) == data, name
+    comp = ref.compress(bytes(INPUTS["text300k"]), 5, 22)
+    with pytest.raises(brotli.error):
+        brotli.decompress(comp[:len(comp) // 2])
+    with pytest.raises(brotli.error):
+        brotli.decompress(b"\xff" * 100)
+
+
 def test_invalid_arguments_and_unsupported_quality(brotli):
     with pytest.raises(brotli.error):
         brotli.Compressor(quality=12)
