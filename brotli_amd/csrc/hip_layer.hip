@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <atomic>
+#include <algorithm>
 #include <string>
 #include <thread>
 #include <vector>
@@ -758,7 +759,8 @@ bool stream_init(BrotliAmdStream* s, uint32_t stream_offset) {
   BrotliAmdCtx* c = s->c;
   const JobParams& J = s->J;
   const uint64_t mb = J.max_metablock_size;
-  if (!ensure_log2(c, (uint32_t)(mb + 2))) return false;
+  // (the FastLog2 table grows with the bytes actually fed, stream_run: a histogram cannot count more
+  // than the stream holds, and most streams are far shorter than a full meta-block of 8 - 16 Mi entries)
   ShardDesc& D = s->D;
   memset(&D, 0, sizeof(D));
   uint64_t so = stream_offset;
@@ -799,6 +801,14 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
   BrotliAmdCtx* c = s->c;
   const JobParams& J = s->J;
   if (s->fed + len >= (3ull << 30)) return fail(c, "stream longer than 3 GiB is not supported");
+  {
+    const uint64_t need = std::min<uint64_t>(J.max_metablock_size, s->fed + len) + 2;
+    if (need > c->log2_n) {
+      uint64_t n = 1u << 16;
+      while (n < need) n <<= 1;
+      if (!ensure_log2(c, (uint32_t)std::min<uint64_t>(n, (uint64_t)J.max_metablock_size + 2))) return false;
+    }
+  }
   // input: the whole stream stays resident (positions are stream offsets)
   const uint64_t need_in = s->fed + len + BROTLI_AMD_INPUT_SLACK;
   if (need_in > s->in_cap) {
