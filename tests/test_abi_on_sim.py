@@ -98,6 +98,35 @@ def test_attached_dictionaries(simabi, stock, ref, quality, lgwin, nbytes, dict_
         assert len(want) < len(plain)
 
 
+def test_attached_dictionary_edge_shapes(simabi, stock):
+    """Fifteen chunks, chunks too short to have an index entry and an empty one between others,
+    BROTLI_PARAM_STREAM_OFFSET, a metadata block in the stream, a dictionary equal to the input (one
+    copy through ExtendLastCommand across chunk borders), inputs shorter than a hash, a flush every
+    few KB (copies continued into the dictionary at block starts)."""
+    data, ch = G.dictionary_case(30000, 20000, 1, seed=1)
+    d, n = ch[0], 30000
+
+    def same(ops, params, chunks, data=data, **kw):
+        want, fin_w = drive(stock, data, ops, params, dictionaries=chunks, **kw)
+        got, fin_g = drive(simabi, data, ops, params, dictionaries=chunks, **kw)
+        assert got == want and fin_w == fin_g, (ops[:3], params)
+
+    same([(n, 2)], ((1, 5), (2, 22)), [d[i * 1300:(i + 1) * 1300] for i in range(15)])
+    same([(n, 2)], ((1, 5), (2, 22)), [d[:5], d[5:12], b"", d[12:]])
+    same([(n, 2)], ((1, 9), (2, 20)), [d[:5], b"", d[5:]])
+    same([(n, 1)], ((1, 5), (2, 22), (5, 300000), (9, 100000)), [d])
+    same([(n, 2)], ((1, 6), (2, 16), (9, 70000)), [d])
+    meta = bytes(range(50))
+    same([(10000, 0), (len(meta), 3), (n - 10000, 2)], ((1, 5), (2, 22)), [d],
+         data=data[:10000] + meta + data[10000:], out_chunk=4096)
+    same([(n, 2)], ((1, 5), (2, 22)), [data[:11000], data[11000:]])
+    same([(n, 2)], ((1, 3), (2, 18)), [data])
+    same([(7, 2)], ((1, 5), (2, 22)), [d], data=data[:7])
+    same([(3, 2)], ((1, 2), (2, 22)), [d], data=data[:3])
+    same(_chunks(n, 3000, 2, 1), ((1, 5), (2, 22)), [data[5000:25000]], take=True)
+    same(_chunks(n, 5000, 2, 3), ((1, 7), (2, 14)), [data[5000:25000]])
+
+
 def test_dictionary_api_edges_and_cli(simabi, tmp_path):
     """Not-a-dictionary handles, the 15-chunk limit, a partition plan, quality 1 (ignores them);
     `brotli -D FILE` of the reference CLI over this library (the simulator build) next to the
