@@ -68,6 +68,7 @@ struct BrotliEncoderStateStruct {
   /* attached raw dictionaries in attach order (params.dictionary.compound, encode.c:1828-1850) */
   const DictIndex* dicts[15];
   uint32_t ndicts;
+  uint32_t ctx_dicts;      /* how many of them the context's jobs already carry (plan mode) */
   uint64_t dict_total;
 };
 
@@ -163,7 +164,10 @@ void BrotliEncoderDestroyInstance(BrotliEncoderState* s) {
   if (s->stream) brotli_amd_stream_destroy(s->stream);
   if (s->ctx) {
     if (s->failed) brotli_amd_ctx_destroy(s->ctx);   /* whatever went wrong, do not pass it on */
-    else pool_give(s->ctx, s->device);
+    else {
+      if (s->ctx_dicts) (void)brotli_amd_ctx_set_dictionary(s->ctx, NULL, 0);
+      pool_give(s->ctx, s->device);
+    }
   }
   st_free(s, s->in_buf);
   st_free(s, s->out_buf);
@@ -239,6 +243,9 @@ static int ensure_initialized(BrotliEncoderState* s) {
     if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
     return 0;
   }
+  /* a pooled context may still carry its previous user's dictionaries */
+  if (brotli_amd_ctx_set_dictionary(s->ctx, NULL, 0) != BROTLI_AMD_OK) { s->failed = 1; return 0; }
+  s->ctx_dicts = 0;
   if (s->size_hint != 0) { s->eff_hint = s->size_hint; s->hint_fixed = 1; }
   if (s->quality == 1 && s->stream_offset == 0) {
     /* the stream header waits in the partial byte; quality 0/1 announce at least
@@ -265,7 +272,16 @@ static int out_append(BrotliEncoderState* s, const uint8_t* p, size_t n) {
 }
 
 /* The device stream of one encoder instance, with the dictionaries attached so far. */
-static int push_dictionaries(BrotliEncoderState* s) {
+static int push_dictionaries_to(BrotliEncoderState* s, int to_context);
+static int push_dictionaries(BrotliEncoderState* s) { return push_dictionaries_to(s, 0); }
+/* Plan mode: the jobs of the context carry the dictionaries (every shard's instance has them attached). */
+static int sync_context_dictionaries(BrotliEncoderState* s) {
+  if (s->ctx_dicts == s->ndicts) return 1;
+  if (!push_dictionaries_to(s, 1)) return 0;
+  s->ctx_dicts = s->ndicts;
+  return 1;
+}
+static int push_dictionaries_to(BrotliEncoderState* s, int to_context) {
   BrotliAmdDictChunk ch[15];
   uint32_t i;
   for (i = 0; i < s->ndicts; ++i) {
@@ -275,6 +291,7 @@ static int push_dictionaries(BrotliEncoderState* s) {
     ch[i].source_size = s->dicts[i]->source_size;
     ch[i].bucket_bits = s->dicts[i]->bucket_bits;
   }
+  if (to_context) return brotli_amd_ctx_set_dictionary(s->ctx, ch, s->ndicts) == BROTLI_AMD_OK;
   return brotli_amd_stream_attach_dictionary(s->stream, ch, s->ndicts) == BROTLI_AMD_OK;
 }
 static int open_stream(BrotliEncoderState* s) {
@@ -396,6 +413,7 @@ static int submit(BrotliEncoderState* s, int op) {
     if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
     cap = brotli_amd_max_output(s->in_len, &p);
     if (cap == 0) return 0;
+    if (!sync_context_dictionaries(s)) return 0;
     if (s->out_pos == s->out_len) s->out_pos = s->out_len = 0;
     if (s->direct_out && s->out_len == 0) {
       /* straight into the caller's buffer; if the result does not fit (the caller offered less
@@ -469,6 +487,7 @@ static int forward_pending_input(BrotliEncoderState* s) {
     if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
     cap = brotli_amd_max_output(whole, &p);
     if (cap == 0) return 0;
+    if (!sync_context_dictionaries(s)) return 0;
     if (s->out_pos == s->out_len) s->out_pos = s->out_len = 0;
     if (!grow(s, &s->out_buf, &s->out_cap, s->out_len, s->out_len + cap)) return 0;
     if (brotli_amd_encode_host(s->ctx, s->in_buf, whole, &p, s->out_buf + s->out_len, cap, &n, &info) != BROTLI_AMD_OK) {
@@ -827,17 +846,16 @@ void BrotliEncoderDestroyPreparedDictionary(BrotliEncoderPreparedDictionary* dic
 /* encode.c:1828-1850 + AttachPreparedDictionary (compound_dictionary.c:182-211): at most 15 chunks,
    2^31 - 1 bytes in total; allowed at any time for raw dictionaries, it then takes effect with the
    next input block.  Qualities 0 / 1 accept and ignore dictionaries (their compressors never look at
-   params.dictionary).  A partition plan (BROTLI_AMD_SHARD_KB) has no dictionary path: refused. */
+   params.dictionary).  In a partition plan every shard's instance has the dictionaries attached (the
+   jobs of the context carry them, brotli_amd_ctx_set_dictionary): the bytes are the reference's driven
+   with the same plan and the same Attach calls on every instance, and shards submitted after an Attach
+   see the new dictionary. */
 BROTLI_BOOL BrotliEncoderAttachPreparedDictionary(BrotliEncoderState* state,
                                                   const BrotliEncoderPreparedDictionary* dictionary) {
   const DictIndex* d = (const DictIndex*)dictionary;
   if (!state || !d || d->magic != DICT_INDEX_MAGIC) return BROTLI_FALSE;
   if (state->ndicts == 15) return BROTLI_FALSE;
   if (d->source_size > DICT_INDEX_MAX_RAW - state->dict_total) return BROTLI_FALSE;
-  if (state->shard_bytes != 0) {
-    if (verbose()) fprintf(stderr, "brotli_amd: dictionaries cannot be attached to a partition plan\n");
-    return BROTLI_FALSE;
-  }
   state->dicts[state->ndicts++] = d;
   state->dict_total += d->source_size;
   if (state->stream && !push_dictionaries(state)) {

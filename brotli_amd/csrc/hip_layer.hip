@@ -56,6 +56,9 @@ struct BrotliAmdCtx {
   uint64_t ffrag_cap = 0, fblock_cap = 0;
   hipEvent_t ev[8] = {};
   hipEvent_t ev_ix = nullptr, ev_ixb = nullptr;
+  // attached dictionaries of the jobs run on this context (k_dict.h; brotli_amd_ctx_set_dictionary)
+  std::vector<void*> dict_allocs;
+  CompoundDict* d_cd = nullptr;
   // decoder (k_decode.h): word transforms, per-piece arenas, piece descriptors / results
   HostTransforms htr;
   std::string tables_path;
@@ -247,6 +250,50 @@ bool ensure_ws(BrotliAmdCtx* c, uint64_t ws_bytes, uint64_t nshards) {
   return true;
 }
 
+// Copies the chunks of a compound dictionary (bytes + index, k_dict.h) to the device; `allocs` owns the memory.
+int upload_dictionary(BrotliAmdCtx* c, const BrotliAmdDictChunk* chunks, uint32_t nchunks,
+                      std::vector<void*>* allocs, CompoundDict** d_cd) {
+  if (nchunks > DICT_MAX_CHUNKS) { fail(c, "more than 15 dictionary chunks"); return BROTLI_AMD_UNSUPPORTED; }
+  if (hipStreamSynchronize(c->stream) != hipSuccess) { fail(c, "stream sync failed"); return BROTLI_AMD_ERROR; }
+  for (void* p : *allocs) (void)hipFree(p);
+  allocs->clear();
+  *d_cd = nullptr;
+  if (nchunks == 0) return BROTLI_AMD_OK;
+  CompoundDict cd;
+  memset(&cd, 0, sizeof(cd));
+  auto upload = [&](const void* src, uint64_t bytes, uint64_t slack) -> void* {
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes + slack + 16) != hipSuccess) return nullptr;
+    allocs->push_back(d);
+    if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (slack && hipMemset((uint8_t*)d + bytes, 0, slack) != hipSuccess) return nullptr;
+    return d;
+  };
+  uint64_t total = 0;
+  for (uint32_t k = 0; k < nchunks; ++k) {
+    const BrotliAmdDictChunk& h = chunks[k];
+    if (h.bucket_bits < 17 || h.bucket_bits > 22 || total + h.source_size > 0x7FFFFFFFull) {
+      fail(c, "bad dictionary chunk");
+      return BROTLI_AMD_UNSUPPORTED;
+    }
+    const uint64_t nkeys = 1ull << h.bucket_bits;
+    DictChunk& g = cd.chunks[k];
+    g.source = (const uint8_t*)upload(h.source, h.source_size, DICT_SOURCE_SLACK);
+    g.starts = (const uint32_t*)upload(h.starts, (nkeys + 1) * 4, 0);
+    g.items = (const uint32_t*)upload(h.items, (uint64_t)h.starts[nkeys] * 4, 0);
+    if (!g.source || !g.starts || !g.items) { fail(c, "dictionary upload failed"); return BROTLI_AMD_ERROR; }
+    g.source_size = h.source_size;
+    g.bucket_bits = h.bucket_bits;
+    g.offset = (uint32_t)total;
+    total += h.source_size;
+  }
+  cd.num_chunks = nchunks;
+  cd.total_size = (uint32_t)total;
+  *d_cd = (CompoundDict*)upload(&cd, sizeof(cd), 0);
+  if (!*d_cd) { fail(c, "dictionary upload failed"); return BROTLI_AMD_ERROR; }
+  return BROTLI_AMD_OK;
+}
+
 int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, JobPlan* plan) {
   if (len == 0) { fail(c, "empty job"); return BROTLI_AMD_UNSUPPORTED; }
   if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
@@ -255,13 +302,16 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
     return BROTLI_AMD_UNSUPPORTED;
   }
   uint32_t too_long = 0;
-  if (!plan_choose_kernels(plan, p->flags, c->num_cus, &too_long)) {
+  // with dictionaries attached to the context every shard looks them up after each search: that lives in the
+  // one-shard-per-wave kernels (k_parse / k_parse_deep / k_parse_quick), thousands of which run side by side
+  const uint32_t api_flags = p->flags | (c->d_cd ? (uint32_t)(BROTLI_AMD_FLAG_NO_QUAD | BROTLI_AMD_FLAG_NO_INDEX) : 0u);
+  if (!plan_choose_kernels(plan, api_flags, c->num_cus, &too_long)) {
     fail(c, "quality %d needs shards of at most %u bytes", plan->J.quality, too_long);
     return BROTLI_AMD_UNSUPPORTED;
   }
   // Quality 5 on shards that fit the window: the position index + table-free chain.
   c->ix_region_bytes = 0;
-  if ((plan->J.flags & JOB_FLAG_QUAD) && !(p->flags & BROTLI_AMD_FLAG_NO_INDEX)) {
+  if ((plan->J.flags & JOB_FLAG_QUAD) && !(api_flags & BROTLI_AMD_FLAG_NO_INDEX)) {
     const char* e = getenv("BROTLI_AMD_INDEXED");
     if (!e || atoi(e) != 0) {
       c->ix_region_bytes = plan_add_index(plan, /*ix_in_ws=*/false);
@@ -319,6 +369,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
   a.ws = c->d_ws;
   a.nshards = nshards;
   a.counters = c->d_counters;
+  a.cd = c->d_cd;
   // Table init: enough 256-thread blocks per shard to stream the 128-byte
   // records at HBM rate without flooding the dispatcher.
   uint32_t ibs = 4096u / (nshards < 4096u ? nshards : 4096u);
@@ -460,6 +511,7 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
                   c->d_dec_pieces, c->d_dec_results};
   for (void* p : ptrs) if (p) (void)hipFree(p);
   for (uint8_t* p : c->d_table_chunks) if (p) (void)hipFree(p);
+  for (void* p : c->dict_allocs) (void)hipFree(p);
   for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
   if (c->ev_ix) (void)hipEventDestroy(c->ev_ix);
   if (c->ev_ixb) (void)hipEventDestroy(c->ev_ixb);
@@ -925,45 +977,13 @@ int brotli_amd_stream_attach_dictionary(BrotliAmdStream* s, const BrotliAmdDictC
   BrotliAmdCtx* c = s->c;
   DeviceScope dev(c->device);
   if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
-  if (nchunks > DICT_MAX_CHUNKS) { fail(c, "more than 15 dictionary chunks"); return BROTLI_AMD_UNSUPPORTED; }
-  if (hipStreamSynchronize(c->stream) != hipSuccess) { fail(c, "stream sync failed"); return BROTLI_AMD_ERROR; }
-  for (void* p : s->dict_allocs) (void)hipFree(p);
-  s->dict_allocs.clear();
-  s->d_cd = nullptr;
-  if (nchunks == 0) return BROTLI_AMD_OK;
-  CompoundDict cd;
-  memset(&cd, 0, sizeof(cd));
-  auto upload = [&](const void* src, uint64_t bytes, uint64_t slack) -> void* {
-    void* d = nullptr;
-    if (hipMalloc(&d, bytes + slack + 16) != hipSuccess) return nullptr;
-    s->dict_allocs.push_back(d);
-    if (bytes && hipMemcpy(d, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-    if (slack && hipMemset((uint8_t*)d + bytes, 0, slack) != hipSuccess) return nullptr;
-    return d;
-  };
-  uint64_t total = 0;
-  for (uint32_t k = 0; k < nchunks; ++k) {
-    const BrotliAmdDictChunk& h = chunks[k];
-    if (h.bucket_bits < 17 || h.bucket_bits > 22 || total + h.source_size > 0x7FFFFFFFull) {
-      fail(c, "bad dictionary chunk");
-      return BROTLI_AMD_UNSUPPORTED;
-    }
-    const uint64_t nkeys = 1ull << h.bucket_bits;
-    DictChunk& g = cd.chunks[k];
-    g.source = (const uint8_t*)upload(h.source, h.source_size, DICT_SOURCE_SLACK);
-    g.starts = (const uint32_t*)upload(h.starts, (nkeys + 1) * 4, 0);
-    g.items = (const uint32_t*)upload(h.items, (uint64_t)h.starts[nkeys] * 4, 0);
-    if (!g.source || !g.starts || !g.items) { fail(c, "dictionary upload failed"); return BROTLI_AMD_ERROR; }
-    g.source_size = h.source_size;
-    g.bucket_bits = h.bucket_bits;
-    g.offset = (uint32_t)total;
-    total += h.source_size;
-  }
-  cd.num_chunks = nchunks;
-  cd.total_size = (uint32_t)total;
-  s->d_cd = (CompoundDict*)upload(&cd, sizeof(cd), 0);
-  if (!s->d_cd) { fail(c, "dictionary upload failed"); return BROTLI_AMD_ERROR; }
-  return BROTLI_AMD_OK;
+  return upload_dictionary(c, chunks, nchunks, &s->dict_allocs, &s->d_cd);
+}
+
+int brotli_amd_ctx_set_dictionary(BrotliAmdCtx* c, const BrotliAmdDictChunk* chunks, uint32_t nchunks) {
+  DeviceScope dev(c->device);
+  if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  return upload_dictionary(c, chunks, nchunks, &c->dict_allocs, &c->d_cd);
 }
 
 int brotli_amd_stream_take_partial(BrotliAmdStream* s, uint32_t* nbits, uint32_t* value) {

@@ -148,6 +148,13 @@ typedef struct BrotliAmdDictChunk {
 } BrotliAmdDictChunk;
 int brotli_amd_stream_attach_dictionary(BrotliAmdStream* stream, const BrotliAmdDictChunk* chunks,
                                         uint32_t nchunks);
+/* The same for the JOBS of a context (brotli_amd_encode_device / _host with a partition plan): every
+   shard's encoder instance has the chunks attached — bytes identical to the reference driven with the
+   same plan and BrotliEncoderAttachPreparedDictionary on every instance; the concatenation decodes
+   with the dictionary attached once.  Jobs with a dictionary run one shard per wave on the hash-table
+   kernels (the indexed quality-5 parse has no dictionary lookup).  nchunks = 0 detaches; a context
+   taken from a pool should be cleared by its new user. */
+int brotli_amd_ctx_set_dictionary(BrotliAmdCtx* ctx, const BrotliAmdDictChunk* chunks, uint32_t nchunks);
 /* Hands the pending partial byte (s->last_bytes_ / last_bytes_bits_) to the caller and
    clears it on the device: the caller continues the byte (metadata header). */
 int brotli_amd_stream_take_partial(BrotliAmdStream* stream, uint32_t* nbits, uint32_t* value);

@@ -64,8 +64,8 @@ class Ref:
         return out.raw[:n.value]
 
     def encode_shard(self, data, quality, lgwin, size_hint, stream_offset,
-                     is_last):
-        """One instance per shard, SURVEY.md §8(e) contract."""
+                     is_last, dictionaries=()):
+        """One instance per shard, SURVEY.md §8(e) contract; `dictionaries` are attached to it."""
         L = self.L
         st = L.BrotliEncoderCreateInstance(None, None, None)
         assert L.BrotliEncoderSetParameter(st, PARAM_QUALITY, quality)
@@ -74,6 +74,12 @@ class Ref:
         if stream_offset:
             assert L.BrotliEncoderSetParameter(st, PARAM_STREAM_OFFSET,
                                                stream_offset)
+        keep = [C.create_string_buffer(bytes(d), max(len(d), 1)) for d in dictionaries]
+        prepared = []
+        for d, buf in zip(dictionaries, keep):
+            pd = L.BrotliEncoderPrepareDictionary(0, len(d), buf, 11, None, None, None)
+            assert pd and L.BrotliEncoderAttachPreparedDictionary(st, pd)
+            prepared.append(pd)
         cap = 2 * len(data) + 1024
         out = C.create_string_buffer(cap)
         inbuf = C.create_string_buffer(bytes(data), len(data))
@@ -91,6 +97,8 @@ class Ref:
             if avail_in.value == 0 and not L.BrotliEncoderHasMoreOutput(st):
                 break
         L.BrotliEncoderDestroyInstance(st)
+        for pd in prepared:
+            L.BrotliEncoderDestroyPreparedDictionary(pd)
         return out.raw[:total.value]
 
     def encode_calls(self, data, quality, lgwin, calls, size_hint=0, dictionaries=()):
@@ -136,7 +144,7 @@ class Ref:
         # encode.c:1590-1600: measure what actually left)
         return out.raw[:cap - avail_out.value]
 
-    def encode_plan(self, data, quality, lgwin, shard_size):
+    def encode_plan(self, data, quality, lgwin, shard_size, dictionaries=()):
         n = len(data)
         if n == 0:
             return b"\x06"
@@ -149,7 +157,7 @@ class Ref:
             m = min(shard_size, n - off)
             parts.append(self.encode_shard(
                 data[off:off + m], quality, lgwin, hint, min(off, 1 << 30),
-                off + m == n))
+                off + m == n, dictionaries))
             off += m
         return b"".join(parts)
 

@@ -11,9 +11,46 @@
 
 #include "../../include/brotli_amd_hip.h"
 
+struct SimDict {
+  std::vector<std::vector<uint8_t>> src;
+  std::vector<std::vector<uint32_t>> starts, items;
+  CompoundDict cd;
+  bool have = false;
+  int set(const BrotliAmdDictChunk* chunks, uint32_t nchunks) {
+    if (nchunks > DICT_MAX_CHUNKS) return BROTLI_AMD_UNSUPPORTED;
+    src.assign(nchunks, {});
+    starts.assign(nchunks, {});
+    items.assign(nchunks, {});
+    memset(&cd, 0, sizeof(cd));
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < nchunks; ++k) {
+      const BrotliAmdDictChunk& h = chunks[k];
+      const size_t nkeys = (size_t)1 << h.bucket_bits;
+      src[k].assign(h.source, h.source + h.source_size);
+      src[k].resize(h.source_size + DICT_SOURCE_SLACK, 0);
+      starts[k].assign(h.starts, h.starts + nkeys + 1);
+      items[k].assign(h.items, h.items + h.starts[nkeys]);
+      items[k].push_back(0);
+      DictChunk& g = cd.chunks[k];
+      g.source = src[k].data();
+      g.starts = starts[k].data();
+      g.items = items[k].data();
+      g.source_size = h.source_size;
+      g.bucket_bits = h.bucket_bits;
+      g.offset = total;
+      total += h.source_size;
+    }
+    cd.num_chunks = nchunks;
+    cd.total_size = total;
+    have = nchunks != 0;
+    return BROTLI_AMD_OK;
+  }
+};
+
 struct BrotliAmdCtx {
   std::string tables, err;
   HostTables ht;
+  SimDict dict;       // brotli_amd_ctx_set_dictionary
 };
 
 struct BrotliAmdStream {
@@ -27,10 +64,7 @@ struct BrotliAmdStream {
   uint32_t counters[16];
   uint64_t fed = 0;
   bool finished = false;
-  std::vector<std::vector<uint8_t>> dict_src;
-  std::vector<std::vector<uint32_t>> dict_starts, dict_items;
-  CompoundDict cd;
-  bool have_cd = false;
+  SimDict dict;
 };
 
 namespace {
@@ -56,6 +90,7 @@ long run_plan_on_sim(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* in, size_t l
   a.init_blocks_per_shard = 2;
   uint32_t counters[16] = {0};
   a.counters = counters;
+  a.cd = c->dict.have ? &c->dict.cd : nullptr;
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
   for (int round = 0; round < 100000; ++round) {
     memset(counters, 0, sizeof(counters));
@@ -115,7 +150,8 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len, con
                             p->is_last != 0, &plan))
     return set_err(c, "parameters outside the GPU path", BROTLI_AMD_UNSUPPORTED);
   uint32_t lim = 0;
-  if (!plan_choose_kernels(&plan, p->flags, 256, &lim)) return set_err(c, "shard too long", BROTLI_AMD_UNSUPPORTED);
+  // (a dictionary on the context: one shard per wave on the hash-table kernels, as hip_layer.hip does)
+  if (!plan_choose_kernels(&plan, p->flags | (c->dict.have ? 2u : 0u), 256, &lim)) return set_err(c, "shard too long", BROTLI_AMD_UNSUPPORTED);
   const long n = run_plan_on_sim(c, plan, in, (size_t)len, out, (size_t)out_cap);
   if (n == -4) return set_err(c, "output capacity too small", BROTLI_AMD_OVERFLOW);
   if (n < 0) return set_err(c, "device fault", BROTLI_AMD_DEVICE_FAULT);
@@ -216,7 +252,7 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
   a.nshards = 1;
   a.init_blocks_per_shard = 1;
   a.counters = s->counters;
-  a.cd = s->have_cd ? &s->cd : nullptr;
+  a.cd = s->dict.have ? &s->dict.cd : nullptr;
   for (uint64_t round = 0;; ++round) {
     if (round > (s->fed >> 10) + 64) return set_err(c, "stream rounds do not converge (device fault)", BROTLI_AMD_ERROR);
     memset(s->counters, 0, sizeof(s->counters));
@@ -239,33 +275,13 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
 }
 
 int brotli_amd_stream_attach_dictionary(BrotliAmdStream* s, const BrotliAmdDictChunk* chunks, uint32_t nchunks) {
-  if (nchunks > DICT_MAX_CHUNKS) return set_err(s->c, "more than 15 dictionary chunks", BROTLI_AMD_UNSUPPORTED);
-  s->dict_src.assign(nchunks, {});
-  s->dict_starts.assign(nchunks, {});
-  s->dict_items.assign(nchunks, {});
-  memset(&s->cd, 0, sizeof(s->cd));
-  uint32_t total = 0;
-  for (uint32_t k = 0; k < nchunks; ++k) {
-    const BrotliAmdDictChunk& h = chunks[k];
-    const size_t nkeys = (size_t)1 << h.bucket_bits;
-    s->dict_src[k].assign(h.source, h.source + h.source_size);
-    s->dict_src[k].resize(h.source_size + DICT_SOURCE_SLACK, 0);
-    s->dict_starts[k].assign(h.starts, h.starts + nkeys + 1);
-    s->dict_items[k].assign(h.items, h.items + h.starts[nkeys]);
-    s->dict_items[k].push_back(0);
-    DictChunk& g = s->cd.chunks[k];
-    g.source = s->dict_src[k].data();
-    g.starts = s->dict_starts[k].data();
-    g.items = s->dict_items[k].data();
-    g.source_size = h.source_size;
-    g.bucket_bits = h.bucket_bits;
-    g.offset = total;
-    total += h.source_size;
-  }
-  s->cd.num_chunks = nchunks;
-  s->cd.total_size = total;
-  s->have_cd = nchunks != 0;
-  return BROTLI_AMD_OK;
+  const int rc = s->dict.set(chunks, nchunks);
+  return rc == BROTLI_AMD_OK ? rc : set_err(s->c, "more than 15 dictionary chunks", rc);
+}
+
+int brotli_amd_ctx_set_dictionary(BrotliAmdCtx* c, const BrotliAmdDictChunk* chunks, uint32_t nchunks) {
+  const int rc = c->dict.set(chunks, nchunks);
+  return rc == BROTLI_AMD_OK ? rc : set_err(c, "more than 15 dictionary chunks", rc);
 }
 
 int brotli_amd_stream_take_partial(BrotliAmdStream* s, uint32_t* nbits, uint32_t* value) {

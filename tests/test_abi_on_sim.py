@@ -127,8 +127,31 @@ def test_attached_dictionary_edge_shapes(simabi, stock):
     same(_chunks(n, 5000, 2, 3), ((1, 7), (2, 14)), [data[5000:25000]])
 
 
+@pytest.mark.parametrize("quality,lgwin", [(5, 22), (9, 20), (3, 18), (6, 14)])
+def test_attached_dictionaries_in_a_partition_plan(simabi, ref, oracle, quality, lgwin):
+    """A plan with dictionaries: every shard's encoder instance has them attached — bytes equal the
+    reference driven with the same plan and the same Attach calls on each instance (and the oracle's),
+    and the concatenation is one stream that decodes with the dictionary attached once."""
+    data, chunks = G.dictionary_case(100000, 60000, 2, seed=quality * 10 + lgwin)
+    shard = 1 << 15
+    want = ref.encode_plan(data, quality, lgwin, shard, dictionaries=chunks)
+    assert ref.decompress_with(want, len(data), chunks) == data
+    oracle.set_dictionary(chunks)
+    try:
+        assert oracle.encode_plan(data, quality, lgwin, shard) == want
+    finally:
+        oracle.set_dictionary(())
+    params = ((1, quality), (2, lgwin), (5, len(data)), (0x4D490001, shard))
+    got, fin = drive(simabi, data, [(len(data), 2)], params, dictionaries=chunks)
+    assert fin and got == want
+    # the next instance on the same (pooled) context starts without them
+    plain, fin = drive(simabi, data, [(len(data), 2)], params)
+    assert fin and plain == ref.encode_plan(data, quality, lgwin, shard)
+    assert len(want) < len(plain)
+
+
 def test_dictionary_api_edges_and_cli(simabi, tmp_path):
-    """Not-a-dictionary handles, the 15-chunk limit, a partition plan, quality 1 (ignores them);
+    """Not-a-dictionary handles, the 15-chunk limit, quality 1 (ignores them);
     `brotli -D FILE` of the reference CLI over this library (the simulator build) next to the
     stock CLI."""
     L = simabi
@@ -142,10 +165,6 @@ def test_dictionary_api_edges_and_cli(simabi, tmp_path):
         assert L.BrotliEncoderAttachPreparedDictionary(st, pd)
     assert not L.BrotliEncoderAttachPreparedDictionary(st, pd)
     assert not L.BrotliEncoderAttachPreparedDictionary(st, None)
-    L.BrotliEncoderDestroyInstance(st)
-    st = L.BrotliEncoderCreateInstance(None, None, None)
-    assert L.BrotliEncoderSetParameter(st, 0x4D490001, 1 << 17)
-    assert not L.BrotliEncoderAttachPreparedDictionary(st, pd)
     L.BrotliEncoderDestroyInstance(st)
     L.BrotliEncoderDestroyPreparedDictionary(pd)
     data, chunks = G.dictionary_case(30000, 20000, 1, seed=5)

@@ -292,8 +292,23 @@ def test_attached_dictionary_past_one_mebibyte(amd, stock):
         assert fin_w and fin_g and got == want, quality
 
 
+@pytest.mark.parametrize("quality,lgwin", [(5, 22), (9, 22), (3, 18), (6, 14)])
+def test_attached_dictionaries_in_a_partition_plan(amd, ref, quality, lgwin):
+    """Every shard's instance has the dictionaries attached: bytes equal the reference driven with the
+    same plan and Attach calls per instance; one valid stream; the pooled context is clean afterwards."""
+    data, chunks = G.dictionary_case(4 << 20, 300000, 2, seed=quality * 10 + lgwin)
+    shard = 1 << 16
+    want = ref.encode_plan(data, quality, lgwin, shard, dictionaries=chunks)
+    assert ref.decompress_with(want, len(data), chunks) == data
+    params = ((1, quality), (2, lgwin), (5, len(data)), (0x4D490001, shard))
+    got, fin = drive(amd, data, [(len(data), 2)], params, dictionaries=chunks)
+    assert fin and got == want
+    plain, fin = drive(amd, data, [(len(data), 2)], params)
+    assert fin and plain == ref.encode_plan(data, quality, lgwin, shard) and len(want) < len(plain)
+
+
 def test_dictionary_api_edges(amd):
-    """Not-a-dictionary handles, the 15-chunk limit, a partition plan, quality 1 (ignores them)."""
+    """Not-a-dictionary handles, the 15-chunk limit, quality 1 (ignores them)."""
     assert amd.BrotliEncoderPrepareDictionary(1, 4, b"abcd", 11, None, None, None) is None   # serialized: not built
     assert amd.BrotliEncoderGetPreparedDictionarySize(None) == 0
     d = C.create_string_buffer(b"hello hello hello hello", 23)
@@ -304,10 +319,6 @@ def test_dictionary_api_edges(amd):
         assert amd.BrotliEncoderAttachPreparedDictionary(st, pd)
     assert not amd.BrotliEncoderAttachPreparedDictionary(st, pd)          # SHARED_BROTLI_MAX_COMPOUND_DICTS
     assert not amd.BrotliEncoderAttachPreparedDictionary(st, None)
-    amd.BrotliEncoderDestroyInstance(st)
-    st = amd.BrotliEncoderCreateInstance(None, None, None)
-    assert amd.BrotliEncoderSetParameter(st, 0x4D490001, 1 << 17)
-    assert not amd.BrotliEncoderAttachPreparedDictionary(st, pd)          # partition plan: refused
     amd.BrotliEncoderDestroyInstance(st)
     amd.BrotliEncoderDestroyPreparedDictionary(pd)
     data, chunks = G.dictionary_case(100000, 50000, 1, seed=5)
