@@ -87,8 +87,9 @@ size_t BrotliEncoderGetPreparedDictionarySize(const BrotliEncoderPreparedDiction
    keeps the dictionary bytes alive while a prepared dictionary exists, and the prepared dictionary
    alive while an encoder uses it — as with the reference.  Any other type returns NULL (the
    reference's serialized form is an experimental build option).  Attached dictionaries are looked
-   up on the device by the single-stream path at qualities 2 - 9; qualities 0 - 1 ignore them; an
-   instance driven by a partition plan (BROTLI_AMD_SHARD_KB) refuses Attach. */
+   up on the device at qualities 2 - 9 — by the single stream, and by every shard of a partition plan
+   (BROTLI_AMD_SHARD_KB: each shard's instance has them attached, as the reference driven with the same
+   plan would); qualities 0 - 1 ignore them. */
 BrotliEncoderPreparedDictionary* BrotliEncoderPrepareDictionary(
     int type, size_t data_size, const uint8_t* data, int quality,
     brotli_amd_alloc_func alloc_func, brotli_amd_free_func free_func, void* opaque);
