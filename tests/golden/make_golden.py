@@ -70,6 +70,13 @@ DICT_CASES = [
     ({"nbytes": 200000, "dict_bytes": 80000, "nchunks": 2, "seed": 47}, 4, 18),
     ({"nbytes": (1 << 20) + 50000, "dict_bytes": 150000, "nchunks": 2, "seed": 48}, 5, 22),   # H68
 ]
+# the same in a partition plan: every shard's instance has the dictionaries attached (..., shard size)
+DICT_PLAN_CASES = [
+    ({"nbytes": 1 << 20, "dict_bytes": 200000, "nchunks": 2, "seed": 51}, 5, 22, 1 << 16),
+    ({"nbytes": 1 << 20, "dict_bytes": 200000, "nchunks": 1, "seed": 52}, 9, 22, 1 << 17),
+    ({"nbytes": 1 << 20, "dict_bytes": 100000, "nchunks": 1, "seed": 53}, 3, 18, 1 << 16),
+    ({"nbytes": 1 << 20, "dict_bytes": 100000, "nchunks": 3, "seed": 54}, 6, 14, 1 << 15),
+]
 
 
 def q1_calls(n, feed_kb):
@@ -111,6 +118,13 @@ def main():
         out = ref.encode_calls(data, q, w, [(len(data), 2)], dictionaries=chunks)
         assert ref.decompress_with(out, len(data), chunks) == data
         dc.append({"input": spec, "quality": q, "lgwin": w, "size": len(out),
+                   "sha256": hashlib.sha256(out).hexdigest()})
+        print(dc[-1])
+    for spec, q, w, shard in DICT_PLAN_CASES:
+        data, chunks = G.dictionary_case(**spec)
+        out = ref.encode_plan(data, q, w, shard, dictionaries=chunks)
+        assert ref.decompress_with(out, len(data), chunks) == data
+        dc.append({"input": spec, "quality": q, "lgwin": w, "shard_size": shard, "size": len(out),
                    "sha256": hashlib.sha256(out).hexdigest()})
         print(dc[-1])
     json.dump({"generator": "oracle/_ref (google/brotli c/enc, gcc x86-64)",

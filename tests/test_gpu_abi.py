@@ -277,7 +277,10 @@ def test_golden_vectors_dictionaries(amd):
     gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
     for case in gold["dictionary_cases"]:
         data, chunks = G.dictionary_case(**case["input"])
-        got, fin = drive(amd, data, [(len(data), 2)], ((1, case["quality"]), (2, case["lgwin"])), dictionaries=chunks)
+        params = ((1, case["quality"]), (2, case["lgwin"]))
+        if case.get("shard_size"):
+            params += ((5, len(data)), (0x4D490001, case["shard_size"]))
+        got, fin = drive(amd, data, [(len(data), 2)], params, dictionaries=chunks)
         assert fin and len(got) == case["size"] and hashlib.sha256(got).hexdigest() == case["sha256"], case
 
 

@@ -156,7 +156,10 @@ def test_golden_vectors_dictionaries(oracle):
         data, chunks = G.dictionary_case(**case["input"])
         oracle.set_dictionary(chunks)
         try:
-            out = oracle.encode_shard(data, case["quality"], case["lgwin"], 0, 0, True)
+            if case.get("shard_size"):
+                out = oracle.encode_plan(data, case["quality"], case["lgwin"], case["shard_size"])
+            else:
+                out = oracle.encode_shard(data, case["quality"], case["lgwin"], 0, 0, True)
         finally:
             oracle.set_dictionary(())
         assert len(out) == case["size"] and hashlib.sha256(out).hexdigest() == case["sha256"], case
