@@ -156,18 +156,12 @@ def decompress(string):
     """python/brotli.py:56-73: the decoded bytes of one complete Brotli stream; `brotli.error` if the
     stream is damaged or incomplete.  Device decoder (k_decode.h); the output size is not known in
     advance, so the buffer is grown until the stream fits."""
-    global _dec_ctx
-    from . import hip
     data = bytes(string)
+    ctx = _decoder_context()
     with _lib_lock:
-        if _dec_ctx is None:
-            try:
-                _dec_ctx = hip.Context(int(os.environ.get("BROTLI_AMD_DEVICE", "0")))
-            except hip.BrotliAmdError as e:
-                raise error(str(e))
         cap = max(1 << 16, 6 * len(data))
         while True:
-            out, res, bits = _dec_ctx.decode_host(data, cap, check=False, with_bits=True)
+            out, res, bits = ctx.decode_host(data, cap, check=False, with_bits=True)
             n, err, finished = res[0]
             if err == 6 and cap < (1 << 31):      # output overrun: more room
                 cap *= 4
@@ -178,6 +172,71 @@ def decompress(string):
             if (bits[0] + 7) // 8 != len(data):          # python/_brotli.c:917: input left over is an error
                 raise error("BrotliDecoderDecompress failed (data after the end of the stream)")
             return out[:n]
+
+
+def _decoder_context():
+    global _dec_ctx
+    from . import hip
+    with _lib_lock:
+        if _dec_ctx is None:
+            try:
+                _dec_ctx = hip.Context(int(os.environ.get("BROTLI_AMD_DEVICE", "0")))
+            except hip.BrotliAmdError as e:
+                raise error(str(e))
+    return _dec_ctx
+
+
+class Decompressor(object):
+    """python/_brotli.c:640-860 `Decompressor`: process(data) returns the bytes that became available,
+    is_finished() tells whether the stream has ended.  The device decoder works on resident data: a
+    call decodes what has arrived so far from the start, and output is handed out once the stream is
+    complete (what a wave decodes from the last, cut-off bytes of a partial input is not trustworthy,
+    so nothing is returned before that) — the concatenation of the returned pieces is the reference's,
+    their timing is not (this class is for checks, not for streaming at rate).  `output_buffer_limit`
+    is accepted and ignored, so can_accept_more_data() is always True."""
+
+    def __init__(self):
+        self._in = bytearray()
+        self._finished = False
+        self._cap = 1 << 16
+        self._busy = threading.Lock()
+
+    def is_finished(self):
+        return self._finished
+
+    def can_accept_more_data(self):
+        return True
+
+    def process(self, string, output_buffer_limit=None):
+        if not self._busy.acquire(False):
+            raise error("Concurrently sharing Decompressor instances is not supported")
+        try:
+            if self._finished:
+                if len(string):
+                    raise error("BrotliDecoderDecompressStream failed: data after the end of the stream")
+                return b""
+            self._in += bytes(string)
+            if not self._in:
+                return b""
+            ctx = _decoder_context()
+            data = bytes(self._in)
+            while True:
+                out, res, bits = ctx.decode_host(data, self._cap, check=False, with_bits=True)
+                n, err, finished = res[0]
+                if err == 6 and self._cap < (1 << 31):
+                    self._cap *= 4
+                    continue
+                break
+            if err not in (0, 7) or (err == 7 and finished):
+                raise error("BrotliDecoderDecompressStream failed (device decoder error %d)" % err)
+            if not finished:
+                return b""
+            if (bits[0] + 7) // 8 != len(data):
+                raise error("BrotliDecoderDecompressStream failed: data after the end of the stream")
+            self._finished = True
+            return out[:n]
+        finally:
+            self._busy.release()
 
 
 def compress(string, mode=MODE_GENERIC, quality=11, lgwin=22, lgblock=0, shard_size=0):

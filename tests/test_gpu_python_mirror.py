@@ -77,6 +77,10 @@ def test_decompress_round_trip_and_errors(brotli, ref):
         brotli.decompress(comp[:len(comp) // 2])
     with pytest.raises(brotli.error):
         brotli.decompress(b"\xff" * 100)
+    d, got = brotli.Decompressor(), b""
+    for i in range(0, len(comp), 20000):
+        got += d.process(comp[i:i + 20000])
+    assert got == bytes(INPUTS["text300k"]) and d.is_finished()
 
 
 def test_invalid_arguments_and_unsupported_quality(brotli):

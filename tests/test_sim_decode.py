@@ -135,3 +135,32 @@ def test_damaged_streams_end_in_an_error(sim, ref):
                 sz = C.c_size_t(len(data) + 1)
                 assert ref.L.BrotliDecoderDecompress(len(bad), bytes(bad), C.byref(sz), buf) == 1
                 assert buf.raw[:sz.value] == out[:n]
+
+
+def test_python_mirror_decompress_over_the_simulator(sim, ref, monkeypatch):
+    """brotli_amd.brotli.decompress / Decompressor (python/brotli.py:56-73, python/_brotli.c:640-930)
+    with the device decoder replaced by the simulator: the buffer grows until the stream fits, cut or
+    damaged streams and trailing data raise brotli.error, the streaming class hands out the bytes
+    once the stream is complete."""
+    import brotli_amd.brotli as b
+
+    class OnSim:
+        def decode_host(self, comp, n_out, pieces=None, check=True, with_bits=False):
+            out, res = sim.decode(comp, n_out)
+            return out, [(res[0][0], res[0][2], res[0][3])], [res[0][1]]
+
+    monkeypatch.setattr(b, "_dec_ctx", OnSim())
+    data = INPUTS["alice"][:40000]
+    comp = ref.compress(data, 5, 22)
+    assert b.decompress(comp) == data
+    assert b.decompress(ref.compress(bytes(300000), 5, 22)) == bytes(300000)     # 20 bytes -> 300 000
+    for bad in (comp[:500], b"\xff" * 100, comp + b"\0"):
+        with pytest.raises(b.error):
+            b.decompress(bad)
+    d, got = b.Decompressor(), b""
+    for i in range(0, len(comp), 3000):
+        assert not d.is_finished() and d.can_accept_more_data()
+        got += d.process(comp[i:i + 3000])
+    assert got == data and d.is_finished() and d.process(b"") == b""
+    with pytest.raises(b.error):
+        d.process(b"x")
