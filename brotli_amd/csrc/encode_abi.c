@@ -457,8 +457,8 @@ static size_t feed_threshold(const BrotliEncoderState* s) {
   if (kb == 0) kb = 1;
   return kb << 10;
 }
-static int forward_pending_input(BrotliEncoderState* s) {
-  if (s->quality == 1 || !s->hint_fixed || s->in_len < feed_threshold(s)) return 1;
+static int forward_pending_input(BrotliEncoderState* s, int force) {
+  if (s->quality == 1 || !s->hint_fixed || s->in_len == 0 || (!force && s->in_len < feed_threshold(s))) return 1;
   if (s->shard_bytes == 0) {
     const uint8_t* out;
     uint64_t out_len;
@@ -685,7 +685,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
     if (op != OP_PROCESS) {
       if (!submit(s, op)) { s->failed = 1; return BROTLI_FALSE; }
       s->stream_state = op == OP_FINISH ? ST_FINISHED : ST_FLUSH_REQUESTED;
-    } else if (!forward_pending_input(s)) {
+    } else if (!forward_pending_input(s, 0)) {
       s->failed = 1;
       return BROTLI_FALSE;
     }
@@ -856,6 +856,13 @@ BROTLI_BOOL BrotliEncoderAttachPreparedDictionary(BrotliEncoderState* state,
   if (!state || !d || d->magic != DICT_INDEX_MAGIC) return BROTLI_FALSE;
   if (state->ndicts == 15) return BROTLI_FALSE;
   if (d->source_size > DICT_INDEX_MAX_RAW - state->dict_total) return BROTLI_FALSE;
+  /* The reference has already parsed every complete input block it was given (encode.c:1700-1720) — without
+     this dictionary.  Input still waiting on the host goes to the device first (complete blocks are parsed there,
+     the partial one stays pending, as in the reference), then the dictionary joins. */
+  if (state->initialized && !state->failed && state->ctx && !forward_pending_input(state, 1)) {
+    state->failed = 1;
+    return BROTLI_FALSE;
+  }
   state->dicts[state->ndicts++] = d;
   state->dict_total += d->source_size;
   if (state->stream && !push_dictionaries(state)) {

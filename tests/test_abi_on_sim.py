@@ -125,6 +125,11 @@ def test_attached_dictionary_edge_shapes(simabi, stock):
     same([(3, 2)], ((1, 2), (2, 22)), [d], data=data[:3])
     same(_chunks(n, 3000, 2, 1), ((1, 5), (2, 22)), [data[5000:25000]], take=True)
     same(_chunks(n, 5000, 2, 3), ((1, 7), (2, 14)), [data[5000:25000]])
+    # attached while input is waiting (found by tools/fuzz_abi_sim.py): the reference has parsed the complete
+    # blocks of the PROCESS calls without the dictionary, the partial block and what follows with it
+    big, ch2 = G.dictionary_case(100000, 20000, 1, seed=2)
+    same([(70000, 0), (30000, 2)], ((1, 5), (2, 18)), ch2, data=big, attach_before_op=1)
+    same([(20000, 0), (20000, 0), (60000, 2)], ((1, 3), (2, 14)), ch2, data=big, attach_before_op=2)
 
 
 @pytest.mark.parametrize("quality,lgwin", [(5, 22), (9, 20), (3, 18), (6, 14)])

@@ -23,8 +23,8 @@ stock = _bind(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
 
 def one(seed):
     rng = np.random.default_rng(seed)
-    quality = int(rng.choice([1, 1, 5, 5, 5, 6, 7, 8, 9]))
-    lgwin = int(rng.choice([10, 16, 18, 22, 24])) if quality == 1 else int(rng.choice([17, 18, 20, 22, 24]))
+    quality = int(rng.choice([1, 1, 2, 3, 4, 5, 5, 5, 6, 7, 8, 9]))
+    lgwin = int(rng.choice([10, 12, 14, 16, 17, 18, 20, 22, 24]))
     pieces = [_fuzz_input(rng) for _ in range(int(rng.integers(1, 5)))]
     if rng.integers(0, 3) == 0:
         pieces.append(G.enwik_text(int(rng.integers(20000, 90000)), seed=seed, vocab=3000))
@@ -56,9 +56,20 @@ def one(seed):
         take = False     # reference quirk, not reproduced: with STREAM_OFFSET the flint block must be
                          # pushed out (available_out > 0); in TakeOutput style its stream stops there
     chunk = int(rng.choice([64, 4096, 1 << 16]))
+    # attached dictionaries: pieces of the input itself and of unrelated text, attached before a random call
+    dictionaries, attach_at = [], 0
+    if rng.integers(0, 3) == 0:
+        for _ in range(int(rng.integers(1, 4))):
+            if rng.integers(0, 2) and len(data) > 64:
+                a = int(rng.integers(0, len(data) - 32))
+                dictionaries.append(bytes(data[a:a + int(rng.integers(1, 40000))]))
+            else:
+                dictionaries.append(bytes(G.enwik_text(int(rng.integers(1, 30000)), seed=seed + 7, vocab=3000)))
+        attach_at = int(rng.integers(0, len(ops))) if rng.integers(0, 3) == 0 else 0
     def run(L):
         try:
-            return drive(L, data, ops, tuple(params), out_chunk=chunk, take=take)
+            return drive(L, data, ops, tuple(params), out_chunk=chunk, take=take, dictionaries=dictionaries,
+                         attach_before_op=attach_at)
         except AssertionError:
             return None, None                      # the library refused a call (BROTLI_FALSE)
     want, fw = run(stock)
@@ -66,8 +77,9 @@ def one(seed):
     ok = (want is None and got is None) or (want is not None and fw and fg and got == want)
     if want is None:
         print("   (the reference refuses this sequence)", end="")
-    print("seed %d q%d lgwin %d len %d calls %d params %s take %d: %s" % (
-        seed, quality, lgwin, len(data), len(ops), params[2:], take, "ok" if ok else "MISMATCH"), flush=True)
+    print("seed %d q%d lgwin %d len %d calls %d params %s take %d dicts %s@%d: %s" % (
+        seed, quality, lgwin, len(data), len(ops), params[2:], take, [len(d) for d in dictionaries], attach_at,
+        "ok" if ok else "MISMATCH"), flush=True)
     return ok
 
 
