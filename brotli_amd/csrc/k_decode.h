@@ -475,6 +475,7 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
         skip += 1u;
       }
       if (br_align(b) != 0u) { error = DEC_ERR_HEADER; break; }
+      if ((br_bitpos(b) >> 3) + skip > P.in_len) { error = DEC_ERR_INPUT; break; }   // (never seek outside the input)
       br_seek(b, (br_bitpos(b) >> 3) + skip);
       if (is_last) finished = 1;
       continue;
