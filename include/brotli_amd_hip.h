@@ -206,7 +206,8 @@ typedef struct BrotliAmdDecodePiece {
 #define BROTLI_AMD_PIECE_HEADER 1u     /* starts with the stream header (window bits) */
 #define BROTLI_AMD_PIECE_ISOLATED 2u   /* a shard of a plan: a copy reaching before the piece is an error */
 typedef struct BrotliAmdDecodeResult {
-  uint64_t out_bytes;
+  uint64_t out_bytes;        /* bytes written; with error != 0 the last of them are not to be trusted (a cut
+                                input is noticed a few symbols late) */
   uint64_t in_bits;          /* bits consumed */
   uint32_t error;            /* 0 = ok; 1 header, 2 prefix code, 3 context map, 4 distance, 5 dictionary,
                                 6 output overrun, 7 input overrun, 8 arena (too many prefix codes for the
