@@ -155,6 +155,19 @@ def test_attached_dictionaries_in_a_partition_plan(simabi, ref, oracle, quality,
     assert len(want) < len(plain)
 
 
+def test_large_dictionary_wider_index_and_saturated_keys(simabi, stock):
+    """A dictionary past 2 MiB gets a wider index (one more key bit per doubling, compound_dictionary.c:
+    163-170) and a run of repeats fills keys past their 32 entries (only the newest 32 stay); the
+    dictionary is also far larger than the window of the second case."""
+    data, ch = G.dictionary_case(40000, 5 << 20, 1, seed=77)
+    d = ch[0][:(5 << 20) - 200000] + b"the quick brown fox " * 10000
+    for quality, lgwin in ((5, 22), (3, 16)):
+        params = ((1, quality), (2, lgwin))
+        want, fin_w = drive(stock, data, [(len(data), 2)], params, dictionaries=[d])
+        got, fin_g = drive(simabi, data, [(len(data), 2)], params, dictionaries=[d])
+        assert fin_w and fin_g and got == want, (quality, lgwin)
+
+
 def test_dictionary_api_edges_and_cli(simabi, tmp_path):
     """Not-a-dictionary handles, the 15-chunk limit, quality 1 (ignores them);
     `brotli -D FILE` of the reference CLI over this library (the simulator build) next to the
