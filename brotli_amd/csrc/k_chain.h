@@ -438,8 +438,13 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     // generic step carries on with (it may ask the dictionary again at the next position).
     bool gate_closed = g.dict_matches < (g.dict_lookups >> 7);
     bool dict0 = false;                                         // the dictionary was asked about position 0, in vain
+    // literals allowed before the spree check trips (:208)
+    const uint32_t room = g.apply_random_heuristics >= pos ? g.apply_random_heuristics - pos : 0u;
     {
-      const bool dq = can && !gate_closed && (hit16 & 1u) == 0u;
+      // (not when the literal spree trips right behind this position: that step belongs to the generic path,
+      // which searches the position itself — asking here as well would count the two lookups twice and close
+      // the gate earlier than the reference does; found by tools/fuzz_index_sim.py)
+      const bool dq = can && !gate_closed && (hit16 & 1u) == 0u && room != 0u;
       if (wave_any(dq)) {
         QResult r;
         r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; r.delta = 0;
@@ -462,8 +467,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     const uint32_t adv16 = q_mask16(wave_ballot(t < 15 && sc_next >= sc + 175u));
     const uint32_t U = (uint32_t)dev_ctz32(~use16 | 0x10000u);                  // usable prefix
     const uint32_t m = (uint32_t)dev_ctz32(hit16 | 0x10000u);                   // first match
-    // literals allowed before the spree check trips (:208) / the dictionary has to be asked
-    const uint32_t room = g.apply_random_heuristics >= pos ? g.apply_random_heuristics - pos : 0u;
+    // ... / the dictionary has to be asked
     const uint32_t missmax = gate_closed ? room : dict0 ? umin(room, 1u) : 0u;
     const uint32_t tt = umin((uint32_t)dev_ctz32(~(adv16 >> (m & 15u)) | 0x10u), 4u);   // positions the match is delayed by
     const uint32_t last = m + umin(tt + 1u, 4u);                                // last position probed

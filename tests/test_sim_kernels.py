@@ -7,6 +7,10 @@ import numpy as np
 import pytest
 
 import gen_inputs as G
+
+import os  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 from simharness import Sim, oracle_commands
 
 ALICE = open(__file__.replace("test_sim_kernels.py", "golden/alice29.txt"), "rb").read()
@@ -225,6 +229,25 @@ def test_indexed_parse_fuzz(sim, oracle, seed):
             assert sim.encode(data, size_hint=hint, shard_size=shard, reverse=rev, flags=IX_LAYOUTS[layout]) == want, \
                 (seed, len(data), shard, hint, layout)
         assert sim.encode(data, size_hint=hint, shard_size=shard, reverse=rev, flags=IX_LAYOUTS["groups4"] | 4) == want
+
+
+@pytest.mark.parametrize("seed", [431, 1011, 1638])
+def test_indexed_parse_dictionary_gate_at_the_spree_boundary(sim, oracle, seed):
+    """Cases of tools/fuzz_index_sim.py that differed: no match at the first position of a fast step, the static
+    dictionary still being consulted, and the literal spree tripping right behind it — the step goes to the generic
+    path, which searches the position itself; the fast path must not have asked the dictionary already (two lookups
+    counted twice close the gate earlier than the reference does, and a later dictionary match is missed)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "fuzz_index_sim", os.path.join(os.path.dirname(HERE), "tools", "fuzz_index_sim.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    data, shard, hint, rev = fz.make_case(seed)
+    if seed == 431:
+        data = data[:600]
+    want = _oracle_plan(oracle, data, hint, shard)
+    for layout in IX_LAYOUTS:
+        assert sim.encode(data, size_hint=hint, shard_size=shard, reverse=rev, flags=IX_LAYOUTS[layout]) == want, layout
 
 
 def test_quad_kernel_many_shards_reverse(sim, oracle):

@@ -14,10 +14,8 @@ from refharness import Oracle  # noqa: E402
 from simharness import Sim  # noqa: E402
 from test_sim_kernels import IX_LAYOUTS, _fuzz_input, _oracle_plan  # noqa: E402
 
-sim, oracle = Sim(), Oracle()
-
-
-def one(seed):
+def make_case(seed):
+    """(data, shard size, size hint, lane order) of a seed."""
     rng = np.random.default_rng(seed)
     pieces = [_fuzz_input(rng) for _ in range(int(rng.integers(1, 4)))]
     if rng.integers(0, 3) == 0:
@@ -27,8 +25,13 @@ def one(seed):
     data = b"".join(pieces)
     shard = int(rng.choice([0, 0, 300, 1000, 2500, 7000, 20000]))
     hint = (1 << 30) if rng.integers(0, 2) else 0                     # H68 vs H58
-    want = _oracle_plan(oracle, data, hint, shard)
     rev = int(rng.integers(0, 2))
+    return data, shard, hint, rev
+
+
+def one(seed, sim, oracle):
+    data, shard, hint, rev = make_case(seed)
+    want = _oracle_plan(oracle, data, hint, shard)
     bad = []
     for layout, flags in IX_LAYOUTS.items():
         for extra in (0, 4):
@@ -41,4 +44,5 @@ def one(seed):
 if __name__ == "__main__":
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     count = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-    print("mismatching seeds:", [s for s in range(first, first + count) if not one(s)])
+    sim, oracle = Sim(), Oracle()
+    print("mismatching seeds:", [s for s in range(first, first + count) if not one(s, sim, oracle)])
