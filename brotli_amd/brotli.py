@@ -163,7 +163,8 @@ def decompress(string):
         while True:
             out, res, bits = ctx.decode_host(data, cap, check=False, with_bits=True)
             n, err, finished = res[0]
-            if err == 6 and cap < (1 << 31):      # output overrun: more room
+            if err == 6 and cap < (1 << 31):      # a meta-block announces more than the buffer holds (error 10,
+                                                  # a command past its meta-block's length, is damage: no retry)
                 cap *= 4
                 continue
             if err != 0 or not finished:
@@ -220,13 +221,14 @@ class Decompressor(object):
                 return b""
             ctx = _decoder_context()
             data = bytes(self._in)
-            while True:
-                out, res, bits = ctx.decode_host(data, self._cap, check=False, with_bits=True)
-                n, err, finished = res[0]
-                if err == 6 and self._cap < (1 << 31):
-                    self._cap *= 4
-                    continue
-                break
+            with _lib_lock:     # the shared decoder context is not re-entrant (decompress() holds the same lock)
+                while True:
+                    out, res, bits = ctx.decode_host(data, self._cap, check=False, with_bits=True)
+                    n, err, finished = res[0]
+                    if err == 6 and self._cap < (1 << 31):   # a meta-block announces more than the buffer holds
+                        self._cap *= 4
+                        continue
+                    break
             if err not in (0, 7) or (err == 7 and finished):
                 raise error("BrotliDecoderDecompressStream failed (device decoder error %d)" % err)
             if not finished:

@@ -1027,7 +1027,7 @@ int brotli_amd_decode_device(BrotliAmdCtx* c, const void* d_in, uint64_t in_len,
   if (npieces > (1u << 22)) { fail(c, "too many pieces"); return BROTLI_AMD_UNSUPPORTED; }
   for (uint64_t k = 0; k < npieces; ++k) {
     const BrotliAmdDecodePiece& p = pieces[k];
-    if (p.in_off + p.in_len > in_len || p.out_off + p.out_cap > out_cap ||
+    if (p.in_len > in_len || p.in_off > in_len - p.in_len || p.out_cap > out_cap || p.out_off > out_cap - p.out_cap ||
         (!(p.flags & BROTLI_AMD_PIECE_HEADER) && (p.lgwin < 10 || p.lgwin > 24))) {
       fail(c, "piece %llu does not fit its buffers", (unsigned long long)k);
       return BROTLI_AMD_UNSUPPORTED;

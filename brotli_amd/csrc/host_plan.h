@@ -146,7 +146,9 @@ static inline uint64_t plan_add_index(JobPlan* plan, bool ix_in_ws) {
   if (slices > 64) slices = 64;
   plan->J.ix_slices = slices;
   uint32_t nb = IX_NB_MAX_LOG2 - 2u;                         // ~256 positions per bucket
-  while (nb < IX_NB_MAX_LOG2 && (longest >> nb) > 320u) ++nb;
+  uint32_t per_bucket = 320u;
+  if (const char* e = getenv("BROTLI_AMD_IX_TARGET")) { const int v = atoi(e); if (v >= 64 && v <= 4096) per_bucket = (uint32_t)v; }   // experiment knob
+  while (nb < IX_NB_MAX_LOG2 && (longest >> nb) > per_bucket) ++nb;
   if ((int)nb > plan->J.bucket_bits - 4) nb = (uint32_t)plan->J.bucket_bits - 4u;
   plan->J.ix_nb_log2 = nb;
   // Few buckets per wave = many waves per shard: the waves of one shard run on one XCD

@@ -36,10 +36,11 @@
 #define DEC_ERR_CONTEXT_MAP 3u
 #define DEC_ERR_DISTANCE 4u
 #define DEC_ERR_DICTIONARY 5u
-#define DEC_ERR_OVERRUN 6u       // output past the piece's capacity or the meta-block length
+#define DEC_ERR_OVERRUN 6u       // a meta-block announces more output than the piece's capacity has room for (a bigger buffer helps)
 #define DEC_ERR_INPUT 7u         // ran past the end of the input
 #define DEC_ERR_ARENA 8u         // more prefix codes than the arena of the piece holds
 #define DEC_ERR_UNSUPPORTED 9u   // large window
+#define DEC_ERR_BLOCK_LENGTH 10u // a command writes past the length its meta-block announced (damaged stream; no buffer helps)
 
 struct DecPiece {
   uint64_t in_off, in_len;     // compressed bytes of the piece in the job input
@@ -631,7 +632,7 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
         else { nb = 24; base = 2118; }
         copy_len = base + (nb ? br_read(b, nb) : 0u);
       }
-      if (pos + insert_len > mb_end) { error = DEC_ERR_OVERRUN; break; }
+      if (pos + insert_len > mb_end) { error = DEC_ERR_BLOCK_LENGTH; break; }
       // literals
       for (uint32_t k = 0; k < insert_len; ++k) {
         if (br_overrun(b, P.in_len)) { error = DEC_ERR_INPUT; break; }
@@ -691,7 +692,7 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
       const uint32_t max_distance = stream_pos < max_backward ? (uint32_t)stream_pos : max_backward;
       if (distance <= max_distance) {
         if (dcode != 0u) { ring[3] = ring[2]; ring[2] = ring[1]; ring[1] = ring[0]; ring[0] = (int32_t)distance; }
-        if (pos + copy_len > mb_end) { error = DEC_ERR_OVERRUN; break; }
+        if (pos + copy_len > mb_end) { error = DEC_ERR_BLOCK_LENGTH; break; }
         if ((P.flags & DEC_FLAG_ISOLATED) && distance > pos) { error = DEC_ERR_DISTANCE; break; }
         wave_sync();
         uint8_t* dst = a.out + stream_pos;
@@ -713,7 +714,7 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
         const uint64_t room = mb_end - pos;
         const uint32_t n = dec_dictionary_word(a, word, copy_len, transform, out + pos,
                                                room > 64u ? 64u : (uint32_t)room);
-        if (n == 0xFFFFFFFFu) { error = DEC_ERR_OVERRUN; break; }
+        if (n == 0xFFFFFFFFu) { error = DEC_ERR_BLOCK_LENGTH; break; }
         pos += n;
       }
       wave_sync();
@@ -723,7 +724,9 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
     if (error) break;
     if (is_last) finished = 1;
   }
-  if (!error && br_bitpos(b) > P.in_len * 8u) error = DEC_ERR_INPUT;
+  // Whatever went wrong after the reader had left the input went wrong on the zeroed slack behind it: that is a
+  // stream cut short (the caller may have more bytes), not a damaged one.
+  if (br_bitpos(b) > P.in_len * 8u) { error = DEC_ERR_INPUT; finished = 0; }
   if (!error && finished) {                      // the last byte is padded with zeros (section 9.1 / 9.3)
     if (b.n < 8u) br_fill(b);
     if (br_align(b) != 0u) error = DEC_ERR_HEADER;

@@ -13,7 +13,9 @@
 
 #define IX_NB_MAX_LOG2 10u                    // first-level buckets by the top key bits: 2^8 .. 2^10 per shard
 #define IX_NB_MAX (1u << IX_NB_MAX_LOG2)      //   (JobParams::ix_nb_log2, chosen so that a bucket holds ~256 positions)
+#ifndef IX_LROWS
 #define IX_LROWS 8u                           // a bucket of <= 64 * IX_LROWS entries is sorted and searched in LDS
+#endif
 #define IX_CAP 40u                            // bytes compared per candidate by ix_bucket
 #define IX_KIND_NONE 0u
 #define IX_KIND_EXACT 1u                      // (len, distance) is the bucket loop's result

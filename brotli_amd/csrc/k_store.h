@@ -203,6 +203,102 @@ DEV void zero_output(uint8_t* out, uint64_t from, uint64_t bytes) {
   wave_mem_barrier();   // zeros are in the L2 before any atomic OR is issued
 }
 
+// ---- the literal context map (EncodeContextMap, brotli_bit_stream.c:574-734), the whole wave on it ----
+// context_map[t * 64 + j] = t * nc + static_map[j] (metablock.c:677-697): row t is the static map shifted
+// by t * nc.  Two rows share no value, so the map is a sequence of value runs none of which crosses a
+// row, and the run heads sit in the same columns of every row (one ballot, taken once).  Under
+// move-to-front (:592-618) a run of length L becomes the list index of its value followed by L - 1 zeros,
+// and the zero coder (:626-673) turns those into run-length codes.  Hence
+//   pass A, per row: only the heads consult the list — 256 entries in four registers x 64 lanes, entry e
+//     in register e / 64 of lane e % 64; "where is the value" is one ballot per register, "shift the
+//     entries before it" is every lane taking its left neighbour's entry;
+//   pass B, per row: every head sizes its symbols (the index unless it is zero, then the codes of its
+//     zero run), a wave scan places them; the symbols overwrite the array they are read from — a row
+//     never yields more symbols than it has elements, and it is in registers before anything is written.
+// cmap_rle[i] = symbol | extra bits << 9 as the header writer expects; histo[] = the symbol counts.
+DEV void store_literal_context_map(uint32_t ntypes, uint32_t nc, const uint8_t* static_map, uint32_t* cmap_rle,
+                                   uint32_t* histo, uint32_t* lds_hist, uint32_t& nrle_out, uint32_t& max_prefix_out) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  uint32_t m[4];
+#pragma unroll
+  for (uint32_t r = 0; r < 4; ++r) m[r] = r * 64u + lane;
+  const uint32_t sm = static_map[lane];
+  const uint32_t sm_left = wave_shfl(sm, (int)((lane - 1u) & 63u));
+  const bool head = lane == 0 || sm != sm_left;
+  const uint64_t heads = wave_ballot(head);
+  const uint64_t above = (heads >> lane) >> 1;
+  const uint32_t run = above ? (uint32_t)dev_ctz64(above) + 1u : 64u - lane;   // (meaningful in head lanes)
+  uint32_t max_reps = 0;
+  for (uint32_t t = 0; t < ntypes; ++t) {
+    uint32_t my_index = 0;
+    for (uint64_t hm = heads; hm != 0; hm &= hm - 1) {
+      const int j = dev_ctz64(hm);
+      const uint32_t value = t * nc + wave_bcast(sm, j);
+      uint32_t index = 0;
+#pragma unroll
+      for (uint32_t r = 0; r < 4; ++r) {
+        const uint64_t at = wave_ballot(m[r] == value);
+        if (at != 0) index = r * 64u + (uint32_t)dev_ctz64(at);
+      }
+      if ((int)lane == j) my_index = index;
+      // entries 1 .. index take their predecessor, the value goes to the front (register 3 first: a
+      // register's lane 0 needs the old lane 63 of the register below it)
+#pragma unroll
+      for (int r = 3; r >= 0; --r) {
+        if ((uint32_t)r * 64u > index) continue;
+        const uint32_t up = wave_shfl(m[r], (int)((lane - 1u) & 63u));
+        const uint32_t carry = r > 0 ? wave_bcast(m[r > 0 ? r - 1 : 0], 63) : value;
+        if ((uint32_t)r * 64u + lane <= index) m[r] = lane == 0 ? carry : up;
+      }
+    }
+    // the very first element can sit at index 0 already (the list starts as the identity): it is a zero itself
+    const uint32_t zeros = head ? run - 1u + ((t == 0 && lane == 0 && my_index == 0) ? 1u : 0u) : 0u;
+    max_reps = umax(max_reps, wave_max_u32(zeros));
+    cmap_rle[t * 64u + lane] = head ? (my_index | (zeros << 16)) : 0xFFFFFFFFu;
+  }
+  const uint32_t max_prefix = max_reps != 0 ? umin(log2floor(max_reps), 6u) : 0u;
+  for (uint32_t i = lane; i < MB_MAX_CMAP_SYMS; i += 64u) lds_hist[i] = 0;
+  wave_sync();
+  uint32_t base = 0;
+  for (uint32_t t = 0; t < ntypes; ++t) {
+    const uint32_t w = cmap_rle[t * 64u + lane];
+    const bool is_head = w != 0xFFFFFFFFu;
+    const uint32_t index = w & 0xFFFFu, zeros = is_head ? w >> 16 : 0u;
+    uint32_t n = (is_head && index != 0) ? 1u : 0u;
+    for (uint32_t reps = zeros; reps != 0;) {
+      ++n;
+      if (reps < (2u << max_prefix)) break;
+      reps -= (2u << max_prefix) - 1u;
+    }
+    const uint32_t incl = wave_incl_scan(n);
+    wave_sync();
+    uint32_t at = base + incl - n;
+    if (is_head && index != 0) {
+      cmap_rle[at++] = index + max_prefix;
+      lds_atomic_add(&lds_hist[index + max_prefix], 1u);
+    }
+    for (uint32_t reps = zeros; reps != 0;) {
+      uint32_t code;
+      if (reps < (2u << max_prefix)) {
+        const uint32_t p = log2floor(reps);
+        code = p + ((reps - (1u << p)) << 9);
+        reps = 0;
+      } else {
+        code = max_prefix + (((1u << max_prefix) - 1u) << 9);
+        reps -= (2u << max_prefix) - 1u;
+      }
+      cmap_rle[at++] = code;
+      lds_atomic_add(&lds_hist[code & 511u], 1u);
+    }
+    base += wave_bcast(incl, 63);
+    wave_sync();
+  }
+  for (uint32_t i = lane; i < MB_MAX_CMAP_SYMS; i += 64u) histo[i] = lds_hist[i];
+  wave_sync();
+  nrle_out = base;
+  max_prefix_out = max_prefix;
+}
+
 DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
                      const DeviceTables* T, const uint8_t* input, uint8_t* ws, uint32_t* lds_store) {
   const int lane = wave_lane();
@@ -289,61 +385,10 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
         sc->cmap_histo[m][0] = 1;
         for (uint32_t i = context_bits; i < alphabet_size; ++i) sc->cmap_histo[m][i] = 1;
       }
-    } else if (lane == 5 && s.nc > 1) {
-      // EncodeContextMap (:574-734): move-to-front + zero run lengths of
-      // context_map[t * 64 + j] = t * nc + static_map[j] (metablock.c:677-697).
-      const uint32_t size = ntypes[0] << 6;
-      const uint32_t num_clusters = nhist[0];
-      uint8_t mtf[256];
-      const uint32_t max_value = (ntypes[0] - 1) * s.nc + (s.nc - 1);  // every context id occurs in the static maps
-      for (uint32_t i = 0; i <= max_value; ++i) mtf[i] = (uint8_t)i;
-      const uint32_t mtf_size = max_value + 1;
-      for (uint32_t i = 0; i < size; ++i) {
-        const uint8_t value = (uint8_t)((i >> 6) * s.nc + static_map[i & 63]);
-        uint32_t index = 0;
-        for (; index < mtf_size; ++index) if (mtf[index] == value) break;
-        cmap_rle[i] = index;
-        for (uint32_t k = index; k != 0; --k) mtf[k] = mtf[k - 1];
-        mtf[0] = value;
-      }
-      uint32_t max_reps = 0;
-      for (uint32_t i = 0; i < size;) {
-        uint32_t reps = 0;
-        for (; i < size && cmap_rle[i] != 0; ++i) {}
-        for (; i < size && cmap_rle[i] == 0; ++i) ++reps;
-        if (reps > max_reps) max_reps = reps;
-      }
-      uint32_t max_prefix = max_reps > 0 ? log2floor(max_reps) : 0;
-      if (max_prefix > 6) max_prefix = 6;
-      uint32_t num_rle = 0;
-      for (uint32_t i = 0; i < size;) {
-        if (cmap_rle[i] != 0) {
-          cmap_rle[num_rle++] = cmap_rle[i] + max_prefix;
-          ++i;
-        } else {
-          uint32_t reps = 1;
-          for (uint32_t k = i + 1; k < size && cmap_rle[k] == 0; ++k) ++reps;
-          i += reps;
-          while (reps != 0) {
-            if (reps < (2u << max_prefix)) {
-              const uint32_t p = log2floor(reps);
-              cmap_rle[num_rle++] = p + ((reps - (1u << p)) << 9);
-              break;
-            } else {
-              cmap_rle[num_rle++] = max_prefix + (((1u << max_prefix) - 1u) << 9);
-              reps -= (2u << max_prefix) - 1u;
-            }
-          }
-        }
-      }
-      for (uint32_t i = 0; i < MB_MAX_CMAP_SYMS; ++i) sc->cmap_histo[0][i] = 0;
-      for (uint32_t i = 0; i < num_rle; ++i) ++sc->cmap_histo[0][cmap_rle[i] & 511u];
-      cmap_nrle = num_rle;
-      cmap_max_prefix = max_prefix;
-      (void)num_clusters;
     }
-    cmap_nrle = wave_bcast(cmap_nrle, 5);
-    cmap_max_prefix = wave_bcast(cmap_max_prefix, 5);
+    wave_sync();
+    if (s.nc > 1) store_literal_context_map(ntypes[0], s.nc, static_map, cmap_rle, sc->cmap_histo[0], lds_store,
+                                            cmap_nrle, cmap_max_prefix);
     wave_sync();
 
     SP_ADD(S, 1, spt);

@@ -164,3 +164,38 @@ def test_python_mirror_decompress_over_the_simulator(sim, ref, monkeypatch):
     assert got == data and d.is_finished() and d.process(b"") == b""
     with pytest.raises(b.error):
         d.process(b"x")
+    # a first chunk may end anywhere — inside a meta-block header, inside a prefix code: until the stream is
+    # complete the reference says "needs more input", whatever the decoder made of the zeroed slack behind the cut
+    for quality in (5, 9, 11):
+        comp = ref.compress(data, quality, 22)
+        for cut in list(range(1, 200, 7)) + [len(comp) // 2, len(comp) - 1]:
+            out, res = sim.decode(comp[:cut], len(data))
+            assert res[0][2] == 7 and res[0][3] == 0, (quality, cut, res[0])
+            d = b.Decompressor()
+            assert d.process(comp[:cut]) == b"" and not d.is_finished()
+            assert d.process(comp[cut:]) == data and d.is_finished()
+    comp = ref.compress(data[:3000], 5, 22)
+    d, got = b.Decompressor(), b""
+    for i in range(len(comp)):                      # byte by byte
+        got += d.process(comp[i:i + 1])
+    assert got == data[:3000] and d.is_finished()
+
+
+def test_damage_never_asks_for_a_bigger_buffer(sim, ref):
+    """Error 6 = a meta-block announces more output than the buffer has room for (the Python mirror grows the
+    buffer on it); a command that writes past the length its meta-block announced is damage (error 10) and
+    must not send a caller on a walk up to 2 GiB buffers."""
+    data = INPUTS["alice"][:20000]
+    comp = ref.compress(data, 5, 22)
+    rng = random.Random(11)
+    room = 1 << 20
+    for _ in range(150):
+        bad = bytearray(comp)
+        p = rng.randrange(len(bad))
+        bad[p] ^= 1 << rng.randrange(8)
+        out, res = sim.decode(bytes(bad), room)
+        n, bits, err, fin = res[0]
+        assert err != 6 or n + (1 << 24) > room, (p, res[0])      # (a header can announce at most 16 MiB)
+    # and the real thing still reports 6
+    out, res = sim.decode(comp, 100)
+    assert res[0][2] == 6
