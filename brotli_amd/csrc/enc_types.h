@@ -51,6 +51,8 @@ struct JobParams {
   uint32_t ix_nb_log2;          //   and log2 of the first-level buckets per shard
   uint32_t ix_bpw;              //   buckets one wave of k_ix_bucket works through (a power of two)
   uint32_t flush_symbols;       // qualities 2 - 3: a meta-block is cut once literals + commands reach this (encode.c:1150-1153); 0 = never
+  uint32_t tile_log2;           // JOB_FLAG_TILED: log2 of the bytes of a chain tile (a multiple of the input block), k_chain.h
+  uint32_t tile_warm;           //   bytes before a tile's first block that its speculative parse starts from
 };
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
 #define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal
@@ -65,6 +67,10 @@ struct JobParams {
 #define JOB_FLAG_QUICK 128u    // with JOB_FLAG_DEEP: qualities 2 - 4, the HashLongestMatchQuickly family (k_parse_quick.h);
                                //   block_bits carries BUCKET_SWEEP_BITS
 #define JOB_FLAG_DEEP 16u      // one shard per wave, 32 .. 256 slots per bucket (k_parse_deep.h)
+#define JOB_FLAG_TILED 1024u   // indexed job whose shards are parsed tile by tile, all tiles at once: a tile starts from a
+                               //   speculated state, joins are verified, differences repaired by sweeps (k_chain.h, k_tile.h)
+#define JOB_FLAG_SWEEP 2048u   // (per launch) k_chain replays the tiles' previous commands and parses again only where an
+                               //   event is pending
 
 // Per-shard description written by the host.
 struct ShardDesc {
@@ -83,7 +89,42 @@ struct ShardDesc {
   uint64_t out_off;        // shard output bytes
   uint64_t out_cap;
   uint64_t ix_off;         // JOB_FLAG_INDEXED: the shard's index region (IxLayout, k_index.h)
+  uint64_t cmds2_off;      // JOB_FLAG_TILED: the second command buffer (sweeps write the one the tile's commands are not in)
+  uint32_t tile_base;      // JOB_FLAG_TILED: index of the shard's first tile in the job's tile arrays
+  uint32_t ntiles;
 };
+
+// ---- chain tiles (JOB_FLAG_TILED) -------------------------------------------------------------
+// A tile = TB consecutive input blocks of one shard, parsed by one 16-lane group of k_chain.  Tile t > 0 of a
+// shard does not know the encoder state it starts from: it parses `tile_warm` bytes of the block before it from a
+// neutral state and takes what that parse arrives at the block boundary with (round 0), k_tile_verify compares it
+// with what the tile before it really ended with, and a sweep parses again from the true state where they differ.
+struct TileDesc { uint32_t shard, t; };
+struct TileRec {
+  // state at the tile's first block boundary as the tile's parse assumed it
+  int32_t in_dc[4];
+  uint32_t in_insert;      // literals carried over the boundary (last_insert_len_)
+  uint32_t in_copy_len;    // the last command before the boundary: copy length (0 = none known) ...
+  uint32_t in_code;        //   ... and distance code — what ExtendLastCommand looks at (encode.c:905-971)
+  uint32_t in_ext;         // bytes ExtendLastCommand added to that command at the tile's first block
+  // state the tile's parse ended with
+  int32_t out_dc[4];
+  uint32_t out_insert, out_copy_len, out_code;
+  uint32_t out_ncmds, out_nlits;   // commands / literals of the tile
+  uint32_t out_gate;       // 1: the static-dictionary gate was closed when the tile ended (hash.h:186)
+  uint32_t flags;          // TILE_*
+  uint32_t buf;            // command buffer the tile's commands are in (0: cmds_off, 1: cmds2_off)
+  uint32_t cmd_off;        // index of the tile's first command in the shard's final command array (k_tile_verify)
+  // the in-state the tile's last parse actually ran with (k_tile_verify may have replaced in_* since)
+  int32_t used_dc[4];
+  uint32_t used_insert, used_ext;
+  uint32_t out_lpp;        // last tile: last_processed_pos_ and how the meta-block ended (bit 0 have, 1 is_last, 2 flush, 3 flush without seal)
+  uint32_t out_mb;
+};
+#define TILE_START_EVENT 1u   // the in-state was replaced by k_tile_verify: the next sweep parses from the tile's start
+#define TILE_BAD 2u           // the shard cannot be parsed in tiles (gate open, counter wrap, meta-block cut ...): serial path
+#define TILE_RAN 4u           // the tile's parse has run at least once
+#define TILE_CHANGED 8u       // the last sweep parsed something again in this tile
 
 // Persistent per-shard encoder state (c/enc/state.h:49-110 subset).
 struct ShardState {

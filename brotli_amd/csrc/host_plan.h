@@ -19,6 +19,7 @@
 struct JobPlan {
   JobParams J;
   std::vector<ShardDesc> shards;
+  std::vector<TileDesc> tiles;       // JOB_FLAG_TILED
   uint64_t ws_bytes;
   uint64_t in_bytes;
   uint64_t max_out_bytes;
@@ -164,6 +165,37 @@ static inline uint64_t plan_add_index(JobPlan* plan, bool ix_in_ws) {
     plan->ws_bytes = off;
   }
   return L.bytes;
+}
+
+// Chain tiles (k_chain.h, k_tile.h) for an indexed plan whose shards are longer than a tile: the tile table, the
+// two slot buffers for the tiles' commands (behind the rest of the workspace) and a bigger final command array.
+// tile_kb: KiB per tile (a power of two >= the input block), 0 = no tiles.  Returns the number of tiles.
+static inline uint32_t plan_add_tiles(JobPlan* plan, uint32_t tile_kb, uint32_t warm_bytes) {
+  if (!(plan->J.flags & JOB_FLAG_INDEXED) || tile_kb == 0) return 0;
+  uint32_t tl = 10;
+  while ((1u << (tl - 10u)) < tile_kb) ++tl;
+  if ((int)tl < plan->J.lgblock) tl = (uint32_t)plan->J.lgblock;
+  if (tl > 22u) return 0;
+  uint64_t longest = 0;
+  for (const ShardDesc& D : plan->shards) if (D.len > longest) longest = D.len;
+  if (longest <= (1ull << tl) + 2u) return 0;                     // every shard is one tile: the plain chain
+  plan->J.tile_log2 = tl;
+  plan->J.tile_warm = warm_bytes < 256u ? 256u : warm_bytes > (1u << plan->J.lgblock) / 2u ? (1u << plan->J.lgblock) / 2u : warm_bytes;
+  plan->J.flags |= JOB_FLAG_TILED;
+  const uint32_t slot = tile_slot_cmds(tl, (uint32_t)plan->J.lgblock);
+  uint64_t off = plan->ws_bytes;
+  plan->tiles.clear();
+  for (size_t k = 0; k < plan->shards.size(); ++k) {
+    ShardDesc& D = plan->shards[k];
+    const uint32_t first = D.stream_offset != 0 ? 2u : 0u;
+    D.ntiles = tile_count(D.len, first, tl);
+    D.tile_base = (uint32_t)plan->tiles.size();
+    for (uint32_t t = 0; t < D.ntiles; ++t) { TileDesc d; d.shard = (uint32_t)k; d.t = t; plan->tiles.push_back(d); }
+    D.cmds2_off = off;
+    off = plan_align(off + 2ull * D.ntiles * slot * sizeof(Command));
+  }
+  plan->ws_bytes = off;
+  return (uint32_t)plan->tiles.size();
 }
 
 // Which parse kernel a plan runs on and in which wave layout (api_flags: BROTLI_AMD_FLAG_*

@@ -39,10 +39,36 @@ struct CShard {
   IxGeom geo;
   uint64_t* res;
   const uint32_t* srt;
-  uint8_t* skip;
+  uint8_t* skip;         // bit (x - geo.first): storable position x was NOT stored by the parse
   uint32_t frontier;     // every storable position below it is either stored or marked in `skip`
   uint32_t nslow;
+  // tiled jobs (JOB_FLAG_TILED): this group parses [tile_lo, tile_hi) of the shard; only positions of the tile
+  // are marked / tainted by it (the bitmap's words never straddle tiles: tiles are multiples of 32 positions
+  // counted from geo.first)
+  uint32_t tile_lo, tile_hi;
+  uint32_t mode;         // C_*
 };
+#define C_VIEW_ALL 1u     // sweeps: the bitmap holds for every position (round 0: positions below the tile count as stored)
+#define C_TILED 2u        // a settled range gets all its bits written, set and cleared (a sweep may settle a range again)
+#define C_BAD 4u          // the tiled parse met something it does not handle (counter wrap): the shard goes the serial way
+
+DEV bool c_skipped(const CShard& C, uint32_t q) {
+  const uint32_t b = q - C.geo.first;
+  return ((C.skip[b >> 3] >> (b & 7u)) & 1u) != 0;
+}
+// Bits [bi, bi + nb) of the bitmap (nb <= 16): `set` are the marked ones, the others are cleared when `all` (aligned
+// dwords only: a tile's bits are whole dwords, so neighbours never write the same word).
+DEV void c_bitmap_settle(uint8_t* skip, uint32_t bi, uint32_t nb, uint32_t set, bool all) {
+  uint32_t* w = (uint32_t*)skip + (bi >> 5);
+  const uint32_t sh = bi & 31u;
+  const uint64_t rm = all ? (((1ull << nb) - 1ull) << sh) : 0ull, sm = (uint64_t)set << sh;
+  const uint32_t o0 = w[0], n0 = (o0 & ~(uint32_t)rm) | (uint32_t)sm;
+  if (n0 != o0) w[0] = n0;
+  if (sh + nb > 32u) {
+    const uint32_t o1 = w[1], n1 = (o1 & ~(uint32_t)(rm >> 32)) | (uint32_t)(sm >> 32);
+    if (n1 != o1) w[1] = n1;
+  }
+}
 
 DEV uint32_t c_res_hi(const CShard& C, uint32_t x) { return ((const uint32_t*)(C.res + x))[1]; }
 
@@ -55,7 +81,7 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
                       uint32_t sfirst, uint32_t stride) {
   const int t = q_t();
   (void)J;
-  uint32_t cur = a;
+  uint32_t cur = umax(a, umax(C.geo.first, C.tile_lo));        // (what lies below the tile is not this group's to settle)
   while (wave_any(act && cur < b)) {
     const bool on = act && cur < b;
     const uint32_t x = cur + (uint32_t)t;
@@ -67,20 +93,32 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
     for (uint32_t j = 1; j <= nmax; ++j) {
       if (j <= ns) {
         const uint32_t p = C.srt[s + j] & 0xFFFFFFu;
-        uint32_t* w = (uint32_t*)(C.res + p) + 1;
-        *w = *w | IX_TAINT;      // (lanes that hit the same word write the same bit)
+        if (p < C.tile_hi) {     // (a tiled job: successors in later tiles are told by k_tile_events)
+          uint32_t* w = (uint32_t*)(C.res + p) + 1;
+          *w = *w | IX_TAINT;      // (lanes that hit the same word write the same bit)
+        }
       }
     }
     const uint32_t m16 = q_mask16(wave_ballot(sk));
 #if defined(BROTLI_AMD_SIMT_SIM)
     if (on && t == 0 && m16 != 0) { g_sim_counts[13] += (unsigned)__builtin_popcount(m16); if (getenv("SIM_SKIPS")) fprintf(stderr, "skip [%u..] mask %x (range %u..%u stride %u)\n", cur, m16, a, b, stride); }
 #endif
-    if (on && t == 0 && m16 != 0) {
-      uint8_t* p = C.skip + (cur >> 3);
-      st32(p, ld32(p) | (m16 << (cur & 7u)));
-    }
+    if (on && t == 0 && (m16 != 0 || (C.mode & C_TILED) != 0))
+      c_bitmap_settle(C.skip, cur - C.geo.first, umin(16u, b - cur), m16, (C.mode & C_TILED) != 0);
     wave_sync();
     if (on) cur += 16u;
+  }
+}
+
+// Sweeps: [a, b) was stored by the parse — whatever an earlier parse of the tile had marked there is taken back.
+DEV void c_clear_range(CShard& C, bool act, uint32_t a, uint32_t b) {
+  const int t = q_t();
+  if (!(C.mode & C_VIEW_ALL)) return;
+  uint32_t cur = umax(a, umax(C.geo.first, C.tile_lo));
+  while (wave_any(act && cur < b)) {
+    if (act && cur < b && t == 0) c_bitmap_settle(C.skip, cur - C.geo.first, umin(16u, b - cur), 0u, true);
+    wave_sync();
+    if (act && cur < b) cur += 16u;
   }
 }
 
@@ -88,6 +126,7 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
 // storable between the frontier and a was passed over.
 DEV void c_stored(const JobParams& J, CShard& C, bool act, uint32_t a, uint32_t b) {
   if (wave_any(act && C.frontier < a)) c_mark_range(J, C, act && C.frontier < a, C.frontier, a, 0, 1);
+  if ((C.mode & C_VIEW_ALL) != 0 && wave_any(act && a < b)) c_clear_range(C, act && a < b, umax(a, C.frontier), b);
   if (act) C.frontier = b;
 }
 
@@ -142,7 +181,8 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
     bool inrun = false, stored = false;
     if (ok) {
       inrun = hash_pos(ld64(g.data + q), J.hasher_type, J.bucket_bits).key == kt.key;
-      stored = inrun && !((C.skip[q >> 3] >> (q & 7u)) & 1u);
+      // (round 0 of a tiled job: what other tiles skipped is not known yet — taken as stored, k_tile_events tells)
+      stored = inrun && !(((C.mode & C_VIEW_ALL) != 0 || q >= C.tile_lo) && c_skipped(C, q));
     }
     const uint32_t nr16 = q_mask16(wave_ballot(on && !inrun));
     const uint32_t te = nr16 ? (uint32_t)dev_ctz32(nr16) : 16u;
@@ -161,6 +201,7 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   }
   wave_sync();
   if (want && danger && t == 0) { scratch[16] = kt.key; scratch[17] = (uint32_t)sidx; scratch[18] = total; }
+  if (want && danger && (C.mode & C_TILED) != 0) C.mode |= C_BAD;      // (the carried store count is a serial matter)
   // slots the 16-bit counter leaves visible (:250-257): all 16 once it has seen 16 stores,
   // and — only reachable after a wrap — count mod 65536 when that is below 16
   uint32_t nvalid = umin(found, 16u);
@@ -524,7 +565,8 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
         }
         if (t == 0) {
           Command c;
-          c.insert_len = ins; c.copy_len = sr_len; c.dist_extra = code; c.cmd_prefix = CMD_RAW; c.dist_prefix = 0;
+          c.insert_len = ins; c.copy_len = sr_len; c.dist_extra = code; c.cmd_prefix = CMD_RAW;
+          c.dist_prefix = (uint16_t)(tt == 4u ? CMDF_NOPROBE : 0u);
           g.cmds[g.r.ncmds] = c;
         }
         ++g.r.ncmds;
@@ -541,16 +583,110 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
   g.status &= 0x7FFFFFFFu;
 }
 
+// ---- tiled jobs: replay of a tile's previous commands (sweeps) ---------------------------------------
+// A sweep (JOB_FLAG_SWEEP) walks the commands the tile's last parse produced and takes each one over as long as
+// nothing it was decided from has changed: the group is at the command's boundary with the same distance cache,
+// no event (k_tile.h: a position whose bucket ring differs from what the last parse saw) is pending in the
+// positions the command's decision searched — its insert run, the copy's start and the lazy probe behind it — and
+// neither the literal spree nor the static dictionary had a say.  Where that does not hold the generic step of
+// chain_round parses for real (every search exact, with the bitmap as it stands) until its state meets the old
+// command list again.
+struct CReplay {
+  const Command* old;    // the tile's previous commands
+  uint32_t oi, on;       // next old command / one past the last copy command
+  uint32_t obnd;         // position where old command oi's insert run begins
+  int32_t odc[4];        // distance cache of the old parse there
+  const uint8_t* ev;     // event bitmap, bit (x - first)
+  uint32_t changed;      // generic commits of this sweep
+};
+// Distance an old command's code stands for (ComputeDistanceCode backwards, backward_references.c:87-109).
+DEV uint32_t c_code_distance(uint32_t code, int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
+  if (code >= 16u) return code - 15u;
+  if (code < 4u) return c_dc_pick((uint32_t)d0, (uint32_t)d1, (uint32_t)d2, (uint32_t)d3, code);
+  const uint32_t k = code - 4u, kk = k < 6u ? k : k - 6u;
+  const uint32_t base = (uint32_t)(k < 6u ? d0 : d1), mag = (kk >> 1) + 1u;
+  return (kk & 1u) ? base + mag : base - mag;
+}
+DEV bool c_ev_any(const uint8_t* ev, uint32_t first, uint32_t a, uint32_t b) {   // an event bit in positions [a, b]?
+  const uint32_t* w = (const uint32_t*)ev;
+  const uint32_t ba = a - first, bb = b - first;
+  for (uint32_t i = ba >> 5; i <= (bb >> 5); ++i) {
+    uint32_t m = 0xFFFFFFFFu;
+    if (i == (ba >> 5)) m &= 0xFFFFFFFFu << (ba & 31u);
+    if (i == (bb >> 5)) m &= 0xFFFFFFFFu >> (31u - (bb & 31u));
+    if (w[i] & m) return true;
+  }
+  return false;
+}
+DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, uint32_t htl) {
+  QShard& g = C.g;
+  const int t = q_t();
+  const uint32_t limit = J.max_backward_limit;
+  for (;;) {
+    bool can = alive && g.state == Q_SEARCH && g.st_count == 0;
+    const uint32_t nb = g.position - g.insert_length;
+    // the old parse's state at (or past) this boundary
+    while (can && R.oi < R.on && R.obnd < nb) {
+      const Command c = R.old[R.oi];
+      const uint32_t code = c.dist_extra, pc = R.obnd + c.insert_len;
+      const uint32_t dist = c_code_distance(code, R.odc[0], R.odc[1], R.odc[2], R.odc[3]);
+      if (dist <= umin(pc + g.stream_offset, limit) && code > 0u) { R.odc[3] = R.odc[2]; R.odc[2] = R.odc[1]; R.odc[1] = R.odc[0]; R.odc[0] = (int32_t)dist; }
+      R.obnd = pc + (c.copy_len & 0x1FFFFFFu);
+      ++R.oi;
+    }
+    can = can && R.oi < R.on && R.obnd == nb && R.odc[0] == g.dc[0] && R.odc[1] == g.dc[1] && R.odc[2] == g.dc[2] && R.odc[3] == g.dc[3];
+    Command c;
+    c.insert_len = c.copy_len = c.dist_extra = 0; c.cmd_prefix = c.dist_prefix = 0;
+    if (can) c = R.old[R.oi];
+    const uint32_t pc = R.obnd + c.insert_len, L = c.copy_len & 0x1FFFFFFu, code = c.dist_extra;
+    const uint32_t dist = c_code_distance(code, g.dc[0], g.dc[1], g.dc[2], g.dc[3]);
+    const uint32_t dictionary_start = umin(pc + g.stream_offset, limit);
+    bool ok = can && pc >= g.position && pc + htl < g.pos_end && pc <= g.apply_random_heuristics &&
+              (c.dist_prefix & CMDF_SPREE) == 0 && (c.copy_len >> 25) == 0u && dist <= dictionary_start && L >= 2u;
+    if (ok) ok = !c_ev_any(R.ev, C.geo.first, g.position, umin(pc + 1u, g.pos_end - 1u));
+    if (!wave_any(ok)) break;
+    if (ok) {
+      // the positions passed over by the old parse before this command are marked already; the searched ones stored
+      const uint32_t L0 = umin(L, g.pos_end - pc);              // (ExtendLastCommand adds the rest again at the next block)
+      if (dist <= dictionary_start && code > 0u) {
+        g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)dist;
+        R.odc[3] = R.odc[2]; R.odc[2] = R.odc[1]; R.odc[1] = R.odc[0]; R.odc[0] = (int32_t)dist;
+      }
+      if (t == 0) {
+        Command n;
+        n.insert_len = c.insert_len; n.copy_len = L0; n.dist_extra = code; n.cmd_prefix = CMD_RAW; n.dist_prefix = c.dist_prefix;
+        g.cmds[g.r.ncmds] = n;
+      }
+      ++g.r.ncmds;
+      g.r.nlits += c.insert_len;
+      g.insert_length = 0;
+      g.apply_random_heuristics = pc + 2u * L0 + J.spree_window;
+      g.position = pc + L0;
+      C.frontier = umax(C.frontier, g.position);
+      R.obnd = pc + L;
+      ++R.oi;
+    }
+    if (wave_any(alive && g.state != Q_DONE && !ok)) break;      // somebody needs the generic step
+  }
+}
+
 // ---- the kernel body ---------------------------------------------------------------------
-// Up to four shards per wave (q_groups_per_wave): group gi of wave w serves shard w * gpw + gi.
+// Up to four units per wave (q_groups_per_wave): group gi of wave w serves unit w * gpw + gi — a shard, or, in a
+// tiled job, a tile of a shard (`tiles`).
+DEV Command* c_tile_slot(uint8_t* ws, const ShardDesc& D, const JobParams& J, uint32_t buf, uint32_t tt) {
+  return (Command*)(ws + D.cmds2_off) + ((uint64_t)buf * D.ntiles + tt) * tile_slot_cmds(J.tile_log2, (uint32_t)J.lgblock);
+}
 DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* states,
                      uint32_t nshards, const DeviceTables* T, const uint8_t* input, uint8_t* ws,
-                     uint32_t wave_index, uint32_t* lds) {
+                     uint32_t wave_index, uint32_t* lds, const TileDesc* tiles, TileRec* trecs, uint32_t ntiles) {
   const int t = q_t();
   const uint32_t gpw = q_groups_per_wave(J);
   const uint32_t gi = (uint32_t)(wave_lane() >> 4);
-  const uint32_t shard = wave_index * gpw + gi;
-  const bool alive = gi < gpw && shard < nshards;
+  const bool tiled = (J.flags & JOB_FLAG_TILED) != 0, sweep = tiled && (J.flags & JOB_FLAG_SWEEP) != 0;
+  const uint32_t unit = wave_index * gpw + gi;
+  bool alive = gi < gpw && unit < (tiled ? ntiles : nshards);
+  uint32_t shard = unit, tt = 0;
+  if (tiled) { shard = tiles[alive ? unit : 0u].shard; tt = tiles[alive ? unit : 0u].t; }
   const bool writer = alive && t == 0;
   constexpr int NPOS = 4;
   const uint32_t htl = hasher_htl(J.hasher_type);
@@ -559,6 +695,11 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   uint32_t* scratch = lds + gi * C_GROUP_LDS_WORDS;
   if (t == 0) scratch[16] = 0xFFFFFFFFu;               // no carried store count yet (c_search_exact)
   const int kpos = t >> 2, idc = t & 3;   // this lane's probe: position P0 + kpos, cache entry idc
+  // a shard of one tile is parsed the plain way even in a tiled job
+  const bool tile_mode = tiled && D.ntiles > 1u;
+  const bool last_tile = !tile_mode || tt + 1u == D.ntiles;
+  TileRec* TR = trecs + (tile_mode && alive ? unit : 0u);
+  if (tiled && !tile_mode && sweep) alive = false;     // (nothing to sweep)
 
   CShard C;
   QShard& g = C.g;
@@ -570,6 +711,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   g.wsb = ws;
   g.shard = alive ? shard : 0u;
   g.stream_offset = D.stream_offset;
+  g.raw_cmds = 1;
   regs_load(g.r, S0);
   for (int i = 0; i < 4; ++i) g.dc[i] = S0->dist_cache[i];
   g.dict_lookups = S0->dict_lookups;
@@ -587,7 +729,6 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   g.pf_val = g.pf_acc = 0;
   for (int i = 0; i < 12; ++i) g.prof[i] = 0;
   g.state = (alive && !S0->done && !S0->mb_valid && !S0->error) ? Q_PRE : Q_DONE;
-  const bool participated = g.state != Q_DONE;
   C.geo = ix_geom(J, D);
   IxLayout L;
   ix_layout(D.len, J.ix_slices, J.ix_nb_log2, &L);
@@ -597,17 +738,113 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   C.skip = ixb + L.skip;
   C.frontier = S0->ix_frontier;
   C.nslow = 0;
-  const bool force_slow = (J.flags & JOB_FLAG_FORCE_SLOW) != 0;
+  C.tile_lo = 0;
+  C.tile_hi = D.len;
+  C.mode = tiled ? C_TILED : 0u;
+  bool force_slow = (J.flags & JOB_FLAG_FORCE_SLOW) != 0;
+
+  // ---- a tile of a tiled job: where it starts from (wave operations stay outside the per-group branches) ----
+  uint32_t warm = 0;                                   // 1: the group is in the warm-up of a speculative start
+  CReplay R;
+  R.old = g.cmds; R.oi = R.on = 0; R.obnd = 0; R.changed = 0;
+  R.odc[0] = R.odc[1] = R.odc[2] = R.odc[3] = 0;
+  R.ev = ixb + L.ev;
+  {
+    if (tile_mode) {
+      C.tile_lo = tile_lo(C.geo.first, tt, J.tile_log2);
+      C.tile_hi = tile_hi(D.len, C.geo.first, tt, J.tile_log2);
+    }
+    const uint32_t ev_w0 = (C.tile_lo - umin(C.tile_lo, C.geo.first)) >> 5, ev_w1 = (C.tile_hi - C.geo.first + 31u) >> 5;
+    bool run = alive && tile_mode && !S0->error;
+    uint32_t any = 0;
+    if (sweep && run) {
+      // only tiles with something pending run: a replaced in-state or an event among their positions
+      if (TR->flags & TILE_START_EVENT) any = 1;
+      const uint32_t* evw = (const uint32_t*)R.ev;
+      for (uint32_t i = ev_w0 + (uint32_t)t; i < ev_w1; i += 16u) any |= evw[i];
+    }
+    any = q_or(any);
+    if (sweep) run = run && any != 0 && (TR->flags & TILE_BAD) == 0;
+    int32_t used_dc[4] = {0, 0, 0, 0};
+    uint32_t used_insert = 0, used_ext = 0;
+    if (tile_mode) {
+      g.lim_len = C.tile_hi;
+      g.lim_op = last_tile ? D.final_op : 0u;
+      g.lim_cmd_cap = tile_slot_cmds(J.tile_log2, (uint32_t)J.lgblock);
+      const uint32_t oldbuf = sweep ? TR->buf : 1u;
+      g.cmds = c_tile_slot(ws, D, J, oldbuf ^ 1u, tt);
+      if (sweep) {
+        C.mode |= C_VIEW_ALL;
+        force_slow = true;
+        R.old = c_tile_slot(ws, D, J, oldbuf, tt);
+        R.oi = tt == 0 ? 0u : 1u;
+        R.on = R.oi + (run ? TR->out_ncmds : 0u);
+        if (run && R.on > R.oi && R.old[R.on - 1u].cmd_prefix != CMD_RAW) --R.on;     // (the trailing insert-only command)
+        for (int i = 0; i < 4; ++i) used_dc[i] = TR->used_dc[i];
+        used_insert = TR->used_insert; used_ext = TR->used_ext;
+      }
+      alive = run;
+      // every tile's parse begins from a state of its own making: nothing is taken from ShardState
+      ShardState init;
+      init_shard_state(J, D, &init);
+      regs_load(g.r, &init);
+      for (int i = 0; i < 4; ++i) g.dc[i] = init.dist_cache[i];
+      g.dict_lookups = g.dict_matches = 0;
+      C.frontier = 0;
+      g.state = run ? Q_PRE : Q_DONE;
+      if (tt == 0) {
+        R.obnd = C.geo.first;
+        for (int i = 0; i < 4; ++i) R.odc[i] = init.dist_cache[i];
+      } else {
+        const uint32_t B = C.tile_lo;
+        g.r.flint = -2;
+        g.r.last_flush_pos = C.geo.first;
+        g.r.last_bytes = g.r.last_bytes_bits = 0;
+        g.dict_lookups = 256u;                         // the gate is taken as closed (hash.h:186); k_tile_verify checks
+        if (!sweep) {
+          // round 0: the state at B is what a parse of the `tile_warm` bytes before it arrives with
+          const uint32_t S = B - umin(J.tile_warm, 1u << (J.lgblock - 1));
+          g.dc[0] = 4; g.dc[1] = 11; g.dc[2] = 15; g.dc[3] = 16;
+          g.r.input_pos = B;
+          g.r.last_processed_pos = S;
+          g.blk_flags = 0; g.blk_bytes = B - S; g.blk_pos = S; g.pos_end = B;
+          C.frontier = S;
+          if (run) { g.state = Q_SETUP; warm = 1; }
+        } else {
+          // sweeps: the state k_tile_verify put into the record (the true one as far as it is known)
+          for (int i = 0; i < 4; ++i) { R.odc[i] = used_dc[i]; g.dc[i] = TR->in_dc[i]; }
+          R.obnd = B + used_ext - used_insert;
+          g.r.last_insert_len = TR->in_insert;
+          g.r.input_pos = g.r.last_processed_pos = B;
+          g.r.ncmds = 1;
+          C.frontier = B;
+        }
+      }
+    }
+    wave_sync();
+    if (tile_mode && sweep && tt != 0u && alive && t == 0) {
+      Command gh;
+      gh.insert_len = 0; gh.copy_len = TR->in_copy_len; gh.dist_extra = TR->in_code; gh.cmd_prefix = CMD_RAW; gh.dist_prefix = 0;
+      g.cmds[0] = gh;
+      for (int i = 0; i < 4; ++i) TR->used_dc[i] = TR->in_dc[i];
+      TR->used_insert = TR->in_insert;
+    }
+    wave_sync();
+  }
+  const bool participated = g.state != Q_DONE;
 
   uint32_t nsteps = 0;
   while (wave_any(g.state != Q_DONE)) {
     SIM_COUNT(7, 1);                                   // chain steps (wave level)
     uint64_t qt = QP_NOW();
+    if (sweep) c_group_replay(J, C, R, alive, htl);
+    else {
 #if defined(BROTLI_AMD_SIMT_SIM)
-    if (!getenv("SIM_NOFAST")) c_group_fast(J, T, C, alive, scratch, nsteps);   // (test knob: generic steps only)
+      if (!getenv("SIM_NOFAST")) c_group_fast(J, T, C, alive, scratch, nsteps);   // (test knob: generic steps only)
 #else
-    c_group_fast(J, T, C, alive, scratch, nsteps);
+      c_group_fast(J, T, C, alive, scratch, nsteps);
 #endif
+    }
     if (g.state == Q_PRE) q_driver_pre(J, g);
     if (wave_any(g.state == Q_SETUP)) {
       const bool su = g.state == Q_SETUP;
@@ -615,7 +852,13 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       // previous block
       if (wave_any(su && (g.blk_flags & QBLK_STITCH)))
         c_stored(J, C, su && (g.blk_flags & QBLK_STITCH), g.blk_pos - 3u, g.blk_pos);
+      const bool first_blk = tile_mode && tt != 0u && su && g.blk_pos == C.tile_lo && (g.blk_flags & QBLK_EXTEND) != 0;
+      const uint32_t ghost_len = first_blk ? (g.cmds[0].copy_len & 0x1FFFFFFu) : 0u;
+      wave_sync();
       q_setup_extend(J, g, su);
+      // a tile's first block: what ExtendLastCommand added to the last command of the tile before it
+      const uint32_t ext_len = first_blk ? (g.cmds[0].copy_len & 0x1FFFFFFu) - ghost_len : 0u;
+      if (tile_mode && tt != 0u && su && g.blk_pos == C.tile_lo && writer) { TR->in_ext = ext_len; TR->used_ext = ext_len; }
     }
     // block finished? (loop guard of CreateBackwardReferences, :44 and :239-241)
     if (g.state == Q_SEARCH && !(g.position + htl < g.pos_end)) {
@@ -626,8 +869,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
     const bool want = g.state == Q_SEARCH || g.state == Q_LAZY;
     if (wave_any(want)) {
       const uint32_t P0 = g.position + (g.state == Q_LAZY ? 1u : 0u);
-      // positions passed over since the last store are known now; the Bloom filter must hold
-      // them before this step's searches consult it
+      // positions passed over since the last store are known now
       if (wave_any(want && C.frontier < P0)) c_mark_range(J, C, want && C.frontier < P0, C.frontier, P0, 0, 1);
       if (want) C.frontier = umax(C.frontier, P0);
       wave_sync();
@@ -668,7 +910,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
             if (sk >= g.sr_score + 175u) {
               ++g.position; ++g.insert_length;
               g.sr_score = sk; sr_from = (uint32_t)k; g.sr_delta = 0;
-              if (!(++g.delayed < 4u && g.position + htl < g.pos_end)) { commit = true; stop = true; }
+              if (!(++g.delayed < 4u && g.position + htl < g.pos_end)) { commit = true; stop = true; g.cmd_flags |= CMDF_NOPROBE; }
             } else { commit = true; stop = true; }
           }
         }
@@ -704,6 +946,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
           const QResult sx = c_search_exact(J, C, exact, P0, scratch);
           if (exact) { cur = sx; ++C.nslow; }
         }
+        if (sweep && wave_any(take)) c_clear_range(C, take, P0, P0 + 1u);
         if (take) C.frontier = P0 + 1u;          // FindLongestMatch stores the position it searched
         // static dictionary when nothing was found (hash.h:179-202)
         q_dict_search(J, T, g, take && cur.score == K_MIN_SCORE, P0, g.pos_end - P0, cur);
@@ -711,6 +954,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
         committed = q_transition(J, g, take, cur, htl) || committed;
       }
       QP_ADD(g, 5, qt);
+      if (committed) ++R.changed;
       // what the step stored: the copied range (StoreRange) or the literal spree
       if (wave_any(want && g.st_count != 0)) {
         const bool st = want && g.st_count != 0;
@@ -724,15 +968,88 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
         }
         if (st) g.st_count = 0;
       }
-      (void)committed;
       QP_ADD(g, 6, qt);
+    }
+    {
+      // ---- a warm-up that has reached the tile's first block boundary: this is the state the tile starts from ----
+      const bool wpost = g.state == Q_POST && warm != 0;
+      if (wave_any(wpost)) {
+        Command gh;
+        gh.insert_len = 0; gh.copy_len = 0; gh.dist_extra = 0; gh.cmd_prefix = CMD_RAW; gh.dist_prefix = 0;
+        if (wpost && g.r.ncmds != 0) gh = g.cmds[g.r.ncmds - 1u];
+        wave_sync();
+        if (wpost && writer) {
+          gh.copy_len &= 0x1FFFFFFu;
+          g.cmds[0] = gh;
+          for (int i = 0; i < 4; ++i) { TR->in_dc[i] = g.dc[i]; TR->used_dc[i] = g.dc[i]; }
+          TR->in_insert = TR->used_insert = g.r.last_insert_len;
+          TR->in_copy_len = gh.copy_len;
+          TR->in_code = gh.dist_extra;
+          TR->in_ext = TR->used_ext = 0;
+        }
+        wave_sync();
+        if (wpost) {
+          g.r.ncmds = 1;
+          g.r.nlits = 0;
+          g.r.input_pos = g.r.last_processed_pos = C.tile_lo;
+          g.cmd_flags = 0;
+          C.frontier = C.tile_lo;
+          warm = 0;
+          g.state = Q_PRE;
+        }
+      }
     }
     if (g.state == Q_POST) q_driver_post(J, g, writer);
     QP_ADD(g, 7, qt);
   }
 
   wave_sync();
-  if (writer && participated) {
+  {
+    // ---- a tile's result: the state it ended with (k_tile.h takes it from here) ----
+    const bool tp = tile_mode && participated;
+    // the storable positions behind the last store stay unstored — but for the last three, which the next
+    // tile's first block stitches in (..64_simd_inc.h:139-151; ix_storable knows when it does)
+    const bool m = tp && !last_tile && !(g.status & QST_ERROR) && C.frontier + 3u < C.tile_hi;
+    if (wave_any(m)) c_mark_range(J, C, m, C.frontier, C.tile_hi - 3u, 0, 1);
+    const uint32_t base = tt == 0 ? 0u : 1u;
+    Command lastc;
+    lastc.insert_len = lastc.copy_len = lastc.dist_extra = 0; lastc.cmd_prefix = lastc.dist_prefix = 0;
+    if (tp && g.r.ncmds > base) lastc = g.cmds[g.r.ncmds - 1u];
+    wave_sync();
+    if (tp && t == 0) {
+      for (int i = 0; i < 4; ++i) TR->out_dc[i] = g.dc[i];
+      TR->out_insert = g.r.last_insert_len;
+      TR->out_copy_len = lastc.cmd_prefix == CMD_RAW ? (lastc.copy_len & 0x1FFFFFFu) : 0u;
+      TR->out_code = lastc.dist_extra;
+      TR->out_ncmds = g.r.ncmds - base;
+      TR->out_nlits = g.r.nlits;
+      TR->out_gate = (g.dict_matches < (g.dict_lookups >> 7)) ? 1u : 0u;
+      TR->out_lpp = g.r.last_processed_pos;
+      TR->out_mb = ((g.status & QST_HAVE_MB) ? 1u : 0u) | ((g.blk_flags & QBLK_LAST) ? 2u : 0u) |
+                   ((g.blk_flags & QBLK_FLUSH) ? ((g.blk_flags & QBLK_NOSEAL) ? 8u : 4u) : 0u);
+      TR->buf = sweep ? (TR->buf ^ 1u) : 0u;
+      uint32_t fl = (TR->flags | TILE_RAN) & ~(TILE_START_EVENT | TILE_CHANGED);
+      if ((C.mode & C_BAD) != 0 || (g.status & QST_ERROR) != 0 || (last_tile && !(g.status & QST_HAVE_MB))) fl |= TILE_BAD;
+      if (R.changed != 0) fl |= TILE_CHANGED;
+      TR->flags = fl;
+      if (tt == 0) {
+        // what the shard's first blocks left behind (the flint bytes' meta-block, the stream header bits)
+        ShardState* S = &states[shard];
+        regs_save(g.r, S);
+        S->dict_lookups = g.dict_lookups;
+        S->dict_matches = g.dict_matches;
+        S->done = 0; S->mb_valid = 0;
+      }
+    }
+    if (tp && sweep) {
+      // the events of the tile are dealt with
+      uint32_t* evw = (uint32_t*)(ixb + L.ev);
+      const uint32_t w0 = (C.tile_lo - umin(C.tile_lo, C.geo.first)) >> 5, w1 = (C.tile_hi - C.geo.first + 31u) >> 5;
+      for (uint32_t i = w0 + (uint32_t)t; i < w1; i += 16u) evw[i] = 0;
+    }
+    wave_sync();
+  }
+  if (!tile_mode && writer && participated) {
     ShardState* S = &states[shard];
     regs_save(g.r, S);
     for (int i = 0; i < 4; ++i) S->dist_cache[i] = g.dc[i];

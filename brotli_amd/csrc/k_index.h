@@ -130,6 +130,11 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
   uint32_t* skip = (uint32_t*)(base + L.skip);
   const uint32_t w_lo = lo / 32u, w_hi = (umin(lo + per, g.n + 128u) + 31u) / 32u;
   for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) skip[i] = 0;
+  if (J.flags & JOB_FLAG_TILED) {
+    uint32_t* prev = (uint32_t*)(base + L.skip_prev);
+    uint32_t* ev = (uint32_t*)(base + L.ev);
+    for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) { prev[i] = 0; ev[i] = 0; }
+  }
   wave_sync();
 }
 

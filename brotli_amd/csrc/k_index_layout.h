@@ -33,12 +33,14 @@
 struct IxEntry { uint32_t w0, w1; uint64_t d, d2; };
 
 // Index region of one shard, offsets relative to ShardDesc::ix_off.
-struct IxLayout { uint64_t cnt, skip, srt, res, ent, ent2, bytes; };
+struct IxLayout { uint64_t cnt, skip, skip_prev, ev, srt, res, ent, ent2, bytes; };
 static inline IX_HD uint64_t ix_align(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
 static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, uint32_t nb_log2, IxLayout* L) {
   uint64_t off = 0;
   L->cnt = off;   off = ix_align(off + 4ull * (((uint64_t)slices << nb_log2) + 2));
   L->skip = off;  off = ix_align(off + n / 8 + 32);
+  L->skip_prev = off;  off = ix_align(off + n / 8 + 32);    // JOB_FLAG_TILED: `skip` as the last k_tile_events pass saw it
+  L->ev = off;    off = ix_align(off + n / 8 + 32);         // JOB_FLAG_TILED: positions whose search has to be done again
   L->srt = off;   off = ix_align(off + 4 * n + 16);
   L->res = off;   off = ix_align(off + 8 * n + 16);
   L->ent = off;   off = ix_align(off + 4 * n + 16);
@@ -46,5 +48,21 @@ static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, uint32_t nb_log2
   L->bytes = off;
 }
 
+// ---- chain tiles (JOB_FLAG_TILED, enc_types.h) ----------------------------------------------
+// Tile t of a shard of n bytes whose input blocks start at `first` (2 behind a stream offset: the "flint" bytes are a
+// block of their own, encode.c:1686-1694): tile 0 = [0, first + T), tile t = [first + t T, first + (t + 1) T), T = 1 << tile_log2.
+static inline IX_HD uint32_t tile_count(uint32_t n, uint32_t first, uint32_t tile_log2) {
+  return n <= first + 1u ? 1u : (uint32_t)((((uint64_t)(n - first)) + ((1ull << tile_log2) - 1u)) >> tile_log2);
+}
+static inline IX_HD uint32_t tile_lo(uint32_t first, uint32_t t, uint32_t tile_log2) { return t == 0 ? 0u : first + (t << tile_log2); }
+static inline IX_HD uint32_t tile_hi(uint32_t n, uint32_t first, uint32_t t, uint32_t tile_log2) {
+  const uint64_t e = (uint64_t)first + (((uint64_t)t + 1u) << tile_log2);
+  return e < n ? (uint32_t)e : n;
+}
+// Commands a tile's slot holds: index 0 = the copy of the last command before the tile ("ghost", what
+// ExtendLastCommand may lengthen), then the tile's own (<= bytes / 2 per block + one trailing insert).
+static inline IX_HD uint32_t tile_slot_cmds(uint32_t tile_log2, uint32_t lgblock) {
+  return (1u << (tile_log2 - 1u)) + (1u << (tile_log2 - lgblock)) + 16u;
+}
 
 #endif  // BROTLI_AMD_CSRC_K_INDEX_LAYOUT_H_

@@ -109,9 +109,18 @@ struct QShard {
   // attached dictionaries (k_dict.h): only the one-shard-per-wave stream kernels set them
   const CompoundDict* cd = nullptr;
   uint32_t gap = 0;        // their total size (backward_references_inc.h:31)
+  // k_chain.h, tiled jobs: the part of the shard this group parses (0xFFFFFFFF: what the descriptor says)
+  uint32_t lim_len = 0xFFFFFFFFu, lim_op = 0xFFFFFFFFu, lim_cmd_cap = 0xFFFFFFFFu;
+  // k_chain.h: commands are left raw (CMD_RAW, enc_types.h) with CMDF_* in dist_prefix
+  uint32_t raw_cmds = 0, cmd_flags = 0;
 };
+#define CMDF_NOPROBE 1u    // the position behind the copy's start was not searched (the lazy chain ended on an advance)
+#define CMDF_SPREE 2u      // the literal spree (backward_references_inc.h:208-236) skipped searches before this command
 
 DEV const ShardDesc& q_desc(const QShard& g) { return g.descs[g.shard]; }
+DEV uint32_t q_len(const QShard& g) { return g.lim_len != 0xFFFFFFFFu ? g.lim_len : q_desc(g).len; }
+DEV uint32_t q_final_op(const QShard& g) { return g.lim_op != 0xFFFFFFFFu ? g.lim_op : q_desc(g).final_op; }
+DEV uint32_t q_cmd_cap(const QShard& g) { return g.lim_cmd_cap != 0xFFFFFFFFu ? g.lim_cmd_cap : q_desc(g).cmd_cap; }
 DEV uint8_t* q_out(const QShard& g) { return g.wsb + q_desc(g).out_off; }
 DEV int q_t() { return wave_lane() & 15; }
 DEV int q_base() { return wave_lane() & 48; }
@@ -535,7 +544,7 @@ DEV void q_driver_pre(const JobParams& J, QShard& g) {
   const uint32_t block = 1u << J.lgblock;
   const uint32_t htl = hasher_htl(J.hasher_type);
   for (;;) {
-    const uint32_t avail = q_desc(g).len - r.input_pos;
+    const uint32_t avail = q_len(g) - r.input_pos;
     const uint32_t d = r.input_pos - r.last_processed_pos;
     uint32_t remaining = d >= block ? 0u : block - d;
     if (r.flint >= 0 && remaining > (uint32_t)r.flint) remaining = (uint32_t)r.flint;
@@ -545,14 +554,14 @@ DEV void q_driver_pre(const JobParams& J, QShard& g) {
       if (r.flint > 0) r.flint -= (int32_t)n;
       continue;
     }
-    if (remaining != 0 && avail == 0 && q_desc(g).final_op == 0) { g.status |= QST_DONE; g.state = Q_DONE; return; }
-    bool is_last = avail == 0 && q_desc(g).final_op == 2;
-    bool force_flush = avail == 0 && (q_desc(g).final_op == 1 || q_desc(g).final_op == 3);
-    bool seal = avail == 0 && q_desc(g).final_op == 1;
+    if (remaining != 0 && avail == 0 && q_final_op(g) == 0) { g.status |= QST_DONE; g.state = Q_DONE; return; }
+    bool is_last = avail == 0 && q_final_op(g) == 2;
+    bool force_flush = avail == 0 && (q_final_op(g) == 1 || q_final_op(g) == 3);
+    bool seal = avail == 0 && q_final_op(g) == 1;
     if (!is_last && r.flint == 0) { r.flint = -1; force_flush = true; seal = true; }
     const uint32_t bytes = r.input_pos - r.last_processed_pos;
     const uint32_t pos = r.last_processed_pos;
-    if (r.ncmds + bytes / 2u + 2u > q_desc(g).cmd_cap) { g.status |= QST_ERROR; g.state = Q_DONE; return; }
+    if (r.ncmds + bytes / 2u + 2u > q_cmd_cap(g)) { g.status |= QST_ERROR; g.state = Q_DONE; return; }
     g.blk_flags = (is_last ? QBLK_LAST : 0u) | (force_flush ? QBLK_FLUSH : 0u) |
                   (force_flush && !seal ? QBLK_NOSEAL : 0u);
     g.blk_bytes = bytes;
@@ -570,7 +579,7 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
   RoundRegs& r = g.r;
   const uint32_t block = 1u << J.lgblock;
   const bool is_last = (g.blk_flags & QBLK_LAST) != 0, force_flush = (g.blk_flags & QBLK_FLUSH) != 0;
-  const uint32_t avail = q_desc(g).len - r.input_pos;
+  const uint32_t avail = q_len(g) - r.input_pos;
   {
     const uint32_t processed = r.input_pos - r.last_flush_pos;
     const bool next_fits = processed + block <= J.max_metablock_size;
@@ -753,7 +762,16 @@ DEV void q_commit(const JobParams& J, QShard& g, bool commit, uint32_t htl) {
   if (g.sr_dist <= dictionary_start && distance_code > 0) {
     g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)g.sr_dist;
   }
-  if (t == 0 && g.role == 0) g.cmds[g.r.ncmds] = make_command(g.insert_length, g.sr_len, g.sr_delta, distance_code);
+  if (g.raw_cmds) {
+    if (t == 0 && g.role == 0) {
+      Command c;
+      c.insert_len = g.insert_length;
+      c.copy_len = g.sr_len | (((uint32_t)(uint8_t)(int8_t)g.sr_delta) << 25);
+      c.dist_extra = distance_code; c.cmd_prefix = CMD_RAW; c.dist_prefix = (uint16_t)g.cmd_flags;
+      g.cmds[g.r.ncmds] = c;
+    }
+    g.cmd_flags = 0;
+  } else if (t == 0 && g.role == 0) g.cmds[g.r.ncmds] = make_command(g.insert_length, g.sr_len, g.sr_delta, distance_code);
   ++g.r.ncmds;
   g.r.nlits += g.insert_length;
   g.insert_length = 0;
@@ -789,6 +807,7 @@ DEV bool q_transition(const JobParams& J, QShard& g, bool act, const QResult& cu
           g.st_first = g.position;
           g.st_count = cnt;
           g.st_stride = step;
+          g.cmd_flags |= CMDF_SPREE;
           g.position += cnt * step;
           g.insert_length += cnt * step;
         }
@@ -801,6 +820,7 @@ DEV bool q_transition(const JobParams& J, QShard& g, bool act, const QResult& cu
       ++g.insert_length;
       g.sr_len = cur.len; g.sr_dist = cur.distance; g.sr_score = cur.score; g.sr_delta = cur.delta;
       if (++g.delayed < 4 && g.position + htl < g.pos_end) commit = false;
+      else g.cmd_flags |= CMDF_NOPROBE;
     }
   }
   q_commit(J, g, commit, htl);

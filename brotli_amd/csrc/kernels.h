@@ -10,6 +10,7 @@
 #include "k_parse_quick.h"
 #include "k_index.h"
 #include "k_chain.h"
+#include "k_tile.h"
 
 // Register budgets (waves per SIMD the compiler must leave room for).
 #ifndef PARSE4_WAVES
@@ -41,6 +42,10 @@ struct JobArgs {
   uint32_t init_blocks_per_shard;
   uint32_t* counters;   // [0] shards with work left after this round, [1] faults
   const CompoundDict* cd = nullptr;   // attached dictionaries of a single stream (k_dict.h)
+  // JOB_FLAG_TILED (k_chain.h, k_tile.h): the job's chain tiles and their records
+  const TileDesc* tiles = nullptr;
+  TileRec* trecs = nullptr;
+  uint32_t ntiles = 0;
 };
 
 // grid = nshards * init_blocks_per_shard, block = 256
@@ -140,12 +145,41 @@ __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain(JobArgs a) {
 #else
   extern __shared__ uint32_t lds_c[];
 #endif
-  chain_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c);
+  chain_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, a.tiles, a.trecs, a.ntiles);
+  if (a.J.flags & JOB_FLAG_TILED) return;            // (k_tile_verify looks at the tiles' records)
   const uint32_t gpw = q_groups_per_wave(a.J);
   const uint32_t gi = threadIdx.x >> 4;
   const uint32_t shard = blockIdx.x * gpw + gi;
   if ((threadIdx.x & 15) == 0 && gi < gpw && shard < a.nshards && a.states[shard].error)
     glb_atomic_add(&a.counters[1], 1u);
+}
+
+// ---- tiled jobs (k_tile.h) ----
+// grid = nshards, block = 64
+__global__ void __launch_bounds__(64) k_tile_verify(JobArgs a) {
+  if (blockIdx.x < a.nshards) tile_verify(a.J, a.shards[blockIdx.x], &a.states[blockIdx.x], a.trecs, a.counters);
+}
+// grid = nshards * ix_slices, block = 64
+__global__ void __launch_bounds__(64) k_tile_events(JobArgs a) {
+  const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
+  if (shard < a.nshards) tile_events(a.J, a.shards[shard], a.ws, a.trecs, w, a.counters);
+}
+// grid = ntiles, block = 64
+__global__ void __launch_bounds__(64) k_tile_finish(JobArgs a) {
+  if (blockIdx.x >= a.ntiles) return;
+  const TileDesc d = a.tiles[blockIdx.x];
+  tile_finish(a.J, a.shards[d.shard], &a.states[d.shard], a.ws, a.trecs, d.t);
+}
+// grid = nshards, block = 64: the shards that left the tiled path start over for the plain chain
+__global__ void __launch_bounds__(64) k_tile_fallback(JobArgs a) {
+  if (blockIdx.x >= a.nshards) return;
+  const ShardDesc& D = a.shards[blockIdx.x];
+  if (D.ntiles <= 1u || !(a.trecs[D.tile_base].flags & TILE_BAD)) return;
+  IxLayout L;
+  ix_layout(D.len, a.J.ix_slices, a.J.ix_nb_log2, &L);
+  uint32_t* skip = (uint32_t*)(a.ws + D.ix_off + L.skip);
+  for (uint32_t i = threadIdx.x; i < (D.len + 128u + 31u) / 32u; i += 64u) skip[i] = 0;
+  if (threadIdx.x == 0) init_shard_state(a.J, D, &a.states[blockIdx.x]);
 }
 
 // grid = nshards * CE_SPLIT, block = 64: prefix fields of the commands the chain left raw

@@ -35,6 +35,7 @@ template <class T> static inline T lds_atomic_add(T* p, T v) { T o = *p; *p = o 
 template <class T> static inline T lds_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
 static inline uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 static inline uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+static inline uint32_t glb_atomic_and(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o & v; return o; }
 static inline uint32_t glb_atomic_max(uint32_t* p, uint32_t v) { uint32_t o = *p; if (v > o) *p = v; return o; }
 static inline uint32_t glb_load_l2(const uint32_t* p) { return *p; }
 static inline uint32_t dev_bitrev32(uint32_t x) {
@@ -130,6 +131,7 @@ template <class T> __device__ __forceinline__ T lds_atomic_or(T* p, T v) { retur
 // Device-scope OR on a global dword (executed at the L2; result optional).
 __device__ __forceinline__ uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 __device__ __forceinline__ uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
+__device__ __forceinline__ uint32_t glb_atomic_and(uint32_t* p, uint32_t v) { return atomicAnd(p, v); }
 __device__ __forceinline__ uint32_t glb_atomic_max(uint32_t* p, uint32_t v) { return atomicMax(p, v); }
 // A load served by the L2 (not the CU's L1): sees this wave's earlier atomics on the same word.
 __device__ __forceinline__ uint32_t glb_load_l2(const uint32_t* p) {

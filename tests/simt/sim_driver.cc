@@ -36,6 +36,35 @@ void run_parse_kernel(const JobArgs& a, int reverse) {
     if (a.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
     else if (a.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
     else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
+  } else if (a.J.flags & JOB_FLAG_TILED) {
+    // the tiles' parses, then verify / events / sweep until nothing is pending (what run_rounds of hip_layer.hip does)
+    const uint32_t gpw = q_groups_per_wave(a.J);
+    run(k_chain, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+    bool settled = false;
+    int rounds = 0;
+    for (; rounds < 12 && !settled; ++rounds) {
+      a.counters[TILE_CNT_START] = a.counters[TILE_CNT_FLIPS] = 0;
+      run(k_tile_verify, a, a.nshards, 64, reverse);
+      run(k_tile_events, a, a.nshards * a.J.ix_slices, 64, reverse);
+      if (getenv("SIM_TILE_LOG")) fprintf(stderr, "tile round %d: start events %u, changed skip bits %u, shards off the tiled path %u\n", rounds,
+                                          a.counters[TILE_CNT_START], a.counters[TILE_CNT_FLIPS], a.counters[TILE_CNT_BAD]);
+      if (a.counters[TILE_CNT_START] == 0 && a.counters[TILE_CNT_FLIPS] == 0) { settled = true; break; }
+      JobArgs b = a;
+      b.J.flags |= JOB_FLAG_SWEEP;
+      run(k_chain, b, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+    }
+    if (!settled) {           // give up on the tiles: every shard the plain way
+      for (uint32_t k = 0; k < a.nshards; ++k) if (a.shards[k].ntiles > 1) a.trecs[a.shards[k].tile_base].flags |= TILE_BAD;
+      a.counters[TILE_CNT_BAD] = 1;
+    }
+    run(k_tile_finish, a, a.ntiles, 64, reverse);
+    if (a.counters[TILE_CNT_BAD] != 0) {
+      run(k_tile_fallback, a, a.nshards, 64, reverse);
+      JobArgs c = a;
+      c.J.flags &= ~(uint32_t)(JOB_FLAG_TILED | JOB_FLAG_SWEEP);
+      run(k_chain, c, (a.nshards + gpw - 1) / gpw, 64, reverse);
+      run(k_cmd_encode, c, a.nshards * CE_SPLIT, 64, reverse);
+    }
   } else if (a.J.flags & JOB_FLAG_INDEXED) {
     run(k_chain, a, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
     run(k_cmd_encode, a, a.nshards * CE_SPLIT, 64, reverse);
@@ -64,6 +93,10 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   plan.J.flags |= (uint32_t)(no_pair & ~7);   // other job flags pass through (DUO, GROUPS)
   if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~(JOB_FLAG_QUAD | JOB_FLAG_INDEXED)) | JOB_FLAG_DEEP;
   if (plan.J.flags & JOB_FLAG_INDEXED) plan_add_index(&plan, true);
+  if ((plan.J.flags & JOB_FLAG_INDEXED) && getenv("SIM_TILE_KB"))
+    plan_add_tiles(&plan, (uint32_t)atoi(getenv("SIM_TILE_KB")), getenv("SIM_TILE_WARM") ? (uint32_t)atoi(getenv("SIM_TILE_WARM")) : 2048u);
+  std::vector<TileRec> trecs(plan.tiles.size() + 1);
+  memset(trecs.data(), 0, trecs.size() * sizeof(TileRec));
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);
   std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
@@ -82,6 +115,9 @@ long sim_parse(const char* tables_path, const uint8_t* in, size_t len, int quali
   a.init_blocks_per_shard = 2;
   uint32_t counters[16] = {0};
   a.counters = counters;
+  a.tiles = plan.tiles.data();
+  a.trecs = trecs.data();
+  a.ntiles = (uint32_t)plan.tiles.size();
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
   if (plan.J.flags & JOB_FLAG_INDEXED) run_index(a, reverse);
   run_parse_kernel(a, reverse);
@@ -119,6 +155,10 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   plan.J.flags |= (uint32_t)flags;
   if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~(JOB_FLAG_QUAD | JOB_FLAG_INDEXED)) | JOB_FLAG_DEEP;
   if (plan.J.flags & JOB_FLAG_INDEXED) plan_add_index(&plan, true);
+  if ((plan.J.flags & JOB_FLAG_INDEXED) && getenv("SIM_TILE_KB"))
+    plan_add_tiles(&plan, (uint32_t)atoi(getenv("SIM_TILE_KB")), getenv("SIM_TILE_WARM") ? (uint32_t)atoi(getenv("SIM_TILE_WARM")) : 2048u);
+  std::vector<TileRec> trecs(plan.tiles.size() + 1);
+  memset(trecs.data(), 0, trecs.size() * sizeof(TileRec));
   std::vector<uint8_t> input(len + 64, 0);
   memcpy(input.data(), in, len);
   std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
@@ -137,10 +177,14 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   a.init_blocks_per_shard = 2;
   uint32_t counters[16] = {0};
   a.counters = counters;
+  a.tiles = plan.tiles.data();
+  a.trecs = trecs.data();
+  a.ntiles = (uint32_t)plan.tiles.size();
   run(k_init, a, a.nshards * a.init_blocks_per_shard, 256, 0);
   if (plan.J.flags & JOB_FLAG_INDEXED) run_index(a, reverse);
   for (int round = 0; round < 100000; ++round) {
     memset(counters, 0, sizeof(counters));
+    if (round > 0 && (a.J.flags & JOB_FLAG_TILED)) return -5;     // (a tiled shard is one meta-block)
     run_parse_kernel(a, reverse);
     run(k_build, a, a.nshards, 64, reverse);
     if (getenv("SIM_DEBUG")) {
