@@ -42,8 +42,11 @@ struct BrotliAmdCtx {
   ShardDesc* d_shards = nullptr;
   ShardState* d_states = nullptr;
   uint64_t* d_scan = nullptr;       // nshards + 1 output offsets
-  uint32_t* d_counters = nullptr;   // [0] shards not done, [1] shards in error
+  uint32_t* d_counters = nullptr;   // [0] shards not done, [1] shards in error, [2..4] tiled jobs (k_tile.h)
   uint64_t shard_cap = 0;
+  TileDesc* d_tiles = nullptr;      // tiled jobs (JOB_FLAG_TILED): the tile table and the tiles' records
+  TileRec* d_trecs = nullptr;
+  uint64_t tile_cap = 0;
   uint8_t* d_stage_in = nullptr;    // encode_host staging
   uint8_t* d_stage_out = nullptr;
   uint64_t stage_in_cap = 0, stage_out_cap = 0;
@@ -250,6 +253,18 @@ bool ensure_ws(BrotliAmdCtx* c, uint64_t ws_bytes, uint64_t nshards) {
   return true;
 }
 
+bool ensure_tiles(BrotliAmdCtx* c, uint64_t ntiles) {
+  if (ntiles > c->tile_cap) {
+    if (c->d_tiles) HIP_OK(c, hipFree(c->d_tiles));
+    if (c->d_trecs) HIP_OK(c, hipFree(c->d_trecs));
+    c->d_tiles = nullptr; c->d_trecs = nullptr; c->tile_cap = 0;
+    HIP_OK(c, hipMalloc((void**)&c->d_tiles, ntiles * sizeof(TileDesc)));
+    HIP_OK(c, hipMalloc((void**)&c->d_trecs, ntiles * sizeof(TileRec)));
+    c->tile_cap = ntiles;
+  }
+  return true;
+}
+
 // Copies the chunks of a compound dictionary (bytes + index, k_dict.h) to the device; `allocs` owns the memory.
 int upload_dictionary(BrotliAmdCtx* c, const BrotliAmdDictChunk* chunks, uint32_t nchunks,
                       std::vector<void*>* allocs, CompoundDict** d_cd) {
@@ -320,9 +335,15 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
         if (v == 1 || v == 2 || v == 4 || v == 8) plan->J.ix_bpw = v;
       }
       plan->J.flags &= ~(uint32_t)JOB_FLAG_DUO;
+      // Shards longer than a tile: their chain runs tile by tile, all tiles at once (k_chain.h, k_tile.h).
+      // BROTLI_AMD_TILE_KB: KiB per tile (0 = off), BROTLI_AMD_TILE_WARM: bytes of warm-up before a tile.
+      uint32_t tile_kb = 0, tile_warm = 2048;
+      if (const char* e = getenv("BROTLI_AMD_TILE_KB")) tile_kb = (uint32_t)atoi(e);
+      if (const char* e = getenv("BROTLI_AMD_TILE_WARM")) tile_warm = (uint32_t)atoi(e);
+      if (tile_kb != 0 && !(api_flags & BROTLI_AMD_FLAG_FORCE_SLOW)) plan_add_tiles(plan, tile_kb, tile_warm);
       // shards per wave of k_chain: one 16-lane group per shard, as many waves as stay resident
       const uint64_t resident = (uint64_t)c->num_cus * 4u * CHAIN_WAVES;
-      const uint64_t ns = plan->shards.size();
+      const uint64_t ns = (plan->J.flags & JOB_FLAG_TILED) ? plan->tiles.size() : plan->shards.size();
       // measured (profiles/r02_b/c): the step is bound by instruction issue, so four shards per
       // wave win as soon as there are enough shards to give every SIMD a wave
       (void)resident;
@@ -370,6 +391,17 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
   a.nshards = nshards;
   a.counters = c->d_counters;
   a.cd = c->d_cd;
+  const bool tiled = (plan.J.flags & JOB_FLAG_TILED) != 0;
+  const uint32_t ntiles = (uint32_t)plan.tiles.size();
+  uint32_t tile_sweeps = 0, tile_bad = 0;
+  if (tiled) {
+    if (!ensure_tiles(c, ntiles)) return false;
+    HIP_OK(c, hipMemcpyAsync(c->d_tiles, plan.tiles.data(), ntiles * sizeof(TileDesc), hipMemcpyHostToDevice, c->stream));
+    HIP_OK(c, hipMemsetAsync(c->d_trecs, 0, ntiles * sizeof(TileRec), c->stream));
+    a.tiles = c->d_tiles;
+    a.trecs = c->d_trecs;
+    a.ntiles = ntiles;
+  }
   // Table init: enough 256-thread blocks per shard to stream the 128-byte
   // records at HBM rate without flooding the dispatcher.
   uint32_t ibs = 4096u / (nshards < 4096u ? nshards : 4096u);
@@ -413,13 +445,49 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       if (plan.J.block_bits <= 6) hipLaunchKernelGGL(k_parse_deep<1>, dim3(nshards), dim3(64), 0, c->stream, a);
       else if (plan.J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(nshards), dim3(64), 0, c->stream, a);
       else hipLaunchKernelGGL(k_parse_deep<4>, dim3(nshards), dim3(64), 0, c->stream, a);
+    } else if (tiled) {
+      // the tiles' parses, then verify / events / sweep until nothing is pending (k_tile.h)
+      if (rounds != 0) return fail(c, "a tiled shard holds one meta-block");
+      const dim3 cgrid((ntiles + gpw - 1) / gpw);
+      const uint32_t clds = gpw * C_GROUP_LDS_WORDS * 4u;
+      hipLaunchKernelGGL(k_chain_tiles, cgrid, dim3(64), clds, c->stream, a);
+      bool settled = false;
+      uint32_t tc[16];
+      for (int pass = 0; pass < 12 && !settled; ++pass) {
+        HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_START, 0, 2 * sizeof(uint32_t), c->stream));
+        hipLaunchKernelGGL(k_tile_verify, dim3(nshards), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(k_tile_events, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
+        HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(c, hipStreamSynchronize(c->stream));
+        tile_bad = tc[TILE_CNT_BAD];
+        if (getenv("BROTLI_AMD_TILE_LOG")) fprintf(stderr, "tile pass %d: start events %u, changed skip bits %u, shards off the tiled path %u\n",
+                                                   pass, tc[TILE_CNT_START], tc[TILE_CNT_FLIPS], tc[TILE_CNT_BAD]);
+        if (tc[TILE_CNT_START] == 0 && tc[TILE_CNT_FLIPS] == 0) { settled = true; break; }
+        JobArgs b = a;
+        b.J.flags |= JOB_FLAG_SWEEP;
+        hipLaunchKernelGGL(k_chain_sweep, cgrid, dim3(64), clds, c->stream, b);
+        ++tile_sweeps;
+      }
+      if (!settled) {
+        // give up on the tiles: every tiled shard goes the plain way
+        hipLaunchKernelGGL(k_tile_giveup, dim3(nshards), dim3(64), 0, c->stream, a);
+        tile_bad = nshards;
+      }
+      hipLaunchKernelGGL(k_tile_finish, dim3(ntiles), dim3(64), 0, c->stream, a);
+      if (tile_bad != 0) {
+        hipLaunchKernelGGL(k_tile_fallback, dim3(nshards), dim3(64), 0, c->stream, a);
+        JobArgs p = a;
+        p.J.flags &= ~(uint32_t)(JOB_FLAG_TILED | JOB_FLAG_SWEEP);
+        hipLaunchKernelGGL(k_chain, dim3((nshards + gpw - 1) / gpw), dim3(64), clds, c->stream, p);
+        hipLaunchKernelGGL(k_cmd_encode, dim3(nshards * CE_SPLIT), dim3(64), 0, c->stream, p);
+      }
     } else if (indexed)
       hipLaunchKernelGGL(k_chain, dim3((nshards + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, a);
     else if (plan.J.flags & JOB_FLAG_QUAD)
       hipLaunchKernelGGL(k_parse4, dim3((nshards + gpw - 1) / gpw), dim3(64), 0, c->stream, a);
     else
       hipLaunchKernelGGL(k_parse, dim3(nshards), dim3(64), 0, c->stream, a);
-    if (indexed) hipLaunchKernelGGL(k_cmd_encode, dim3(nshards * CE_SPLIT), dim3(64), 0, c->stream, a);
+    if (indexed && !tiled) hipLaunchKernelGGL(k_cmd_encode, dim3(nshards * CE_SPLIT), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev[3], c->stream));
     if (stages & STAGE_BUILD) hipLaunchKernelGGL(k_build, dim3(nshards), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev[4], c->stream));
@@ -451,6 +519,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     info->ms_build = ms_build;
     info->ms_store = ms_store;
     info->rounds = rounds;
+    info->reserved = tile_sweeps | (tile_bad << 8);     // tiled jobs: sweeps of the chain, shards that went the plain way
     info->nshards = nshards;
     info->ws_bytes = plan.ws_bytes;
   }
@@ -505,7 +574,7 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   DeviceScope dev(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_lut, c->d_dict, c->d_hash_words, c->d_hash_lengths, c->d_log2, c->d_T,
-                  c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters,
+                  c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters, c->d_tiles, c->d_trecs,
                   c->d_stage_in, c->d_stage_out, c->d_ffrags, c->d_fblocks, c->d_fbstate,
                   c->d_ffstate, c->d_fresult, c->d_transforms, c->d_transform_text, c->d_dec_arena,
                   c->d_dec_pieces, c->d_dec_results};

@@ -676,13 +676,16 @@ DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, u
 DEV Command* c_tile_slot(uint8_t* ws, const ShardDesc& D, const JobParams& J, uint32_t buf, uint32_t tt) {
   return (Command*)(ws + D.cmds2_off) + ((uint64_t)buf * D.ntiles + tt) * tile_slot_cmds(J.tile_log2, (uint32_t)J.lgblock);
 }
+// MODE 0: the plain chain (one unit = one shard), 1: the tiles' first parse, 2: a sweep — three kernels, so that
+// the plain chain does not carry the registers of the other two.
+template <int MODE>
 DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* states,
                      uint32_t nshards, const DeviceTables* T, const uint8_t* input, uint8_t* ws,
                      uint32_t wave_index, uint32_t* lds, const TileDesc* tiles, TileRec* trecs, uint32_t ntiles) {
   const int t = q_t();
   const uint32_t gpw = q_groups_per_wave(J);
   const uint32_t gi = (uint32_t)(wave_lane() >> 4);
-  const bool tiled = (J.flags & JOB_FLAG_TILED) != 0, sweep = tiled && (J.flags & JOB_FLAG_SWEEP) != 0;
+  constexpr bool tiled = MODE != 0, sweep = MODE == 2;
   const uint32_t unit = wave_index * gpw + gi;
   bool alive = gi < gpw && unit < (tiled ? ntiles : nshards);
   uint32_t shard = unit, tt = 0;

@@ -62,6 +62,15 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
   }
   // a meta-block cut inside the shard (encode.c:1141-1166) is not something the tiles know about
   bad = bad || nlits >= J.max_literals || ncmds >= J.max_commands || S->error != 0;
+#if defined(BROTLI_AMD_SIMT_SIM)
+  if (getenv("SIM_TILE_LOG")) {
+    for (uint32_t t = 0; t < D.ntiles; ++t)
+      fprintf(stderr, "  tile %u: flags %x ncmds %u nlits %u gate %u in(dc %d %d %d %d ins %u cl %u code %u ext %u) out(dc %d %d %d %d ins %u cl %u code %u) buf %u\n", t, R[t].flags,
+              R[t].out_ncmds, R[t].out_nlits, R[t].out_gate, R[t].in_dc[0], R[t].in_dc[1], R[t].in_dc[2], R[t].in_dc[3], R[t].in_insert, R[t].in_copy_len, R[t].in_code, R[t].in_ext,
+              R[t].out_dc[0], R[t].out_dc[1], R[t].out_dc[2], R[t].out_dc[3], R[t].out_insert, R[t].out_copy_len, R[t].out_code, R[t].buf);
+    if (bad) fprintf(stderr, "  -> shard leaves the tiled path (nlits %u ncmds %u error %u)\n", nlits, ncmds, S->error);
+  }
+#endif
   if (bad) {
     R[0].flags |= TILE_BAD;
     glb_atomic_add(&counters[TILE_CNT_BAD], 1u);

@@ -145,13 +145,30 @@ __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain(JobArgs a) {
 #else
   extern __shared__ uint32_t lds_c[];
 #endif
-  chain_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, a.tiles, a.trecs, a.ntiles);
-  if (a.J.flags & JOB_FLAG_TILED) return;            // (k_tile_verify looks at the tiles' records)
+  chain_round<0>(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, nullptr, nullptr, 0);
   const uint32_t gpw = q_groups_per_wave(a.J);
   const uint32_t gi = threadIdx.x >> 4;
   const uint32_t shard = blockIdx.x * gpw + gi;
   if ((threadIdx.x & 15) == 0 && gi < gpw && shard < a.nshards && a.states[shard].error)
     glb_atomic_add(&a.counters[1], 1u);
+}
+// The same for the tiles of a tiled job (grid = ceil(ntiles / tiles per wave)): their first parse, and a sweep.
+// (k_tile_verify looks at the tiles' records; errors surface there.)
+__global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain_tiles(JobArgs a) {
+#if defined(BROTLI_AMD_SIMT_SIM)
+  __shared__ uint32_t lds_c[C_LDS_WORDS];
+#else
+  extern __shared__ uint32_t lds_c[];
+#endif
+  chain_round<1>(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, a.tiles, a.trecs, a.ntiles);
+}
+__global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain_sweep(JobArgs a) {
+#if defined(BROTLI_AMD_SIMT_SIM)
+  __shared__ uint32_t lds_c[C_LDS_WORDS];
+#else
+  extern __shared__ uint32_t lds_c[];
+#endif
+  chain_round<2>(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, a.tiles, a.trecs, a.ntiles);
 }
 
 // ---- tiled jobs (k_tile.h) ----
@@ -169,6 +186,12 @@ __global__ void __launch_bounds__(64) k_tile_finish(JobArgs a) {
   if (blockIdx.x >= a.ntiles) return;
   const TileDesc d = a.tiles[blockIdx.x];
   tile_finish(a.J, a.shards[d.shard], &a.states[d.shard], a.ws, a.trecs, d.t);
+}
+// grid = nshards, block = 64: the sweeps did not settle — every tiled shard leaves the tiled path
+__global__ void __launch_bounds__(64) k_tile_giveup(JobArgs a) {
+  if (blockIdx.x >= a.nshards || threadIdx.x != 0) return;
+  const ShardDesc& D = a.shards[blockIdx.x];
+  if (D.ntiles > 1u) a.trecs[D.tile_base].flags |= TILE_BAD;
 }
 // grid = nshards, block = 64: the shards that left the tiled path start over for the plain chain
 __global__ void __launch_bounds__(64) k_tile_fallback(JobArgs a) {

@@ -39,7 +39,7 @@ void run_parse_kernel(const JobArgs& a, int reverse) {
   } else if (a.J.flags & JOB_FLAG_TILED) {
     // the tiles' parses, then verify / events / sweep until nothing is pending (what run_rounds of hip_layer.hip does)
     const uint32_t gpw = q_groups_per_wave(a.J);
-    run(k_chain, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+    run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
     bool settled = false;
     int rounds = 0;
     for (; rounds < 12 && !settled; ++rounds) {
@@ -51,7 +51,7 @@ void run_parse_kernel(const JobArgs& a, int reverse) {
       if (a.counters[TILE_CNT_START] == 0 && a.counters[TILE_CNT_FLIPS] == 0) { settled = true; break; }
       JobArgs b = a;
       b.J.flags |= JOB_FLAG_SWEEP;
-      run(k_chain, b, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+      run(k_chain_sweep, b, (a.ntiles + gpw - 1) / gpw, 64, reverse);
     }
     if (!settled) {           // give up on the tiles: every shard the plain way
       for (uint32_t k = 0; k < a.nshards; ++k) if (a.shards[k].ntiles > 1) a.trecs[a.shards[k].tile_base].flags |= TILE_BAD;
