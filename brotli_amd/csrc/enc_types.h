@@ -120,11 +120,23 @@ struct TileRec {
   uint32_t used_insert, used_ext;
   uint32_t out_lpp;        // last tile: last_processed_pos_ and how the meta-block ended (bit 0 have, 1 is_last, 2 flush, 3 flush without seal)
   uint32_t out_mb;
+  uint32_t nflips;         // tile 0: unstored-position bits of the shard that changed in the last k_tile_events pass
+  uint32_t pad;
 };
 #define TILE_START_EVENT 1u   // the in-state was replaced by k_tile_verify: the next sweep parses from the tile's start
 #define TILE_BAD 2u           // the shard cannot be parsed in tiles (gate open, counter wrap, meta-block cut ...): serial path
 #define TILE_RAN 4u           // the tile's parse has run at least once
 #define TILE_CHANGED 8u       // the last sweep parsed something again in this tile
+// why a shard left the tiled path (diagnostics; on the record of the tile / of tile 0)
+#define TILE_WHY_WRAP 0x100u      // a search past rank 65520 of its key (the 16-bit store counter, k_chain.h)
+#define TILE_WHY_ERROR 0x200u     // the tile's parse failed (command capacity, an impossible state)
+#define TILE_WHY_NO_MB 0x400u     // the last tile did not end with the shard's meta-block
+#define TILE_WHY_NOT_RUN 0x800u
+#define TILE_WHY_NO_CMD 0x1000u   // a tile without a command: nothing ExtendLastCommand could lengthen
+#define TILE_WHY_GATE 0x2000u     // the static-dictionary gate still open behind a tile
+#define TILE_WHY_CUT 0x4000u      // a meta-block would have been cut inside the shard (encode.c:1141-1166)
+#define TILE_WHY_EVENTS 0x8000u   // too many unstored positions: the tiles would parse everything twice
+#define TILE_WHY_TILE 0x10000u    // (tile 0: one of the shard's tiles carries a reason of its own)
 
 // Persistent per-shard encoder state (c/enc/state.h:49-110 subset).
 struct ShardState {

@@ -7,6 +7,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <atomic>
 #include <algorithm>
@@ -450,23 +451,37 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       if (rounds != 0) return fail(c, "a tiled shard holds one meta-block");
       const dim3 cgrid((ntiles + gpw - 1) / gpw);
       const uint32_t clds = gpw * C_GROUP_LDS_WORDS * 4u;
+      const bool tlog = getenv("BROTLI_AMD_TILE_LOG") != nullptr;
+      auto lap = [&](const char* what) {           // (diagnostics: wall time per stage, with a sync each)
+        static double t_prev = 0;
+        if (!tlog) return;
+        (void)hipStreamSynchronize(c->stream);
+        timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+        const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+        if (what) fprintf(stderr, "  tile stage %-14s %8.3f ms\n", what, now - t_prev);
+        t_prev = now;
+      };
+      lap(nullptr);
       hipLaunchKernelGGL(k_chain_tiles, cgrid, dim3(64), clds, c->stream, a);
+      lap("first parse");
       bool settled = false;
       uint32_t tc[16];
       for (int pass = 0; pass < 12 && !settled; ++pass) {
         HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_START, 0, 2 * sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k_tile_verify, dim3(nshards), dim3(64), 0, c->stream, a);
         hipLaunchKernelGGL(k_tile_events, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
+        hipLaunchKernelGGL(k_tile_verify, dim3(nshards), dim3(64), 0, c->stream, a);
         HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
         HIP_OK(c, hipStreamSynchronize(c->stream));
+        lap("events+verify");
         tile_bad = tc[TILE_CNT_BAD];
-        if (getenv("BROTLI_AMD_TILE_LOG")) fprintf(stderr, "tile pass %d: start events %u, changed skip bits %u, shards off the tiled path %u\n",
-                                                   pass, tc[TILE_CNT_START], tc[TILE_CNT_FLIPS], tc[TILE_CNT_BAD]);
+        if (tlog) fprintf(stderr, "tile pass %d: start events %u, changed skip bits %u, shards off the tiled path %u\n",
+                          pass, tc[TILE_CNT_START], tc[TILE_CNT_FLIPS], tc[TILE_CNT_BAD]);
         if (tc[TILE_CNT_START] == 0 && tc[TILE_CNT_FLIPS] == 0) { settled = true; break; }
         JobArgs b = a;
         b.J.flags |= JOB_FLAG_SWEEP;
         hipLaunchKernelGGL(k_chain_sweep, cgrid, dim3(64), clds, c->stream, b);
         ++tile_sweeps;
+        lap("sweep");
       }
       if (!settled) {
         // give up on the tiles: every tiled shard goes the plain way
@@ -474,12 +489,28 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
         tile_bad = nshards;
       }
       hipLaunchKernelGGL(k_tile_finish, dim3(ntiles), dim3(64), 0, c->stream, a);
+      lap("finish");
       if (tile_bad != 0) {
+        if (tlog) {
+          std::vector<TileRec> tr(ntiles);
+          HIP_OK(c, hipMemcpy(tr.data(), c->d_trecs, ntiles * sizeof(TileRec), hipMemcpyDeviceToHost));
+          uint32_t why[32] = {0};
+          for (const ShardDesc& D : plan.shards) {
+            if (D.ntiles <= 1) continue;
+            uint32_t f = tr[D.tile_base].flags;
+            if (!(f & TILE_BAD)) continue;
+            for (uint32_t t = 1; t < D.ntiles; ++t) if (tr[D.tile_base + t].flags & TILE_BAD) f |= tr[D.tile_base + t].flags;
+            for (int b = 8; b < 32; ++b) if (f & (1u << b)) ++why[b];
+          }
+          fprintf(stderr, "  shards off the tiled path: wrap %u error %u no-mb %u not-run %u no-cmd %u gate %u cut %u events %u\n",
+                  why[8], why[9], why[10], why[11], why[12], why[13], why[14], why[15]);
+        }
         hipLaunchKernelGGL(k_tile_fallback, dim3(nshards), dim3(64), 0, c->stream, a);
         JobArgs p = a;
         p.J.flags &= ~(uint32_t)(JOB_FLAG_TILED | JOB_FLAG_SWEEP);
         hipLaunchKernelGGL(k_chain, dim3((nshards + gpw - 1) / gpw), dim3(64), clds, c->stream, p);
         hipLaunchKernelGGL(k_cmd_encode, dim3(nshards * CE_SPLIT), dim3(64), 0, c->stream, p);
+        lap("plain chain");
       }
     } else if (indexed)
       hipLaunchKernelGGL(k_chain, dim3((nshards + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, a);

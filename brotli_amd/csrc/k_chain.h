@@ -113,7 +113,7 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
 // Sweeps: [a, b) was stored by the parse — whatever an earlier parse of the tile had marked there is taken back.
 DEV void c_clear_range(CShard& C, bool act, uint32_t a, uint32_t b) {
   const int t = q_t();
-  if (!(C.mode & C_VIEW_ALL)) return;
+  act = act && (C.mode & C_VIEW_ALL) != 0;
   uint32_t cur = umax(a, umax(C.geo.first, C.tile_lo));
   while (wave_any(act && cur < b)) {
     if (act && cur < b && t == 0) c_bitmap_settle(C.skip, cur - C.geo.first, umin(16u, b - cur), 0u, true);
@@ -126,7 +126,10 @@ DEV void c_clear_range(CShard& C, bool act, uint32_t a, uint32_t b) {
 // storable between the frontier and a was passed over.
 DEV void c_stored(const JobParams& J, CShard& C, bool act, uint32_t a, uint32_t b) {
   if (wave_any(act && C.frontier < a)) c_mark_range(J, C, act && C.frontier < a, C.frontier, a, 0, 1);
-  if ((C.mode & C_VIEW_ALL) != 0 && wave_any(act && a < b)) c_clear_range(C, act && a < b, umax(a, C.frontier), b);
+  {
+    const bool clr = act && a < b && (C.mode & C_VIEW_ALL) != 0;
+    if (wave_any(clr)) c_clear_range(C, clr, umax(a, C.frontier), b);
+  }
   if (act) C.frontier = b;
 }
 
@@ -641,7 +644,9 @@ DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, u
     const uint32_t pc = R.obnd + c.insert_len, L = c.copy_len & 0x1FFFFFFu, code = c.dist_extra;
     const uint32_t dist = c_code_distance(code, g.dc[0], g.dc[1], g.dc[2], g.dc[3]);
     const uint32_t dictionary_start = umin(pc + g.stream_offset, limit);
-    bool ok = can && pc >= g.position && pc + htl < g.pos_end && pc <= g.apply_random_heuristics &&
+    // (while the static dictionary is still consulted — the first kilobytes of a shard — its two counters are
+    // part of the state and only real searches keep them: no replay until the gate has closed, hash.h:186)
+    bool ok = can && g.dict_matches < (g.dict_lookups >> 7) && pc >= g.position && pc + htl < g.pos_end && pc <= g.apply_random_heuristics &&
               (c.dist_prefix & CMDF_SPREE) == 0 && (c.copy_len >> 25) == 0u && dist <= dictionary_start && L >= 2u;
     if (ok) ok = !c_ev_any(R.ev, C.geo.first, g.position, umin(pc + 1u, g.pos_end - 1u));
     if (!wave_any(ok)) break;
@@ -767,7 +772,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       for (uint32_t i = ev_w0 + (uint32_t)t; i < ev_w1; i += 16u) any |= evw[i];
     }
     any = q_or(any);
-    if (sweep) run = run && any != 0 && (TR->flags & TILE_BAD) == 0;
+    if (sweep) run = run && any != 0 && (trecs[D.tile_base].flags & TILE_BAD) == 0;
     int32_t used_dc[4] = {0, 0, 0, 0};
     uint32_t used_insert = 0, used_ext = 0;
     if (tile_mode) {
@@ -1032,7 +1037,9 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
                    ((g.blk_flags & QBLK_FLUSH) ? ((g.blk_flags & QBLK_NOSEAL) ? 8u : 4u) : 0u);
       TR->buf = sweep ? (TR->buf ^ 1u) : 0u;
       uint32_t fl = (TR->flags | TILE_RAN) & ~(TILE_START_EVENT | TILE_CHANGED);
-      if ((C.mode & C_BAD) != 0 || (g.status & QST_ERROR) != 0 || (last_tile && !(g.status & QST_HAVE_MB))) fl |= TILE_BAD;
+      if ((C.mode & C_BAD) != 0) fl |= TILE_BAD | TILE_WHY_WRAP;
+      if ((g.status & QST_ERROR) != 0) fl |= TILE_BAD | TILE_WHY_ERROR;
+      if (last_tile && !(g.status & QST_HAVE_MB)) fl |= TILE_BAD | TILE_WHY_NO_MB;
       if (R.changed != 0) fl |= TILE_CHANGED;
       TR->flags = fl;
       if (tt == 0) {

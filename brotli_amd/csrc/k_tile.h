@@ -36,18 +36,23 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
   if (D.ntiles <= 1u || wave_lane() != 0) return;
   TileRec* R = trecs + D.tile_base;
   if (R[0].flags & TILE_BAD) return;                    // (decided in an earlier pass)
-  bool bad = false;
+  uint32_t why = 0;
   uint32_t ncmds = 0, nlits = 0, starts = 0;
+  // a shard most of whose searches the tiles would have to do twice is better off on the plain chain
+  if (R[0].nflips > D.len / 32u + 64u) why |= TILE_WHY_EVENTS;
+  R[0].nflips = 0;
   for (uint32_t t = 0; t < D.ntiles; ++t) {
     TileRec& c = R[t];
-    bad = bad || (c.flags & TILE_BAD) != 0 || !(c.flags & TILE_RAN);
+    if (c.flags & TILE_BAD) why |= TILE_WHY_TILE;
+    if (!(c.flags & TILE_RAN)) why |= TILE_WHY_NOT_RUN;
     c.cmd_off = ncmds;
     ncmds += c.out_ncmds;
     nlits += c.out_nlits;
     if (t + 1u == D.ntiles) break;
     // what the next tile has to start from
     TileRec& n = R[t + 1u];
-    bad = bad || c.out_ncmds == 0u || c.out_gate == 0u;     // (no command to extend / the dictionary still consulted)
+    if (c.out_ncmds == 0u) why |= TILE_WHY_NO_CMD;          // (no command ExtendLastCommand could lengthen)
+    if (c.out_gate == 0u) why |= TILE_WHY_GATE;             // (the dictionary still consulted)
     const bool same_cmd = c.out_insert != 0u || (n.in_copy_len == c.out_copy_len && n.in_code == c.out_code);
     const bool same = n.in_dc[0] == c.out_dc[0] && n.in_dc[1] == c.out_dc[1] && n.in_dc[2] == c.out_dc[2] &&
                       n.in_dc[3] == c.out_dc[3] && n.in_insert == c.out_insert && same_cmd;
@@ -61,7 +66,9 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
     }
   }
   // a meta-block cut inside the shard (encode.c:1141-1166) is not something the tiles know about
-  bad = bad || nlits >= J.max_literals || ncmds >= J.max_commands || S->error != 0;
+  if (nlits >= J.max_literals || ncmds >= J.max_commands) why |= TILE_WHY_CUT;
+  if (S->error != 0) why |= TILE_WHY_ERROR;
+  const bool bad = why != 0;
 #if defined(BROTLI_AMD_SIMT_SIM)
   if (getenv("SIM_TILE_LOG")) {
     for (uint32_t t = 0; t < D.ntiles; ++t)
@@ -72,13 +79,13 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
   }
 #endif
   if (bad) {
-    R[0].flags |= TILE_BAD;
+    R[0].flags |= TILE_BAD | why;
     glb_atomic_add(&counters[TILE_CNT_BAD], 1u);
   } else if (starts != 0) glb_atomic_add(&counters[TILE_CNT_START], starts);
 }
 
 // grid = nshards * ix_slices, block = 64: the slice's words of the bitmap.
-DEV void tile_events(const JobParams& J, const ShardDesc& D, uint8_t* ws, const TileRec* trecs, uint32_t w, uint32_t* counters) {
+DEV void tile_events(const JobParams& J, const ShardDesc& D, uint8_t* ws, TileRec* trecs, uint32_t w, uint32_t* counters) {
   if (D.ntiles <= 1u || (trecs[D.tile_base].flags & TILE_BAD)) return;
   const uint32_t lane = (uint32_t)wave_lane();
   const uint32_t first = D.stream_offset != 0 ? 2u : 0u;
@@ -109,7 +116,10 @@ DEV void tile_events(const JobParams& J, const ShardDesc& D, uint8_t* ws, const 
       }
     }
   }
-  if (flips != 0) glb_atomic_add(&counters[TILE_CNT_FLIPS], flips);
+  if (flips != 0) {
+    glb_atomic_add(&counters[TILE_CNT_FLIPS], flips);
+    glb_atomic_add((uint32_t*)&trecs[D.tile_base].nflips, flips);
+  }
 }
 
 // grid = ntiles, block = 64: a tile's commands to their place in the shard's array, encoded; tile 0's wave also

@@ -44,8 +44,8 @@ void run_parse_kernel(const JobArgs& a, int reverse) {
     int rounds = 0;
     for (; rounds < 12 && !settled; ++rounds) {
       a.counters[TILE_CNT_START] = a.counters[TILE_CNT_FLIPS] = 0;
-      run(k_tile_verify, a, a.nshards, 64, reverse);
       run(k_tile_events, a, a.nshards * a.J.ix_slices, 64, reverse);
+      run(k_tile_verify, a, a.nshards, 64, reverse);
       if (getenv("SIM_TILE_LOG")) fprintf(stderr, "tile round %d: start events %u, changed skip bits %u, shards off the tiled path %u\n", rounds,
                                           a.counters[TILE_CNT_START], a.counters[TILE_CNT_FLIPS], a.counters[TILE_CNT_BAD]);
       if (a.counters[TILE_CNT_START] == 0 && a.counters[TILE_CNT_FLIPS] == 0) { settled = true; break; }
