@@ -285,6 +285,34 @@ def main_q1(args):
     print(json.dumps(line), flush=True)
 
 
+ALL_CONFIGS = [
+    ("configs[1]: 1 GiB enwik-style text, quality 5, lgwin 22", []),
+    ("configs[2]: 1 GiB random bytes, quality 1", ["--quality", "1", "--data", "random"]),
+    ("configs[3] workload on one GPU: 1 GiB Silesia-style mix, quality 5, lgwin 22", ["--workload", "silesia"]),
+    ("configs[4]: 1 GiB text, quality 9, lgwin 24", ["--quality", "9", "--lgwin", "24", "--shard-kb", "512"]),
+]
+
+
+def main_all_configs(args):
+    """Runs this script once per single-GPU BASELINE configuration (a process each: every one builds its own input and
+    context) and prints their JSON lines in order; `cpu_baseline` is part of every line."""
+    import subprocess
+    rc = 0
+    for label, extra in ALL_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(args.steps), "--warmup", str(args.warmup),
+               "--size-mb", str(args.size_mb)] + extra
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not lines:
+            rc = 1
+            print(json.dumps({"config_label": label, "error": (r.stderr or r.stdout)[-600:]}), flush=True)
+            continue
+        line = json.loads(lines[-1])
+        line["config_label"] = label
+        print(json.dumps(line), flush=True)
+    sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,7 +328,12 @@ def main():
                          "size-mb MiB per GPU: 8 GiB on 8 GPUs)")
     ap.add_argument("--data", choices=["text", "random"], default="text", help="quality 1 only")
     ap.add_argument("--feed-kb", type=int, default=0, help="quality 1 only: KiB per CompressStream call (0 = one call)")
+    ap.add_argument("--all-configs", action="store_true",
+                    help="one line per single-GPU BASELINE configuration (configs[1], [2], [4], and [3]'s workload on one "
+                         "GPU), each with the reference timed beside it on this box's host cores")
     args = ap.parse_args()
+    if args.all_configs:
+        return main_all_configs(args)
     if args.quality == 1:
         return main_q1(args)
 
@@ -344,9 +377,10 @@ def main():
 
     gathered = None
     stream = None
+    pad_hint = 0
 
     def step():
-        nonlocal gathered, stream
+        nonlocal gathered, stream, pad_hint
         got = {}
 
         def encode_local():
@@ -356,7 +390,7 @@ def main():
             # C1: one all-gather of the sizes, one of the padded payloads, padding stripped —
             # all of it inside the timed region (brotli_amd/dist.py, shared with the gloo test)
             from brotli_amd.dist import sharded_step
-            stream, _, gathered = sharded_step(encode_local, scratch=gathered)
+            stream, _, gathered, pad_hint = sharded_step(encode_local, scratch=gathered, pad_hint=pad_hint)
         else:
             encode_local()
         return got["nbytes"], got["info"]

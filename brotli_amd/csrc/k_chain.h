@@ -600,6 +600,7 @@ struct CReplay {
   uint32_t obnd;         // position where old command oi's insert run begins
   int32_t odc[4];        // distance cache of the old parse there
   const uint8_t* ev;     // event bitmap, bit (x - first)
+  uint32_t next_ev;      // no event in [the group's position, next_ev); next_ev is one, or the tile's end
   uint32_t changed;      // generic commits of this sweep
 };
 // Distance an old command's code stands for (ComputeDistanceCode backwards, backward_references.c:87-109).
@@ -610,25 +611,52 @@ DEV uint32_t c_code_distance(uint32_t code, int32_t d0, int32_t d1, int32_t d2, 
   const uint32_t base = (uint32_t)(k < 6u ? d0 : d1), mag = (kk >> 1) + 1u;
   return (kk & 1u) ? base + mag : base - mag;
 }
-DEV bool c_ev_any(const uint8_t* ev, uint32_t first, uint32_t a, uint32_t b) {   // an event bit in positions [a, b]?
-  const uint32_t* w = (const uint32_t*)ev;
-  const uint32_t ba = a - first, bb = b - first;
-  for (uint32_t i = ba >> 5; i <= (bb >> 5); ++i) {
-    uint32_t m = 0xFFFFFFFFu;
-    if (i == (ba >> 5)) m &= 0xFFFFFFFFu << (ba & 31u);
-    if (i == (bb >> 5)) m &= 0xFFFFFFFFu >> (31u - (bb & 31u));
-    if (w[i] & m) return true;
-  }
-  return false;
+// Inclusive sum over the lanes 0 .. t of a group (row rotations, no LDS).
+DEV uint32_t q_incl_scan(uint32_t v) {
+  const int t = q_t();
+  uint32_t o;
+  o = wave_row_ror(v, 1); if (t >= 1) v += o;
+  o = wave_row_ror(v, 2); if (t >= 2) v += o;
+  o = wave_row_ror(v, 4); if (t >= 4) v += o;
+  o = wave_row_ror(v, 8); if (t >= 8) v += o;
+  return v;
 }
+// First event at or behind `from` (for the groups in `act`), `limit` if there is none below it: the 16 lanes of
+// a group look at 16 words of the bitmap per round.
+DEV uint32_t c_next_event(const uint8_t* ev, uint32_t first, bool act, uint32_t from, uint32_t limit) {
+  const uint32_t t = (uint32_t)q_t();
+  const uint32_t* w = (const uint32_t*)ev;
+  uint32_t word0 = (from - first) >> 5;
+  uint32_t found = limit;
+  bool scanning = act && from < limit;
+  while (wave_any(scanning)) {
+    const uint32_t i = word0 + t;
+    uint32_t v = 0;
+    if (scanning && i * 32u + first < limit) v = w[i];
+    if (i == ((from - first) >> 5)) v &= 0xFFFFFFFFu << ((from - first) & 31u);
+    const uint32_t m16 = q_mask16(wave_ballot(v != 0));
+    const int j = m16 ? dev_ctz32(m16) : 0;
+    const uint32_t vj = q_bcast(v, j);
+    if (scanning) {
+      if (m16 != 0) { found = umin(limit, first + (word0 + (uint32_t)j) * 32u + (uint32_t)dev_ctz32(vj | 0x80000000u)); scanning = false; }
+      else { word0 += 16u; if (word0 * 32u + first >= limit) scanning = false; }
+    }
+  }
+  return found;
+}
+// Sixteen old commands per round, one per lane: their boundaries by a scan, their distances and the distance
+// cache by a walk over the lanes in registers, the conditions per lane; the leading commands that hold are
+// taken over at once.
 DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, uint32_t htl) {
   QShard& g = C.g;
   const int t = q_t();
   const uint32_t limit = J.max_backward_limit;
   for (;;) {
-    bool can = alive && g.state == Q_SEARCH && g.st_count == 0;
+    bool can = alive && g.state == Q_SEARCH && g.st_count == 0 && g.dict_matches < (g.dict_lookups >> 7);
+    // (while the static dictionary is still consulted — the first kilobytes of a shard — its two counters are
+    // part of the state and only real searches keep them: no replay until the gate has closed, hash.h:186)
     const uint32_t nb = g.position - g.insert_length;
-    // the old parse's state at (or past) this boundary
+    // the old parse's state at (or past) this boundary: only behind generic commits is there anything to skip
     while (can && R.oi < R.on && R.obnd < nb) {
       const Command c = R.old[R.oi];
       const uint32_t code = c.dist_extra, pc = R.obnd + c.insert_len;
@@ -638,40 +666,73 @@ DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, u
       ++R.oi;
     }
     can = can && R.oi < R.on && R.obnd == nb && R.odc[0] == g.dc[0] && R.odc[1] == g.dc[1] && R.odc[2] == g.dc[2] && R.odc[3] == g.dc[3];
+    // the next event at or behind the group's position
+    {
+      const bool rescan = can && g.position > R.next_ev;
+      if (wave_any(rescan)) {
+        const uint32_t ne = c_next_event(R.ev, C.geo.first, rescan, g.position, C.tile_hi);
+        if (rescan) R.next_ev = ne;
+      }
+    }
+    const uint32_t k = R.oi + (uint32_t)t;
+    const bool have = can && k < R.on;
     Command c;
     c.insert_len = c.copy_len = c.dist_extra = 0; c.cmd_prefix = c.dist_prefix = 0;
-    if (can) c = R.old[R.oi];
-    const uint32_t pc = R.obnd + c.insert_len, L = c.copy_len & 0x1FFFFFFu, code = c.dist_extra;
-    const uint32_t dist = c_code_distance(code, g.dc[0], g.dc[1], g.dc[2], g.dc[3]);
+    if (have) c = R.old[k];
+    const uint32_t I = c.insert_len, L = c.copy_len & 0x1FFFFFFu, code = c.dist_extra;
+    const uint32_t span = have ? I + L : 0u;
+    const uint32_t bnd = R.obnd + q_incl_scan(span) - span;      // the boundary before this lane's command
+    const uint32_t pc = bnd + I;
     const uint32_t dictionary_start = umin(pc + g.stream_offset, limit);
-    // (while the static dictionary is still consulted — the first kilobytes of a shard — its two counters are
-    // part of the state and only real searches keep them: no replay until the gate has closed, hash.h:186)
-    bool ok = can && g.dict_matches < (g.dict_lookups >> 7) && pc >= g.position && pc + htl < g.pos_end && pc <= g.apply_random_heuristics &&
-              (c.dist_prefix & CMDF_SPREE) == 0 && (c.copy_len >> 25) == 0u && dist <= dictionary_start && L >= 2u;
-    if (ok) ok = !c_ev_any(R.ev, C.geo.first, g.position, umin(pc + 1u, g.pos_end - 1u));
-    if (!wave_any(ok)) break;
-    if (ok) {
-      // the positions passed over by the old parse before this command are marked already; the searched ones stored
-      const uint32_t L0 = umin(L, g.pos_end - pc);              // (ExtendLastCommand adds the rest again at the next block)
-      if (dist <= dictionary_start && code > 0u) {
-        g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)dist;
-        R.odc[3] = R.odc[2]; R.odc[2] = R.odc[1]; R.odc[1] = R.odc[0]; R.odc[0] = (int32_t)dist;
-      }
-      if (t == 0) {
-        Command n;
-        n.insert_len = c.insert_len; n.copy_len = L0; n.dist_extra = code; n.cmd_prefix = CMD_RAW; n.dist_prefix = c.dist_prefix;
-        g.cmds[g.r.ncmds] = n;
-      }
-      ++g.r.ncmds;
-      g.r.nlits += c.insert_len;
-      g.insert_length = 0;
-      g.apply_random_heuristics = pc + 2u * L0 + J.spree_window;
-      g.position = pc + L0;
-      C.frontier = umax(C.frontier, g.position);
-      R.obnd = pc + L;
-      ++R.oi;
+    // distances and the cache behind every command, lane by lane (registers only)
+    int32_t x0 = g.dc[0], x1 = g.dc[1], x2 = g.dc[2], x3 = g.dc[3];
+    int32_t a0 = x0, a1 = x1, a2 = x2, a3 = x3;                  // ... behind this lane's command
+    uint32_t dist = 0;
+    const uint32_t nhave = (uint32_t)__builtin_popcount(q_mask16(wave_ballot(have)));
+    const uint32_t nmax = wave_max_u32(nhave);
+    for (uint32_t j = 0; j < nmax; ++j) {
+      const uint32_t cj = q_bcast(code, (int)j), dsj = q_bcast(dictionary_start, (int)j);
+      const uint32_t dj = c_code_distance(cj, x0, x1, x2, x3);
+      if (j < nhave && dj <= dsj && cj > 0u) { x3 = x2; x2 = x1; x1 = x0; x0 = (int32_t)dj; }
+      if ((uint32_t)t == j) { dist = dj; a0 = x0; a1 = x1; a2 = x2; a3 = x3; }
     }
-    if (wave_any(alive && g.state != Q_DONE && !ok)) break;      // somebody needs the generic step
+    const uint32_t L0 = umin(L, g.pos_end - umin(pc, g.pos_end));        // (ExtendLastCommand adds the rest again at the next block)
+    const uint32_t arh_next = pc + 2u * L0 + J.spree_window;
+    const uint32_t arh_prev = wave_row_ror(arh_next, 1);
+    const uint32_t arh = t == 0 ? g.apply_random_heuristics : arh_prev;
+    const uint32_t from = t == 0 ? g.position : bnd;
+    const bool ok = have && pc >= from && pc + htl < g.pos_end && pc <= arh && (c.dist_prefix & CMDF_SPREE) == 0 &&
+                    (c.copy_len >> 25) == 0u && dist <= dictionary_start && L >= 2u && c.cmd_prefix == CMD_RAW &&
+                    umin(pc + 1u, g.pos_end - 1u) < R.next_ev;
+    const uint32_t m = (uint32_t)dev_ctz32(~q_mask16(wave_ballot(ok)) | 0x10000u);   // leading commands that hold
+    if (!wave_any(m != 0)) break;
+    const uint32_t ins_sum = q_incl_scan(have ? I : 0u);
+    if ((uint32_t)t < m) {
+      Command n;
+      n.insert_len = I; n.copy_len = L0; n.dist_extra = code; n.cmd_prefix = CMD_RAW; n.dist_prefix = c.dist_prefix;
+      g.cmds[g.r.ncmds + (uint32_t)t] = n;
+    }
+    {
+      // the state behind the last command taken over (every lane takes part in the shuffles)
+      const int last = q_base() | (int)(m != 0 ? m - 1u : 0u);
+      const uint32_t n0 = wave_shfl((uint32_t)a0, last), n1 = wave_shfl((uint32_t)a1, last);
+      const uint32_t n2 = wave_shfl((uint32_t)a2, last), n3 = wave_shfl((uint32_t)a3, last);
+      const uint32_t nl = wave_shfl(ins_sum, last), na = wave_shfl(arh_next, last);
+      const uint32_t np = wave_shfl(pc + L0, last), no = wave_shfl(pc + L, last);
+      if (m != 0) {
+        g.dc[0] = (int32_t)n0; g.dc[1] = (int32_t)n1; g.dc[2] = (int32_t)n2; g.dc[3] = (int32_t)n3;
+        R.odc[0] = g.dc[0]; R.odc[1] = g.dc[1]; R.odc[2] = g.dc[2]; R.odc[3] = g.dc[3];
+        g.r.ncmds += m;
+        g.r.nlits += nl;
+        g.insert_length = 0;
+        g.apply_random_heuristics = na;
+        g.position = np;
+        C.frontier = umax(C.frontier, g.position);
+        R.obnd = no;
+        R.oi += m;
+      }
+    }
+    if (wave_any(alive && g.state != Q_DONE && m == 0u)) break;      // somebody needs the generic step
   }
 }
 
@@ -754,7 +815,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   // ---- a tile of a tiled job: where it starts from (wave operations stay outside the per-group branches) ----
   uint32_t warm = 0;                                   // 1: the group is in the warm-up of a speculative start
   CReplay R;
-  R.old = g.cmds; R.oi = R.on = 0; R.obnd = 0; R.changed = 0;
+  R.old = g.cmds; R.oi = R.on = 0; R.obnd = 0; R.changed = 0; R.next_ev = 0;
   R.odc[0] = R.odc[1] = R.odc[2] = R.odc[3] = 0;
   R.ev = ixb + L.ev;
   {
@@ -838,6 +899,10 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       TR->used_insert = TR->in_insert;
     }
     wave_sync();
+    if (sweep) {
+      const uint32_t ne = c_next_event(R.ev, C.geo.first, alive, umax(C.tile_lo, C.geo.first), C.tile_hi);
+      R.next_ev = alive ? ne : 0u;
+    }
   }
   const bool participated = g.state != Q_DONE;
 

@@ -14,7 +14,8 @@
 #define IX_NB_MAX_LOG2 10u                    // first-level buckets by the top key bits: 2^8 .. 2^10 per shard
 #define IX_NB_MAX (1u << IX_NB_MAX_LOG2)      //   (JobParams::ix_nb_log2, chosen so that a bucket holds ~256 positions)
 #ifndef IX_LROWS
-#define IX_LROWS 8u                           // a bucket of <= 64 * IX_LROWS entries is sorted and searched in LDS
+#define IX_LROWS 5u                           // a bucket of <= 64 * IX_LROWS entries is sorted and searched in LDS: 6.6 KB per
+                                              //   wave, five waves per SIMD (8 rows: 11 KB, 3.5 waves, +5.7 ms per GiB — profiles/r03_c)
 #endif
 #define IX_CAP 40u                            // bytes compared per candidate by ix_bucket
 #define IX_KIND_NONE 0u

@@ -20,7 +20,7 @@
 #define CHAIN_WAVES 3
 #endif
 #ifndef IXB_WAVES
-#define IXB_WAVES 4
+#define IXB_WAVES 5
 #endif
 #ifndef BUILD_WAVES
 #define BUILD_WAVES 4

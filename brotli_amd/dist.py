@@ -16,43 +16,62 @@ def rank_params(rank, world, piece_bytes, total_bytes):
     return rank * piece_bytes, rank == world - 1, min(total_bytes, 1 << 30)
 
 
-def gather_stream(local, nbytes, group=None, scratch=None, align=256):
-    """local: 1-D uint8 tensor holding this rank's compressed piece in
-    local[:nbytes] (its storage must extend to the padded size).  Returns
-    (padded all-gather buffer, sizes tensor, padded_piece_len); the stream is
-    cat(buffer[r * pad : r * pad + sizes[r]])."""
+def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0):
+    """local: 1-D uint8 tensor holding this rank's compressed piece in local[:nbytes].  Returns (padded
+    all-gather buffer, sizes as a list of ints, padded_piece_len); the stream is
+    cat(buffer[r * pad : r * pad + sizes[r]]).
+
+    Both collectives are enqueued back to back: the payload gather does not wait for the host to read the
+    sizes.  Its slot size is `pad_hint` (what the previous step needed — the steps of a job compress the
+    same pieces) or, the first time, this rank's own size plus a margin; the ONE host read of the step —
+    the gathered sizes, needed to cut the padding off anyway — tells afterwards whether every piece fitted,
+    and only a piece that did not makes the gather run again with the right slot."""
     world = dist.get_world_size(group)
     dev = local.device
     sizes = torch.zeros(world, dtype=torch.int64, device=dev)
     mine = torch.tensor([nbytes], dtype=torch.int64, device=dev)
     dist.all_gather_into_tensor(sizes, mine, group=group)
-    pad = int(sizes.max().item())
-    pad = (pad + align - 1) // align * align
-    if local.numel() < pad:
-        grown = torch.zeros(pad, dtype=torch.uint8, device=dev)
-        grown[:nbytes] = local[:nbytes]
-        local = grown
-    if scratch is None or scratch.numel() < world * pad:
-        scratch = torch.empty(world * pad, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(scratch[:world * pad], local[:pad].contiguous(), group=group)
-    return scratch, sizes, pad
+
+    def gather(pad, local, scratch):
+        if local.numel() < pad:
+            grown = torch.zeros(pad, dtype=torch.uint8, device=dev)
+            grown[:nbytes] = local[:nbytes]
+            local = grown
+        if scratch is None or scratch.numel() < world * pad:
+            scratch = torch.empty(world * pad, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(scratch[:world * pad], local[:pad].contiguous(), group=group)
+        return scratch
+
+    def round_up(v):
+        return (int(v) + align - 1) // align * align
+    # every rank must choose the same slot: the hint is the same everywhere (it comes from gathered sizes);
+    # without one the slot has to wait for the sizes
+    pad = round_up(pad_hint) if pad_hint else 0
+    if pad:
+        scratch = gather(pad, local, scratch)
+    host_sizes = [int(v) for v in sizes.cpu()]               # the step's one host read
+    need = round_up(max(host_sizes))
+    if need > pad:
+        pad = need
+        scratch = gather(pad, local, scratch)
+    return scratch, host_sizes, pad
 
 
 def compact(buffer, sizes, pad):
-    """Removes the padding: the final contiguous stream (uint8 tensor)."""
-    parts = [buffer[r * pad:r * pad + int(n)] for r, n in enumerate(sizes.tolist())]
-    return torch.cat(parts)
+    """Removes the padding: the final contiguous stream (uint8 tensor).  `sizes`: host integers."""
+    return torch.cat([buffer[r * pad:r * pad + n] for r, n in enumerate(sizes)])
 
 
-def sharded_step(encode_local, group=None, scratch=None):
+def sharded_step(encode_local, group=None, scratch=None, pad_hint=0):
     """One step of the N-rank job, the same code for bench.py (RCCL, device tensors) and the gloo
     test (CPU tensors): encode this rank's piece, all-gather, strip the padding.  The pieces of
     one stream compress to within a few per cent of each other, so the padded gather moves hardly
     more than the stream itself; an exact-size gather would cost `world` broadcasts instead of one
-    collective.  encode_local() -> (uint8 tensor, nbytes).  Returns (stream, sizes, gather buffer)."""
+    collective.  encode_local() -> (uint8 tensor, nbytes).  Returns (stream, sizes, gather buffer, pad):
+    hand `pad` back as pad_hint of the next step."""
     local, nbytes = encode_local()
-    buf, sizes, pad = gather_stream(local, nbytes, group=group, scratch=scratch)
-    return compact(buf, sizes, pad), sizes, buf
+    buf, sizes, pad = gather_stream(local, nbytes, group=group, scratch=scratch, pad_hint=pad_hint)
+    return compact(buf, sizes, pad), sizes, buf, pad
 
 
 def same_stream_on_all_ranks(stream, group=None):

@@ -41,9 +41,10 @@ def _worker(rank, world, port, q):
         local = torch.zeros(len(comp) + 4096, dtype=torch.uint8)
         local[:len(comp)] = torch.frombuffer(bytearray(comp), dtype=torch.uint8)
         return local, len(comp)
-    scratch = None
-    for _ in range(2):      # (the second step reuses the gather buffer, as bench.py's steps do)
-        stream_t, sizes, scratch = sharded_step(encode_local, scratch=scratch)
+    scratch, pad = None, 0
+    for hint in (0, None, 256):   # first step: no hint; then the previous step's slot, as bench.py's steps do; then a
+        #                           hint that is too small (the gather must notice and run again)
+        stream_t, sizes, scratch, pad = sharded_step(encode_local, scratch=scratch, pad_hint=pad if hint is None else hint)
     same, _ = same_stream_on_all_ranks(stream_t)
     stream = stream_t.numpy().tobytes()
     # every rank holds the same, complete stream
@@ -52,7 +53,7 @@ def _worker(rank, world, port, q):
         m = min(shard, total - off, piece - off % piece)
         want_parts.append(o.encode_shard(data[off:off + m], 5, 22, hint, off, off + m == total))
         off += m
-    ok = same and stream == b"".join(want_parts) and int(sizes.sum().item()) == len(stream)
+    ok = same and stream == b"".join(want_parts) and sum(sizes) == len(stream)
     q.put((rank, ok, len(stream)))
     dist.barrier()
     dist.destroy_process_group()
