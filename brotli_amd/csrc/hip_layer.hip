@@ -468,7 +468,11 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       uint32_t tc[16];
       for (int pass = 0; pass < 12 && !settled; ++pass) {
         HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_START, 0, 2 * sizeof(uint32_t), c->stream));
-        hipLaunchKernelGGL(k_tile_events, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
+        {
+          JobArgs e = a;
+          if (pass != 0) e.J.flags |= JOB_FLAG_SWEEP;     // (first pass: cross-tile successors only, k_tile.h)
+          hipLaunchKernelGGL(k_tile_events, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, e);
+        }
         hipLaunchKernelGGL(k_tile_verify, dim3(nshards), dim3(64), 0, c->stream, a);
         HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
         HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -479,7 +483,13 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
         if (tc[TILE_CNT_START] == 0 && tc[TILE_CNT_FLIPS] == 0) { settled = true; break; }
         JobArgs b = a;
         b.J.flags |= JOB_FLAG_SWEEP;
-        hipLaunchKernelGGL(k_chain_sweep, cgrid, dim3(64), clds, c->stream, b);
+        // a sweep is a few hundred dependent steps per tile around its events: one tile per wave, so that no tile
+        // waits for the steps of three others (BROTLI_AMD_SWEEP_GROUPS: 1, 2 or 4 tiles per wave)
+        uint32_t sg = 1;
+        if (const char* e = getenv("BROTLI_AMD_SWEEP_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) sg = (uint32_t)v; }
+        b.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
+        if (sg != 4) b.J.flags |= sg << JOB_FLAG_GROUPS_SHIFT;
+        hipLaunchKernelGGL(k_chain_sweep, dim3((ntiles + sg - 1) / sg), dim3(64), sg * C_GROUP_LDS_WORDS * 4u, c->stream, b);
         ++tile_sweeps;
         lap("sweep");
       }

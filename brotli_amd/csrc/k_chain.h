@@ -566,10 +566,11 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
         if (sr_dist <= dictionary_start && code > 0u) {
           g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)sr_dist;
         }
+        const uint32_t dflags = q_dict_flags(g);
         if (t == 0) {
           Command c;
           c.insert_len = ins; c.copy_len = sr_len; c.dist_extra = code; c.cmd_prefix = CMD_RAW;
-          c.dist_prefix = (uint16_t)(tt == 4u ? CMDF_NOPROBE : 0u);
+          c.dist_prefix = (uint16_t)((tt == 4u ? CMDF_NOPROBE : 0u) | dflags);
           g.cmds[g.r.ncmds] = c;
         }
         ++g.r.ncmds;
@@ -652,9 +653,7 @@ DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, u
   const int t = q_t();
   const uint32_t limit = J.max_backward_limit;
   for (;;) {
-    bool can = alive && g.state == Q_SEARCH && g.st_count == 0 && g.dict_matches < (g.dict_lookups >> 7);
-    // (while the static dictionary is still consulted — the first kilobytes of a shard — its two counters are
-    // part of the state and only real searches keep them: no replay until the gate has closed, hash.h:186)
+    bool can = alive && g.state == Q_SEARCH && g.st_count == 0;
     const uint32_t nb = g.position - g.insert_length;
     // the old parse's state at (or past) this boundary: only behind generic commits is there anything to skip
     while (can && R.oi < R.on && R.obnd < nb) {
@@ -705,8 +704,11 @@ DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, u
                     (c.copy_len >> 25) == 0u && dist <= dictionary_start && L >= 2u && c.cmd_prefix == CMD_RAW &&
                     umin(pc + 1u, g.pos_end - 1u) < R.next_ev;
     const uint32_t m = (uint32_t)dev_ctz32(~q_mask16(wave_ballot(ok)) | 0x10000u);   // leading commands that hold
+    SIM_COUNT(15, 1);
     if (!wave_any(m != 0)) break;
     const uint32_t ins_sum = q_incl_scan(have ? I : 0u);
+    // the static dictionary's two counters move as they did when the commands were decided (hash.h:49-50, 186)
+    const uint32_t dict_sum = q_incl_scan(have ? ((uint32_t)(c.dist_prefix >> CMDF_LOOKUPS_SHIFT) & 255u) | (((uint32_t)c.dist_prefix >> 10) & 15u) << 16 : 0u);
     if ((uint32_t)t < m) {
       Command n;
       n.insert_len = I; n.copy_len = L0; n.dist_extra = code; n.cmd_prefix = CMD_RAW; n.dist_prefix = c.dist_prefix;
@@ -718,12 +720,14 @@ DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, u
       const uint32_t n0 = wave_shfl((uint32_t)a0, last), n1 = wave_shfl((uint32_t)a1, last);
       const uint32_t n2 = wave_shfl((uint32_t)a2, last), n3 = wave_shfl((uint32_t)a3, last);
       const uint32_t nl = wave_shfl(ins_sum, last), na = wave_shfl(arh_next, last);
-      const uint32_t np = wave_shfl(pc + L0, last), no = wave_shfl(pc + L, last);
+      const uint32_t np = wave_shfl(pc + L0, last), no = wave_shfl(pc + L, last), nd = wave_shfl(dict_sum, last);
       if (m != 0) {
         g.dc[0] = (int32_t)n0; g.dc[1] = (int32_t)n1; g.dc[2] = (int32_t)n2; g.dc[3] = (int32_t)n3;
         R.odc[0] = g.dc[0]; R.odc[1] = g.dc[1]; R.odc[2] = g.dc[2]; R.odc[3] = g.dc[3];
         g.r.ncmds += m;
         g.r.nlits += nl;
+        g.dict_lookups += nd & 0xFFFFu; g.dict_matches += nd >> 16;
+        g.dict_mark_l = g.dict_lookups; g.dict_mark_m = g.dict_matches;
         g.insert_length = 0;
         g.apply_random_heuristics = na;
         g.position = np;
@@ -950,7 +954,11 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       ++nsteps;
       QP_ADD(g, 0, qt);
       // ---- evaluation: lane (kpos, idc) ----
-      const CEval ce = c_evaluate(J, C, want, P0, kpos, idc, force_slow, htl);
+      CEval ce;
+      if (sweep) {      // every search of a sweep is exact: nothing to evaluate from the index
+        ce.e_flags = K_MIN_SCORE | ((want && P0 + (uint32_t)kpos + htl <= g.pos_end) ? 0xC0000000u : 0u);
+        ce.e_len = ce.e_dist = 0;
+      } else ce = c_evaluate(J, C, want, P0, kpos, idc, force_slow, htl);
       const uint32_t e_flags = ce.e_flags, e_len = ce.e_len, e_dist = ce.e_dist;
       QP_ADD(g, 1, qt);
       QP_ADD(g, 2, qt);

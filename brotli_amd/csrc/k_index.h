@@ -26,10 +26,11 @@
 //     of visit as the tie break) and stores the arg-max in res[P];
 //   * the serial chain (k_chain.h) walks CreateBackwardReferences with res[P]
 //     plus the distance-cache candidates it computes itself.  It keeps a bitmap
-//     of the positions of F it did NOT store and a Bloom filter of their keys;
-//     a search whose key may be affected, or whose result the index marked as
-//     not decidable in isolation, is redone exactly from the sorted array
-//     (`srt`), so the output never depends on how often the shortcut applied.
+//     of the positions of F it did NOT store and sets a taint bit in res[] of the
+//     (at most 16) positions that follow such a position in its key run; a search
+//     that is tainted, or whose result the index marked as not decidable in
+//     isolation, is redone exactly from the sorted array (`srt`), so the output
+//     never depends on how often the shortcut applied.
 //
 // Everything here is one 64-lane wave per workgroup, no inter-workgroup
 // communication inside a kernel; kernels hand over through HBM.
@@ -75,12 +76,15 @@ DEV bool ix_searchable(const IxGeom& g, uint32_t x) {
   return x + g.htl <= ix_block_end(g, x);
 }
 
-// The 16 bytes at the entry's position and its full bucket key (w1).
+// The 16 bytes at the entry's position, its full bucket key (w1), and its tag in place of the low key bits the
+// entry travelled with (w0 = position | tag << 24 from here on: what the window search compares and srt[] keeps).
 DEV void ix_fetch(const JobParams& J, const uint8_t* data, IxEntry& e) {
   uint64_t b[2];
   __builtin_memcpy(b, data + (e.w0 & 0xFFFFFFu), 16);
   e.d = b[0]; e.d2 = b[1];
-  e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key;
+  const KeyTag kt = hash_pos(e.d, J.hasher_type, J.bucket_bits);
+  e.w1 = kt.key;
+  e.w0 = (e.w0 & 0xFFFFFFu) | (kt.tag << 24);
 }
 
 // Lanes of the wave whose `v` (nbits wide) equals this lane's, among the lanes with `act`.
@@ -162,7 +166,7 @@ DEV void ix_scan(const JobParams& J, const ShardDesc& D, uint8_t* ws) {
 // A row of 64 consecutive positions lands in ~64 different buckets: written straight to HBM that
 // is one 4-byte transaction per entry (measured: 1 G transactions bound the kernel at 16 ms per
 // GiB).  So the slice goes through LDS in chunks of IX_CHUNK positions: counted, scanned and
-// counting-sorted by bucket inside the chunk (entries packed as chunk-relative position | tag |
+// counting-sorted by bucket inside the chunk (entries packed as chunk-relative position | low key bits |
 // bucket), then copied out index by index — neighbours in LDS are neighbours in their bucket's
 // range, and a bucket's share of a chunk leaves as one contiguous piece.
 #define IX_CHUNK 2048u
@@ -199,7 +203,7 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
       if (x < c1 && ix_storable(g, x)) {
         const KeyTag kt = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits);
         const uint32_t b = kt.key >> shift;
-        pk[r] = (x - c0) | (kt.tag << 11) | (b << 19);
+        pk[r] = (x - c0) | ((kt.key & ((1u << shift) - 1u)) << 11) | (b << 19);    // position | low key bits | bucket
         lds_atomic_add(&start[b], 1u);
       }
     }
@@ -496,12 +500,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   // ---- a bigger bucket: sorted through HBM (ent -> ent2), searched row by row ----
   for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
     const uint32_t i = r0 + (uint32_t)lane;
-    if (i < m) {
-      IxEntry e;
-      e.w0 = ent[start + i];
-      ix_fetch(J, data, e);
-      lds_atomic_add(&bins[e.w1 & lowmask], 1u);
-    }
+    if (i < m) lds_atomic_add(&bins[ent[start + i] >> 24], 1u);     // (the entry carries its low key bits: no fetch)
   }
   wave_sync();
   {
@@ -517,10 +516,8 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
     const uint32_t i = r0 + (uint32_t)lane;
     const bool act = i < m;
-    IxEntry e;
-    e.w0 = e.w1 = 0; e.d = e.d2 = 0;
-    if (act) { e.w0 = ent[start + i]; ix_fetch(J, data, e); }
-    const uint32_t kl = e.w1 & lowmask;
+    const uint32_t ew = act ? ent[start + i] : 0u;
+    const uint32_t kl = ew >> 24;
     const uint64_t same = ix_match_any(act, kl, lowbits);
     const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
     const uint32_t total = (uint32_t)dev_popc64(same);
@@ -529,7 +526,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     wave_sync();
     if (act && rank + 1u == total) cursor[kl] = at + total;
     wave_sync();
-    if (act) ent2[start + at + rank] = e.w0;
+    if (act) ent2[start + at + rank] = ew;
   }
   wave_sync();
   // staged entries 0..15 = the last 16 entries of the previous row, 16 + lane = this row's

@@ -28,9 +28,10 @@
                                               //   stored by the parse, so the index result of p does not hold (k_chain.h)
 #define IX_DANGER 0x80000000u                 // the bucket counter may have wrapped (>= 65520 stores of one key)
 
-// Entry of the sort as it travels through HBM: position | tag << 24 (4 bytes).  The bucket pass
-// re-reads the 16 bytes at the position from the shard's input (which sits in the L2) and keeps
-// {w0, key, bytes 0..7, bytes 8..15} per entry in registers / LDS.
+// Entry of the sort as it travels through HBM: position | (low bits of the key: the ones the first level did not
+// sort by) << 24 (4 bytes) — a bucket too big for LDS is sorted by them without looking at the input again.  The
+// bucket pass re-reads the 16 bytes at the position from the shard's input (which sits in the L2) once and keeps
+// {position | tag << 24, key, bytes 0..7, bytes 8..15} per entry in registers / LDS; srt[] gets position | tag << 24.
 struct IxEntry { uint32_t w0, w1; uint64_t d, d2; };
 
 // Index region of one shard, offsets relative to ShardDesc::ix_off.

@@ -113,9 +113,20 @@ struct QShard {
   uint32_t lim_len = 0xFFFFFFFFu, lim_op = 0xFFFFFFFFu, lim_cmd_cap = 0xFFFFFFFFu;
   // k_chain.h: commands are left raw (CMD_RAW, enc_types.h) with CMDF_* in dist_prefix
   uint32_t raw_cmds = 0, cmd_flags = 0;
+  // ... and with the static-dictionary lookups / matches (hash.h:49-50) counted since the last command or block
+  // start, so that a replay of the command (k_chain.h sweeps) keeps the two counters without searching
+  uint32_t dict_mark_l = 0, dict_mark_m = 0;
 };
 #define CMDF_NOPROBE 1u    // the position behind the copy's start was not searched (the lazy chain ended on an advance)
 #define CMDF_SPREE 2u      // the literal spree (backward_references_inc.h:208-236) skipped searches before this command
+                           //   (or the counts below did not fit): a sweep parses this command again
+#define CMDF_LOOKUPS_SHIFT 2u   // 8 bits: dictionary lookups, 4 bits from bit 10: matches, while the command was decided
+DEV uint32_t q_dict_flags(QShard& g) {
+  const uint32_t dl = g.dict_lookups - g.dict_mark_l, dm = g.dict_matches - g.dict_mark_m;
+  g.dict_mark_l = g.dict_lookups;
+  g.dict_mark_m = g.dict_matches;
+  return (dl > 255u || dm > 15u) ? CMDF_SPREE : (dl << CMDF_LOOKUPS_SHIFT) | (dm << 10);
+}
 
 DEV const ShardDesc& q_desc(const QShard& g) { return g.descs[g.shard]; }
 DEV uint32_t q_len(const QShard& g) { return g.lim_len != 0xFFFFFFFFu ? g.lim_len : q_desc(g).len; }
@@ -728,6 +739,8 @@ DEV void q_setup_extend(const JobParams& J, QShard& g, bool want) {
     g.store_end = bytes >= htl ? g.pos_end - htl + 1u : pos;
     g.insert_length = g.r.last_insert_len;
     g.apply_random_heuristics = pos + J.spree_window;
+    g.dict_mark_l = g.dict_lookups;
+    g.dict_mark_m = g.dict_matches;
     g.state = Q_SEARCH;
   }
 }
@@ -767,9 +780,9 @@ DEV void q_commit(const JobParams& J, QShard& g, bool commit, uint32_t htl) {
       Command c;
       c.insert_len = g.insert_length;
       c.copy_len = g.sr_len | (((uint32_t)(uint8_t)(int8_t)g.sr_delta) << 25);
-      c.dist_extra = distance_code; c.cmd_prefix = CMD_RAW; c.dist_prefix = (uint16_t)g.cmd_flags;
+      c.dist_extra = distance_code; c.cmd_prefix = CMD_RAW; c.dist_prefix = (uint16_t)(g.cmd_flags | q_dict_flags(g));
       g.cmds[g.r.ncmds] = c;
-    }
+    } else (void)q_dict_flags(g);
     g.cmd_flags = 0;
   } else if (t == 0 && g.role == 0) g.cmds[g.r.ncmds] = make_command(g.insert_length, g.sr_len, g.sr_delta, distance_code);
   ++g.r.ncmds;

@@ -85,7 +85,7 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
 }
 
 // grid = nshards * ix_slices, block = 64: the slice's words of the bitmap.
-DEV void tile_events(const JobParams& J, const ShardDesc& D, uint8_t* ws, TileRec* trecs, uint32_t w, uint32_t* counters) {
+DEV void tile_events(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws, TileRec* trecs, uint32_t w, uint32_t* counters) {
   if (D.ntiles <= 1u || (trecs[D.tile_base].flags & TILE_BAD)) return;
   const uint32_t lane = (uint32_t)wave_lane();
   const uint32_t first = D.stream_offset != 0 ? 2u : 0u;
@@ -97,6 +97,8 @@ DEV void tile_events(const JobParams& J, const ShardDesc& D, uint8_t* ws, TileRe
   uint32_t* ev = (uint32_t*)(base + L.ev);
   const uint32_t* srt = (const uint32_t*)(base + L.srt);
   const uint64_t* res = (const uint64_t*)(base + L.res);
+  const uint8_t* data = input + D.in_off;
+  const uint32_t total = ((const uint32_t*)(base + L.cnt))[J.ix_slices << J.ix_nb_log2];    // sorted entries of the shard
   const uint32_t per = ix_slice_len(D.len, J.ix_slices);
   const uint32_t w_lo = (w * per) / 32u, w_hi = umin(((w + 1u) * per) / 32u, (D.len + 31u) / 32u);
   uint32_t flips = 0;
@@ -107,12 +109,22 @@ DEV void tile_events(const JobParams& J, const ShardDesc& D, uint8_t* ws, TileRe
     prev[i] = cur;
     flips += (uint32_t)__builtin_popcount(diff);
     for (; diff != 0; diff &= diff - 1u) {
+      // x changed: every later position of its key run whose ring — the 16 nearest STORED predecessors,
+      // hash_longest_match64_simd_inc.h:246-262 — reaches back to x has to be searched again: the successors of x up
+      // to the 16th one that is stored (behind a run of unstored positions that is more than 16 entries away)
       const uint32_t x = first + i * 32u + (uint32_t)dev_ctz32(diff);
-      const uint32_t hi = (uint32_t)(res[x] >> 32);
-      const uint32_t s = hi & 0xFFFFFFu, ns = (hi >> IX_NSUCC_SHIFT) & 31u;
-      for (uint32_t j = 1; j <= ns; ++j) {
-        const uint32_t b = (srt[s + j] & 0xFFFFFFu) - first;
-        glb_atomic_or(&ev[b >> 5], 1u << (b & 31u));
+      const uint32_t s = (uint32_t)(res[x] >> 32) & 0xFFFFFFu;
+      const uint32_t key = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits).key;
+      // (the first pass: a tile's own parse already knew what it had left unstored itself — only the searches
+      //  of LATER tiles went without it)
+      const uint32_t xt = (J.flags & JOB_FLAG_SWEEP) ? 0xFFFFFFFFu : (x - first) >> J.tile_log2;
+      uint32_t stored = 0;
+      for (uint32_t j = s + 1u; j < total && stored < 16u; ++j) {
+        const uint32_t q = srt[j] & 0xFFFFFFu;
+        if (hash_pos(ld64(data + q), J.hasher_type, J.bucket_bits).key != key) break;
+        const uint32_t b = q - first;
+        if ((b >> J.tile_log2) != xt) glb_atomic_or(&ev[b >> 5], 1u << (b & 31u));
+        if (!((skip[b >> 5] >> (b & 31u)) & 1u)) ++stored;
       }
     }
   }

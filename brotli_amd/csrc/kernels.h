@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(64) k_tile_verify(JobArgs a) {
 // grid = nshards * ix_slices, block = 64
 __global__ void __launch_bounds__(64) k_tile_events(JobArgs a) {
   const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
-  if (shard < a.nshards) tile_events(a.J, a.shards[shard], a.ws, a.trecs, w, a.counters);
+  if (shard < a.nshards) tile_events(a.J, a.shards[shard], a.input, a.ws, a.trecs, w, a.counters);
 }
 // grid = ntiles, block = 64
 __global__ void __launch_bounds__(64) k_tile_finish(JobArgs a) {

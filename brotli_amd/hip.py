@@ -41,6 +41,9 @@ class JobInfo(C.Structure):
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_ if k not in ("reserved", "prof")}
         d["prof"] = list(self.prof)
+        # tiled jobs (k_tile.h): sweeps of the chain, shards that left the tiled path for the plain chain
+        d["tile_sweeps"] = self.reserved & 0xFF
+        d["tile_fallback_shards"] = self.reserved >> 8
         return d
 
 

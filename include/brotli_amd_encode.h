@@ -1,5 +1,5 @@
 /* include/brotli_amd_encode.h — the drop-in boundary: the encoder C ABI of
- * google/brotli (libbrotlienc.so.1, 13 exported symbols) as
+ * google/brotli (libbrotlienc.so.1: the 13 BROTLI_ENC_API + 2 BROTLI_ENC_EXTRA_API symbols of 1.2.0) as
  * exported by brotli_amd/lib/libbrotlienc_amd.so.
  *
  * Every entry point below has the name, argument order, argument meaning and

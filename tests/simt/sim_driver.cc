@@ -44,14 +44,27 @@ void run_parse_kernel(const JobArgs& a, int reverse) {
     int rounds = 0;
     for (; rounds < 12 && !settled; ++rounds) {
       a.counters[TILE_CNT_START] = a.counters[TILE_CNT_FLIPS] = 0;
-      run(k_tile_events, a, a.nshards * a.J.ix_slices, 64, reverse);
+      {
+        JobArgs e = a;
+        if (rounds != 0 || getenv("SIM_EVENTS_ALL")) e.J.flags |= JOB_FLAG_SWEEP;     // (first pass: cross-tile successors only, k_tile.h)
+        run(k_tile_events, e, a.nshards * a.J.ix_slices, 64, reverse);
+      }
       run(k_tile_verify, a, a.nshards, 64, reverse);
       if (getenv("SIM_TILE_LOG")) fprintf(stderr, "tile round %d: start events %u, changed skip bits %u, shards off the tiled path %u\n", rounds,
                                           a.counters[TILE_CNT_START], a.counters[TILE_CNT_FLIPS], a.counters[TILE_CNT_BAD]);
       if (a.counters[TILE_CNT_START] == 0 && a.counters[TILE_CNT_FLIPS] == 0) { settled = true; break; }
       JobArgs b = a;
       b.J.flags |= JOB_FLAG_SWEEP;
-      run(k_chain_sweep, b, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+      const unsigned long long c7 = g_sim_counts[7], c15 = g_sim_counts[15], c5 = g_sim_counts[5];
+      {
+        uint32_t sg = getenv("SIM_SWEEP_GROUPS") ? (uint32_t)atoi(getenv("SIM_SWEEP_GROUPS")) : 1u;
+        if (sg != 1 && sg != 2 && sg != 4) sg = 1;
+        b.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
+        if (sg != 4) b.J.flags |= sg << JOB_FLAG_GROUPS_SHIFT;
+        run(k_chain_sweep, b, (a.ntiles + sg - 1) / sg, 64, reverse);
+      }
+      if (getenv("SIM_TILE_LOG")) fprintf(stderr, "  sweep: %llu main-loop rounds, %llu replay rounds, %llu exact resolves (%u tiles)\n",
+                                          g_sim_counts[7] - c7, g_sim_counts[15] - c15, g_sim_counts[5] - c5, a.ntiles);
     }
     if (!settled) {           // give up on the tiles: every shard the plain way
       for (uint32_t k = 0; k < a.nshards; ++k) if (a.shards[k].ntiles > 1) a.trecs[a.shards[k].tile_base].flags |= TILE_BAD;
