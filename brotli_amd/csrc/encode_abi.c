@@ -351,10 +351,13 @@ static int submit_fast(BrotliEncoderState* s, int op) {
 /* Hands everything buffered to the device and applies `op` (1 flush, 2 finish). */
 static int submit(BrotliEncoderState* s, int op) {
   if (s->quality == 1) return submit_fast(s, op);
-  if (s->shard_bytes == 0 && s->quality != 5 && op == OP_FINISH && s->submitted == 0 && !s->stream &&
-      s->in_len != 0 && s->ndicts == 0) {
-    /* Qualities 6-9, everything in one FINISH: the same bytes come from a one-shard job
-       (falls through to the plan code below with shard size 0 = one shard). */
+  if (s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream &&
+      s->in_len != 0 && s->ndicts == 0 &&
+      (s->quality != 5 || (s->lgwin >= 17 && s->in_len <= ((size_t)1 << s->lgwin) - 16))) {
+    /* Everything in one FINISH (BrotliEncoderCompress, the CLI on a small file): the same bytes come from a
+       one-shard job (falls through to the plan code below with shard size 0 = one shard).  Qualities 6-9: any
+       length; quality 5: an input that fits the window runs the position index and the tiled chain (k_index.h,
+       k_chain.h: every tile of the stream parsed at once) instead of one wave on the whole stream. */
   } else if (s->shard_bytes == 0 && !(s->in_len == 0 && s->submitted == 0 && !s->stream)) {
     /* One encoder instance: the persistent device stream reproduces the
        reference for any op sequence (qualities 6-9: up to the window size).
