@@ -488,9 +488,11 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
   hipLaunchKernelGGL(k_init, dim3(nshards * ibs), dim3(256), 0, c->stream, a);
   HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
   float ms_index = 0;
-  // A plain indexed job with enough shards to keep every batch's chain busy: the first round in batches (run_batches).
-  // BROTLI_AMD_BATCHES: number of batches (default 4; 1 = everything on the context stream, one kernel after the other).
-  uint32_t nbatch = 4;
+  // A plain indexed job with enough shards to keep every batch's chain busy can run its first round in batches
+  // (run_batches; BROTLI_AMD_BATCHES = number of batches).  Measured and NOT the default (profiles/r03_h_batches.txt,
+  // 1 GiB text in 128 KiB shards): 1 batch 95.8 ms per step, 2: 107.8, 3: 101.7, 4: 121.8, 8: 144.5 — the chain's waves
+  // and the index kernels' waves take each other's LDS and issue slots, both get slower than what the overlap saves.
+  uint32_t nbatch = 1;
   if (const char* e = getenv("BROTLI_AMD_BATCHES")) { const int v = atoi(e); if (v >= 1 && v <= 16) nbatch = (uint32_t)v; }
   bool batched = false;
   float ms_ixb_batches = 0;

@@ -570,7 +570,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
         if (t == 0) {
           Command c;
           c.insert_len = ins; c.copy_len = sr_len; c.dist_extra = code; c.cmd_prefix = CMD_RAW;
-          c.dist_prefix = (uint16_t)((tt == 4u ? CMDF_NOPROBE : 0u) | dflags);
+          c.dist_prefix = (uint16_t)((tt == 4u ? CMDF_NOPROBE : 0u) | dflags | (umin(tt, 3u) << CMDF_DELAYED_SHIFT));
           g.cmds[g.r.ncmds] = c;
         }
         ++g.r.ncmds;
@@ -648,7 +648,15 @@ DEV uint32_t c_next_event(const uint8_t* ev, uint32_t first, bool act, uint32_t 
 // Sixteen old commands per round, one per lane: their boundaries by a scan, their distances and the distance
 // cache by a walk over the lanes in registers, the conditions per lane; the leading commands that hold are
 // taken over at once.
-DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, uint32_t htl) {
+// Score FindLongestMatch gave a match of (len, distance) under the distance cache d0..d3 (hash.h:123-138,
+// ..64_simd_inc.h:201-240): a distance the cache holds was found as a cache candidate first, with the bonus.
+DEV uint32_t c_match_score(uint32_t len, uint32_t dist, int32_t d0, int32_t d1, int32_t d2, int32_t d3) {
+  if (dist == (uint32_t)d0) return 135u * len + 1935u;
+  if (dist == (uint32_t)d1) return 135u * len + 1935u - 39u;
+  if (len >= 3u && (dist == (uint32_t)d2 || dist == (uint32_t)d3)) return 135u * len + 1935u - 43u;
+  return 1920u + 135u * len - 30u * log2floor(dist | 1u);
+}
+DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, uint32_t htl, uint32_t* scratch) {
   QShard& g = C.g;
   const int t = q_t();
   const uint32_t limit = J.max_backward_limit;
@@ -703,9 +711,52 @@ DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, u
     const bool ok = have && pc >= from && pc + htl < g.pos_end && pc <= arh && (c.dist_prefix & CMDF_SPREE) == 0 &&
                     (c.copy_len >> 25) == 0u && dist <= dictionary_start && L >= 2u && c.cmd_prefix == CMD_RAW &&
                     umin(pc + 1u, g.pos_end - 1u) < R.next_ev;
+    const bool okn = have && pc >= from && pc + htl < g.pos_end && pc <= arh && (c.dist_prefix & CMDF_SPREE) == 0 &&
+                     (c.copy_len >> 25) == 0u && dist <= dictionary_start && L >= 2u && c.cmd_prefix == CMD_RAW;
     const uint32_t m = (uint32_t)dev_ctz32(~q_mask16(wave_ballot(ok)) | 0x10000u);   // leading commands that hold
     SIM_COUNT(15, 1);
-    if (!wave_any(m != 0)) break;
+    // The group's first command holds but for an event in the positions it searched: instead of parsing it again, the
+    // searches at the event positions are done again (exactly, with the bitmap as it stands) and compared with what the
+    // command says their results were — no match at a literal in front of the lazy chain, the copy itself at the copy's
+    // start, a loser (by the margin of 175, backward_references_inc.h:139) at the probe behind it.  Only a result that
+    // differs — or one the command does not tell, a position inside the lazy chain — sends the group to the generic step.
+    {
+      const bool first_okn = q_bcast(okn ? 1u : 0u, 0) != 0;
+      bool qc = m == 0u && first_okn && g.dict_matches < (g.dict_lookups >> 7);
+      if (wave_any(qc)) {
+        const uint32_t pc0 = q_bcast(pc, 0), L0c = q_bcast(L0, 0), dist0 = q_bcast(dist, 0), fl0 = q_bcast((uint32_t)c.dist_prefix, 0);
+        const uint32_t delayed = (fl0 >> CMDF_DELAYED_SHIFT) & 3u;
+        const uint32_t rend = umin(pc0 + 1u, g.pos_end - 1u);
+        const uint32_t sc_commit = c_match_score(L0c, dist0, g.dc[0], g.dc[1], g.dc[2], g.dc[3]);
+        while (wave_any(qc)) {
+          const uint32_t e = R.next_ev;
+          bool done = qc && e > rend;                      // every event of the range is dealt with: the command holds
+          bool bad = qc && !done && e < pc0 && e + delayed >= pc0;      // inside the lazy chain
+          if (qc && !done && e == pc0 && delayed == 3u) bad = true;     // (3 = three or more: the chain's start is not known)
+          const bool skip_probe = qc && !done && !bad && e == pc0 + 1u && (fl0 & CMDF_NOPROBE) != 0;   // (was not searched)
+          const bool srch = qc && !done && !bad && !skip_probe;
+          if (wave_any(srch)) {
+            const QResult r = c_search_exact(J, C, srch, e, scratch);
+            if (srch) {
+              if (e < pc0) bad = r.score != K_MIN_SCORE;
+              else if (e == pc0) bad = !(r.len == L0c && r.distance == dist0);
+              else bad = r.score >= sc_commit + 175u;
+            }
+          }
+          const bool next = qc && !done && !bad;
+          if (wave_any(next)) {
+            const uint32_t ne = c_next_event(R.ev, C.geo.first, next, e + 1u, C.tile_hi);
+            if (next) R.next_ev = ne;
+          }
+          if (done || bad) qc = false;
+          if (bad) R.changed |= 0x80000000u;               // (statistics: quick checks that failed)
+        }
+      }
+    }
+    // (a group whose quick check passed has its first command hold now: it takes it in the next round)
+    const bool again = m == 0u && have && okn && umin(pc + 1u, g.pos_end - 1u) < R.next_ev && t == 0;
+    const bool retry = q_bcast(again ? 1u : 0u, 0) != 0;
+    if (!wave_any(m != 0) && !wave_any(retry)) break;
     const uint32_t ins_sum = q_incl_scan(have ? I : 0u);
     // the static dictionary's two counters move as they did when the commands were decided (hash.h:49-50, 186)
     const uint32_t dict_sum = q_incl_scan(have ? ((uint32_t)(c.dist_prefix >> CMDF_LOOKUPS_SHIFT) & 255u) | (((uint32_t)c.dist_prefix >> 10) & 15u) << 16 : 0u);
@@ -736,7 +787,7 @@ DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, u
         R.oi += m;
       }
     }
-    if (wave_any(alive && g.state != Q_DONE && m == 0u)) break;      // somebody needs the generic step
+    if (wave_any(alive && g.state != Q_DONE && m == 0u && !retry)) break;      // somebody needs the generic step
   }
 }
 
@@ -914,7 +965,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   while (wave_any(g.state != Q_DONE)) {
     SIM_COUNT(7, 1);                                   // chain steps (wave level)
     uint64_t qt = QP_NOW();
-    if (sweep) c_group_replay(J, C, R, alive, htl);
+    if (sweep) c_group_replay(J, C, R, alive, htl, scratch);
     else {
 #if defined(BROTLI_AMD_SIMT_SIM)
       if (!getenv("SIM_NOFAST")) c_group_fast(J, T, C, alive, scratch, nsteps);   // (test knob: generic steps only)

@@ -121,6 +121,7 @@ struct QShard {
 #define CMDF_SPREE 2u      // the literal spree (backward_references_inc.h:208-236) skipped searches before this command
                            //   (or the counts below did not fit): a sweep parses this command again
 #define CMDF_LOOKUPS_SHIFT 2u   // 8 bits: dictionary lookups, 4 bits from bit 10: matches, while the command was decided
+#define CMDF_DELAYED_SHIFT 14u  // 2 bits: by how many positions the lazy matching moved the copy's start (3 = three or more)
 DEV uint32_t q_dict_flags(QShard& g) {
   const uint32_t dl = g.dict_lookups - g.dict_mark_l, dm = g.dict_matches - g.dict_mark_m;
   g.dict_mark_l = g.dict_lookups;
@@ -780,7 +781,7 @@ DEV void q_commit(const JobParams& J, QShard& g, bool commit, uint32_t htl) {
       Command c;
       c.insert_len = g.insert_length;
       c.copy_len = g.sr_len | (((uint32_t)(uint8_t)(int8_t)g.sr_delta) << 25);
-      c.dist_extra = distance_code; c.cmd_prefix = CMD_RAW; c.dist_prefix = (uint16_t)(g.cmd_flags | q_dict_flags(g));
+      c.dist_extra = distance_code; c.cmd_prefix = CMD_RAW; c.dist_prefix = (uint16_t)(g.cmd_flags | q_dict_flags(g) | (umin(g.delayed, 3u) << CMDF_DELAYED_SHIFT));
       g.cmds[g.r.ncmds] = c;
     } else (void)q_dict_flags(g);
     g.cmd_flags = 0;
