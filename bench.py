@@ -190,6 +190,46 @@ def end_to_end_abi(data, quality, lgwin, shard_kb, want_bytes, want_sha):
                     "median of 3 (the first includes context creation)" % shard_kb}
 
 
+def stock_call(data, quality, lgwin):
+    """What a caller that knows nothing of this library gets: BrotliEncoderCompress(quality, lgwin, ...) of the drop-in
+    library with NO partition plan (BROTLI_AMD_SHARD_KB unset), on the first (1 << lgwin) - 16 bytes of the input — the
+    longest input a one-shot quality-5 call runs on the index + tiled chain; longer inputs take one wave per stream."""
+    lib_path = os.path.join(ROOT, "brotli_amd", "lib", "libbrotlienc_amd.so")
+    if not os.path.exists(lib_path) or quality != 5 or lgwin < 17:
+        return None
+    os.environ.pop("BROTLI_AMD_SHARD_KB", None)
+    L = C.CDLL(lib_path)
+    L.BrotliEncoderMaxCompressedSize.restype = C.c_size_t
+    L.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
+    L.BrotliEncoderCompress.restype = C.c_int
+    L.BrotliEncoderCompress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.c_char_p]
+    n = min(len(data), (1 << lgwin) - 16)
+    piece = data[:n]
+    cap = L.BrotliEncoderMaxCompressedSize(n)
+    out = C.create_string_buffer(cap)
+    times = []
+    for _ in range(4):
+        sz = C.c_size_t(cap)
+        t0 = time.perf_counter()
+        ok = L.BrotliEncoderCompress(quality, lgwin, 0, n, piece, C.byref(sz), out)
+        times.append(time.perf_counter() - t0)
+        if not ok:
+            return {"error": "BrotliEncoderCompress returned BROTLI_FALSE"}
+    dt = sorted(times[1:])[1]
+    res = {"bytes": n, "MBps": round(n / 1e6 / dt, 1), "seconds_all": [round(t, 4) for t in times], "out_bytes": sz.value,
+           "note": "one BrotliEncoderCompress call, no partition plan, pageable host buffers; median of calls 2-4"}
+    try:
+        from refharness import Ref, have_ref
+        if have_ref():
+            t0 = time.perf_counter()
+            want = Ref().compress(piece, quality, lgwin)
+            res["reference_1core_MBps"] = round(n / 1e6 / (time.perf_counter() - t0), 1)
+            res["bytes_equal_reference"] = want == out.raw[:sz.value]
+    except Exception as e:
+        res["reference"] = repr(e)[:200]
+    return res
+
+
 def main_q1(args):
     """BASELINE configs[2]: quality 1 (two-pass fragment compressor) on one GPU.  The stream is
     the reference's own unpartitioned stream: one BrotliEncoderCompress-style FINISH call
@@ -523,6 +563,7 @@ def main():
             line["config"]["single_stream_ratio"] = cb.get("single_stream_ratio")
             line["config"]["end_to_end_abi"] = end_to_end_abi(data, args.quality, args.lgwin, args.shard_kb, nbytes,
                                                              line["config"]["gpu_output_sha256"])
+            line["config"]["stock_call_no_plan"] = stock_call(data, args.quality, args.lgwin)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
