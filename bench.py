@@ -473,8 +473,9 @@ def main():
             kernel = "k_chain" if indexed else ("k_parse4" if args.quality == 5 else "k_parse_quick" if args.quality < 5 else "k_parse_deep")
             k_ms, k_bytes = ms_parse, (algo if not indexed else 9.0 + 16.0 * 0.4)
         achieved = k_bytes * n / (k_ms / 1e3) / 1e9
-        # HBM bytes of the dominant kernel: NOT measured by this run — a constant from PMC passes of a
-        # separate run of the same command (profiles/traffic.json names its source), null otherwise
+        # HBM bytes of the dominant kernel: not measured by this process (the counters need rocprofv3 around it) — from
+        # the PMC passes of the same command in tools/gpu_r03_f.sh, calibrated on known byte counts in the same
+        # session (profiles/traffic.json names its source), null for configurations without such a pass
         traffic, traffic_source = None, "not measured (no PMC pass on record for this configuration)"
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof) and args.workload == "text":
@@ -516,8 +517,8 @@ def main():
                                         "frac": round(path / HBM_PEAK_GBS, 5),
                                         "model": "SURVEY.md 8(d): %.0f B per input byte for the whole LZ77 parse" % algo},
                          "note": "%s: algorithmic bytes = %.1f B per input byte x %d bytes per launch; kernel "
-                                 "time %.3f ms (HIP events on the library's stream).  The parse is bound by "
-                                 "instruction issue and dependent accesses, not by bandwidth (DESIGN.md 5)" % (
+                                 "time %.3f ms (HIP events on the library's stream).  The kernel is bound by "
+                                 "latency and occupancy (its gathers, its LDS), not by bandwidth (DESIGN.md 5)" % (
                                      kernel, k_bytes, n, k_ms)},
         }
         if world == 1:

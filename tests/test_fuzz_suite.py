@@ -23,12 +23,12 @@ def sim():
     return Sim()
 
 
-@pytest.mark.parametrize("chunk", range(30))
+@pytest.mark.parametrize("chunk", range(60))
 def test_index_fuzz(sim, oracle, chunk):
     from fuzz_index_sim import make_case
     from test_sim_kernels import IX_LAYOUTS, _oracle_plan
     variants = [(l, e) for l in IX_LAYOUTS.values() for e in (0, 4)]
-    for seed in range(INDEX_BASE + 10 * chunk, INDEX_BASE + 10 * chunk + 10):
+    for seed in range(INDEX_BASE + 5 * chunk, INDEX_BASE + 5 * chunk + 5):
         data, shard, hint, rev = make_case(seed)
         flags, extra = variants[seed % len(variants)]
         got = sim.encode(data, size_hint=hint, shard_size=shard, reverse=rev, flags=flags | extra)
@@ -42,10 +42,10 @@ def test_abi_fuzz(ref, chunk):
     assert not bad
 
 
-@pytest.mark.parametrize("chunk", range(20))
+@pytest.mark.parametrize("chunk", range(40))
 def test_plan_fuzz(ref, chunk):
     import fuzz_plan_sim
-    bad = [s for s in range(PLAN_BASE + 10 * chunk, PLAN_BASE + 10 * chunk + 10) if not fuzz_plan_sim.one(s)]
+    bad = [s for s in range(PLAN_BASE + 5 * chunk, PLAN_BASE + 5 * chunk + 5) if not fuzz_plan_sim.one(s)]
     assert not bad
 
 
