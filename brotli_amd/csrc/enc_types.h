@@ -67,6 +67,7 @@ struct JobParams {
 #define JOB_FLAG_QUICK 128u    // with JOB_FLAG_DEEP: qualities 2 - 4, the HashLongestMatchQuickly family (k_parse_quick.h);
                                //   block_bits carries BUCKET_SWEEP_BITS
 #define JOB_FLAG_DEEP 16u      // one shard per wave, 32 .. 256 slots per bucket (k_parse_deep.h)
+#define JOB_FLAG_NO_LITCTX 4096u // BROTLI_PARAM_DISABLE_LITERAL_CONTEXT_MODELING (encode.c:561): k_build keeps one literal context
 #define JOB_FLAG_TILED 1024u   // indexed job whose shards are parsed tile by tile, all tiles at once: a tile starts from a
                                //   speculated state, joins are verified, differences repaired by sweeps (k_chain.h, k_tile.h)
 #define JOB_FLAG_SWEEP 2048u   // (per launch) k_chain replays the tiles' previous commands and parses again only where an

@@ -226,7 +226,7 @@ static int ensure_initialized(BrotliEncoderState* s) {
     if (s->large_window || s->shard_bytes != 0) s->failed = 1;
   } else if (s->quality < 2 || s->quality > 9 || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
       s->mode == 2 /* FONT: non-zero distance parameters, encode.c:616-640 */ ||
-      s->npostfix != 0 || s->ndirect != 0 || s->base64_mode != 0 || s->disable_ctx != 0 ||
+      s->npostfix != 0 || s->ndirect != 0 || s->base64_mode != 0 ||
       s->simd_hasher != 0 /* ENABLE / DISABLE change the hasher choice at q5-q7 */) {
     s->failed = 1;
   }
@@ -297,7 +297,8 @@ static int push_dictionaries_to(BrotliEncoderState* s, int to_context) {
 static int open_stream(BrotliEncoderState* s) {
   if (s->stream) return 1;
   if (brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
-                               s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u,
+                               (s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u) |
+                               (s->disable_ctx ? BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT : 0u),
                                &s->stream) != BROTLI_AMD_OK) return 0;
   if (s->ndicts && !push_dictionaries(s)) return 0;
   return 1;
@@ -414,6 +415,7 @@ static int submit(BrotliEncoderState* s, int op) {
     p.stream_base = (uint64_t)s->stream_offset + s->submitted;
     p.is_last = op == OP_FINISH;
     if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
+    if (s->disable_ctx) p.flags |= BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT;
     cap = brotli_amd_max_output(s->in_len, &p);
     if (cap == 0) return 0;
     if (!sync_context_dictionaries(s)) return 0;
@@ -488,6 +490,7 @@ static int forward_pending_input(BrotliEncoderState* s, int force) {
     p.stream_base = (uint64_t)s->stream_offset + s->submitted;
     p.is_last = 0;
     if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
+    if (s->disable_ctx) p.flags |= BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT;
     cap = brotli_amd_max_output(whole, &p);
     if (cap == 0) return 0;
     if (!sync_context_dictionaries(s)) return 0;

@@ -1160,6 +1160,7 @@ int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t s
   }
   if (quality != 5) s->J.flags |= JOB_FLAG_DEEP;   // k_parse_deep.h; k_parse.h serves the 16-slot hashers
   if (flags & BROTLI_AMD_FLAG_NO_HEADER) s->J.flags |= JOB_FLAG_NO_HEADER;
+  if (flags & BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT) s->J.flags |= JOB_FLAG_NO_LITCTX;
   s->J.log2_lut_size = s->J.max_metablock_size + 2;
   if (!stream_init(s, stream_offset)) { brotli_amd_stream_destroy(s); return BROTLI_AMD_ERROR; }
   *out = s;

@@ -208,6 +208,7 @@ static inline bool plan_choose_kernels(JobPlan* plan, uint32_t api_flags, int nu
   if (api_flags & 1u) plan->J.flags |= JOB_FLAG_NO_PAIR;
   if (api_flags & 4u) plan->J.flags |= JOB_FLAG_FORCE_SLOW;
   if (api_flags & 8u) plan->J.flags |= JOB_FLAG_NO_HEADER;
+  if (api_flags & 32u) plan->J.flags |= JOB_FLAG_NO_LITCTX;
   // Four shards per wave (k_parse4.h) whenever no shard can wrap the ring or
   // see a candidate beyond the window.
   uint64_t longest = 0;

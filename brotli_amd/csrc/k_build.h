@@ -151,7 +151,7 @@ DEV void decide_contexts(BuildCtx& b, uint32_t start, uint32_t length) {
   const double* lut2 = b.T->log2_lut;
   b.nc = 1;
   b.map_kind = 0;
-  if (J.quality < 5 || length < 64) return;
+  if (J.quality < 5 || length < 64 || (J.flags & JOB_FLAG_NO_LITCTX) != 0) return;
   const uint32_t end = start + length;
   const uint8_t* clut = b.T->context_lut;
   if (J.size_hint >= (1u << 20)) {

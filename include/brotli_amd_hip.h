@@ -61,6 +61,8 @@ typedef struct BrotliAmdJobParams {
 #define BROTLI_AMD_FLAG_NO_HEADER 8u  /* the stream header (window bits) has already been
                                          written by the caller (empty FLUSH at stream start,
                                          encode.c:1356-1415): the first shard starts byte aligned */
+#define BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT 32u /* BROTLI_PARAM_DISABLE_LITERAL_CONTEXT_MODELING: one literal context
+                                        (encode.c:561; qualities below 5 have one anyway) */
 #define BROTLI_AMD_FLAG_NO_INDEX 16u  /* quality 5: hash-table parse (k_parse4) instead of the position index
                                          (k_index.h + k_chain.h) */
 

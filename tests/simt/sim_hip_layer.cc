@@ -187,6 +187,7 @@ int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t s
   JobParams& J = s->J;
   if (quality != 5) J.flags |= JOB_FLAG_DEEP;
   if (flags & BROTLI_AMD_FLAG_NO_HEADER) J.flags |= JOB_FLAG_NO_HEADER;
+  if (flags & BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT) J.flags |= JOB_FLAG_NO_LITCTX;
   const uint64_t mb = J.max_metablock_size;
   J.log2_lut_size = (uint32_t)(mb + 2);
   ShardDesc& D = s->D;

@@ -353,3 +353,27 @@ def test_python_mirror_over_the_sim_library(simabi, stock, monkeypatch):
     with pytest.raises(b.error):
         b.compress(data, quality=11)          # outside the GPU path: fails loudly
     monkeypatch.setattr(b, "_lib", None)
+
+
+@pytest.mark.parametrize("quality,lgwin", [(5, 22), (9, 22), (7, 18), (3, 22)])
+def test_disable_literal_context_modeling(simabi, stock, quality, lgwin):
+    """BROTLI_PARAM_DISABLE_LITERAL_CONTEXT_MODELING (encode.h:194-201, encode.c:561): the build kernel keeps one literal
+    context; a stream in two flushes, a partition plan, and the one-shot call give the stock library's bytes — and,
+    at quality >= 5 on text, not the bytes of the default."""
+    data = G.enwik_text(150000, seed=41, vocab=3000)
+    n = len(data)
+    params = ((1, quality), (2, lgwin), (5, 1 << 20), (4, 1))
+    for ops in ([(n, 2)], [(n // 2, 1), (n - n // 2, 2)]):
+        want, fin_w = drive(stock, data, ops, params)
+        got, fin_g = drive(simabi, data, ops, params)
+        assert fin_w and fin_g and got == want
+    if quality >= 5:
+        default, _ = drive(stock, data, [(n, 2)], params[:3])
+        assert default != want
+    got, fin = drive(simabi, data, [(n, 2)], params + ((0x4D490001, 1 << 16),))
+    parts = []
+    for off in range(0, n, 1 << 16):
+        piece = data[off:off + (1 << 16)]
+        p, f = drive(stock, piece, [(len(piece), 2 if off + (1 << 16) >= n else 1)], params + ((9, off),) if off else params)
+        parts.append(p)
+    assert fin and got == b"".join(parts)
