@@ -203,7 +203,7 @@ def stock_call(data, quality, lgwin):
     L.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
     L.BrotliEncoderCompress.restype = C.c_int
     L.BrotliEncoderCompress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.c_char_p]
-    n = min(len(data), (1 << lgwin) - 16)
+    n = min(len(data), (1 << min(lgwin, 22)) - 16)
     piece = data[:n]
     cap = L.BrotliEncoderMaxCompressedSize(n)
     out = C.create_string_buffer(cap)

@@ -354,11 +354,13 @@ static int submit(BrotliEncoderState* s, int op) {
   if (s->quality == 1) return submit_fast(s, op);
   if (s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream &&
       s->in_len != 0 && s->ndicts == 0 &&
-      (s->quality != 5 || (s->lgwin >= 17 && s->in_len <= ((size_t)1 << s->lgwin) - 16))) {
+      (s->quality != 5 || (s->lgwin >= 17 && s->in_len <= ((size_t)1 << (s->lgwin < 22 ? s->lgwin : 22)) - 16))) {
     /* Everything in one FINISH (BrotliEncoderCompress, the CLI on a small file): the same bytes come from a
        one-shard job (falls through to the plan code below with shard size 0 = one shard).  Qualities 6-9: any
-       length; quality 5: an input that fits the window runs the position index and the tiled chain (k_index.h,
-       k_chain.h: every tile of the stream parsed at once) instead of one wave on the whole stream. */
+       length; quality 5: an input that fits the window — and 4 MiB: beyond that a text has keys with more than 65 520
+       positions, whose searches count the 16-bit store counter's wraps the slow way (k_chain.h, c_search_exact) — runs
+       the position index and the tiled chain (k_index.h, k_chain.h: every tile of the stream parsed at once) instead
+       of one wave on the whole stream. */
   } else if (s->shard_bytes == 0 && !(s->in_len == 0 && s->submitted == 0 && !s->stream)) {
     /* One encoder instance: the persistent device stream reproduces the
        reference for any op sequence (qualities 6-9: up to the window size).

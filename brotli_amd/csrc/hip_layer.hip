@@ -540,9 +540,15 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       if (plan.J.block_bits <= 6) hipLaunchKernelGGL(k_parse_deep<1>, dim3(nshards), dim3(64), 0, c->stream, a);
       else if (plan.J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(nshards), dim3(64), 0, c->stream, a);
       else hipLaunchKernelGGL(k_parse_deep<4>, dim3(nshards), dim3(64), 0, c->stream, a);
+    } else if (tiled && rounds != 0) {
+      // a shard that left the tiled path and holds more than one meta-block (incompressible data: a cut every
+      // max_literals, encode.c:1141-1166): its later rounds are the plain chain's
+      JobArgs p = a;
+      p.J.flags &= ~(uint32_t)(JOB_FLAG_TILED | JOB_FLAG_SWEEP);
+      hipLaunchKernelGGL(k_chain, dim3((nshards + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, p);
+      hipLaunchKernelGGL(k_cmd_encode, dim3(nshards * CE_SPLIT), dim3(64), 0, c->stream, p);
     } else if (tiled) {
       // the tiles' parses, then verify / events / sweep until nothing is pending (k_tile.h)
-      if (rounds != 0) return fail(c, "a tiled shard holds one meta-block");
       const dim3 cgrid((ntiles + gpw - 1) / gpw);
       const uint32_t clds = gpw * C_GROUP_LDS_WORDS * 4u;
       const bool tlog = getenv("BROTLI_AMD_TILE_LOG") != nullptr;

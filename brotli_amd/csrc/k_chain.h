@@ -1132,6 +1132,9 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       }
     }
     if (g.state == Q_POST) q_driver_post(J, g, writer);
+    // a tile that met a counter wrap gives up at once: the shard goes the plain way anyway, and the counted
+    // searches (c_search_exact walks a whole key run) are what makes such shards slow
+    if (tiled && (C.mode & C_BAD) != 0 && g.state != Q_DONE) { g.status |= QST_ERROR | QST_DONE; g.state = Q_DONE; }
     QP_ADD(g, 7, qt);
   }
 

@@ -29,13 +29,19 @@ void run_index(const JobArgs& a, int reverse) {
   run(k_ix_scatter, a, a.nshards * a.J.ix_slices, 64, reverse);
   run(k_ix_bucket, a, ((a.nshards + 7u) / 8u) * 8u * ((1u << a.J.ix_nb_log2) / a.J.ix_bpw), 64, reverse);
 }
-void run_parse_kernel(const JobArgs& a, int reverse) {
+void run_parse_kernel(JobArgs a, int reverse, int round = 0) {
   if (a.J.flags & JOB_FLAG_QUICK) {
     run(k_parse_quick, a, a.nshards, 64, reverse);
   } else if (a.J.flags & JOB_FLAG_DEEP) {
     if (a.J.block_bits <= 6) run(k_parse_deep<1>, a, a.nshards, 64, reverse);
     else if (a.J.block_bits == 7) run(k_parse_deep<2>, a, a.nshards, 64, reverse);
     else run(k_parse_deep<4>, a, a.nshards, 64, reverse);
+  } else if ((a.J.flags & JOB_FLAG_TILED) && round != 0) {
+    // later rounds of a shard that left the tiled path (several meta-blocks): the plain chain
+    JobArgs c = a;
+    c.J.flags &= ~(uint32_t)(JOB_FLAG_TILED | JOB_FLAG_SWEEP);
+    run(k_chain, c, (a.nshards + q_groups_per_wave(a.J) - 1) / q_groups_per_wave(a.J), 64, reverse);
+    run(k_cmd_encode, c, a.nshards * CE_SPLIT, 64, reverse);
   } else if (a.J.flags & JOB_FLAG_TILED) {
     // the tiles' parses, then verify / events / sweep until nothing is pending (what run_rounds of hip_layer.hip does)
     const uint32_t gpw = q_groups_per_wave(a.J);
@@ -197,8 +203,7 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   if (plan.J.flags & JOB_FLAG_INDEXED) run_index(a, reverse);
   for (int round = 0; round < 100000; ++round) {
     memset(counters, 0, sizeof(counters));
-    if (round > 0 && (a.J.flags & JOB_FLAG_TILED)) return -5;     // (a tiled shard is one meta-block)
-    run_parse_kernel(a, reverse);
+    run_parse_kernel(a, reverse, round);
     run(k_build, a, a.nshards, 64, reverse);
     if (getenv("SIM_DEBUG")) {
       for (size_t k = 0; k < plan.shards.size(); ++k) {

@@ -146,12 +146,12 @@ def test_one_shot_empty_and_small_buffer(amd):
     assert not amd.BrotliEncoderCompress(5, 22, 0, len(ALICE), ALICE, C.byref(n), out)
 
 
-@pytest.mark.parametrize("size,lgwin", [((4 << 20) - 16, 22), ((4 << 20) - 15, 22), (3000000, 22), ((16 << 20) - 16, 24),
-                                        (700000, 20), ((1 << 17) - 16, 17), (5 << 20, 22)])
+@pytest.mark.parametrize("size,lgwin", [((4 << 20) - 16, 22), ((4 << 20) - 15, 22), (3000000, 22), ((4 << 20) - 16, 24),
+                                        ((4 << 20) + 1000, 24), (700000, 20), ((1 << 17) - 16, 17)])
 def test_one_shot_quality_5_without_a_plan_equals_reference(amd, stock, monkeypatch, size, lgwin):
     """A stock caller: BrotliEncoderCompress(5, lgwin, ...) and no vendor setting.  An input that fits the window runs
     as a one-shard job on the position index with its chain tiles parsed at once (encode_abi.c submit(), k_chain.h
-    tiles); one byte more (and the 5 MiB case) takes the single-stream path.  Same bytes as the stock library either way."""
+    tiles) up to 4 MiB; one byte more takes the single-stream path.  Same bytes as the stock library either way."""
     monkeypatch.delenv("BROTLI_AMD_SHARD_KB", raising=False)
     data = G.enwik_text(size, seed=31, vocab=20000)
     outs = []

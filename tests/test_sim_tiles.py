@@ -69,3 +69,24 @@ def test_fuzz_slice(sim, oracle, seed):
     """A slice of tools/fuzz_tiles_sim.py (run offline over hundreds of seeds)."""
     from fuzz_tiles_sim import one
     assert one(seed, sim, oracle, verbose=False)
+
+
+def test_shard_of_several_meta_blocks_leaves_the_tiles_and_goes_on(sim, oracle, monkeypatch):
+    """More literals than a meta-block holds (encode.c:1141-1166: a cut at max_literals = 64 Ki at lgwin 18): the tiles do
+    not know about cuts — the shard takes the plain chain, whose later rounds must follow (it once stopped there)."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    text = G.enwik_text(200000, seed=13, vocab=3000)
+    noise = rng.integers(0, 256, 120000, dtype=np.uint8).tobytes()
+    data = b"".join(text[i:i + 5] + noise[3 * (i // 5):3 * (i // 5) + 3] for i in range(0, 200000, 5))[:262000]
+    monkeypatch.setenv("SIM_TILE_KB", "64")
+    got = sim.encode(data, 5, 18, 1 << 30, 0, flags=IX)
+    parts = oracle.encode_shard(data, 5, 18, 1 << 30, 0, True)
+    assert got == parts
+
+
+def test_counter_wrap_leaves_the_tiles_at_once(sim, oracle, monkeypatch):
+    """A key run longer than the reference's 16-bit store counter (300 000 zeros): the tile that meets it stops, the shard
+    goes the plain way (k_chain.h: c_search_exact counts the wraps) — same bytes."""
+    data = G.enwik_text(70000, seed=2) + bytes(300000) + G.enwik_text(70000, seed=3)
+    assert _tiled(monkeypatch, sim, data, 0) == _oracle_plan(oracle, data, 1 << 30, 0)
