@@ -63,8 +63,8 @@ void run_parse_kernel(JobArgs a, int reverse, int round = 0) {
       b.J.flags |= JOB_FLAG_SWEEP;
       const unsigned long long c7 = g_sim_counts[7], c15 = g_sim_counts[15], c5 = g_sim_counts[5];
       {
-        uint32_t sg = getenv("SIM_SWEEP_GROUPS") ? (uint32_t)atoi(getenv("SIM_SWEEP_GROUPS")) : 1u;
-        if (sg != 1 && sg != 2 && sg != 4) sg = 1;
+        uint32_t sg = getenv("SIM_SWEEP_GROUPS") ? (uint32_t)atoi(getenv("SIM_SWEEP_GROUPS")) : 2u;      // (the library's default)
+        if (sg != 1 && sg != 2 && sg != 4) sg = 2;
         b.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
         if (sg != 4) b.J.flags |= sg << JOB_FLAG_GROUPS_SHIFT;
         run(k_chain_sweep, b, (a.ntiles + sg - 1) / sg, 64, reverse);

@@ -60,18 +60,26 @@ def make_case(seed):
     return data, shard, rev, warm
 
 
+def case_hint(seed, data):
+    """H68 (a MiB announced) for two seeds of three, else the hint the library derives itself: below a MiB that is H58,
+    the 4-byte hasher with its own block-tail rules (hash_longest_match_simd_inc.h)."""
+    return (1 << 30) if seed % 3 else 0
+
+
 def one(seed, sim, oracle, verbose=True):
     data, shard, rev, warm = make_case(seed)
-    want = _oracle_plan(oracle, data, 1 << 30, shard)
+    hint = case_hint(seed, data)
+    want = _oracle_plan(oracle, data, hint, shard)
     os.environ["SIM_TILE_KB"] = "64"
     os.environ["SIM_TILE_WARM"] = str(warm)
+    os.environ["SIM_SWEEP_GROUPS"] = str((1, 2, 4)[seed % 3 if seed % 2 else 1])     # (2 = the library's default)
     try:
-        got = sim.encode(data, 5, 22, 1 << 30, shard, reverse=rev, flags=2 | 64)
+        got = sim.encode(data, 5, 22, hint, shard, reverse=rev, flags=2 | 64)
     finally:
-        del os.environ["SIM_TILE_KB"], os.environ["SIM_TILE_WARM"]
+        del os.environ["SIM_TILE_KB"], os.environ["SIM_TILE_WARM"], os.environ["SIM_SWEEP_GROUPS"]
     ok = got == want
     if verbose:
-        print("seed %d len %d shard %d rev %d warm %d: %s" % (seed, len(data), shard, rev, warm, "ok" if ok else "MISMATCH"), flush=True)
+        print("seed %d len %d shard %d rev %d warm %d hint %d: %s" % (seed, len(data), shard, rev, warm, hint, "ok" if ok else "MISMATCH"), flush=True)
     return ok
 
 
