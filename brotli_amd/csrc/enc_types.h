@@ -53,6 +53,11 @@ struct JobParams {
   uint32_t flush_symbols;       // qualities 2 - 3: a meta-block is cut once literals + commands reach this (encode.c:1150-1153); 0 = never
   uint32_t tile_log2;           // JOB_FLAG_TILED: log2 of the bytes of a chain tile (a multiple of the input block), k_chain.h
   uint32_t tile_warm;           //   bytes before a tile's first block that its speculative parse starts from
+  uint32_t chunk_log2;          // JOB_FLAG_STREAMT: log2 of the bytes of an index chunk (>= lgwin: a chunk's look-back covers the window)
+  uint32_t nchunks;
+  uint64_t sbm_off;             // JOB_FLAG_STREAMT: the stream's three position bitmaps (unstored / as last seen / events), workspace offset
+  uint64_t sbm_stride;          //   and the bytes of one of them
+  uint64_t skt_off;             // JOB_FLAG_STREAMT: per chunk, seven words per bucket key (k_tile.h: StreamKeyTable), workspace offset
 };
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
 #define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal
@@ -70,6 +75,9 @@ struct JobParams {
 #define JOB_FLAG_NO_LITCTX 4096u // BROTLI_PARAM_DISABLE_LITERAL_CONTEXT_MODELING (encode.c:561): k_build keeps one literal context
 #define JOB_FLAG_TILED 1024u   // indexed job whose shards are parsed tile by tile, all tiles at once: a tile starts from a
                                //   speculated state, joins are verified, differences repaired by sweeps (k_chain.h, k_tile.h)
+#define JOB_FLAG_STREAMT 8192u // one unpartitioned stream longer than the window, parsed in tiles: the index is built per
+                               //   chunk of 1 << chunk_log2 positions plus a look-back of the same size (ShardDesc::ix_*),
+                               //   the chain works in stream positions, meta-block cuts are part of the tiles' join state
 #define JOB_FLAG_SWEEP 2048u   // (per launch) k_chain replays the tiles' previous commands and parses again only where an
                                //   event is pending
 
@@ -93,6 +101,11 @@ struct ShardDesc {
   uint64_t cmds2_off;      // JOB_FLAG_TILED: the second command buffer (sweeps write the one the tile's commands are not in)
   uint32_t tile_base;      // JOB_FLAG_TILED: index of the shard's first tile in the job's tile arrays
   uint32_t ntiles;
+  // JOB_FLAG_STREAMT, index chunks only (descriptors the index kernels run over; in_off / len = the chunk with its
+  // look-back): stream position of the chunk's local position 0, first local position that is searched from this
+  // chunk (what lies below is look-back: candidates only), and the stream's length (0 = an ordinary shard)
+  uint32_t ix_base, ix_own, ix_glen;
+  uint32_t ix_ownc;        //   first local position that belongs to this chunk alone (ix_own lies a tile's warm-up below it)
 };
 
 // ---- chain tiles (JOB_FLAG_TILED) -------------------------------------------------------------
@@ -122,6 +135,10 @@ struct TileRec {
   uint32_t out_lpp;        // last tile: last_processed_pos_ and how the meta-block ended (bit 0 have, 1 is_last, 2 flush, 3 flush without seal)
   uint32_t out_mb;
   uint32_t nflips;         // tile 0: unstored-position bits of the shard that changed in the last k_tile_events pass
+  // JOB_FLAG_STREAMT: a meta-block was cut in front of this tile (encode.c:1141-1216: the pending literals became a
+  // command of their own and the next block's ExtendLastCommand found no command) — as k_stream_cuts sees it now,
+  // and as the tile's last parse assumed it; cmd_off counts the cuts' insert-only commands in
+  uint32_t cut, used_cut;
   uint32_t pad;
 };
 #define TILE_START_EVENT 1u   // the in-state was replaced by k_tile_verify: the next sweep parses from the tile's start
@@ -138,6 +155,8 @@ struct TileRec {
 #define TILE_WHY_CUT 0x4000u      // a meta-block would have been cut inside the shard (encode.c:1141-1166)
 #define TILE_WHY_EVENTS 0x8000u   // too many unstored positions: the tiles would parse everything twice
 #define TILE_WHY_TILE 0x10000u    // (tile 0: one of the shard's tiles carries a reason of its own)
+#define TILE_WHY_RAW 0x20000u     // JOB_FLAG_STREAMT: a meta-block would be stored uncompressed (or might be: the decision
+                                  //   depends on the bit it starts at) — the distance cache is rolled back then (encode.c:598-614)
 
 // Persistent per-shard encoder state (c/enc/state.h:49-110 subset).
 struct ShardState {
@@ -155,6 +174,7 @@ struct ShardState {
   // meta-block handed from the parse kernel to the build/store kernels
   uint32_t mb_valid, mb_start, mb_bytes, mb_is_last, mb_force_flush;
   uint32_t mb_raw;           // ShouldCompress() said no (set by build kernel)
+  uint32_t mb_was_raw;       // JOB_FLAG_STREAMT: the meta-block was (1) or might have to be (2) stored uncompressed
   uint32_t mb_num_contexts, mb_context_map_id;
   uint64_t out_bytes;        // whole bytes already final in the shard output
   uint64_t stat_searches, stat_pairs, stat_b_used;

@@ -20,6 +20,8 @@ struct JobPlan {
   JobParams J;
   std::vector<ShardDesc> shards;
   std::vector<TileDesc> tiles;       // JOB_FLAG_TILED
+  std::vector<ShardDesc> chunks;     // JOB_FLAG_STREAMT: index chunks (what the index kernels run over)
+  uint32_t mcap = 0;                 //   meta-blocks the stream can have at most
   uint64_t ws_bytes;
   uint64_t in_bytes;
   uint64_t max_out_bytes;
@@ -139,9 +141,11 @@ static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_
 // Gives every shard an index region (k_index.h) behind the rest of the workspace (simulator)
 // or leaves the placement to the caller (ix_in_ws false: the HIP layer keeps the regions in
 // allocations of their own and patches ix_off).  Returns the bytes one region needs.
-static inline uint64_t plan_add_index(JobPlan* plan, bool ix_in_ws) {
+static inline uint64_t plan_add_index_for(JobPlan* plan, std::vector<ShardDesc>& units, bool ix_in_ws);
+static inline uint64_t plan_add_index(JobPlan* plan, bool ix_in_ws) { return plan_add_index_for(plan, plan->shards, ix_in_ws); }
+static inline uint64_t plan_add_index_for(JobPlan* plan, std::vector<ShardDesc>& units, bool ix_in_ws) {
   uint64_t longest = 0;
-  for (const ShardDesc& D : plan->shards) if (D.len > longest) longest = D.len;
+  for (const ShardDesc& D : units) if (D.len > longest) longest = D.len;
   uint32_t slices = (uint32_t)((longest + 8191) / 8192);    // ~128 rows of 64 positions per slice
   if (slices < 1) slices = 1;
   if (slices > 64) slices = 64;
@@ -161,7 +165,7 @@ static inline uint64_t plan_add_index(JobPlan* plan, bool ix_in_ws) {
   ix_layout(longest, slices, nb, &L);
   if (ix_in_ws) {
     uint64_t off = plan->ws_bytes;
-    for (ShardDesc& D : plan->shards) { D.ix_off = off; off = plan_align(off + L.bytes); }
+    for (ShardDesc& D : units) { D.ix_off = off; off = plan_align(off + L.bytes); }
     plan->ws_bytes = off;
   }
   return L.bytes;
@@ -199,6 +203,78 @@ static inline uint32_t plan_add_tiles(JobPlan* plan, uint32_t tile_kb, uint32_t 
   }
   plan->ws_bytes = off;
   return (uint32_t)plan->tiles.size();
+}
+
+// One unpartitioned quality-5 stream parsed in tiles (JOB_FLAG_STREAMT; k_tile.h): the stream as one shard whose
+// tiles are its input blocks, index chunks of 1 << lgwin positions with a look-back of the same size, the stream's
+// bitmaps, and room for its meta-blocks, which k_stream_cuts carves out by position on the device (the offsets of
+// the stream's descriptor are the bases).  ix_in_ws false: the caller places the chunks' index regions.
+// Returns false where the tiles do not apply (the caller takes the serial path).
+static inline bool plan_stream(uint64_t len, int lgwin, uint32_t size_hint, uint32_t warm_bytes, bool ix_in_ws,
+                               JobPlan* plan, uint64_t* ix_region_bytes = nullptr) {
+  if (size_hint == 0) size_hint = len >= (1u << 30) ? (1u << 30) : (uint32_t)len;
+  if (!plan_params(5, lgwin, size_hint, &plan->J)) return false;
+  if (lgwin < 17 || lgwin > 22) return false;          // (entries hold 24-bit positions of a chunk and its look-back)
+  if (len >= (1ull << 31)) return false;
+  JobParams& J = plan->J;
+  const uint32_t tl = (uint32_t)J.lgblock;
+  const uint32_t ntiles = tile_count((uint32_t)len, 0u, tl);
+  if (ntiles < 3u) return false;
+  J.tile_log2 = tl;
+  J.tile_warm = warm_bytes < 256u ? 256u : warm_bytes > (1u << tl) / 2u ? (1u << tl) / 2u : warm_bytes;
+  J.chunk_log2 = (uint32_t)lgwin;
+  const uint64_t C = 1ull << J.chunk_log2;
+  J.nchunks = (uint32_t)((len + C - 1) / C);
+  J.flags |= JOB_FLAG_INDEXED | JOB_FLAG_TILED | JOB_FLAG_STREAMT | JOB_FLAG_QUAD;
+  J.log2_lut_size = J.max_metablock_size + 2u;
+  uint64_t mcap = len / J.max_literals + 2u;
+  if (mcap > ntiles) mcap = ntiles;
+  plan->mcap = (uint32_t)mcap;
+  plan->shards.resize(1);
+  ShardDesc& D = plan->shards[0];
+  memset(&D, 0, sizeof(D));
+  D.len = (uint32_t)len;
+  D.final_op = 2u;
+  const uint64_t cmd_cap = len / 2 + ntiles + mcap + 64;
+  D.cmd_cap = (uint32_t)cmd_cap;
+  uint64_t off = 0;
+  D.cmds_off = off;    off = plan_align(off + cmd_cap * sizeof(Command));
+  D.lits_off = off;    off = plan_align(off + 2 * len + 512 * mcap + 1024);
+  D.dsym_off = off;    off = plan_align(off + 2 * cmd_cap + 512 * mcap + 1024);
+  D.mb_off = off;      off = plan_align(off + mcap * plan_align(mb_work_bytes(J.max_metablock_size)));
+  D.scratch_off = off; off = plan_align(off + 8 * len + len / 32 + 1280 * mcap + ((uint64_t)J.max_metablock_size / 256 + 64) * 8 + 4096);
+  D.out_off = off;     off = plan_align(off + 2 * len + len / 1024 + 4096 * mcap + 8192);
+  D.out_cap = 2 * len + 8192;
+  D.ntiles = ntiles;
+  D.tile_base = 0;
+  plan->tiles.clear();
+  for (uint32_t t = 0; t < ntiles; ++t) { TileDesc d; d.shard = 0; d.t = t; plan->tiles.push_back(d); }
+  D.cmds2_off = off;   off = plan_align(off + 2ull * ntiles * tile_slot_cmds(tl, tl) * sizeof(Command));
+  J.sbm_stride = plan_align(len / 8 + 64);
+  J.sbm_off = off;     off = plan_align(off + 3 * J.sbm_stride);
+  J.skt_off = off;     off = plan_align(off + (uint64_t)J.nchunks * skt_chunk_bytes((uint32_t)J.bucket_bits));
+  plan->ws_bytes = off;
+  // the index chunks: chunk j searches [j C, (j + 1) C) (and the warm-up bytes in front of it) with
+  // [(j - 1) C, j C) as look-back
+  plan->chunks.resize(J.nchunks);
+  const uint32_t warm_cap = (1u << tl) / 2u;
+  for (uint32_t j = 0; j < J.nchunks; ++j) {
+    ShardDesc& K = plan->chunks[j];
+    memset(&K, 0, sizeof(K));
+    const uint64_t base = j == 0 ? 0 : (uint64_t)(j - 1) * C;
+    const uint64_t end = (uint64_t)(j + 1) * C < len ? (uint64_t)(j + 1) * C : len;
+    K.in_off = base;
+    K.len = (uint32_t)(end - base);
+    K.ix_base = (uint32_t)base;
+    K.ix_own = j == 0 ? 0u : (uint32_t)(C - warm_cap);
+    K.ix_ownc = j == 0 ? 0u : (uint32_t)C;
+    K.ix_glen = (uint32_t)len;
+  }
+  const uint64_t region = plan_add_index_for(plan, plan->chunks, ix_in_ws);
+  if (ix_region_bytes) *ix_region_bytes = region;
+  plan->in_bytes = len;
+  plan->max_out_bytes = len + 8 * mcap + 1024;
+  return true;
 }
 
 // Which parse kernel a plan runs on and in which wave layout (api_flags: BROTLI_AMD_FLAG_*

@@ -39,6 +39,7 @@ struct CShard {
   IxGeom geo;
   uint64_t* res;
   const uint32_t* srt;
+  uint32_t ibase;        // position of the local position 0 of `srt`'s entries (a stream's index chunk; 0 otherwise)
   uint8_t* skip;         // bit (x - geo.first): storable position x was NOT stored by the parse
   uint32_t frontier;     // every storable position below it is either stored or marked in `skip`
   uint32_t nslow;
@@ -92,7 +93,7 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
     const uint32_t nmax = wave_max_u32(ns);
     for (uint32_t j = 1; j <= nmax; ++j) {
       if (j <= ns) {
-        const uint32_t p = C.srt[s + j] & 0xFFFFFFu;
+        const uint32_t p = (C.srt[s + j] & 0xFFFFFFu) + C.ibase;
         if (p < C.tile_hi) {     // (a tiled job: successors in later tiles are told by k_tile_events)
           uint32_t* w = (uint32_t*)(C.res + p) + 1;
           *w = *w | IX_TAINT;      // (lanes that hit the same word write the same bit)
@@ -162,7 +163,10 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   const KeyTag kt = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits);
   const uint32_t hi = want ? (uint32_t)(C.res[P] >> 32) : 0u;
   const int32_t sidx = (int32_t)(hi & 0xFFFFFFu);
-  const bool danger = (hi & IX_DANGER) != 0;
+  // (a stream, k_tile.h: the visible slots of a search behind a counter wrap come with the mark)
+  const bool sdanger = (hi & IX_DANGER) != 0 && g.ring_mask_stream != 0u;
+  const uint32_t svis = want ? (uint32_t)C.res[P] & 31u : 0u;
+  const bool danger = (hi & IX_DANGER) != 0 && !sdanger;
   // the ring: the last 16 stored positions of the key run before P, newest first.  Past rank
   // 65520 the 16-bit store counter of the reference may have wrapped (:250-257), and the number
   // of stores of the whole run decides what is visible: counted once, then carried in the
@@ -180,7 +184,7 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
     const int32_t idx = sidx - 1 - (int32_t)(j0 + (uint32_t)t);
     const bool ok = on && idx >= 0;
     const uint32_t w0 = ok ? C.srt[idx] : 0u;
-    const uint32_t q = w0 & 0xFFFFFFu;
+    const uint32_t q = (w0 & 0xFFFFFFu) + C.ibase;
     bool inrun = false, stored = false;
     if (ok) {
       inrun = hash_pos(ld64(g.data + q), J.hasher_type, J.bucket_bits).key == kt.key;
@@ -209,8 +213,9 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   // and — only reachable after a wrap — count mod 65536 when that is below 16
   uint32_t nvalid = umin(found, 16u);
   if (danger) { const uint32_t n = total & 0xFFFFu; nvalid = n < 16u ? n : 16u; }
+  if (sdanger) nvalid = umin(nvalid, svis);
   const uint32_t w0 = (uint32_t)t < nvalid ? scratch[t] : 0u;
-  const uint32_t b_prev = w0 & 0xFFFFFFu;
+  const uint32_t b_prev = (w0 & 0xFFFFFFu) + C.ibase;
   const bool b_cand = want && (uint32_t)t < nvalid && (w0 >> 24) == kt.tag && (P - b_prev) <= max_backward;
   wave_sync();
   uint32_t b_len = 0, d_len = 0;
@@ -240,7 +245,14 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   const uint32_t dc_score = d_best ? (d_best >> 5) : K_MIN_SCORE;
   const uint32_t dc_len = q_max((d_key != 0 && d_key == d_best) ? d_len : 0u);
   const uint32_t dc_len3 = dc_len < 3u ? 3u : dc_len;
-  const bool unsure = b_ok && b_score > dc_score && b_len <= dc_len3;
+  bool unsure = b_ok && b_score > dc_score && b_len <= dc_len3;
+  if (g.ring_mask != 0xFFFFFFFFu) {
+    // a stream longer than the ring: a search in the last block of a lap, or with a candidate within reach of the
+    // ring's physical end, follows the order-dependent rules of q_resolve_slow
+    const uint32_t rm = g.ring_mask;
+    unsure = unsure || (want && (P & rm) + max_length > rm) || (d_cand && (d_prev & rm) + max_length > rm) ||
+             (b_cand && (b_prev & rm) + max_length > rm);
+  }
   const bool slow = q_mask16(wave_ballot(unsure)) != 0 || ((J.flags & JOB_FLAG_FORCE_SLOW) != 0 && want);
   const uint32_t best = q_max(b_key > d_key ? b_key : d_key);
   const bool win_is_d = best != 0 && d_key == best;
@@ -314,6 +326,13 @@ DEV CEval c_evaluate(const JobParams& J, CShard& C, bool want, uint32_t P0, int 
   const uint32_t d_key = d_ok ? (d_len << 2) | (3u - (uint32_t)idc) : 0u;
   uint32_t d_best = umax(d_key, wave_quad_xor(d_key, 1));
   d_best = umax(d_best, wave_quad_xor(d_best, 2));
+  uint32_t ring_risk = 0;
+  if (g.ring_mask != 0xFFFFFFFFu) {      // (the ring's physical end: see c_search_exact)
+    const uint32_t rm = g.ring_mask;
+    ring_risk = (ev && (Pk & rm) + max_length > rm) || (d_cand && ((Pk - backward) & rm) + max_length > rm) ? 1u : 0u;
+    ring_risk |= wave_quad_xor(ring_risk, 1);
+    ring_risk |= wave_quad_xor(ring_risk, 2);
+  }
   const uint32_t dc_len = d_best >> 2;
   const uint32_t dc_i = 3u - (d_best & 3u);
   const uint32_t dc_dist = q_dc_entry(g, (int)dc_i);
@@ -334,7 +353,7 @@ DEV CEval c_evaluate(const JobParams& J, CShard& C, bool want, uint32_t P0, int 
   const bool b_ok = ev && (kind == IX_KIND_EXACT || kind == IX_KIND_LONG);
   const uint32_t b_score = b_ok ? 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u) : 0u;
   const bool b_wins = b_ok && b_score > dc_score;
-  const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & (IX_DANGER | IX_TAINT)) != 0 || force_slow ||
+  const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & (IX_DANGER | IX_TAINT)) != 0 || force_slow || ring_risk != 0 ||
                                  (b_wins && b_len <= umax(dc_len, 3u)));
 #if defined(BROTLI_AMD_SIMT_SIM)
   if (ev && idc == 0) {   // (statistics of the simulator runs: why positions go to the exact path)
@@ -456,7 +475,14 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     const uint32_t kind = rlo >> 30, b_len = (rlo >> 24) & 63u, b_dist = rlo & 0xFFFFFFu;
     const uint32_t b_score = 1920u + dev_mul24(135u, b_len) - dev_mul24(30u, log2floor(b_dist | 1u));
     const bool b_wins = kind == IX_KIND_EXACT && b_score > dc_score;
-    const bool need = kind >= IX_KIND_LONG || (rhi & (IX_DANGER | IX_TAINT)) != 0 || d_long || force_slow ||
+    bool ring_risk = false;
+    if (g.ring_mask != 0xFFFFFFFFu) {    // (the ring's physical end: see c_search_exact)
+      const uint32_t rm = g.ring_mask, ml = g.pos_end - Pk;
+      ring_risk = (Pk & rm) + ml > rm;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ring_risk = ring_risk || (d_cand[i] && ((Pk - dcs[i]) & rm) + ml > rm);
+    }
+    const bool need = kind >= IX_KIND_LONG || (rhi & (IX_DANGER | IX_TAINT)) != 0 || d_long || force_slow || ring_risk ||
                       (b_wins && b_len <= umax(dc_len, 3u));
     uint32_t sc = b_wins ? b_score : dc_score;
     uint32_t ln = b_wins ? b_len : dc_len;
@@ -802,7 +828,8 @@ DEV Command* c_tile_slot(uint8_t* ws, const ShardDesc& D, const JobParams& J, ui
 template <int MODE>
 DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* states,
                      uint32_t nshards, const DeviceTables* T, const uint8_t* input, uint8_t* ws,
-                     uint32_t wave_index, uint32_t* lds, const TileDesc* tiles, TileRec* trecs, uint32_t ntiles) {
+                     uint32_t wave_index, uint32_t* lds, const TileDesc* tiles, TileRec* trecs, uint32_t ntiles,
+                     const ShardDesc* chunks = nullptr) {
   const int t = q_t();
   const uint32_t gpw = q_groups_per_wave(J);
   const uint32_t gi = (uint32_t)(wave_lane() >> 4);
@@ -855,11 +882,29 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   g.state = (alive && !S0->done && !S0->mb_valid && !S0->error) ? Q_PRE : Q_DONE;
   C.geo = ix_geom(J, D);
   IxLayout L;
-  ix_layout(D.len, J.ix_slices, J.ix_nb_log2, &L);
-  uint8_t* ixb = ws + D.ix_off;
-  C.res = (uint64_t*)(ixb + L.res);
-  C.srt = (const uint32_t*)(ixb + L.srt);
-  C.skip = ixb + L.skip;
+  uint8_t* evb;                                        // the event bitmap (sweeps)
+  if (tiled && (J.flags & JOB_FLAG_STREAMT) != 0) {
+    // a stream: the index chunk the tile's positions are searched from, addressed by stream position
+    const uint32_t lo = alive ? tile_lo(C.geo.first, tt, J.tile_log2) : 0u;
+    const ShardDesc& K = chunks[umin(lo >> J.chunk_log2, J.nchunks - 1u)];
+    ix_layout(K.len, J.ix_slices, J.ix_nb_log2, &L);
+    uint8_t* ixb = ws + K.ix_off;
+    C.res = (uint64_t*)(ixb + L.res) - K.ix_base;
+    C.srt = (const uint32_t*)(ixb + L.srt);
+    C.ibase = K.ix_base;
+    C.skip = ws + J.sbm_off;
+    evb = ws + J.sbm_off + 2u * J.sbm_stride;
+    if (D.len > J.ring_mask) g.ring_mask = J.ring_mask;
+    g.ring_mask_stream = 1u;
+  } else {
+    ix_layout(D.len, J.ix_slices, J.ix_nb_log2, &L);
+    uint8_t* ixb = ws + D.ix_off;
+    C.res = (uint64_t*)(ixb + L.res);
+    C.srt = (const uint32_t*)(ixb + L.srt);
+    C.ibase = 0;
+    C.skip = ixb + L.skip;
+    evb = ixb + L.ev;
+  }
   C.frontier = S0->ix_frontier;
   C.nslow = 0;
   C.tile_lo = 0;
@@ -869,10 +914,12 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
 
   // ---- a tile of a tiled job: where it starts from (wave operations stay outside the per-group branches) ----
   uint32_t warm = 0;                                   // 1: the group is in the warm-up of a speculative start
+  const bool stream = tiled && (J.flags & JOB_FLAG_STREAMT) != 0;
+  bool cut_in = false;                                 // a stream's tile that begins a meta-block: no ExtendLastCommand
   CReplay R;
   R.old = g.cmds; R.oi = R.on = 0; R.obnd = 0; R.changed = 0; R.next_ev = 0;
   R.odc[0] = R.odc[1] = R.odc[2] = R.odc[3] = 0;
-  R.ev = ixb + L.ev;
+  R.ev = evb;
   {
     if (tile_mode) {
       C.tile_lo = tile_lo(C.geo.first, tt, J.tile_log2);
@@ -891,6 +938,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
     if (sweep) run = run && any != 0 && (trecs[D.tile_base].flags & TILE_BAD) == 0;
     int32_t used_dc[4] = {0, 0, 0, 0};
     uint32_t used_insert = 0, used_ext = 0;
+    if (tile_mode && stream) g.no_cut = last_tile ? 0u : 1u;     // (cuts are k_stream_cuts' to find, k_tile.h)
     if (tile_mode) {
       g.lim_len = C.tile_hi;
       g.lim_op = last_tile ? D.final_op : 0u;
@@ -906,6 +954,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
         if (run && R.on > R.oi && R.old[R.on - 1u].cmd_prefix != CMD_RAW) --R.on;     // (the trailing insert-only command)
         for (int i = 0; i < 4; ++i) used_dc[i] = TR->used_dc[i];
         used_insert = TR->used_insert; used_ext = TR->used_ext;
+        cut_in = stream && run && TR->cut != 0;
       }
       alive = run;
       // every tile's parse begins from a state of its own making: nothing is taken from ShardState
@@ -922,7 +971,9 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       } else {
         const uint32_t B = C.tile_lo;
         g.r.flint = -2;
-        g.r.last_flush_pos = C.geo.first;
+        // (a stream's tile: nothing of its own block is "flushed" yet, so the next block always fits; the last one
+        //  ends the stream's last meta-block, whose size the tile need not know)
+        g.r.last_flush_pos = stream ? (last_tile ? 0u : B) : C.geo.first;
         g.r.last_bytes = g.r.last_bytes_bits = 0;
         g.dict_lookups = 256u;                         // the gate is taken as closed (hash.h:186); k_tile_verify checks
         if (!sweep) {
@@ -952,6 +1003,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       g.cmds[0] = gh;
       for (int i = 0; i < 4; ++i) TR->used_dc[i] = TR->in_dc[i];
       TR->used_insert = TR->in_insert;
+      TR->used_cut = cut_in ? 1u : 0u;
     }
     wave_sync();
     if (sweep) {
@@ -980,6 +1032,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       // previous block
       if (wave_any(su && (g.blk_flags & QBLK_STITCH)))
         c_stored(J, C, su && (g.blk_flags & QBLK_STITCH), g.blk_pos - 3u, g.blk_pos);
+      if (cut_in && su && g.blk_pos == C.tile_lo) g.blk_flags &= ~QBLK_EXTEND;      // (num_commands_ is 0 behind a cut, encode.c:1103)
       const bool first_blk = tile_mode && tt != 0u && su && g.blk_pos == C.tile_lo && (g.blk_flags & QBLK_EXTEND) != 0;
       const uint32_t ghost_len = first_blk ? (g.cmds[0].copy_len & 0x1FFFFFFu) : 0u;
       wave_sync();
@@ -1118,6 +1171,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
           TR->in_copy_len = gh.copy_len;
           TR->in_code = gh.dist_extra;
           TR->in_ext = TR->used_ext = 0;
+          TR->used_cut = 0;
         }
         wave_sync();
         if (wpost) {
@@ -1180,7 +1234,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
     }
     if (tp && sweep) {
       // the events of the tile are dealt with
-      uint32_t* evw = (uint32_t*)(ixb + L.ev);
+      uint32_t* evw = (uint32_t*)evb;
       const uint32_t w0 = (C.tile_lo - umin(C.tile_lo, C.geo.first)) >> 5, w1 = (C.tile_hi - C.geo.first + 31u) >> 5;
       for (uint32_t i = w0 + (uint32_t)t; i < w1; i += 16u) evw[i] = 0;
     }

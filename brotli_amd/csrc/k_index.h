@@ -44,14 +44,39 @@
 // (BrotliEncoderCompressStream re-blocks the input to 1 << lgblock, encode.c:1666-1681;
 // a shard with a stream offset first emits its two "flint" bytes as a block of their own,
 // encode.c:1686-1694.)
-struct IxGeom { uint32_t n, first, lgblock, htl; };
+// Positions in ix_block_end / ix_storable / ix_searchable are positions of the shard (of the stream, JOB_FLAG_STREAMT).
+// An index chunk of a stream (ShardDesc::ix_glen != 0) holds the stream positions [base, base + len) under the local
+// positions [0, len): the index kernels work in local positions (24 bits in an entry) and ask these functions about
+// local + base; [0, own) is the chunk's look-back (candidates for the searches from `own` on, not searched itself —
+// the chunk before this one searches them).
+struct IxGeom { uint32_t n, first, lgblock, htl, len, base, own, ownc, maxdist, ring_mask; bool stream; };
 DEV IxGeom ix_geom(const JobParams& J, const ShardDesc& D) {
   IxGeom g;
-  g.n = D.len;
+  g.stream = D.ix_glen != 0u;
+  g.n = g.stream ? D.ix_glen : D.len;
+  g.len = D.len;
+  g.base = D.ix_base;
+  g.own = D.ix_own;
+  g.ownc = D.ix_ownc;
+  g.maxdist = g.stream ? J.max_backward_limit : 0xFFFFFFFFu;
+  g.ring_mask = J.ring_mask;
   g.first = D.stream_offset != 0 ? 2u : 0u;
   g.lgblock = (uint32_t)J.lgblock;
   g.htl = hasher_htl(J.hasher_type);
   return g;
+}
+// The three position bitmaps of a shard (bit x - first) — for a chunk of a stream the chunk's window on the stream's.
+struct IxBitmaps { uint8_t* skip; uint8_t* prev; uint8_t* ev; };
+DEV IxBitmaps ix_bitmaps(const JobParams& J, const ShardDesc& D, uint8_t* ws, const IxLayout& L) {
+  IxBitmaps b;
+  if (D.ix_glen != 0u) {
+    uint8_t* G = ws + J.sbm_off + D.ix_base / 8u;
+    b.skip = G; b.prev = G + J.sbm_stride; b.ev = G + 2u * J.sbm_stride;
+  } else {
+    uint8_t* base = ws + D.ix_off;
+    b.skip = base + L.skip; b.prev = base + L.skip_prev; b.ev = base + L.ev;
+  }
+  return b;
 }
 // End of the input block that contains x.
 DEV uint32_t ix_block_end(const IxGeom& g, uint32_t x) {
@@ -111,18 +136,18 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
   const int lane = wave_lane();
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
-  ix_layout(g.n, J.ix_slices, J.ix_nb_log2, &L);
+  ix_layout(g.len, J.ix_slices, J.ix_nb_log2, &L);
   uint8_t* base = ws + D.ix_off;
   const uint8_t* data = input + D.in_off;
-  const uint32_t per = ix_slice_len(g.n, J.ix_slices);
-  const uint32_t lo = w * per, hi = umin(lo + per, g.n);
+  const uint32_t per = ix_slice_len(g.len, J.ix_slices);
+  const uint32_t lo = w * per, hi = umin(lo + per, g.len);
   const uint32_t nbk = 1u << J.ix_nb_log2;
   for (uint32_t b = (uint32_t)lane; b < nbk; b += 64u) lds_cnt[b] = 0;
   wave_sync();
   const int shift = J.bucket_bits - (int)J.ix_nb_log2;
   for (uint32_t x0 = lo; x0 < hi; x0 += 64u) {
     const uint32_t x = x0 + (uint32_t)lane;
-    if (x < hi && ix_storable(g, x)) {
+    if (x < hi && ix_storable(g, x + g.base)) {
       const KeyTag kt = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits);
       lds_atomic_add(&lds_cnt[kt.key >> shift], 1u);
     }
@@ -131,12 +156,20 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
   uint32_t* cnt = (uint32_t*)(base + L.cnt);
   for (uint32_t b = (uint32_t)lane; b < nbk; b += 64u) cnt[b * J.ix_slices + w] = lds_cnt[b];
   // bitmap bytes of this slice (per is a multiple of 64 positions = 8 bytes)
-  uint32_t* skip = (uint32_t*)(base + L.skip);
-  const uint32_t w_lo = lo / 32u, w_hi = (umin(lo + per, g.n + 128u) + 31u) / 32u;
+  const IxBitmaps bm = ix_bitmaps(J, D, ws, L);
+  uint32_t* skip = (uint32_t*)bm.skip;
+  const uint32_t w_lo = lo / 32u, w_hi = (umin(lo + per, g.len + 128u) + 31u) / 32u;
   for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) skip[i] = 0;
+  if (g.stream) {
+    // the chunk's key table (k_tile.h): every slice clears its share
+    const uint32_t cj = g.ownc == 0u ? 0u : (g.base >> J.chunk_log2) + 1u;
+    uint32_t* kt = (uint32_t*)(ws + J.skt_off + (uint64_t)cj * skt_chunk_bytes((uint32_t)J.bucket_bits));
+    const uint32_t words = SKT_WORDS << J.bucket_bits, share = (words + J.ix_slices - 1u) / J.ix_slices;
+    for (uint32_t i = w * share + (uint32_t)lane; i < umin((w + 1u) * share, words); i += 64u) kt[i] = 0;
+  }
   if (J.flags & JOB_FLAG_TILED) {
-    uint32_t* prev = (uint32_t*)(base + L.skip_prev);
-    uint32_t* ev = (uint32_t*)(base + L.ev);
+    uint32_t* prev = (uint32_t*)bm.prev;
+    uint32_t* ev = (uint32_t*)bm.ev;
     for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) { prev[i] = 0; ev[i] = 0; }
   }
   wave_sync();
@@ -177,13 +210,13 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
   const uint32_t lane = (uint32_t)wave_lane();
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
-  ix_layout(g.n, J.ix_slices, J.ix_nb_log2, &L);
+  ix_layout(g.len, J.ix_slices, J.ix_nb_log2, &L);
   uint8_t* base = ws + D.ix_off;
   const uint8_t* data = input + D.in_off;
   const uint32_t* cnt = (const uint32_t*)(base + L.cnt);
   uint32_t* ent = (uint32_t*)(base + L.ent);
-  const uint32_t per = ix_slice_len(g.n, J.ix_slices);
-  const uint32_t lo = w * per, hi = umin(lo + per, g.n);
+  const uint32_t per = ix_slice_len(g.len, J.ix_slices);
+  const uint32_t lo = w * per, hi = umin(lo + per, g.len);
   const uint32_t nbk = 1u << J.ix_nb_log2;
   uint32_t* sorted = lds;                       // [IX_CHUNK] packed entries in bucket order
   uint32_t* start = lds + IX_CHUNK;             // [nbk] first LDS index of a bucket in this chunk (counts first)
@@ -200,7 +233,7 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
     for (uint32_t r = 0; r < IX_CHUNK / 64u; ++r) {
       const uint32_t x = c0 + r * 64u + lane;
       pk[r] = 0xFFFFFFFFu;
-      if (x < c1 && ix_storable(g, x)) {
+      if (x < c1 && ix_storable(g, x + g.base)) {
         const KeyTag kt = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits);
         const uint32_t b = kt.key >> shift;
         pk[r] = (x - c0) | ((kt.key & ((1u << shift) - 1u)) << 11) | (b << 19);    // position | low key bits | bucket
@@ -302,11 +335,24 @@ DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + dev_mul24(13
 // Writes srt[] and res[].
 struct IxLds { const uint32_t* w0; const uint64_t* d; const uint64_t* d2; };
 DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool act, uint32_t rank, uint32_t nsucc,
-                   const IxLds& S, uint32_t li, uint32_t sidx, uint32_t* srt, uint64_t* res) {
+                   const IxLds& S, uint32_t li, uint32_t sidx, uint32_t* srt, uint64_t* res, uint32_t* kt = nullptr, uint32_t nkeys = 0) {
+  if (kt != nullptr && act) {
+    // a stream's chunk: the key run's place in srt[], and how much of it lies in the chunk's own part
+    const uint32_t pp = e.w0 & 0xFFFFFFu;
+    if (rank == 0u) { kt[SKT_RS * nkeys + e.w1] = sidx; kt[SKT_RL * nkeys + e.w1] = nsucc + 1u; }
+    if (pp >= g.ownc && (rank == 0u || (S.w0[li - 1u] & 0xFFFFFFu) < g.ownc)) kt[SKT_OWN * nkeys + e.w1] = nsucc + 1u;
+  }
   const uint32_t p = e.w0 & 0xFFFFFFu, tag = e.w0 >> 24;
-  const bool danger = rank >= 65520u;
-  const bool search = act && ix_searchable(g, p);
-  const uint32_t max_length = search ? ix_block_end(g, p) - p : 0u;
+  const uint32_t P = p + g.base;                                // its position in the shard / stream
+  // (a stream: what the 16-bit counter hides depends on the stores since the stream's start — k_tile.h finds those
+  //  positions once the chunks before this one are parsed)
+  const bool danger = !g.stream && rank >= 65520u;
+  const bool search = act && p >= g.own && ix_searchable(g, P);
+  const uint32_t max_length = search ? ix_block_end(g, P) - P : 0u;
+  const uint32_t maxb = umin(P, g.maxdist);                     // max_backward (backward_references_inc.h:56-57)
+  // the ring buffer's physical end (..64_simd_inc.h:243-249): a search in the last block of a lap, or one with a
+  // candidate that close to the end of a lap, follows rules that depend on the order of visit — the chain's to do
+  bool ringrisk = g.stream && search && (P & g.ring_mask) + max_length > g.ring_mask;
   uint32_t best = 0, best_len = 0, best_dist = 0;               // exact candidates
   uint32_t longmask = 0;
 #if defined(IX_NOWIN)       // (timing experiments only: results are wrong)
@@ -322,6 +368,8 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
     const uint64_t x = S.d[li - j] ^ e.d;
     uint32_t l = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
     if (l < 4u) continue;                                       // first4 != current4
+    if (p - (qw & 0xFFFFFFu) > maxb) continue;                  // beyond the window (:239-241: it and everything older)
+    if (g.stream && (((qw & 0xFFFFFFu) + g.base) & g.ring_mask) + max_length > g.ring_mask) ringrisk = true;
     if (l == 8u) {
       const uint64_t x2 = S.d2[li - j] ^ e.d2;
       l = x2 ? 8u + ((uint32_t)dev_ctz64(x2) >> 3) : 16u;
@@ -384,7 +432,7 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
     srt[sidx] = e.w0;
     uint32_t kind, len = 0, dist = 0;
     if (!search) kind = IX_KIND_NONE;
-    else if (danger || ncapped >= 2u) kind = IX_KIND_SLOW;
+    else if (danger || ringrisk || ncapped >= 2u) kind = IX_KIND_SLOW;
     else if (ncapped == 1u) {
       // the long candidate's score can only grow with its real length
       if (cap_key > best) { kind = IX_KIND_LONG; len = IX_CAP; dist = cap_dist; }
@@ -415,7 +463,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   const int lane = wave_lane();
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
-  ix_layout(g.n, J.ix_slices, J.ix_nb_log2, &L);
+  ix_layout(g.len, J.ix_slices, J.ix_nb_log2, &L);
   uint8_t* base = ws + D.ix_off;
   const uint8_t* data = input + D.in_off;
   const uint32_t* cnt = (const uint32_t*)(base + L.cnt);
@@ -423,6 +471,8 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   uint32_t* ent2 = (uint32_t*)(base + L.ent2);
   uint32_t* srt = (uint32_t*)(base + L.srt);
   uint64_t* res = (uint64_t*)(base + L.res);
+  uint32_t* kt = nullptr;
+  if (g.stream) kt = (uint32_t*)(ws + J.skt_off + (uint64_t)(g.ownc == 0u ? 0u : (g.base >> J.chunk_log2) + 1u) * skt_chunk_bytes((uint32_t)J.bucket_bits));
   const uint32_t start = cnt[bucket * J.ix_slices];
   const uint32_t end = cnt[(bucket + 1u) * J.ix_slices];   // (the last one reads the total)
   const uint32_t m = end - start;
@@ -492,7 +542,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       const uint32_t kl = e.w1 & lowmask;
       const uint32_t rank = act ? i - bins[kl] : 0u;
       const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
-      ix_window(g, data, e, act, rank, nsucc, S, act ? i : 0u, start + i, srt, res);
+      ix_window(g, data, e, act, rank, nsucc, S, act ? i : 0u, start + i, srt, res, kt, 1u << J.bucket_bits);
     }
     wave_sync();
     return;
@@ -541,7 +591,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     const uint32_t kl = e.w1 & lowmask;
     const uint32_t rank = act ? i - bins[kl] : 0u;
     const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;
-    ix_window(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res);
+    ix_window(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res, kt, 1u << J.bucket_bits);
     wave_sync();
     if (lane >= 48) ix_lds_put(w0S, dS, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
     wave_sync();

@@ -50,6 +50,20 @@ static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, uint32_t nb_log2
   L->bytes = off;
 }
 
+// ---- a tiled stream (JOB_FLAG_STREAMT): per chunk and bucket key, what the 16-bit store counter needs (k_tile.h) ----
+// run start / run length in the chunk's sorted array, entries of the run in the chunk's own part, how many of those
+// the parse did not store, stores of the key before the chunk's look-back, and the sorted-index range the last pass
+// marked counter-wrap positions in.
+#define SKT_RS 0u
+#define SKT_RL 1u
+#define SKT_OWN 2u
+#define SKT_SK 3u
+#define SKT_B 4u
+#define SKT_ZLO 5u
+#define SKT_ZHI 6u
+#define SKT_WORDS 7u
+static inline IX_HD uint64_t skt_chunk_bytes(uint32_t bucket_bits) { return (uint64_t)SKT_WORDS * 4u << bucket_bits; }
+
 // ---- chain tiles (JOB_FLAG_TILED, enc_types.h) ----------------------------------------------
 // Tile t of a shard of n bytes whose input blocks start at `first` (2 behind a stream offset: the "flint" bytes are a
 // block of their own, encode.c:1686-1694): tile 0 = [0, first + T), tile t = [first + t T, first + (t + 1) T), T = 1 << tile_log2.

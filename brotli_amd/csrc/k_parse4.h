@@ -111,6 +111,9 @@ struct QShard {
   uint32_t gap = 0;        // their total size (backward_references_inc.h:31)
   // k_chain.h, tiled jobs: the part of the shard this group parses (0xFFFFFFFF: what the descriptor says)
   uint32_t lim_len = 0xFFFFFFFFu, lim_op = 0xFFFFFFFFu, lim_cmd_cap = 0xFFFFFFFFu;
+  uint32_t ring_mask = 0xFFFFFFFFu;   // a stream longer than the ring buffer: its mask (the rules of the ring's physical end, q_resolve_slow)
+  uint32_t ring_mask_stream = 0;      // 1: the group parses a tile of a stream (JOB_FLAG_STREAMT)
+  uint32_t no_cut = 0;     // a stream's tile (JOB_FLAG_STREAMT): the block always merges — where meta-blocks end is decided elsewhere
   // k_chain.h: commands are left raw (CMD_RAW, enc_types.h) with CMDF_* in dist_prefix
   uint32_t raw_cmds = 0, cmd_flags = 0;
   // ... and with the static-dictionary lookups / matches (hash.h:49-50) counted since the last command or block
@@ -160,8 +163,13 @@ DEV uint32_t q_or(uint32_t v) {
 DEV uint32_t q_from(uint32_t v, int i) { return q_max(q_t() == i ? v : 0u); }
 DEV uint16_t ld16(const uint8_t* p) { uint16_t v; __builtin_memcpy(&v, p, 2); return v; }
 
-// Byte the reference reads at ring index x <= pos_end on the first lap.
-DEV uint32_t q_ring_byte(const QShard& g, uint32_t x) { return x < g.pos_end ? g.data[x] : 0u; }
+// Byte the reference reads at ring index x <= pos_end: real data below pos_end; at pos_end the zero bytes written
+// behind the block on the first lap (encode.c:879-893) or, once the ring has been lapped (a stream longer than the
+// ring, k_chain.h), the stale byte of the lap before (ringbuffer.h:103-159).
+DEV uint32_t q_ring_byte(const QShard& g, uint32_t x) {
+  if (x < g.pos_end) return g.data[x];
+  return g.pos_end > g.ring_mask ? g.data[x - g.ring_mask - 1u] : 0u;
+}
 
 DEV uint32_t q_dc_entry(const QShard& g, int i) {
   return (uint32_t)(i == 0 ? g.dc[0] : i == 1 ? g.dc[1] : i == 2 ? g.dc[2] : g.dc[3]);
@@ -286,10 +294,16 @@ DEV QResult q_resolve_slow(const QShard& g, bool want, uint32_t P, uint32_t max_
   QResult r;
   r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; r.delta = 0;
   uint32_t best_len = 0;
+  // the ring's physical end (:187-195, 243-249): nothing more is looked at once the current position is within
+  // best_len of it, and a candidate that close to it is passed over
+  const uint32_t rm = g.ring_mask, cur_masked = P & rm;
+  bool stopped = false;
   for (int i = 0; i < ndist; ++i) {
     const bool ok = q_bcast(d_ok ? 1u : 0u, i) != 0;
     const uint32_t len_i = q_bcast(d_len, i), prev_i = q_bcast(d_prev, i), score_i = q_bcast(d_score, i);
-    if (!want || !ok) continue;
+    if (!want || !ok || stopped) continue;
+    if (cur_masked + best_len > rm) { stopped = true; continue; }
+    if ((prev_i & rm) + best_len > rm) continue;
     if (q_ring_byte(g, P + best_len) != q_ring_byte(g, prev_i + best_len)) continue;
     if (!(len_i >= 3 || (len_i == 2 && i < 2))) continue;
     if (!(r.score < score_i)) continue;
@@ -297,11 +311,14 @@ DEV QResult q_resolve_slow(const QShard& g, bool want, uint32_t P, uint32_t max_
     r.len = len_i; r.distance = P - prev_i; r.score = score_i;
   }
   if (best_len < 3) best_len = 3;
+  stopped = false;
   for (int j = 0; j < 16; ++j) {
     const int src = (int)((head + (uint32_t)j) & 15u);
     const bool ok = q_bcast(b_ok ? 1u : 0u, src) != 0;
     const uint32_t len_j = q_bcast(b_len, src), prev_j = q_bcast(b_prev, src), score_j = q_bcast(b_score, src);
-    if (!want || !ok) continue;
+    if (!want || !ok || stopped) continue;
+    if (cur_masked + best_len > rm) { stopped = true; continue; }
+    if ((prev_j & rm) + best_len > rm) continue;
     bool pass = true;
     for (uint32_t k = best_len - 3; k <= best_len; ++k) {
       if (q_ring_byte(g, P + k) != q_ring_byte(g, prev_j + k)) { pass = false; break; }
@@ -597,7 +614,7 @@ DEV void q_driver_post(const JobParams& J, QShard& g, bool writer) {
     const bool next_fits = processed + block <= J.max_metablock_size;
     // without block splitting a meta-block is cut as soon as enough symbols have gathered (:1150-1153)
     const bool should_flush = J.flush_symbols != 0u && r.nlits + r.ncmds >= J.flush_symbols;
-    if (!is_last && !force_flush && !should_flush && next_fits && r.nlits < J.max_literals && r.ncmds < J.max_commands) {
+    if (g.no_cut != 0u || (!is_last && !force_flush && !should_flush && next_fits && r.nlits < J.max_literals && r.ncmds < J.max_commands)) {
       // (a block without bytes and without an operation to carry out would come back here
       // forever: an unknown final_op — fail instead of spinning)
       if (g.blk_bytes == 0 && avail == 0) { g.status |= QST_ERROR | QST_DONE; g.state = Q_DONE; return; }

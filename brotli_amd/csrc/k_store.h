@@ -312,6 +312,15 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   const uint32_t start = S->mb_start, bytes = S->mb_bytes;
   const bool is_last = S->mb_is_last != 0, force_flush = S->mb_force_flush != 0;
   bool raw = S->mb_raw != 0;
+  // A meta-block of a tiled stream (JOB_FLAG_STREAMT) is written as if it began at bit 0 and moved to its place
+  // afterwards (k_stream_place): a raw one cannot be (its payload is byte aligned in the stream), nor is the
+  // distance-cache roll-back behind it something the tiles know about — the stream goes the serial way then.
+  const bool stream = (J.flags & JOB_FLAG_STREAMT) != 0;
+  if (stream && raw) {
+    if (lane == 0) { S->mb_was_raw = 1; S->mb_valid = 0; }
+    wave_sync();
+    return;
+  }
 
   // Everything this meta-block can touch, zeroed; then the carried bits.
   const uint64_t zero_bytes = 2ull * bytes + 520ull;
@@ -730,11 +739,18 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     if (lane == 0 && W[0]) sink.base[wbit >> 5] = W[0];
     wave_sync();
     SP_ADD(S, 5, spt);
-    if (is_last) sink.bitpos = (sink.bitpos + 7u) & ~(uint64_t)7u;
+    if (is_last && !stream) sink.bitpos = (sink.bitpos + 7u) & ~(uint64_t)7u;
     total_bits = sink.bitpos - bit0;
     wave_sync();
     // encode.c:604-613: larger than the input + 4 bytes -> store uncompressed.
-    if ((uint64_t)bytes + 4u < (total_bits >> 3)) raw = true;
+    if (!stream) {
+      if ((uint64_t)bytes + 4u < (total_bits >> 3)) raw = true;
+    } else {
+      // (the reference compares with the bytes counted from the byte the meta-block's first bit is in, padding of
+      //  the last one included: between these two bounds the answer depends on where the meta-block starts)
+      const uint64_t lo = total_bits >> 3, hi = ((total_bits + 7u) >> 3) + (is_last ? 1u : 0u);
+      if (lane == 0) S->mb_was_raw = (uint64_t)bytes + 4u < lo ? 1u : (uint64_t)bytes + 4u < hi ? 2u : 0u;
+    }
   }
 
   if (raw) {

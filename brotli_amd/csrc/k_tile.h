@@ -25,6 +25,7 @@
 #define BROTLI_AMD_CSRC_K_TILE_H_
 
 #include "k_chain.h"
+#include "mb_layout.h"
 
 // counters[]: [2] tiles with a start event, [3] changed skip bits, [4] shards that left the tiled path
 #define TILE_CNT_START 2
@@ -185,6 +186,387 @@ DEV void tile_finish(const JobParams& J, const ShardDesc& D, ShardState* S, uint
     S->mb_force_flush = (z.out_mb & 8u) ? 2u : (z.out_mb & 4u) ? 1u : 0u;
     S->mb_raw = 0;
     if (!(z.out_mb & 1u)) S->error = 3;
+  }
+}
+
+// ---- a tiled stream (JOB_FLAG_STREAMT): one encoder instance longer than the window ------------------------------
+// The stream is one shard whose tiles are its input blocks (tile_log2 == lgblock).  Besides the joins of the tiled
+// shards above, a tile's parse depends on whether a meta-block was cut in front of it (encode.c:1141-1216: the
+// pending literals become an insert-only command of the meta-block that ends, last_insert_len_ and num_commands_
+// start from zero, so the block's ExtendLastCommand does nothing) — and where the cuts fall depends on the counts
+// of all the tiles before: k_stream_cuts walks the tiles' counts (one wave), k_stream_verify compares every tile's
+// assumed in-state (cut included) with what its predecessor left, sweeps repair, until nothing changes.  Then the
+// meta-blocks are known: k_stream_cuts (finalize) describes each one as a shard of its own for k_build / k_store
+// (its commands, its literals' context bytes, workspace carved out by its position), written as if it began at bit
+// 0 of its own output, and k_stream_place shifts the results to their bit offsets in the stream.
+#define TILE_CNT_RAW 5
+#define TILE_CNT_NMB 6       // meta-blocks of the stream (k_stream_cuts, finalize)
+
+DEV uint64_t st_al(uint64_t x) { return (x + 255u) & ~(uint64_t)255u; }
+// One meta-block [tile s, tile e] of the stream as a shard description + state (lane 0 of the caller).
+DEV void stream_emit_mb(const JobParams& J, const ShardDesc& D, const uint8_t* input, ShardDesc* md, ShardState* ms,
+                        uint32_t m, uint32_t s, uint32_t e, uint32_t cmd_lo, uint32_t ncmds, uint32_t nlits, bool is_last) {
+  const uint32_t start = tile_lo(0u, s, J.tile_log2), end = tile_hi(D.len, 0u, e, J.tile_log2), bytes = end - start;
+  MbLayout ML;
+  mb_layout(J.max_metablock_size, &ML);
+  ShardDesc X;
+  __builtin_memset(&X, 0, sizeof(X));
+  X.in_off = D.in_off;
+  X.len = bytes;
+  X.final_op = 2u;
+  X.cmd_cap = ncmds;
+  X.cmds_off = D.cmds_off + 16ull * cmd_lo;
+  X.lits_off = st_al(D.lits_off + 2ull * start + 512ull * m);
+  X.dsym_off = st_al(D.dsym_off + 2ull * cmd_lo + 512ull * m);
+  X.mb_off = D.mb_off + (uint64_t)m * st_al(ML.total);
+  X.scratch_off = st_al(D.scratch_off + 8ull * start + (start >> 5) + 1280ull * m);
+  X.out_off = st_al(D.out_off + 2ull * start + (start >> 10) + 4096ull * m);
+  X.out_cap = 2ull * bytes + 1024u;
+  md[m] = X;
+  ShardState Y;
+  __builtin_memset(&Y, 0, sizeof(Y));
+  if (m == 0) { ShardState init; init_shard_state(J, D, &init); Y.last_bytes = init.last_bytes; Y.last_bytes_bits = init.last_bytes_bits; }
+  Y.input_pos = end;
+  Y.last_processed_pos = Y.last_flush_pos = start;
+  Y.ncmds = ncmds;
+  Y.nlits = nlits;
+  Y.flint = -2;
+  const uint8_t* data = input + D.in_off;
+  if (start > 0) Y.prev_byte = data[start - 1];
+  if (start > 1) Y.prev_byte2 = data[start - 2];
+  Y.mb_valid = 1;
+  Y.mb_start = start;
+  Y.mb_bytes = bytes;
+  Y.mb_is_last = is_last ? 1u : 0u;
+  ms[m] = Y;
+}
+
+// grid = 1, block = 64.  Where the reference cuts its meta-blocks, given the tiles' counts as they stand: after the
+// block of tile t when the literals / commands gathered since the last cut reach the limits or the next block would
+// not fit (encode.c:1141-1166).  Writes TileRec::cut (tile t + 1 begins a meta-block) and TileRec::cmd_off; with
+// `finalize` also the meta-blocks' descriptions.
+DEV void stream_cuts(const JobParams& J, const ShardDesc& D, TileRec* R, const uint8_t* input, ShardDesc* md, ShardState* ms,
+                     uint32_t mcap, uint32_t* counters, bool finalize) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  const uint32_t nt = D.ntiles;
+  const uint64_t block = 1ull << J.lgblock;
+  uint32_t s_tile = 0, accL = 0, accC = 0, m = 0, cmd_row = 0, mb_cmd_lo = 0;
+  uint32_t prev_cut = 0;                     // the row before ended with a cut behind its last tile
+  bool overflow = false;
+  for (uint32_t r0 = 0; r0 < nt; r0 += 64u) {
+    const uint32_t t = r0 + lane;
+    const bool have = t < nt;
+    const uint32_t nl = have ? R[t].out_nlits : 0u, nc = have ? R[t].out_ncmds : 0u, oi = have ? R[t].out_insert : 0u;
+    uint32_t startlane = 0;
+    uint64_t cutmask = 0;
+    uint32_t carryL = accL, carryC = accC;
+    for (;;) {
+      const bool on = have && lane >= startlane;
+      const uint32_t sl = carryL + wave_incl_scan(on ? nl : 0u), sc = carryC + wave_incl_scan(on ? nc : 0u);
+      const uint64_t nb = (uint64_t)t - s_tile + 1u;
+      const bool cond = on && t + 1u < nt &&
+                        (sl >= J.max_literals || sc >= J.max_commands || (nb + 1u) * block > (uint64_t)J.max_metablock_size);
+      const uint64_t mask = wave_ballot(cond);
+      if (mask == 0) { accL = wave_bcast(sl, 63); accC = wave_bcast(sc, 63); break; }
+      const int f = dev_ctz64(mask);
+      cutmask |= 1ull << f;
+      const uint32_t fl = wave_bcast(sl, f), fc = wave_bcast(sc, f), fi = wave_bcast(oi, f);
+      const uint32_t ncm = fc + (fi != 0 ? 1u : 0u);
+      if (finalize) {
+        if (m < mcap) { if (lane == 0) stream_emit_mb(J, D, input, md, ms, m, s_tile, r0 + (uint32_t)f, mb_cmd_lo, ncm, fl + fi, false); }
+        else overflow = true;
+      }
+      mb_cmd_lo += ncm;
+      ++m;
+      s_tile = r0 + (uint32_t)f + 1u;
+      startlane = (uint32_t)f + 1u;
+      carryL = carryC = 0;
+    }
+    // the row's cut flags and command offsets
+    const uint64_t flushmask = cutmask & wave_ballot(oi != 0);
+    const uint32_t ex = wave_incl_scan(nc) - nc;
+    const uint32_t before = (uint32_t)dev_popc64(flushmask & ((1ull << lane) - 1ull));
+    if (have) {
+      R[t].cmd_off = cmd_row + ex + before;
+      R[t].cut = lane == 0 ? prev_cut : (uint32_t)((cutmask >> (lane - 1u)) & 1ull);
+    }
+    cmd_row += wave_bcast(ex + nc, 63) + (uint32_t)dev_popc64(flushmask);
+    prev_cut = (uint32_t)((cutmask >> 63) & 1ull);
+  }
+  if (finalize) {
+    if (m < mcap) { if (lane == 0) stream_emit_mb(J, D, input, md, ms, m, s_tile, nt - 1u, mb_cmd_lo, accC, accL, true); }
+    else overflow = true;
+    ++m;
+    if (lane == 0) {
+      counters[TILE_CNT_NMB] = m;
+      if (overflow) { R[0].flags |= TILE_BAD | TILE_WHY_ERROR; glb_atomic_add(&counters[TILE_CNT_BAD], 1u); }
+    }
+  }
+  wave_sync();
+}
+
+// grid = ceil(ntiles / 64), block = 64: lane = tile t; the join between t and t + 1.
+DEV void stream_verify(const JobParams& J, const ShardDesc& D, TileRec* R, uint32_t t, uint32_t* counters) {
+  if (t >= D.ntiles || (R[0].flags & TILE_BAD)) return;
+  uint32_t why = 0;
+  TileRec& c = R[t];
+  if (c.flags & TILE_BAD) why |= TILE_WHY_TILE;
+  if (!(c.flags & TILE_RAN)) why |= TILE_WHY_NOT_RUN;
+  if (t == 0) {
+    if (c.nflips > D.len / 32u + 64u) why |= TILE_WHY_EVENTS;
+    c.nflips = 0;
+  }
+  if (t + 1u < D.ntiles) {
+    TileRec& n = R[t + 1u];
+    const bool cut = n.cut != 0;
+    if (c.out_ncmds == 0u && !cut) why |= TILE_WHY_NO_CMD;
+    if (c.out_gate == 0u) why |= TILE_WHY_GATE;
+    const uint32_t req_insert = cut ? 0u : c.out_insert;
+    const bool same_cmd = cut || c.out_insert != 0u || (n.in_copy_len == c.out_copy_len && n.in_code == c.out_code);
+    const bool same = n.in_dc[0] == c.out_dc[0] && n.in_dc[1] == c.out_dc[1] && n.in_dc[2] == c.out_dc[2] &&
+                      n.in_dc[3] == c.out_dc[3] && n.in_insert == req_insert && (n.used_cut != 0) == cut && same_cmd;
+    if (!same && why == 0) {
+      for (int i = 0; i < 4; ++i) n.in_dc[i] = c.out_dc[i];
+      n.in_insert = req_insert;
+      n.in_copy_len = cut ? 0u : c.out_copy_len;
+      n.in_code = c.out_code;
+      n.flags |= TILE_START_EVENT;
+      glb_atomic_add(&counters[TILE_CNT_START], 1u);
+    }
+  }
+  if (why != 0) {
+    glb_atomic_or(&R[0].flags, TILE_BAD | why);
+    glb_atomic_add(&counters[TILE_CNT_BAD], 1u);
+  }
+}
+
+// grid = nchunks * ix_slices, block = 64: the words of the stream's bitmap that lie in the chunk's own part.  A
+// position whose bit changed is looked up in its own chunk and in the next one (where it is look-back): its
+// successors in both key runs are the searches its store was, or now is, a candidate of.
+DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* chunks, uint32_t cj, const uint8_t* input,
+                       uint8_t* ws, TileRec* trecs, uint32_t w, uint32_t* counters) {
+  if (trecs[0].flags & TILE_BAD) return;
+  const uint32_t lane = (uint32_t)wave_lane();
+  const uint32_t* skip = (const uint32_t*)(ws + J.sbm_off);
+  uint32_t* prev = (uint32_t*)(ws + J.sbm_off + J.sbm_stride);
+  uint32_t* ev = (uint32_t*)(ws + J.sbm_off + 2u * J.sbm_stride);
+  const uint8_t* data = input + D.in_off;
+  const uint32_t own_lo = cj << J.chunk_log2;
+  const uint32_t own_hi = umin(D.len, (cj + 1u) << J.chunk_log2);
+  const uint32_t per = ix_slice_len(own_hi - own_lo, J.ix_slices);
+  const uint32_t w_lo = (own_lo + w * per) / 32u, w_hi = umin((own_lo + (w + 1u) * per) / 32u, (own_hi + 31u) / 32u);
+  uint32_t flips = 0;
+  for (uint32_t i = w_lo + lane; i < w_hi; i += 64u) {
+    const uint32_t cur = skip[i];
+    uint32_t diff = cur ^ prev[i];
+    if (diff == 0) continue;
+    prev[i] = cur;
+    flips += (uint32_t)__builtin_popcount(diff);
+    for (; diff != 0; diff &= diff - 1u) {
+      const uint32_t x = i * 32u + (uint32_t)dev_ctz32(diff);
+      const uint32_t key = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits).key;
+      const uint32_t xt = (J.flags & JOB_FLAG_SWEEP) ? 0xFFFFFFFFu : x >> J.tile_log2;
+      for (uint32_t c = cj; c <= cj + 1u && c < J.nchunks; ++c) {
+        const ShardDesc& K = chunks[c];
+        IxLayout L;
+        ix_layout(K.len, J.ix_slices, J.ix_nb_log2, &L);
+        const uint8_t* kb = ws + K.ix_off;
+        const uint32_t* srt = (const uint32_t*)(kb + L.srt);
+        const uint64_t* res = (const uint64_t*)(kb + L.res);
+        const uint32_t total = ((const uint32_t*)(kb + L.cnt))[J.ix_slices << J.ix_nb_log2];
+        const uint32_t s = (uint32_t)(res[x - K.ix_base] >> 32) & 0xFFFFFFu;
+        uint32_t stored = 0;
+        for (uint32_t j = s + 1u; j < total && stored < 16u; ++j) {
+          const uint32_t q = (srt[j] & 0xFFFFFFu) + K.ix_base;
+          if (hash_pos(ld64(data + q), J.hasher_type, J.bucket_bits).key != key) break;
+          if ((q >> J.tile_log2) != xt) glb_atomic_or(&ev[q >> 5], 1u << (q & 31u));
+          if (!((skip[q >> 5] >> (q & 31u)) & 1u)) ++stored;
+        }
+      }
+    }
+  }
+  if (flips != 0) {
+    glb_atomic_add(&counters[TILE_CNT_FLIPS], flips);
+    glb_atomic_add((uint32_t*)&trecs[0].nflips, flips);
+  }
+}
+
+// grid = ntiles, block = 64: the tile's commands to their place in the stream's array, encoded; the insert-only
+// command of a cut behind the tile.
+DEV void stream_finish(const JobParams& J, const ShardDesc& D, uint8_t* ws, const TileRec* R, uint32_t tt) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  if (R[0].flags & TILE_BAD) return;
+  Command* dst = (Command*)(ws + D.cmds_off);
+  const TileRec& r = R[tt];
+  const Command* src = c_tile_slot(ws, D, J, r.buf, tt) + (tt == 0 ? 0u : 1u);
+  const uint32_t n = r.out_ncmds;
+  const bool more = tt + 1u < D.ntiles;
+  const uint32_t ext = more ? R[tt + 1u].in_ext : 0u;
+  for (uint32_t i = lane; i < n; i += 64u) {
+    Command c = src[i];
+    if (c.cmd_prefix == CMD_RAW) {
+      uint32_t len = c.copy_len & 0x1FFFFFFu;
+      if (i + 1u == n) len += ext;
+      const uint32_t m = c.copy_len >> 25;
+      const int32_t delta = (int8_t)((uint8_t)(m | ((m & 0x40) << 1)));
+      c = make_command(c.insert_len, len, delta, c.dist_extra);
+    }
+    dst[r.cmd_off + i] = c;
+  }
+  if (lane == 0 && more && R[tt + 1u].cut != 0 && r.out_insert != 0) dst[r.cmd_off + n] = make_insert_command(r.out_insert);
+}
+
+// ---- the 16-bit store counter of a tiled stream ---------------------------------------------------------------------
+// FindLongestMatch sees min(16, stores of the key so far mod 65536) ring slots (..64_simd_inc.h:250-257): the first
+// 16 searches of a key after every 65536th store of it see fewer.  Which positions those are depends on every store
+// of the key since the stream's start: per chunk and key, the stores before the chunk's look-back (SKT_B) come from
+// the run lengths (k_ix_bucket) less the unstored positions (k_stream_skcount counts the bitmap's bits per chunk and
+// key), summed over the chunks before (k_stream_kprefix); k_stream_zones then walks the runs that contain a wrap,
+// marks the searches behind it in res[] (IX_DANGER, the visible slots in the low bits, IX_KIND_SLOW: the chain
+// searches them itself) and raises an event where a mark changed.  Part of every pass of the sweep loop: the marks
+// follow the bitmap as it settles.
+DEV uint32_t* stream_kt(const JobParams& J, uint8_t* ws, uint32_t c) {
+  return (uint32_t*)(ws + J.skt_off + (uint64_t)c * skt_chunk_bytes((uint32_t)J.bucket_bits));
+}
+// grid = nchunks * ix_slices, block = 64: (first clears SKT_SK of the chunk — a separate launch, k_stream_skclear)
+DEV void stream_skclear(const JobParams& J, uint8_t* ws, uint32_t c, uint32_t w) {
+  uint32_t* kt = stream_kt(J, ws, c) + ((uint64_t)SKT_SK << J.bucket_bits);
+  const uint32_t nk = 1u << J.bucket_bits, share = (nk + J.ix_slices - 1u) / J.ix_slices;
+  for (uint32_t i = w * share + (uint32_t)wave_lane(); i < umin((w + 1u) * share, nk); i += 64u) kt[i] = 0;
+}
+DEV void stream_skcount(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws, uint32_t c, uint32_t w) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  const uint32_t* skip = (const uint32_t*)(ws + J.sbm_off);
+  const uint8_t* data = input + D.in_off;
+  uint32_t* sk = stream_kt(J, ws, c) + ((uint64_t)SKT_SK << J.bucket_bits);
+  const uint32_t own_lo = c << J.chunk_log2, own_hi = umin(D.len, (c + 1u) << J.chunk_log2);
+  const uint32_t per = ix_slice_len(own_hi - own_lo, J.ix_slices);
+  const uint32_t w_lo = (own_lo + w * per) / 32u, w_hi = umin((own_lo + (w + 1u) * per) / 32u, (own_hi + 31u) / 32u);
+  for (uint32_t i = w_lo + lane; i < w_hi; i += 64u) {
+    for (uint32_t v = skip[i]; v != 0; v &= v - 1u) {
+      const uint32_t x = i * 32u + (uint32_t)dev_ctz32(v);
+      glb_atomic_add(&sk[hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits).key], 1u);
+    }
+  }
+}
+// grid = keys / 64, block = 64: lane = key; SKT_B of chunk c = stores in the own parts of the chunks 0 .. c - 2.
+DEV void stream_kprefix(const JobParams& J, uint8_t* ws, uint32_t key) {
+  const uint32_t nk = 1u << J.bucket_bits;
+  if (key >= nk) return;
+  uint32_t run = 0;
+  for (uint32_t c = 0; c < J.nchunks; ++c) {
+    uint32_t* kt = stream_kt(J, ws, c);
+    kt[SKT_B * nk + key] = run;
+    if (c >= 1u) { const uint32_t* kp = stream_kt(J, ws, c - 1u); run += kp[SKT_OWN * nk + key] - kp[SKT_SK * nk + key]; }
+  }
+}
+// grid = nchunks * keys / 64, block = 64: the wave's 64 keys of chunk c, one after the other.
+DEV void stream_zones(const JobParams& J, const ShardDesc& D, const ShardDesc* chunks, uint8_t* ws, uint32_t c, uint32_t kg, uint32_t* counters) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  const uint32_t nk = 1u << J.bucket_bits;
+  uint32_t* kt = stream_kt(J, ws, c);
+  const ShardDesc& K = chunks[c];
+  IxLayout L;
+  ix_layout(K.len, J.ix_slices, J.ix_nb_log2, &L);
+  const uint32_t* srt = (const uint32_t*)(ws + K.ix_off + L.srt);
+  uint64_t* res = (uint64_t*)(ws + K.ix_off + L.res);
+  const uint32_t* skip = (const uint32_t*)(ws + J.sbm_off);
+  uint32_t* ev = (uint32_t*)(ws + J.sbm_off + 2u * J.sbm_stride);
+  const uint32_t key = kg * 64u + lane;
+  const uint32_t rl_l = kt[SKT_RL * nk + key], b_l = kt[SKT_B * nk + key], zlo_l = kt[SKT_ZLO * nk + key], zhi_l = kt[SKT_ZHI * nk + key];
+  // a wrap inside the run (however few of its entries are stored, the run cannot wrap if this says no), or marks
+  // of an earlier pass to look after
+  uint64_t todo = wave_ballot((rl_l != 0u && (b_l & 0xFFFFu) + rl_l >= 65536u) || zhi_l > zlo_l);
+  uint32_t changes = 0;
+  for (; todo != 0; todo &= todo - 1ull) {
+    const int src = dev_ctz64(todo);
+    const uint32_t k = kg * 64u + (uint32_t)src;
+    const uint32_t rs = kt[SKT_RS * nk + k], rl = wave_bcast(rl_l, src), B = wave_bcast(b_l, src);
+    const uint32_t zlo = wave_bcast(zlo_l, src), zhi = wave_bcast(zhi_l, src);
+    // the run, 64 entries per step: `stored` = stores of the key before the entry
+    uint32_t stored = B, nlo = 0xFFFFFFFFu, nhi = 0;
+    for (uint32_t i0 = 0; i0 < rl; i0 += 64u) {
+      const uint32_t i = i0 + lane;
+      const bool in = i < rl;
+      const uint32_t w0 = in ? srt[rs + i] : 0u;
+      const uint32_t p = w0 & 0xFFFFFFu, P = p + K.ix_base;
+      const bool st = in && !((skip[P >> 5] >> (P & 31u)) & 1u);
+      const uint64_t sm = wave_ballot(st);
+      const uint32_t before = stored + (uint32_t)dev_popc64(sm & ((1ull << lane) - 1ull));     // the counter when this entry is searched
+      const uint32_t vis = before & 0xFFFFu;
+      const bool zone = in && before >= 65536u && vis < 16u && p >= K.ix_ownc;
+      const bool old = in && rs + i >= zlo && rs + i < zhi;
+      if (zone || old) {
+        const uint64_t r = res[p];
+        const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
+        uint32_t nlo2 = lo, nhi2 = hi;
+        if (zone) { nlo2 = (IX_KIND_SLOW << 30) | vis; nhi2 = hi | IX_DANGER; }
+        else if (hi & IX_DANGER) { nlo2 = IX_KIND_SLOW << 30; nhi2 = hi & ~IX_DANGER; }
+        if (nlo2 != lo || nhi2 != hi) {
+          res[p] = (uint64_t)nlo2 | ((uint64_t)nhi2 << 32);
+          glb_atomic_or(&ev[P >> 5], 1u << (P & 31u));
+          ++changes;
+        }
+      }
+      const uint64_t zm = wave_ballot(zone);
+      if (zm != 0) { nlo = umin(nlo, rs + i0 + (uint32_t)dev_ctz64(zm)); nhi = umax(nhi, rs + i0 + 64u - (uint32_t)__builtin_clzll(zm)); }
+      stored += (uint32_t)dev_popc64(sm);
+    }
+    if (lane == 0) { kt[SKT_ZLO * nk + k] = nhi > nlo ? nlo : 0u; kt[SKT_ZHI * nk + k] = nhi > nlo ? nhi : 0u; }
+  }
+  changes = wave_incl_scan(changes);
+  if (lane == 63 && changes != 0) glb_atomic_add(&counters[TILE_CNT_FLIPS], changes);
+}
+
+// grid = 1, block = 64: bit offsets of the meta-blocks in the stream; result[0] = bits of the stream.
+DEV void stream_scan(ShardState* ms, uint32_t nmb, uint64_t* moff, uint32_t* counters) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  uint64_t run = 0;
+  uint32_t rawish = 0;
+  for (uint32_t r0 = 0; r0 < nmb; r0 += 64u) {
+    const uint32_t m = r0 + lane;
+    uint64_t bits = 0;
+    if (m < nmb) {
+      bits = ms[m].out_bytes * 8u + ms[m].last_bytes_bits;
+      if (ms[m].mb_was_raw != 0 || ms[m].error != 0 || ms[m].mb_valid != 0) rawish = 1;
+    }
+    // inclusive scan of 64-bit values: two 32-bit scans would lose carries — do it by halves of the wave instead
+    uint64_t v = bits;
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t o = wave_shfl64(v, (int)((lane - (uint32_t)d) & 63u));
+      if (lane >= (uint32_t)d) v += o;
+    }
+    if (m < nmb) moff[m] = run + v - bits;
+    run += wave_bcast64(v, 63);
+  }
+  if (wave_ballot(rawish != 0) != 0 && lane == 0) glb_atomic_add(&counters[TILE_CNT_RAW], 1u);
+  if (lane == 0) moff[nmb] = run;
+  wave_sync();
+}
+
+// grid = nmb * parts, block = 256: the bits of meta-block m (written from bit 0 of its own buffer) to bit moff[m] of
+// the stream, 32 bits per lane and step; the first and last word of a meta-block are shared with its neighbours.
+DEV void stream_place(const ShardDesc* md, const ShardState* ms, const uint64_t* moff, const uint8_t* ws, uint8_t* out,
+                      uint32_t m, uint32_t part, uint32_t parts, uint32_t tid, uint32_t nthreads) {
+  const uint64_t nbits = ms[m].out_bytes * 8u + ms[m].last_bytes_bits;
+  if (nbits == 0) return;
+  const uint64_t o = moff[m];
+  const uint32_t* src = (const uint32_t*)(ws + md[m].out_off);
+  uint32_t* dst = (uint32_t*)out;
+  const uint64_t k0 = o >> 5, k1 = (o + nbits + 31u) >> 5;      // destination words [k0, k1)
+  const uint64_t per = (k1 - k0 + parts - 1u) / parts;
+  const uint64_t lo = k0 + (uint64_t)part * per, hi = lo + per < k1 ? lo + per : k1;
+  for (uint64_t k = lo + tid; k < hi; k += nthreads) {
+    const int64_t rel = (int64_t)(k * 32u) - (int64_t)o;         // first source bit of this word
+    const uint64_t a = rel < 0 ? 0u : (uint64_t)rel;
+    const uint64_t b = (uint64_t)(rel + 32) < nbits ? (uint64_t)(rel + 32) : nbits;
+    const uint32_t cnt = (uint32_t)(b - a);
+    const uint64_t wd = (uint64_t)src[a >> 5] | ((uint64_t)src[(a >> 5) + 1u] << 32);
+    uint32_t bits = (uint32_t)(wd >> (a & 31u));
+    if (cnt < 32u) bits &= (1u << cnt) - 1u;
+    const uint32_t val = bits << (uint32_t)((int64_t)a - rel);
+    if (k == k0 || k + 1u == k1) glb_atomic_or(&dst[k], val);
+    else dst[k] = val;
   }
 }
 

@@ -46,6 +46,14 @@ struct JobArgs {
   const TileDesc* tiles = nullptr;
   TileRec* trecs = nullptr;
   uint32_t ntiles = 0;
+  // JOB_FLAG_STREAMT: the stream's index chunks (the index kernels run with them as `shards`)
+  const ShardDesc* chunks = nullptr;
+  ShardDesc* mdesc = nullptr;         //   its meta-blocks as shards of their own for k_build / k_store (k_stream_cuts fills them)
+  ShardState* mstate = nullptr;
+  uint64_t* moff = nullptr;           //   [mcap + 1] bit offsets of the meta-blocks in the stream
+  uint8_t* sout = nullptr;            //   the stream's output
+  uint32_t mcap = 0;
+  uint32_t aux = 0;                   //   k_stream_cuts: 1 = describe the meta-blocks
 };
 
 // grid = nshards * init_blocks_per_shard, block = 256
@@ -160,7 +168,7 @@ __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain_tiles(JobArgs a) {
 #else
   extern __shared__ uint32_t lds_c[];
 #endif
-  chain_round<1>(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, a.tiles, a.trecs, a.ntiles);
+  chain_round<1>(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, a.tiles, a.trecs, a.ntiles, a.chunks);
 }
 __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain_sweep(JobArgs a) {
 #if defined(BROTLI_AMD_SIMT_SIM)
@@ -168,7 +176,7 @@ __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain_sweep(JobArgs a) {
 #else
   extern __shared__ uint32_t lds_c[];
 #endif
-  chain_round<2>(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, a.tiles, a.trecs, a.ntiles);
+  chain_round<2>(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, a.tiles, a.trecs, a.ntiles, a.chunks);
 }
 
 // ---- tiled jobs (k_tile.h) ----
@@ -203,6 +211,52 @@ __global__ void __launch_bounds__(64) k_tile_fallback(JobArgs a) {
   uint32_t* skip = (uint32_t*)(a.ws + D.ix_off + L.skip);
   for (uint32_t i = threadIdx.x; i < (D.len + 128u + 31u) / 32u; i += 64u) skip[i] = 0;
   if (threadIdx.x == 0) init_shard_state(a.J, D, &a.states[blockIdx.x]);
+}
+
+// ---- a tiled stream (JOB_FLAG_STREAMT, k_tile.h) ----
+// grid = 1, block = 64
+__global__ void __launch_bounds__(64) k_stream_cuts(JobArgs a) {
+  stream_cuts(a.J, a.shards[0], a.trecs, a.input, a.mdesc, a.mstate, a.mcap, a.counters, a.aux != 0);
+}
+// grid = ceil(ntiles / 64), block = 64
+__global__ void __launch_bounds__(64) k_stream_verify(JobArgs a) {
+  stream_verify(a.J, a.shards[0], a.trecs, blockIdx.x * 64u + threadIdx.x, a.counters);
+}
+// grid = nchunks * ix_slices, block = 64
+__global__ void __launch_bounds__(64) k_stream_events(JobArgs a) {
+  const uint32_t cj = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
+  if (cj < a.J.nchunks) stream_events(a.J, a.shards[0], a.chunks, cj, a.input, a.ws, a.trecs, w, a.counters);
+}
+// the 16-bit store counter (k_tile.h): grid = nchunks * ix_slices; keys / 64; nchunks * keys / 64; block = 64
+__global__ void __launch_bounds__(64) k_stream_skclear(JobArgs a) {
+  const uint32_t cj = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
+  if (cj < a.J.nchunks) stream_skclear(a.J, a.ws, cj, w);
+}
+__global__ void __launch_bounds__(64) k_stream_skcount(JobArgs a) {
+  const uint32_t cj = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
+  if (cj < a.J.nchunks) stream_skcount(a.J, a.shards[0], a.input, a.ws, cj, w);
+}
+__global__ void __launch_bounds__(64) k_stream_kprefix(JobArgs a) {
+  stream_kprefix(a.J, a.ws, blockIdx.x * 64u + threadIdx.x);
+}
+__global__ void __launch_bounds__(64) k_stream_zones(JobArgs a) {
+  const uint32_t per = (1u << a.J.bucket_bits) / 64u;
+  const uint32_t cj = blockIdx.x / per, kg = blockIdx.x % per;
+  if (cj < a.J.nchunks) stream_zones(a.J, a.shards[0], a.chunks, a.ws, cj, kg, a.counters);
+}
+// grid = ntiles, block = 64
+__global__ void __launch_bounds__(64) k_stream_finish(JobArgs a) {
+  if (blockIdx.x < a.ntiles) stream_finish(a.J, a.shards[0], a.ws, a.trecs, blockIdx.x);
+}
+// grid = 1, block = 64
+__global__ void __launch_bounds__(64) k_stream_scan(JobArgs a) {
+  stream_scan(a.mstate, a.counters[TILE_CNT_NMB], a.moff, a.counters);
+}
+// grid = mcap * STREAM_PLACE_PARTS, block = 256
+#define STREAM_PLACE_PARTS 16u
+__global__ void __launch_bounds__(256) k_stream_place(JobArgs a) {
+  const uint32_t m = blockIdx.x / STREAM_PLACE_PARTS, part = blockIdx.x % STREAM_PLACE_PARTS;
+  if (m < a.counters[TILE_CNT_NMB]) stream_place(a.mdesc, a.mstate, a.moff, a.ws, a.sout, m, part, STREAM_PLACE_PARTS, threadIdx.x, 256u);
 }
 
 // grid = nshards * CE_SPLIT, block = 64: prefix fields of the commands the chain left raw

@@ -47,6 +47,23 @@ class Sim:
             C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_uint32,
             C.c_size_t, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
 
+    def encode_stream(self, data, lgwin=22, size_hint=0, reverse=0, flags=0):
+        """One unpartitioned quality-5 stream on the tiled path (JOB_FLAG_STREAMT).  Returns (bytes, info) — bytes
+        is None when the stream leaves the tiled path; info = (reasons, sweeps, meta-blocks)."""
+        self.L.sim_encode_stream.restype = C.c_long
+        self.L.sim_encode_stream.argtypes = [
+            C.c_char_p, C.c_char_p, C.c_size_t, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_char_p, C.c_size_t,
+            C.POINTER(C.c_uint32)]
+        cap = len(data) + len(data) // 512 + 8192
+        out = C.create_string_buffer(cap)
+        info = (C.c_uint32 * 4)()
+        n = self.L.sim_encode_stream(TABLES.encode(), bytes(data), len(data), lgwin, size_hint, reverse, flags,
+                                     out, cap, info)
+        if n == -10:
+            return None, tuple(info[:3])
+        assert n >= 0, n
+        return out.raw[:n], tuple(info[:3])
+
     def decode(self, comp, n_out, pieces=None, arena_words=0, reverse=0):
         """k_decode on the simulator.  pieces = [(in_off, in_len, out_off, out_cap, flags, lgwin)],
         default: one whole stream.  Returns (bytes, [(out_bytes, in_bits, error, finished)])."""

@@ -247,6 +247,120 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   return (long)n;
 }
 
+// One unpartitioned quality-5 stream on the tiled path (JOB_FLAG_STREAMT; what run_stream_job of hip_layer.hip
+// does).  Returns the number of bytes, -10 when the stream leaves the tiled path (info[0] = the reasons, TILE_WHY_*:
+// the library then takes the serial path), other negatives on errors.  info: [0] reasons, [1] sweeps, [2] meta-blocks.
+long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, int lgwin, uint32_t size_hint,
+                       int reverse, int flags, uint8_t* out, size_t out_cap, uint32_t* info) {
+  HostTables ht;
+  if (!host_tables_load(tables_path, &ht)) return -1;
+  JobPlan plan;
+  const uint32_t warm = getenv("SIM_TILE_WARM") ? (uint32_t)atoi(getenv("SIM_TILE_WARM")) : 2048u;
+  if (!plan_stream(len, lgwin, size_hint, warm, true, &plan)) return -2;
+  plan.J.flags |= (uint32_t)flags;
+  std::vector<TileRec> trecs(plan.tiles.size() + 1);
+  memset(trecs.data(), 0, trecs.size() * sizeof(TileRec));
+  std::vector<uint8_t> input(len + 64, 0);
+  memcpy(input.data(), in, len);
+  std::vector<uint8_t> ws(plan.ws_bytes, 0xCD);
+  std::vector<ShardState> states(1);
+  std::vector<ShardDesc> mdesc(plan.mcap);
+  std::vector<ShardState> mstate(plan.mcap);
+  memset(mstate.data(), 0, mstate.size() * sizeof(ShardState));
+  std::vector<uint64_t> moff(plan.mcap + 1, 0);
+  std::vector<uint8_t> sout(plan.max_out_bytes + 64, 0);
+  std::vector<double> log2lut;
+  DeviceTables T;
+  host_tables_fill(ht, plan.J.log2_lut_size, &log2lut, &T);
+  uint32_t counters[16] = {0};
+  JobArgs a;
+  a.J = plan.J;
+  a.shards = plan.shards.data();
+  a.states = states.data();
+  a.T = &T;
+  a.input = input.data();
+  a.ws = ws.data();
+  a.nshards = 1;
+  a.init_blocks_per_shard = 1;
+  a.counters = counters;
+  a.tiles = plan.tiles.data();
+  a.trecs = trecs.data();
+  a.ntiles = (uint32_t)plan.tiles.size();
+  a.chunks = plan.chunks.data();
+  a.mdesc = mdesc.data();
+  a.mstate = mstate.data();
+  a.moff = moff.data();
+  a.sout = sout.data();
+  a.mcap = plan.mcap;
+  info[0] = info[1] = info[2] = 0;
+  run(k_init, a, 1, 256, 0);
+  {
+    JobArgs c = a;                                  // the index kernels see the chunks as their shards
+    c.shards = plan.chunks.data();
+    c.nshards = plan.J.nchunks;
+    run_index(c, reverse);
+  }
+  const uint32_t gpw = q_groups_per_wave(a.J);
+  const uint32_t nkg = (1u << a.J.bucket_bits) / 64u;
+  // the searches behind a wrap of the 16-bit store counter, as far as they can be told before the parse
+  const bool zones = !getenv("SIM_NO_ZONES");      // (test knob: without them a stream with a counter wrap comes out wrong)
+  if (zones) run(k_stream_kprefix, a, nkg, 64, reverse);
+  if (zones) run(k_stream_zones, a, a.J.nchunks * nkg, 64, reverse);
+  run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+  bool settled = false;
+  int rounds = 0;
+  for (; rounds < 16 && !settled; ++rounds) {
+    counters[TILE_CNT_START] = counters[TILE_CNT_FLIPS] = 0;
+    {
+      JobArgs e = a;
+      if (rounds != 0 || getenv("SIM_EVENTS_ALL")) e.J.flags |= JOB_FLAG_SWEEP;
+      run(k_stream_events, e, a.J.nchunks * a.J.ix_slices, 64, reverse);
+    }
+    run(k_stream_skclear, a, a.J.nchunks * a.J.ix_slices, 64, reverse);
+    run(k_stream_skcount, a, a.J.nchunks * a.J.ix_slices, 64, reverse);
+    if (zones) run(k_stream_kprefix, a, nkg, 64, reverse);
+    if (zones) run(k_stream_zones, a, a.J.nchunks * nkg, 64, reverse);
+    a.aux = 0;
+    run(k_stream_cuts, a, 1, 64, reverse);
+    run(k_stream_verify, a, (a.ntiles + 63) / 64, 64, reverse);
+    if (getenv("SIM_TILE_LOG")) fprintf(stderr, "stream round %d: start events %u, changed skip bits %u, bad %u (flags %x)\n", rounds,
+                                        counters[TILE_CNT_START], counters[TILE_CNT_FLIPS], counters[TILE_CNT_BAD], trecs[0].flags);
+    if (counters[TILE_CNT_BAD] != 0) { info[0] = trecs[0].flags; info[1] = (uint32_t)rounds; return -10; }
+    if (counters[TILE_CNT_START] == 0 && counters[TILE_CNT_FLIPS] == 0) { settled = true; break; }
+    JobArgs b = a;
+    b.J.flags |= JOB_FLAG_SWEEP;
+    uint32_t sg = getenv("SIM_SWEEP_GROUPS") ? (uint32_t)atoi(getenv("SIM_SWEEP_GROUPS")) : 2u;
+    if (sg != 1 && sg != 2 && sg != 4) sg = 2;
+    b.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
+    if (sg != 4) b.J.flags |= sg << JOB_FLAG_GROUPS_SHIFT;
+    run(k_chain_sweep, b, (a.ntiles + sg - 1) / sg, 64, reverse);
+  }
+  info[1] = (uint32_t)rounds;
+  if (!settled) { info[0] = TILE_WHY_EVENTS; return -10; }
+  a.aux = 1;
+  run(k_stream_cuts, a, 1, 64, reverse);
+  if (counters[TILE_CNT_BAD] != 0) { info[0] = trecs[0].flags; return -10; }
+  run(k_stream_finish, a, a.ntiles, 64, reverse);
+  const uint32_t nmb = counters[TILE_CNT_NMB];
+  info[2] = nmb;
+  {
+    JobArgs m = a;                                  // build / store see the meta-blocks as their shards
+    m.shards = mdesc.data();
+    m.states = mstate.data();
+    m.nshards = nmb;
+    run(k_build, m, nmb, 64, reverse);
+    run(k_store, m, nmb, 64, reverse);
+  }
+  run(k_stream_scan, a, 1, 64, reverse);
+  if (counters[1]) return -3;
+  if (counters[TILE_CNT_RAW] != 0) { info[0] = TILE_WHY_RAW; return -10; }
+  run(k_stream_place, a, nmb * STREAM_PLACE_PARTS, 256, reverse);
+  const uint64_t nbytes = (moff[nmb] + 7) / 8;
+  if (nbytes > out_cap) return -4;
+  memcpy(out, sout.data(), nbytes);
+  return (long)nbytes;
+}
+
 // Quality 1 on the simulator: the k_fast_* pipeline for one run of calls ending in
 // FINISH (is_last) or at a byte-pending point.  Returns the number of output bits
 // (bytes = (bits + 7) / 8 are written), negative on error.

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Fuzzer of the tiled stream path (JOB_FLAG_STREAMT) on the SIMT simulator: one-shot quality-5 streams longer than
+the window (several laps of the ring at lgwin 17 / 18), compared byte for byte with the reference library.
+usage: fuzz_stream_sim.py first_seed count"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+import gen_inputs  # noqa: E402
+from refharness import Ref  # noqa: E402
+from simharness import Sim  # noqa: E402
+
+
+def make(seed):
+    rng = np.random.default_rng(seed)
+    lgwin = int(rng.choice([17, 17, 18, 19]))
+    kind = int(rng.integers(0, 5))
+    n = int(rng.integers(3 << 16, (14 << 16) if lgwin == 17 else (20 << 16)))
+    if kind == 0:
+        data = bytes(gen_inputs.enwik_text(n, seed=seed))
+    elif kind == 1:
+        # a block of text repeated with a period near the window / the ring, mutated a little: long matches that
+        # age out of the window, reach over block and ring ends, ExtendLastCommand across them
+        period = int(rng.choice([1 << lgwin, 2 << lgwin, (1 << lgwin) - 16, (1 << lgwin) + 7, (2 << lgwin) - 3, 65536, 65536 + 11, 40000]))
+        base = np.frombuffer(bytes(gen_inputs.enwik_text(period, seed=seed)), dtype=np.uint8).copy()
+        reps = -(-n // period)
+        buf = np.tile(base, reps)[:n].copy()
+        nm = int(rng.integers(0, n // 2000 + 2))
+        pos = rng.integers(0, n, nm)
+        buf[pos] = rng.integers(32, 127, nm)
+        data = buf.tobytes()
+    elif kind == 2:
+        data = bytes(gen_inputs.enwik_text(n, seed=seed, vocab=int(rng.choice([300, 3000, 30000]))))
+    elif kind == 3:
+        # text with the block boundaries' neighbourhood made repetitive (copies cut by block ends)
+        buf = np.frombuffer(bytes(gen_inputs.enwik_text(n, seed=seed)), dtype=np.uint8).copy()
+        for b in range(65536, n, 65536):
+            w = int(rng.integers(16, 3000))
+            a = max(0, b - w)
+            d = int(rng.integers(1, min(a, 1 << lgwin) - 1)) if a > 2 else 1
+            if a - d >= 0 and b + w <= n:
+                buf[a:b + w] = buf[a - d:b + w - d]
+        data = buf.tobytes()
+    else:
+        t = bytes(gen_inputs.enwik_text(n, seed=seed))
+        cut = int(rng.integers(1, 65536))
+        data = t[:n - cut]
+    return data, lgwin, kind
+
+
+def main():
+    first, count = int(sys.argv[1]), int(sys.argv[2])
+    sim, ref = Sim(), Ref()
+    bad = 0
+    for seed in range(first, first + count):
+        data, lgwin, kind = make(seed)
+        want = ref.compress(data, 5, lgwin)
+        t = time.time()
+        got, info = sim.encode_stream(data, lgwin=lgwin, reverse=seed & 1)
+        if got is None:
+            print("seed %d kind %d n %d lgwin %d: off the tiled path, reasons %#x (%.0f s)" % (seed, kind, len(data), lgwin, info[0], time.time() - t), flush=True)
+        elif got != want:
+            bad += 1
+            print("seed %d kind %d n %d lgwin %d: MISMATCH (%d vs %d bytes, sweeps %d, meta-blocks %d)" % (seed, kind, len(data), lgwin, len(got), len(want), info[1], info[2]), flush=True)
+        else:
+            print("seed %d kind %d n %d lgwin %d: ok (sweeps %d, meta-blocks %d, %.0f s)" % (seed, kind, len(data), lgwin, info[1], info[2], time.time() - t), flush=True)
+    print("mismatches:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
