@@ -86,7 +86,10 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
   while (wave_any(act && cur < b)) {
     const bool on = act && cur < b;
     const uint32_t x = cur + (uint32_t)t;
-    bool sk = on && x < b && ix_storable(C.geo, x);
+    // (the last three positions of a block are stored by the next block's stitch whatever the parse does —
+    //  ..64_simd_inc.h:139-151 — and nothing searches between the block's end and the stitch: never unstored.
+    //  A copy of the fast path that runs to the block's end passes over them; found by tools/fuzz_stream_sim.py)
+    bool sk = on && x < b && ix_storable(C.geo, x) && x + C.geo.htl <= ix_block_end(C.geo, x);
     if (sk && stride > 1u && ((x - sfirst) % stride) == 0u) sk = false;
     const uint32_t hi = sk ? c_res_hi(C, x) : 0u;
     const uint32_t s = hi & 0xFFFFFFu, ns = sk ? (hi >> IX_NSUCC_SHIFT) & 31u : 0u;
@@ -191,6 +194,10 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
       // (round 0 of a tiled job: what other tiles skipped is not known yet — taken as stored, k_tile_events tells)
       stored = inrun && !(((C.mode & C_VIEW_ALL) != 0 || q >= C.tile_lo) && c_skipped(C, q));
     }
+#if defined(BROTLI_AMD_SIMT_SIM)
+    if (getenv("SIM_DBGPOS") && want && ok && P == (uint32_t)atoi(getenv("SIM_DBGPOS")))
+      fprintf(stderr, "  WALK P %u idx %d q %u inrun %d stored %d skipbit %d mode %x tile_lo %u\n", P, idx, q, (int)inrun, (int)stored, (int)c_skipped(C, q), C.mode, C.tile_lo);
+#endif
     const uint32_t nr16 = q_mask16(wave_ballot(on && !inrun));
     const uint32_t te = nr16 ? (uint32_t)dev_ctz32(nr16) : 16u;
     stored = stored && (uint32_t)t < te;

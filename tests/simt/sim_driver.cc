@@ -343,6 +343,11 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   run(k_stream_finish, a, a.ntiles, 64, reverse);
   const uint32_t nmb = counters[TILE_CNT_NMB];
   info[2] = nmb;
+  if (const char* path = getenv("SIM_STREAM_CMDS")) {        // (debugging: the stream's commands, all meta-blocks)
+    uint64_t total = 0;
+    for (uint32_t m = 0; m < nmb; ++m) total += mstate[m].ncmds;
+    if (FILE* f = fopen(path, "wb")) { fwrite(ws.data() + plan.shards[0].cmds_off, sizeof(Command), total, f); fclose(f); }
+  }
   {
     JobArgs m = a;                                  // build / store see the meta-blocks as their shards
     m.shards = mdesc.data();
