@@ -349,10 +349,41 @@ static int submit_fast(BrotliEncoderState* s, int op) {
   return 1;
 }
 
+/* One encoder instance: the persistent device stream reproduces the reference for any op sequence. */
+static int submit_serial(BrotliEncoderState* s, int op) {
+  const uint8_t* out;
+  uint64_t out_len;
+  if (!open_stream(s)) {
+    if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+    return 0;
+  }
+  if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, op, &out, &out_len) != BROTLI_AMD_OK) {
+    if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+    return 0;
+  }
+  s->submitted += s->in_len;
+  s->in_len = 0;
+  s->header_written = 1;
+  return out_append(s, out, (size_t)out_len);
+}
+
+/* A whole quality-5 stream in one FINISH that is longer than the window (BrotliEncoderCompress of a big buffer, the
+   CLI on a big file): the tiled stream path of the HIP layer (BROTLI_AMD_FLAG_STREAM_TILES; k_tile.h) parses all its
+   input blocks at once.  BROTLI_AMD_STREAM_TILES=0 keeps such streams on the serial device stream. */
+static int wants_stream_tiles(const BrotliEncoderState* s, int op) {
+  const char* e = getenv("BROTLI_AMD_STREAM_TILES");
+  if (e && atoi(e) == 0) return 0;
+  return s->quality == 5 && s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream && s->ndicts == 0 &&
+         s->lgwin >= 17 && s->lgwin <= 22 && s->in_len > ((size_t)1 << s->lgwin) - 16 && s->in_len < ((size_t)1 << 31);
+}
+
 /* Hands everything buffered to the device and applies `op` (1 flush, 2 finish). */
 static int submit(BrotliEncoderState* s, int op) {
+  const int stream_tiles = wants_stream_tiles(s, op);
   if (s->quality == 1) return submit_fast(s, op);
-  if (s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream &&
+  if (stream_tiles) {
+    /* (the plan code below with shard size 0 and the flag; BROTLI_AMD_SERIAL sends it to submit_serial) */
+  } else if (s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream &&
       s->in_len != 0 && s->ndicts == 0 &&
       (s->quality != 5 || (s->lgwin >= 17 && s->in_len <= ((size_t)1 << (s->lgwin < 22 ? s->lgwin : 22)) - 16))) {
     /* Everything in one FINISH (BrotliEncoderCompress, the CLI on a small file): the same bytes come from a
@@ -367,20 +398,7 @@ static int submit(BrotliEncoderState* s, int op) {
        (An operation before the first data byte is answered on the host, below: the reference has
        not chosen its hasher yet either — UpdateSizeHint, encode.c:1619-1632, keeps a hint of 0
        open — so the device stream is only created once there is data to size it by.) */
-    const uint8_t* out;
-    uint64_t out_len;
-    if (!open_stream(s)) {
-      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
-      return 0;
-    }
-    if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, op, &out, &out_len) != BROTLI_AMD_OK) {
-      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
-      return 0;
-    }
-    s->submitted += s->in_len;
-    s->in_len = 0;
-    s->header_written = 1;
-    return out_append(s, out, (size_t)out_len);
+    return submit_serial(s, op);
   }
   /* Partition plan: the buffered bytes become ceil(n / shard) independent
      shards that start at stream offset stream_offset + submitted. */
@@ -418,6 +436,7 @@ static int submit(BrotliEncoderState* s, int op) {
     p.is_last = op == OP_FINISH;
     if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
     if (s->disable_ctx) p.flags |= BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT;
+    if (stream_tiles) p.flags |= BROTLI_AMD_FLAG_STREAM_TILES;
     cap = brotli_amd_max_output(s->in_len, &p);
     if (cap == 0) return 0;
     if (!sync_context_dictionaries(s)) return 0;
@@ -433,6 +452,7 @@ static int submit(BrotliEncoderState* s, int op) {
         s->header_written = 1;
         return 1;
       }
+      if (rc == BROTLI_AMD_SERIAL) return submit_serial(s, op);
       if (rc != BROTLI_AMD_OVERFLOW) {
         if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
         return 0;
@@ -440,10 +460,13 @@ static int submit(BrotliEncoderState* s, int op) {
       n = 0;
     }
     if (!grow(s, &s->out_buf, &s->out_cap, s->out_len, s->out_len + cap)) return 0;
-    if (brotli_amd_encode_host(s->ctx, s->in_buf, s->in_len, &p, s->out_buf + s->out_len, cap, &n,
-                               &info) != BROTLI_AMD_OK) {
-      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
-      return 0;
+    {
+      const int rc = brotli_amd_encode_host(s->ctx, s->in_buf, s->in_len, &p, s->out_buf + s->out_len, cap, &n, &info);
+      if (rc == BROTLI_AMD_SERIAL) return submit_serial(s, op);
+      if (rc != BROTLI_AMD_OK) {
+        if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+        return 0;
+      }
     }
     s->out_len += (size_t)n;
     s->submitted += s->in_len;

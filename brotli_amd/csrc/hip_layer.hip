@@ -53,6 +53,12 @@ struct BrotliAmdCtx {
   TileDesc* d_tiles = nullptr;      // tiled jobs (JOB_FLAG_TILED): the tile table and the tiles' records
   TileRec* d_trecs = nullptr;
   uint64_t tile_cap = 0;
+  // a tiled stream (JOB_FLAG_STREAMT): index chunks, the meta-blocks as shards, their bit offsets
+  ShardDesc* d_chunks = nullptr;
+  ShardDesc* d_mdesc = nullptr;
+  ShardState* d_mstate = nullptr;
+  uint64_t* d_moff = nullptr;
+  uint64_t chunk_cap = 0, mb_cap = 0;
   uint8_t* d_stage_in = nullptr;    // encode_host staging
   uint8_t* d_stage_out = nullptr;
   uint64_t stage_in_cap = 0, stage_out_cap = 0;
@@ -676,6 +682,220 @@ rounds_done:
   return true;
 }
 
+
+// One unpartitioned quality-5 stream longer than the window on the tiled path (JOB_FLAG_STREAMT, k_tile.h; the
+// simulator's sim_encode_stream is the same sequence).  rc: BROTLI_AMD_OK, BROTLI_AMD_SERIAL (the stream left the
+// tiled path: nothing written), BROTLI_AMD_OVERFLOW.  info->reserved = sweeps | meta-blocks << 8 | reasons << 16.
+bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, const uint8_t* d_in, uint8_t* d_out,
+                    uint64_t out_cap, uint64_t* out_size, BrotliAmdJobInfo* info, int* rc) {
+  JobPlan plan;
+  uint32_t warm = 2048;
+  if (const char* e = getenv("BROTLI_AMD_TILE_WARM")) warm = (uint32_t)atoi(e);
+  uint64_t region = 0;
+  if (!plan_stream(len, p->lgwin, p->size_hint, warm, /*ix_in_ws=*/false, &plan, &region)) { *rc = BROTLI_AMD_SERIAL; return true; }
+  if (p->flags & BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT) plan.J.flags |= JOB_FLAG_NO_LITCTX;
+  if (p->flags & BROTLI_AMD_FLAG_NO_HEADER) plan.J.flags |= JOB_FLAG_NO_HEADER;
+  const uint32_t ntiles = (uint32_t)plan.tiles.size(), nchunks = plan.J.nchunks, mcap = plan.mcap;
+  if (!ensure_log2(c, plan.J.log2_lut_size)) return false;
+  if (!ensure_ws(c, plan.ws_bytes, 1)) return false;
+  if (!ensure_tiles(c, ntiles)) return false;
+  {
+    // the chunks' index regions: the allocations the shards' regions of a plan live in
+    JobPlan cp;
+    cp.J = plan.J;
+    cp.shards = plan.chunks;
+    c->ix_region_bytes = region;
+    if (!prepare_tables(c, &cp)) return false;
+    plan.chunks = cp.shards;
+  }
+  if (nchunks > c->chunk_cap) {
+    if (c->d_chunks) HIP_OK(c, hipFree(c->d_chunks));
+    c->d_chunks = nullptr; c->chunk_cap = 0;
+    HIP_OK(c, hipMalloc((void**)&c->d_chunks, nchunks * sizeof(ShardDesc)));
+    c->chunk_cap = nchunks;
+  }
+  if (mcap > c->mb_cap) {
+    if (c->d_mdesc) HIP_OK(c, hipFree(c->d_mdesc));
+    if (c->d_mstate) HIP_OK(c, hipFree(c->d_mstate));
+    if (c->d_moff) HIP_OK(c, hipFree(c->d_moff));
+    c->d_mdesc = nullptr; c->d_mstate = nullptr; c->d_moff = nullptr; c->mb_cap = 0;
+    HIP_OK(c, hipMalloc((void**)&c->d_mdesc, mcap * sizeof(ShardDesc)));
+    HIP_OK(c, hipMalloc((void**)&c->d_mstate, mcap * sizeof(ShardState)));
+    HIP_OK(c, hipMalloc((void**)&c->d_moff, (mcap + 1) * sizeof(uint64_t)));
+    c->mb_cap = mcap;
+  }
+  HIP_OK(c, hipEventRecord(c->ev[6], c->stream));
+  HIP_OK(c, hipMemcpyAsync(c->d_shards, plan.shards.data(), sizeof(ShardDesc), hipMemcpyHostToDevice, c->stream));
+  HIP_OK(c, hipMemcpyAsync(c->d_chunks, plan.chunks.data(), nchunks * sizeof(ShardDesc), hipMemcpyHostToDevice, c->stream));
+  HIP_OK(c, hipMemcpyAsync(c->d_tiles, plan.tiles.data(), ntiles * sizeof(TileDesc), hipMemcpyHostToDevice, c->stream));
+  HIP_OK(c, hipMemsetAsync(c->d_trecs, 0, ntiles * sizeof(TileRec), c->stream));
+  HIP_OK(c, hipMemsetAsync(c->d_mstate, 0, mcap * sizeof(ShardState), c->stream));
+  HIP_OK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
+  const uint64_t zero_out = plan.max_out_bytes + 8 < out_cap ? plan.max_out_bytes + 8 : out_cap;
+  HIP_OK(c, hipMemsetAsync(d_out, 0, zero_out, c->stream));
+  JobArgs a;
+  a.J = plan.J;
+  a.shards = c->d_shards;
+  a.states = c->d_states;
+  a.T = c->d_T;
+  a.input = d_in;
+  a.ws = c->d_ws;
+  a.nshards = 1;
+  a.init_blocks_per_shard = 1;
+  a.counters = c->d_counters;
+  a.tiles = c->d_tiles;
+  a.trecs = c->d_trecs;
+  a.ntiles = ntiles;
+  a.chunks = c->d_chunks;
+  a.mdesc = c->d_mdesc;
+  a.mstate = c->d_mstate;
+  a.moff = c->d_moff;
+  a.sout = d_out;
+  a.mcap = mcap;
+  const bool tlog = getenv("BROTLI_AMD_TILE_LOG") != nullptr;
+  auto lap = [&](const char* what) {
+    static double t_prev = 0;
+    if (!tlog) return;
+    (void)hipStreamSynchronize(c->stream);
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double now = ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+    if (what) fprintf(stderr, "  stream stage %-14s %8.3f ms\n", what, now - t_prev);
+    t_prev = now;
+  };
+  lap(nullptr);
+  hipLaunchKernelGGL(k_init, dim3(1), dim3(256), 0, c->stream, a);
+  HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
+  {
+    JobArgs x = a;                          // the index kernels see the chunks as their shards
+    x.shards = c->d_chunks;
+    x.nshards = nchunks;
+    hipLaunchKernelGGL(k_ix_count, dim3(nchunks * plan.J.ix_slices), dim3(64), 0, c->stream, x);
+    hipLaunchKernelGGL(k_ix_scan, dim3(nchunks), dim3(64), 0, c->stream, x);
+    hipLaunchKernelGGL(k_ix_scatter, dim3(nchunks * plan.J.ix_slices), dim3(64), (IX_CHUNK + (3u << plan.J.ix_nb_log2)) * 4u, c->stream, x);
+    HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
+    hipLaunchKernelGGL(k_ix_bucket, dim3(((nchunks + 7u) / 8u) * 8u * ((1u << plan.J.ix_nb_log2) / plan.J.ix_bpw)), dim3(64), 0, c->stream, x);
+    HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
+  }
+  lap("index");
+  const uint32_t nkg = (1u << plan.J.bucket_bits) / 64u;
+  const dim3 egrid(nchunks * plan.J.ix_slices);
+  hipLaunchKernelGGL(k_stream_kprefix, dim3(nkg), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, a);
+  HIP_OK(c, hipEventRecord(c->ev[2], c->stream));
+  const uint32_t gpw = ntiles >= 1024 ? 4u : ntiles >= 512 ? 2u : 1u;
+  {
+    JobArgs f = a;
+    f.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
+    if (gpw != 4) f.J.flags |= gpw << JOB_FLAG_GROUPS_SHIFT;
+    hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f);
+  }
+  lap("first parse");
+  bool settled = false;
+  uint32_t tc[16], sweeps = 0, reasons = 0;
+  auto reasons_of = [&]() -> bool {
+    TileRec r0;
+    HIP_OK(c, hipMemcpy(&r0, c->d_trecs, sizeof(TileRec), hipMemcpyDeviceToHost));
+    reasons = r0.flags >> 8;
+    return true;
+  };
+  for (int pass = 0; pass < 24 && !settled; ++pass) {
+    HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_START, 0, 2 * sizeof(uint32_t), c->stream));
+    {
+      JobArgs e = a;
+      if (pass != 0) e.J.flags |= JOB_FLAG_SWEEP;
+      hipLaunchKernelGGL(k_stream_events, egrid, dim3(64), 0, c->stream, e);
+    }
+    hipLaunchKernelGGL(k_stream_skclear, egrid, dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_stream_skcount, egrid, dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_stream_kprefix, dim3(nkg), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, a);
+    a.aux = 0;
+    hipLaunchKernelGGL(k_stream_cuts, dim3(1), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_stream_verify, dim3((ntiles + 63u) / 64u), dim3(64), 0, c->stream, a);
+    HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(c, hipStreamSynchronize(c->stream));
+    lap("events..verify");
+    if (tlog) fprintf(stderr, "stream pass %d: start events %u, changed bits / marks %u, off the tiled path %u\n", pass,
+                      tc[TILE_CNT_START], tc[TILE_CNT_FLIPS], tc[TILE_CNT_BAD]);
+    if (tc[TILE_CNT_BAD] != 0) {
+      if (!reasons_of()) return false;
+      if (info) info->reserved = sweeps | (reasons << 16);
+      *rc = BROTLI_AMD_SERIAL;
+      return true;
+    }
+    if (tc[TILE_CNT_START] == 0 && tc[TILE_CNT_FLIPS] == 0) { settled = true; break; }
+    JobArgs b = a;
+    b.J.flags |= JOB_FLAG_SWEEP;
+    uint32_t sg = 2;
+    if (const char* e = getenv("BROTLI_AMD_SWEEP_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) sg = (uint32_t)v; }
+    b.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
+    if (sg != 4) b.J.flags |= sg << JOB_FLAG_GROUPS_SHIFT;
+    hipLaunchKernelGGL(k_chain_sweep, dim3((ntiles + sg - 1) / sg), dim3(64), sg * C_GROUP_LDS_WORDS * 4u, c->stream, b);
+    ++sweeps;
+    lap("sweep");
+  }
+  if (!settled) {
+    if (info) info->reserved = sweeps | ((TILE_WHY_EVENTS >> 8) << 16);
+    *rc = BROTLI_AMD_SERIAL;
+    return true;
+  }
+  a.aux = 1;
+  hipLaunchKernelGGL(k_stream_cuts, dim3(1), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(k_stream_finish, dim3(ntiles), dim3(64), 0, c->stream, a);
+  HIP_OK(c, hipEventRecord(c->ev[3], c->stream));
+  lap("cuts+finish");
+  {
+    JobArgs m = a;                          // build / store see the meta-blocks as their shards
+    m.shards = c->d_mdesc;
+    m.states = c->d_mstate;
+    m.nshards = mcap;
+    hipLaunchKernelGGL(k_build, dim3(mcap), dim3(64), 0, c->stream, m);
+    HIP_OK(c, hipEventRecord(c->ev[4], c->stream));
+    hipLaunchKernelGGL(k_store, dim3(mcap), dim3(64), 0, c->stream, m);
+    HIP_OK(c, hipEventRecord(c->ev[5], c->stream));
+  }
+  lap("build+store");
+  hipLaunchKernelGGL(k_stream_scan, dim3(1), dim3(64), 0, c->stream, a);
+  HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  if (tc[1]) return fail(c, "%u meta-block(s) reported a device fault", tc[1]);
+  const uint32_t nmb = tc[TILE_CNT_NMB];
+  if (tc[TILE_CNT_BAD] != 0 || tc[TILE_CNT_RAW] != 0 || nmb == 0 || nmb > mcap) {
+    if (tc[TILE_CNT_BAD] != 0) { if (!reasons_of()) return false; } else reasons = TILE_WHY_RAW >> 8;
+    if (info) info->reserved = sweeps | (nmb << 8) | (reasons << 16);
+    *rc = BROTLI_AMD_SERIAL;
+    return true;
+  }
+  uint64_t total_bits = 0;
+  HIP_OK(c, hipMemcpy(&total_bits, c->d_moff + nmb, 8, hipMemcpyDeviceToHost));
+  const uint64_t total = (total_bits + 7) / 8;
+  *out_size = total;
+  if (total + 8 > out_cap) { c->err = "output capacity too small"; *rc = BROTLI_AMD_OVERFLOW; return true; }
+  hipLaunchKernelGGL(k_stream_place, dim3(nmb * STREAM_PLACE_PARTS), dim3(256), 0, c->stream, a);
+  HIP_OK(c, hipEventRecord(c->ev[7], c->stream));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  HIP_OK(c, hipGetLastError());
+  lap("place");
+  if (info) {
+    float t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[6], c->ev[1])); info->ms_init = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[1], c->ev_ix)); info->ms_index = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev_ixb, c->ev_ix)); info->ms_ix_bucket = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev_ix, c->ev[3])); info->ms_parse = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[3], c->ev[4])); info->ms_build = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[4], c->ev[5])); info->ms_store = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[5], c->ev[7])); info->ms_gather = t;
+    HIP_OK(c, hipEventElapsedTime(&t, c->ev[6], c->ev[7])); info->ms_total = t;
+    info->rounds = 1;
+    info->reserved = sweeps | (nmb << 8);
+    info->nshards = 1;
+    info->ws_bytes = plan.ws_bytes;
+    info->out_bytes = total;
+  }
+  *rc = BROTLI_AMD_OK;
+  return true;
+}
+
 }  // namespace
 
 extern "C" {
@@ -720,6 +940,7 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_lut, c->d_dict, c->d_hash_words, c->d_hash_lengths, c->d_log2, c->d_T,
                   c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters, c->d_tiles, c->d_trecs,
+                  c->d_chunks, c->d_mdesc, c->d_mstate, c->d_moff,
                   c->d_stage_in, c->d_stage_out, c->d_ffrags, c->d_fblocks, c->d_fbstate,
                   c->d_ffstate, c->d_fresult, c->d_transforms, c->d_transform_text, c->d_dec_arena,
                   c->d_dec_pieces, c->d_dec_results};
@@ -760,6 +981,17 @@ int brotli_amd_encode_device(BrotliAmdCtx* c, const void* d_in, uint64_t len,
   *out_size = 0;
   DeviceScope dev(c->device);
   if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  if (p->flags & BROTLI_AMD_FLAG_STREAM_TILES) {
+    if (p->quality != 5 || p->shard_size != 0 || p->stream_base != 0 || !p->is_last || c->d_cd || d_shard_sizes) {
+      fail(c, "BROTLI_AMD_FLAG_STREAM_TILES: quality 5, one whole stream, no dictionary");
+      return BROTLI_AMD_UNSUPPORTED;
+    }
+    int src = BROTLI_AMD_ERROR;
+    if (!run_stream_job(c, len, p, (const uint8_t*)d_in, (uint8_t*)d_out, out_cap, out_size, info, &src))
+      return c->err.find("device fault") != std::string::npos ? BROTLI_AMD_DEVICE_FAULT : BROTLI_AMD_ERROR;
+    if (src == BROTLI_AMD_SERIAL) c->err = "the stream left the tiled path";
+    return src;
+  }
   JobPlan plan;
   int rc = plan_from_params(c, len, p, &plan);
   if (rc != BROTLI_AMD_OK) return rc;

@@ -254,11 +254,12 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   const uint32_t dc_len3 = dc_len < 3u ? 3u : dc_len;
   bool unsure = b_ok && b_score > dc_score && b_len <= dc_len3;
   if (g.ring_mask != 0xFFFFFFFFu) {
-    // a stream longer than the ring: a search in the last block of a lap, or with a candidate within reach of the
-    // ring's physical end, follows the order-dependent rules of q_resolve_slow
+    // a stream longer than the ring: a search with a candidate at the ring's physical end follows the
+    // order-dependent rules of q_resolve_slow
+    // (only a candidate whose match reaches over the end can change the outcome: see ix_window)
     const uint32_t rm = g.ring_mask;
-    unsure = unsure || (want && (P & rm) + max_length > rm) || (d_cand && (d_prev & rm) + max_length > rm) ||
-             (b_cand && (b_prev & rm) + max_length > rm);
+    unsure = unsure || (d_cand && ((d_prev & rm) + d_len > rm || (P & rm) + d_len > rm)) ||
+             (b_cand && ((b_prev & rm) + b_len > rm || (P & rm) + b_len > rm));
   }
   const bool slow = q_mask16(wave_ballot(unsure)) != 0 || ((J.flags & JOB_FLAG_FORCE_SLOW) != 0 && want);
   const uint32_t best = q_max(b_key > d_key ? b_key : d_key);
@@ -336,7 +337,7 @@ DEV CEval c_evaluate(const JobParams& J, CShard& C, bool want, uint32_t P0, int 
   uint32_t ring_risk = 0;
   if (g.ring_mask != 0xFFFFFFFFu) {      // (the ring's physical end: see c_search_exact)
     const uint32_t rm = g.ring_mask;
-    ring_risk = (ev && (Pk & rm) + max_length > rm) || (d_cand && ((Pk - backward) & rm) + max_length > rm) ? 1u : 0u;
+    ring_risk = (d_cand && (((Pk - backward) & rm) + d_len > rm || (Pk & rm) + d_len > rm)) ? 1u : 0u;
     ring_risk |= wave_quad_xor(ring_risk, 1);
     ring_risk |= wave_quad_xor(ring_risk, 2);
   }
@@ -484,10 +485,13 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     const bool b_wins = kind == IX_KIND_EXACT && b_score > dc_score;
     bool ring_risk = false;
     if (g.ring_mask != 0xFFFFFFFFu) {    // (the ring's physical end: see c_search_exact)
-      const uint32_t rm = g.ring_mask, ml = g.pos_end - Pk;
-      ring_risk = (Pk & rm) + ml > rm;
+      // (cache candidates of up to 16 compared bytes: a longer one goes to the exact search anyway)
+      const uint32_t rm = g.ring_mask;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ring_risk = ring_risk || (d_cand[i] && ((Pk - dcs[i]) & rm) + ml > rm);
+      for (int i = 0; i < 4; ++i) {
+        const uint32_t md = c_prefix16(cb, pb[i]);
+        ring_risk = ring_risk || (d_cand[i] && (((Pk - dcs[i]) & rm) + md > rm || (Pk & rm) + md > rm));
+      }
     }
     const bool need = kind >= IX_KIND_LONG || (rhi & (IX_DANGER | IX_TAINT)) != 0 || d_long || force_slow || ring_risk ||
                       (b_wins && b_len <= umax(dc_len, 3u));

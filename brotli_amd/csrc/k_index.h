@@ -350,9 +350,13 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
   const bool search = act && p >= g.own && ix_searchable(g, P);
   const uint32_t max_length = search ? ix_block_end(g, P) - P : 0u;
   const uint32_t maxb = umin(P, g.maxdist);                     // max_backward (backward_references_inc.h:56-57)
-  // the ring buffer's physical end (..64_simd_inc.h:243-249): a search in the last block of a lap, or one with a
-  // candidate that close to the end of a lap, follows rules that depend on the order of visit — the chain's to do
-  bool ringrisk = g.stream && search && (P & g.ring_mask) + max_length > g.ring_mask;
+  // the ring buffer's physical end (..64_simd_inc.h:243-249: no candidate is looked at once the current position is
+  // within best_len of it, one that is within best_len of it is passed over): a candidate whose match does not reach
+  // over the end — at either position — loses whenever one of the two rules would have applied to it (best_len is then
+  // longer than its match), so only a candidate whose match does reach over it makes the search order-dependent —
+  // the chain's to do
+  bool ringrisk = false;
+  const uint32_t rm = g.stream ? g.ring_mask : 0xFFFFFFFFu;
   uint32_t best = 0, best_len = 0, best_dist = 0;               // exact candidates
   uint32_t longmask = 0;
 #if defined(IX_NOWIN)       // (timing experiments only: results are wrong)
@@ -369,7 +373,6 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
     uint32_t l = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
     if (l < 4u) continue;                                       // first4 != current4
     if (p - (qw & 0xFFFFFFu) > maxb) continue;                  // beyond the window (:239-241: it and everything older)
-    if (g.stream && (((qw & 0xFFFFFFu) + g.base) & g.ring_mask) + max_length > g.ring_mask) ringrisk = true;
     if (l == 8u) {
       const uint64_t x2 = S.d2[li - j] ^ e.d2;
       l = x2 ? 8u + ((uint32_t)dev_ctz64(x2) >> 3) : 16u;
@@ -378,6 +381,7 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
 #endif
     }
     const uint32_t len = umin(l, max_length);
+    if ((((qw & 0xFFFFFFu) + g.base) & rm) + len > rm || (P & rm) + len > rm) ringrisk = true;
     const uint32_t dist = p - (qw & 0xFFFFFFu);
     const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
     if (k > best) { best = k; best_len = len; best_dist = dist; }
@@ -420,6 +424,10 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
         if (jj[u] == 0) continue;
         const uint32_t len = umin(ln[u], max_length);
         const uint32_t dist = p - qp[u];
+        {
+          const uint32_t reach = (len == IX_CAP && max_length > IX_CAP) ? max_length : len;     // (a capped one: as far as it may go)
+          if (((qp[u] + g.base) & rm) + reach > rm || (P & rm) + reach > rm) ringrisk = true;
+        }
         const uint32_t k = (ix_score(len, dist) << 5) | (16u - jj[u]);
         if (len == IX_CAP && max_length > IX_CAP) {
           ++ncapped;

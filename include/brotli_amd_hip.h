@@ -28,6 +28,7 @@ extern "C" {
 #define BROTLI_AMD_ERROR (-1)        /* HIP failure, see brotli_amd_last_error */
 #define BROTLI_AMD_UNSUPPORTED (-2)  /* parameters outside the GPU path */
 #define BROTLI_AMD_OVERFLOW (-3)     /* output capacity too small */
+#define BROTLI_AMD_SERIAL (-5)       /* BROTLI_AMD_FLAG_STREAM_TILES: the stream has to go through brotli_amd_stream_* */
 #define BROTLI_AMD_DEVICE_FAULT (-4) /* a shard reported an internal error */
 
 /* Device input buffers must stay readable this many bytes past `len`
@@ -63,6 +64,11 @@ typedef struct BrotliAmdJobParams {
                                          encode.c:1356-1415): the first shard starts byte aligned */
 #define BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT 32u /* BROTLI_PARAM_DISABLE_LITERAL_CONTEXT_MODELING: one literal context
                                         (encode.c:561; qualities below 5 have one anyway) */
+#define BROTLI_AMD_FLAG_STREAM_TILES 64u /* quality 5, shard_size 0, the whole stream in this one call (stream_base 0, is_last):
+                                          parse it in tiles although it is longer than the window (k_tile.h, JOB_FLAG_STREAMT).
+                                          BROTLI_AMD_SERIAL comes back when the stream turns out not to suit the tiles (static
+                                          dictionary still consulted, a meta-block stored raw ...): nothing was written, the
+                                          caller runs it through brotli_amd_stream_* instead */
 #define BROTLI_AMD_FLAG_NO_INDEX 16u  /* quality 5: hash-table parse (k_parse4) instead of the position index
                                          (k_index.h + k_chain.h) */
 

@@ -293,6 +293,15 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   a.sout = sout.data();
   a.mcap = plan.mcap;
   info[0] = info[1] = info[2] = 0;
+  const bool tlog = getenv("SIM_TILE_LOG") != nullptr;
+  auto lap = [&](const char* what) {
+    static double t_prev = 0;
+    timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    const double now = ts.tv_sec + ts.tv_nsec * 1e-9;
+    if (tlog && what) fprintf(stderr, "  [sim] %-16s %7.2f s\n", what, now - t_prev);
+    t_prev = now;
+  };
+  lap(nullptr);
   run(k_init, a, 1, 256, 0);
   {
     JobArgs c = a;                                  // the index kernels see the chunks as their shards
@@ -300,13 +309,16 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
     c.nshards = plan.J.nchunks;
     run_index(c, reverse);
   }
+  lap("index");
   const uint32_t gpw = q_groups_per_wave(a.J);
   const uint32_t nkg = (1u << a.J.bucket_bits) / 64u;
   // the searches behind a wrap of the 16-bit store counter, as far as they can be told before the parse
   const bool zones = !getenv("SIM_NO_ZONES");      // (test knob: without them a stream with a counter wrap comes out wrong)
   if (zones) run(k_stream_kprefix, a, nkg, 64, reverse);
   if (zones) run(k_stream_zones, a, a.J.nchunks * nkg, 64, reverse);
+  lap("zones0");
   run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+  lap("first parse");
   bool settled = false;
   int rounds = 0;
   for (; rounds < 16 && !settled; ++rounds) {
@@ -316,13 +328,16 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
       if (rounds != 0 || getenv("SIM_EVENTS_ALL")) e.J.flags |= JOB_FLAG_SWEEP;
       run(k_stream_events, e, a.J.nchunks * a.J.ix_slices, 64, reverse);
     }
+    lap("events");
     run(k_stream_skclear, a, a.J.nchunks * a.J.ix_slices, 64, reverse);
     run(k_stream_skcount, a, a.J.nchunks * a.J.ix_slices, 64, reverse);
     if (zones) run(k_stream_kprefix, a, nkg, 64, reverse);
     if (zones) run(k_stream_zones, a, a.J.nchunks * nkg, 64, reverse);
+    lap("zones");
     a.aux = 0;
     run(k_stream_cuts, a, 1, 64, reverse);
     run(k_stream_verify, a, (a.ntiles + 63) / 64, 64, reverse);
+    lap("cuts+verify");
     if (getenv("SIM_TILE_LOG")) fprintf(stderr, "stream round %d: start events %u, changed skip bits %u, bad %u (flags %x)\n", rounds,
                                         counters[TILE_CNT_START], counters[TILE_CNT_FLIPS], counters[TILE_CNT_BAD], trecs[0].flags);
     if (counters[TILE_CNT_BAD] != 0) { info[0] = trecs[0].flags; info[1] = (uint32_t)rounds; return -10; }
@@ -334,6 +349,7 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
     b.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
     if (sg != 4) b.J.flags |= sg << JOB_FLAG_GROUPS_SHIFT;
     run(k_chain_sweep, b, (a.ntiles + sg - 1) / sg, 64, reverse);
+    lap("sweep");
   }
   info[1] = (uint32_t)rounds;
   if (!settled) { info[0] = TILE_WHY_EVENTS; return -10; }
@@ -353,8 +369,10 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
     m.shards = mdesc.data();
     m.states = mstate.data();
     m.nshards = nmb;
+    lap("finish");
     run(k_build, m, nmb, 64, reverse);
     run(k_store, m, nmb, 64, reverse);
+    lap("build+store");
   }
   run(k_stream_scan, a, 1, 64, reverse);
   if (counters[1]) return -3;

@@ -145,6 +145,22 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len, con
                            uint8_t* out, uint64_t out_cap, uint64_t* out_size, BrotliAmdJobInfo* info) {
   *out_size = 0;
   if (info) memset(info, 0, sizeof(*info));
+  if (p->flags & BROTLI_AMD_FLAG_STREAM_TILES) {
+    // (hip_layer.hip: run_stream_job)
+    if (p->quality != 5 || p->shard_size != 0 || p->stream_base != 0 || !p->is_last || c->dict.have)
+      return set_err(c, "BROTLI_AMD_FLAG_STREAM_TILES: quality 5, one whole stream, no dictionary", BROTLI_AMD_UNSUPPORTED);
+    uint32_t sinfo[4] = {0, 0, 0, 0};
+    int jflags = 0;
+    if (p->flags & BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT) jflags |= (int)JOB_FLAG_NO_LITCTX;
+    if (p->flags & BROTLI_AMD_FLAG_NO_HEADER) jflags |= (int)JOB_FLAG_NO_HEADER;
+    const long n = sim_encode_stream(c->tables.c_str(), in, (size_t)len, p->lgwin, p->size_hint, 0, jflags, out, (size_t)out_cap, sinfo);
+    if (info) info->reserved = sinfo[1] | (sinfo[2] << 8) | ((sinfo[0] >> 8) << 16);
+    if (n == -10 || n == -2) return set_err(c, "the stream left the tiled path", BROTLI_AMD_SERIAL);
+    if (n == -4) return set_err(c, "output capacity too small", BROTLI_AMD_OVERFLOW);
+    if (n < 0) return set_err(c, "device fault", BROTLI_AMD_DEVICE_FAULT);
+    *out_size = (uint64_t)n;
+    return BROTLI_AMD_OK;
+  }
   JobPlan plan;
   if (len == 0 || !plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
                             p->is_last != 0, &plan))

@@ -1,0 +1,115 @@
+"""The tiled parse of ONE unpartitioned quality-5 stream longer than the window (JOB_FLAG_STREAMT: k_tile.h stream_*,
+k_chain.h in stream positions, index chunks with a look-back) on the host SIMT simulator, byte for byte against the
+reference library's one-shot BrotliEncoderCompress — several laps of the ring buffer at lgwin 17 / 18, meta-block cuts,
+wraps of the 16-bit store counter — and through brotli_amd/csrc/encode_abi.c (the stock call, routed to the tiled path
+and, where the stream does not suit the tiles, on to the serial device stream).  The `-m gpu` tests run the same at
+full size through the C ABI."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import gen_inputs as G
+from simharness import Sim
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+import fuzz_stream_sim  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def sim():
+    return Sim()
+
+
+def _same(sim, ref, data, lgwin, **kw):
+    got, info = sim.encode_stream(data, lgwin=lgwin, **kw)
+    assert got is not None, "left the tiled path: reasons %#x" % info[0]
+    assert got == ref.compress(data, 5, lgwin)
+    return info
+
+
+@pytest.mark.parametrize("n,lgwin,seed", [(250000, 17, 1), (131073, 17, 7), (430000, 17, 2)])
+def test_text_streams(sim, ref, n, lgwin, seed):
+    """Two tiles and a byte; inside one lap of the ring; 1.6 laps (stale bytes behind a block end, candidates at
+    the ring's physical end, window ageing); two or three meta-blocks each."""
+    info = _same(sim, ref, bytes(G.enwik_text(n, seed=seed)), lgwin, reverse=seed & 1)
+    assert info[2] >= (2 if n > 200000 else 1)
+
+
+def test_counter_wrap_changes_the_bytes_and_is_followed(sim, ref, monkeypatch):
+    """Two words in random order behind 30 kB of noise (which closes the static-dictionary gate): every inner
+    4-byte key is stored more than 65536 times, and the first searches behind a wrap see fewer ring slots
+    (hash_longest_match_simd_inc.h: num_ as uint16).  Without the marks of k_stream_zones the stream comes out wrong."""
+    rng = np.random.default_rng(1)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(5, 10)), dtype=np.uint8)) + b" " for _ in range(2)]
+    n = 1300000
+    data = (bytes(rng.integers(97, 123, 30000, dtype=np.uint8)) + b"".join(words[i] for i in rng.integers(0, 2, n // 5)))[:n]
+    want = ref.compress(data, 5, 17)
+    got, info = sim.encode_stream(data, lgwin=17)
+    assert got == want
+    monkeypatch.setenv("SIM_NO_ZONES", "1")
+    got, info = sim.encode_stream(data, lgwin=17)
+    assert got is not None and got != want
+
+
+def test_copies_cut_by_block_ends(sim, ref):
+    """Found by tools/fuzz_stream_sim.py (seed 15): a copy of the chain's fast path that ran to its block's end marked
+    the block's last three positions as unstored, though the next block's stitch stores them — the plain chain had
+    the same fault.  Both are checked here."""
+    data, lgwin, kind = fuzz_stream_sim.make(15)
+    assert kind == 3
+    data = data[:540000]        # (the position that came out wrong is 478 843, its missing candidate 458 750)
+    _same(sim, ref, data, lgwin, reverse=1)
+    assert sim.encode(data, 5, 22, flags=64) == ref.compress(data, 5, 22)
+
+
+def test_streams_that_leave_the_tiled_path(sim):
+    """Noise / floats (too many unstored positions) and data on which the static-dictionary gate stays open: the tiled
+    path says so and writes nothing (the library then runs the serial device stream)."""
+    got, info = sim.encode_stream(bytes(G.mixed_corpus(262144, seed=6)), lgwin=17)
+    assert got is None and info[0] & 0x8000
+    rng = np.random.default_rng(3)
+    words = [bytes(rng.integers(97, 123, 7, dtype=np.uint8)) + b" " for _ in range(4)]
+    got, info = sim.encode_stream(b"".join(words[i] for i in rng.integers(0, 4, 60000))[:300000], lgwin=17)
+    assert got is None and info[0] & 0x2000
+
+
+@pytest.mark.parametrize("seed", range(300, 304))
+def test_fuzz_slice(sim, ref, seed):
+    data, lgwin, kind = fuzz_stream_sim.make(seed)
+    data = data[:400000]
+    got, info = sim.encode_stream(data, lgwin=lgwin, reverse=seed & 1)
+    if got is not None:
+        assert got == ref.compress(data, 5, lgwin)
+    else:
+        assert info[0] != 0
+
+
+def test_stock_call_through_the_boundary(ref, monkeypatch):
+    """BrotliEncoderCompress(5, lgwin, ...) of encode_abi.c over the simulator: a text longer than the window takes the
+    tiled stream path, a stream that does not suit it the serial device stream — the bytes are the reference's either
+    way; BROTLI_AMD_STREAM_TILES=0 keeps everything on the serial stream."""
+    from test_abi_on_sim import SIM_ABI
+    from test_gpu_abi import _bind
+    from refharness import ROOT, TABLES
+    import subprocess
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "simt")], check=True)
+    monkeypatch.setenv("BROTLI_AMD_TABLES", TABLES)
+    L = _bind(SIM_ABI)
+
+    def call(data, lgwin):
+        cap = L.BrotliEncoderMaxCompressedSize(len(data))
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t(cap)
+        assert L.BrotliEncoderCompress(5, lgwin, 0, len(data), data, C.byref(n), out)
+        return out.raw[:n.value]
+
+    text = bytes(G.enwik_text(280000, seed=12))
+    assert call(text, 17) == ref.compress(text, 5, 17)
+    mixed = bytes(G.mixed_corpus(200000, seed=5))
+    assert call(mixed, 17) == ref.compress(mixed, 5, 17)
+    monkeypatch.setenv("BROTLI_AMD_STREAM_TILES", "0")
+    assert call(text[:200000], 17) == ref.compress(text[:200000], 5, 17)
