@@ -1,0 +1,97 @@
+"""The stock call on a big buffer, on the GPU: BrotliEncoderCompress(5, lgwin, ...) of libbrotlienc_amd.so — no partition
+plan, no vendor parameter — on inputs longer than the window, next to the reference library's BrotliEncoderCompress
+(oracle/_ref/libbrotli_ref.so, prebuilt; nothing here reads /root/reference).  Such a stream takes the tiled stream path
+(JOB_FLAG_STREAMT: k_tile.h stream_*, index chunks with a look-back, meta-block cuts, the ring's physical end, the
+16-bit store counter) or, where it does not suit the tiles, the serial device stream; the bytes must be the
+reference's either way.  ctypes only (no torch): the boundary is the C ABI."""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import gen_inputs as G
+from test_gpu_abi import LIBDIR, ROOT, _bind
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1500, method="thread")]
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    return _bind(os.path.join(LIBDIR, "libbrotlienc_amd.so"))
+
+
+@pytest.fixture(scope="module")
+def stock(ref):
+    return _bind(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
+
+
+def one_shot(L, data, lgwin, quality=5):
+    cap = L.BrotliEncoderMaxCompressedSize(len(data))
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t(cap)
+    t = time.time()
+    assert L.BrotliEncoderCompress(quality, lgwin, 0, len(data), data, C.byref(n), out)
+    return out.raw[:n.value], time.time() - t
+
+
+@pytest.mark.parametrize("mib,lgwin,seed", [(48, 22, 5), (9, 18, 6), (3, 17, 7), (20, 20, 8)])
+def test_text_longer_than_the_window(amd, stock, mib, lgwin, seed):
+    """6 / 18 / 12 / 10 laps of the ring buffer, a dozen and more meta-blocks, keys stored more than 65536 times."""
+    data = bytes(G.enwik_text((mib << 20) + 12345, seed=seed))
+    got, _ = one_shot(amd, data, lgwin)
+    want, _ = one_shot(stock, data, lgwin)
+    assert got == want
+
+
+def test_plain_chain_copy_to_the_block_end(amd, stock):
+    """tools/fuzz_stream_sim.py seed 15 (a copy of the chain's fast path that runs to its block's end: the three
+    positions the next block's stitch stores were marked unstored) through the paths a stream of that size takes:
+    inside the window (tiled shard), longer than it (tiled stream), and as a partition plan of 128 KiB shards."""
+    import fuzz_stream_sim
+    from test_gpu_abi import drive
+    data, lgwin, kind = fuzz_stream_sim.make(15)
+    for lw in (22, 19):
+        got, _ = one_shot(amd, data, lw)
+        want, _ = one_shot(stock, data, lw)
+        assert got == want
+    got, fin = drive(amd, data, [(len(data), 2)], params=((0x4D490001, 128 << 10),))
+    assert fin
+    from refharness import Ref
+    assert bytes(got) == Ref().encode_plan(data, 5, 22, 128 << 10)
+
+
+def test_streams_that_do_not_suit_the_tiles_take_the_serial_stream(amd, stock):
+    data = bytes(G.mixed_corpus(6 << 20, seed=3))
+    got, _ = one_shot(amd, data, 22)
+    want, _ = one_shot(stock, data, 22)
+    assert got == want
+
+
+def test_1gib_stock_call(amd, stock):
+    """BrotliEncoderCompress(5, 22) of 1 GiB with no vendor setting, byte-identical to the
+    reference's (sha256), timed from the host buffer to the host buffer (PCIe both ways included); the second call
+    has the context's allocations behind it.  The numbers go to gpurun_out/ for profiles/."""
+    data = bytes(G.enwik_text(1 << 30))
+    got, t1 = one_shot(amd, data, 22)
+    sha = hashlib.sha256(got).hexdigest()
+    n1 = len(got)
+    del got
+    got2, t2 = one_shot(amd, data, 22)
+    assert hashlib.sha256(got2).hexdigest() == sha
+    del got2
+    want, tr = one_shot(stock, data, 22)
+    rec = {"bytes_in": len(data), "bytes_out": n1, "seconds_first_call": round(t1, 3), "seconds_second_call": round(t2, 3),
+           "MB_per_s_second_call": round(len(data) / t2 / 1e6, 1), "reference_seconds_one_core": round(tr, 3),
+           "sha256_equal": hashlib.sha256(want).hexdigest() == sha}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "stock_call_1GiB.json"), "w") as f:
+        json.dump(rec, f)
+    print(json.dumps(rec))
+    assert rec["sha256_equal"]
+    assert len(want) == n1
