@@ -76,7 +76,7 @@ def test_streams_that_do_not_suit_the_tiles_take_the_serial_stream(amd, stock):
 def test_1gib_stock_call(amd, stock):
     """BrotliEncoderCompress(5, 22) of 1 GiB with no vendor setting, byte-identical to the
     reference's (sha256), timed from the host buffer to the host buffer (PCIe both ways included); the second call
-    has the context's allocations behind it.  The numbers go to gpurun_out/ for profiles/."""
+    has the context's allocations behind it (bench.py reports the same call as config.stock_call_no_plan.whole_input)."""
     data = bytes(G.enwik_text(1 << 30))
     got, t1 = one_shot(amd, data, 22)
     sha = hashlib.sha256(got).hexdigest()
