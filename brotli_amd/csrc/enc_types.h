@@ -139,12 +139,19 @@ struct TileRec {
   // command of their own and the next block's ExtendLastCommand found no command) — as k_stream_cuts sees it now,
   // and as the tile's last parse assumed it; cmd_off counts the cuts' insert-only commands in
   uint32_t cut, used_cut;
+  // the static dictionary's two counters (hash.h:49-50, 186) moved by this much during the tile's parse: with the gate
+  // taken as open (TILE_GATE_OPEN) the true counters at a tile's start are the sums over the tiles before
+  uint32_t dlookups, dmatches;
   uint32_t pad;
 };
 #define TILE_START_EVENT 1u   // the in-state was replaced by k_tile_verify: the next sweep parses from the tile's start
 #define TILE_BAD 2u           // the shard cannot be parsed in tiles (gate open, counter wrap, meta-block cut ...): serial path
 #define TILE_RAN 4u           // the tile's parse has run at least once
 #define TILE_CHANGED 8u       // the last sweep parsed something again in this tile
+#define TILE_GATE_OPEN 64u    // (tile 0) the shard's tiles t > 0 are parsed with the static-dictionary gate taken as OPEN for
+                              //   good (real English: the dictionary keeps matching) instead of closed: tile 0, which starts
+                              //   from the true counters, ended with it open (k_tile_restart); k_tile_verify / k_stream_cuts
+                              //   check with the summed counters that it cannot have closed inside any tile
 // why a shard left the tiled path (diagnostics; on the record of the tile / of tile 0)
 #define TILE_WHY_WRAP 0x100u      // a search past rank 65520 of its key (the 16-bit store counter, k_chain.h)
 #define TILE_WHY_ERROR 0x200u     // the tile's parse failed (command capacity, an impossible state)

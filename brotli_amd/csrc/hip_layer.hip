@@ -572,6 +572,12 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       lap(nullptr);
       hipLaunchKernelGGL(k_chain_tiles, cgrid, dim3(64), clds, c->stream, a);
       lap("first parse");
+      // shards whose tile 0 ended with the static dictionary's gate open (real English): their other tiles once more,
+      // the gate taken as open for good (k_tile.h); for everything else the second launch finds nothing to do
+      hipLaunchKernelGGL(k_tile_restart, dim3(nshards), dim3(64), 0, c->stream, a);
+      hipLaunchKernelGGL(k_tile_restart_clear, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
+      hipLaunchKernelGGL(k_chain_tiles, cgrid, dim3(64), clds, c->stream, a);
+      lap("second parse");
       bool settled = false;
       uint32_t tc[16];
       for (int pass = 0; pass < 12 && !settled; ++pass) {
@@ -788,8 +794,12 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     f.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
     if (gpw != 4) f.J.flags |= gpw << JOB_FLAG_GROUPS_SHIFT;
     hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f);
+    lap("first parse");
+    hipLaunchKernelGGL(k_tile_restart, dim3(1), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_tile_restart_clear, egrid, dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f);
   }
-  lap("first parse");
+  lap("second parse");
   bool settled = false;
   uint32_t tc[16], sweeps = 0, reasons = 0;
   auto reasons_of = [&]() -> bool {

@@ -926,6 +926,10 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   // ---- a tile of a tiled job: where it starts from (wave operations stay outside the per-group branches) ----
   uint32_t warm = 0;                                   // 1: the group is in the warm-up of a speculative start
   const bool stream = tiled && (J.flags & JOB_FLAG_STREAMT) != 0;
+  // the gate hypothesis of the shard's tiles t > 0 (enc_types.h: TILE_GATE_OPEN), and the counter values that stand
+  // for it at a tile's start: closed = 256 lookups without a match; open for good = a match count no lookup count reaches
+  const bool gate_open = tile_mode && alive && (trecs[D.tile_base].flags & TILE_GATE_OPEN) != 0;
+  const uint32_t gate_l0 = gate_open ? 0u : 256u, gate_m0 = gate_open ? 0x40000000u : 0u;
   bool cut_in = false;                                 // a stream's tile that begins a meta-block: no ExtendLastCommand
   CReplay R;
   R.old = g.cmds; R.oi = R.on = 0; R.obnd = 0; R.changed = 0; R.next_ev = 0;
@@ -938,6 +942,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
     }
     const uint32_t ev_w0 = (C.tile_lo - umin(C.tile_lo, C.geo.first)) >> 5, ev_w1 = (C.tile_hi - C.geo.first + 31u) >> 5;
     bool run = alive && tile_mode && !S0->error;
+    if (!sweep && run && (TR->flags & TILE_RAN) != 0) run = false;       // (a second launch parses the restarted tiles only, k_tile_restart)
     uint32_t any = 0;
     if (sweep && run) {
       // only tiles with something pending run: a replaced in-state or an event among their positions
@@ -986,7 +991,8 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
         //  ends the stream's last meta-block, whose size the tile need not know)
         g.r.last_flush_pos = stream ? (last_tile ? 0u : B) : C.geo.first;
         g.r.last_bytes = g.r.last_bytes_bits = 0;
-        g.dict_lookups = 256u;                         // the gate is taken as closed (hash.h:186); k_tile_verify checks
+        g.dict_lookups = gate_l0;                      // the gate is taken as closed (hash.h:186) or as open for good;
+        g.dict_matches = gate_m0;                      //   k_tile_verify / k_stream_cuts check
         if (!sweep) {
           // round 0: the state at B is what a parse of the `tile_warm` bytes before it arrives with
           const uint32_t S = B - umin(J.tile_warm, 1u << (J.lgblock - 1));
@@ -1189,6 +1195,8 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
           g.r.ncmds = 1;
           g.r.nlits = 0;
           g.r.input_pos = g.r.last_processed_pos = C.tile_lo;
+          g.dict_lookups = gate_l0; g.dict_matches = gate_m0;      // (the warm-up's lookups are not the tile's)
+          g.dict_mark_l = g.dict_lookups; g.dict_mark_m = g.dict_matches;
           g.cmd_flags = 0;
           C.frontier = C.tile_lo;
           warm = 0;
@@ -1224,6 +1232,8 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       TR->out_ncmds = g.r.ncmds - base;
       TR->out_nlits = g.r.nlits;
       TR->out_gate = (g.dict_matches < (g.dict_lookups >> 7)) ? 1u : 0u;
+      TR->dlookups = g.dict_lookups - (tt == 0 ? 0u : gate_l0);
+      TR->dmatches = g.dict_matches - (tt == 0 ? 0u : gate_m0);
       TR->out_lpp = g.r.last_processed_pos;
       TR->out_mb = ((g.status & QST_HAVE_MB) ? 1u : 0u) | ((g.blk_flags & QBLK_LAST) ? 2u : 0u) |
                    ((g.blk_flags & QBLK_FLUSH) ? ((g.blk_flags & QBLK_NOSEAL) ? 8u : 4u) : 0u);

@@ -42,6 +42,12 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
   // a shard most of whose searches the tiles would have to do twice is better off on the plain chain
   if (R[0].nflips > D.len / 32u + 64u) why |= TILE_WHY_EVENTS;
   R[0].nflips = 0;
+  R[0].pad = 0;                                         // (k_tile_restart's mark)
+  // the static dictionary's gate (hash.h:186): with the tiles t > 0 parsed as if it stayed open for good, the counters
+  // at a tile's start are tile 0's plus the tiles' before — it cannot close inside a tile whose start has
+  // matches >= (lookups + the tile's lookups) >> 7 (matches only grow, lookups end at that sum)
+  const bool gate_open = (R[0].flags & TILE_GATE_OPEN) != 0;
+  uint32_t gl = 0, gm = 0;
   for (uint32_t t = 0; t < D.ntiles; ++t) {
     TileRec& c = R[t];
     if (c.flags & TILE_BAD) why |= TILE_WHY_TILE;
@@ -49,11 +55,15 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
     c.cmd_off = ncmds;
     ncmds += c.out_ncmds;
     nlits += c.out_nlits;
+    if (gate_open) {
+      if (t != 0u && gm < ((gl + c.dlookups) >> 7)) why |= TILE_WHY_GATE;
+      gl += c.dlookups; gm += c.dmatches;
+    }
     if (t + 1u == D.ntiles) break;
     // what the next tile has to start from
     TileRec& n = R[t + 1u];
     if (c.out_ncmds == 0u) why |= TILE_WHY_NO_CMD;          // (no command ExtendLastCommand could lengthen)
-    if (c.out_gate == 0u) why |= TILE_WHY_GATE;             // (the dictionary still consulted)
+    if (!gate_open && c.out_gate == 0u) why |= TILE_WHY_GATE;   // (taken as closed, but the dictionary is still consulted)
     const bool same_cmd = c.out_insert != 0u || (n.in_copy_len == c.out_copy_len && n.in_code == c.out_code);
     const bool same = n.in_dc[0] == c.out_dc[0] && n.in_dc[1] == c.out_dc[1] && n.in_dc[2] == c.out_dc[2] &&
                       n.in_dc[3] == c.out_dc[3] && n.in_insert == c.out_insert && same_cmd;
@@ -189,6 +199,33 @@ DEV void tile_finish(const JobParams& J, const ShardDesc& D, ShardState* S, uint
   }
 }
 
+// ---- the gate hypothesis (TILE_GATE_OPEN) ---------------------------------------------------------------------------
+// Tiles t > 0 are first parsed with the static dictionary's gate taken as closed — right for everything but text
+// the dictionary keeps matching (real English), where tile 0 — the one that starts from the true counters — ends with
+// the gate open.  Then the shard's other tiles start over with the gate taken as open for good: k_tile_restart
+// (grid = nshards, block = 64; between the tiles' first launch and a second one that parses the restarted tiles
+// only) un-runs them, k_tile_restart_clear (grid = units * ix_slices) wipes their bitmaps.
+#define TILE_CNT_RESTART 7
+DEV void tile_restart(const ShardDesc& D, TileRec* trecs, uint32_t* counters) {
+  if (D.ntiles <= 1u) return;
+  TileRec* R = trecs + D.tile_base;
+  const uint32_t f0 = R[0].flags;
+  if (!(f0 & TILE_RAN) || (f0 & (TILE_BAD | TILE_GATE_OPEN)) != 0 || R[0].out_gate != 0u) return;
+  for (uint32_t t = 1u + (uint32_t)wave_lane(); t < D.ntiles; t += 64u) R[t].flags &= ~(TILE_RAN | TILE_START_EVENT | TILE_CHANGED);
+  wave_sync();
+  if (wave_lane() == 0) {
+    R[0].flags = f0 | TILE_GATE_OPEN;
+    R[0].pad = 1u;
+    glb_atomic_add(&counters[TILE_CNT_RESTART], 1u);
+  }
+}
+// The words of the three bitmaps from tile 1 on, slice w of `nslices` of the word range [w_lo, w_hi).
+DEV void tile_restart_clear(uint32_t* skip, uint32_t* prev, uint32_t* ev, uint32_t w_lo, uint32_t w_hi, uint32_t w, uint32_t nslices) {
+  const uint32_t per = (w_hi - w_lo + nslices - 1u) / nslices;
+  const uint32_t a = w_lo + w * per, b = umin(a + per, w_hi);
+  for (uint32_t i = a + (uint32_t)wave_lane(); i < b; i += 64u) { skip[i] = 0; prev[i] = 0; ev[i] = 0; }
+}
+
 // ---- a tiled stream (JOB_FLAG_STREAMT): one encoder instance longer than the window ------------------------------
 // The stream is one shard whose tiles are its input blocks (tile_log2 == lgblock).  Besides the joins of the tiled
 // shards above, a tile's parse depends on whether a meta-block was cut in front of it (encode.c:1141-1216: the
@@ -253,10 +290,20 @@ DEV void stream_cuts(const JobParams& J, const ShardDesc& D, TileRec* R, const u
   uint32_t s_tile = 0, accL = 0, accC = 0, m = 0, cmd_row = 0, mb_cmd_lo = 0;
   uint32_t prev_cut = 0;                     // the row before ended with a cut behind its last tile
   bool overflow = false;
+  // the gate taken as open for good (TILE_GATE_OPEN): the same check as tile_verify's, 64 tiles per step
+  const bool gate_open = (R[0].flags & TILE_GATE_OPEN) != 0;
+  uint32_t gl = 0, gm = 0;
+  bool gate_fail = false;
   for (uint32_t r0 = 0; r0 < nt; r0 += 64u) {
     const uint32_t t = r0 + lane;
     const bool have = t < nt;
     const uint32_t nl = have ? R[t].out_nlits : 0u, nc = have ? R[t].out_ncmds : 0u, oi = have ? R[t].out_insert : 0u;
+    if (gate_open) {
+      const uint32_t dl = have ? R[t].dlookups : 0u, dm = have ? R[t].dmatches : 0u;
+      const uint32_t lb = gl + wave_incl_scan(dl) - dl, mb = gm + wave_incl_scan(dm) - dm;      // the counters at the tile's start
+      if (wave_ballot(have && t != 0u && mb < ((lb + dl) >> 7)) != 0) gate_fail = true;
+      gl = wave_bcast(lb + dl, 63); gm = wave_bcast(mb + dm, 63);
+    }
     uint32_t startlane = 0;
     uint64_t cutmask = 0;
     uint32_t carryL = accL, carryC = accC;
@@ -293,6 +340,10 @@ DEV void stream_cuts(const JobParams& J, const ShardDesc& D, TileRec* R, const u
     cmd_row += wave_bcast(ex + nc, 63) + (uint32_t)dev_popc64(flushmask);
     prev_cut = (uint32_t)((cutmask >> 63) & 1ull);
   }
+  if (gate_fail && lane == 0 && !(R[0].flags & TILE_BAD)) {
+    R[0].flags |= TILE_BAD | TILE_WHY_GATE;
+    glb_atomic_add(&counters[TILE_CNT_BAD], 1u);
+  }
   if (finalize) {
     if (m < mcap) { if (lane == 0) stream_emit_mb(J, D, input, md, ms, m, s_tile, nt - 1u, mb_cmd_lo, accC, accL, true); }
     else overflow = true;
@@ -315,12 +366,13 @@ DEV void stream_verify(const JobParams& J, const ShardDesc& D, TileRec* R, uint3
   if (t == 0) {
     if (c.nflips > D.len / 32u + 64u) why |= TILE_WHY_EVENTS;
     c.nflips = 0;
+    c.pad = 0;                                          // (k_tile_restart's mark)
   }
   if (t + 1u < D.ntiles) {
     TileRec& n = R[t + 1u];
     const bool cut = n.cut != 0;
     if (c.out_ncmds == 0u && !cut) why |= TILE_WHY_NO_CMD;
-    if (c.out_gate == 0u) why |= TILE_WHY_GATE;
+    if (!(R[0].flags & TILE_GATE_OPEN) && c.out_gate == 0u) why |= TILE_WHY_GATE;      // (open for good: k_stream_cuts checks)
     const uint32_t req_insert = cut ? 0u : c.out_insert;
     const bool same_cmd = cut || c.out_insert != 0u || (n.in_copy_len == c.out_copy_len && n.in_code == c.out_code);
     const bool same = n.in_dc[0] == c.out_dc[0] && n.in_dc[1] == c.out_dc[1] && n.in_dc[2] == c.out_dc[2] &&

@@ -46,6 +46,11 @@ void run_parse_kernel(JobArgs a, int reverse, int round = 0) {
     // the tiles' parses, then verify / events / sweep until nothing is pending (what run_rounds of hip_layer.hip does)
     const uint32_t gpw = q_groups_per_wave(a.J);
     run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+    // shards whose tile 0 ended with the static dictionary's gate open: their other tiles once more, gate taken as open
+    run(k_tile_restart, a, a.nshards, 64, reverse);
+    run(k_tile_restart_clear, a, a.nshards * a.J.ix_slices, 64, reverse);
+    run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+    if (getenv("SIM_TILE_LOG")) fprintf(stderr, "shards restarted with the gate taken as open: %u\n", a.counters[TILE_CNT_RESTART]);
     bool settled = false;
     int rounds = 0;
     for (; rounds < 12 && !settled; ++rounds) {
@@ -319,6 +324,11 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   lap("zones0");
   run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
   lap("first parse");
+  run(k_tile_restart, a, 1, 64, reverse);
+  run(k_tile_restart_clear, a, a.J.nchunks * a.J.ix_slices, 64, reverse);
+  run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+  if (tlog) fprintf(stderr, "restarted with the gate taken as open: %u\n", counters[TILE_CNT_RESTART]);
+  lap("second parse");
   bool settled = false;
   int rounds = 0;
   for (; rounds < 16 && !settled; ++rounds) {

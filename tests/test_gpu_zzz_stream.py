@@ -49,6 +49,21 @@ def test_text_longer_than_the_window(amd, stock, mib, lgwin, seed):
     assert got == want
 
 
+def test_english_keeps_the_dictionary_gate_open(amd, stock):
+    """alice29.txt over and over with synthetic text in between, 24 MiB: the static dictionary's gate stays open behind
+    the first block, the tiles start over with it taken as open for good (k_tile.h: TILE_GATE_OPEN)."""
+    alice = open(os.path.join(ROOT, "tests", "golden", "alice29.txt"), "rb").read()
+    parts = []
+    for k in range(120):
+        parts.append(alice[(k * 7919) % 50000:])
+        parts.append(bytes(G.enwik_text(60000, seed=100 + k)))
+    data = b"".join(parts)[:24 << 20]
+    for lgwin in (22, 19):
+        got, _ = one_shot(amd, data, lgwin)
+        want, _ = one_shot(stock, data, lgwin)
+        assert got == want
+
+
 def test_plain_chain_copy_to_the_block_end(amd, stock):
     """tools/fuzz_stream_sim.py seed 15 (a copy of the chain's fast path that runs to its block's end: the three
     positions the next block's stitch stores were marked unstored) through the paths a stream of that size takes:

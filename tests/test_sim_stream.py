@@ -67,14 +67,21 @@ def test_copies_cut_by_block_ends(sim, ref):
 
 
 def test_streams_that_leave_the_tiled_path(sim):
-    """Noise / floats (too many unstored positions) and data on which the static-dictionary gate stays open: the tiled
-    path says so and writes nothing (the library then runs the serial device stream)."""
+    """Noise / floats (too many unstored positions): the tiled path says so and writes nothing (the library then runs
+    the serial device stream)."""
     got, info = sim.encode_stream(bytes(G.mixed_corpus(262144, seed=6)), lgwin=17)
     assert got is None and info[0] & 0x8000
+
+
+def test_the_dictionary_gate_stays_open(sim, ref):
+    """Data on which the static dictionary's gate never closes (hash.h:186) — English, where the dictionary keeps
+    matching, and a highly repetitive stream, where hardly a search fails: tile 0 ends with the gate open, the other
+    tiles start over with the gate taken as open for good, and the summed counters confirm it (k_tile.h)."""
+    alice = open(os.path.join(HERE, "golden", "alice29.txt"), "rb").read()
+    _same(sim, ref, (alice * 3)[:400000], 17)
     rng = np.random.default_rng(3)
     words = [bytes(rng.integers(97, 123, 7, dtype=np.uint8)) + b" " for _ in range(4)]
-    got, info = sim.encode_stream(b"".join(words[i] for i in rng.integers(0, 4, 60000))[:300000], lgwin=17)
-    assert got is None and info[0] & 0x2000
+    _same(sim, ref, b"".join(words[i] for i in rng.integers(0, 4, 60000))[:300000], 17, reverse=1)
 
 
 @pytest.mark.parametrize("seed", range(300, 304))

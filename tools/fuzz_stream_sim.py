@@ -17,7 +17,7 @@ from simharness import Sim  # noqa: E402
 def make(seed):
     rng = np.random.default_rng(seed)
     lgwin = int(rng.choice([17, 17, 18, 19]))
-    kind = int(rng.integers(0, 5))
+    kind = int(rng.integers(0, 6))
     n = int(rng.integers(3 << 16, (14 << 16) if lgwin == 17 else (20 << 16)))
     if kind == 0:
         data = bytes(gen_inputs.enwik_text(n, seed=seed))
@@ -44,6 +44,19 @@ def make(seed):
             if a - d >= 0 and b + w <= n:
                 buf[a:b + w] = buf[a - d:b + w - d]
         data = buf.tobytes()
+    elif kind == 5:
+        # English (the static dictionary's gate stays open) with stretches of the synthetic text (on which it closes)
+        alice = open(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "alice29.txt"), "rb").read()
+        parts, have = [], 0
+        while have < n:
+            if rng.integers(0, 3) != 0:
+                a = int(rng.integers(0, len(alice) - 1000))
+                piece = alice[a:a + int(rng.integers(1000, 120000))]
+            else:
+                piece = bytes(gen_inputs.enwik_text(int(rng.integers(1000, 90000)), seed=seed + have))
+            parts.append(piece)
+            have += len(piece)
+        data = b"".join(parts)[:n]
     else:
         t = bytes(gen_inputs.enwik_text(n, seed=seed))
         cut = int(rng.integers(1, 65536))
