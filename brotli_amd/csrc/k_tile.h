@@ -364,7 +364,9 @@ DEV void stream_verify(const JobParams& J, const ShardDesc& D, TileRec* R, uint3
   if (c.flags & TILE_BAD) why |= TILE_WHY_TILE;
   if (!(c.flags & TILE_RAN)) why |= TILE_WHY_NOT_RUN;
   if (t == 0) {
-    if (c.nflips > D.len / 32u + 64u) why |= TILE_WHY_EVENTS;
+    // (a stream's other way is one wave on the whole stream: searching half of the positions twice is still
+    //  far better — the bound only keeps literal-spree data, of which most positions are unstored, off the sweeps)
+    if (c.nflips > D.len / 2u + 64u) why |= TILE_WHY_EVENTS;
     c.nflips = 0;
     c.pad = 0;                                          // (k_tile_restart's mark)
   }

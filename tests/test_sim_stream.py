@@ -66,11 +66,17 @@ def test_copies_cut_by_block_ends(sim, ref):
     assert sim.encode(data, 5, 22, flags=64) == ref.compress(data, 5, 22)
 
 
-def test_streams_that_leave_the_tiled_path(sim):
-    """Noise / floats (too many unstored positions): the tiled path says so and writes nothing (the library then runs
-    the serial device stream)."""
-    got, info = sim.encode_stream(bytes(G.mixed_corpus(262144, seed=6)), lgwin=17)
-    assert got is None and info[0] & 0x8000
+def test_streams_that_leave_the_tiled_path(sim, ref):
+    """Random bytes (most positions unstored by the literal spree, meta-blocks stored raw) and English followed by text
+    on which the gate closes (the "open for good" hypothesis fails): the tiled path says so and writes nothing — the
+    library then runs the serial device stream.  The mixed corpus (floats, sparse zeros, noise, text) stays on it."""
+    rng = np.random.default_rng(9)
+    got, info = sim.encode_stream(bytes(rng.integers(0, 256, 300000, dtype=np.uint8)), lgwin=17)
+    assert got is None and info[0] & (0x8000 | 0x20000)
+    data, lgwin, kind = fuzz_stream_sim.make(5004)
+    got, info = sim.encode_stream(data[:400000], lgwin=lgwin)
+    assert kind == 5 and got is None and info[0] & 0x2000
+    _same(sim, ref, bytes(G.mixed_corpus(262144, seed=6)), 17)
 
 
 def test_the_dictionary_gate_stays_open(sim, ref):
