@@ -131,6 +131,10 @@ def load_library(path=LIB_PATH):
     return L
 
 
+FLAG_STREAM_TILES = 64   # BROTLI_AMD_FLAG_STREAM_TILES (include/brotli_amd_hip.h): one whole quality-5 stream, longer than
+                         # the window, parsed in tiles; the call fails with BROTLI_AMD_SERIAL (-5) when the data does not suit them
+
+
 def make_params(quality=5, lgwin=22, shard_size=0, size_hint=0, stream_base=0,
                 is_last=True, flags=0):
     return JobParams(quality, lgwin, size_hint, flags, shard_size, stream_base,
