@@ -143,6 +143,11 @@ struct TileRec {
   // taken as open (TILE_GATE_OPEN) the true counters at a tile's start are the sums over the tiles before
   uint32_t dlookups, dmatches;
   uint32_t pad;
+  // JOB_FLAG_STREAMT: the meta-block that ends in front of this tile is stored uncompressed, so the distance cache the
+  // tile starts from is the one that meta-block started from (encode.c:598-614) — known once the meta-blocks have been
+  // built and placed (k_stream_scan / k_stream_rollback), part of the join like the rest
+  uint32_t rb, rb_new;
+  int32_t rb_dc[4], rb_dc_new[4];
 };
 #define TILE_START_EVENT 1u   // the in-state was replaced by k_tile_verify: the next sweep parses from the tile's start
 #define TILE_BAD 2u           // the shard cannot be parsed in tiles (gate open, counter wrap, meta-block cut ...): serial path
@@ -162,8 +167,7 @@ struct TileRec {
 #define TILE_WHY_CUT 0x4000u      // a meta-block would have been cut inside the shard (encode.c:1141-1166)
 #define TILE_WHY_EVENTS 0x8000u   // too many unstored positions: the tiles would parse everything twice
 #define TILE_WHY_TILE 0x10000u    // (tile 0: one of the shard's tiles carries a reason of its own)
-#define TILE_WHY_RAW 0x20000u     // JOB_FLAG_STREAMT: a meta-block would be stored uncompressed (or might be: the decision
-                                  //   depends on the bit it starts at) — the distance cache is rolled back then (encode.c:598-614)
+#define TILE_WHY_RAW 0x20000u     // JOB_FLAG_STREAMT: the roll-backs behind raw meta-blocks did not settle
 
 // Persistent per-shard encoder state (c/enc/state.h:49-110 subset).
 struct ShardState {

@@ -800,19 +800,27 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f);
   }
   lap("second parse");
-  bool settled = false;
-  uint32_t tc[16], sweeps = 0, reasons = 0;
+  uint32_t tc[16], sweeps = 0, reasons = 0, nmb = 0, passes = 0;
   auto reasons_of = [&]() -> bool {
     TileRec r0;
     HIP_OK(c, hipMemcpy(&r0, c->d_trecs, sizeof(TileRec), hipMemcpyDeviceToHost));
     reasons = r0.flags >> 8;
     return true;
   };
-  for (int pass = 0; pass < 24 && !settled; ++pass) {
+  // (the whole loop once more when a raw meta-block rolls the distance cache back for the tile behind it: which
+  //  meta-blocks are raw is known behind k_store / k_stream_scan only, encode.c:598-614)
+  for (int outer = 0;; ++outer) {
+  if (outer >= 8) {
+    if (info) info->reserved = sweeps | ((TILE_WHY_RAW >> 8) << 16);
+    *rc = BROTLI_AMD_SERIAL;
+    return true;
+  }
+  bool settled = false;
+  for (int pass = 0; pass < 24 && !settled; ++pass, ++passes) {
     HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_START, 0, 2 * sizeof(uint32_t), c->stream));
     {
       JobArgs e = a;
-      if (pass != 0) e.J.flags |= JOB_FLAG_SWEEP;
+      if (passes != 0) e.J.flags |= JOB_FLAG_SWEEP;
       hipLaunchKernelGGL(k_stream_events, egrid, dim3(64), 0, c->stream, e);
     }
     hipLaunchKernelGGL(k_stream_skclear, egrid, dim3(64), 0, c->stream, a);
@@ -869,12 +877,21 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
   HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   if (tc[1]) return fail(c, "%u meta-block(s) reported a device fault", tc[1]);
-  const uint32_t nmb = tc[TILE_CNT_NMB];
-  if (tc[TILE_CNT_BAD] != 0 || tc[TILE_CNT_RAW] != 0 || nmb == 0 || nmb > mcap) {
-    if (tc[TILE_CNT_BAD] != 0) { if (!reasons_of()) return false; } else reasons = TILE_WHY_RAW >> 8;
+  nmb = tc[TILE_CNT_NMB];
+  if (tc[TILE_CNT_RAW] != 0) return fail(c, "a meta-block of the stream was not built (device fault)");
+  if (tc[TILE_CNT_BAD] != 0 || nmb == 0 || nmb > mcap) {
+    if (!reasons_of()) return false;
     if (info) info->reserved = sweeps | (nmb << 8) | (reasons << 16);
     *rc = BROTLI_AMD_SERIAL;
     return true;
+  }
+  HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_RBCHG, 0, sizeof(uint32_t), c->stream));
+  hipLaunchKernelGGL(k_stream_rollback, dim3(1), dim3(64), 0, c->stream, a);
+  HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  if (tlog) fprintf(stderr, "stream: %u meta-blocks, tiles with a new roll-back behind a raw meta-block: %u\n", nmb, tc[TILE_CNT_RBCHG]);
+  if (tc[TILE_CNT_RBCHG] == 0) break;
+  HIP_OK(c, hipMemsetAsync(c->d_mstate, 0, mcap * sizeof(ShardState), c->stream));
   }
   uint64_t total_bits = 0;
   HIP_OK(c, hipMemcpy(&total_bits, c->d_moff + nmb, 8, hipMemcpyDeviceToHost));
@@ -897,7 +914,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     HIP_OK(c, hipEventElapsedTime(&t, c->ev[5], c->ev[7])); info->ms_gather = t;
     HIP_OK(c, hipEventElapsedTime(&t, c->ev[6], c->ev[7])); info->ms_total = t;
     info->rounds = 1;
-    info->reserved = sweeps | (nmb << 8);
+    info->reserved = (sweeps & 0xFFu) | (nmb << 8);
     info->nshards = 1;
     info->ws_bytes = plan.ws_bytes;
     info->out_bytes = total;

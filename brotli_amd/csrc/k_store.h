@@ -313,10 +313,12 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   const bool is_last = S->mb_is_last != 0, force_flush = S->mb_force_flush != 0;
   bool raw = S->mb_raw != 0;
   // A meta-block of a tiled stream (JOB_FLAG_STREAMT) is written as if it began at bit 0 and moved to its place
-  // afterwards (k_stream_place): a raw one cannot be (its payload is byte aligned in the stream), nor is the
-  // distance-cache roll-back behind it something the tiles know about — the stream goes the serial way then.
+  // afterwards (k_stream_place).  A raw one is not written here at all (its payload is byte aligned in the STREAM):
+  // mb_was_raw = 1 tells k_stream_scan / k_stream_place, which emit it; 2 = the size comparison depends on the bit the
+  // meta-block starts at, k_stream_scan decides.
   const bool stream = (J.flags & JOB_FLAG_STREAMT) != 0;
   if (stream && raw) {
+    wave_sync();                 // (every lane has read the state by now)
     if (lane == 0) { S->mb_was_raw = 1; S->mb_valid = 0; }
     wave_sync();
     return;

@@ -373,14 +373,18 @@ DEV void stream_verify(const JobParams& J, const ShardDesc& D, TileRec* R, uint3
   if (t + 1u < D.ntiles) {
     TileRec& n = R[t + 1u];
     const bool cut = n.cut != 0;
-    if (c.out_ncmds == 0u && !cut) why |= TILE_WHY_NO_CMD;
+    // (a tile without a command — a block of noise — ends with literals pending: the next block's ExtendLastCommand
+    //  does nothing then, encode.c:1103, and nobody asks for the last command)
+    if (c.out_ncmds == 0u && c.out_insert == 0u && !cut) why |= TILE_WHY_NO_CMD;
     if (!(R[0].flags & TILE_GATE_OPEN) && c.out_gate == 0u) why |= TILE_WHY_GATE;      // (open for good: k_stream_cuts checks)
     const uint32_t req_insert = cut ? 0u : c.out_insert;
     const bool same_cmd = cut || c.out_insert != 0u || (n.in_copy_len == c.out_copy_len && n.in_code == c.out_code);
-    const bool same = n.in_dc[0] == c.out_dc[0] && n.in_dc[1] == c.out_dc[1] && n.in_dc[2] == c.out_dc[2] &&
-                      n.in_dc[3] == c.out_dc[3] && n.in_insert == req_insert && (n.used_cut != 0) == cut && same_cmd;
+    // (behind a raw meta-block the distance cache is the one that meta-block began with: k_stream_rollback)
+    const int32_t* rdc = (n.rb != 0u && cut) ? n.rb_dc : c.out_dc;
+    const bool same = n.in_dc[0] == rdc[0] && n.in_dc[1] == rdc[1] && n.in_dc[2] == rdc[2] &&
+                      n.in_dc[3] == rdc[3] && n.in_insert == req_insert && (n.used_cut != 0) == cut && same_cmd;
     if (!same && why == 0) {
-      for (int i = 0; i < 4; ++i) n.in_dc[i] = c.out_dc[i];
+      for (int i = 0; i < 4; ++i) n.in_dc[i] = rdc[i];
       n.in_insert = req_insert;
       n.in_copy_len = cut ? 0u : c.out_copy_len;
       n.in_code = c.out_code;
@@ -572,36 +576,128 @@ DEV void stream_zones(const JobParams& J, const ShardDesc& D, const ShardDesc* c
   if (lane == 63 && changes != 0) glb_atomic_add(&counters[TILE_CNT_FLIPS], changes);
 }
 
-// grid = 1, block = 64: bit offsets of the meta-blocks in the stream; result[0] = bits of the stream.
-DEV void stream_scan(ShardState* ms, uint32_t nmb, uint64_t* moff, uint32_t* counters) {
-  const uint32_t lane = (uint32_t)wave_lane();
-  uint64_t run = 0;
-  uint32_t rawish = 0;
-  for (uint32_t r0 = 0; r0 < nmb; r0 += 64u) {
-    const uint32_t m = r0 + lane;
-    uint64_t bits = 0;
-    if (m < nmb) {
-      bits = ms[m].out_bytes * 8u + ms[m].last_bytes_bits;
-      if (ms[m].mb_was_raw != 0 || ms[m].error != 0 || ms[m].mb_valid != 0) rawish = 1;
+// Bits of BrotliStoreUncompressedMetaBlock's header for `len` bytes (brotli_bit_stream.c:1321-1352; k_round.h:
+// emit_raw_metablock): ISLAST 0, MNIBBLES, MLEN - 1, ISUNCOMPRESSED.
+DEV uint32_t stream_raw_header(uint32_t len, uint64_t* value) {
+  const uint32_t lg = (len == 1u) ? 1u : log2floor(len - 1u) + 1u;
+  const uint32_t mnibbles = (lg < 16u ? 16u : (lg + 3u)) / 4u;
+  *value = ((uint64_t)(mnibbles - 4u) << 1) | ((uint64_t)(len - 1u) << 3) | (1ull << (3u + 4u * mnibbles));
+  return 4u + 4u * mnibbles;
+}
+// grid = 1, block = 64: the meta-blocks' bit offsets in the stream, one after the other (lane 0: where a raw
+// meta-block's payload starts depends on everything in front of it) — and which meta-blocks are raw: the ones
+// k_build / k_store said (mb_was_raw 1), and of the ones that depend on the starting bit (2) those for which the
+// reference's comparison (encode.c:604: the bytes counted from the byte the meta-block's first bit is in, the last
+// one's padding included) says so.  moff[nmb] = bits of the stream.
+DEV void stream_scan(const JobParams& J, const ShardDesc& D, ShardState* ms, uint32_t nmb, uint64_t* moff, uint32_t* counters) {
+  if (wave_lane() != 0) return;
+  ShardState init;
+  init_shard_state(J, D, &init);
+  const uint32_t hb = init.last_bytes_bits;             // the stream header in front of meta-block 0
+  uint64_t o = 0;
+  uint32_t fault = 0;
+  for (uint32_t m = 0; m < nmb; ++m) {
+    ShardState& S = ms[m];
+    if (S.error != 0 || S.mb_valid != 0) fault = 1;
+    const uint32_t bytes = S.mb_bytes;
+    const bool last = S.mb_is_last != 0;
+    const uint64_t T = S.out_bytes * 8u + S.last_bytes_bits;       // compressed form (meta-block 0: the header bits in front)
+    bool raw = S.mb_was_raw == 1u;
+    if (S.mb_was_raw == 2u) {
+      uint64_t sx = (m == 0 ? T : (o & 7u) + T);
+      if (last) sx = (sx + 7u) & ~(uint64_t)7u;
+      raw = (uint64_t)bytes + 4u < (sx >> 3);
     }
-    // inclusive scan of 64-bit values: two 32-bit scans would lose carries — do it by halves of the wave instead
-    uint64_t v = bits;
-    for (int d = 1; d < 64; d <<= 1) {
-      const uint64_t o = wave_shfl64(v, (int)((lane - (uint32_t)d) & 63u));
-      if (lane >= (uint32_t)d) v += o;
+    moff[m] = o;
+    if (raw) {
+      uint64_t hv;
+      uint64_t p = o + (m == 0 ? hb : 0u) + stream_raw_header(bytes, &hv);
+      p = ((p + 7u) & ~(uint64_t)7u) + 8ull * bytes;
+      if (last) p = (p + 2u + 7u) & ~(uint64_t)7u;
+      o = p;
+    } else {
+      o += T;
     }
-    if (m < nmb) moff[m] = run + v - bits;
-    run += wave_bcast64(v, 63);
+    S.mb_was_raw = raw ? 1u : 0u;
   }
-  if (wave_ballot(rawish != 0) != 0 && lane == 0) glb_atomic_add(&counters[TILE_CNT_RAW], 1u);
-  if (lane == 0) moff[nmb] = run;
+  moff[nmb] = o;
+  if (fault) glb_atomic_add(&counters[TILE_CNT_RAW], 1u);
+}
+
+// grid = 1, block = 64: what the raw meta-blocks mean for the parse — the tile behind a raw meta-block starts from
+// the distance cache that meta-block started from.  Sets TileRec::rb / rb_dc of the tiles that begin a meta-block
+// and counts the tiles for which that is news (counters[TILE_CNT_RBCHG]): the sweep loop runs again then.
+#define TILE_CNT_RBCHG 8
+DEV void stream_rollback(const JobParams& J, const ShardDesc& D, const ShardState* ms, uint32_t nmb, TileRec* R, uint32_t* counters) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  for (uint32_t t = lane; t < D.ntiles; t += 64u) R[t].rb_new = 0;
+  wave_sync();
+  if (lane == 0) {
+    ShardState init;
+    init_shard_state(J, D, &init);
+    int32_t dc[4];                                       // the cache meta-block m starts from
+    for (int i = 0; i < 4; ++i) dc[i] = init.dist_cache[i];
+    for (uint32_t m = 0; m + 1u < nmb; ++m) {
+      const uint32_t tn = ms[m + 1u].mb_start >> J.tile_log2;   // the tile the next meta-block begins with
+      TileRec& n = R[tn];
+      if (ms[m].mb_was_raw != 0u) {
+        n.rb_new = 1;
+        for (int i = 0; i < 4; ++i) n.rb_dc_new[i] = dc[i];    // (and the next one starts from the same cache)
+      } else {
+        for (int i = 0; i < 4; ++i) dc[i] = n.used_dc[i];       // what the tile was parsed from = the cache behind m
+      }
+    }
+  }
+  wave_sync();
+  uint32_t changed = 0;
+  for (uint32_t t = lane; t < D.ntiles; t += 64u) {
+    TileRec& r = R[t];
+    bool diff = r.rb != r.rb_new;
+    if (r.rb_new != 0u) for (int i = 0; i < 4; ++i) diff = diff || r.rb_dc[i] != r.rb_dc_new[i];
+    if (diff) {
+      r.rb = r.rb_new;
+      for (int i = 0; i < 4; ++i) r.rb_dc[i] = r.rb_dc_new[i];
+      ++changed;
+    }
+  }
+  changed = wave_incl_scan(changed);
+  if (lane == 63 && changed != 0) glb_atomic_add(&counters[TILE_CNT_RBCHG], changed);
   wave_sync();
 }
 
 // grid = nmb * parts, block = 256: the bits of meta-block m (written from bit 0 of its own buffer) to bit moff[m] of
 // the stream, 32 bits per lane and step; the first and last word of a meta-block are shared with its neighbours.
-DEV void stream_place(const ShardDesc* md, const ShardState* ms, const uint64_t* moff, const uint8_t* ws, uint8_t* out,
+DEV void stream_place_bits(uint32_t* dst, uint64_t at, uint64_t value, uint32_t nbits) {     // nbits <= 40, one thread
+  const uint64_t w = at >> 5;
+  const uint32_t sh = (uint32_t)(at & 31u);
+  glb_atomic_or(&dst[w], (uint32_t)(value << sh));
+  if (sh + nbits > 32u) glb_atomic_or(&dst[w + 1u], (uint32_t)(value >> (32u - sh)));
+  if (sh + nbits > 64u) glb_atomic_or(&dst[w + 2u], (uint32_t)(value >> (64u - sh)));
+}
+DEV void stream_place(const JobParams& J, const ShardDesc& D, const ShardDesc* md, const ShardState* ms, const uint64_t* moff,
+                      const uint8_t* input, const uint8_t* ws, uint8_t* out,
                       uint32_t m, uint32_t part, uint32_t parts, uint32_t tid, uint32_t nthreads) {
+  if (ms[m].mb_was_raw != 0u) {
+    // BrotliStoreUncompressedMetaBlock at its place in the stream: header bits, the payload from the next byte on
+    ShardState init;
+    init_shard_state(J, D, &init);
+    const uint32_t bytes = ms[m].mb_bytes;
+    uint64_t hv;
+    const uint32_t hbits = stream_raw_header(bytes, &hv);
+    uint64_t p = moff[m];
+    if (part == 0 && tid == 0) {
+      if (m == 0 && init.last_bytes_bits != 0u) stream_place_bits((uint32_t*)out, p, init.last_bytes, init.last_bytes_bits);
+      stream_place_bits((uint32_t*)out, p + (m == 0 ? init.last_bytes_bits : 0u), hv, hbits);
+    }
+    p += (m == 0 ? init.last_bytes_bits : 0u) + hbits;
+    const uint64_t b0 = (p + 7u) >> 3;
+    const uint8_t* src = input + md[m].in_off + ms[m].mb_start;
+    const uint64_t per = ((uint64_t)bytes + parts - 1u) / parts;
+    const uint64_t lo = (uint64_t)part * per, hi = lo + per < bytes ? lo + per : bytes;
+    for (uint64_t i = lo + tid; i < hi; i += nthreads) out[b0 + i] = src[i];
+    if (ms[m].mb_is_last != 0u && part == 0 && tid == 0) stream_place_bits((uint32_t*)out, (b0 + bytes) * 8u, 3u, 2u);   // ISLAST, ISEMPTY
+    return;
+  }
   const uint64_t nbits = ms[m].out_bytes * 8u + ms[m].last_bytes_bits;
   if (nbits == 0) return;
   const uint64_t o = moff[m];

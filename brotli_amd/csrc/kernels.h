@@ -278,13 +278,17 @@ __global__ void __launch_bounds__(64) k_stream_finish(JobArgs a) {
 }
 // grid = 1, block = 64
 __global__ void __launch_bounds__(64) k_stream_scan(JobArgs a) {
-  stream_scan(a.mstate, a.counters[TILE_CNT_NMB], a.moff, a.counters);
+  stream_scan(a.J, a.shards[0], a.mstate, a.counters[TILE_CNT_NMB], a.moff, a.counters);
+}
+// grid = 1, block = 64
+__global__ void __launch_bounds__(64) k_stream_rollback(JobArgs a) {
+  stream_rollback(a.J, a.shards[0], a.mstate, a.counters[TILE_CNT_NMB], a.trecs, a.counters);
 }
 // grid = mcap * STREAM_PLACE_PARTS, block = 256
 #define STREAM_PLACE_PARTS 16u
 __global__ void __launch_bounds__(256) k_stream_place(JobArgs a) {
   const uint32_t m = blockIdx.x / STREAM_PLACE_PARTS, part = blockIdx.x % STREAM_PLACE_PARTS;
-  if (m < a.counters[TILE_CNT_NMB]) stream_place(a.mdesc, a.mstate, a.moff, a.ws, a.sout, m, part, STREAM_PLACE_PARTS, threadIdx.x, 256u);
+  if (m < a.counters[TILE_CNT_NMB]) stream_place(a.J, a.shards[0], a.mdesc, a.mstate, a.moff, a.input, a.ws, a.sout, m, part, STREAM_PLACE_PARTS, threadIdx.x, 256u);
 }
 
 // grid = nshards * CE_SPLIT, block = 64: prefix fields of the commands the chain left raw

@@ -329,9 +329,12 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
   if (tlog) fprintf(stderr, "restarted with the gate taken as open: %u\n", counters[TILE_CNT_RESTART]);
   lap("second parse");
+  uint32_t nmb = 0;
+  int rounds = 0, outer = 0;
+  for (;; ++outer) {           // (again when a raw meta-block rolls the distance cache back for the tile behind it)
+  if (outer >= 8) { info[0] = TILE_WHY_RAW; return -10; }
   bool settled = false;
-  int rounds = 0;
-  for (; rounds < 16 && !settled; ++rounds) {
+  for (int r = 0; r < 16 && !settled; ++r, ++rounds) {
     counters[TILE_CNT_START] = counters[TILE_CNT_FLIPS] = 0;
     {
       JobArgs e = a;
@@ -367,7 +370,7 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   run(k_stream_cuts, a, 1, 64, reverse);
   if (counters[TILE_CNT_BAD] != 0) { info[0] = trecs[0].flags; return -10; }
   run(k_stream_finish, a, a.ntiles, 64, reverse);
-  const uint32_t nmb = counters[TILE_CNT_NMB];
+  nmb = counters[TILE_CNT_NMB];
   info[2] = nmb;
   if (const char* path = getenv("SIM_STREAM_CMDS")) {        // (debugging: the stream's commands, all meta-blocks)
     uint64_t total = 0;
@@ -381,12 +384,23 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
     m.nshards = nmb;
     lap("finish");
     run(k_build, m, nmb, 64, reverse);
+    lap("build");
     run(k_store, m, nmb, 64, reverse);
-    lap("build+store");
+    lap("store");
   }
   run(k_stream_scan, a, 1, 64, reverse);
   if (counters[1]) return -3;
-  if (counters[TILE_CNT_RAW] != 0) { info[0] = TILE_WHY_RAW; return -10; }
+  if (counters[TILE_CNT_RAW] != 0) return -3;
+  counters[TILE_CNT_RBCHG] = 0;
+  run(k_stream_rollback, a, 1, 64, reverse);
+  if (tlog) {
+    uint32_t nraw = 0;
+    for (uint32_t m = 0; m < nmb; ++m) nraw += mstate[m].mb_was_raw != 0;
+    fprintf(stderr, "outer %d: %u meta-blocks (%u raw), tiles with a new roll-back %u\n", outer, nmb, nraw, counters[TILE_CNT_RBCHG]);
+  }
+  if (counters[TILE_CNT_RBCHG] == 0) break;
+  memset(mstate.data(), 0, mstate.size() * sizeof(ShardState));
+  }
   run(k_stream_place, a, nmb * STREAM_PLACE_PARTS, 256, reverse);
   const uint64_t nbytes = (moff[nmb] + 7) / 8;
   if (nbytes > out_cap) return -4;

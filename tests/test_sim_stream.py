@@ -79,6 +79,19 @@ def test_streams_that_leave_the_tiled_path(sim, ref):
     _same(sim, ref, bytes(G.mixed_corpus(262144, seed=6)), 17)
 
 
+def test_a_raw_meta_block_rolls_the_distance_cache_back(sim, ref):
+    """400 kB of random bytes inside text: one meta-block of the stream is stored uncompressed (encode.c:598-614) — its
+    payload byte aligned in the stream, and the tile behind it starts from the distance cache the raw meta-block
+    started from: k_stream_scan decides which are raw, k_stream_rollback tells the tiles, the sweep loop runs again."""
+    rng = np.random.default_rng(9)
+    text = bytes(G.enwik_text(700000, seed=3))
+    data = text[:300000] + bytes(rng.integers(0, 256, 400000, dtype=np.uint8)) + text[300000:600000]
+    want = ref.compress(data, 5, 17)
+    assert len(want) > 400000           # (the noise did not compress)
+    got, info = sim.encode_stream(data, lgwin=17)
+    assert got == want and info[2] >= 5
+
+
 def test_the_dictionary_gate_stays_open(sim, ref):
     """Data on which the static dictionary's gate never closes (hash.h:186) — English, where the dictionary keeps
     matching, and a highly repetitive stream, where hardly a search fails: tile 0 ends with the gate open, the other
