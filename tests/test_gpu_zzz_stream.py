@@ -81,11 +81,19 @@ def test_plain_chain_copy_to_the_block_end(amd, stock):
     assert bytes(got) == Ref().encode_plan(data, 5, 22, 128 << 10)
 
 
-def test_streams_that_do_not_suit_the_tiles_take_the_serial_stream(amd, stock):
-    data = bytes(G.mixed_corpus(6 << 20, seed=3))
-    got, _ = one_shot(amd, data, 22)
-    want, _ = one_shot(stock, data, 22)
-    assert got == want
+def test_mixed_data_and_raw_meta_blocks(amd, stock):
+    """The mixed corpus (floats, sparse zeros, noise, text) and text with 2 MiB of random bytes in it (meta-blocks
+    stored raw, the distance cache rolled back behind them: k_stream_scan / k_stream_rollback) stay on the tiled path;
+    random bytes alone leave it for the serial stream.  The bytes are the reference's every time."""
+    rng = np.random.default_rng(4)
+    text = bytes(G.enwik_text(6 << 20, seed=9))
+    cases = [(bytes(G.mixed_corpus(6 << 20, seed=3)), 22),
+             (text[:4 << 20] + bytes(rng.integers(0, 256, 2 << 20, dtype=np.uint8)) + text[4 << 20:], 18),
+             (bytes(rng.integers(0, 256, 3 << 20, dtype=np.uint8)), 20)]
+    for data, lgwin in cases:
+        got, _ = one_shot(amd, data, lgwin)
+        want, _ = one_shot(stock, data, lgwin)
+        assert got == want
 
 
 def test_1gib_stock_call(amd, stock):

@@ -137,5 +137,12 @@ def test_stock_call_through_the_boundary(ref, monkeypatch):
     assert call(text, 17) == ref.compress(text, 5, 17)
     mixed = bytes(G.mixed_corpus(200000, seed=5))
     assert call(mixed, 17) == ref.compress(mixed, 5, 17)
+    # input handed over in pieces: with BROTLI_AMD_FEED_KB above the input's size the library holds it until FINISH,
+    # and the FINISH takes the tiled stream path like the one-shot call
+    from test_gpu_abi import drive
+    monkeypatch.setenv("BROTLI_AMD_FEED_KB", "1000000")
+    got, fin = drive(L, text, [(100000, 0), (100001, 0), (len(text) - 200001, 2)], params=((2, 17),))
+    assert fin and bytes(got) == ref.compress(text, 5, 17)
+    monkeypatch.delenv("BROTLI_AMD_FEED_KB")
     monkeypatch.setenv("BROTLI_AMD_STREAM_TILES", "0")
     assert call(text[:200000], 17) == ref.compress(text[:200000], 5, 17)

@@ -20,6 +20,8 @@ def make(seed):
     kind = int(rng.integers(0, 5))
     if seed >= 4000 and seed % 4 == 0:
         kind = 5             # (seeds below 4000 keep what they generated when tests/test_sim_stream.py pinned them)
+    if seed >= 7000 and seed % 4 == 1:
+        kind = 6
     n = int(rng.integers(3 << 16, (14 << 16) if lgwin == 17 else (20 << 16)))
     if kind == 0:
         data = bytes(gen_inputs.enwik_text(n, seed=seed))
@@ -45,6 +47,15 @@ def make(seed):
             d = int(rng.integers(1, min(a, 1 << lgwin) - 1)) if a > 2 else 1
             if a - d >= 0 and b + w <= n:
                 buf[a:b + w] = buf[a - d:b + w - d]
+        data = buf.tobytes()
+    elif kind == 6:
+        # text with stretches of random bytes: meta-blocks stored raw, the distance cache rolled back behind them,
+        # tiles without a command
+        buf = np.frombuffer(bytes(gen_inputs.enwik_text(n, seed=seed)), dtype=np.uint8).copy()
+        for _ in range(int(rng.integers(1, 4))):
+            w = int(rng.integers(20000, min(500000, n // 3)))
+            a = int(rng.integers(0, n - w))
+            buf[a:a + w] = rng.integers(0, 256, w, dtype=np.uint8)
         data = buf.tobytes()
     elif kind == 5:
         # English (the static dictionary's gate stays open) with stretches of the synthetic text (on which it closes)
