@@ -78,6 +78,9 @@ struct JobParams {
 #define JOB_FLAG_STREAMT 8192u // one unpartitioned stream longer than the window, parsed in tiles: the index is built per
                                //   chunk of 1 << chunk_log2 positions plus a look-back of the same size (ShardDesc::ix_*),
                                //   the chain works in stream positions, meta-block cuts are part of the tiles' join state
+#define JOB_FLAG_VIEWALL 16384u // (per launch, with JOB_FLAG_FORCE_SLOW) k_chain_tiles parses tiles again in a later pass (k_tile.h:
+                               //   gate_walk): the bitmap holds what the other tiles left unstored — the events that told so
+                               //   in the first pass are used up —, so every search is done exactly against it
 #define JOB_FLAG_SWEEP 2048u   // (per launch) k_chain replays the tiles' previous commands and parses again only where an
                                //   event is pending
 
@@ -143,6 +146,9 @@ struct TileRec {
   // taken as open (TILE_GATE_OPEN) the true counters at a tile's start are the sums over the tiles before
   uint32_t dlookups, dmatches;
   uint32_t pad;
+  // the gate hypothesis this tile is (to be) parsed with: 0 closed, 1 open for good, 2 from the exact counters in_l / in_m
+  // (the tile in which it may close: k_tile.h, gate_walk)
+  uint32_t hyp, in_l, in_m;
   // JOB_FLAG_STREAMT: the meta-block that ends in front of this tile is stored uncompressed, so the distance cache the
   // tile starts from is the one that meta-block started from (encode.c:598-614) — known once the meta-blocks have been
   // built and placed (k_stream_scan / k_stream_rollback), part of the join like the rest

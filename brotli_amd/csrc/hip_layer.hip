@@ -575,13 +575,23 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       // shards whose tile 0 ended with the static dictionary's gate open (real English): their other tiles once more,
       // the gate taken as open for good (k_tile.h); for everything else the second launch finds nothing to do
       hipLaunchKernelGGL(k_tile_restart, dim3(nshards), dim3(64), 0, c->stream, a);
-      hipLaunchKernelGGL(k_tile_restart_clear, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
+      hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, a);
       hipLaunchKernelGGL(k_chain_tiles, cgrid, dim3(64), clds, c->stream, a);
       lap("second parse");
       bool settled = false;
       uint32_t tc[16];
       for (int pass = 0; pass < 12 && !settled; ++pass) {
         HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_START, 0, 2 * sizeof(uint32_t), c->stream));
+        HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_RESTART, 0, sizeof(uint32_t), c->stream));
+        if (pass != 0 && tc[TILE_CNT_RESTART] != 0) {
+          // tiles the gate walk sent back (k_tile.h: the static dictionary's gate may close in them, or has closed in
+          // front of them): parsed again from scratch, every search exact against the bitmap as it stands
+          JobArgs l = a;
+          l.J.flags |= JOB_FLAG_VIEWALL | JOB_FLAG_FORCE_SLOW;
+          hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, l);
+          hipLaunchKernelGGL(k_chain_tiles, cgrid, dim3(64), clds, c->stream, l);
+          lap("tiles again");
+        }
         {
           JobArgs e = a;
           if (pass != 0) e.J.flags |= JOB_FLAG_SWEEP;     // (first pass: cross-tile successors only, k_tile.h)
@@ -594,7 +604,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
         tile_bad = tc[TILE_CNT_BAD];
         if (tlog) fprintf(stderr, "tile pass %d: start events %u, changed skip bits %u, shards off the tiled path %u\n",
                           pass, tc[TILE_CNT_START], tc[TILE_CNT_FLIPS], tc[TILE_CNT_BAD]);
-        if (tc[TILE_CNT_START] == 0 && tc[TILE_CNT_FLIPS] == 0) { settled = true; break; }
+        if (tc[TILE_CNT_START] == 0 && tc[TILE_CNT_FLIPS] == 0 && tc[TILE_CNT_RESTART] == 0) { settled = true; break; }
         JobArgs b = a;
         b.J.flags |= JOB_FLAG_SWEEP;
         // a sweep is a few hundred dependent steps per tile around its events: few tiles per wave, so that a tile
@@ -796,7 +806,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f);
     lap("first parse");
     hipLaunchKernelGGL(k_tile_restart, dim3(1), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_tile_restart_clear, egrid, dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f);
   }
   lap("second parse");
@@ -818,6 +828,17 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
   bool settled = false;
   for (int pass = 0; pass < 24 && !settled; ++pass, ++passes) {
     HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_START, 0, 2 * sizeof(uint32_t), c->stream));
+    HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_RESTART, 0, sizeof(uint32_t), c->stream));
+    if (passes != 0 && tc[TILE_CNT_RESTART] != 0) {
+      // tiles the gate walk sent back (k_tile.h): parsed again from scratch, every search exact
+      JobArgs l = a;
+      l.J.flags |= JOB_FLAG_VIEWALL | JOB_FLAG_FORCE_SLOW;
+      l.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
+      if (gpw != 4) l.J.flags |= gpw << JOB_FLAG_GROUPS_SHIFT;
+      hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, l);
+      hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, l);
+      lap("tiles again");
+    }
     {
       JobArgs e = a;
       if (passes != 0) e.J.flags |= JOB_FLAG_SWEEP;
@@ -841,7 +862,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
       *rc = BROTLI_AMD_SERIAL;
       return true;
     }
-    if (tc[TILE_CNT_START] == 0 && tc[TILE_CNT_FLIPS] == 0) { settled = true; break; }
+    if (tc[TILE_CNT_START] == 0 && tc[TILE_CNT_FLIPS] == 0 && tc[TILE_CNT_RESTART] == 0) { settled = true; break; }
     JobArgs b = a;
     b.J.flags |= JOB_FLAG_SWEEP;
     uint32_t sg = 2;

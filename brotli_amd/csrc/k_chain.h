@@ -814,7 +814,9 @@ DEV void c_group_replay(const JobParams& J, CShard& C, CReplay& R, bool alive, u
         R.odc[0] = g.dc[0]; R.odc[1] = g.dc[1]; R.odc[2] = g.dc[2]; R.odc[3] = g.dc[3];
         g.r.ncmds += m;
         g.r.nlits += nl;
-        g.dict_lookups += nd & 0xFFFFu; g.dict_matches += nd >> 16;
+        // (counted from the mark = the counters behind the last commit: the generic steps may have searched — and
+        //  looked up — a part of the first command's insert run already, and the command's counts cover all of it)
+        g.dict_lookups = g.dict_mark_l + (nd & 0xFFFFu); g.dict_matches = g.dict_mark_m + (nd >> 16);
         g.dict_mark_l = g.dict_lookups; g.dict_mark_m = g.dict_matches;
         g.insert_length = 0;
         g.apply_random_heuristics = na;
@@ -928,8 +930,9 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   const bool stream = tiled && (J.flags & JOB_FLAG_STREAMT) != 0;
   // the gate hypothesis of the shard's tiles t > 0 (enc_types.h: TILE_GATE_OPEN), and the counter values that stand
   // for it at a tile's start: closed = 256 lookups without a match; open for good = a match count no lookup count reaches
-  const bool gate_open = tile_mode && alive && (trecs[D.tile_base].flags & TILE_GATE_OPEN) != 0;
-  const uint32_t gate_l0 = gate_open ? 0u : 256u, gate_m0 = gate_open ? 0x40000000u : 0u;
+  const uint32_t hyp = (tile_mode && alive && tt != 0u) ? TR->hyp : 0u;
+  const uint32_t gate_l0 = hyp == 2u ? TR->in_l : hyp == 1u ? 0u : 256u;
+  const uint32_t gate_m0 = hyp == 2u ? TR->in_m : hyp == 1u ? 0x40000000u : 0u;
   bool cut_in = false;                                 // a stream's tile that begins a meta-block: no ExtendLastCommand
   CReplay R;
   R.old = g.cmds; R.oi = R.on = 0; R.obnd = 0; R.changed = 0; R.next_ev = 0;
@@ -942,7 +945,8 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
     }
     const uint32_t ev_w0 = (C.tile_lo - umin(C.tile_lo, C.geo.first)) >> 5, ev_w1 = (C.tile_hi - C.geo.first + 31u) >> 5;
     bool run = alive && tile_mode && !S0->error;
-    if (!sweep && run && (TR->flags & TILE_RAN) != 0) run = false;       // (a second launch parses the restarted tiles only, k_tile_restart)
+    if (!sweep && run && (TR->flags & TILE_RAN) != 0) run = false;       // (a later launch parses the tiles sent back only, k_tile.h)
+    if (sweep && run && (TR->flags & TILE_RAN) == 0) run = false;        // (... and a sweep leaves those alone)
     uint32_t any = 0;
     if (sweep && run) {
       // only tiles with something pending run: a replaced in-state or an event among their positions
@@ -961,6 +965,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       g.lim_cmd_cap = tile_slot_cmds(J.tile_log2, (uint32_t)J.lgblock);
       const uint32_t oldbuf = sweep ? TR->buf : 1u;
       g.cmds = c_tile_slot(ws, D, J, oldbuf ^ 1u, tt);
+      if (!sweep && (J.flags & JOB_FLAG_VIEWALL) != 0) C.mode |= C_VIEW_ALL;
       if (sweep) {
         C.mode |= C_VIEW_ALL;
         force_slow = true;
@@ -1204,6 +1209,10 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
         }
       }
     }
+#if defined(BROTLI_AMD_SIMT_SIM)
+    if (g.state == Q_POST && t == 0 && alive && getenv("SIM_GATE_LOG"))
+      fprintf(stderr, "GATE mode %d tile %u block end %u: lookups %u matches %u\n", MODE, tt, g.pos_end, g.dict_lookups, g.dict_matches);
+#endif
     if (g.state == Q_POST) q_driver_post(J, g, writer);
     // a tile that met a counter wrap gives up at once: the shard goes the plain way anyway, and the counted
     // searches (c_search_exact walks a whole key run) are what makes such shards slow

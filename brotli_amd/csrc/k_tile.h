@@ -32,6 +32,77 @@
 #define TILE_CNT_FLIPS 3
 #define TILE_CNT_BAD 4
 
+// ---- the gate hypothesis (TILE_GATE_OPEN) ---------------------------------------------------------------------------
+// Tiles t > 0 are first parsed with the static dictionary's gate taken as closed — right for everything but text
+// the dictionary keeps matching (real English), where tile 0 — the one that starts from the true counters — ends with
+// the gate open.  Then the shard's other tiles start over with the gate taken as open for good: k_tile_restart
+// (grid = nshards, block = 64; between the tiles' first launch and a second one that parses the restarted tiles
+// only) un-runs them, k_tile_restart_clear (grid = units * ix_slices) wipes their bitmaps.
+#define TILE_CNT_RESTART 7
+DEV void tile_unrun(TileRec& r, uint32_t hyp) {
+  r.hyp = hyp;
+  r.flags &= ~(TILE_RAN | TILE_START_EVENT | TILE_CHANGED);
+}
+DEV void tile_restart(const ShardDesc& D, TileRec* trecs, uint32_t* counters) {
+  if (D.ntiles <= 1u) return;
+  TileRec* R = trecs + D.tile_base;
+  const uint32_t f0 = R[0].flags;
+  if (!(f0 & TILE_RAN) || (f0 & (TILE_BAD | TILE_GATE_OPEN)) != 0 || R[0].out_gate != 0u) return;
+  for (uint32_t t = 1u + (uint32_t)wave_lane(); t < D.ntiles; t += 64u) tile_unrun(R[t], 1u);
+  wave_sync();
+  if (wave_lane() == 0) {
+    R[0].flags = f0 | TILE_GATE_OPEN;
+    glb_atomic_add(&counters[TILE_CNT_RESTART], 1u);
+  }
+}
+// grid = ntiles, block = 64: a tile that is to be parsed again from scratch forgets what it marked.
+DEV void tile_restart_clear(const JobParams& J, const ShardDesc& D, uint8_t* ws, const TileRec* trecs, uint32_t tt) {
+  if (D.ntiles <= 1u || tt == 0u || (trecs[D.tile_base + tt].flags & TILE_RAN) != 0) return;
+  const uint32_t first = D.stream_offset != 0 ? 2u : 0u;
+  uint32_t *skip, *prev, *ev;
+  if (J.flags & JOB_FLAG_STREAMT) {
+    skip = (uint32_t*)(ws + J.sbm_off); prev = (uint32_t*)(ws + J.sbm_off + J.sbm_stride); ev = (uint32_t*)(ws + J.sbm_off + 2u * J.sbm_stride);
+  } else {
+    IxLayout L;
+    ix_layout(D.len, J.ix_slices, J.ix_nb_log2, &L);
+    uint8_t* base = ws + D.ix_off;
+    skip = (uint32_t*)(base + L.skip); prev = (uint32_t*)(base + L.skip_prev); ev = (uint32_t*)(base + L.ev);
+  }
+  const uint32_t w0 = (tile_lo(first, tt, J.tile_log2) - first) >> 5;
+  const uint32_t w1 = tt + 1u == D.ntiles ? (D.len + 128u + 31u) >> 5 : (tile_lo(first, tt + 1u, J.tile_log2) - first) >> 5;
+  for (uint32_t i = w0 + (uint32_t)wave_lane(); i < w1; i += 64u) { skip[i] = 0; prev[i] = 0; ev[i] = 0; }
+}
+// The gate along a shard whose tile 0 ended with it open (one lane): tiles parsed as "open for good" are confirmed
+// with the summed counters; the first one that cannot be (the gate may close in it) is parsed again from the exact
+// counters, and once a tile has ended with the gate closed everything behind it is parsed as closed.  Returns the
+// tiles sent back to be parsed again (the caller's loop goes on while there are any).
+DEV uint32_t gate_walk(TileRec* R, uint32_t ntiles) {
+  uint32_t gl = R[0].dlookups, gm = R[0].dmatches, again = 0;
+  bool closed = false;
+  for (uint32_t t = 1; t < ntiles; ++t) {
+    TileRec& c = R[t];
+    if (closed) {
+      if (c.hyp != 0u) { tile_unrun(c, 0u); ++again; }
+      continue;
+    }
+    if (!(c.flags & TILE_RAN)) break;                     // (on its way already: nothing behind it can be told yet)
+    if (c.hyp == 1u) {
+      if (gm >= ((gl + c.dlookups) >> 7)) { gl += c.dlookups; gm += c.dmatches; continue; }
+      c.in_l = gl; c.in_m = gm;
+      tile_unrun(c, 2u); ++again;
+      break;
+    }
+    if (c.hyp == 2u) {
+      if (c.in_l != gl || c.in_m != gm) { c.in_l = gl; c.in_m = gm; tile_unrun(c, 2u); ++again; break; }
+      if (c.out_gate != 0u) closed = true; else { gl += c.dlookups; gm += c.dmatches; }
+      continue;
+    }
+    tile_unrun(c, 1u); ++again;                           // parsed as closed, but it is not closed here
+    break;
+  }
+  return again;
+}
+
 // grid = nshards, block = 64: lane 0 walks the shard's tiles.
 DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, TileRec* trecs, uint32_t* counters) {
   if (D.ntiles <= 1u || wave_lane() != 0) return;
@@ -42,12 +113,14 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
   // a shard most of whose searches the tiles would have to do twice is better off on the plain chain
   if (R[0].nflips > D.len / 32u + 64u) why |= TILE_WHY_EVENTS;
   R[0].nflips = 0;
-  R[0].pad = 0;                                         // (k_tile_restart's mark)
-  // the static dictionary's gate (hash.h:186): with the tiles t > 0 parsed as if it stayed open for good, the counters
-  // at a tile's start are tile 0's plus the tiles' before — it cannot close inside a tile whose start has
-  // matches >= (lookups + the tile's lookups) >> 7 (matches only grow, lookups end at that sum)
+  // the static dictionary's gate (hash.h:186): with tiles parsed as if it stayed open for good, the counters at a
+  // tile's start are tile 0's plus the tiles' before — it cannot close inside a tile whose start has
+  // matches >= (lookups + the tile's lookups) >> 7 (matches only grow, lookups end at that sum): gate_walk
   const bool gate_open = (R[0].flags & TILE_GATE_OPEN) != 0;
-  uint32_t gl = 0, gm = 0;
+  if (gate_open) {
+    const uint32_t again = gate_walk(R, D.ntiles);
+    if (again != 0) { glb_atomic_add(&counters[TILE_CNT_RESTART], again); return; }     // (joins: once every tile has run)
+  }
   for (uint32_t t = 0; t < D.ntiles; ++t) {
     TileRec& c = R[t];
     if (c.flags & TILE_BAD) why |= TILE_WHY_TILE;
@@ -55,15 +128,11 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
     c.cmd_off = ncmds;
     ncmds += c.out_ncmds;
     nlits += c.out_nlits;
-    if (gate_open) {
-      if (t != 0u && gm < ((gl + c.dlookups) >> 7)) why |= TILE_WHY_GATE;
-      gl += c.dlookups; gm += c.dmatches;
-    }
     if (t + 1u == D.ntiles) break;
     // what the next tile has to start from
     TileRec& n = R[t + 1u];
     if (c.out_ncmds == 0u) why |= TILE_WHY_NO_CMD;          // (no command ExtendLastCommand could lengthen)
-    if (!gate_open && c.out_gate == 0u) why |= TILE_WHY_GATE;   // (taken as closed, but the dictionary is still consulted)
+    if (!gate_open && c.out_gate == 0u) why |= TILE_WHY_GATE;   // (cannot happen: tile 0 open restarts the shard, a closed gate stays closed)
     const bool same_cmd = c.out_insert != 0u || (n.in_copy_len == c.out_copy_len && n.in_code == c.out_code);
     const bool same = n.in_dc[0] == c.out_dc[0] && n.in_dc[1] == c.out_dc[1] && n.in_dc[2] == c.out_dc[2] &&
                       n.in_dc[3] == c.out_dc[3] && n.in_insert == c.out_insert && same_cmd;
@@ -199,33 +268,6 @@ DEV void tile_finish(const JobParams& J, const ShardDesc& D, ShardState* S, uint
   }
 }
 
-// ---- the gate hypothesis (TILE_GATE_OPEN) ---------------------------------------------------------------------------
-// Tiles t > 0 are first parsed with the static dictionary's gate taken as closed — right for everything but text
-// the dictionary keeps matching (real English), where tile 0 — the one that starts from the true counters — ends with
-// the gate open.  Then the shard's other tiles start over with the gate taken as open for good: k_tile_restart
-// (grid = nshards, block = 64; between the tiles' first launch and a second one that parses the restarted tiles
-// only) un-runs them, k_tile_restart_clear (grid = units * ix_slices) wipes their bitmaps.
-#define TILE_CNT_RESTART 7
-DEV void tile_restart(const ShardDesc& D, TileRec* trecs, uint32_t* counters) {
-  if (D.ntiles <= 1u) return;
-  TileRec* R = trecs + D.tile_base;
-  const uint32_t f0 = R[0].flags;
-  if (!(f0 & TILE_RAN) || (f0 & (TILE_BAD | TILE_GATE_OPEN)) != 0 || R[0].out_gate != 0u) return;
-  for (uint32_t t = 1u + (uint32_t)wave_lane(); t < D.ntiles; t += 64u) R[t].flags &= ~(TILE_RAN | TILE_START_EVENT | TILE_CHANGED);
-  wave_sync();
-  if (wave_lane() == 0) {
-    R[0].flags = f0 | TILE_GATE_OPEN;
-    R[0].pad = 1u;
-    glb_atomic_add(&counters[TILE_CNT_RESTART], 1u);
-  }
-}
-// The words of the three bitmaps from tile 1 on, slice w of `nslices` of the word range [w_lo, w_hi).
-DEV void tile_restart_clear(uint32_t* skip, uint32_t* prev, uint32_t* ev, uint32_t w_lo, uint32_t w_hi, uint32_t w, uint32_t nslices) {
-  const uint32_t per = (w_hi - w_lo + nslices - 1u) / nslices;
-  const uint32_t a = w_lo + w * per, b = umin(a + per, w_hi);
-  for (uint32_t i = a + (uint32_t)wave_lane(); i < b; i += 64u) { skip[i] = 0; prev[i] = 0; ev[i] = 0; }
-}
-
 // ---- a tiled stream (JOB_FLAG_STREAMT): one encoder instance longer than the window ------------------------------
 // The stream is one shard whose tiles are its input blocks (tile_log2 == lgblock).  Besides the joins of the tiled
 // shards above, a tile's parse depends on whether a meta-block was cut in front of it (encode.c:1141-1216: the
@@ -290,20 +332,18 @@ DEV void stream_cuts(const JobParams& J, const ShardDesc& D, TileRec* R, const u
   uint32_t s_tile = 0, accL = 0, accC = 0, m = 0, cmd_row = 0, mb_cmd_lo = 0;
   uint32_t prev_cut = 0;                     // the row before ended with a cut behind its last tile
   bool overflow = false;
-  // the gate taken as open for good (TILE_GATE_OPEN): the same check as tile_verify's, 64 tiles per step
-  const bool gate_open = (R[0].flags & TILE_GATE_OPEN) != 0;
-  uint32_t gl = 0, gm = 0;
-  bool gate_fail = false;
+  // the gate along a stream whose first block left it open (gate_walk; one lane: only such streams pay for it)
+  if ((R[0].flags & TILE_GATE_OPEN) != 0 && !finalize) {
+    uint32_t again = 0;
+    if (lane == 0) again = gate_walk(R, nt);
+    again = wave_bcast(again, 0);
+    if (again != 0 && lane == 0) glb_atomic_add(&counters[TILE_CNT_RESTART], again);
+  }
+  wave_sync();
   for (uint32_t r0 = 0; r0 < nt; r0 += 64u) {
     const uint32_t t = r0 + lane;
     const bool have = t < nt;
     const uint32_t nl = have ? R[t].out_nlits : 0u, nc = have ? R[t].out_ncmds : 0u, oi = have ? R[t].out_insert : 0u;
-    if (gate_open) {
-      const uint32_t dl = have ? R[t].dlookups : 0u, dm = have ? R[t].dmatches : 0u;
-      const uint32_t lb = gl + wave_incl_scan(dl) - dl, mb = gm + wave_incl_scan(dm) - dm;      // the counters at the tile's start
-      if (wave_ballot(have && t != 0u && mb < ((lb + dl) >> 7)) != 0) gate_fail = true;
-      gl = wave_bcast(lb + dl, 63); gm = wave_bcast(mb + dm, 63);
-    }
     uint32_t startlane = 0;
     uint64_t cutmask = 0;
     uint32_t carryL = accL, carryC = accC;
@@ -340,10 +380,6 @@ DEV void stream_cuts(const JobParams& J, const ShardDesc& D, TileRec* R, const u
     cmd_row += wave_bcast(ex + nc, 63) + (uint32_t)dev_popc64(flushmask);
     prev_cut = (uint32_t)((cutmask >> 63) & 1ull);
   }
-  if (gate_fail && lane == 0 && !(R[0].flags & TILE_BAD)) {
-    R[0].flags |= TILE_BAD | TILE_WHY_GATE;
-    glb_atomic_add(&counters[TILE_CNT_BAD], 1u);
-  }
   if (finalize) {
     if (m < mcap) { if (lane == 0) stream_emit_mb(J, D, input, md, ms, m, s_tile, nt - 1u, mb_cmd_lo, accC, accL, true); }
     else overflow = true;
@@ -362,21 +398,21 @@ DEV void stream_verify(const JobParams& J, const ShardDesc& D, TileRec* R, uint3
   uint32_t why = 0;
   TileRec& c = R[t];
   if (c.flags & TILE_BAD) why |= TILE_WHY_TILE;
-  if (!(c.flags & TILE_RAN)) why |= TILE_WHY_NOT_RUN;
   if (t == 0) {
     // (a stream's other way is one wave on the whole stream: searching half of the positions twice is still
     //  far better — the bound only keeps literal-spree data, of which most positions are unstored, off the sweeps)
     if (c.nflips > D.len / 2u + 64u) why |= TILE_WHY_EVENTS;
     c.nflips = 0;
-    c.pad = 0;                                          // (k_tile_restart's mark)
   }
-  if (t + 1u < D.ntiles) {
+  // (tiles sent back by gate_walk are parsed at the top of the next pass: their joins are checked then)
+  const bool pending = !(c.flags & TILE_RAN) || (t + 1u < D.ntiles && !(R[t + 1u].flags & TILE_RAN));
+  if (t + 1u < D.ntiles && !pending) {
     TileRec& n = R[t + 1u];
     const bool cut = n.cut != 0;
     // (a tile without a command — a block of noise — ends with literals pending: the next block's ExtendLastCommand
     //  does nothing then, encode.c:1103, and nobody asks for the last command)
     if (c.out_ncmds == 0u && c.out_insert == 0u && !cut) why |= TILE_WHY_NO_CMD;
-    if (!(R[0].flags & TILE_GATE_OPEN) && c.out_gate == 0u) why |= TILE_WHY_GATE;      // (open for good: k_stream_cuts checks)
+    if (!(R[0].flags & TILE_GATE_OPEN) && c.out_gate == 0u) why |= TILE_WHY_GATE;      // (cannot happen: see tile_verify)
     const uint32_t req_insert = cut ? 0u : c.out_insert;
     const bool same_cmd = cut || c.out_insert != 0u || (n.in_copy_len == c.out_copy_len && n.in_code == c.out_code);
     // (behind a raw meta-block the distance cache is the one that meta-block began with: k_stream_rollback)

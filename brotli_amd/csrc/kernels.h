@@ -189,33 +189,15 @@ __global__ void __launch_bounds__(64) k_tile_events(JobArgs a) {
   const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
   if (shard < a.nshards) tile_events(a.J, a.shards[shard], a.input, a.ws, a.trecs, w, a.counters);
 }
-// the gate hypothesis (k_tile.h): grid = nshards; then grid = nshards * ix_slices (a stream: nchunks * ix_slices)
+// the gate hypothesis (k_tile.h): grid = nshards
 __global__ void __launch_bounds__(64) k_tile_restart(JobArgs a) {
   if (blockIdx.x < a.nshards) tile_restart(a.shards[blockIdx.x], a.trecs, a.counters);
 }
+// grid = ntiles
 __global__ void __launch_bounds__(64) k_tile_restart_clear(JobArgs a) {
-  const uint32_t unit = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
-  if (a.J.flags & JOB_FLAG_STREAMT) {
-    if (unit >= a.J.nchunks || a.trecs[0].pad == 0u) return;
-    const ShardDesc& D = a.shards[0];
-    // chunk `unit`'s own words of the stream's bitmaps, from tile 1 on
-    const uint32_t lo = umax(unit << a.J.chunk_log2, 1u << a.J.tile_log2), hi = umin(D.len + 128u, (unit + 1u) << a.J.chunk_log2);
-    if (lo >= hi) return;
-    uint32_t* G = (uint32_t*)(a.ws + a.J.sbm_off);
-    const uint32_t stride = (uint32_t)(a.J.sbm_stride / 4u);
-    tile_restart_clear(G, G + stride, G + 2u * stride, lo >> 5, (hi + 31u) >> 5, w, a.J.ix_slices);
-    return;
-  }
-  if (unit >= a.nshards) return;
-  const ShardDesc& D = a.shards[unit];
-  if (D.ntiles <= 1u || a.trecs[D.tile_base].pad == 0u) return;
-  IxLayout L;
-  ix_layout(D.len, a.J.ix_slices, a.J.ix_nb_log2, &L);
-  uint8_t* base = a.ws + D.ix_off;
-  const uint32_t first = D.stream_offset != 0 ? 2u : 0u;
-  const uint32_t lo = tile_lo(first, 1u, a.J.tile_log2) - first;
-  tile_restart_clear((uint32_t*)(base + L.skip), (uint32_t*)(base + L.skip_prev), (uint32_t*)(base + L.ev), lo >> 5,
-                     (D.len + 128u + 31u) >> 5, w, a.J.ix_slices);
+  if (blockIdx.x >= a.ntiles) return;
+  const TileDesc d = a.tiles[blockIdx.x];
+  tile_restart_clear(a.J, a.shards[d.shard], a.ws, a.trecs, d.t);
 }
 // grid = ntiles, block = 64
 __global__ void __launch_bounds__(64) k_tile_finish(JobArgs a) {

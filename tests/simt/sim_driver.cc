@@ -48,13 +48,19 @@ void run_parse_kernel(JobArgs a, int reverse, int round = 0) {
     run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
     // shards whose tile 0 ended with the static dictionary's gate open: their other tiles once more, gate taken as open
     run(k_tile_restart, a, a.nshards, 64, reverse);
-    run(k_tile_restart_clear, a, a.nshards * a.J.ix_slices, 64, reverse);
+    run(k_tile_restart_clear, a, a.ntiles, 64, reverse);
     run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
     if (getenv("SIM_TILE_LOG")) fprintf(stderr, "shards restarted with the gate taken as open: %u\n", a.counters[TILE_CNT_RESTART]);
     bool settled = false;
     int rounds = 0;
     for (; rounds < 12 && !settled; ++rounds) {
-      a.counters[TILE_CNT_START] = a.counters[TILE_CNT_FLIPS] = 0;
+      a.counters[TILE_CNT_START] = a.counters[TILE_CNT_FLIPS] = a.counters[TILE_CNT_RESTART] = 0;
+      if (rounds != 0) {       // tiles the gate walk sent back (k_tile.h): parsed again from scratch, every search exact
+        JobArgs l = a;
+        l.J.flags |= JOB_FLAG_VIEWALL | JOB_FLAG_FORCE_SLOW;
+        run(k_tile_restart_clear, l, a.ntiles, 64, reverse);
+        run(k_chain_tiles, l, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+      }
       {
         JobArgs e = a;
         if (rounds != 0 || getenv("SIM_EVENTS_ALL")) e.J.flags |= JOB_FLAG_SWEEP;     // (first pass: cross-tile successors only, k_tile.h)
@@ -63,7 +69,7 @@ void run_parse_kernel(JobArgs a, int reverse, int round = 0) {
       run(k_tile_verify, a, a.nshards, 64, reverse);
       if (getenv("SIM_TILE_LOG")) fprintf(stderr, "tile round %d: start events %u, changed skip bits %u, shards off the tiled path %u\n", rounds,
                                           a.counters[TILE_CNT_START], a.counters[TILE_CNT_FLIPS], a.counters[TILE_CNT_BAD]);
-      if (a.counters[TILE_CNT_START] == 0 && a.counters[TILE_CNT_FLIPS] == 0) { settled = true; break; }
+      if (a.counters[TILE_CNT_START] == 0 && a.counters[TILE_CNT_FLIPS] == 0 && a.counters[TILE_CNT_RESTART] == 0) { settled = true; break; }
       JobArgs b = a;
       b.J.flags |= JOB_FLAG_SWEEP;
       const unsigned long long c7 = g_sim_counts[7], c15 = g_sim_counts[15], c5 = g_sim_counts[5];
@@ -325,7 +331,7 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
   lap("first parse");
   run(k_tile_restart, a, 1, 64, reverse);
-  run(k_tile_restart_clear, a, a.J.nchunks * a.J.ix_slices, 64, reverse);
+  run(k_tile_restart_clear, a, a.ntiles, 64, reverse);
   run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
   if (tlog) fprintf(stderr, "restarted with the gate taken as open: %u\n", counters[TILE_CNT_RESTART]);
   lap("second parse");
@@ -335,7 +341,13 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   if (outer >= 8) { info[0] = TILE_WHY_RAW; return -10; }
   bool settled = false;
   for (int r = 0; r < 16 && !settled; ++r, ++rounds) {
-    counters[TILE_CNT_START] = counters[TILE_CNT_FLIPS] = 0;
+    counters[TILE_CNT_START] = counters[TILE_CNT_FLIPS] = counters[TILE_CNT_RESTART] = 0;
+    if (rounds != 0) {         // tiles the gate walk sent back (k_tile.h): parsed again from scratch, every search exact
+      JobArgs l = a;
+      l.J.flags |= JOB_FLAG_VIEWALL | JOB_FLAG_FORCE_SLOW;
+      run(k_tile_restart_clear, l, a.ntiles, 64, reverse);
+      run(k_chain_tiles, l, (a.ntiles + gpw - 1) / gpw, 64, reverse);
+    }
     {
       JobArgs e = a;
       if (rounds != 0 || getenv("SIM_EVENTS_ALL")) e.J.flags |= JOB_FLAG_SWEEP;
@@ -354,7 +366,7 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
     if (getenv("SIM_TILE_LOG")) fprintf(stderr, "stream round %d: start events %u, changed skip bits %u, bad %u (flags %x)\n", rounds,
                                         counters[TILE_CNT_START], counters[TILE_CNT_FLIPS], counters[TILE_CNT_BAD], trecs[0].flags);
     if (counters[TILE_CNT_BAD] != 0) { info[0] = trecs[0].flags; info[1] = (uint32_t)rounds; return -10; }
-    if (counters[TILE_CNT_START] == 0 && counters[TILE_CNT_FLIPS] == 0) { settled = true; break; }
+    if (counters[TILE_CNT_START] == 0 && counters[TILE_CNT_FLIPS] == 0 && counters[TILE_CNT_RESTART] == 0) { settled = true; break; }
     JobArgs b = a;
     b.J.flags |= JOB_FLAG_SWEEP;
     uint32_t sg = getenv("SIM_SWEEP_GROUPS") ? (uint32_t)atoi(getenv("SIM_SWEEP_GROUPS")) : 2u;
@@ -366,6 +378,10 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   }
   info[1] = (uint32_t)rounds;
   if (!settled) { info[0] = TILE_WHY_EVENTS; return -10; }
+  if (tlog && (trecs[0].flags & TILE_GATE_OPEN))
+    for (uint32_t t = 0; t < a.ntiles; ++t)
+      fprintf(stderr, "  gate: tile %u hyp %u in (%u, %u) moved (%u, %u) closed at end %u flags %x\n", t, trecs[t].hyp, trecs[t].in_l, trecs[t].in_m,
+              trecs[t].dlookups, trecs[t].dmatches, trecs[t].out_gate, trecs[t].flags);
   a.aux = 1;
   run(k_stream_cuts, a, 1, 64, reverse);
   if (counters[TILE_CNT_BAD] != 0) { info[0] = trecs[0].flags; return -10; }
