@@ -233,7 +233,7 @@ def stock_call(data, quality, lgwin):
     return res
 
 
-def stock_call_whole(data, quality, lgwin, timeout_s=300):
+def stock_call_whole(data, quality, lgwin, timeout_s=180):
     """The same stock call on the WHOLE input (1 GiB by default): longer than the window, it takes the tiled stream
     path of the library (k_tile.h, JOB_FLAG_STREAMT) — or the serial device stream where the data does not suit it.
     Run in a child process with a timeout, after everything else has been measured: whatever happens there, the

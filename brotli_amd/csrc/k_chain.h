@@ -1041,10 +1041,12 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
     uint64_t qt = QP_NOW();
     if (sweep) c_group_replay(J, C, R, alive, htl, scratch);
     else {
+      // (tiles parsed again in a later pass — JOB_FLAG_VIEWALL — take the generic step only, like a sweep: it re-settles
+      //  every bit of what it passes over)
 #if defined(BROTLI_AMD_SIMT_SIM)
-      if (!getenv("SIM_NOFAST")) c_group_fast(J, T, C, alive, scratch, nsteps);   // (test knob: generic steps only)
+      if (!getenv("SIM_NOFAST") && !(J.flags & JOB_FLAG_VIEWALL)) c_group_fast(J, T, C, alive, scratch, nsteps);   // (test knob: generic steps only)
 #else
-      c_group_fast(J, T, C, alive, scratch, nsteps);
+      if (!(J.flags & JOB_FLAG_VIEWALL)) c_group_fast(J, T, C, alive, scratch, nsteps);
 #endif
     }
     if (g.state == Q_PRE) q_driver_pre(J, g);
@@ -1153,7 +1155,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
           const QResult sx = c_search_exact(J, C, exact, P0, scratch);
           if (exact) { cur = sx; ++C.nslow; }
         }
-        if (sweep && wave_any(take)) c_clear_range(C, take, P0, P0 + 1u);
+        if ((sweep || (J.flags & JOB_FLAG_VIEWALL) != 0) && wave_any(take)) c_clear_range(C, take, P0, P0 + 1u);
         if (take) C.frontier = P0 + 1u;          // FindLongestMatch stores the position it searched
         // static dictionary when nothing was found (hash.h:179-202)
         q_dict_search(J, T, g, take && cur.score == K_MIN_SCORE, P0, g.pos_end - P0, cur);

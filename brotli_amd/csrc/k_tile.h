@@ -70,7 +70,13 @@ DEV void tile_restart_clear(const JobParams& J, const ShardDesc& D, uint8_t* ws,
   }
   const uint32_t w0 = (tile_lo(first, tt, J.tile_log2) - first) >> 5;
   const uint32_t w1 = tt + 1u == D.ntiles ? (D.len + 128u + 31u) >> 5 : (tile_lo(first, tt + 1u, J.tile_log2) - first) >> 5;
-  for (uint32_t i = w0 + (uint32_t)wave_lane(); i < w1; i += 64u) { skip[i] = 0; prev[i] = 0; ev[i] = 0; }
+  // (in a later pass — JOB_FLAG_VIEWALL — the tile's new parse re-settles every bit of its range and the difference to
+  //  `prev` is what the other tiles have to hear about: only its pending events go, which an exact parse has no use for)
+  const bool late = (J.flags & JOB_FLAG_VIEWALL) != 0;
+  for (uint32_t i = w0 + (uint32_t)wave_lane(); i < w1; i += 64u) {
+    if (!late) { skip[i] = 0; prev[i] = 0; }
+    ev[i] = 0;
+  }
 }
 // The gate along a shard whose tile 0 ended with it open (one lane): tiles parsed as "open for good" are confirmed
 // with the summed counters; the first one that cannot be (the gate may close in it) is parsed again from the exact
