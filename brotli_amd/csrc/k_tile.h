@@ -415,12 +415,15 @@ DEV void stream_verify(const JobParams& J, const ShardDesc& D, TileRec* R, uint3
   if (t + 1u < D.ntiles && !pending) {
     TileRec& n = R[t + 1u];
     const bool cut = n.cut != 0;
-    // (a tile without a command — a block of noise — ends with literals pending: the next block's ExtendLastCommand
-    //  does nothing then, encode.c:1103, and nobody asks for the last command)
-    if (c.out_ncmds == 0u && c.out_insert == 0u && !cut) why |= TILE_WHY_NO_CMD;
+    // (a tile without a command: a block of noise ends with literals pending — the next block's ExtendLastCommand does
+    //  nothing then, encode.c:1103, and nobody asks for the last command — and a block that ExtendLastCommand consumed
+    //  whole, the middle of a copy longer than a block, hands on the command it was given, longer by what it added)
+    const bool hollow = c.out_ncmds == 0u && c.out_insert == 0u;
+    const uint32_t eff_copy_len = hollow ? c.in_copy_len + c.in_ext : c.out_copy_len;
+    const uint32_t eff_code = hollow ? c.in_code : c.out_code;
     if (!(R[0].flags & TILE_GATE_OPEN) && c.out_gate == 0u) why |= TILE_WHY_GATE;      // (cannot happen: see tile_verify)
     const uint32_t req_insert = cut ? 0u : c.out_insert;
-    const bool same_cmd = cut || c.out_insert != 0u || (n.in_copy_len == c.out_copy_len && n.in_code == c.out_code);
+    const bool same_cmd = cut || c.out_insert != 0u || (n.in_copy_len == eff_copy_len && n.in_code == eff_code);
     // (behind a raw meta-block the distance cache is the one that meta-block began with: k_stream_rollback)
     const int32_t* rdc = (n.rb != 0u && cut) ? n.rb_dc : c.out_dc;
     const bool same = n.in_dc[0] == rdc[0] && n.in_dc[1] == rdc[1] && n.in_dc[2] == rdc[2] &&
@@ -428,8 +431,8 @@ DEV void stream_verify(const JobParams& J, const ShardDesc& D, TileRec* R, uint3
     if (!same && why == 0) {
       for (int i = 0; i < 4; ++i) n.in_dc[i] = rdc[i];
       n.in_insert = req_insert;
-      n.in_copy_len = cut ? 0u : c.out_copy_len;
-      n.in_code = c.out_code;
+      n.in_copy_len = cut ? 0u : eff_copy_len;
+      n.in_code = eff_code;
       n.flags |= TILE_START_EVENT;
       glb_atomic_add(&counters[TILE_CNT_START], 1u);
     }
@@ -501,7 +504,13 @@ DEV void stream_finish(const JobParams& J, const ShardDesc& D, uint8_t* ws, cons
   const Command* src = c_tile_slot(ws, D, J, r.buf, tt) + (tt == 0 ? 0u : 1u);
   const uint32_t n = r.out_ncmds;
   const bool more = tt + 1u < D.ntiles;
-  const uint32_t ext = more ? R[tt + 1u].in_ext : 0u;
+  // what ExtendLastCommand added to the tile's last command at the next block — and at the blocks behind that one
+  // as long as it consumed them whole
+  uint32_t ext = 0;
+  for (uint32_t u = tt + 1u; u < D.ntiles; ++u) {
+    ext += R[u].in_ext;
+    if (!(R[u].out_ncmds == 0u && R[u].out_insert == 0u)) break;
+  }
   for (uint32_t i = lane; i < n; i += 64u) {
     Command c = src[i];
     if (c.cmd_prefix == CMD_RAW) {

@@ -66,6 +66,16 @@ def test_copies_cut_by_block_ends(sim, ref):
     assert sim.encode(data, 5, 22, flags=64) == ref.compress(data, 5, 22)
 
 
+def test_copies_longer_than_a_block(sim, ref):
+    """A 150 kB piece that comes again twice: ExtendLastCommand consumes whole input blocks (tiles without a command
+    and without pending literals), the command it lengthens belongs to a tile two or three blocks back."""
+    text = bytes(G.enwik_text(500000, seed=5))
+    piece = text[100000:250000]
+    data = text[:300000] + piece + text[300000:380000] + piece + piece[:70000] + text[380000:]
+    info = _same(sim, ref, data, 19)
+    assert info[2] >= 1
+
+
 def test_streams_that_leave_the_tiled_path(sim, ref):
     """Random bytes (most positions unstored by the literal spree): the tiled path says so and writes nothing — the
     library then runs the serial device stream.  The mixed corpus (floats, sparse zeros, noise, text) stays on it."""
