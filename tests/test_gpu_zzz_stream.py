@@ -64,6 +64,18 @@ def test_english_keeps_the_dictionary_gate_open(amd, stock):
         assert got == want
 
 
+def test_duplicated_pieces_copies_longer_than_a_block(amd, stock):
+    """An archive with files in it twice: 1.5 MiB pieces that come again — ExtendLastCommand consumes whole input
+    blocks, dozens in a row (k_tile.h: tiles without a command and without pending literals)."""
+    text = bytes(G.enwik_text(9 << 20, seed=21))
+    piece = text[1 << 20:(5 << 19)]
+    data = text[:6 << 20] + piece + text[6 << 20:7 << 20] + piece + piece[:900000] + text[7 << 20:]
+    for lgwin in (22, 20):
+        got, _ = one_shot(amd, data, lgwin)
+        want, _ = one_shot(stock, data, lgwin)
+        assert got == want
+
+
 def test_plain_chain_copy_to_the_block_end(amd, stock):
     """tools/fuzz_stream_sim.py seed 15 (a copy of the chain's fast path that runs to its block's end: the three
     positions the next block's stitch stores were marked unstored) through the paths a stream of that size takes:

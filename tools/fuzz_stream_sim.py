@@ -22,6 +22,8 @@ def make(seed):
         kind = 5             # (seeds below 4000 keep what they generated when tests/test_sim_stream.py pinned them)
     if seed >= 7000 and seed % 4 == 1:
         kind = 6
+    if seed >= 10000 and seed % 4 == 2:
+        kind = 7
     n = int(rng.integers(3 << 16, (14 << 16) if lgwin == 17 else (20 << 16)))
     if kind == 0:
         data = bytes(gen_inputs.enwik_text(n, seed=seed))
@@ -48,6 +50,20 @@ def make(seed):
             if a - d >= 0 and b + w <= n:
                 buf[a:b + w] = buf[a - d:b + w - d]
         data = buf.tobytes()
+    elif kind == 7:
+        # pieces of 70 ... 300 kB that come again (duplicate files in an archive): copies longer than a block
+        t = bytes(gen_inputs.enwik_text(n, seed=seed))
+        parts, have = [], 0
+        while have < n:
+            w = int(rng.integers(20000, 200000))
+            a = int(rng.integers(0, max(1, n - w)))
+            parts.append(t[a:a + w])
+            have += w
+            if parts and rng.integers(0, 2) == 0:
+                k = int(rng.integers(0, len(parts)))
+                parts.append(parts[k])
+                have += len(parts[k])
+        data = b"".join(parts)[:n]
     elif kind == 6:
         # text with stretches of random bytes: meta-blocks stored raw, the distance cache rolled back behind them,
         # tiles without a command
