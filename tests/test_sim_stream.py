@@ -120,7 +120,7 @@ def test_the_dictionary_gate_closes_in_a_later_block(sim, ref, seed, n):
     _same(sim, ref, data[:n], lgwin)
 
 
-@pytest.mark.parametrize("seed", range(300, 304))
+@pytest.mark.parametrize("seed", [300, 301, 302, 303, 10000, 10001, 10002])
 def test_fuzz_slice(sim, ref, seed):
     data, lgwin, kind = fuzz_stream_sim.make(seed)
     data = data[:400000]
