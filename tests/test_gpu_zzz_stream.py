@@ -108,6 +108,28 @@ def test_mixed_data_and_raw_meta_blocks(amd, stock):
         assert got == want
 
 
+def test_reference_cli_on_a_big_file(tmp_path):
+    """`brotli -q 5 -w 22 file` — the reference's CLI, unmodified, linked against our library — on a 20 MiB file: the
+    CLI announces the file's size (BROTLI_PARAM_SIZE_HINT) and feeds it piece by piece; the library holds the pieces
+    until FINISH and the stream takes the tiled path.  Same bytes as the CLI linked against the reference library."""
+    import subprocess
+    cli, cli_ref = (os.path.join(ROOT, "oracle", "_ref", n) for n in ("brotli_cli_amd", "brotli_cli_ref"))
+    if not (os.path.exists(cli) and os.path.exists(cli_ref)):
+        pytest.skip("oracle/_ref/brotli_cli_amd / brotli_cli_ref not built")
+    dropin = os.path.join(LIBDIR, "dropin")
+    os.makedirs(dropin, exist_ok=True)
+    for name, target in (("libbrotlienc.so.1", "../libbrotlienc_amd.so"), ("libbrotli_amd_hip.so", "../libbrotli_amd_hip.so")):
+        p = os.path.join(dropin, name)
+        if not os.path.lexists(p):
+            os.symlink(target, p)
+    env = dict(os.environ, LD_LIBRARY_PATH=dropin + ":" + os.environ.get("LD_LIBRARY_PATH", ""))
+    src = tmp_path / "big.txt"
+    src.write_bytes(bytes(G.enwik_text(20 << 20, seed=77)))
+    got = subprocess.run([cli, "-q", "5", "-w", "22", "-c", str(src)], capture_output=True, env=env, check=True).stdout
+    want = subprocess.run([cli_ref, "-q", "5", "-w", "22", "-c", str(src)], capture_output=True, check=True).stdout
+    assert got == want
+
+
 def test_1gib_stock_call(amd, stock):
     """BrotliEncoderCompress(5, 22) of 1 GiB with no vendor setting, byte-identical to the
     reference's (sha256), timed from the host buffer to the host buffer (PCIe both ways included); the second call

@@ -161,5 +161,13 @@ def test_stock_call_through_the_boundary(ref, monkeypatch):
     got, fin = drive(L, text, [(100000, 0), (100001, 0), (len(text) - 200001, 2)], params=((2, 17),))
     assert fin and bytes(got) == ref.compress(text, 5, 17)
     monkeypatch.delenv("BROTLI_AMD_FEED_KB")
+    # ... and without any vendor setting when the caller announced the size (BROTLI_PARAM_SIZE_HINT = 5: what the CLI
+    # does for a file), next to the reference library driven the same way
+    from test_gpu_abi import _bind as bind2
+    stock = bind2(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
+    ops = [(65536, 0)] * 3 + [(len(text) - 3 * 65536, 2)]
+    got, fin = drive(L, text, ops, params=((2, 17), (5, len(text))))
+    want, fin2 = drive(stock, text, ops, params=((2, 17), (5, len(text))))
+    assert fin and fin2 and bytes(got) == bytes(want)
     monkeypatch.setenv("BROTLI_AMD_STREAM_TILES", "0")
     assert call(text[:200000], 17) == ref.compress(text[:200000], 5, 17)
