@@ -712,10 +712,24 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
   if (p->flags & BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT) plan.J.flags |= JOB_FLAG_NO_LITCTX;
   if (p->flags & BROTLI_AMD_FLAG_NO_HEADER) plan.J.flags |= JOB_FLAG_NO_HEADER;
   const uint32_t ntiles = (uint32_t)plan.tiles.size(), nchunks = plan.J.nchunks, mcap = plan.mcap;
-  if (!ensure_log2(c, plan.J.log2_lut_size)) return false;
-  if (!ensure_ws(c, plan.ws_bytes, 1)) return false;
-  if (!ensure_tiles(c, ntiles)) return false;
   {
+    // ≈ 85 bytes of device memory per input byte (index chunks with their look-back, two command slots per tile,
+    // the meta-blocks' workspaces): a stream that does not fit beside what else lives on the device takes the serial
+    // path, as it did before there were tiles — never an error of the stock call
+    size_t free_b = 0, total_b = 0;
+    const uint64_t need = plan.ws_bytes + (uint64_t)nchunks * region + (uint64_t)ntiles * (sizeof(TileDesc) + sizeof(TileRec));
+    uint64_t cached = c->ws_cap;
+    cached += (uint64_t)c->d_table_chunks.size() * c->chunk_shards * c->chunk_shard_bytes;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (uint64_t)free_b + cached - ((uint64_t)free_b + cached) / 16u) {
+      c->err = "tiled stream: not enough device memory";
+      *rc = BROTLI_AMD_SERIAL;
+      return true;
+    }
+  }
+  auto room = [&]() -> bool {
+    if (!ensure_log2(c, plan.J.log2_lut_size)) return false;
+    if (!ensure_ws(c, plan.ws_bytes, 1)) return false;
+    if (!ensure_tiles(c, ntiles)) return false;
     // the chunks' index regions: the allocations the shards' regions of a plan live in
     JobPlan cp;
     cp.J = plan.J;
@@ -723,6 +737,12 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     c->ix_region_bytes = region;
     if (!prepare_tables(c, &cp)) return false;
     plan.chunks = cp.shards;
+    return true;
+  };
+  if (!room()) {
+    (void)hipGetLastError();
+    *rc = BROTLI_AMD_SERIAL;
+    return true;
   }
   if (nchunks > c->chunk_cap) {
     if (c->d_chunks) HIP_OK(c, hipFree(c->d_chunks));
