@@ -8,7 +8,7 @@ import os
 import pytest
 
 import gen_inputs as G
-from test_gpu_zy_full_size import _reference, _threads
+from test_gpu_zy_full_size import ROOT, _reference, _threads
 
 pytestmark = pytest.mark.gpu
 
@@ -58,6 +58,25 @@ def test_tiles_and_plain_chain_agree_on_mixed_data(ctx, monkeypatch):
     assert tiled == plain
     ref = _reference(data, 5, 22, shard, min(len(data), 1 << 30), _threads())
     assert len(tiled) == ref["out_bytes"] and hashlib.sha256(tiled).hexdigest() == ref["sha256"]
+
+
+def test_english_shards_keep_the_dictionary_gate_open(ctx, monkeypatch):
+    """alice29.txt over and over (with synthetic text in between) in 1 MiB shards: behind the first tile of most shards
+    the static dictionary's gate is still open — the shard's other tiles start over with it taken as open (k_tile.h:
+    k_tile_restart, gate_walk) instead of the shard leaving the tiled path; where it closes on the way, the tile in
+    which it does is parsed from the exact counters."""
+    alice = open(os.path.join(ROOT, "tests", "golden", "alice29.txt"), "rb").read()
+    parts = []
+    for k in range(400):
+        parts.append(alice[(k * 7919) % 60000:])
+        if k % 3 == 0:
+            parts.append(bytes(G.enwik_text(90000, seed=500 + k)))
+    data = b"".join(parts)[:48 << 20]
+    shard = 1 << 20
+    comp, info = _encode(ctx, data, shard, 64, monkeypatch)
+    ref = _reference(data, 5, 22, shard, min(len(data), 1 << 30), _threads())
+    assert len(comp) == ref["out_bytes"] and hashlib.sha256(comp).hexdigest() == ref["sha256"]
+    assert info["tile_sweeps"] >= 1
 
 
 def test_lgwin_18_shards_of_a_window(ctx, monkeypatch):
