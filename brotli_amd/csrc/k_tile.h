@@ -137,16 +137,20 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
     if (t + 1u == D.ntiles) break;
     // what the next tile has to start from
     TileRec& n = R[t + 1u];
-    if (c.out_ncmds == 0u) why |= TILE_WHY_NO_CMD;          // (no command ExtendLastCommand could lengthen)
+    // (a tile without a command: literals pending at its end — nobody asks for the last command then — or a block that
+    //  ExtendLastCommand consumed whole, which hands on the command it was given, longer by what it added)
+    const bool hollow = c.out_ncmds == 0u && c.out_insert == 0u;
+    const uint32_t eff_copy_len = hollow ? c.in_copy_len + c.in_ext : c.out_copy_len;
+    const uint32_t eff_code = hollow ? c.in_code : c.out_code;
     if (!gate_open && c.out_gate == 0u) why |= TILE_WHY_GATE;   // (cannot happen: tile 0 open restarts the shard, a closed gate stays closed)
-    const bool same_cmd = c.out_insert != 0u || (n.in_copy_len == c.out_copy_len && n.in_code == c.out_code);
+    const bool same_cmd = c.out_insert != 0u || (n.in_copy_len == eff_copy_len && n.in_code == eff_code);
     const bool same = n.in_dc[0] == c.out_dc[0] && n.in_dc[1] == c.out_dc[1] && n.in_dc[2] == c.out_dc[2] &&
                       n.in_dc[3] == c.out_dc[3] && n.in_insert == c.out_insert && same_cmd;
     if (!same) {
       for (int i = 0; i < 4; ++i) n.in_dc[i] = c.out_dc[i];
       n.in_insert = c.out_insert;
-      n.in_copy_len = c.out_copy_len;
-      n.in_code = c.out_code;
+      n.in_copy_len = eff_copy_len;
+      n.in_code = eff_code;
       n.flags |= TILE_START_EVENT;
       ++starts;
     }
@@ -241,7 +245,13 @@ DEV void tile_finish(const JobParams& J, const ShardDesc& D, ShardState* S, uint
   const TileRec& r = R[tt];
   const Command* src = c_tile_slot(ws, D, J, r.buf, tt) + (tt == 0 ? 0u : 1u);
   const uint32_t n = r.out_ncmds;
-  const uint32_t ext = tt + 1u < D.ntiles ? R[tt + 1u].in_ext : 0u;
+  // what ExtendLastCommand added to the tile's last command at the next block — and at the blocks behind that one
+  // as long as it consumed them whole
+  uint32_t ext = 0;
+  for (uint32_t u = tt + 1u; u < D.ntiles; ++u) {
+    ext += R[u].in_ext;
+    if (!(R[u].out_ncmds == 0u && R[u].out_insert == 0u)) break;
+  }
   for (uint32_t i = lane; i < n; i += 64u) {
     Command c = src[i];
     if (c.cmd_prefix == CMD_RAW) {
