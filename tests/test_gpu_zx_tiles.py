@@ -71,7 +71,7 @@ def test_english_shards_keep_the_dictionary_gate_open(ctx, monkeypatch):
         parts.append(alice[(k * 7919) % 60000:])
         if k % 3 == 0:
             parts.append(bytes(G.enwik_text(90000, seed=500 + k)))
-    data = b"".join(parts)[:48 << 20]
+    data = b"".join(parts)[:24 << 20]
     shard = 1 << 20
     comp, info = _encode(ctx, data, shard, 64, monkeypatch)
     ref = _reference(data, 5, 22, shard, min(len(data), 1 << 30), _threads())
