@@ -334,9 +334,12 @@ DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + dev_mul24(13
 // Matches of up to 16 bytes are decided from LDS alone; longer ones compare on in the input.
 // Writes srt[] and res[].
 struct IxLds { const uint32_t* w0; const uint64_t* d; const uint64_t* d2; };
+// (STREAM: a chunk of a tiled stream — the window limit, the ring's end and the key table exist there only; a plain
+//  shard's instantiation carries none of it)
+template <bool STREAM>
 DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool act, uint32_t rank, uint32_t nsucc,
                    const IxLds& S, uint32_t li, uint32_t sidx, uint32_t* srt, uint64_t* res, uint32_t* kt = nullptr, uint32_t nkeys = 0) {
-  if (kt != nullptr && act) {
+  if (STREAM && kt != nullptr && act) {
     // a stream's chunk: the key run's place in srt[], and how much of it lies in the chunk's own part
     const uint32_t pp = e.w0 & 0xFFFFFFu;
     if (rank == 0u) { kt[SKT_RS * nkeys + e.w1] = sidx; kt[SKT_RL * nkeys + e.w1] = nsucc + 1u; }
@@ -346,7 +349,7 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
   const uint32_t P = p + g.base;                                // its position in the shard / stream
   // (a stream: what the 16-bit counter hides depends on the stores since the stream's start — k_tile.h finds those
   //  positions once the chunks before this one are parsed)
-  const bool danger = !g.stream && rank >= 65520u;
+  const bool danger = !STREAM && rank >= 65520u;
   const bool search = act && p >= g.own && ix_searchable(g, P);
   const uint32_t max_length = search ? ix_block_end(g, P) - P : 0u;
   const uint32_t maxb = umin(P, g.maxdist);                     // max_backward (backward_references_inc.h:56-57)
@@ -356,7 +359,7 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
   // longer than its match), so only a candidate whose match does reach over it makes the search order-dependent —
   // the chain's to do
   bool ringrisk = false;
-  const uint32_t rm = g.stream ? g.ring_mask : 0xFFFFFFFFu;
+  const uint32_t rm = STREAM ? g.ring_mask : 0xFFFFFFFFu;
   uint32_t best = 0, best_len = 0, best_dist = 0;               // exact candidates
   uint32_t longmask = 0;
 #if defined(IX_NOWIN)       // (timing experiments only: results are wrong)
@@ -372,7 +375,7 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
     const uint64_t x = S.d[li - j] ^ e.d;
     uint32_t l = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
     if (l < 4u) continue;                                       // first4 != current4
-    if (p - (qw & 0xFFFFFFu) > maxb) continue;                  // beyond the window (:239-241: it and everything older)
+    if (STREAM && p - (qw & 0xFFFFFFu) > maxb) continue;        // beyond the window (:239-241: it and everything older)
     if (l == 8u) {
       const uint64_t x2 = S.d2[li - j] ^ e.d2;
       l = x2 ? 8u + ((uint32_t)dev_ctz64(x2) >> 3) : 16u;
@@ -381,7 +384,7 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
 #endif
     }
     const uint32_t len = umin(l, max_length);
-    if ((((qw & 0xFFFFFFu) + g.base) & rm) + len > rm || (P & rm) + len > rm) ringrisk = true;
+    if (STREAM && ((((qw & 0xFFFFFFu) + g.base) & rm) + len > rm || (P & rm) + len > rm)) ringrisk = true;
     const uint32_t dist = p - (qw & 0xFFFFFFu);
     const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
     if (k > best) { best = k; best_len = len; best_dist = dist; }
@@ -426,7 +429,7 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
         const uint32_t dist = p - qp[u];
         {
           const uint32_t reach = (len == IX_CAP && max_length > IX_CAP) ? max_length : len;     // (a capped one: as far as it may go)
-          if (((qp[u] + g.base) & rm) + reach > rm || (P & rm) + reach > rm) ringrisk = true;
+          if (STREAM && (((qp[u] + g.base) & rm) + reach > rm || (P & rm) + reach > rm)) ringrisk = true;
         }
         const uint32_t k = (ix_score(len, dist) << 5) | (16u - jj[u]);
         if (len == IX_CAP && max_length > IX_CAP) {
@@ -550,7 +553,8 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       const uint32_t kl = e.w1 & lowmask;
       const uint32_t rank = act ? i - bins[kl] : 0u;
       const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
-      ix_window(g, data, e, act, rank, nsucc, S, act ? i : 0u, start + i, srt, res, kt, 1u << J.bucket_bits);
+      if (g.stream) ix_window<true>(g, data, e, act, rank, nsucc, S, act ? i : 0u, start + i, srt, res, kt, 1u << J.bucket_bits);
+      else ix_window<false>(g, data, e, act, rank, nsucc, S, act ? i : 0u, start + i, srt, res, nullptr, 0u);
     }
     wave_sync();
     return;
@@ -599,7 +603,8 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     const uint32_t kl = e.w1 & lowmask;
     const uint32_t rank = act ? i - bins[kl] : 0u;
     const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;
-    ix_window(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res, kt, 1u << J.bucket_bits);
+    if (g.stream) ix_window<true>(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res, kt, 1u << J.bucket_bits);
+    else ix_window<false>(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res, nullptr, 0u);
     wave_sync();
     if (lane >= 48) ix_lds_put(w0S, dS, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
     wave_sync();
