@@ -78,7 +78,7 @@ struct JobParams {
 #define JOB_FLAG_STREAMT 8192u // one unpartitioned stream longer than the window, parsed in tiles: the index is built per
                                //   chunk of 1 << chunk_log2 positions plus a look-back of the same size (ShardDesc::ix_*),
                                //   the chain works in stream positions, meta-block cuts are part of the tiles' join state
-#define JOB_FLAG_VIEWALL 16384u // (per launch, with JOB_FLAG_FORCE_SLOW) k_chain_tiles parses tiles again in a later pass (k_tile.h:
+#define JOB_FLAG_VIEWALL 16384u // (per launch) k_chain_tiles parses tiles again in a later pass (k_tile.h:
                                //   gate_walk): the bitmap holds what the other tiles left unstored — the events that told so
                                //   in the first pass are used up —, so every search is done exactly against it
 #define JOB_FLAG_SWEEP 2048u   // (per launch) k_chain replays the tiles' previous commands and parses again only where an

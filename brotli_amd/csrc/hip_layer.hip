@@ -587,7 +587,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
           // tiles the gate walk sent back (k_tile.h: the static dictionary's gate may close in them, or has closed in
           // front of them): parsed again from scratch, every search exact against the bitmap as it stands
           JobArgs l = a;
-          l.J.flags |= JOB_FLAG_VIEWALL | JOB_FLAG_FORCE_SLOW;
+          l.J.flags |= JOB_FLAG_VIEWALL;
           hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, l);
           hipLaunchKernelGGL(k_chain_tiles, cgrid, dim3(64), clds, c->stream, l);
           lap("tiles again");
@@ -852,7 +852,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     if (passes != 0 && tc[TILE_CNT_RESTART] != 0) {
       // tiles the gate walk sent back (k_tile.h): parsed again from scratch, every search exact
       JobArgs l = a;
-      l.J.flags |= JOB_FLAG_VIEWALL | JOB_FLAG_FORCE_SLOW;
+      l.J.flags |= JOB_FLAG_VIEWALL;
       l.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
       if (gpw != 4) l.J.flags |= gpw << JOB_FLAG_GROUPS_SHIFT;
       hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, l);

@@ -965,7 +965,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       g.lim_cmd_cap = tile_slot_cmds(J.tile_log2, (uint32_t)J.lgblock);
       const uint32_t oldbuf = sweep ? TR->buf : 1u;
       g.cmds = c_tile_slot(ws, D, J, oldbuf ^ 1u, tt);
-      if (!sweep && (J.flags & JOB_FLAG_VIEWALL) != 0) C.mode |= C_VIEW_ALL;
+      if (!sweep && (J.flags & JOB_FLAG_VIEWALL) != 0) { C.mode |= C_VIEW_ALL; force_slow = true; }     // (every search exact, as in a sweep)
       if (sweep) {
         C.mode |= C_VIEW_ALL;
         force_slow = true;

@@ -57,7 +57,7 @@ void run_parse_kernel(JobArgs a, int reverse, int round = 0) {
       a.counters[TILE_CNT_START] = a.counters[TILE_CNT_FLIPS] = a.counters[TILE_CNT_RESTART] = 0;
       if (rounds != 0) {       // tiles the gate walk sent back (k_tile.h): parsed again from scratch, every search exact
         JobArgs l = a;
-        l.J.flags |= JOB_FLAG_VIEWALL | JOB_FLAG_FORCE_SLOW;
+        l.J.flags |= JOB_FLAG_VIEWALL;
         run(k_tile_restart_clear, l, a.ntiles, 64, reverse);
         run(k_chain_tiles, l, (a.ntiles + gpw - 1) / gpw, 64, reverse);
       }
@@ -344,7 +344,7 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
     counters[TILE_CNT_START] = counters[TILE_CNT_FLIPS] = counters[TILE_CNT_RESTART] = 0;
     if (rounds != 0) {         // tiles the gate walk sent back (k_tile.h): parsed again from scratch, every search exact
       JobArgs l = a;
-      l.J.flags |= JOB_FLAG_VIEWALL | JOB_FLAG_FORCE_SLOW;
+      l.J.flags |= JOB_FLAG_VIEWALL;
       run(k_tile_restart_clear, l, a.ntiles, 64, reverse);
       run(k_chain_tiles, l, (a.ntiles + gpw - 1) / gpw, 64, reverse);
     }
