@@ -424,6 +424,57 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   return (long)nbytes;
 }
 
+// The workspace arithmetic of a tiled stream (plan_stream + stream_emit_mb) at sizes the simulator cannot run: a
+// stream of `len` bytes cut into meta-blocks at random tile boundaries (at least `min_tiles` tiles each, as many
+// meta-blocks as the plan allows at most) with the most commands a meta-block can have; every meta-block's literal /
+// symbol / scratch / work / output regions must lie inside the stream's regions and must not overlap its
+// neighbour's.  Returns 0, or the number of the first check that failed.
+long sim_stream_layout_check(uint64_t len, int lgwin, uint32_t seed) {
+  JobPlan plan;
+  if (!plan_stream(len, lgwin, 0, 2048, /*ix_in_ws=*/false, &plan)) return -2;
+  const JobParams& J = plan.J;
+  const ShardDesc& D = plan.shards[0];
+  const uint32_t nt = D.ntiles, mcap = plan.mcap;
+  std::vector<ShardDesc> md(mcap);
+  std::vector<ShardState> ms(mcap);
+  uint8_t* input = (uint8_t*)calloc(len + 64, 1);          // (stream_emit_mb reads the two bytes in front of a meta-block)
+  if (!input) return -3;
+  struct Free { uint8_t* p; ~Free() { free(p); } } guard{input};
+  // a meta-block holds at least max_literals bytes unless it is the last one (a cut needs that many literals, or
+  // twice as many commands' bytes, or the size limit): cut as early as that allows, sometimes later
+  const uint32_t min_tiles = (J.max_literals + (1u << J.tile_log2) - 1u) >> J.tile_log2;
+  uint32_t s = 0, m = 0, cmd_lo = 0, rng = seed * 2654435761u + 1u;
+  uint64_t end_prev[5] = {0, 0, 0, 0, 0};
+  while (s < nt) {
+    rng = rng * 1664525u + 1013904223u;
+    uint32_t e = s + (min_tiles ? min_tiles : 1u) - 1u + ((rng >> 20) % 3u == 0 ? (rng >> 8) % 40u : 0u);
+    const uint32_t max_tiles = J.max_metablock_size >> J.tile_log2;
+    if (e - s + 1u > max_tiles) e = s + max_tiles - 1u;
+    if (e >= nt - 1u) e = nt - 1u;
+    if (m >= mcap) return 1;
+    const uint64_t start = (uint64_t)s << J.tile_log2, end = e + 1u == nt ? len : (uint64_t)(e + 1u) << J.tile_log2, bytes = end - start;
+    const uint32_t ncmds = (uint32_t)(bytes / 2 + (e - s + 1u) + 1u);
+    stream_emit_mb(J, D, input, md.data(), ms.data(), m, s, e, cmd_lo, ncmds, (uint32_t)bytes, e + 1u == nt);
+    const ShardDesc& X = md[m];
+    if (X.len != bytes || ms[m].mb_start != start) return 2;
+    const uint64_t lo[5] = {X.lits_off, X.dsym_off, X.mb_off, X.scratch_off, X.out_off};
+    const uint64_t need[5] = {(bytes + 8) * 2, (uint64_t)ncmds * 2, mb_work_bytes(bytes), (bytes / 256 + 64) * 8 + (2 * bytes + 64) * 4, X.out_cap};
+    const uint64_t rlo[5] = {D.lits_off, D.dsym_off, D.mb_off, D.scratch_off, D.out_off};
+    const uint64_t rhi[5] = {D.dsym_off, D.mb_off, D.scratch_off, D.out_off, D.cmds2_off};
+    if (X.out_cap < 2 * bytes + 536) return 3;
+    for (int k = 0; k < 5; ++k) {
+      if (lo[k] < rlo[k] || lo[k] + need[k] > rhi[k]) return 10 + k;
+      if (lo[k] < end_prev[k]) return 20 + k;
+      end_prev[k] = lo[k] + need[k];
+    }
+    if (X.cmds_off < D.cmds_off || X.cmds_off + (uint64_t)ncmds * 16 > D.lits_off) return 4;
+    cmd_lo += ncmds;
+    s = e + 1u;
+    ++m;
+  }
+  return 0;
+}
+
 // Quality 1 on the simulator: the k_fast_* pipeline for one run of calls ending in
 // FINISH (is_last) or at a byte-pending point.  Returns the number of output bits
 // (bytes = (bits + 7) / 8 are written), negative on error.

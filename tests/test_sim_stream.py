@@ -31,6 +31,17 @@ def _same(sim, ref, data, lgwin, **kw):
     return info
 
 
+@pytest.mark.parametrize("n,lgwin", [(1 << 30, 22), ((1 << 31) - 1, 22), (1 << 30, 17), (123456789, 19), (5 << 20, 22)])
+def test_workspace_arithmetic_at_sizes_the_simulator_cannot_run(sim, n, lgwin):
+    """plan_stream + stream_emit_mb (the meta-blocks' workspace, carved out of stream-sized regions by position on the
+    device) for a GiB and for the largest stream the path takes: every meta-block's regions inside the stream's,
+    none overlapping its neighbour's, for random cut patterns with the most commands a meta-block can hold."""
+    sim.L.sim_stream_layout_check.restype = C.c_long
+    sim.L.sim_stream_layout_check.argtypes = [C.c_uint64, C.c_int, C.c_uint32]
+    for seed in range(6):
+        assert sim.L.sim_stream_layout_check(n, lgwin, seed) == 0
+
+
 @pytest.mark.parametrize("n,lgwin,seed", [(250000, 17, 1), (131073, 17, 7), (430000, 17, 2)])
 def test_text_streams(sim, ref, n, lgwin, seed):
     """Two tiles and a byte; inside one lap of the ring; 1.6 laps (stale bytes behind a block end, candidates at
