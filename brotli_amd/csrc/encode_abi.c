@@ -374,6 +374,7 @@ static int wants_stream_tiles(const BrotliEncoderState* s, int op) {
   const char* e = getenv("BROTLI_AMD_STREAM_TILES");
   if (e && atoi(e) == 0) return 0;
   return s->quality == 5 && s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream && s->ndicts == 0 &&
+         s->stream_offset == 0 &&
          s->lgwin >= 17 && s->lgwin <= 22 && s->in_len > ((size_t)1 << s->lgwin) - 16 && s->in_len < ((size_t)1 << 31);
 }
 
@@ -485,7 +486,7 @@ static size_t feed_threshold(const BrotliEncoderState* s) {
   const char* e = getenv("BROTLI_AMD_FEED_KB");       /* default: 256 MiB of shards / 4 MiB of one stream */
   size_t kb = e ? (size_t)strtoull(e, NULL, 10) : (s->shard_bytes ? (256u << 10) : (4u << 10));
   if (!e && s->shard_bytes == 0 && s->quality == 5 && s->lgwin >= 17 && s->lgwin <= 22 && s->ndicts == 0 &&
-      !s->stream && s->submitted == 0 && s->size_hint != 0) {
+      !s->stream && s->submitted == 0 && s->size_hint != 0 && s->stream_offset == 0) {
     /* One quality-5 stream whose size was announced (BROTLI_PARAM_SIZE_HINT: the CLI does that for files): the input
        is held until FINISH, so that the whole stream takes the tiled stream path (submit / wants_stream_tiles) instead
        of going to the serial device stream 4 MiB at a time.  BROTLI_AMD_HOLD_MB bounds what is held (default 1024;

@@ -180,5 +180,12 @@ def test_stock_call_through_the_boundary(ref, monkeypatch):
     got, fin = drive(L, text, ops, params=((2, 17), (5, len(text))))
     want, fin2 = drive(stock, text, ops, params=((2, 17), (5, len(text))))
     assert fin and fin2 and bytes(got) == bytes(want)
+    # what the tiled path does not take stays where it was: a stream offset (BROTLI_PARAM_STREAM_OFFSET = 9), an empty
+    # FLUSH in front (the header gone: BROTLI_AMD_FLAG_NO_HEADER), literal context modelling switched off (4)
+    for ops, params in (([(len(text), 2)], ((2, 17), (9, 70000))), ([(0, 1), (len(text), 2)], ((2, 17),)),
+                        ([(len(text), 2)], ((2, 17), (4, 1)))):
+        got, fin = drive(L, text, ops, params=params)
+        want, fin2 = drive(stock, text, ops, params=params)
+        assert fin and fin2 and bytes(got) == bytes(want)
     monkeypatch.setenv("BROTLI_AMD_STREAM_TILES", "0")
     assert call(text[:200000], 17) == ref.compress(text[:200000], 5, 17)
