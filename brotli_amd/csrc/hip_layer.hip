@@ -788,9 +788,17 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
   a.moff = c->d_moff;
   a.sout = d_out;
   a.mcap = mcap;
-  const bool tlog = getenv("BROTLI_AMD_TILE_LOG") != nullptr;
+  const char* tlog_env = getenv("BROTLI_AMD_TILE_LOG");
+  const bool tlog = tlog_env != nullptr;
+  const bool tlog_each = tlog && atoi(tlog_env) >= 2;     // 2: synchronize and report behind every launch (names a faulting kernel)
+  double t_prev = 0;
+  auto each = [&](const char* what) {
+    if (!tlog_each) return;
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    fprintf(stderr, "    behind %-22s %s\n", what, e == hipSuccess ? "ok" : hipGetErrorString(e));
+    fflush(stderr);
+  };
   auto lap = [&](const char* what) {
-    static double t_prev = 0;
     if (!tlog) return;
     (void)hipStreamSynchronize(c->stream);
     timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
@@ -799,35 +807,35 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     t_prev = now;
   };
   lap(nullptr);
-  hipLaunchKernelGGL(k_init, dim3(1), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_init, dim3(1), dim3(256), 0, c->stream, a); each("k_init");
   HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
   {
     JobArgs x = a;                          // the index kernels see the chunks as their shards
     x.shards = c->d_chunks;
     x.nshards = nchunks;
-    hipLaunchKernelGGL(k_ix_count, dim3(nchunks * plan.J.ix_slices), dim3(64), 0, c->stream, x);
-    hipLaunchKernelGGL(k_ix_scan, dim3(nchunks), dim3(64), 0, c->stream, x);
-    hipLaunchKernelGGL(k_ix_scatter, dim3(nchunks * plan.J.ix_slices), dim3(64), (IX_CHUNK + (3u << plan.J.ix_nb_log2)) * 4u, c->stream, x);
+    hipLaunchKernelGGL(k_ix_count, dim3(nchunks * plan.J.ix_slices), dim3(64), 0, c->stream, x); each("k_ix_count");
+    hipLaunchKernelGGL(k_ix_scan, dim3(nchunks), dim3(64), 0, c->stream, x); each("k_ix_scan");
+    hipLaunchKernelGGL(k_ix_scatter, dim3(nchunks * plan.J.ix_slices), dim3(64), (IX_CHUNK + (3u << plan.J.ix_nb_log2)) * 4u, c->stream, x); each("k_ix_scatter");
     HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
-    hipLaunchKernelGGL(k_ix_bucket, dim3(((nchunks + 7u) / 8u) * 8u * ((1u << plan.J.ix_nb_log2) / plan.J.ix_bpw)), dim3(64), 0, c->stream, x);
+    hipLaunchKernelGGL(k_ix_bucket, dim3(((nchunks + 7u) / 8u) * 8u * ((1u << plan.J.ix_nb_log2) / plan.J.ix_bpw)), dim3(64), 0, c->stream, x); each("k_ix_bucket");
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
   }
   lap("index");
   const uint32_t nkg = (1u << plan.J.bucket_bits) / 64u;
   const dim3 egrid(nchunks * plan.J.ix_slices);
-  hipLaunchKernelGGL(k_stream_kprefix, dim3(nkg), dim3(64), 0, c->stream, a);
-  hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(k_stream_kprefix, dim3(nkg), dim3(64), 0, c->stream, a); each("k_stream_kprefix");
+  hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, a); each("k_stream_zones");
   HIP_OK(c, hipEventRecord(c->ev[2], c->stream));
   const uint32_t gpw = ntiles >= 1024 ? 4u : ntiles >= 512 ? 2u : 1u;
   {
     JobArgs f = a;
     f.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
     if (gpw != 4) f.J.flags |= gpw << JOB_FLAG_GROUPS_SHIFT;
-    hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f);
+    hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f); each("k_chain_tiles");
     lap("first parse");
-    hipLaunchKernelGGL(k_tile_restart, dim3(1), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f);
+    hipLaunchKernelGGL(k_tile_restart, dim3(1), dim3(64), 0, c->stream, a); each("k_tile_restart");
+    hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, a); each("k_tile_restart_clear");
+    hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f); each("k_chain_tiles");
   }
   lap("second parse");
   uint32_t tc[16], sweeps = 0, reasons = 0, nmb = 0, passes = 0;
@@ -855,22 +863,22 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
       l.J.flags |= JOB_FLAG_VIEWALL;
       l.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
       if (gpw != 4) l.J.flags |= gpw << JOB_FLAG_GROUPS_SHIFT;
-      hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, l);
-      hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, l);
+      hipLaunchKernelGGL(k_tile_restart_clear, dim3(ntiles), dim3(64), 0, c->stream, l); each("k_tile_restart_clear");
+      hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, l); each("k_chain_tiles");
       lap("tiles again");
     }
     {
       JobArgs e = a;
       if (passes != 0) e.J.flags |= JOB_FLAG_SWEEP;
-      hipLaunchKernelGGL(k_stream_events, egrid, dim3(64), 0, c->stream, e);
+      hipLaunchKernelGGL(k_stream_events, egrid, dim3(64), 0, c->stream, e); each("k_stream_events");
     }
-    hipLaunchKernelGGL(k_stream_skclear, egrid, dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_stream_skcount, egrid, dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_stream_kprefix, dim3(nkg), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_stream_skclear, egrid, dim3(64), 0, c->stream, a); each("k_stream_skclear");
+    hipLaunchKernelGGL(k_stream_skcount, egrid, dim3(64), 0, c->stream, a); each("k_stream_skcount");
+    hipLaunchKernelGGL(k_stream_kprefix, dim3(nkg), dim3(64), 0, c->stream, a); each("k_stream_kprefix");
+    hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, a); each("k_stream_zones");
     a.aux = 0;
-    hipLaunchKernelGGL(k_stream_cuts, dim3(1), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_stream_verify, dim3((ntiles + 63u) / 64u), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_stream_cuts, dim3(1), dim3(64), 0, c->stream, a); each("k_stream_cuts");
+    hipLaunchKernelGGL(k_stream_verify, dim3((ntiles + 63u) / 64u), dim3(64), 0, c->stream, a); each("k_stream_verify");
     HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(c, hipStreamSynchronize(c->stream));
     lap("events..verify");
@@ -889,7 +897,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     if (const char* e = getenv("BROTLI_AMD_SWEEP_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) sg = (uint32_t)v; }
     b.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
     if (sg != 4) b.J.flags |= sg << JOB_FLAG_GROUPS_SHIFT;
-    hipLaunchKernelGGL(k_chain_sweep, dim3((ntiles + sg - 1) / sg), dim3(64), sg * C_GROUP_LDS_WORDS * 4u, c->stream, b);
+    hipLaunchKernelGGL(k_chain_sweep, dim3((ntiles + sg - 1) / sg), dim3(64), sg * C_GROUP_LDS_WORDS * 4u, c->stream, b); each("k_chain_sweep");
     ++sweeps;
     lap("sweep");
   }
@@ -899,35 +907,47 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     return true;
   }
   a.aux = 1;
-  hipLaunchKernelGGL(k_stream_cuts, dim3(1), dim3(64), 0, c->stream, a);
-  hipLaunchKernelGGL(k_stream_finish, dim3(ntiles), dim3(64), 0, c->stream, a);
-  HIP_OK(c, hipEventRecord(c->ev[3], c->stream));
-  lap("cuts+finish");
-  {
-    JobArgs m = a;                          // build / store see the meta-blocks as their shards
-    m.shards = c->d_mdesc;
-    m.states = c->d_mstate;
-    m.nshards = mcap;
-    hipLaunchKernelGGL(k_build, dim3(mcap), dim3(64), 0, c->stream, m);
-    HIP_OK(c, hipEventRecord(c->ev[4], c->stream));
-    hipLaunchKernelGGL(k_store, dim3(mcap), dim3(64), 0, c->stream, m);
-    HIP_OK(c, hipEventRecord(c->ev[5], c->stream));
-  }
-  lap("build+store");
-  hipLaunchKernelGGL(k_stream_scan, dim3(1), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(k_stream_cuts, dim3(1), dim3(64), 0, c->stream, a); each("k_stream_cuts");
+  // (the finalize cut can still take the stream off the tiled path — more meta-blocks than planned, a tile that went
+  //  bad: nothing behind it may then read the descriptors it did not write)
   HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
   HIP_OK(c, hipStreamSynchronize(c->stream));
-  if (tc[1]) return fail(c, "%u meta-block(s) reported a device fault", tc[1]);
   nmb = tc[TILE_CNT_NMB];
-  if (tc[TILE_CNT_RAW] != 0) return fail(c, "a meta-block of the stream was not built (device fault)");
   if (tc[TILE_CNT_BAD] != 0 || nmb == 0 || nmb > mcap) {
     if (!reasons_of()) return false;
     if (info) info->reserved = sweeps | (nmb << 8) | (reasons << 16);
     *rc = BROTLI_AMD_SERIAL;
     return true;
   }
+  hipLaunchKernelGGL(k_stream_finish, dim3(ntiles), dim3(64), 0, c->stream, a); each("k_stream_finish");
+  HIP_OK(c, hipEventRecord(c->ev[3], c->stream));
+  lap("cuts+finish");
+  {
+    JobArgs m = a;                          // build / store see the meta-blocks as their shards
+    m.shards = c->d_mdesc;
+    m.states = c->d_mstate;
+    m.nshards = nmb;
+    hipLaunchKernelGGL(k_build, dim3(nmb), dim3(64), 0, c->stream, m); each("k_build");
+    HIP_OK(c, hipEventRecord(c->ev[4], c->stream));
+    hipLaunchKernelGGL(k_store, dim3(nmb), dim3(64), 0, c->stream, m); each("k_store");
+    HIP_OK(c, hipEventRecord(c->ev[5], c->stream));
+  }
+  lap("build+store");
+  hipLaunchKernelGGL(k_stream_scan, dim3(1), dim3(64), 0, c->stream, a); each("k_stream_scan");
+  HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
+  HIP_OK(c, hipStreamSynchronize(c->stream));
+  // a meta-block that k_build / k_store gave up on, or one that was not built: the serial device stream encodes the
+  // input instead (the stock call must not fail on data the library handled before there were tiles)
+  if (tc[1] != 0 || tc[TILE_CNT_RAW] != 0 || tc[TILE_CNT_BAD] != 0 || tc[TILE_CNT_NMB] != nmb) {
+    if (!reasons_of()) return false;
+    if (tlog) fprintf(stderr, "stream: off the tiled path behind build / store (errors %u, not built %u, bad %u)\n", tc[1], tc[TILE_CNT_RAW], tc[TILE_CNT_BAD]);
+    if (info) info->reserved = sweeps | (nmb << 8) | ((reasons | (TILE_WHY_ERROR >> 8)) << 16);
+    c->err = "tiled stream: a meta-block was not built";
+    *rc = BROTLI_AMD_SERIAL;
+    return true;
+  }
   HIP_OK(c, hipMemsetAsync(c->d_counters + TILE_CNT_RBCHG, 0, sizeof(uint32_t), c->stream));
-  hipLaunchKernelGGL(k_stream_rollback, dim3(1), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL(k_stream_rollback, dim3(1), dim3(64), 0, c->stream, a); each("k_stream_rollback");
   HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   if (tlog) fprintf(stderr, "stream: %u meta-blocks, tiles with a new roll-back behind a raw meta-block: %u\n", nmb, tc[TILE_CNT_RBCHG]);
@@ -939,7 +959,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
   const uint64_t total = (total_bits + 7) / 8;
   *out_size = total;
   if (total + 8 > out_cap) { c->err = "output capacity too small"; *rc = BROTLI_AMD_OVERFLOW; return true; }
-  hipLaunchKernelGGL(k_stream_place, dim3(nmb * STREAM_PLACE_PARTS), dim3(256), 0, c->stream, a);
+  hipLaunchKernelGGL(k_stream_place, dim3(nmb * STREAM_PLACE_PARTS), dim3(256), 0, c->stream, a); each("k_stream_place");
   HIP_OK(c, hipEventRecord(c->ev[7], c->stream));
   HIP_OK(c, hipStreamSynchronize(c->stream));
   HIP_OK(c, hipGetLastError());

@@ -130,25 +130,36 @@ def test_reference_cli_on_a_big_file(tmp_path):
     assert got == want
 
 
-def test_1gib_stock_call(amd, stock):
-    """BrotliEncoderCompress(5, 22) of 1 GiB with no vendor setting, byte-identical to the
+def run_isolated(args, timeout_s, env=None):
+    """tools/stock_call.py in a child process with a time limit: whatever a kernel does at that size (a GPU memory
+    fault ends the process with SIGABRT), this suite goes on and the test that asked reports it."""
+    import subprocess
+    e = dict(os.environ)
+    e.pop("BROTLI_AMD_SHARD_KB", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stock_call.py")] + [str(a) for a in args],
+                       capture_output=True, text=True, timeout=timeout_s, env=e)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, lines, r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("mib", [96, 320])
+def test_stock_call_between_the_sizes(mib):
+    """Sizes between the 48 MiB case above and the 1 GiB call (four chain groups per wave from 64 MiB on, hundreds of index
+    chunks, dozens of meta-blocks), each in a process of its own, next to the reference library."""
+    rc, lines, err = run_isolated([mib, 22, "text", 1, "--ref"], 600)
+    assert rc == 0 and lines and lines[-1].get("bytes_equal_reference") is True, (rc, lines[-2:], err)
+
+
+def test_1gib_stock_call():
+    """The metric's own call: BrotliEncoderCompress(5, 22) of 1 GiB with no vendor setting, byte-identical to the
     reference's (sha256), timed from the host buffer to the host buffer (PCIe both ways included); the second call
-    has the context's allocations behind it (bench.py reports the same call as config.stock_call_no_plan.whole_input)."""
-    data = bytes(G.enwik_text(1 << 30))
-    got, t1 = one_shot(amd, data, 22)
-    sha = hashlib.sha256(got).hexdigest()
-    n1 = len(got)
-    del got
-    got2, t2 = one_shot(amd, data, 22)
-    assert hashlib.sha256(got2).hexdigest() == sha
-    del got2
-    want, tr = one_shot(stock, data, 22)
-    rec = {"bytes_in": len(data), "bytes_out": n1, "seconds_first_call": round(t1, 3), "seconds_second_call": round(t2, 3),
-           "MB_per_s_second_call": round(len(data) / t2 / 1e6, 1), "reference_seconds_one_core": round(tr, 3),
-           "sha256_equal": hashlib.sha256(want).hexdigest() == sha}
+    has the context's allocations behind it (bench.py reports the same call as config.stock_call_no_plan.whole_input).
+    In a child process: see run_isolated."""
+    rc, lines, err = run_isolated([1024, 22, "text", 2, "--ref"], 900)
+    rec = lines[-1] if lines else {}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "stock_call_1GiB.json"), "w") as f:
-        json.dump(rec, f)
+        json.dump({"rc": rc, "lines": lines, "stderr_tail": err[-500:]}, f)
     print(json.dumps(rec))
-    assert rec["sha256_equal"]
-    assert len(want) == n1
+    assert rc == 0 and rec.get("bytes_equal_reference") is True, (rc, lines[-2:], err)
