@@ -47,9 +47,6 @@ struct BrotliAmdCtx {
   uint64_t shard_cap = 0;
   // batches of an indexed job: the index kernels of batch b + 1 run beside the chain of batch b and the
   // build / store of batch b - 1 (run_batches)
-  hipStream_t s_index = nullptr;
-  std::vector<hipStream_t> s_batch;
-  std::vector<hipEvent_t> ev_batch;   // five per batch: index start / bucket start / index end / chain end / store end
   TileDesc* d_tiles = nullptr;      // tiled jobs (JOB_FLAG_TILED): the tile table and the tiles' records
   TileRec* d_trecs = nullptr;
   uint64_t tile_cap = 0;
@@ -385,71 +382,6 @@ struct DeviceScope {
 
 enum { STAGE_PARSE = 1, STAGE_BUILD = 2, STAGE_STORE = 4, STAGE_ALL = 7 };
 
-// First round of a plain indexed job (quality 5, shards of at most a chain tile) in B batches of whole shards: the
-// index kernels of the batches run one after the other on a stream of their own, the chain + command encoding +
-// build + store of a batch on the batch's stream as soon as its index is there.  The chain holds two waves per SIMD
-// for 28 ms whatever the number of shards (a dependent chain per shard), the index kernels are bound by their LDS and
-// their gathers: side by side they fill what the other leaves idle.  Kernels see a batch as a job of its own (the
-// per-shard arrays start at the batch's first shard).  Fills the per-stage times as the sums over the batches of the
-// time their streams were busy with the stage (they overlap: the sum exceeds the wall time).
-bool run_batches(BrotliAmdCtx* c, const JobPlan& plan, const JobArgs& a, uint32_t nbatch, uint32_t gpw,
-                 float* ms_index, float* ms_ixb, float* ms_parse, float* ms_build_store) {
-  const uint32_t nshards = a.nshards;
-  if (!c->s_index) HIP_OK(c, hipStreamCreateWithFlags(&c->s_index, hipStreamNonBlocking));
-  while (c->s_batch.size() < nbatch) {
-    hipStream_t st = nullptr;
-    HIP_OK(c, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    c->s_batch.push_back(st);
-  }
-  while (c->ev_batch.size() < 5u * nbatch + 1u) {
-    hipEvent_t e = nullptr;
-    HIP_OK(c, hipEventCreate(&e));
-    c->ev_batch.push_back(e);
-  }
-  hipEvent_t ev_go = c->ev_batch[5u * nbatch];
-  HIP_OK(c, hipEventRecord(ev_go, c->stream));                 // descriptors, k_init and the counters are in place
-  HIP_OK(c, hipStreamWaitEvent(c->s_index, ev_go, 0));
-  const uint32_t per = (nshards + nbatch - 1) / nbatch;
-  for (uint32_t b = 0; b < nbatch; ++b) {
-    const uint32_t s0 = b * per, cnt = s0 < nshards ? (nshards - s0 < per ? nshards - s0 : per) : 0u;
-    if (cnt == 0) continue;
-    JobArgs ab = a;
-    ab.shards = a.shards + s0;
-    ab.states = a.states + s0;
-    ab.nshards = cnt;
-    hipEvent_t* e = &c->ev_batch[5u * b];
-    HIP_OK(c, hipEventRecord(e[0], c->s_index));
-    hipLaunchKernelGGL(k_ix_count, dim3(cnt * plan.J.ix_slices), dim3(64), 0, c->s_index, ab);
-    hipLaunchKernelGGL(k_ix_scan, dim3(cnt), dim3(64), 0, c->s_index, ab);
-    hipLaunchKernelGGL(k_ix_scatter, dim3(cnt * plan.J.ix_slices), dim3(64), (IX_CHUNK + (3u << plan.J.ix_nb_log2)) * 4u, c->s_index, ab);
-    HIP_OK(c, hipEventRecord(e[1], c->s_index));
-    hipLaunchKernelGGL(k_ix_bucket, dim3(((cnt + 7u) / 8u) * 8u * ((1u << plan.J.ix_nb_log2) / plan.J.ix_bpw)), dim3(64), 0, c->s_index, ab);
-    HIP_OK(c, hipEventRecord(e[2], c->s_index));
-    hipStream_t sb = c->s_batch[b];
-    HIP_OK(c, hipStreamWaitEvent(sb, e[2], 0));
-    hipLaunchKernelGGL(k_chain, dim3((cnt + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, sb, ab);
-    hipLaunchKernelGGL(k_cmd_encode, dim3(cnt * CE_SPLIT), dim3(64), 0, sb, ab);
-    HIP_OK(c, hipEventRecord(e[3], sb));
-    hipLaunchKernelGGL(k_build, dim3(cnt), dim3(64), 0, sb, ab);
-    hipLaunchKernelGGL(k_store, dim3(cnt), dim3(64), 0, sb, ab);
-    HIP_OK(c, hipEventRecord(e[4], sb));
-    HIP_OK(c, hipStreamWaitEvent(c->stream, e[4], 0));          // the context stream goes on when every batch is through
-  }
-  HIP_OK(c, hipStreamSynchronize(c->stream));
-  HIP_OK(c, hipGetLastError());
-  *ms_index = *ms_ixb = *ms_parse = *ms_build_store = 0;
-  for (uint32_t b = 0; b < nbatch; ++b) {
-    if (b * per >= nshards) continue;
-    hipEvent_t* e = &c->ev_batch[5u * b];
-    float t;
-    HIP_OK(c, hipEventElapsedTime(&t, e[0], e[2])); *ms_index += t;
-    HIP_OK(c, hipEventElapsedTime(&t, e[1], e[2])); *ms_ixb += t;
-    HIP_OK(c, hipEventElapsedTime(&t, e[2], e[3])); *ms_parse += t;     // (from "index there" on: includes waiting for the SIMDs)
-    HIP_OK(c, hipEventElapsedTime(&t, e[3], e[4])); *ms_build_store += t;
-  }
-  return true;
-}
-
 // Runs the job's rounds on the context stream.  On return (synchronised) the
 // shard states describe the outputs sitting in the workspace.
 bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
@@ -496,22 +428,10 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
   hipLaunchKernelGGL(k_init, dim3(nshards * ibs), dim3(256), 0, c->stream, a);
   HIP_OK(c, hipEventRecord(c->ev[1], c->stream));
   float ms_index = 0;
-  // A plain indexed job with enough shards to keep every batch's chain busy can run its first round in batches
-  // (run_batches; BROTLI_AMD_BATCHES = number of batches).  Measured and NOT the default (profiles/r03_h_batches.txt,
-  // 1 GiB text in 128 KiB shards): 1 batch 95.8 ms per step, 2: 107.8, 3: 101.7, 4: 121.8, 8: 144.5 — the chain's waves
-  // and the index kernels' waves take each other's LDS and issue slots, both get slower than what the overlap saves.
-  uint32_t nbatch = 1;
-  if (const char* e = getenv("BROTLI_AMD_BATCHES")) { const int v = atoi(e); if (v >= 1 && v <= 16) nbatch = (uint32_t)v; }
-  bool batched = false;
-  float ms_ixb_batches = 0;
-  if (indexed && !tiled && stages == STAGE_ALL && nbatch > 1 && nshards >= 512u * nbatch && !getenv("BROTLI_AMD_INDEX_ONLY")) {
-    HIP_OK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
-    float bs = 0;
-    if (!run_batches(c, plan, a, nbatch, gpw, &ms_index, &ms_ixb_batches, &ms_parse, &bs)) return false;
-    ms_build = bs;          // (build + store of a batch run back to back on its stream: reported together)
-    batched = true;
-  }
-  if (indexed && !batched) {
+  // (Batches of whole shards with the index of one batch beside the chain of the one before were measured and
+  //  dropped: 95.8 ms per step became 101.7 ... 144.5, profiles/r03_h_batches.txt — the chain's waves and the index
+  //  kernels' waves take each other's LDS and issue slots.)
+  if (indexed) {
     // the data-parallel half of the parse, once per job (k_index.h)
     hipLaunchKernelGGL(k_ix_count, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_scan, dim3(nshards), dim3(64), 0, c->stream, a);
@@ -531,14 +451,6 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     }
   }
   uint32_t rounds = 0;
-  if (batched) {
-    // the first round is through: what is left (shards of several meta-blocks) goes the plain way below
-    uint32_t counters[16];
-    HIP_OK(c, hipMemcpy(counters, c->d_counters, sizeof(counters), hipMemcpyDeviceToHost));
-    ++rounds;
-    if (counters[1]) return fail(c, "%u shard(s) reported a device fault", counters[1]);
-    if (counters[0] == 0) goto rounds_done;
-  }
   for (;;) {
     HIP_OK(c, hipMemsetAsync(c->d_counters, 0, 16 * sizeof(uint32_t), c->stream));
     HIP_OK(c, hipEventRecord(c->ev[2], c->stream));
@@ -670,17 +582,15 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     if (counters[1]) return fail(c, "%u shard(s) reported a device fault", counters[1]);
     if (counters[0] == 0 || stages != STAGE_ALL) break;
   }
-rounds_done:
   if (info) {
     float t;
     HIP_OK(c, hipEventElapsedTime(&t, c->ev[0], c->ev[1]));
     info->ms_init = t;
     info->ms_ix_bucket = 0;
-    if (indexed && !batched) {
+    if (indexed) {
       HIP_OK(c, hipEventElapsedTime(&ms_index, c->ev[1], c->ev_ix));
       HIP_OK(c, hipEventElapsedTime(&info->ms_ix_bucket, c->ev_ixb, c->ev_ix));
     }
-    if (batched) info->ms_ix_bucket = ms_ixb_batches;
     info->ms_index = ms_index;
     info->ms_parse = ms_parse;
     info->ms_build = ms_build;
@@ -1042,9 +952,6 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
     for (int k = 0; k < 2; ++k) { if (l.pin[k]) (void)hipHostFree(l.pin[k]); if (l.ev[k]) (void)hipEventDestroy(l.ev[k]); }
     if (l.s) (void)hipStreamDestroy(l.s);
   }
-  if (c->s_index) (void)hipStreamDestroy(c->s_index);
-  for (hipStream_t st : c->s_batch) if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t e : c->ev_batch) if (e) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

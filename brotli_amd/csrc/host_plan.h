@@ -172,12 +172,13 @@ static inline uint64_t plan_add_index_for(JobPlan* plan, std::vector<ShardDesc>&
 }
 
 // Chain tiles (k_chain.h, k_tile.h) for an indexed plan whose shards are longer than a tile: the tile table, the
-// two slot buffers for the tiles' commands (behind the rest of the workspace) and a bigger final command array.
-// tile_kb: KiB per tile (a power of two >= the input block), 0 = no tiles.  Returns the number of tiles.
+// two slot buffers for the tiles' commands (behind the rest of the workspace).
+// tile_kb: KiB per tile (rounded up to a power of two >= the input block; above 4096 — an environment knob may hold
+// anything — there are no tiles), 0 = no tiles.  Returns the number of tiles.
 static inline uint32_t plan_add_tiles(JobPlan* plan, uint32_t tile_kb, uint32_t warm_bytes) {
-  if (!(plan->J.flags & JOB_FLAG_INDEXED) || tile_kb == 0) return 0;
+  if (!(plan->J.flags & JOB_FLAG_INDEXED) || tile_kb == 0 || tile_kb > 4096u) return 0;
   uint32_t tl = 10;
-  while ((1u << (tl - 10u)) < tile_kb) ++tl;
+  while (tl < 22u && (1u << (tl - 10u)) < tile_kb) ++tl;
   if ((int)tl < plan->J.lgblock) tl = (uint32_t)plan->J.lgblock;
   if (tl > 22u) return 0;
   uint64_t longest = 0;

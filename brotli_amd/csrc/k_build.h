@@ -48,14 +48,27 @@ static __device__ const uint8_t k_ctx_maps[4][64] = {
 // ---- entropy (summation order of the reference) ------------------------------
 // BitsEntropy of a[k] + g[k] (either pointer may be null), bit_cost.c:18-44.
 DEV double bits_entropy2(const uint32_t* a, const uint32_t* g, uint32_t n, const double* lut) {
+  // One lane walks a whole histogram; the sum has to be taken in index order (the doubles are the reference's), but
+  // the loads need not wait for it: eight counts and their eight log2 values are fetched at once, then added in
+  // order.  A zero count needs no branch: lut[0] = 0, and r - 0.0 == r.  (The loop used to take one L1 round trip
+  // per entry for lut[p]: 37 us per decision of the literal splitter with 13 contexts.)
   uint64_t sum = 0;
   double r = 0.0;
-  for (uint32_t k = 0; k < n; ++k) {
+  uint32_t k = 0;
+  for (; k + 8u <= n; k += 8u) {
+    uint32_t p[8];
+    double l[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = (a ? a[k + j] : 0u) + (g ? g[k + j] : 0u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = lut[p[j]];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sum += p[j]; r -= (double)p[j] * l[j]; }
+  }
+  for (; k < n; ++k) {
     const uint32_t p = (a ? a[k] : 0u) + (g ? g[k] : 0u);
-    if (p) {
-      sum += p;
-      r -= (double)p * lut[p];
-    }
+    sum += p;
+    r -= (double)p * lut[p];
   }
   if (sum) r += (double)sum * lut[sum];
   if (r < (double)sum) r = (double)sum;

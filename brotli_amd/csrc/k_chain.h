@@ -454,7 +454,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     const uint32_t Pk = pos + (uint32_t)t;
     // ---- evaluation of position Pk ----
     const C16 cb = c_load16(g.data + (can ? Pk : 0u));
-    const uint64_t rw = C.res[can ? Pk : 0u];
+    const uint64_t rw = C.res[can ? Pk : C.ibase];      // (a stream: C.res is the chunk's array shifted by its base — index 0 lies gigabytes below it)
     C16 pb[4];
     const uint32_t maxb = umin(Pk, limit);
     const uint32_t dcs[4] = {(uint32_t)g.dc[0], (uint32_t)g.dc[1], (uint32_t)g.dc[2], (uint32_t)g.dc[3]};

@@ -28,8 +28,8 @@ def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0
     and only a piece that did not makes the gather run again with the right slot."""
     world = dist.get_world_size(group)
     dev = local.device
-    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
-    mine = torch.tensor([nbytes], dtype=torch.int64, device=dev)
+    sizes = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    mine = torch.tensor([nbytes, int(pad_hint)], dtype=torch.int64, device=dev)       # (the hint travels with the size: checked below)
     dist.all_gather_into_tensor(sizes, mine, group=group)
 
     def gather(pad, local, scratch):
@@ -49,7 +49,12 @@ def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0
     pad = round_up(pad_hint) if pad_hint else 0
     if pad:
         scratch = gather(pad, local, scratch)
-    host_sizes = [int(v) for v in sizes.cpu()]               # the step's one host read
+    both = [int(v) for v in sizes.cpu()]                     # the step's one host read
+    host_sizes, hints = both[0::2], both[1::2]
+    if any(h != hints[0] for h in hints):
+        # pad_hint must be the same on every rank (sharded_step's comes from gathered sizes, so it is): ranks that
+        # disagree have just exchanged slots of different sizes
+        raise ValueError("gather_stream: pad_hint differs between ranks: %r" % (hints,))
     need = round_up(max(host_sizes))
     if need > pad:
         pad = need

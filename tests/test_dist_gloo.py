@@ -24,15 +24,16 @@ def _worker(rank, world, port, q):
     from brotli_amd.dist import rank_params, same_stream_on_all_ranks, sharded_step
     from refharness import Oracle
     o = Oracle()
-    piece, shard = 300000, 1 << 16
+    piece, shard = 600000, 1 << 16      # total >= 1 MiB: the size hint decides the hasher (H68, not H58: quality.h:186-204)
     total = piece * world
     data = G.enwik_text(total, seed=21, vocab=5000)
-    base, is_last, hint = rank_params(rank, world, piece, total)
+    base, is_last, size_hint = rank_params(rank, world, piece, total)
+    assert size_hint == total >= (1 << 20)
     mine = data[base:base + piece]
     parts, off = [], 0
     while off < piece:
         m = min(shard, piece - off)
-        parts.append(o.encode_shard(mine[off:off + m], 5, 22, hint, base + off,
+        parts.append(o.encode_shard(mine[off:off + m], 5, 22, size_hint, base + off,
                                     is_last and off + m == piece))
         off += m
     comp = b"".join(parts)
@@ -42,18 +43,27 @@ def _worker(rank, world, port, q):
         local[:len(comp)] = torch.frombuffer(bytearray(comp), dtype=torch.uint8)
         return local, len(comp)
     scratch, pad = None, 0
-    for hint in (0, None, 256):   # first step: no hint; then the previous step's slot, as bench.py's steps do; then a
+    for slot in (0, None, 256):   # first step: no hint; then the previous step's slot, as bench.py's steps do; then a
         #                           hint that is too small (the gather must notice and run again)
-        stream_t, sizes, scratch, pad = sharded_step(encode_local, scratch=scratch, pad_hint=pad if hint is None else hint)
+        stream_t, sizes, scratch, pad = sharded_step(encode_local, scratch=scratch, pad_hint=pad if slot is None else slot)
     same, _ = same_stream_on_all_ranks(stream_t)
     stream = stream_t.numpy().tobytes()
     # every rank holds the same, complete stream
     want_parts, off = [], 0
     while off < total:
         m = min(shard, total - off, piece - off % piece)
-        want_parts.append(o.encode_shard(data[off:off + m], 5, 22, hint, off, off + m == total))
+        want_parts.append(o.encode_shard(data[off:off + m], 5, 22, size_hint, off, off + m == total))
         off += m
     ok = same and stream == b"".join(want_parts) and sum(sizes) == len(stream)
+    # (the hint matters: with one below 1 MiB the shards come out differently)
+    ok = ok and o.encode_shard(data[:shard], 5, 22, 256, 0, False) != want_parts[0]
+    # ranks that disagree on the hint are told so (hints that still round up to the same slot: a real mismatch would
+    # break gloo's transport right here — and go unnoticed under RCCL, which is what the check is for)
+    try:
+        sharded_step(encode_local, scratch=scratch, pad_hint=100 * (rank + 1))
+        ok = False
+    except ValueError:
+        pass
     q.put((rank, ok, len(stream)))
     dist.barrier()
     dist.destroy_process_group()
