@@ -244,18 +244,20 @@ DEV void decide_contexts(BuildCtx& b, uint32_t start, uint32_t length) {
 // lane, each lane finding its command by a binary search over the 64 start
 // indices kept in LDS (so one long insert run is spread over all lanes and
 // every load of a step is independent).
-DEV void build_streams(BuildCtx& b, uint32_t start, uint32_t ncmds, uint32_t* nlits_out,
-                       uint32_t* ndist_out) {
+// Commands [c0, c1) of the meta-block (c0 a multiple of 64), given where they begin: source position `pos`, first
+// literal index `nlits`, first distance index `ndist`.  The whole meta-block in one call (k_build) or one part of it
+// per wave (k_wide.h: the parts' starting values come from a scan over their totals).
+DEV void build_streams_range(BuildCtx& b, uint32_t c0, uint32_t c1, uint32_t pos, uint32_t nlits, uint32_t ndist,
+                             uint32_t* nlits_out, uint32_t* ndist_out) {
   const int lane = wave_lane();
   const uint8_t* clut = b.T->context_lut;
   const uint8_t* cmap = k_ctx_maps[b.map_kind];
   const bool use_ctx = b.nc > 1;
   uint32_t* s_start = b.lds;        // [65] first literal index of command i of the step
   uint32_t* s_src = b.lds + 65;     // [64] source position of that literal
-  uint32_t pos = start, nlits = 0, ndist = 0;
-  for (uint32_t base = 0; base < ncmds; base += 64) {
+  for (uint32_t base = c0; base < c1; base += 64) {
     const uint32_t i = base + (uint32_t)lane;
-    const bool valid = i < ncmds;
+    const bool valid = i < c1;
     uint32_t ins = 0, cpy = 0, prefix = 0, dprefix = 0;
     if (valid) {
       const Command c = b.cmds[i];
@@ -302,6 +304,9 @@ DEV void build_streams(BuildCtx& b, uint32_t start, uint32_t ncmds, uint32_t* nl
   wave_sync();
   *nlits_out = nlits;
   *ndist_out = ndist;
+}
+DEV void build_streams(BuildCtx& b, uint32_t start, uint32_t ncmds, uint32_t* nlits_out, uint32_t* ndist_out) {
+  build_streams_range(b, 0u, ncmds, start, 0u, 0u, nlits_out, ndist_out);
 }
 
 // ---- greedy block splitter -------------------------------------------------------
@@ -557,12 +562,8 @@ DEV void smooth_histogram_for_rle(uint32_t length, uint32_t* counts, uint8_t* st
 }
 
 // ---- the round --------------------------------------------------------------------
-DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
-                     const DeviceTables* T, const uint8_t* input, uint8_t* ws,
-                     uint32_t* lds, double* lds_ent, double* lds_last, double* lds_terms) {
-  const int lane = wave_lane();
-  if (!S->mb_valid || S->error) return;
-  BuildCtx b;
+DEV void build_ctx_init(BuildCtx& b, const JobParams& J, const ShardDesc& D, const DeviceTables* T, const uint8_t* input,
+                        uint8_t* ws, uint32_t* lds, double* lds_ent, double* lds_last, double* lds_terms) {
   b.J = &J;
   b.data = input + D.in_off;
   b.T = T;
@@ -573,12 +574,49 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   b.dsym = (uint16_t*)(ws + D.dsym_off);
   b.lds = lds;
   b.lds_ent = lds_ent;               // [0..2] call results, [4..4+39) per-decision table
-  b.lds_ent3 = lds_ent + 4;
+  b.lds_ent3 = lds_ent ? lds_ent + 4 : nullptr;        // (a caller that only makes the symbol streams has none of these)
   b.lds_last = lds_last;
   b.lds_terms = lds_terms;
-  b.lds_sums = (uint32_t*)(lds_terms + BUILD_TERMS);
+  b.lds_sums = lds_terms ? (uint32_t*)(lds_terms + BUILD_TERMS) : nullptr;
   b.nc = 1;
   b.map_kind = 0;
+}
+
+// BrotliOptimizeHistograms: one lane per histogram, but on LDS copies (the
+// smoothing is a serial scan with data-dependent rewrites: ~5 passes of
+// dependent accesses per entry).  Batches of as many histograms as fit the
+// block-splitter's LDS row buffer; the flag bytes live in the term buffer.
+DEV void build_smooth_histograms(BuildCtx& b, const MbInfo* info) {
+  const int lane = wave_lane();
+  const uint32_t nh[3] = {info->split[0].num_histograms, info->split[1].num_histograms,
+                          info->split[2].num_histograms};
+  const uint32_t alpha[3] = {256u, 704u, 64u};
+  uint8_t* flags = (uint8_t*)b.lds_terms;
+  for (int c = 0; c < 3; ++c) {
+    uint32_t* G = (uint32_t*)(b.mb + b.L.histos[c]);
+    const uint32_t A = alpha[c];
+    uint32_t per = umin(BUILD_LDS_WORDS / A, (BUILD_TERMS * 8u) / A);
+    per = umin(per, 64u);
+    for (uint32_t h0 = 0; h0 < nh[c]; h0 += per) {
+      const uint32_t nb = umin(per, nh[c] - h0);
+      for (uint32_t k = (uint32_t)lane; k < nb * A; k += 64) b.lds[k] = G[(size_t)h0 * A + k];
+      wave_sync();
+      if ((uint32_t)lane < nb) smooth_histogram_for_rle(A, b.lds + (uint32_t)lane * A, flags + (uint32_t)lane * A);
+      wave_sync();
+      for (uint32_t k = (uint32_t)lane; k < nb * A; k += 64) G[(size_t)h0 * A + k] = b.lds[k];
+      wave_sync();
+    }
+  }
+  wave_sync();
+}
+
+DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
+                     const DeviceTables* T, const uint8_t* input, uint8_t* ws,
+                     uint32_t* lds, double* lds_ent, double* lds_last, double* lds_terms) {
+  const int lane = wave_lane();
+  if (!S->mb_valid || S->error) return;
+  BuildCtx b;
+  build_ctx_init(b, J, D, T, input, ws, lds, lds_ent, lds_last, lds_terms);
 
   const uint32_t start = S->mb_start, bytes = S->mb_bytes;
   const uint32_t ncmds = S->ncmds, nlits_state = S->nlits;
@@ -610,32 +648,7 @@ DEV void build_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   BP_ADD(S, 4, bpt);
 
   if (J.quality < 4) { wave_sync(); BP_ADD(S, 5, bpt); return; }   // encode.c:587: from quality 4 on
-  // BrotliOptimizeHistograms: one lane per histogram, but on LDS copies (the
-  // smoothing is a serial scan with data-dependent rewrites: ~5 passes of
-  // dependent accesses per entry).  Batches of as many histograms as fit the
-  // block-splitter's LDS row buffer; the flag bytes live in the term buffer.
-  {
-    const uint32_t nh[3] = {info->split[0].num_histograms, info->split[1].num_histograms,
-                            info->split[2].num_histograms};
-    const uint32_t alpha[3] = {256u, 704u, 64u};
-    uint8_t* flags = (uint8_t*)b.lds_terms;
-    for (int c = 0; c < 3; ++c) {
-      uint32_t* G = (uint32_t*)(b.mb + b.L.histos[c]);
-      const uint32_t A = alpha[c];
-      uint32_t per = umin(BUILD_LDS_WORDS / A, (BUILD_TERMS * 8u) / A);
-      per = umin(per, 64u);
-      for (uint32_t h0 = 0; h0 < nh[c]; h0 += per) {
-        const uint32_t nb = umin(per, nh[c] - h0);
-        for (uint32_t k = (uint32_t)lane; k < nb * A; k += 64) b.lds[k] = G[(size_t)h0 * A + k];
-        wave_sync();
-        if ((uint32_t)lane < nb) smooth_histogram_for_rle(A, b.lds + (uint32_t)lane * A, flags + (uint32_t)lane * A);
-        wave_sync();
-        for (uint32_t k = (uint32_t)lane; k < nb * A; k += 64) G[(size_t)h0 * A + k] = b.lds[k];
-        wave_sync();
-      }
-    }
-  }
-  wave_sync();
+  build_smooth_histograms(b, info);
   BP_ADD(S, 5, bpt);
 }
 

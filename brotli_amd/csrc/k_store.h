@@ -299,451 +299,457 @@ DEV void store_literal_context_map(uint32_t ntypes, uint32_t nc, const uint8_t* 
   max_prefix_out = max_prefix;
 }
 
-DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
-                     const DeviceTables* T, const uint8_t* input, uint8_t* ws, uint32_t* lds_store) {
+// ---- the pieces of a meta-block's store ------------------------------------------------------------
+// store_round (one wave does everything, below) and the kernels of k_wide.h (a long meta-block spread over many
+// waves) are built from the same pieces, so the bits are the same whichever way a meta-block is written.
+struct StoreMeta {          // wave-uniform facts about the meta-block
+  uint32_t ntypes[3], nblocks[3], nhist[3];
+  uint32_t ncmds, njobs;
+};
+DEV void store_ctx_init(StoreCtx& s, StoreMeta& M, const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws) {
+  s.J = &J;
+  s.data = input + D.in_off;
+  s.mb = ws + D.mb_off;
+  mb_layout(umin(D.len, J.max_metablock_size), &s.L);
+  s.info = (const MbInfo*)(s.mb + s.L.info);
+  s.small = (SmallCodes*)(s.mb + s.L.small);
+  s.cmds = (const Command*)(ws + D.cmds_off);
+  s.lits = (const uint16_t*)(ws + D.lits_off);
+  s.dsym = (const uint16_t*)(ws + D.dsym_off);
+  // scratch: switch codes (<= mb / 256 + 64 blocks in total), then two words per literal
+  const uint32_t mb_cap = umin(D.len, J.max_metablock_size);
+  s.sw = (uint64_t*)(ws + D.scratch_off);
+  s.lsum = (uint32_t*)(ws + D.scratch_off + ((uint64_t)mb_cap / 256u + 64u) * 8u);
+  s.lcode = s.lsum + (mb_cap + 16u);
+  s.nc = s.info->num_contexts;
+  for (int c = 0; c < 3; ++c) {
+    s.types[c] = s.mb + s.L.types[c];
+    s.lengths[c] = (const uint32_t*)(s.mb + s.L.lengths[c]);
+    s.blkmap[c] = (const uint16_t*)(s.mb + s.L.blkmap[c]);
+    s.depths[c] = s.mb + s.L.depths[c];
+    s.bits[c] = (const uint16_t*)(s.mb + s.L.bits[c]);
+    M.ntypes[c] = s.info->split[c].num_types;
+    M.nblocks[c] = s.info->split[c].num_blocks;
+    M.nhist[c] = s.info->split[c].num_histograms;
+  }
+  s.sw_off[0] = 0;
+  s.sw_off[1] = M.nblocks[0];
+  s.sw_off[2] = M.nblocks[0] + M.nblocks[1];
+  M.ncmds = s.info->ncmds;
+  M.njobs = 8 + M.nhist[0] + M.nhist[1] + M.nhist[2];
+}
+
+// phase 0: histograms of the small codes (a lane each), the literal context map (the whole wave)
+DEV void store_small_histos(StoreCtx& s, const StoreMeta& M, uint32_t* lds_store, uint32_t& cmap_nrle, uint32_t& cmap_max_prefix) {
   const int lane = wave_lane();
-  if (!S->mb_valid || S->error) return;
-  const uint8_t* data = input + D.in_off;
-  uint8_t* out = ws + D.out_off;
-  RoundRegs r;
-  regs_load(r, S);
-  int32_t dc[4];
-  for (int i = 0; i < 4; ++i) dc[i] = S->dist_cache[i];
-  const uint32_t start = S->mb_start, bytes = S->mb_bytes;
-  const bool is_last = S->mb_is_last != 0, force_flush = S->mb_force_flush != 0;
-  bool raw = S->mb_raw != 0;
-  // A meta-block of a tiled stream (JOB_FLAG_STREAMT) is written as if it began at bit 0 and moved to its place
-  // afterwards (k_stream_place).  A raw one is not written here at all (its payload is byte aligned in the STREAM):
-  // mb_was_raw = 1 tells k_stream_scan / k_stream_place, which emit it; 2 = the size comparison depends on the bit the
-  // meta-block starts at, k_stream_scan decides.
-  const bool stream = (J.flags & JOB_FLAG_STREAMT) != 0;
-  if (stream && raw) {
-    wave_sync();                 // (every lane has read the state by now)
-    if (lane == 0) { S->mb_was_raw = 1; S->mb_valid = 0; }
-    wave_sync();
-    return;
+  SmallCodes* sc = s.small;
+  cmap_nrle = 0; cmap_max_prefix = 0;
+  if (lane < 3) {
+    const int c = lane;
+    for (uint32_t i = 0; i < M.ntypes[c] + 2; ++i) sc->type_histo[c][i] = 0;
+    for (uint32_t i = 0; i < 26; ++i) sc->len_histo[c][i] = 0;
+    for (uint32_t b = 0; b < M.nblocks[c]; ++b) {
+      if (b != 0) ++sc->type_histo[c][block_type_code(s.types[c], b)];
+      ++sc->len_histo[c][block_length_prefix_code(s.lengths[c][b])];
+    }
+  } else if (lane == 3 || lane == 4) {
+    // Trivial context maps (:794-830): literal (only when nc == 1), distance.
+    const int m = lane - 3;
+    const uint32_t num_types = m == 0 ? M.nhist[0] : M.nhist[2];
+    const uint32_t context_bits = m == 0 ? 6u : 2u;
+    if ((m == 1 || s.nc == 1) && num_types > 1) {
+      const uint32_t repeat_code = context_bits - 1u;
+      const uint32_t alphabet_size = num_types + repeat_code;
+      for (uint32_t i = 0; i < alphabet_size; ++i) sc->cmap_histo[m][i] = 0;
+      sc->cmap_histo[m][repeat_code] = num_types;
+      sc->cmap_histo[m][0] = 1;
+      for (uint32_t i = context_bits; i < alphabet_size; ++i) sc->cmap_histo[m][i] = 1;
+    }
   }
+  wave_sync();
+  if (s.nc > 1) store_literal_context_map(M.ntypes[0], s.nc, k_ctx_maps[s.info->map_kind], (uint32_t*)(s.mb + s.L.cmap_rle),
+                                          sc->cmap_histo[0], lds_store, cmap_nrle, cmap_max_prefix);
+  wave_sync();
+}
 
-  // Everything this meta-block can touch, zeroed; then the carried bits.
-  const uint64_t zero_bytes = 2ull * bytes + 520ull;
-  if (r.out_bytes + zero_bytes + 16 > D.out_cap) {
-    if (lane == 0) S->error = 2;
-    return;
+// phase 1, one job: a prefix code, the whole wave on it.  job ids: 0-2 block types, 3-5 block lengths, 6 literal
+// context map, 7 distance context map, then literal / command / distance histograms.
+DEV void store_code_job(StoreCtx& s, const StoreMeta& M, uint32_t j, uint32_t cmap_max_prefix, uint32_t* lds_store) {
+  const int lane = wave_lane();
+  const JobParams& J = *s.J;
+  const uint32_t alpha[3] = {256u, 704u, 64u};
+  SmallCodes* sc = s.small;
+  uint8_t* tree_bufs = s.mb + s.L.tree_bufs;
+  uint32_t* job_nbits = (uint32_t*)(s.mb + s.L.jobs);
+  const uint32_t lit_cmap_alpha = s.nc > 1 ? M.nhist[0] + cmap_max_prefix : M.nhist[0] + 5u;
+  const uint32_t* histo = nullptr;
+  uint8_t* depth = nullptr;
+  uint16_t* bits = nullptr;
+  uint32_t length = 0;
+  bool skip = false;
+  if (j < 3) {
+    histo = sc->type_histo[j]; depth = sc->type_depth[j]; bits = sc->type_bits[j];
+    length = M.ntypes[j] + 2; skip = M.ntypes[j] <= 1;
+  } else if (j < 6) {
+    const uint32_t c = j - 3;
+    histo = sc->len_histo[c]; depth = sc->len_depth[c]; bits = sc->len_bits[c];
+    length = 26; skip = M.ntypes[c] <= 1;
+  } else if (j == 6) {
+    histo = sc->cmap_histo[0]; depth = sc->cmap_depth[0]; bits = sc->cmap_bits[0];
+    length = lit_cmap_alpha; skip = M.nhist[0] <= 1;
+  } else if (j == 7) {
+    histo = sc->cmap_histo[1]; depth = sc->cmap_depth[1]; bits = sc->cmap_bits[1];
+    length = M.nhist[2] + 1u; skip = M.nhist[2] <= 1;
+  } else {
+    uint32_t h = j - 8;
+    int c = 0;
+    if (h >= M.nhist[0]) { h -= M.nhist[0]; c = 1; if (h >= M.nhist[1]) { h -= M.nhist[1]; c = 2; } }
+    histo = (const uint32_t*)(s.mb + s.L.histos[c]) + (size_t)h * alpha[c];
+    depth = (uint8_t*)(s.mb + s.L.depths[c]) + (size_t)h * alpha[c];
+    bits = (uint16_t*)(s.mb + s.L.bits[c]) + (size_t)h * alpha[c];
+    length = alpha[c];
   }
-  uint64_t total_bits = 0;   // relative to out + r.out_bytes, carried bits included
-  uint64_t spt = SP_NOW();
-
-  if (!raw) {
-    zero_output(out, r.out_bytes, zero_bytes);
-    StoreCtx s;
-    s.J = &J;
-    s.data = data;
-    s.mb = ws + D.mb_off;
-    mb_layout(umin(D.len, J.max_metablock_size), &s.L);
-    s.info = (const MbInfo*)(s.mb + s.L.info);
-    s.small = (SmallCodes*)(s.mb + s.L.small);
-    s.cmds = (const Command*)(ws + D.cmds_off);
-    s.lits = (const uint16_t*)(ws + D.lits_off);
-    s.dsym = (const uint16_t*)(ws + D.dsym_off);
-    // scratch: switch codes (<= mb / 256 + 64 blocks in total), then two words per literal
-    const uint32_t mb_cap = umin(D.len, J.max_metablock_size);
-    s.sw = (uint64_t*)(ws + D.scratch_off);
-    s.lsum = (uint32_t*)(ws + D.scratch_off + ((uint64_t)mb_cap / 256u + 64u) * 8u);
-    s.lcode = s.lsum + (mb_cap + 16u);
-    s.nc = s.info->num_contexts;
-    const uint32_t alpha[3] = {256u, 704u, 64u};
-    const uint32_t minb[3] = {MB_LIT_MIN_BLOCK, MB_CMD_MIN_BLOCK, MB_DIST_MIN_BLOCK};
-    uint32_t ntypes[3], nblocks[3], nhist[3];
-    for (int c = 0; c < 3; ++c) {
-      s.types[c] = s.mb + s.L.types[c];
-      s.lengths[c] = (const uint32_t*)(s.mb + s.L.lengths[c]);
-      s.blkmap[c] = (const uint16_t*)(s.mb + s.L.blkmap[c]);
-      s.depths[c] = s.mb + s.L.depths[c];
-      s.bits[c] = (const uint16_t*)(s.mb + s.L.bits[c]);
-      ntypes[c] = s.info->split[c].num_types;
-      nblocks[c] = s.info->split[c].num_blocks;
-      nhist[c] = s.info->split[c].num_histograms;
-    }
-    s.sw_off[0] = 0;
-    s.sw_off[1] = nblocks[0];
-    s.sw_off[2] = nblocks[0] + nblocks[1];
-    const uint32_t ncmds = s.info->ncmds;
-    SmallCodes* sc = s.small;
-    uint32_t* cmap_rle = (uint32_t*)(s.mb + s.L.cmap_rle);
-    const uint8_t* static_map = k_ctx_maps[s.info->map_kind];
-
-    SP_ADD(S, 0, spt);
-    // ---- phase 0: histograms of the small codes (a lane each) ----
-    uint32_t cmap_nrle = 0, cmap_max_prefix = 0;
-    if (lane < 3) {
-      const int c = lane;
-      for (uint32_t i = 0; i < ntypes[c] + 2; ++i) sc->type_histo[c][i] = 0;
-      for (uint32_t i = 0; i < 26; ++i) sc->len_histo[c][i] = 0;
-      for (uint32_t b = 0; b < nblocks[c]; ++b) {
-        if (b != 0) ++sc->type_histo[c][block_type_code(s.types[c], b)];
-        ++sc->len_histo[c][block_length_prefix_code(s.lengths[c][b])];
+  uint32_t nb = 0;
+  if (!skip && J.quality == 2 && j >= 8) {
+    // BrotliStoreMetaBlockFast (brotli_bit_stream.c:1242-1314): count-only trees; up to 128
+    // commands the command and distance codes are the static ones (entropy_encode_static.h:
+    // 448 command symbols of 9 bits + 256 of 11, 64 distance symbols of 6 bits, canonical,
+    // bits reversed; their serialised forms are the constants of :524-541)
+    uint8_t* buf = tree_bufs + (size_t)j * MB_TREE_BUF_BYTES;
+    if (j == 8 || M.ncmds > 128u) {
+      nb = pfx_build_and_store<true>(histo, length, length, lds_store, depth, bits, buf);
+    } else if (j == 9) {
+      for (uint32_t i = (uint32_t)lane; i < 704u; i += 64) {
+        const uint32_t code = i < 448u ? i : 1792u + (i - 448u), nbits = i < 448u ? 9u : 11u;
+        depth[i] = (uint8_t)nbits;
+        bits[i] = (uint16_t)(dev_bitrev32(code) >> (32u - nbits));
       }
-    } else if (lane == 3 || lane == 4) {
-      // Trivial context maps (:794-830): literal (only when nc == 1), distance.
-      const int m = lane - 3;
-      const uint32_t num_types = m == 0 ? nhist[0] : nhist[2];
-      const uint32_t context_bits = m == 0 ? 6u : 2u;
-      if ((m == 1 || s.nc == 1) && num_types > 1) {
-        const uint32_t repeat_code = context_bits - 1u;
-        const uint32_t alphabet_size = num_types + repeat_code;
-        for (uint32_t i = 0; i < alphabet_size; ++i) sc->cmap_histo[m][i] = 0;
-        sc->cmap_histo[m][repeat_code] = num_types;
-        sc->cmap_histo[m][0] = 1;
-        for (uint32_t i = context_bits; i < alphabet_size; ++i) sc->cmap_histo[m][i] = 1;
-      }
-    }
-    wave_sync();
-    if (s.nc > 1) store_literal_context_map(ntypes[0], s.nc, static_map, cmap_rle, sc->cmap_histo[0], lds_store,
-                                            cmap_nrle, cmap_max_prefix);
-    wave_sync();
-
-    SP_ADD(S, 1, spt);
-    // ---- phase 1: every prefix code, one after the other, the whole wave on each ----
-    // job ids: 0-2 block types, 3-5 block lengths, 6 literal context map,
-    // 7 distance context map, then literal / command / distance histograms.
-    const uint32_t njobs = 8 + nhist[0] + nhist[1] + nhist[2];
-    uint8_t* tree_bufs = s.mb + s.L.tree_bufs;
-    uint32_t* job_nbits = (uint32_t*)(s.mb + s.L.jobs);
-    const uint32_t lit_cmap_alpha = s.nc > 1 ? nhist[0] + cmap_max_prefix : nhist[0] + 5u;
-    for (uint32_t j = 0; j < njobs; ++j) {
-      const uint32_t* histo = nullptr;
-      uint8_t* depth = nullptr;
-      uint16_t* bits = nullptr;
-      uint32_t length = 0;
-      bool skip = false;
-      if (j < 3) {
-        histo = sc->type_histo[j]; depth = sc->type_depth[j]; bits = sc->type_bits[j];
-        length = ntypes[j] + 2; skip = ntypes[j] <= 1;
-      } else if (j < 6) {
-        const uint32_t c = j - 3;
-        histo = sc->len_histo[c]; depth = sc->len_depth[c]; bits = sc->len_bits[c];
-        length = 26; skip = ntypes[c] <= 1;
-      } else if (j == 6) {
-        histo = sc->cmap_histo[0]; depth = sc->cmap_depth[0]; bits = sc->cmap_bits[0];
-        length = lit_cmap_alpha; skip = nhist[0] <= 1;
-      } else if (j == 7) {
-        histo = sc->cmap_histo[1]; depth = sc->cmap_depth[1]; bits = sc->cmap_bits[1];
-        length = nhist[2] + 1u; skip = nhist[2] <= 1;
-      } else {
-        uint32_t h = j - 8;
-        int c = 0;
-        if (h >= nhist[0]) { h -= nhist[0]; c = 1; if (h >= nhist[1]) { h -= nhist[1]; c = 2; } }
-        histo = (const uint32_t*)(s.mb + s.L.histos[c]) + (size_t)h * alpha[c];
-        depth = (uint8_t*)(s.mb + s.L.depths[c]) + (size_t)h * alpha[c];
-        bits = (uint16_t*)(s.mb + s.L.bits[c]) + (size_t)h * alpha[c];
-        length = alpha[c];
-      }
-      uint32_t nb = 0;
-      if (!skip && J.quality == 2 && j >= 8) {
-        // BrotliStoreMetaBlockFast (brotli_bit_stream.c:1242-1314): count-only trees; up to 128
-        // commands the command and distance codes are the static ones (entropy_encode_static.h:
-        // 448 command symbols of 9 bits + 256 of 11, 64 distance symbols of 6 bits, canonical,
-        // bits reversed; their serialised forms are the constants of :524-541)
-        uint8_t* buf = tree_bufs + (size_t)j * MB_TREE_BUF_BYTES;
-        if (j == 8 || ncmds > 128u) {
-          nb = pfx_build_and_store<true>(histo, length, length, lds_store, depth, bits, buf);
-        } else if (j == 9) {
-          for (uint32_t i = (uint32_t)lane; i < 704u; i += 64) {
-            const uint32_t code = i < 448u ? i : 1792u + (i - 448u), nbits = i < 448u ? 9u : 11u;
-            depth[i] = (uint8_t)nbits;
-            bits[i] = (uint16_t)(dev_bitrev32(code) >> (32u - nbits));
-          }
-          if (lane == 0) { st32(buf, 0x16307003u); st32(buf + 4, 0x00926244u); }
-          nb = 59;
-        } else {
-          if (lane < 64) { depth[lane] = 6; bits[lane] = (uint16_t)(dev_bitrev32((uint32_t)lane) >> 26); }
-          if (lane == 0) st32(buf, 0x0369DC03u);
-          nb = 28;
-        }
-        wave_sync();
-      } else if (!skip) {
-        nb = pfx_build_and_store(histo, length, length, lds_store, depth, bits,
-                                 tree_bufs + (size_t)j * MB_TREE_BUF_BYTES);
-      }
-      if (lane == 0) job_nbits[j] = nb;
-    }
-    wave_sync();
-
-    SP_ADD(S, 2, spt);
-    // Block switch codes for every block b >= 1 (StoreBlockSwitch :737-756).
-    for (int c = 0; c < 3; ++c) {
-      for (uint32_t b = (uint32_t)lane; b < nblocks[c]; b += 64) {
-        uint64_t v = 0;
-        uint32_t n = 0;
-        if (ntypes[c] > 1) {
-          const uint32_t lencode = block_length_prefix_code(s.lengths[c][b]);
-          if (b != 0) {
-            const uint32_t tc = block_type_code(s.types[c], b);
-            v = sc->type_bits[c][tc];
-            n = sc->type_depth[c][tc];
-          }
-          v |= (uint64_t)sc->len_bits[c][lencode] << n;
-          n += sc->len_depth[c][lencode];
-          v |= (uint64_t)(s.lengths[c][b] - k_blocklen_offset[lencode]) << n;
-          n += k_blocklen_nbits[lencode];
-        }
-        s.sw[s.sw_off[c] + b] = v | ((uint64_t)n << 56);
-      }
-    }
-    wave_sync();
-
-    SP_ADD(S, 3, spt);
-    // ---- phase 2: header, in order ----
-    BitSink sink;
-    sink.base = (uint32_t*)(out + (r.out_bytes & ~(uint64_t)3));
-    sink.bitpos = (r.out_bytes & 3) * 8;
-    const uint64_t bit0 = sink.bitpos;
-    sink_put(sink, r.last_bytes_bits, r.last_bytes);
-    {
-      // StoreCompressedMetaBlockHeader :120-143
-      const uint32_t lg = (bytes == 1) ? 1u : log2floor(bytes - 1u) + 1u;
-      const uint32_t mnibbles = (lg < 16u ? 16u : (lg + 3u)) / 4u;
-      sink_put(sink, 1, is_last ? 1 : 0);
-      if (is_last) sink_put(sink, 1, 0);
-      sink_put(sink, 2, mnibbles - 4u);
-      sink_put(sink, mnibbles * 4u, bytes - 1u);
-      if (!is_last) sink_put(sink, 1, 0);
-    }
-    for (int c = 0; c < 3; ++c) {
-      sink_varlen_uint8(sink, ntypes[c] - 1u);
-      if (ntypes[c] > 1) {
-        sink_splice(sink, tree_bufs + (size_t)c * MB_TREE_BUF_BYTES, job_nbits[c]);
-        sink_splice(sink, tree_bufs + (size_t)(3 + c) * MB_TREE_BUF_BYTES, job_nbits[3 + c]);
-        const uint64_t e = s.sw[s.sw_off[c]];
-        sink_put(sink, (uint32_t)(e >> 56), e & ((1ull << 56) - 1ull));
-      }
-    }
-    sink_put(sink, 2, 0);   // NPOSTFIX
-    sink_put(sink, 4, 0);   // NDIRECT >> NPOSTFIX
-    // CONTEXT_UTF8 (encode.c:486-496); the writers of qualities 2 - 3 leave the field zero ("13 zero bits")
-    for (uint32_t i = 0; i < ntypes[0]; ++i) sink_put(sink, 2, J.quality < 4 ? 0 : 2);
-    if (s.nc == 1) {
-      // StoreTrivialContextMap(num literal histograms, 6 context bits)
-      sink_varlen_uint8(sink, nhist[0] - 1u);
-      if (nhist[0] > 1) {
-        sink_put(sink, 1, 1);
-        sink_put(sink, 4, 4);
-        sink_splice(sink, tree_bufs + 6u * MB_TREE_BUF_BYTES, job_nbits[6]);
-        for (uint32_t i = 0; i < nhist[0]; ++i) {
-          const uint32_t code = i == 0 ? 0u : i + 5u;
-          sink_put(sink, sc->cmap_depth[0][code], sc->cmap_bits[0][code]);
-          sink_put(sink, sc->cmap_depth[0][5], sc->cmap_bits[0][5]);
-          sink_put(sink, 5, 31);
-        }
-        sink_put(sink, 1, 1);
-      }
+      if (lane == 0) { st32(buf, 0x16307003u); st32(buf + 4, 0x00926244u); }
+      nb = 59;
     } else {
-      sink_varlen_uint8(sink, nhist[0] - 1u);
-      const bool use_rle = cmap_max_prefix > 0;
-      sink_put(sink, 1, use_rle ? 1 : 0);
-      if (use_rle) sink_put(sink, 4, cmap_max_prefix - 1u);
+      if (lane < 64) { depth[lane] = 6; bits[lane] = (uint16_t)(dev_bitrev32((uint32_t)lane) >> 26); }
+      if (lane == 0) st32(buf, 0x0369DC03u);
+      nb = 28;
+    }
+    wave_sync();
+  } else if (!skip) {
+    nb = pfx_build_and_store(histo, length, length, lds_store, depth, bits,
+                             tree_bufs + (size_t)j * MB_TREE_BUF_BYTES);
+  }
+  if (lane == 0) job_nbits[j] = nb;
+}
+
+// Block switch codes for every block b >= 1 (StoreBlockSwitch :737-756).
+DEV void store_switch_codes(StoreCtx& s, const StoreMeta& M) {
+  const int lane = wave_lane();
+  SmallCodes* sc = s.small;
+  for (int c = 0; c < 3; ++c) {
+    for (uint32_t b = (uint32_t)lane; b < M.nblocks[c]; b += 64) {
+      uint64_t v = 0;
+      uint32_t n = 0;
+      if (M.ntypes[c] > 1) {
+        const uint32_t lencode = block_length_prefix_code(s.lengths[c][b]);
+        if (b != 0) {
+          const uint32_t tc = block_type_code(s.types[c], b);
+          v = sc->type_bits[c][tc];
+          n = sc->type_depth[c][tc];
+        }
+        v |= (uint64_t)sc->len_bits[c][lencode] << n;
+        n += sc->len_depth[c][lencode];
+        v |= (uint64_t)(s.lengths[c][b] - k_blocklen_offset[lencode]) << n;
+        n += k_blocklen_nbits[lencode];
+      }
+      s.sw[s.sw_off[c] + b] = v | ((uint64_t)n << 56);
+    }
+  }
+  wave_sync();
+}
+
+// phase 2: the meta-block header, in order, behind the bits carried over from the meta-block before.
+DEV void store_header(StoreCtx& s, const StoreMeta& M, BitSink& sink, uint32_t last_bytes, uint32_t last_bytes_bits,
+                      uint32_t bytes, bool is_last, uint32_t cmap_nrle, uint32_t cmap_max_prefix) {
+  const JobParams& J = *s.J;
+  SmallCodes* sc = s.small;
+  uint8_t* tree_bufs = s.mb + s.L.tree_bufs;
+  const uint32_t* job_nbits = (const uint32_t*)(s.mb + s.L.jobs);
+  const uint32_t* cmap_rle = (const uint32_t*)(s.mb + s.L.cmap_rle);
+  sink_put(sink, last_bytes_bits, last_bytes);
+  {
+    // StoreCompressedMetaBlockHeader :120-143
+    const uint32_t lg = (bytes == 1) ? 1u : log2floor(bytes - 1u) + 1u;
+    const uint32_t mnibbles = (lg < 16u ? 16u : (lg + 3u)) / 4u;
+    sink_put(sink, 1, is_last ? 1 : 0);
+    if (is_last) sink_put(sink, 1, 0);
+    sink_put(sink, 2, mnibbles - 4u);
+    sink_put(sink, mnibbles * 4u, bytes - 1u);
+    if (!is_last) sink_put(sink, 1, 0);
+  }
+  for (int c = 0; c < 3; ++c) {
+    sink_varlen_uint8(sink, M.ntypes[c] - 1u);
+    if (M.ntypes[c] > 1) {
+      sink_splice(sink, tree_bufs + (size_t)c * MB_TREE_BUF_BYTES, job_nbits[c]);
+      sink_splice(sink, tree_bufs + (size_t)(3 + c) * MB_TREE_BUF_BYTES, job_nbits[3 + c]);
+      const uint64_t e = s.sw[s.sw_off[c]];
+      sink_put(sink, (uint32_t)(e >> 56), e & ((1ull << 56) - 1ull));
+    }
+  }
+  sink_put(sink, 2, 0);   // NPOSTFIX
+  sink_put(sink, 4, 0);   // NDIRECT >> NPOSTFIX
+  // CONTEXT_UTF8 (encode.c:486-496); the writers of qualities 2 - 3 leave the field zero ("13 zero bits")
+  for (uint32_t i = 0; i < M.ntypes[0]; ++i) sink_put(sink, 2, J.quality < 4 ? 0 : 2);
+  if (s.nc == 1) {
+    // StoreTrivialContextMap(num literal histograms, 6 context bits)
+    sink_varlen_uint8(sink, M.nhist[0] - 1u);
+    if (M.nhist[0] > 1) {
+      sink_put(sink, 1, 1);
+      sink_put(sink, 4, 4);
       sink_splice(sink, tree_bufs + 6u * MB_TREE_BUF_BYTES, job_nbits[6]);
-      for (uint32_t i = 0; i < cmap_nrle; ++i) {
-        const uint32_t sym = cmap_rle[i] & 511u, extra = cmap_rle[i] >> 9;
-        sink_put(sink, sc->cmap_depth[0][sym], sc->cmap_bits[0][sym]);
-        if (sym > 0 && sym <= cmap_max_prefix) sink_put(sink, sym, extra);
+      for (uint32_t i = 0; i < M.nhist[0]; ++i) {
+        const uint32_t code = i == 0 ? 0u : i + 5u;
+        sink_put(sink, sc->cmap_depth[0][code], sc->cmap_bits[0][code]);
+        sink_put(sink, sc->cmap_depth[0][5], sc->cmap_bits[0][5]);
+        sink_put(sink, 5, 31);
       }
       sink_put(sink, 1, 1);
     }
-    {
-      // StoreTrivialContextMap(num distance histograms, 2 context bits)
-      sink_varlen_uint8(sink, nhist[2] - 1u);
-      if (nhist[2] > 1) {
-        sink_put(sink, 1, 1);
-        sink_put(sink, 4, 0);
-        sink_splice(sink, tree_bufs + 7u * MB_TREE_BUF_BYTES, job_nbits[7]);
-        for (uint32_t i = 0; i < nhist[2]; ++i) {
-          const uint32_t code = i == 0 ? 0u : i + 1u;
-          sink_put(sink, sc->cmap_depth[1][code], sc->cmap_bits[1][code]);
-          sink_put(sink, sc->cmap_depth[1][1], sc->cmap_bits[1][1]);
-          sink_put(sink, 1, 1);
-        }
+  } else {
+    sink_varlen_uint8(sink, M.nhist[0] - 1u);
+    const bool use_rle = cmap_max_prefix > 0;
+    sink_put(sink, 1, use_rle ? 1 : 0);
+    if (use_rle) sink_put(sink, 4, cmap_max_prefix - 1u);
+    sink_splice(sink, tree_bufs + 6u * MB_TREE_BUF_BYTES, job_nbits[6]);
+    for (uint32_t i = 0; i < cmap_nrle; ++i) {
+      const uint32_t sym = cmap_rle[i] & 511u, extra = cmap_rle[i] >> 9;
+      sink_put(sink, sc->cmap_depth[0][sym], sc->cmap_bits[0][sym]);
+      if (sym > 0 && sym <= cmap_max_prefix) sink_put(sink, sym, extra);
+    }
+    sink_put(sink, 1, 1);
+  }
+  {
+    // StoreTrivialContextMap(num distance histograms, 2 context bits)
+    sink_varlen_uint8(sink, M.nhist[2] - 1u);
+    if (M.nhist[2] > 1) {
+      sink_put(sink, 1, 1);
+      sink_put(sink, 4, 0);
+      sink_splice(sink, tree_bufs + 7u * MB_TREE_BUF_BYTES, job_nbits[7]);
+      for (uint32_t i = 0; i < M.nhist[2]; ++i) {
+        const uint32_t code = i == 0 ? 0u : i + 1u;
+        sink_put(sink, sc->cmap_depth[1][code], sc->cmap_bits[1][code]);
+        sink_put(sink, sc->cmap_depth[1][1], sc->cmap_bits[1][1]);
         sink_put(sink, 1, 1);
       }
+      sink_put(sink, 1, 1);
     }
-    for (uint32_t j = 8; j < njobs; ++j)
-      sink_splice(sink, tree_bufs + (size_t)j * MB_TREE_BUF_BYTES, job_nbits[j]);
+  }
+  for (uint32_t j = 8; j < M.njobs; ++j)
+    sink_splice(sink, tree_bufs + (size_t)j * MB_TREE_BUF_BYTES, job_nbits[j]);
+}
 
-    SP_ADD(S, 4, spt);
-    // ---- phase 3: the command stream ----
-    // (a) every literal of the meta-block, flat: code, length, and the running
-    //     sum of literal bits (lsum[k] = bits of literals [0, k)).
-    const uint32_t nlits = s.info->nlits;
-    uint32_t* lsum = s.lsum;
-    uint32_t* lcode = s.lcode;
-    {
-      uint32_t carry = 0;
-      for (uint32_t k0 = 0; k0 < nlits; k0 += 64) {
-        const uint32_t k = k0 + (uint32_t)lane;
-        uint32_t nb = 0;
-        if (k < nlits) {
-          const uint32_t v = s.lits[k];
-          const SymBits lb = symbol_bits<0>(s, k, v & 0xFFu, v >> 8);
-          nb = lb.nsw + lb.ncode;
-          lcode[k] = lb.code | (lb.ncode << 16);
-        }
-        const uint32_t incl = wave_incl_scan(nb);
-        if (k < nlits) lsum[k] = carry + incl - nb;
-        carry += wave_bcast(incl, 63);
-      }
-      if (lane == 0) lsum[nlits] = carry;
-      wave_sync();
+// phase 3 (a): literals [k0, k1) of the meta-block, flat: code | length << 16 of every literal (lcode) and the
+// running sum of their bits, block switches included (lsum[k] = `carry` + bits of literals [k0, k)).  Returns
+// `carry` + the bits of the whole range.
+DEV uint32_t store_literal_codes(const StoreCtx& s, uint32_t k0, uint32_t k1, uint32_t carry) {
+  const int lane = wave_lane();
+  for (uint32_t kk = k0; kk < k1; kk += 64) {
+    const uint32_t k = kk + (uint32_t)lane;
+    uint32_t nb = 0;
+    if (k < k1) {
+      const uint32_t v = s.lits[k];
+      const SymBits lb = symbol_bits<0>(s, k, v & 0xFFu, v >> 8);
+      nb = lb.nsw + lb.ncode;
+      s.lcode[k] = lb.code | (lb.ncode << 16);
     }
-    // (b) 64 commands per step: command / distance codes per lane, a wave scan
-    //     for their offsets, then the literals of the step written flat (one
-    //     literal per lane; its command is found by a binary search over the
-    //     step's first-literal indices kept in LDS).  The bits of a step are
-    //     OR-ed into an LDS window (ds_or) and leave as whole dwords with plain
-    //     coalesced stores; only a step whose span exceeds the window (a very
-    //     long literal run) goes to HBM with dword atomics.
-    uint32_t* s_start = lds_store;        // [65]
-    uint32_t* s_base = lds_store + 65;    // [64] bit offset of literal 0 of the stream as seen from command c
-    uint32_t* W = lds_store + 132;        // [STORE_WIN_DW + 4] output window
-    const uint64_t bit_cmds = sink.bitpos;
-    uint64_t wbit = bit_cmds & ~(uint64_t)31;   // bit position of W[0]
-    for (uint32_t j = (uint32_t)lane; j < STORE_WIN_DW + 4u; j += 64) W[j] = 0;
-    wave_mem_barrier();                   // header atomics have landed
-    if (lane == 0) W[0] = glb_atomic_or(sink.base + (wbit >> 5), 0u);
+    const uint32_t incl = wave_incl_scan(nb);
+    if (k < k1) s.lsum[k] = carry + incl - nb;
+    carry += wave_bcast(incl, 63);
+  }
+  return carry;
+}
+
+// Bits of literals [0, k): the array itself when one wave wrote it (lsum[nlits] = the total), or, for a meta-block
+// written in parts (k_wide.h), the sum inside the literal's part + the part's offset.
+struct LitSums {
+  const uint32_t* lsum;
+  const uint32_t* part_off;      // nullptr: lsum[] holds absolute sums
+  uint32_t nlits, total;
+};
+template <bool PARTS>
+DEV uint32_t lit_sum(const LitSums& a, uint32_t k) {
+  if (!PARTS) return a.lsum[k];
+  return k >= a.nlits ? a.total : a.lsum[k] + a.part_off[k / WIDE_LIT_PART];
+}
+
+// phase 3 (b): commands [c0, c1) of the meta-block, 64 per step: command / distance codes per lane, a wave scan
+// for their offsets, then the literals of the step written flat (one literal per lane; its command is found by a
+// binary search over the step's first-literal indices kept in LDS).  The bits of a step are OR-ed into an LDS
+// window (ds_or) and leave as whole dwords with plain coalesced stores; only a step whose span exceeds the window
+// (a very long literal run) goes to HBM with dword atomics.
+// The range starts `cbits` bits of command / distance codes behind `bit_cmds`, at literal `lit_base` and distance
+// `dist_base`.  PARTS: neighbouring ranges are written by other waves at the same time — the first and the last
+// dword of the range are shared with them and go out as atomic ORs (the output is zero where nothing was written).
+// Returns cbits behind the range.
+template <bool PARTS>
+DEV uint32_t store_commands(const StoreCtx& s, uint32_t* sink_base, uint64_t bit_cmds, uint32_t c0, uint32_t c1,
+                            uint32_t cbits, uint32_t lit_base, uint32_t dist_base, const LitSums& LS, uint32_t* lds_store) {
+  const int lane = wave_lane();
+  uint32_t* s_start = lds_store;        // [65]
+  uint32_t* s_base = lds_store + 65;    // [64] bit offset of literal 0 of the stream as seen from command c
+  uint32_t* W = lds_store + 132;        // [STORE_WIN_DW + 4] output window
+  uint64_t wbit = (bit_cmds + cbits + lit_sum<PARTS>(LS, lit_base)) & ~(uint64_t)31;   // bit position of W[0]
+  for (uint32_t j = (uint32_t)lane; j < STORE_WIN_DW + 4u; j += 64) W[j] = 0;
+  bool shared_head = PARTS;             // W[0] is a dword other waves write to as well: it leaves as an atomic OR
+  if (!PARTS) {
+    wave_mem_barrier();                 // header atomics have landed
+    if (lane == 0) W[0] = glb_atomic_or(sink_base + (wbit >> 5), 0u);
+  }
+  wave_sync();
+  for (uint32_t base = c0; base < c1; base += 64) {
+    const uint32_t i = base + (uint32_t)lane;
+    const bool valid = i < c1;
+    Command c;
+    c.insert_len = 0; c.copy_len = 0; c.dist_extra = 0; c.cmd_prefix = 0; c.dist_prefix = 0;
+    if (valid) c = s.cmds[i];
+    const uint32_t ins = c.insert_len;
+    const uint32_t cpy = c.copy_len & 0x1FFFFFFu;
+    const bool has_dist = valid && cpy != 0 && c.cmd_prefix >= 128;
+    const uint64_t dm = wave_ballot(has_dist);
+    const uint32_t ins_incl = wave_incl_scan(ins);
+    const uint32_t my_lit = lit_base + ins_incl - ins;
+    const uint32_t my_dist = dist_base + (uint32_t)dev_popc64(dm & ((1ull << lane) - 1ull));
+    // command symbol + extra bits (StoreCommandExtra :82-93), distance symbol + extra
+    uint64_t xv = 0;
+    uint32_t cn = 0, xn = 0, dn = 0, dxn = 0;
+    SymBits cb, db;
+    cb.sw = db.sw = 0; cb.nsw = db.nsw = cb.code = db.code = cb.ncode = db.ncode = 0;
+    uint32_t ls = 0, le = 0;
+    if (valid) {
+      cb = symbol_bits<1>(s, i, c.cmd_prefix, 0);
+      cn = cb.nsw + cb.ncode;
+      const uint32_t copylen_code = cmd_copy_len_code(c);
+      const uint32_t inscode = insert_length_code(ins);
+      const uint32_t copycode = copy_length_code(copylen_code);
+      const uint32_t insnumextra = k_ins_extra[inscode];
+      xv = ((uint64_t)(copylen_code - k_copy_base[copycode]) << insnumextra) |
+           (uint64_t)(ins - k_ins_base[inscode]);
+      xn = insnumextra + k_copy_extra[copycode];
+      ls = lit_sum<PARTS>(LS, my_lit);
+      le = lit_sum<PARTS>(LS, my_lit + ins);
+    }
+    if (has_dist) {
+      db = symbol_bits<2>(s, my_dist, c.dist_prefix & 0x3FFu, 0);
+      dn = db.nsw + db.ncode;
+      dxn = c.dist_prefix >> 10;
+    }
+    const uint32_t own = cn + xn + dn + dxn;
+    const uint32_t own_incl = wave_incl_scan(own);
+    // bits before this command = codes of earlier commands + literals before its first literal
+    const uint64_t p0 = bit_cmds + cbits + (own_incl - own) + ls;
+    const uint32_t total_ins = wave_bcast(ins_incl, 63);
+    const uint32_t total_own = wave_bcast(own_incl, 63);
+    const uint64_t span_end = bit_cmds + cbits + total_own + lit_sum<PARTS>(LS, lit_base + total_ins);
+    const bool in_window = span_end - wbit <= (uint64_t)STORE_WIN_DW * 32u;
+    s_start[lane] = my_lit;
+    s_base[lane] = (uint32_t)(p0 + cn + xn - bit_cmds) - ls;
+    if (lane == 63) s_start[64] = lit_base + total_ins;
+    if (!in_window) {
+      // hand the partial dword back to memory; this step uses HBM atomics
+      if (lane == 0 && W[0]) glb_atomic_or(sink_base + (wbit >> 5), W[0]);
+      if (lane == 0) W[0] = 0;
+    }
     wave_sync();
-    uint32_t lit_base = 0, dist_base = 0, cbits = 0;
-    for (uint32_t base = 0; base < ncmds; base += 64) {
-      const uint32_t i = base + (uint32_t)lane;
-      const bool valid = i < ncmds;
-      Command c;
-      c.insert_len = 0; c.copy_len = 0; c.dist_extra = 0; c.cmd_prefix = 0; c.dist_prefix = 0;
-      if (valid) c = s.cmds[i];
-      const uint32_t ins = c.insert_len;
-      const uint32_t cpy = c.copy_len & 0x1FFFFFFu;
-      const bool has_dist = valid && cpy != 0 && c.cmd_prefix >= 128;
-      const uint64_t dm = wave_ballot(has_dist);
-      const uint32_t ins_incl = wave_incl_scan(ins);
-      const uint32_t my_lit = lit_base + ins_incl - ins;
-      const uint32_t my_dist = dist_base + (uint32_t)dev_popc64(dm & ((1ull << lane) - 1ull));
-      // command symbol + extra bits (StoreCommandExtra :82-93), distance symbol + extra
-      uint64_t xv = 0;
-      uint32_t cn = 0, xn = 0, dn = 0, dxn = 0;
-      SymBits cb, db;
-      cb.sw = db.sw = 0; cb.nsw = db.nsw = cb.code = db.code = cb.ncode = db.ncode = 0;
-      uint32_t ls = 0, le = 0;
+    const uint64_t pd = p0 + cn + xn + (le - ls);
+    if (in_window) {
       if (valid) {
-        cb = symbol_bits<1>(s, i, c.cmd_prefix, 0);
-        cn = cb.nsw + cb.ncode;
-        const uint32_t copylen_code = cmd_copy_len_code(c);
-        const uint32_t inscode = insert_length_code(ins);
-        const uint32_t copycode = copy_length_code(copylen_code);
-        const uint32_t insnumextra = k_ins_extra[inscode];
-        xv = ((uint64_t)(copylen_code - k_copy_base[copycode]) << insnumextra) |
-             (uint64_t)(ins - k_ins_base[inscode]);
-        xn = insnumextra + k_copy_extra[copycode];
-        ls = lsum[my_lit];
-        le = lsum[my_lit + ins];
+        lds_or_bits(W, (uint32_t)(p0 - wbit), cb.nsw, cb.sw);
+        lds_or_bits(W, (uint32_t)(p0 - wbit) + cb.nsw, cb.ncode, cb.code);
+        lds_or_bits(W, (uint32_t)(p0 - wbit) + cn, xn, xv);
       }
       if (has_dist) {
-        db = symbol_bits<2>(s, my_dist, c.dist_prefix & 0x3FFu, 0);
-        dn = db.nsw + db.ncode;
-        dxn = c.dist_prefix >> 10;
+        lds_or_bits(W, (uint32_t)(pd - wbit), db.nsw, db.sw);
+        lds_or_bits(W, (uint32_t)(pd - wbit) + db.nsw, db.ncode, db.code);
+        lds_or_bits(W, (uint32_t)(pd - wbit) + dn, dxn, c.dist_extra);
       }
-      const uint32_t own = cn + xn + dn + dxn;
-      const uint32_t own_incl = wave_incl_scan(own);
-      // bits before this command = codes of earlier commands + literals before its first literal
-      const uint64_t p0 = bit_cmds + cbits + (own_incl - own) + ls;
-      const uint32_t total_ins = wave_bcast(ins_incl, 63);
-      const uint32_t total_own = wave_bcast(own_incl, 63);
-      const uint64_t span_end = bit_cmds + cbits + total_own + lsum[lit_base + total_ins];
-      const bool in_window = span_end - wbit <= (uint64_t)STORE_WIN_DW * 32u;
-      s_start[lane] = my_lit;
-      s_base[lane] = (uint32_t)(p0 + cn + xn - bit_cmds) - ls;
-      if (lane == 63) s_start[64] = lit_base + total_ins;
-      if (!in_window) {
-        // hand the partial dword back to memory; this step uses HBM atomics
-        if (lane == 0 && W[0]) glb_atomic_or(sink.base + (wbit >> 5), W[0]);
-        if (lane == 0) W[0] = 0;
+    } else {
+      if (valid) {
+        or_sym(sink_base, p0, cb);
+        or_bits(sink_base, p0 + cn, xn, xv);
       }
-      wave_sync();
-      const uint64_t pd = p0 + cn + xn + (le - ls);
-      if (in_window) {
-        if (valid) {
-          lds_or_bits(W, (uint32_t)(p0 - wbit), cb.nsw, cb.sw);
-          lds_or_bits(W, (uint32_t)(p0 - wbit) + cb.nsw, cb.ncode, cb.code);
-          lds_or_bits(W, (uint32_t)(p0 - wbit) + cn, xn, xv);
-        }
-        if (has_dist) {
-          lds_or_bits(W, (uint32_t)(pd - wbit), db.nsw, db.sw);
-          lds_or_bits(W, (uint32_t)(pd - wbit) + db.nsw, db.ncode, db.code);
-          lds_or_bits(W, (uint32_t)(pd - wbit) + dn, dxn, c.dist_extra);
-        }
-      } else {
-        if (valid) {
-          or_sym(sink.base, p0, cb);
-          or_bits(sink.base, p0 + cn, xn, xv);
-        }
-        if (has_dist) {
-          or_sym(sink.base, pd, db);
-          or_bits(sink.base, pd + dn, dxn, c.dist_extra);
-        }
+      if (has_dist) {
+        or_sym(sink_base, pd, db);
+        or_bits(sink_base, pd + dn, dxn, c.dist_extra);
       }
-      for (uint32_t L = lit_base + (uint32_t)lane; L < lit_base + total_ins; L += 64) {
-        uint32_t lo = 0, hi = 63;
-        while (lo < hi) {
-          const uint32_t mid = (lo + hi + 1) >> 1;
-          if (s_start[mid] <= L) lo = mid; else hi = mid - 1;
-        }
-        const uint64_t pos = bit_cmds + s_base[lo] + lsum[L];
-        SymBits lb;
-        lb.sw = 0; lb.nsw = 0;
-        if ((L % MB_LIT_MIN_BLOCK) == 0 && L != 0) {
-          // possibly the first literal of a block: re-derive the block switch
-          const uint32_t v = s.lits[L];
-          lb = symbol_bits<0>(s, L, v & 0xFFu, v >> 8);
-        } else {
-          const uint32_t lc = lcode[L];
-          lb.code = lc & 0xFFFFu;
-          lb.ncode = lc >> 16;
-        }
-        if (in_window) {
-          lds_or_bits(W, (uint32_t)(pos - wbit), lb.nsw, lb.sw);
-          lds_or_bits(W, (uint32_t)(pos - wbit) + lb.nsw, lb.ncode, lb.code);
-        } else {
-          or_sym(sink.base, pos, lb);
-        }
-      }
-      wave_sync();
-      if (in_window) {
-        // whole dwords leave the window; the partial one moves to W[0]
-        const uint32_t ndw = (uint32_t)((span_end - wbit) >> 5);
-        const uint32_t carry = W[ndw];
-        wave_sync();
-        uint32_t* dst = sink.base + (wbit >> 5);
-        for (uint32_t j = (uint32_t)lane; j <= ndw; j += 64) {
-          if (j < ndw) dst[j] = W[j];
-          W[j] = 0;
-        }
-        wave_sync();
-        if (lane == 0) W[0] = carry;
-        wbit += (uint64_t)ndw * 32u;
-      } else {
-        wave_mem_barrier();
-        wbit = span_end & ~(uint64_t)31;
-        if (lane == 0) W[0] = glb_atomic_or(sink.base + (wbit >> 5), 0u);
-      }
-      wave_sync();
-      cbits += total_own;
-      lit_base += total_ins;
-      dist_base += (uint32_t)dev_popc64(dm);
     }
-    sink.bitpos = bit_cmds + cbits + lsum[nlits];
-    // the last partial dword
-    if (lane == 0 && W[0]) sink.base[wbit >> 5] = W[0];
+    for (uint32_t L = lit_base + (uint32_t)lane; L < lit_base + total_ins; L += 64) {
+      uint32_t lo = 0, hi = 63;
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi + 1) >> 1;
+        if (s_start[mid] <= L) lo = mid; else hi = mid - 1;
+      }
+      const uint64_t pos = bit_cmds + s_base[lo] + lit_sum<PARTS>(LS, L);
+      SymBits lb;
+      lb.sw = 0; lb.nsw = 0;
+      if ((L % MB_LIT_MIN_BLOCK) == 0 && L != 0) {
+        // possibly the first literal of a block: re-derive the block switch
+        const uint32_t v = s.lits[L];
+        lb = symbol_bits<0>(s, L, v & 0xFFu, v >> 8);
+      } else {
+        const uint32_t lc = s.lcode[L];
+        lb.code = lc & 0xFFFFu;
+        lb.ncode = lc >> 16;
+      }
+      if (in_window) {
+        lds_or_bits(W, (uint32_t)(pos - wbit), lb.nsw, lb.sw);
+        lds_or_bits(W, (uint32_t)(pos - wbit) + lb.nsw, lb.ncode, lb.code);
+      } else {
+        or_sym(sink_base, pos, lb);
+      }
+    }
     wave_sync();
-    SP_ADD(S, 5, spt);
-    if (is_last && !stream) sink.bitpos = (sink.bitpos + 7u) & ~(uint64_t)7u;
-    total_bits = sink.bitpos - bit0;
+    if (in_window) {
+      // whole dwords leave the window; the partial one moves to W[0]
+      const uint32_t ndw = (uint32_t)((span_end - wbit) >> 5);
+      const uint32_t carry = W[ndw];
+      wave_sync();
+      uint32_t* dst = sink_base + (wbit >> 5);
+      for (uint32_t j = (uint32_t)lane; j <= ndw; j += 64) {
+        if (j < ndw) {
+          if (PARTS && j == 0u && shared_head) { if (W[0]) glb_atomic_or(dst, W[0]); }
+          else dst[j] = W[j];
+        }
+        W[j] = 0;
+      }
+      wave_sync();
+      if (lane == 0) W[0] = carry;
+      if (ndw != 0) shared_head = false;
+      wbit += (uint64_t)ndw * 32u;
+    } else {
+      wave_mem_barrier();
+      wbit = span_end & ~(uint64_t)31;
+      if (!PARTS) { if (lane == 0) W[0] = glb_atomic_or(sink_base + (wbit >> 5), 0u); }
+      else shared_head = true;          // (what the dword holds stays in memory: this wave's bits are OR-ed to it)
+    }
     wave_sync();
+    cbits += total_own;
+    lit_base += total_ins;
+    dist_base += (uint32_t)dev_popc64(dm);
+  }
+  // the last partial dword
+  if (!PARTS) { if (lane == 0 && W[0]) sink_base[wbit >> 5] = W[0]; }
+  else if (lane == 0 && W[0]) glb_atomic_or(sink_base + (wbit >> 5), W[0]);
+  wave_sync();
+  return cbits;
+}
+
+// What follows the command stream: the size check (encode.c:604-613), the raw fallback, the state update of
+// WriteMetaBlockInternal / EncodeData (encode.c:598-614, 1188-1216).  total_bits: bits written behind `out +
+// r.out_bytes`, the carried bits included (a compressed meta-block; ignored for one ShouldCompress refused).
+DEV void store_finish(const JobParams& J, const ShardDesc& D, ShardState* S, RoundRegs& r, int32_t* dc, const uint8_t* data,
+                      uint8_t* out, bool raw, uint64_t total_bits, uint64_t zero_bytes) {
+  const int lane = wave_lane();
+  const uint32_t start = S->mb_start, bytes = S->mb_bytes;
+  const bool is_last = S->mb_is_last != 0, force_flush = S->mb_force_flush != 0;
+  const bool stream = (J.flags & JOB_FLAG_STREAMT) != 0;
+  if (!raw) {
     // encode.c:604-613: larger than the input + 4 bytes -> store uncompressed.
     if (!stream) {
       if ((uint64_t)bytes + 4u < (total_bits >> 3)) raw = true;
@@ -754,7 +760,6 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
       if (lane == 0) S->mb_was_raw = (uint64_t)bytes + 4u < lo ? 1u : (uint64_t)bytes + 4u < hi ? 2u : 0u;
     }
   }
-
   if (raw) {
     zero_output(out, r.out_bytes, zero_bytes);
     for (int i = 0; i < 4; ++i) dc[i] = r.saved_dc[i];
@@ -796,6 +801,76 @@ DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     S->done = done ? 1u : 0u;
   }
   wave_sync();
+}
+
+DEV void store_round(const JobParams& J, const ShardDesc& D, ShardState* S,
+                     const DeviceTables* T, const uint8_t* input, uint8_t* ws, uint32_t* lds_store) {
+  const int lane = wave_lane();
+  if (!S->mb_valid || S->error) return;
+  const uint8_t* data = input + D.in_off;
+  uint8_t* out = ws + D.out_off;
+  RoundRegs r;
+  regs_load(r, S);
+  int32_t dc[4];
+  for (int i = 0; i < 4; ++i) dc[i] = S->dist_cache[i];
+  const uint32_t bytes = S->mb_bytes;
+  const bool is_last = S->mb_is_last != 0;
+  const bool raw = S->mb_raw != 0;
+  // A meta-block of a tiled stream (JOB_FLAG_STREAMT) is written as if it began at bit 0 and moved to its place
+  // afterwards (k_stream_place).  A raw one is not written here at all (its payload is byte aligned in the STREAM):
+  // mb_was_raw = 1 tells k_stream_scan / k_stream_place, which emit it; 2 = the size comparison depends on the bit the
+  // meta-block starts at, k_stream_scan decides.
+  const bool stream = (J.flags & JOB_FLAG_STREAMT) != 0;
+  if (stream && raw) {
+    wave_sync();                 // (every lane has read the state by now)
+    if (lane == 0) { S->mb_was_raw = 1; S->mb_valid = 0; }
+    wave_sync();
+    return;
+  }
+
+  // Everything this meta-block can touch, zeroed; then the carried bits.
+  const uint64_t zero_bytes = 2ull * bytes + 520ull;
+  if (r.out_bytes + zero_bytes + 16 > D.out_cap) {
+    if (lane == 0) S->error = 2;
+    return;
+  }
+  uint64_t total_bits = 0;   // relative to out + r.out_bytes, carried bits included
+  uint64_t spt = SP_NOW();
+
+  if (!raw) {
+    zero_output(out, r.out_bytes, zero_bytes);
+    StoreCtx s;
+    StoreMeta M;
+    store_ctx_init(s, M, J, D, input, ws);
+    SP_ADD(S, 0, spt);
+    uint32_t cmap_nrle = 0, cmap_max_prefix = 0;
+    store_small_histos(s, M, lds_store, cmap_nrle, cmap_max_prefix);
+    SP_ADD(S, 1, spt);
+    for (uint32_t j = 0; j < M.njobs; ++j) store_code_job(s, M, j, cmap_max_prefix, lds_store);
+    wave_sync();
+    SP_ADD(S, 2, spt);
+    store_switch_codes(s, M);
+    SP_ADD(S, 3, spt);
+    BitSink sink;
+    sink.base = (uint32_t*)(out + (r.out_bytes & ~(uint64_t)3));
+    sink.bitpos = (r.out_bytes & 3) * 8;
+    const uint64_t bit0 = sink.bitpos;
+    store_header(s, M, sink, r.last_bytes, r.last_bytes_bits, bytes, is_last, cmap_nrle, cmap_max_prefix);
+    SP_ADD(S, 4, spt);
+    const uint32_t nlits = s.info->nlits;
+    const uint32_t lit_bits = store_literal_codes(s, 0u, nlits, 0u);
+    if (lane == 0) s.lsum[nlits] = lit_bits;
+    wave_sync();
+    LitSums LS;
+    LS.lsum = s.lsum; LS.part_off = nullptr; LS.nlits = nlits; LS.total = lit_bits;
+    const uint32_t cbits = store_commands<false>(s, sink.base, sink.bitpos, 0u, M.ncmds, 0u, 0u, 0u, LS, lds_store);
+    sink.bitpos += (uint64_t)cbits + lit_bits;
+    SP_ADD(S, 5, spt);
+    if (is_last && !stream) sink.bitpos = (sink.bitpos + 7u) & ~(uint64_t)7u;
+    total_bits = sink.bitpos - bit0;
+    wave_sync();
+  }
+  store_finish(J, D, S, r, dc, data, out, raw, total_bits, zero_bytes);
 }
 
 #endif  // BROTLI_AMD_CSRC_K_STORE_H_

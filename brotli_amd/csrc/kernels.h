@@ -30,6 +30,7 @@
 #endif
 #include "k_build.h"
 #include "k_store.h"
+#include "k_wide.h"
 
 struct JobArgs {
   JobParams J;
@@ -329,6 +330,110 @@ __global__ void __launch_bounds__(64, STORE_WAVES) k_store(JobArgs a) {
     if (a.states[shard].error) glb_atomic_add(&a.counters[1], 1u);
     else if (!a.states[shard].done) glb_atomic_add(&a.counters[0], 1u);
   }
+}
+
+// ---- a long meta-block on many waves (k_wide.h); grids: nshards, nshards * WIDE_K ("x K") or nshards * 3 ----
+#define WIDE_BUILD_LDS \
+  __shared__ uint32_t lds[BUILD_LDS_WORDS]; \
+  __shared__ double lds_ent[4 + 3 * 13 + 1]; \
+  __shared__ double lds_last[2 * 13]; \
+  __shared__ double lds_terms[BUILD_TERMS + 2];
+__global__ void __launch_bounds__(64) k_wide_head(JobArgs a) {
+  const uint32_t m = blockIdx.x;
+  if (m >= a.nshards) return;
+  WIDE_BUILD_LDS
+  wide_head(a.J, a.shards[m], &a.states[m], a.T, a.input, a.ws, lds, lds_ent, lds_last, lds_terms);
+}
+__global__ void __launch_bounds__(64) k_wide_count(JobArgs a) {
+  const uint32_t m = blockIdx.x / WIDE_K;
+  if (m >= a.nshards) return;
+  wide_count(a.J, a.shards[m], &a.states[m], a.ws, blockIdx.x % WIDE_K);
+}
+__global__ void __launch_bounds__(64) k_wide_scan1(JobArgs a) {
+  const uint32_t m = blockIdx.x;
+  if (m >= a.nshards) return;
+  wide_scan1(a.J, a.shards[m], &a.states[m], a.ws);
+}
+__global__ void __launch_bounds__(64) k_wide_streams(JobArgs a) {
+  const uint32_t m = blockIdx.x / WIDE_K;
+  if (m >= a.nshards) return;
+  __shared__ uint32_t lds[132];
+  wide_streams(a.J, a.shards[m], &a.states[m], a.T, a.input, a.ws, blockIdx.x % WIDE_K, lds);
+}
+__global__ void __launch_bounds__(64) k_wide_split(JobArgs a) {
+  const uint32_t m = blockIdx.x / 3u;
+  if (m >= a.nshards) return;
+  WIDE_BUILD_LDS
+  wide_split(a.J, a.shards[m], &a.states[m], a.T, a.input, a.ws, blockIdx.x % 3u, lds, lds_ent, lds_last, lds_terms);
+}
+__global__ void __launch_bounds__(64) k_wide_prep(JobArgs a) {
+  const uint32_t m = blockIdx.x;
+  if (m >= a.nshards) return;
+  WIDE_BUILD_LDS
+  wide_prep(a.J, a.shards[m], &a.states[m], a.T, a.input, a.ws, lds, lds_ent, lds_last, lds_terms);
+}
+__global__ void __launch_bounds__(64) k_wide_codes(JobArgs a) {
+  const uint32_t m = blockIdx.x / WIDE_K;
+  if (m >= a.nshards) return;
+  __shared__ uint32_t lds_store[STORE_LDS_WORDS];
+  wide_codes(a.J, a.shards[m], &a.states[m], a.input, a.ws, blockIdx.x % WIDE_K, lds_store);
+}
+__global__ void __launch_bounds__(64) k_wide_header(JobArgs a) {
+  const uint32_t m = blockIdx.x;
+  if (m >= a.nshards) return;
+  wide_header(a.J, a.shards[m], &a.states[m], a.input, a.ws);
+}
+__global__ void __launch_bounds__(64) k_wide_bits(JobArgs a) {
+  const uint32_t m = blockIdx.x / WIDE_K;
+  if (m >= a.nshards) return;
+  wide_bits(a.J, a.shards[m], &a.states[m], a.input, a.ws, blockIdx.x % WIDE_K);
+}
+__global__ void __launch_bounds__(64) k_wide_scan2(JobArgs a) {
+  const uint32_t m = blockIdx.x;
+  if (m >= a.nshards) return;
+  wide_scan2(a.J, a.shards[m], &a.states[m], a.ws);
+}
+__global__ void __launch_bounds__(64) k_wide_emit(JobArgs a) {
+  const uint32_t m = blockIdx.x / WIDE_K;
+  if (m >= a.nshards) return;
+  __shared__ uint32_t lds_store[STORE_LDS_WORDS];
+  wide_emit(a.J, a.shards[m], &a.states[m], a.input, a.ws, blockIdx.x % WIDE_K, lds_store);
+}
+__global__ void __launch_bounds__(64) k_wide_tail(JobArgs a) {
+  const uint32_t m = blockIdx.x;
+  if (m >= a.nshards) return;
+  wide_tail(a.J, a.shards[m], &a.states[m], a.input, a.ws);
+  if (threadIdx.x == 0) {
+    if (a.states[m].error) glb_atomic_add(&a.counters[1], 1u);
+    else if (!a.states[m].done) glb_atomic_add(&a.counters[0], 1u);
+  }
+}
+
+// The build + store stage of a round over `n` meta-blocks (shards of a plan, or the meta-blocks of a tiled stream):
+// one wave per meta-block (k_build, k_store), or — `wide` — the kernels of k_wide.h.  One routine for the HIP layer
+// and the simulator's drivers (R::operator()(kernel, args, grid, block) launches; `mid` runs between the half that
+// models and the half that writes, where the HIP layer records its event).
+template <class R, class Mid>
+static inline void run_build_store(R& run, const JobArgs& m, uint32_t n, bool wide, Mid mid) {
+  if (!wide) {
+    run(k_build, m, n, 64u);
+    mid();
+    run(k_store, m, n, 64u);
+    return;
+  }
+  run(k_wide_head, m, n, 64u);
+  run(k_wide_count, m, n * WIDE_K, 64u);
+  run(k_wide_scan1, m, n, 64u);
+  run(k_wide_streams, m, n * WIDE_K, 64u);
+  run(k_wide_split, m, n * 3u, 64u);
+  run(k_wide_prep, m, n, 64u);
+  mid();
+  run(k_wide_codes, m, n * WIDE_K, 64u);
+  run(k_wide_header, m, n, 64u);
+  run(k_wide_bits, m, n * WIDE_K, 64u);
+  run(k_wide_scan2, m, n, 64u);
+  run(k_wide_emit, m, n * WIDE_K, 64u);
+  run(k_wide_tail, m, n, 64u);
 }
 
 // grid = 1, block = 1024: exclusive scan of the shard output sizes.

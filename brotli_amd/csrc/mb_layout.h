@@ -41,6 +41,17 @@ struct MbInfo {
   uint32_t njobs;
   uint32_t cmap_nrle, cmap_max_prefix;
   SplitHeader split[3];   // 0 literal, 1 command, 2 distance
+  // a meta-block built and written in parts (k_wide.h): what its kernels hand to each other
+  uint32_t wide_bit0, wide_bit_cmds;      // bit (relative to the output dword the meta-block starts in) of its first bit / of its command stream
+  uint32_t wide_lit_bits, wide_cmd_bits;  // bits of all literals (block switches included) / of all command + distance codes
+};
+
+// A meta-block in parts (k_wide.h): WIDE_CMD_PART commands / WIDE_LIT_PART literals per part, a part per wave at a time.
+#define WIDE_CMD_PART 4096u
+#define WIDE_LIT_PART 4096u
+struct WidePart {
+  uint32_t ins, adv, ndist, bits;                    // totals of the part: literals, bytes, distance symbols, bits of its command + distance codes
+  uint32_t lit_off, pos_off, dist_off, bit_off;      // the same summed over the parts before it
 };
 
 struct MbLayout {
@@ -57,6 +68,9 @@ struct MbLayout {
   uint64_t jobs;         // TreeJob[max_jobs]
   uint64_t tree_bufs;    // u8[max_jobs][MB_TREE_BUF_BYTES]
   uint64_t lane_scratch; // u8[64][MB_LANE_SCRATCH_BYTES]
+  uint64_t parts;        // WidePart[max command parts]
+  uint64_t lparts;       // u32[2][max literal parts + 1]: bits of a literal part, bits of the parts before it
+  uint64_t max_lparts;
   uint64_t max_histos[3];
   uint64_t max_jobs;
   uint64_t total;
@@ -115,6 +129,9 @@ MB_HD static inline void mb_layout(uint64_t len, MbLayout* L) {
   L->jobs = off;         off = mb_al(off + jobs * sizeof(TreeJob));
   L->tree_bufs = off;    off = mb_al(off + jobs * MB_TREE_BUF_BYTES);
   L->lane_scratch = off; off = mb_al(off + 64u * (uint64_t)MB_LANE_SCRATCH_BYTES);
+  L->parts = off;        off = mb_al(off + ((len / 2 + (len >> 14) + 64) / WIDE_CMD_PART + 2) * sizeof(WidePart));
+  L->max_lparts = len / WIDE_LIT_PART + 2;
+  L->lparts = off;       off = mb_al(off + 2 * L->max_lparts * 4);
   L->total = off;
 }
 
