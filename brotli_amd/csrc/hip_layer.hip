@@ -382,6 +382,30 @@ struct DeviceScope {
 
 enum { STAGE_PARSE = 1, STAGE_BUILD = 2, STAGE_STORE = 4, STAGE_ALL = 7 };
 
+// What run_build_store (kernels.h) launches through.
+struct HipRun {
+  hipStream_t stream;
+  void operator()(void (*fn)(JobArgs), const JobArgs& a, uint32_t grid, uint32_t block) const {
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(block), 0, stream, a);
+  }
+};
+// Meta-blocks of `longest` bytes at most: one wave each (k_build / k_store: returns 0), or spread over K waves
+// (k_wide.h: returns K)?  One wave needs ~14 ms per MiB of text for the two kernels together; the twelve launches of
+// the many-wave kernels pay from a few hundred KiB on.  K = a wave per 32 KiB (a part of 4096 commands is about
+// that much text), 64 at most.  BROTLI_AMD_WIDE=0 / 1 overrides the choice, BROTLI_AMD_WIDE_KB moves the bound,
+// BROTLI_AMD_WIDE_K sets K (experiments).
+uint32_t use_wide(const JobParams& J, uint64_t longest) {
+  bool wide = J.quality >= 5;
+  uint64_t bound = 512u << 10;
+  if (const char* e = getenv("BROTLI_AMD_WIDE_KB")) { const long v = atol(e); if (v > 0 && v <= (1 << 20)) bound = (uint64_t)v << 10; }
+  wide = wide && longest >= bound;
+  if (const char* e = getenv("BROTLI_AMD_WIDE")) wide = atoi(e) != 0;
+  if (!wide) return 0u;
+  uint64_t k = (longest + (32u << 10) - 1u) / (32u << 10);
+  if (const char* e = getenv("BROTLI_AMD_WIDE_K")) { const int v = atoi(e); if (v >= 1) k = (uint64_t)v; }
+  return k < 1u ? 1u : k > WIDE_K_MAX ? WIDE_K_MAX : (uint32_t)k;
+}
+
 // Runs the job's rounds on the context stream.  On return (synchronised) the
 // shard states describe the outputs sitting in the workspace.
 bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
@@ -404,6 +428,9 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
   a.counters = c->d_counters;
   a.cd = c->d_cd;
   const bool tiled = (plan.J.flags & JOB_FLAG_TILED) != 0;
+  uint64_t longest_shard = 0;
+  for (const ShardDesc& D : plan.shards) if (D.len > longest_shard) longest_shard = D.len;
+  const uint32_t wide = use_wide(plan.J, longest_shard < plan.J.max_metablock_size ? longest_shard : plan.J.max_metablock_size);
   const uint32_t ntiles = (uint32_t)plan.tiles.size();
   uint32_t tile_sweeps = 0, tile_bad = 0;
   if (tiled) {
@@ -566,9 +593,15 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       hipLaunchKernelGGL(k_parse, dim3(nshards), dim3(64), 0, c->stream, a);
     if (indexed && !tiled) hipLaunchKernelGGL(k_cmd_encode, dim3(nshards * CE_SPLIT), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev[3], c->stream));
-    if (stages & STAGE_BUILD) hipLaunchKernelGGL(k_build, dim3(nshards), dim3(64), 0, c->stream, a);
-    HIP_OK(c, hipEventRecord(c->ev[4], c->stream));
-    if (stages & STAGE_STORE) hipLaunchKernelGGL(k_store, dim3(nshards), dim3(64), 0, c->stream, a);
+    if ((stages & (STAGE_BUILD | STAGE_STORE)) == (STAGE_BUILD | STAGE_STORE)) {
+      HipRun R{c->stream};
+      hipError_t ev_err = hipSuccess;
+      run_build_store(R, a, nshards, wide, [&]() { ev_err = hipEventRecord(c->ev[4], c->stream); });
+      HIP_OK(c, ev_err);
+    } else {
+      if (stages & STAGE_BUILD) hipLaunchKernelGGL(k_build, dim3(nshards), dim3(64), 0, c->stream, a);
+      HIP_OK(c, hipEventRecord(c->ev[4], c->stream));
+    }
     HIP_OK(c, hipEventRecord(c->ev[5], c->stream));
     uint32_t counters[16];
     HIP_OK(c, hipMemcpyAsync(counters, c->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
@@ -837,9 +870,11 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     m.shards = c->d_mdesc;
     m.states = c->d_mstate;
     m.nshards = nmb;
-    hipLaunchKernelGGL(k_build, dim3(nmb), dim3(64), 0, c->stream, m); each("k_build");
-    HIP_OK(c, hipEventRecord(c->ev[4], c->stream));
-    hipLaunchKernelGGL(k_store, dim3(nmb), dim3(64), 0, c->stream, m); each("k_store");
+    HipRun R{c->stream};
+    hipError_t ev_err = hipSuccess;
+    run_build_store(R, m, nmb, use_wide(plan.J, plan.J.max_metablock_size), [&]() { ev_err = hipEventRecord(c->ev[4], c->stream); each("build half"); });
+    HIP_OK(c, ev_err);
+    each("store half");
     HIP_OK(c, hipEventRecord(c->ev[5], c->stream));
   }
   lap("build+store");
@@ -1361,8 +1396,10 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
     else if (J.block_bits <= 6) hipLaunchKernelGGL(k_parse_deep<1>, dim3(1), dim3(64), 0, c->stream, a);
     else if (J.block_bits == 7) hipLaunchKernelGGL(k_parse_deep<2>, dim3(1), dim3(64), 0, c->stream, a);
     else hipLaunchKernelGGL(k_parse_deep<4>, dim3(1), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_build, dim3(1), dim3(64), 0, c->stream, a);
-    hipLaunchKernelGGL(k_store, dim3(1), dim3(64), 0, c->stream, a);
+    {
+      HipRun R{c->stream};
+      run_build_store(R, a, 1u, use_wide(J, J.max_metablock_size), []() {});
+    }
     uint32_t counters[16];
     HIP_OK(c, hipMemcpyAsync(counters, s->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(c, hipStreamSynchronize(c->stream));

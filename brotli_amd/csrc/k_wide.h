@@ -13,7 +13,7 @@
 // build_streams_range, ...): the bits are the same whichever way a meta-block is written, and the simulator tests
 // run both ways against the oracle.
 //
-// Kernels, in launch order (kernels.h; "x K" = grid of nmb * WIDE_K waves, wave k of a meta-block takes the parts
+// Kernels, in launch order (kernels.h; "x K" = grid of nmb * K waves, K = JobArgs::wide_k <= WIDE_K_MAX, wave k of a meta-block takes the parts
 // k, k + K, ...):
 //   k_wide_head      ShouldCompress, literal-context decision, output capacity        (build_round's first steps)
 //   k_wide_count xK  per command part: literals, bytes, distance symbols
@@ -32,7 +32,7 @@
 
 #include "k_store.h"
 
-#define WIDE_K 64u                     // waves per meta-block in the part kernels
+#define WIDE_K_MAX 64u                 // waves per meta-block in the part kernels, at most (JobArgs::wide_k)
 
 struct WideMb {
   MbInfo* info;
@@ -84,7 +84,7 @@ DEV void wide_head(const JobParams& J, const ShardDesc& D, ShardState* S, const 
   wave_sync();
 }
 
-DEV void wide_count(const JobParams& J, const ShardDesc& D, const ShardState* S, uint8_t* ws, uint32_t k) {
+DEV void wide_count(const JobParams& J, const ShardDesc& D, const ShardState* S, uint8_t* ws, uint32_t k, uint32_t K) {
   const int lane = wave_lane();
   if (!wide_live(S) || S->mb_raw) return;
   MbLayout L;
@@ -93,7 +93,7 @@ DEV void wide_count(const JobParams& J, const ShardDesc& D, const ShardState* S,
   const uint32_t ncmds = S->ncmds;
   wide_views(w, ws + D.mb_off, L, ncmds, 0u);
   const Command* cmds = (const Command*)(ws + D.cmds_off);
-  for (uint32_t p = k; p < w.nparts; p += WIDE_K) {
+  for (uint32_t p = k; p < w.nparts; p += K) {
     const uint32_t c0 = p * WIDE_CMD_PART, c1 = umin(c0 + WIDE_CMD_PART, ncmds);
     uint32_t ins = 0, adv = 0, nd = 0;
     for (uint32_t i = c0 + (uint32_t)lane; i < c1; i += 64u) {
@@ -130,7 +130,7 @@ DEV void wide_scan1(const JobParams& J, const ShardDesc& D, const ShardState* S,
 }
 
 DEV void wide_streams(const JobParams& J, const ShardDesc& D, const ShardState* S, const DeviceTables* T,
-                      const uint8_t* input, uint8_t* ws, uint32_t k, uint32_t* lds) {
+                      const uint8_t* input, uint8_t* ws, uint32_t k, uint32_t K, uint32_t* lds) {
   if (!wide_live(S) || S->mb_raw) return;
   BuildCtx b;
   build_ctx_init(b, J, D, T, input, ws, lds, nullptr, nullptr, nullptr);
@@ -139,7 +139,7 @@ DEV void wide_streams(const JobParams& J, const ShardDesc& D, const ShardState* 
   wide_views(w, b.mb, b.L, ncmds, 0u);
   b.nc = w.info->num_contexts;
   b.map_kind = w.info->map_kind;
-  for (uint32_t p = k; p < w.nparts; p += WIDE_K) {
+  for (uint32_t p = k; p < w.nparts; p += K) {
     const uint32_t c0 = p * WIDE_CMD_PART, c1 = umin(c0 + WIDE_CMD_PART, ncmds);
     uint32_t nl, nd;
     build_streams_range(b, c0, c1, S->mb_start + w.parts[p].pos_off, w.parts[p].lit_off, w.parts[p].dist_off, &nl, &nd);
@@ -178,7 +178,7 @@ DEV void wide_prep(const JobParams& J, const ShardDesc& D, const ShardState* S, 
 }
 
 DEV void wide_codes(const JobParams& J, const ShardDesc& D, const ShardState* S, const uint8_t* input, uint8_t* ws,
-                    uint32_t k, uint32_t* lds_store) {
+                    uint32_t k, uint32_t K, uint32_t* lds_store) {
   const int lane = wave_lane();
   if (!wide_live(S) || S->mb_raw) return;
   {
@@ -189,7 +189,7 @@ DEV void wide_codes(const JobParams& J, const ShardDesc& D, const ShardState* S,
     if (k == 0 && (uint64_t)lane < head) out[from + (uint64_t)lane] = 0;
     uint32_t* p = (uint32_t*)(out + from + head);
     const uint64_t nw = (bytes - head + 3) >> 2;
-    const uint64_t per = (nw + WIDE_K - 1u) / WIDE_K;
+    const uint64_t per = (nw + K - 1u) / K;
     const uint64_t lo = (uint64_t)k * per, hi = lo + per < nw ? lo + per : nw;
     for (uint64_t i = lo + (uint64_t)lane; i < hi; i += 64) p[i] = 0;
   }
@@ -197,7 +197,7 @@ DEV void wide_codes(const JobParams& J, const ShardDesc& D, const ShardState* S,
   StoreMeta M;
   store_ctx_init(s, M, J, D, input, ws);
   const uint32_t maxp = s.info->cmap_max_prefix;
-  for (uint32_t j = k; j < M.njobs; j += WIDE_K) store_code_job(s, M, j, maxp, lds_store);
+  for (uint32_t j = k; j < M.njobs; j += K) store_code_job(s, M, j, maxp, lds_store);
   wave_sync();
 }
 
@@ -233,7 +233,7 @@ DEV uint32_t wide_own_bits(const StoreCtx& s, uint32_t i, const Command& c, bool
   return n;
 }
 
-DEV void wide_bits(const JobParams& J, const ShardDesc& D, const ShardState* S, const uint8_t* input, uint8_t* ws, uint32_t k) {
+DEV void wide_bits(const JobParams& J, const ShardDesc& D, const ShardState* S, const uint8_t* input, uint8_t* ws, uint32_t k, uint32_t K) {
   const int lane = wave_lane();
   if (!wide_live(S) || S->mb_raw) return;
   StoreCtx s;
@@ -242,12 +242,12 @@ DEV void wide_bits(const JobParams& J, const ShardDesc& D, const ShardState* S, 
   WideMb w;
   const uint32_t nlits = s.info->nlits;
   wide_views(w, s.mb, s.L, M.ncmds, nlits);
-  for (uint32_t lp = k; lp < w.nlparts; lp += WIDE_K) {
+  for (uint32_t lp = k; lp < w.nlparts; lp += K) {
     const uint32_t k0 = lp * WIDE_LIT_PART, k1 = umin(k0 + WIDE_LIT_PART, nlits);
     const uint32_t t = store_literal_codes(s, k0, k1, 0u);
     if (lane == 0) w.lpart_bits[lp] = t;
   }
-  for (uint32_t p = k; p < w.nparts; p += WIDE_K) {
+  for (uint32_t p = k; p < w.nparts; p += K) {
     const uint32_t c0 = p * WIDE_CMD_PART, c1 = umin(c0 + WIDE_CMD_PART, M.ncmds);
     uint32_t dist_base = w.parts[p].dist_off, bits = 0;
     for (uint32_t base = c0; base < c1; base += 64u) {
@@ -298,7 +298,7 @@ DEV void wide_scan2(const JobParams& J, const ShardDesc& D, const ShardState* S,
 }
 
 DEV void wide_emit(const JobParams& J, const ShardDesc& D, const ShardState* S, const uint8_t* input, uint8_t* ws, uint32_t k,
-                   uint32_t* lds_store) {
+                   uint32_t K, uint32_t* lds_store) {
   if (!wide_live(S) || S->mb_raw) return;
   StoreCtx s;
   StoreMeta M;
@@ -309,7 +309,7 @@ DEV void wide_emit(const JobParams& J, const ShardDesc& D, const ShardState* S, 
   LS.lsum = s.lsum; LS.part_off = w.lpart_off; LS.nlits = s.info->nlits; LS.total = s.info->wide_lit_bits;
   uint32_t* sink_base = (uint32_t*)(ws + D.out_off + (S->out_bytes & ~(uint64_t)3));
   const uint64_t bit_cmds = s.info->wide_bit_cmds;
-  for (uint32_t p = k; p < w.nparts; p += WIDE_K) {
+  for (uint32_t p = k; p < w.nparts; p += K) {
     const uint32_t c0 = p * WIDE_CMD_PART, c1 = umin(c0 + WIDE_CMD_PART, M.ncmds);
     (void)store_commands<true>(s, sink_base, bit_cmds, c0, c1, w.parts[p].bit_off, w.parts[p].lit_off, w.parts[p].dist_off, LS, lds_store);
   }

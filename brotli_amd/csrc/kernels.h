@@ -55,6 +55,7 @@ struct JobArgs {
   uint8_t* sout = nullptr;            //   the stream's output
   uint32_t mcap = 0;
   uint32_t aux = 0;                   //   k_stream_cuts: 1 = describe the meta-blocks
+  uint32_t wide_k = 1;                // k_wide.h: waves per meta-block in the part kernels (run_build_store sets it)
 };
 
 // grid = nshards * init_blocks_per_shard, block = 256
@@ -345,9 +346,9 @@ __global__ void __launch_bounds__(64) k_wide_head(JobArgs a) {
   wide_head(a.J, a.shards[m], &a.states[m], a.T, a.input, a.ws, lds, lds_ent, lds_last, lds_terms);
 }
 __global__ void __launch_bounds__(64) k_wide_count(JobArgs a) {
-  const uint32_t m = blockIdx.x / WIDE_K;
+  const uint32_t m = blockIdx.x / a.wide_k;
   if (m >= a.nshards) return;
-  wide_count(a.J, a.shards[m], &a.states[m], a.ws, blockIdx.x % WIDE_K);
+  wide_count(a.J, a.shards[m], &a.states[m], a.ws, blockIdx.x % a.wide_k, a.wide_k);
 }
 __global__ void __launch_bounds__(64) k_wide_scan1(JobArgs a) {
   const uint32_t m = blockIdx.x;
@@ -355,10 +356,10 @@ __global__ void __launch_bounds__(64) k_wide_scan1(JobArgs a) {
   wide_scan1(a.J, a.shards[m], &a.states[m], a.ws);
 }
 __global__ void __launch_bounds__(64) k_wide_streams(JobArgs a) {
-  const uint32_t m = blockIdx.x / WIDE_K;
+  const uint32_t m = blockIdx.x / a.wide_k;
   if (m >= a.nshards) return;
   __shared__ uint32_t lds[132];
-  wide_streams(a.J, a.shards[m], &a.states[m], a.T, a.input, a.ws, blockIdx.x % WIDE_K, lds);
+  wide_streams(a.J, a.shards[m], &a.states[m], a.T, a.input, a.ws, blockIdx.x % a.wide_k, a.wide_k, lds);
 }
 __global__ void __launch_bounds__(64) k_wide_split(JobArgs a) {
   const uint32_t m = blockIdx.x / 3u;
@@ -373,10 +374,10 @@ __global__ void __launch_bounds__(64) k_wide_prep(JobArgs a) {
   wide_prep(a.J, a.shards[m], &a.states[m], a.T, a.input, a.ws, lds, lds_ent, lds_last, lds_terms);
 }
 __global__ void __launch_bounds__(64) k_wide_codes(JobArgs a) {
-  const uint32_t m = blockIdx.x / WIDE_K;
+  const uint32_t m = blockIdx.x / a.wide_k;
   if (m >= a.nshards) return;
   __shared__ uint32_t lds_store[STORE_LDS_WORDS];
-  wide_codes(a.J, a.shards[m], &a.states[m], a.input, a.ws, blockIdx.x % WIDE_K, lds_store);
+  wide_codes(a.J, a.shards[m], &a.states[m], a.input, a.ws, blockIdx.x % a.wide_k, a.wide_k, lds_store);
 }
 __global__ void __launch_bounds__(64) k_wide_header(JobArgs a) {
   const uint32_t m = blockIdx.x;
@@ -384,9 +385,9 @@ __global__ void __launch_bounds__(64) k_wide_header(JobArgs a) {
   wide_header(a.J, a.shards[m], &a.states[m], a.input, a.ws);
 }
 __global__ void __launch_bounds__(64) k_wide_bits(JobArgs a) {
-  const uint32_t m = blockIdx.x / WIDE_K;
+  const uint32_t m = blockIdx.x / a.wide_k;
   if (m >= a.nshards) return;
-  wide_bits(a.J, a.shards[m], &a.states[m], a.input, a.ws, blockIdx.x % WIDE_K);
+  wide_bits(a.J, a.shards[m], &a.states[m], a.input, a.ws, blockIdx.x % a.wide_k, a.wide_k);
 }
 __global__ void __launch_bounds__(64) k_wide_scan2(JobArgs a) {
   const uint32_t m = blockIdx.x;
@@ -394,10 +395,10 @@ __global__ void __launch_bounds__(64) k_wide_scan2(JobArgs a) {
   wide_scan2(a.J, a.shards[m], &a.states[m], a.ws);
 }
 __global__ void __launch_bounds__(64) k_wide_emit(JobArgs a) {
-  const uint32_t m = blockIdx.x / WIDE_K;
+  const uint32_t m = blockIdx.x / a.wide_k;
   if (m >= a.nshards) return;
   __shared__ uint32_t lds_store[STORE_LDS_WORDS];
-  wide_emit(a.J, a.shards[m], &a.states[m], a.input, a.ws, blockIdx.x % WIDE_K, lds_store);
+  wide_emit(a.J, a.shards[m], &a.states[m], a.input, a.ws, blockIdx.x % a.wide_k, a.wide_k, lds_store);
 }
 __global__ void __launch_bounds__(64) k_wide_tail(JobArgs a) {
   const uint32_t m = blockIdx.x;
@@ -414,7 +415,10 @@ __global__ void __launch_bounds__(64) k_wide_tail(JobArgs a) {
 // and the simulator's drivers (R::operator()(kernel, args, grid, block) launches; `mid` runs between the half that
 // models and the half that writes, where the HIP layer records its event).
 template <class R, class Mid>
-static inline void run_build_store(R& run, const JobArgs& m, uint32_t n, bool wide, Mid mid) {
+static inline void run_build_store(R& run, const JobArgs& m0, uint32_t n, uint32_t wide, Mid mid) {
+  JobArgs m = m0;
+  m.wide_k = wide < 1u ? 1u : wide > WIDE_K_MAX ? WIDE_K_MAX : wide;     // wide: 0 = one wave does it all, else the waves per meta-block
+  const uint32_t WIDE_K = m.wide_k;
   if (!wide) {
     run(k_build, m, n, 64u);
     mid();

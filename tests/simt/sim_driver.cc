@@ -22,6 +22,12 @@ void run(void (*fn)(JobArgs), const JobArgs& a, unsigned grid, unsigned block, i
   Launch l{fn, a};
   simt::launch(grid, block, tramp, &l, reverse);
 }
+// What run_build_store (kernels.h) launches through; SIM_WIDE=K: the many-wave kernels of k_wide.h for every meta-block, K waves each.
+struct SimRun {
+  int reverse;
+  void operator()(void (*fn)(JobArgs), const JobArgs& a, unsigned grid, unsigned block) { run(fn, a, grid, block, reverse); }
+};
+uint32_t sim_wide() { const char* e = getenv("SIM_WIDE"); return e ? (uint32_t)atoi(e) : 0u; }     // 0 = off, else waves per meta-block
 // The index kernels of an indexed job (k_index.h), once per job.
 void run_index(const JobArgs& a, int reverse) {
   run(k_ix_count, a, a.nshards * a.J.ix_slices, 64, reverse);
@@ -215,26 +221,29 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   for (int round = 0; round < 100000; ++round) {
     memset(counters, 0, sizeof(counters));
     run_parse_kernel(a, reverse, round);
-    run(k_build, a, a.nshards, 64, reverse);
+    {
+      SimRun R{reverse};
+      run_build_store(R, a, a.nshards, sim_wide(), [&]() {
     if (getenv("SIM_DEBUG")) {
-      for (size_t k = 0; k < plan.shards.size(); ++k) {
-        if (!states[k].mb_valid) continue;
-        MbLayout L;
-        mb_layout(plan.shards[k].len < plan.J.max_metablock_size ? plan.shards[k].len : plan.J.max_metablock_size, &L);
-        const uint8_t* mb = ws.data() + plan.shards[k].mb_off;
-        const MbInfo* I = (const MbInfo*)(mb + L.info);
-        fprintf(stderr, "shard %zu raw=%u nc=%u kind=%u nlits=%u ndist=%u ncmds=%u\n", k, states[k].mb_raw,
-                I->num_contexts, I->map_kind, I->nlits, I->ndist, I->ncmds);
-        for (int c = 0; c < 3; ++c) {
-          fprintf(stderr, "  cat %d types=%u blocks=%u:", c, I->split[c].num_types, I->split[c].num_blocks);
-          const uint8_t* ty = mb + L.types[c];
-          const uint32_t* le = (const uint32_t*)(mb + L.lengths[c]);
-          for (uint32_t b = 0; b < I->split[c].num_blocks && b < 40; ++b) fprintf(stderr, " %u:%u", ty[b], le[b]);
-          fprintf(stderr, "\n");
+        for (size_t k = 0; k < plan.shards.size(); ++k) {
+          if (!states[k].mb_valid) continue;
+          MbLayout L;
+          mb_layout(plan.shards[k].len < plan.J.max_metablock_size ? plan.shards[k].len : plan.J.max_metablock_size, &L);
+          const uint8_t* mb = ws.data() + plan.shards[k].mb_off;
+          const MbInfo* I = (const MbInfo*)(mb + L.info);
+          fprintf(stderr, "shard %zu raw=%u nc=%u kind=%u nlits=%u ndist=%u ncmds=%u\n", k, states[k].mb_raw,
+                  I->num_contexts, I->map_kind, I->nlits, I->ndist, I->ncmds);
+          for (int c = 0; c < 3; ++c) {
+            fprintf(stderr, "  cat %d types=%u blocks=%u:", c, I->split[c].num_types, I->split[c].num_blocks);
+            const uint8_t* ty = mb + L.types[c];
+            const uint32_t* le = (const uint32_t*)(mb + L.lengths[c]);
+            for (uint32_t b = 0; b < I->split[c].num_blocks && b < 40; ++b) fprintf(stderr, " %u:%u", ty[b], le[b]);
+            fprintf(stderr, "\n");
+          }
         }
       }
+      });
     }
-    run(k_store, a, a.nshards, 64, reverse);
     if (counters[1]) return -3;
     if (counters[0] == 0) break;
   }
@@ -399,9 +408,8 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
     m.states = mstate.data();
     m.nshards = nmb;
     lap("finish");
-    run(k_build, m, nmb, 64, reverse);
-    lap("build");
-    run(k_store, m, nmb, 64, reverse);
+    SimRun R{reverse};
+    run_build_store(R, m, nmb, sim_wide(), [&]() { lap("build"); });
     lap("store");
   }
   run(k_stream_scan, a, 1, 64, reverse);
@@ -607,8 +615,10 @@ long sim_stream(const char* tables_path, const uint8_t* in, size_t len, int qual
       else if (J.block_bits <= 6) run(k_parse_deep<1>, a, 1, 64, reverse);
       else if (J.block_bits == 7) run(k_parse_deep<2>, a, 1, 64, reverse);
       else run(k_parse_deep<4>, a, 1, 64, reverse);
-      run(k_build, a, 1, 64, reverse);
-      run(k_store, a, 1, 64, reverse);
+      {
+        SimRun R{reverse};
+        run_build_store(R, a, 1, sim_wide(), []() {});
+      }
       if (counters[1]) return -3;
       if (counters[0] == 0) break;
     }

@@ -105,8 +105,10 @@ long run_plan_on_sim(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* in, size_t l
     } else {
       run(k_parse, a, a.nshards, 64, 0);
     }
-    run(k_build, a, a.nshards, 64, 0);
-    run(k_store, a, a.nshards, 64, 0);
+    {
+      SimRun R{0};
+      run_build_store(R, a, a.nshards, sim_wide(), []() {});
+    }
     if (counters[1]) return -3;
     if (counters[0] == 0) break;
   }
@@ -278,8 +280,10 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
     else if (J.block_bits <= 6) run(k_parse_deep<1>, a, 1, 64, 0);
     else if (J.block_bits == 7) run(k_parse_deep<2>, a, 1, 64, 0);
     else run(k_parse_deep<4>, a, 1, 64, 0);
-    run(k_build, a, 1, 64, 0);
-    run(k_store, a, 1, 64, 0);
+    {
+      SimRun R{0};
+      run_build_store(R, a, 1, sim_wide(), []() {});
+    }
     if (s->counters[1]) return set_err(c, "stream shard reported a device fault", BROTLI_AMD_ERROR);
     if (s->counters[0] == 0) break;
   }
