@@ -333,7 +333,14 @@ DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + dev_mul24(13
 // at li - 1, li - 2, ...  rank = same-key entries before it, nsucc = same-key entries after it.
 // Matches of up to 16 bytes are decided from LDS alone; longer ones compare on in the input.
 // Writes srt[] and res[].
-struct IxLds { const uint32_t* w0; const uint64_t* d; const uint64_t* d2; };
+// LDS arrays of the sorted bucket, 20 bytes per entry: w0 (position | tag << 24), the filter word f, bytes 4..7,
+// bytes 8..15.  f = bytes 0..3 + tag * IX_FMUL: among entries of one tag, f is equal exactly when the first four
+// bytes are — so "same tag and same first four bytes" (the two tests every slot of the reference's bucket loop starts
+// with, ..64_simd_inc.h:258-263) is ONE 4-byte compare per slot, taken for all 16 slots with their loads in flight
+// together; the few slots that pass (1.3 per search on text) are then looked at one by one, tag first (two
+// different tags can give the same f).
+#define IX_FMUL 0x9E3779B1u
+struct IxLds { const uint32_t* w0; const uint32_t* f; const uint32_t* b47; const uint64_t* d2; };
 // (STREAM: a chunk of a tiled stream — the window limit, the ring's end and the key table exist there only; a plain
 //  shard's instantiation carries none of it)
 template <bool STREAM>
@@ -367,15 +374,24 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
 #else
   const uint32_t nwin = search ? umin(rank, 16u) : 0u;
 #endif
-  const uint32_t nmax = (uint32_t)wave_max_u32(nwin);
-  for (uint32_t j = 1; j <= nmax; ++j) {
-    if (j > nwin) continue;
+  // (1) the filter: all 16 slots at once, loads independent of each other
+  const uint32_t my_f = (uint32_t)e.d + tag * IX_FMUL, my47 = (uint32_t)(e.d >> 32);
+  uint32_t cand = 0;
+#pragma unroll
+  for (uint32_t j = 1; j <= 16u; ++j) {
+    const uint32_t fj = S.f[j <= nwin ? li - j : li];
+    if (j <= nwin && fj == my_f) cand |= 1u << j;
+  }
+  // (2) the slots that passed, nearest first — every lane on a slot of its own
+  while (wave_ballot(cand != 0) != 0) {
+    if (cand == 0) continue;
+    const uint32_t j = (uint32_t)dev_ctz32(cand);
+    cand &= cand - 1u;
     const uint32_t qw = S.w0[li - j];
-    if ((qw >> 24) != tag) continue;
-    const uint64_t x = S.d[li - j] ^ e.d;
-    uint32_t l = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
-    if (l < 4u) continue;                                       // first4 != current4
+    if ((qw >> 24) != tag) continue;                            // (f can agree across tags)
     if (STREAM && p - (qw & 0xFFFFFFu) > maxb) continue;        // beyond the window (:239-241: it and everything older)
+    const uint32_t x = S.b47[li - j] ^ my47;
+    uint32_t l = x ? 4u + ((uint32_t)dev_ctz32(x) >> 3) : 8u;   // (first4 == current4 by the filter)
     if (l == 8u) {
       const uint64_t x2 = S.d2[li - j] ^ e.d2;
       l = x2 ? 8u + ((uint32_t)dev_ctz64(x2) >> 3) : 16u;
@@ -440,7 +456,11 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
     }
   }
   if (act) {
+#if defined(IX_NT)
+    nt_store_u32(&srt[sidx], e.w0);
+#else
     srt[sidx] = e.w0;
+#endif
     uint32_t kind, len = 0, dist = 0;
     if (!search) kind = IX_KIND_NONE;
     else if (danger || ringrisk || ncapped >= 2u) kind = IX_KIND_SLOW;
@@ -466,8 +486,13 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
 // bytes 8..15 [N], N = 64 * IX_LROWS entries of the sorted bucket — or, for a bigger bucket, the
 // (16 + 64) staged entries of the row being searched
 #define IX_BUCKET_LDS_WORDS (256u + 64u * IX_LROWS * 5u)
-DEV void ix_lds_put(uint32_t* w0S, uint64_t* dS, uint64_t* d2S, uint32_t i, const IxEntry& e) {
-  w0S[i] = e.w0; dS[i] = e.d; d2S[i] = e.d2;
+DEV void ix_lds_put(uint32_t* w0S, uint32_t* fS, uint32_t* b47S, uint64_t* d2S, uint32_t i, const IxEntry& e) {
+  w0S[i] = e.w0; fS[i] = (uint32_t)e.d + (e.w0 >> 24) * IX_FMUL; b47S[i] = (uint32_t)(e.d >> 32); d2S[i] = e.d2;
+}
+DEV void ix_lds_get(const uint32_t* w0S, const uint32_t* fS, const uint32_t* b47S, const uint64_t* d2S, uint32_t i, IxEntry& e) {
+  e.w0 = w0S[i];
+  e.d = (uint64_t)(fS[i] - (e.w0 >> 24) * IX_FMUL) | ((uint64_t)b47S[i] << 32);
+  e.d2 = d2S[i];
 }
 DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
                    uint32_t bucket, uint32_t* lds) {
@@ -494,10 +519,11 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   uint32_t* cursor = lds + 128;
   const uint32_t NL = 64u * IX_LROWS;
   uint32_t* w0S = lds + 256;
-  uint64_t* dS = (uint64_t*)(lds + 256 + NL);
+  uint32_t* fS = lds + 256 + NL;
+  uint32_t* b47S = lds + 256 + 2u * NL;
   uint64_t* d2S = (uint64_t*)(lds + 256 + 3u * NL);
   IxLds S;
-  S.w0 = w0S; S.d = dS; S.d2 = d2S;
+  S.w0 = w0S; S.f = fS; S.b47 = b47S; S.d2 = d2S;
   wave_sync();
   for (uint32_t b = (uint32_t)lane; b < 128u; b += 64u) bins[b] = 0;
   wave_sync();
@@ -508,7 +534,11 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     for (uint32_t r = 0; r < IX_LROWS; ++r) {
       const uint32_t i = r * 64u + (uint32_t)lane;
       row[r].w0 = row[r].w1 = 0; row[r].d = row[r].d2 = 0;
+#if defined(IX_NT)
+      if (i < m) row[r].w0 = nt_load_u32(&ent[start + i]);
+#else
       if (i < m) row[r].w0 = ent[start + i];
+#endif
     }
 #pragma unroll
     for (uint32_t r = 0; r < IX_LROWS; ++r) {
@@ -541,7 +571,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       if (act) at = cursor[kl];
       wave_sync();
       if (act && rank + 1u == total) cursor[kl] = at + total;
-      if (act) ix_lds_put(w0S, dS, d2S, at + rank, row[r]);
+      if (act) ix_lds_put(w0S, fS, b47S, d2S, at + rank, row[r]);
       wave_sync();
     }
     for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
@@ -549,7 +579,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       const bool act = i < m;
       IxEntry e;
       e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
-      if (act) { e.w0 = w0S[i]; e.d = dS[i]; e.d2 = d2S[i]; e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key; }
+      if (act) { ix_lds_get(w0S, fS, b47S, d2S, i, e); e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key; }
       const uint32_t kl = e.w1 & lowmask;
       const uint32_t rank = act ? i - bins[kl] : 0u;
       const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
@@ -598,7 +628,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     IxEntry e;
     e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
     if (act) { e.w0 = ent2[start + i]; ix_fetch(J, data, e); }
-    ix_lds_put(w0S, dS, d2S, 16u + (uint32_t)lane, e);
+    ix_lds_put(w0S, fS, b47S, d2S, 16u + (uint32_t)lane, e);
     wave_sync();
     const uint32_t kl = e.w1 & lowmask;
     const uint32_t rank = act ? i - bins[kl] : 0u;
@@ -606,7 +636,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     if (g.stream) ix_window<true>(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res, kt, 1u << J.bucket_bits);
     else ix_window<false>(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res, nullptr, 0u);
     wave_sync();
-    if (lane >= 48) ix_lds_put(w0S, dS, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
+    if (lane >= 48) ix_lds_put(w0S, fS, b47S, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
     wave_sync();
   }
 }
