@@ -82,7 +82,7 @@ def host_cpu_info():
             "socket0_physical_cores": len(first_socket), "socket": s0}, first_socket
 
 
-def cpu_baseline(data, quality, lgwin, shard_size, size_hint, reps=5):
+def cpu_baseline(data, quality, lgwin, shard_size, size_hint, reps=5, other_plans=()):
     """The reference encoder (oracle/_ref/libbrotli_ref.so, built from /root/reference by
     oracle/Makefile) driven by oracle/_ref/plan_bench (C, one pinned POSIX thread per physical
     core of socket 0, one encoder instance per shard): (B2) the SAME partition plan as the GPU
@@ -113,6 +113,7 @@ def cpu_baseline(data, quality, lgwin, shard_size, size_hint, reps=5):
             same = run(cores, shard_size, reps, cpus)
             big = 8 << 20
             best = run(cores, big, 3, cpus) if len(data) >= 4 * big else None
+            others = {sh: run(cores, sh, 3, cpus) for sh in other_plans}
             one = data[:min(len(data), 64 << 20)]
             with open(path, "wb") as f:
                 f.write(one)
@@ -132,6 +133,11 @@ def cpu_baseline(data, quality, lgwin, shard_size, size_hint, reps=5):
             "single_stream_ratio": round(single["bytes"] / max(1, single["out_bytes"]), 4),
             "single_stream_sample": "first %d MiB, one encoder instance, 1 thread" % (len(one) >> 20),
         }
+        if others:
+            # the reference driven with the other partition plans of config.plans[] (same cores, median of 3)
+            out["other_plans"] = {str(sh >> 10): {"MBps": round(r["MBps"], 1), "sha256": r["sha256"], "out_bytes": r["out_bytes"],
+                                                  "shards": r["shards"], "seconds_all": r["seconds_all"]}
+                                  for sh, r in others.items()}
         if best:
             out["reference_own_plan"] = {
                 "MBps": round(best["MBps"], 1), "shard_KiB": big >> 10, "shards": best["shards"],
@@ -631,8 +637,54 @@ def main():
             line["config"]["spot_check_first_shards_bit_exact"] = comp[:len(want)] == want
             import hashlib
             line["config"]["gpu_output_sha256"] = hashlib.sha256(comp).hexdigest()
-            cb = cpu_baseline(data, args.quality, args.lgwin, shard, size_hint)
+            # config.plans[]: the headline plan and the other one of {128 KiB, 1 MiB} (the plan
+            # whose ratio is close to the single stream's), each with ratio, MB/s, whole-output sha256 and the reference
+            # driven with the same plan on this box's cores.  Timed the same way as the headline (device-resident input,
+            # synchronize on both sides), outside the headline's timed region.
+            plans = [{"shard_KiB": args.shard_kb, "shards": infos[-1]["nshards"], "MBps": round(value, 1),
+                      "ms_per_step": round(ms_step, 3), "ratio": round(total / out_total, 4), "compressed_bytes": out_total,
+                      "sha256": line["config"]["gpu_output_sha256"], "headline": True}]
+            other_kb = []
+            if args.quality == 5 and args.workload == "text" and args.shard_kb in (128, 1024):
+                other_kb = [1024 if args.shard_kb == 128 else 128]
+            for kb in other_kb:
+                try:
+                    p2 = hip.make_params(args.quality, args.lgwin, kb << 10, size_hint, stream_base=0, is_last=True)
+                    cap2 = ctx.max_output(n, p2)
+                    d_out2 = d_out if cap2 <= d_out.numel() else torch.empty(cap2, dtype=torch.uint8, device=dev)
+                    ctx.encode_device(d_in, n, p2, d_out2)
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    inf2 = []
+                    for _ in range(3):
+                        nb2, i2 = ctx.encode_device(d_in, n, p2, d_out2)
+                        inf2.append(i2)
+                    torch.cuda.synchronize(dev)
+                    dt2 = (time.perf_counter() - t1) / 3
+                    comp2 = d_out2[:nb2].cpu().numpy().tobytes()
+                    plans.append({"shard_KiB": kb, "shards": inf2[-1]["nshards"], "MBps": round(n / 1e6 / dt2, 1),
+                                  "ms_per_step": round(dt2 * 1e3, 3), "ratio": round(n / nb2, 4), "compressed_bytes": nb2,
+                                  "sha256": hashlib.sha256(comp2).hexdigest(), "headline": False, "steps": 3,
+                                  "stage_ms": {k: round(sum(i.get(k, 0.0) for i in inf2) / len(inf2), 3) for k in
+                                               ("ms_total", "ms_index", "ms_ix_bucket", "ms_parse", "ms_build", "ms_store")},
+                                  "tile_sweeps": inf2[-1].get("tile_sweeps"),
+                                  "tile_fallback_shards": inf2[-1].get("tile_fallback_shards")})
+                    del comp2
+                    if d_out2 is not d_out:
+                        del d_out2
+                except Exception as e:
+                    plans.append({"shard_KiB": kb, "error": repr(e)[:300]})
+            cb = cpu_baseline(data, args.quality, args.lgwin, shard, size_hint,
+                              other_plans=[kb << 10 for kb in other_kb if "error" not in plans[-1]])
             line["cpu_baseline"] = cb
+            for pl in plans:
+                ref = ({"MBps": cb["value"], "sha256": cb.get("sha256"), "out_bytes": cb.get("out_bytes")} if pl.get("headline")
+                       else cb.get("other_plans", {}).get(str(pl["shard_KiB"])))
+                if ref and "MBps" in pl:
+                    pl["reference_same_plan_MBps"] = ref["MBps"]
+                    pl["x_reference_same_plan"] = round(pl["MBps"] / ref["MBps"], 2)
+                    pl["sha256_equal_reference"] = ref.get("sha256") == pl["sha256"] and ref.get("out_bytes") == pl["compressed_bytes"]
+            line["config"]["plans"] = plans
             # the reference encoded the WHOLE input with the same plan in this
             # run; its concatenated output must be the GPU's, byte for byte
             if "sha256" in cb:

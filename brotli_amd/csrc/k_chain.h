@@ -73,6 +73,26 @@ DEV void c_bitmap_settle(uint8_t* skip, uint32_t bi, uint32_t nb, uint32_t set, 
 
 DEV uint32_t c_res_hi(const CShard& C, uint32_t x) { return ((const uint32_t*)(C.res + x))[1]; }
 
+// A tainted index result that holds all the same (plain chain only).  IX_TAINT says one of the predecessors of P in
+// its key run was not stored; with IX_FULLRUN the index looked at ALL of them (<= 16), so the ring the reference holds
+// at P — the stored ones — is a subset of the window the index searched, visited in the same order.  The bucket loop
+// is an arg-max with the visiting order as the tie break (the byte gate's dependence on the distance cache is the
+// chain's `unsure` rule either way), so: nothing found in the window = nothing found in the ring; and a winner that is
+// itself stored wins in the ring too.  The winner q = P - dist is stored when the bitmap says so — or when it lies at or
+// behind the frontier: the positions between the frontier and P are the ones this very step searches (and stores,
+// ..64_simd_inc.h:293-295) on its way to P, and a step never uses P without having used them.
+// (Floats and noise: the literal spree leaves most positions unstored and taints nearly every search; almost all of
+//  them find nothing.)
+DEV bool c_taint_soft(uint32_t rhi, uint32_t kind) {
+  return (rhi & (IX_TAINT | IX_FULLRUN | IX_DANGER)) == (IX_TAINT | IX_FULLRUN) && kind != IX_KIND_SLOW;
+}
+DEV bool c_taint_holds(const CShard& C, bool soft, uint32_t kind, uint32_t P, uint32_t dist) {
+  if (!soft) return false;
+  if (kind == IX_KIND_NONE) return true;
+  const uint32_t q = P - dist;
+  return q >= C.frontier || !c_skipped(C, q);
+}
+
 // Marks the storable positions of [a, b) as not stored — except, for a literal spree
 // (stride > 1), the ones the spree did store: sfirst + i * stride.  An unstored position x is
 // missing from the bucket window of the (at most 16) positions that follow it in its key run:
@@ -361,12 +381,17 @@ DEV CEval c_evaluate(const JobParams& J, CShard& C, bool want, uint32_t P0, int 
   const bool b_ok = ev && (kind == IX_KIND_EXACT || kind == IX_KIND_LONG);
   const uint32_t b_score = b_ok ? 1920u + 135u * b_len - 30u * log2floor(b_dist | 1u) : 0u;
   const bool b_wins = b_ok && b_score > dc_score;
-  const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & (IX_DANGER | IX_TAINT)) != 0 || force_slow || ring_risk != 0 ||
+  bool tainted = (rhi & IX_TAINT) != 0;
+  {
+    const bool soft = ev && C.mode == 0u && c_taint_soft(rhi, kind);
+    if (wave_any(soft)) { if (c_taint_holds(C, soft, kind, Pk, b_dist)) tainted = false; }
+  }
+  const bool need_exact = ev && (kind == IX_KIND_SLOW || (rhi & IX_DANGER) != 0 || tainted || force_slow || ring_risk != 0 ||
                                  (b_wins && b_len <= umax(dc_len, 3u)));
 #if defined(BROTLI_AMD_SIMT_SIM)
   if (ev && idc == 0) {   // (statistics of the simulator runs: why positions go to the exact path)
     if (kind == IX_KIND_SLOW) g_sim_counts[8]++;
-    else if (rhi & IX_TAINT) g_sim_counts[9]++;
+    else if (tainted) g_sim_counts[9]++;
     else if (b_wins && b_len <= umax(dc_len, 3u)) g_sim_counts[10]++;
     if (kind == IX_KIND_LONG) g_sim_counts[11]++;
     g_sim_counts[12]++;
@@ -493,7 +518,12 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
         ring_risk = ring_risk || (d_cand[i] && (((Pk - dcs[i]) & rm) + md > rm || (Pk & rm) + md > rm));
       }
     }
-    const bool need = kind >= IX_KIND_LONG || (rhi & (IX_DANGER | IX_TAINT)) != 0 || d_long || force_slow || ring_risk ||
+    bool tainted = (rhi & IX_TAINT) != 0;
+    {
+      const bool soft = can && C.mode == 0u && kind <= IX_KIND_EXACT && c_taint_soft(rhi, kind);
+      if (wave_any(soft)) { if (c_taint_holds(C, soft, kind, Pk, b_dist)) tainted = false; }
+    }
+    const bool need = kind >= IX_KIND_LONG || (rhi & IX_DANGER) != 0 || tainted || d_long || force_slow || ring_risk ||
                       (b_wins && b_len <= umax(dc_len, 3u));
     uint32_t sc = b_wins ? b_score : dc_score;
     uint32_t ln = b_wins ? b_len : dc_len;

@@ -26,7 +26,21 @@
 #define IX_NSUCC_SHIFT 24u
 #define IX_TAINT 0x20000000u                  // set by the chain: one of the 16 predecessors of p in its key run was NOT
                                               //   stored by the parse, so the index result of p does not hold (k_chain.h)
+#define IX_FULLRUN 0x40000000u                // the window of p held EVERY same-key predecessor (rank <= 16): whatever the parse
+                                              //   left unstored, the reference's ring is a subset of it — a tainted result still
+                                              //   holds when it found nothing, or when its winner was stored (k_chain.h)
 #define IX_DANGER 0x80000000u                 // the bucket counter may have wrapped (>= 65520 stores of one key)
+
+// Giant buckets (runs of zeros: one key takes a whole shard): a wave needs tens of milliseconds for one, and one that
+// starts late is the whole kernel's tail.  k_ix_scan lists the buckets above IX_GIANT_MIN entries, per XCD class
+// (shard % 8: the class whose workgroups touch the shard, kernels.h); the first IX_GIANT_WORKERS workgroups of
+// k_ix_bucket work the lists off — longest work first — and the regular waves pass over what is listed.  A class
+// whose list overflows (count > IX_GIANT_CAP) is not listed at all: both sides read the same count.
+// JobArgs::giant: 8 x (count, IX_GIANT_CAP items of shard << 10 | bucket); nullptr = no lists.
+#define IX_GIANT_MIN (8u * 64u * IX_LROWS)
+#define IX_GIANT_CAP 4095u
+#define IX_GIANT_WORKERS 2048u
+#define IX_GIANT_WORDS (8u * (1u + IX_GIANT_CAP))
 
 // Entry of the sort as it travels through HBM: position | (low bits of the key: the ones the first level did not
 // sort by) << 24 (4 bytes) — a bucket too big for LDS is sorted by them without looking at the input again.  The

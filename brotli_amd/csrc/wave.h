@@ -45,8 +45,6 @@ static inline uint32_t dev_bitrev32(uint32_t x) {
   return __builtin_bswap32(x);
 }
 #define block_sync() simt_sync(WAVE_SITE)
-static inline uint32_t nt_load_u32(const uint32_t* p) { return *p; }
-static inline void nt_store_u32(uint32_t* p, uint32_t v) { *p = v; }
 // Lanes [0, n) hold v: prev = highest lane below this one with the same v (-1 if
 // none), next = lowest lane above it with the same v (64 if none).
 static inline void wave_equal_neighbours(uint32_t v, int n, int* prev, int* next) {
@@ -141,10 +139,6 @@ __device__ __forceinline__ uint32_t glb_load_l2(const uint32_t* p) {
 }
 __device__ __forceinline__ uint32_t dev_bitrev32(uint32_t x) { return __builtin_bitreverse32(x); }
 __device__ __forceinline__ void block_sync() { __syncthreads(); }
-// Streaming accesses ("nt": the line is the first to leave the L2): data read once or written once, so that what IS
-// re-used — the scattered res[] lines of k_ix_bucket that fill up over time — stays.
-__device__ __forceinline__ uint32_t nt_load_u32(const uint32_t* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void nt_store_u32(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 // Lanes [0, n) hold v: prev = highest lane below this one with the same v (-1 if
 // none), next = lowest lane above it with the same v (64 if none).  n readlanes
 // (SGPR broadcast) and two compares each: no LDS traffic.

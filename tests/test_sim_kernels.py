@@ -216,6 +216,29 @@ def test_indexed_parse_key_run_past_the_16_bit_store_counter(sim, oracle):
     assert sim.encode(z.tobytes(), 5, 22, 0, 0, flags=IX_LAYOUTS["groups1"]) == _oracle_plan(oracle, z.tobytes(), 0, 0)
 
 
+def _spree_members():
+    """Members of the Silesia-style mix on which the literal spree leaves most positions unstored (floats, noise)
+    and the ones around them, 96 KiB each."""
+    big = G.mixed_corpus(8 << 20)
+    member = (8 << 20) // 12 + 1
+    return {name: big[k * member + 1000:k * member + 1000 + (96 << 10)]
+            for k, name in ((4, "floats"), (5, "gradient"), (6, "zeros"), (7, "noise"))}
+
+
+@pytest.mark.parametrize("name", ["floats", "gradient", "zeros", "noise"])
+def test_indexed_parse_tainted_results_that_still_hold(sim, oracle, name):
+    """IX_FULLRUN (k_index_layout.h): a search whose key run has <= 16 predecessors keeps its index result although
+    some of them were not stored — when it found nothing, or when its winner is a stored position (c_taint_holds).
+    Floats and noise: the literal spree taints nearly every search.  Both hashers, two wave layouts; the forced
+    exact search (which never uses the rule) gives the same bytes."""
+    data = _spree_members()[name]
+    for hint in (1 << 30, 0):
+        want = _oracle_plan(oracle, data, hint, 48 << 10)
+        for layout in ("groups4", "groups1"):
+            assert sim.encode(data, 5, 22, hint, 48 << 10, flags=IX_LAYOUTS[layout]) == want, (hint, layout)
+    assert sim.encode(data, 5, 22, 1 << 30, 48 << 10, flags=IX_LAYOUTS["groups4"] | 4) == _oracle_plan(oracle, data, 1 << 30, 48 << 10)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_indexed_parse_fuzz(sim, oracle, seed):
     rng = np.random.default_rng(4000 + seed)

@@ -26,7 +26,7 @@ echo "== index variants (k_ix_* alone, 1 GiB text)" | tee -a $O/summary.txt
 for v in ixbase ixfilter ixfilter_nt; do
   TAG=$v BROTLI_AMD_HIP_LIB=$PWD/build/var/$v.so PROBE_SHARDS=131072,1048576 timeout 200 python tools/gpu_ix_only.py 2>&1 | grep IXONLY | tee -a $O/summary.txt
 done
-for v in ixfilter ixfilter_nt; do
+for v in ixfilter; do
   for pmc in WRITE_SIZE FETCH_SIZE; do
     ( cd /tmp && TAG=$v BROTLI_AMD_HIP_LIB=/root/repo/build/var/$v.so PROBE_SHARDS=131072 timeout 300 rocprofv3 --pmc $pmc --kernel-trace -d /root/repo/$O/pmc_${v}_$pmc -o p -- python /root/repo/tools/gpu_ix_only.py ) > $O/pmc_${v}_$pmc.log 2>&1
   done
