@@ -472,7 +472,10 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
     if (getenv("BROTLI_AMD_INDEX_ONLY")) {   // timing experiments: stop after the index kernels
       HIP_OK(c, hipStreamSynchronize(c->stream));
-      if (info) { HIP_OK(c, hipEventElapsedTime(&ms_index, c->ev[1], c->ev_ix)); info->ms_index = ms_index; }
+      if (info) {
+        HIP_OK(c, hipEventElapsedTime(&ms_index, c->ev[1], c->ev_ix)); info->ms_index = ms_index;
+        HIP_OK(c, hipEventElapsedTime(&info->ms_ix_bucket, c->ev_ixb, c->ev_ix));
+      }
       if (states_out) {
         states_out->resize(nshards);
         HIP_OK(c, hipMemcpy(states_out->data(), c->d_states, nshards * sizeof(ShardState), hipMemcpyDeviceToHost));
