@@ -44,7 +44,6 @@ struct BrotliAmdCtx {
   ShardState* d_states = nullptr;
   uint64_t* d_scan = nullptr;       // nshards + 1 output offsets
   uint32_t* d_counters = nullptr;   // [0] shards not done, [1] shards in error, [2..4] tiled jobs (k_tile.h)
-  uint32_t* d_giant = nullptr;      // the index kernels' lists of giant buckets (k_index_layout.h: IX_GIANT_WORDS)
   uint64_t shard_cap = 0;
   // batches of an indexed job: the index kernels of batch b + 1 run beside the chain of batch b and the
   // build / store of batch b - 1 (run_batches)
@@ -260,7 +259,6 @@ bool ensure_ws(BrotliAmdCtx* c, uint64_t ws_bytes, uint64_t nshards) {
     c->shard_cap = nshards;
   }
   if (!c->d_counters) HIP_OK(c, hipMalloc((void**)&c->d_counters, 16 * sizeof(uint32_t)));
-  if (!c->d_giant && !getenv("BROTLI_AMD_NO_GIANT_LISTS")) HIP_OK(c, hipMalloc((void**)&c->d_giant, IX_GIANT_WORDS * sizeof(uint32_t)));
   return true;
 }
 
@@ -462,13 +460,12 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
   //  kernels' waves take each other's LDS and issue slots.)
   if (indexed) {
     // the data-parallel half of the parse, once per job (k_index.h)
-    a.giant = c->d_giant;
     hipLaunchKernelGGL(k_ix_count, dim3(nshards * plan.J.ix_slices), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_scan, dim3(nshards), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_scatter, dim3(nshards * plan.J.ix_slices), dim3(64),
                        (IX_CHUNK + (3u << plan.J.ix_nb_log2)) * 4u, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
-    hipLaunchKernelGGL(k_ix_bucket, dim3(ix_bucket_grid(plan.J, (uint32_t)nshards, a.giant != nullptr)), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_ix_bucket, dim3(ix_bucket_grid(plan.J, (uint32_t)nshards)), dim3(64), 0, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
     if (getenv("BROTLI_AMD_INDEX_ONLY")) {   // timing experiments: stop after the index kernels
       HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -762,12 +759,11 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     JobArgs x = a;                          // the index kernels see the chunks as their shards
     x.shards = c->d_chunks;
     x.nshards = nchunks;
-    x.giant = c->d_giant;
     hipLaunchKernelGGL(k_ix_count, dim3(nchunks * plan.J.ix_slices), dim3(64), 0, c->stream, x); each("k_ix_count");
     hipLaunchKernelGGL(k_ix_scan, dim3(nchunks), dim3(64), 0, c->stream, x); each("k_ix_scan");
     hipLaunchKernelGGL(k_ix_scatter, dim3(nchunks * plan.J.ix_slices), dim3(64), (IX_CHUNK + (3u << plan.J.ix_nb_log2)) * 4u, c->stream, x); each("k_ix_scatter");
     HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
-    hipLaunchKernelGGL(k_ix_bucket_s, dim3(ix_bucket_grid(plan.J, nchunks, x.giant != nullptr)), dim3(64), 0, c->stream, x); each("k_ix_bucket_s");
+    hipLaunchKernelGGL(k_ix_bucket_s, dim3(ix_bucket_grid(plan.J, nchunks)), dim3(64), 0, c->stream, x); each("k_ix_bucket_s");
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
   }
   lap("index");
@@ -979,7 +975,7 @@ void brotli_amd_ctx_destroy(BrotliAmdCtx* c) {
   DeviceScope dev(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   void* ptrs[] = {c->d_lut, c->d_dict, c->d_hash_words, c->d_hash_lengths, c->d_log2, c->d_T,
-                  c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters, c->d_giant, c->d_tiles, c->d_trecs,
+                  c->d_ws, c->d_shards, c->d_states, c->d_scan, c->d_counters, c->d_tiles, c->d_trecs,
                   c->d_chunks, c->d_mdesc, c->d_mstate, c->d_moff,
                   c->d_stage_in, c->d_stage_out, c->d_ffrags, c->d_fblocks, c->d_fbstate,
                   c->d_ffstate, c->d_fresult, c->d_transforms, c->d_transform_text, c->d_dec_arena,

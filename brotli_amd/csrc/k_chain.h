@@ -43,6 +43,7 @@ struct CShard {
   uint8_t* skip;         // bit (x - geo.first): storable position x was NOT stored by the parse
   uint32_t frontier;     // every storable position below it is either stored or marked in `skip`
   uint32_t nslow;
+  uint32_t spree_hit;    // position a spree step of the fast path stopped at because it has a match (c_group_fast), or ~0
   // tiled jobs (JOB_FLAG_TILED): this group parses [tile_lo, tile_hi) of the shard; only positions of the tile
   // are marked / tainted by it (the bitmap's words never straddle tiles: tiles are multiples of 32 positions
   // counted from geo.first)
@@ -476,10 +477,26 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     SIM_COUNT(14, 1);
     uint64_t ft = QP_NOW();
     const uint32_t pos = g.position;
-    const uint32_t Pk = pos + (uint32_t)t;
+    // ---- a step inside the literal spree (:208-236; the plain chain, the static dictionary no longer consulted) ----
+    // Behind `apply_random_heuristics` a position that finds nothing is followed by a jump: four stores two (four) bytes
+    // apart, the next search 9 (17) bytes on.  The searches of such a stretch — noise, floats — do not depend on each
+    // other as long as they all miss (no command, the distance cache stays), so the 16 lanes take the next 16 of
+    // them, pos + U t, and the group moves over the leading ones that miss for certain: lane 0 by the usual rules, the
+    // others only when the index saw the whole key run and found nothing in it (IX_FULLRUN, kind NONE: nothing the
+    // jumps before them leave unstored can change that) and no distance-cache candidate matches.  It stops in front of
+    // the first other one; a match there is remembered (spree_hit) and evaluated by a regular step.
+    const uint32_t arh = g.apply_random_heuristics;
+    const bool gate_closed0 = g.dict_matches < (g.dict_lookups >> 7);
+    const bool spree = can && pos >= arh && gate_closed0 && C.mode == 0u && !force_slow && g.ring_mask == 0xFFFFFFFFu &&
+                       C.spree_hit != pos;
+    const bool far = pos + 1u > arh + 4u * J.spree_window;
+    const uint32_t U = far ? 17u : 9u;
+    const uint32_t Pk = pos + (spree ? U * (uint32_t)t : (uint32_t)t);
+    // (units of one kind only, each with its jump and the compares of its search clear of the block's end)
+    const bool canl = can && (!spree || (Pk + 64u <= g.pos_end && (far || Pk + 1u <= arh + 4u * J.spree_window)));
     // ---- evaluation of position Pk ----
-    const C16 cb = c_load16(g.data + (can ? Pk : 0u));
-    const uint64_t rw = C.res[can ? Pk : C.ibase];      // (a stream: C.res is the chunk's array shifted by its base — index 0 lies gigabytes below it)
+    const C16 cb = c_load16(g.data + (canl ? Pk : 0u));
+    const uint64_t rw = C.res[canl ? Pk : C.ibase];      // (a stream: C.res is the chunk's array shifted by its base — index 0 lies gigabytes below it)
     C16 pb[4];
     const uint32_t maxb = umin(Pk, limit);
     const uint32_t dcs[4] = {(uint32_t)g.dc[0], (uint32_t)g.dc[1], (uint32_t)g.dc[2], (uint32_t)g.dc[3]};
@@ -487,7 +504,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t dcv = dcs[i];
-      d_cand[i] = can && (dcv - 1u) < maxb;                   // 0 < distance <= max_backward
+      d_cand[i] = canl && (dcv - 1u) < maxb;                  // 0 < distance <= max_backward
       pb[i] = c_load16(g.data + (d_cand[i] ? Pk - dcv : 0u));
     }
     // (len, earlier entry) orders the cache candidates like their scores do (see c_evaluate)
@@ -520,7 +537,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     }
     bool tainted = (rhi & IX_TAINT) != 0;
     {
-      const bool soft = can && C.mode == 0u && kind <= IX_KIND_EXACT && c_taint_soft(rhi, kind);
+      const bool soft = canl && C.mode == 0u && kind <= IX_KIND_EXACT && c_taint_soft(rhi, kind);
       if (wave_any(soft)) { if (c_taint_holds(C, soft, kind, Pk, b_dist)) tainted = false; }
     }
     const bool need = kind >= IX_KIND_LONG || (rhi & IX_DANGER) != 0 || tainted || d_long || force_slow || ring_risk ||
@@ -528,7 +545,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     uint32_t sc = b_wins ? b_score : dc_score;
     uint32_t ln = b_wins ? b_len : dc_len;
     uint32_t ds = b_wins ? b_dist : dc_dist;
-    uint32_t use16 = q_mask16(wave_ballot(can && !need));
+    uint32_t use16 = q_mask16(wave_ballot(canl && !need));
     QP_ADD(g, 8, ft);
     // ---- an undecidable first position: the exact search, then on with its result ----
     bool dead = false;                                          // this step cannot move the group
@@ -544,6 +561,31 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
       }
     }
     uint32_t hit16 = q_mask16(wave_ballot(sc > K_MIN_SCORE));
+    if (wave_any(spree)) {
+      const bool miss = t == 0 ? ((use16 & 1u) != 0u && sc == K_MIN_SCORE)
+                               : (canl && !need && sc == K_MIN_SCORE && kind == IX_KIND_NONE && (rhi & IX_FULLRUN) != 0u);
+      const uint32_t miss16 = q_mask16(wave_ballot(spree && miss));
+      const uint32_t n = (uint32_t)dev_ctz32(~miss16 | 0x10000u);           // units this step moves over
+      if (spree) {
+        if (n == 0u) g.status |= 0x80000000u;                               // (a match at pos itself: the generic step)
+        else {
+          g.position = pos + U * n;
+          g.insert_length += U * n;
+          g.stat_searches += n;
+          g.cmd_flags |= CMDF_SPREE;
+          C.spree_hit = (n < 16u && ((use16 & hit16) >> n) & 1u) ? pos + U * n : 0xFFFFFFFFu;
+        }
+      }
+      // what the jumps left unstored: [P + 1, P + U) but for P + 1, P + 1 + step, ...
+      const uint32_t nmax = wave_max_u32(spree ? n : 0u);
+      for (uint32_t k = 0; k < nmax; ++k) {
+        const bool on = spree && k < n;
+        const uint32_t a = pos + U * k + 1u;
+        c_mark_range(J, C, on, a, a + U - 1u, a, far ? 4u : 2u);
+      }
+      if (spree && n != 0u) C.frontier = pos + U * n;
+    }
+    const bool canr = can && !spree;                            // the groups on a regular step
     // ---- nothing found at the first position while the static dictionary is being consulted
     // (hash.h:179-202): probe it here.  A dictionary match starts the lazy evaluation, which the
     // generic step carries on with (it may ask the dictionary again at the next position).
@@ -555,7 +597,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
       // (not when the literal spree trips right behind this position: that step belongs to the generic path,
       // which searches the position itself — asking here as well would count the two lookups twice and close
       // the gate earlier than the reference does; found by tools/fuzz_index_sim.py)
-      const bool dq = can && !gate_closed && (hit16 & 1u) == 0u && room != 0u;
+      const bool dq = canr && !gate_closed && (hit16 & 1u) == 0u && room != 0u;
       if (wave_any(dq)) {
         QResult r;
         r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; r.delta = 0;
@@ -576,7 +618,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     // lane t: does position t + 1 beat position t by the lazy-matching margin (:139)?
     const uint32_t sc_next = wave_row_ror(sc, 15);              // lane t reads lane (t + 1) & 15 of its group
     const uint32_t adv16 = q_mask16(wave_ballot(t < 15 && sc_next >= sc + 175u));
-    const uint32_t U = (uint32_t)dev_ctz32(~use16 | 0x10000u);                  // usable prefix
+    const uint32_t Uu = (uint32_t)dev_ctz32(~use16 | 0x10000u);                 // usable prefix
     const uint32_t m = (uint32_t)dev_ctz32(hit16 | 0x10000u);                   // first match
     // ... / the dictionary has to be asked
     const uint32_t missmax = gate_closed ? room : dict0 ? umin(room, 1u) : 0u;
@@ -585,23 +627,23 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     // while the static dictionary is being consulted, a probe that finds nothing asks it:
     // only probes with a match are decidable here
     const uint32_t probes = (0x3FFFFu >> (17u - umin(last, 16u))) & ~(0x1FFFFu >> (16u - umin(m, 16u)));   // bits m + 1 .. last
-    const bool have = can && !dead && m < 16u && m <= missmax && last < U &&
+    const bool have = canr && !dead && m < 16u && m <= missmax && last < Uu &&
                       (gate_closed || (hit16 & probes) == probes);
-    const uint32_t L = umin(umin(m, U), missmax);               // literals this step may consume without a match
-    if (can && !dead && !have && L != 0u) {
+    const uint32_t L = umin(umin(m, Uu), missmax);              // literals this step may consume without a match
+    if (canr && !dead && !have && L != 0u) {
       g.position = pos + L;
       g.insert_length += L;
       g.stat_searches += L;
       C.frontier = pos + L;
     }
-    if (can && !have && (dead || L == 0u)) { g.status |= 0x80000000u; }         // needs the generic step
+    if (canr && !have && (dead || L == 0u)) { g.status |= 0x80000000u; }        // needs the generic step
 #if defined(BROTLI_AMD_SIMT_SIM)
-    if (can && t == 0) {
+    if (canr && t == 0) {
       if (have) g_sim_counts[0]++;                       // steps with a commit
       else if (dead) g_sim_counts[2]++;                  // dictionary match: lazy evaluation handed to the generic step
       else if (L != 0u) g_sim_counts[1]++;               // literal-only steps
-      else if (m < 16u && m < U && m <= missmax && last >= U) g_sim_counts[3]++;   // lazy chain runs into an undecidable position
-      else if (m < 16u && m < U && m <= missmax) g_sim_counts[4]++;                // lazy probe without a match, dictionary gate open
+      else if (m < 16u && m < Uu && m <= missmax && last >= Uu) g_sim_counts[3]++;   // lazy chain runs into an undecidable position
+      else if (m < 16u && m < Uu && m <= missmax) g_sim_counts[4]++;                // lazy probe without a match, dictionary gate open
       else if (missmax == 0u) g_sim_counts[5]++;         // spree / dictionary gate at the first position
       else g_sim_counts[6]++;
     }
@@ -637,9 +679,10 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
         if (t == 0) {
           Command c;
           c.insert_len = ins; c.copy_len = sr_len; c.dist_extra = code; c.cmd_prefix = CMD_RAW;
-          c.dist_prefix = (uint16_t)((tt == 4u ? CMDF_NOPROBE : 0u) | dflags | (umin(tt, 3u) << CMDF_DELAYED_SHIFT));
+          c.dist_prefix = (uint16_t)((tt == 4u ? CMDF_NOPROBE : 0u) | g.cmd_flags | dflags | (umin(tt, 3u) << CMDF_DELAYED_SHIFT));
           g.cmds[g.r.ncmds] = c;
         }
+        g.cmd_flags = 0;
         ++g.r.ncmds;
         g.r.nlits += ins;
         g.insert_length = 0;
@@ -950,6 +993,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   }
   C.frontier = S0->ix_frontier;
   C.nslow = 0;
+  C.spree_hit = 0xFFFFFFFFu;
   C.tile_lo = 0;
   C.tile_hi = D.len;
   C.mode = tiled ? C_TILED : 0u;

@@ -177,7 +177,7 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
 
 // grid = nshards.  Exclusive scan of cnt[] in (bucket, slice) order, in place;
 // cnt[buckets * slices] = number of storable positions of the shard.
-DEV void ix_scan(const JobParams& J, const ShardDesc& D, uint8_t* ws, uint32_t* giant = nullptr, uint32_t shard = 0) {
+DEV void ix_scan(const JobParams& J, const ShardDesc& D, uint8_t* ws) {
   const int lane = wave_lane();
   IxLayout L;
   ix_layout(D.len, J.ix_slices, J.ix_nb_log2, &L);
@@ -193,18 +193,6 @@ DEV void ix_scan(const JobParams& J, const ShardDesc& D, uint8_t* ws, uint32_t* 
   for (uint32_t i = lo; i < hi; ++i) { const uint32_t v = cnt[i]; cnt[i] = run; run += v; }
   if (lane == 63) cnt[total] = incl;
   wave_sync();
-  if (giant != nullptr) {
-    // buckets a single wave would be busy with for long go on the list of the shard's XCD class (k_index_layout.h)
-    uint32_t* G = giant + (shard & 7u) * (1u + IX_GIANT_CAP);
-    const uint32_t nbk = 1u << J.ix_nb_log2;
-    for (uint32_t b = (uint32_t)lane; b < nbk; b += 64u) {
-      const uint32_t m = cnt[(b + 1u) * J.ix_slices] - cnt[b * J.ix_slices];
-      if (m > IX_GIANT_MIN) {
-        const uint32_t k = glb_atomic_add(&G[0], 1u);
-        if (k < IX_GIANT_CAP) G[1u + k] = (shard << 10) | b;
-      }
-    }
-  }
 }
 
 // grid = nshards * slices.  Stable scatter of the slice's entries to their buckets.
@@ -485,16 +473,11 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
 DEV void ix_lds_put(uint32_t* w0S, uint64_t* dS, uint64_t* d2S, uint32_t i, const IxEntry& e) {
   w0S[i] = e.w0; dS[i] = e.d; d2S[i] = e.d2;
 }
-// One wave works through the buckets [b0, b0 + nb) of a shard.  The kernel's time is the length of a bucket's chain of
-// dependent memory round trips (bounds -> entries -> the 16 bytes at each entry's position -> LDS sort -> search),
-// hidden only by the other waves of the SIMD, so the chain is kept short: the gathers of all rows of a bucket are in
-// flight together (indices clamped instead of lanes switched off: no branch, no wait between them), and the bounds and
-// entries of the NEXT bucket are requested before the current one is sorted and searched.
 // (STREAM: the index chunks of a tiled stream — a kernel of its own, k_ix_bucket_s: the plain kernel carries neither
 //  the window limit / ring end / key table code nor the registers it pins.)
 template <bool STREAM>
-DEV void ix_buckets(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
-                    uint32_t b0, uint32_t nb, uint32_t* lds, uint32_t skip_above = 0xFFFFFFFFu) {
+DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
+                   uint32_t bucket, uint32_t* lds) {
   const int lane = wave_lane();
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
@@ -508,6 +491,10 @@ DEV void ix_buckets(const JobParams& J, const ShardDesc& D, const uint8_t* input
   uint64_t* res = (uint64_t*)(base + L.res);
   uint32_t* kt = nullptr;
   if (STREAM) kt = (uint32_t*)(ws + J.skt_off + (uint64_t)(g.ownc == 0u ? 0u : (g.base >> J.chunk_log2) + 1u) * skt_chunk_bytes((uint32_t)J.bucket_bits));
+  const uint32_t start = cnt[bucket * J.ix_slices];
+  const uint32_t end = cnt[(bucket + 1u) * J.ix_slices];   // (the last one reads the total)
+  const uint32_t m = end - start;
+  if (m == 0) return;
   const int lowbits = J.bucket_bits - (int)J.ix_nb_log2;    // 4 .. 7
   const uint32_t lowmask = (1u << lowbits) - 1u;
   uint32_t* bins = lds;
@@ -518,118 +505,25 @@ DEV void ix_buckets(const JobParams& J, const ShardDesc& D, const uint8_t* input
   uint64_t* d2S = (uint64_t*)(lds + 256 + 3u * NL);
   IxLds S;
   S.w0 = w0S; S.d = dS; S.d2 = d2S;
-  // the bounds of all the wave's buckets in one round trip: lane l has the start of bucket b0 + l (the last bucket's
-  // end is the shard's total), lane 63 the total = the storable positions of the shard
-  const uint32_t nbk = 1u << J.ix_nb_log2;
-  const uint32_t bounds = cnt[umin(b0 + ((uint32_t)lane <= nb ? (uint32_t)lane : nbk), nbk) * J.ix_slices];
-  const uint32_t ntot = wave_bcast(bounds, 63);
-  if (ntot == 0u) return;
-  uint32_t start = wave_bcast(bounds, 0);
-  uint32_t end = wave_bcast(bounds, 1);
-  // the first rows of the bucket's entries (an index past the bucket's end reads its last entry, or — an empty
-  // bucket — some entry of the shard: never used)
-  uint32_t pre[IX_LROWS];
-#pragma unroll
-  for (uint32_t r = 0; r < IX_LROWS; ++r) {
-    const uint32_t i = umin(r * 64u + (uint32_t)lane, end - start - (end != start ? 1u : 0u));
-    pre[r] = ent[umin(start + i, ntot - 1u)];
-  }
-  for (uint32_t bucket = b0; bucket < b0 + nb; ++bucket) {
-    const uint32_t m = end - start;
-    const uint32_t cur_start = start;
+  wave_sync();
+  for (uint32_t b = (uint32_t)lane; b < 128u; b += 64u) bins[b] = 0;
+  wave_sync();
+  if (m <= NL) {
+    // ---- the whole bucket in registers, then sorted into LDS ----
     IxEntry row[IX_LROWS];
 #pragma unroll
-    for (uint32_t r = 0; r < IX_LROWS; ++r) { row[r].w0 = pre[r]; row[r].w1 = 0; }
-    // (1) the 16 bytes at every entry's position, all rows in flight together, and (2) the first rows of the next
-    // bucket's entries.  Straight-line code on purpose — the same loads whatever the bucket's size, the last bucket
-    // asking for one line again: the compiler counts the loads in flight exactly only along code without branches,
-    // and everything below waits for precisely the loads it uses.
+    for (uint32_t r = 0; r < IX_LROWS; ++r) {
+      const uint32_t i = r * 64u + (uint32_t)lane;
+      row[r].w0 = row[r].w1 = 0; row[r].d = row[r].d2 = 0;
+      if (i < m) row[r].w0 = ent[start + i];
+    }
 #pragma unroll
     for (uint32_t r = 0; r < IX_LROWS; ++r) {
-      uint64_t b[2];
-      __builtin_memcpy(b, data + (row[r].w0 & 0xFFFFFFu), 16);
-      row[r].d = b[0]; row[r].d2 = b[1];
-    }
-    {
-      const bool more = bucket + 1u < b0 + nb;
-      const uint32_t nstart = more ? end : start;
-      const uint32_t nend = more ? wave_bcast(bounds, (int)umin(bucket + 2u - b0, nb)) : start;
-#pragma unroll
-      for (uint32_t r = 0; r < IX_LROWS; ++r) {
-        const uint32_t i = umin(r * 64u + (uint32_t)lane, nend - nstart - (nend != nstart ? 1u : 0u));
-        pre[r] = ent[umin(nstart + i, ntot - 1u)];
+      if (r * 64u >= m) break;
+      if (r * 64u + (uint32_t)lane < m) {
+        ix_fetch(J, data, row[r]);
+        lds_atomic_add(&bins[row[r].w1 & lowmask], 1u);
       }
-      start = nstart; end = nend;
-    }
-    if (m == 0u || m > skip_above) continue;       // (a listed giant bucket: a worker at the front of the grid has it)
-    wave_sync();
-    for (uint32_t b = (uint32_t)lane; b < 128u; b += 64u) bins[b] = 0;
-    wave_sync();
-    if (m <= NL) {
-      // ---- the whole bucket in registers, sorted into LDS ----
-      // An entry travels with the low bits of its key (k_ix_scatter): counts, offsets and every entry's slot in the
-      // sorted bucket are worked out while the gathers are under way; the bytes go to their slots as they arrive.
-#pragma unroll
-      for (uint32_t r = 0; r < IX_LROWS; ++r) {
-        if (r * 64u >= m) break;
-        if (r * 64u + (uint32_t)lane < m) lds_atomic_add(&bins[row[r].w0 >> 24], 1u);
-      }
-      wave_sync();
-      {
-        const uint32_t a = bins[2 * lane], b = bins[2 * lane + 1];
-        const uint32_t incl = wave_incl_scan(a + b);
-        wave_sync();
-        bins[2 * lane] = incl - a - b;
-        bins[2 * lane + 1] = incl - b;
-        cursor[2 * lane] = incl - a - b;
-        cursor[2 * lane + 1] = incl - b;
-      }
-      wave_sync();
-      uint32_t slot[IX_LROWS];
-#pragma unroll
-      for (uint32_t r = 0; r < IX_LROWS; ++r) {
-        slot[r] = 0;
-        if (r * 64u >= m) break;
-        const bool act = r * 64u + (uint32_t)lane < m;
-        const uint32_t kl = row[r].w0 >> 24;
-        const uint64_t same = ix_match_any(act, kl, lowbits);
-        const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
-        const uint32_t total = (uint32_t)dev_popc64(same);
-        uint32_t at = 0;
-        if (act) at = cursor[kl];
-        wave_sync();
-        if (act && rank + 1u == total) cursor[kl] = at + total;
-        slot[r] = at + rank;
-        wave_sync();
-      }
-#pragma unroll
-      for (uint32_t r = 0; r < IX_LROWS; ++r) {
-        if (r * 64u >= m) break;
-        if (r * 64u + (uint32_t)lane < m) {
-          const KeyTag kt2 = hash_pos(row[r].d, J.hasher_type, J.bucket_bits);
-          row[r].w0 = (row[r].w0 & 0xFFFFFFu) | (kt2.tag << 24);
-          ix_lds_put(w0S, dS, d2S, slot[r], row[r]);
-        }
-      }
-      wave_sync();
-      for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-        const uint32_t i = r0 + (uint32_t)lane;
-        const bool act = i < m;
-        IxEntry e;
-        e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
-        if (act) { e.w0 = w0S[i]; e.d = dS[i]; e.d2 = d2S[i]; e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key; }
-        const uint32_t kl = e.w1 & lowmask;
-        const uint32_t rank = act ? i - bins[kl] : 0u;
-        const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
-        ix_window<STREAM>(g, data, e, act, rank, nsucc, S, act ? i : 0u, cur_start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
-      }
-      wave_sync();
-      continue;
-    }
-    // ---- a bigger bucket: sorted through HBM (ent -> ent2), searched row by row ----
-    for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-      const uint32_t i = r0 + (uint32_t)lane;
-      if (i < m) lds_atomic_add(&bins[ent[cur_start + i] >> 24], 1u);     // (the entry carries its low key bits: no fetch)
     }
     wave_sync();
     {
@@ -642,11 +536,11 @@ DEV void ix_buckets(const JobParams& J, const ShardDesc& D, const uint8_t* input
       cursor[2 * lane + 1] = incl - b;
     }
     wave_sync();
-    for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-      const uint32_t i = r0 + (uint32_t)lane;
-      const bool act = i < m;
-      const uint32_t ew = act ? ent[cur_start + i] : 0u;
-      const uint32_t kl = ew >> 24;
+#pragma unroll
+    for (uint32_t r = 0; r < IX_LROWS; ++r) {
+      if (r * 64u >= m) break;
+      const bool act = r * 64u + (uint32_t)lane < m;
+      const uint32_t kl = row[r].w1 & lowmask;
       const uint64_t same = ix_match_any(act, kl, lowbits);
       const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
       const uint32_t total = (uint32_t)dev_popc64(same);
@@ -654,27 +548,72 @@ DEV void ix_buckets(const JobParams& J, const ShardDesc& D, const uint8_t* input
       if (act) at = cursor[kl];
       wave_sync();
       if (act && rank + 1u == total) cursor[kl] = at + total;
+      if (act) ix_lds_put(w0S, dS, d2S, at + rank, row[r]);
       wave_sync();
-      if (act) ent2[cur_start + at + rank] = ew;
     }
-    wave_sync();
-    // staged entries 0..15 = the last 16 entries of the previous row, 16 + lane = this row's
     for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
       const uint32_t i = r0 + (uint32_t)lane;
       const bool act = i < m;
       IxEntry e;
       e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
-      if (act) { e.w0 = ent2[cur_start + i]; ix_fetch(J, data, e); }
-      ix_lds_put(w0S, dS, d2S, 16u + (uint32_t)lane, e);
-      wave_sync();
+      if (act) { e.w0 = w0S[i]; e.d = dS[i]; e.d2 = d2S[i]; e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key; }
       const uint32_t kl = e.w1 & lowmask;
       const uint32_t rank = act ? i - bins[kl] : 0u;
-      const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;
-      ix_window<STREAM>(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, cur_start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
-      wave_sync();
-      if (lane >= 48) ix_lds_put(w0S, dS, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
-      wave_sync();
+      const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
+      ix_window<STREAM>(g, data, e, act, rank, nsucc, S, act ? i : 0u, start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
     }
+    wave_sync();
+    return;
+  }
+  // ---- a bigger bucket: sorted through HBM (ent -> ent2), searched row by row ----
+  for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+    const uint32_t i = r0 + (uint32_t)lane;
+    if (i < m) lds_atomic_add(&bins[ent[start + i] >> 24], 1u);     // (the entry carries its low key bits: no fetch)
+  }
+  wave_sync();
+  {
+    const uint32_t a = bins[2 * lane], b = bins[2 * lane + 1];
+    const uint32_t incl = wave_incl_scan(a + b);
+    wave_sync();
+    bins[2 * lane] = incl - a - b;
+    bins[2 * lane + 1] = incl - b;
+    cursor[2 * lane] = incl - a - b;
+    cursor[2 * lane + 1] = incl - b;
+  }
+  wave_sync();
+  for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+    const uint32_t i = r0 + (uint32_t)lane;
+    const bool act = i < m;
+    const uint32_t ew = act ? ent[start + i] : 0u;
+    const uint32_t kl = ew >> 24;
+    const uint64_t same = ix_match_any(act, kl, lowbits);
+    const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
+    const uint32_t total = (uint32_t)dev_popc64(same);
+    uint32_t at = 0;
+    if (act) at = cursor[kl];
+    wave_sync();
+    if (act && rank + 1u == total) cursor[kl] = at + total;
+    wave_sync();
+    if (act) ent2[start + at + rank] = ew;
+  }
+  wave_sync();
+  // staged entries 0..15 = the last 16 entries of the previous row, 16 + lane = this row's
+  for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+    const uint32_t i = r0 + (uint32_t)lane;
+    const bool act = i < m;
+    IxEntry e;
+    e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
+    if (act) { e.w0 = ent2[start + i]; ix_fetch(J, data, e); }
+    ix_lds_put(w0S, dS, d2S, 16u + (uint32_t)lane, e);
+    wave_sync();
+    const uint32_t kl = e.w1 & lowmask;
+    const uint32_t rank = act ? i - bins[kl] : 0u;
+    const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;
+    ix_window<STREAM>(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
+    wave_sync();
+    if (lane >= 48) ix_lds_put(w0S, dS, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
+    wave_sync();
   }
 }
+
 #endif  // BROTLI_AMD_CSRC_K_INDEX_H_

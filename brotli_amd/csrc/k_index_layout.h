@@ -31,17 +31,6 @@
                                               //   holds when it found nothing, or when its winner was stored (k_chain.h)
 #define IX_DANGER 0x80000000u                 // the bucket counter may have wrapped (>= 65520 stores of one key)
 
-// Giant buckets (runs of zeros: one key takes a whole shard): a wave needs tens of milliseconds for one, and one that
-// starts late is the whole kernel's tail.  k_ix_scan lists the buckets above IX_GIANT_MIN entries, per XCD class
-// (shard % 8: the class whose workgroups touch the shard, kernels.h); the first IX_GIANT_WORKERS workgroups of
-// k_ix_bucket work the lists off — longest work first — and the regular waves pass over what is listed.  A class
-// whose list overflows (count > IX_GIANT_CAP) is not listed at all: both sides read the same count.
-// JobArgs::giant: 8 x (count, IX_GIANT_CAP items of shard << 10 | bucket); nullptr = no lists.
-#define IX_GIANT_MIN (8u * 64u * IX_LROWS)
-#define IX_GIANT_CAP 4095u
-#define IX_GIANT_WORKERS 2048u
-#define IX_GIANT_WORDS (8u * (1u + IX_GIANT_CAP))
-
 // Entry of the sort as it travels through HBM: position | (low bits of the key: the ones the first level did not
 // sort by) << 24 (4 bytes) — a bucket too big for LDS is sorted by them without looking at the input again.  The
 // bucket pass re-reads the 16 bytes at the position from the shard's input (which sits in the L2) once and keeps

@@ -55,7 +55,6 @@ struct JobArgs {
   uint8_t* sout = nullptr;            //   the stream's output
   uint32_t mcap = 0;
   uint32_t aux = 0;                   //   k_stream_cuts: 1 = describe the meta-blocks
-  uint32_t* giant = nullptr;          // index kernels: the lists of giant buckets (k_index_layout.h: IX_GIANT_WORDS), or none
   uint32_t wide_k = 1;                // k_wide.h: waves per meta-block in the part kernels (run_build_store sets it)
 };
 
@@ -118,14 +117,13 @@ __global__ void __launch_bounds__(64, PARSE4_WAVES) k_parse4(JobArgs a) {
 __global__ void __launch_bounds__(64) k_ix_count(JobArgs a) {
   __shared__ uint32_t lds_cnt[IX_NB_MAX];
   const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
-  if (blockIdx.x == 0 && a.giant != nullptr && threadIdx.x < 8u) a.giant[threadIdx.x * (1u + IX_GIANT_CAP)] = 0;
   if (shard >= a.nshards) return;
   ix_count(a.J, a.shards[shard], a.input, a.ws, w, lds_cnt);
 }
 // grid = nshards, block = 64
 __global__ void __launch_bounds__(64) k_ix_scan(JobArgs a) {
   if (blockIdx.x >= a.nshards) return;
-  ix_scan(a.J, a.shards[blockIdx.x], a.ws, a.giant, blockIdx.x);
+  ix_scan(a.J, a.shards[blockIdx.x], a.ws);
 }
 // grid = nshards * ix_slices, block = 64
 __global__ void __launch_bounds__(64) k_ix_scatter(JobArgs a) {
@@ -144,32 +142,14 @@ __global__ void __launch_bounds__(64) k_ix_scatter(JobArgs a) {
 // together stay in ONE XCD's L2 instead of being written back partially by eight.
 template <bool STREAM>
 DEV void ix_bucket_kernel(const JobArgs& a, uint32_t* lds_b) {
-  uint32_t bid = blockIdx.x;
-  if (a.giant != nullptr) {
-    if (bid < IX_GIANT_WORKERS) {
-      // a worker on the lists of giant buckets: class = its XCD, items k, k + workers per class, ...
-      const uint32_t* G = a.giant + (bid & 7u) * (1u + IX_GIANT_CAP);
-      const uint32_t n = G[0];
-      if (n > IX_GIANT_CAP) return;                 // (overflow: the regular waves do them)
-      for (uint32_t i = bid >> 3; i < n; i += IX_GIANT_WORKERS / 8u) {
-        const uint32_t item = G[1u + i];
-        ix_buckets<STREAM>(a.J, a.shards[item >> 10], a.input, a.ws, item & 1023u, 1u, lds_b);
-      }
-      return;
-    }
-    bid -= IX_GIANT_WORKERS;
-  }
   const uint32_t per = (1u << a.J.ix_nb_log2) / a.J.ix_bpw;
-  const uint32_t xcd = bid & 7u, slot = bid >> 3;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t shard = (slot / per) * 8u + xcd, b0 = (slot % per) * a.J.ix_bpw;
   if (shard >= a.nshards) return;
-  uint32_t skip_above = 0xFFFFFFFFu;
-  if (a.giant != nullptr && a.giant[xcd * (1u + IX_GIANT_CAP)] <= IX_GIANT_CAP) skip_above = IX_GIANT_MIN;
-  ix_buckets<STREAM>(a.J, a.shards[shard], a.input, a.ws, b0, a.J.ix_bpw, lds_b, skip_above);
+  for (uint32_t b = b0; b < b0 + a.J.ix_bpw; ++b) ix_bucket<STREAM>(a.J, a.shards[shard], a.input, a.ws, b, lds_b);
 }
-// Workgroups of k_ix_bucket for a job of nshards shards (the giant-bucket workers come first).
-static inline uint32_t ix_bucket_grid(const JobParams& J, uint32_t nshards, bool giant) {
-  return (giant ? IX_GIANT_WORKERS : 0u) + ((nshards + 7u) / 8u) * 8u * ((1u << J.ix_nb_log2) / J.ix_bpw);
+static inline uint32_t ix_bucket_grid(const JobParams& J, uint32_t nshards) {
+  return ((nshards + 7u) / 8u) * 8u * ((1u << J.ix_nb_log2) / J.ix_bpw);
 }
 __global__ void __launch_bounds__(64, IXB_WAVES) k_ix_bucket(JobArgs a) {
   __shared__ uint32_t lds_b[IX_BUCKET_LDS_WORDS];

@@ -29,15 +29,11 @@ struct SimRun {
 };
 uint32_t sim_wide() { const char* e = getenv("SIM_WIDE"); return e ? (uint32_t)atoi(e) : 0u; }     // 0 = off, else waves per meta-block
 // The index kernels of an indexed job (k_index.h), once per job.
-void run_index(const JobArgs& a0, int reverse) {
-  // (SIM_NO_GIANT_LISTS: every bucket by its regular wave, as on a device without the lists)
-  std::vector<uint32_t> giant(IX_GIANT_WORDS, 0xCDCDCDCDu);
-  JobArgs a = a0;
-  a.giant = getenv("SIM_NO_GIANT_LISTS") ? nullptr : giant.data();
+void run_index(const JobArgs& a, int reverse) {
   run(k_ix_count, a, a.nshards * a.J.ix_slices, 64, reverse);
   run(k_ix_scan, a, a.nshards, 64, reverse);
   run(k_ix_scatter, a, a.nshards * a.J.ix_slices, 64, reverse);
-  run((a.J.flags & JOB_FLAG_STREAMT) ? k_ix_bucket_s : k_ix_bucket, a, ix_bucket_grid(a.J, a.nshards, a.giant != nullptr), 64, reverse);
+  run((a.J.flags & JOB_FLAG_STREAMT) ? k_ix_bucket_s : k_ix_bucket, a, ix_bucket_grid(a.J, a.nshards), 64, reverse);
 }
 void run_parse_kernel(JobArgs a, int reverse, int round = 0) {
   if (a.J.flags & JOB_FLAG_QUICK) {

@@ -239,6 +239,36 @@ def test_indexed_parse_tainted_results_that_still_hold(sim, oracle, name):
     assert sim.encode(data, 5, 22, 1 << 30, 48 << 10, flags=IX_LAYOUTS["groups4"] | 4) == _oracle_plan(oracle, data, 1 << 30, 48 << 10)
 
 
+def _noise_with_echoes(n, seed, echo_every=900, vocab=0):
+    """Noise in which earlier pieces come back (5 .. 60 bytes, from near and far): the literal spree runs, is
+    interrupted by matches — distance-cache ones too: the same piece twice in a row — and starts again."""
+    rng = np.random.default_rng(seed)
+    out = bytearray(rng.integers(0, 256, size=3000, dtype=np.uint8).tobytes())
+    while len(out) < n:
+        out += rng.integers(0, 256 if not vocab else vocab, size=int(rng.integers(20, 2 * echo_every)), dtype=np.uint8).tobytes()
+        ln = int(rng.integers(5, 60))
+        src = int(rng.integers(0, len(out) - ln)) if rng.integers(0, 3) else max(0, len(out) - int(rng.integers(ln, 400)))
+        piece = bytes(out[src:src + ln])
+        out += piece
+        if rng.integers(0, 4) == 0:
+            out += rng.integers(0, 256, size=int(rng.integers(1, 9)), dtype=np.uint8).tobytes() + piece
+    return bytes(out[:n])
+
+
+@pytest.mark.parametrize("seed,n,shard,echo,vocab", [(1, 150000, 0, 900, 0), (2, 200000, 70000, 300, 0), (3, 140000, 0, 5000, 0),
+                                                     (4, 100000, 30000, 200, 7), (5, 180000, 0, 2500, 40)])
+def test_indexed_parse_literal_spree_steps(sim, oracle, seed, n, shard, echo, vocab):
+    """The spree steps of the chain's fast path (c_group_fast: 16 searches 9 / 17 bytes apart per step): noise with
+    echoes, block ends inside the spree (64 KiB blocks, shards of one and of several blocks), both hashers, small
+    alphabets (key runs longer than 16: no IX_FULLRUN), lanes in either order; equal to the forced exact search."""
+    data = _noise_with_echoes(n, seed, echo, vocab)
+    for hint in (1 << 30, 0):
+        want = _oracle_plan(oracle, data, hint, shard)
+        for layout, rev in (("groups4", 0), ("groups4", 1), ("groups1", 0)):
+            assert sim.encode(data, 5, 22, hint, shard, reverse=rev, flags=IX_LAYOUTS[layout]) == want, (hint, layout, rev)
+    assert sim.encode(data, 5, 22, 1 << 30, shard, flags=IX_LAYOUTS["groups2"] | 4) == _oracle_plan(oracle, data, 1 << 30, shard)
+
+
 @pytest.mark.parametrize("seed", range(3))
 def test_indexed_parse_fuzz(sim, oracle, seed):
     rng = np.random.default_rng(4000 + seed)
