@@ -33,6 +33,7 @@ static inline uint32_t dev_mul24(uint32_t a, uint32_t b) { return a * b; }   // 
 static inline uint32_t dev_ffbl32(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 0xFFFFFFFFu; }
 template <class T> static inline T lds_atomic_add(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> static inline T lds_atomic_or(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T> static inline T lds_atomic_max(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
 static inline uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o | v; return o; }
 static inline uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 static inline uint32_t glb_atomic_and(uint32_t* p, uint32_t v) { uint32_t o = *p; *p = o & v; return o; }
@@ -128,6 +129,7 @@ __device__ __forceinline__ uint32_t dev_ffbl32(uint32_t x) {
 }
 template <class T> __device__ __forceinline__ T lds_atomic_add(T* p, T v) { return atomicAdd(p, v); }
 template <class T> __device__ __forceinline__ T lds_atomic_or(T* p, T v) { return atomicOr(p, v); }
+template <class T> __device__ __forceinline__ T lds_atomic_max(T* p, T v) { return atomicMax(p, v); }
 // Device-scope OR on a global dword (executed at the L2; result optional).
 __device__ __forceinline__ uint32_t glb_atomic_or(uint32_t* p, uint32_t v) { return atomicOr(p, v); }
 __device__ __forceinline__ uint32_t glb_atomic_add(uint32_t* p, uint32_t v) { return atomicAdd(p, v); }
