@@ -43,7 +43,6 @@ struct CShard {
   uint8_t* skip;         // bit (x - geo.first): storable position x was NOT stored by the parse
   uint32_t frontier;     // every storable position below it is either stored or marked in `skip`
   uint32_t nslow;
-  uint32_t spree_hit;    // position a spree step of the fast path stopped at because it has a match (c_group_fast), or ~0
   // tiled jobs (JOB_FLAG_TILED): this group parses [tile_lo, tile_hi) of the shard; only positions of the tile
   // are marked / tainted by it (the bitmap's words never straddle tiles: tiles are multiples of 32 positions
   // counted from geo.first)
@@ -170,6 +169,17 @@ DEV uint32_t c_extend_from(const uint8_t* data, uint32_t a, uint32_t b, uint32_t
   return off;
 }
 
+// Inclusive sum over the lanes 0 .. t of a group (row rotations, no LDS).
+DEV uint32_t q_incl_scan(uint32_t v) {
+  const int t = q_t();
+  uint32_t o;
+  o = wave_row_ror(v, 1); if (t >= 1) v += o;
+  o = wave_row_ror(v, 2); if (t >= 2) v += o;
+  o = wave_row_ror(v, 4); if (t >= 4) v += o;
+  o = wave_row_ror(v, 8); if (t >= 8) v += o;
+  return v;
+}
+
 // Exact FindLongestMatch (hash table part + distance cache, ..64_simd_inc.h:201-295) of
 // position P for the groups in `want`, from the sorted array.  The caller runs the
 // dictionary probe.
@@ -201,10 +211,66 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   const int32_t count_from = carried ? (int32_t)c_sidx : 0;
   uint32_t total = carried ? c_cnt : 0u;
   bool counted = !danger;
+  // (scratch[0 .. 15]: the sorted indices of the ring's entries, newest first)
   uint32_t found = 0, j0 = 0;
   bool exhausted = false;
   while (wave_any(want && !exhausted && (found < 16u || !counted))) {
-    const bool on = want && !exhausted && (found < 16u || !counted);
+    const bool on0 = want && !exhausted && (found < 16u || !counted);
+    // ---- 128 entries a round: eight per lane, the round's farthest entry still in the run (then all of them are: a
+    // key's entries are one stretch of the sorted array).  A lane's eight positions usually lie within a few dozen
+    // bytes of each other — runs of zeros, where a copy stores its last four positions and leaves the rest unstored, so
+    // that the 16 stored predecessors lie hundreds of entries back: 13 rounds of 16 entries with three dependent loads
+    // each were the whole chain time of the Silesia-style mix (profiles/r04_d) — and their bits of the bitmap come with
+    // one 8-byte load. ----
+    bool fast = false;
+    if (C.mode == 0u) {
+      const int32_t hi_idx = sidx - 1 - (int32_t)j0, far_idx = hi_idx - 127;
+      const bool tryf = on0 && far_idx >= 0;
+      if (wave_any(tryf)) {
+        if (tryf) fast = hash_pos(ld64(g.data + (C.srt[far_idx] & 0xFFFFFFu) + C.ibase), J.hasher_type, J.bucket_bits).key == kt.key;
+        if (wave_any(fast)) {
+          const int32_t lo_t = hi_idx - 8 * t - 7;                // this lane: entries lo_t .. lo_t + 7, the newest last
+          uint32_t e8[8];
+          e8[0] = e8[7] = 0;
+          if (fast) __builtin_memcpy(e8, C.srt + lo_t, 32);
+          const uint32_t p0 = (e8[0] & 0xFFFFFFu) + C.ibase;
+          uint32_t z = 0;                                         // bit k: entry lo_t + k was stored
+          const bool near = fast && (e8[7] & 0xFFFFFFu) - (e8[0] & 0xFFFFFFu) < 56u;
+          if (near) {
+            const uint32_t b = p0 - C.geo.first;
+            uint64_t bw;
+            __builtin_memcpy(&bw, C.skip + (b >> 3), 8);
+            bw >>= (b & 7u);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) z |= (((uint32_t)(bw >> ((e8[k] & 0xFFFFFFu) + C.ibase - p0)) & 1u) ^ 1u) << k;
+          } else if (fast) {
+            for (int k = 0; k < 8; ++k) z |= (c_skipped(C, (e8[k] & 0xFFFFFFu) + C.ibase) ? 0u : 1u) << k;
+          }
+          uint32_t zc = z;                                        // ... of them, the ones the store count takes in
+          if (lo_t < count_from) { const int32_t sh = count_from - lo_t; zc = sh >= 8 ? 0u : (z >> sh) << sh; }
+          const uint32_t cnt = (uint32_t)__builtin_popcount(z);
+          const uint32_t incl = q_incl_scan(cnt);
+          const uint32_t tot = q_bcast(incl, 15);
+          const uint32_t totc = q_bcast(q_incl_scan((uint32_t)__builtin_popcount(zc)), 15);
+          uint32_t slot = found + incl - cnt;
+          while (z != 0u && slot < 16u) {                         // newest first
+            const uint32_t k = 31u - (uint32_t)dev_clz32(z);
+            scratch[slot++] = (uint32_t)(lo_t + (int32_t)k);
+            z &= ~(1u << k);
+          }
+#if defined(BROTLI_AMD_SIMT_SIM)
+          if (fast && t == 0 && getenv("SIM_FASTWALK")) fprintf(stderr, "FASTWALK P %u j0 %u found %u +%u\n", P, j0, found, tot);
+#endif
+          if (fast) {
+            found += tot; total += totc;
+            j0 += 128u;
+            if (sidx - (int32_t)j0 <= count_from) counted = true;
+          }
+        }
+      }
+    }
+    // ---- entry by entry ----
+    const bool on = on0 && !fast;
     const int32_t idx = sidx - 1 - (int32_t)(j0 + (uint32_t)t);
     const bool ok = on && idx >= 0;
     const uint32_t w0 = ok ? C.srt[idx] : 0u;
@@ -225,7 +291,7 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
     const uint32_t s16 = q_mask16(wave_ballot(stored));
     const uint32_t n16 = q_mask16(wave_ballot(stored && idx >= count_from));
     const uint32_t slot = found + (uint32_t)__builtin_popcount(s16 & ((1u << t) - 1u));
-    if (stored && slot < 16u) scratch[slot] = w0;
+    if (stored && slot < 16u) scratch[slot] = (uint32_t)idx;
     if (on) {
       found += (uint32_t)__builtin_popcount(s16);
       total += (uint32_t)__builtin_popcount(n16);
@@ -242,7 +308,7 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   uint32_t nvalid = umin(found, 16u);
   if (danger) { const uint32_t n = total & 0xFFFFu; nvalid = n < 16u ? n : 16u; }
   if (sdanger) nvalid = umin(nvalid, svis);
-  const uint32_t w0 = (uint32_t)t < nvalid ? scratch[t] : 0u;
+  const uint32_t w0 = (uint32_t)t < nvalid ? C.srt[scratch[t]] : 0u;
   const uint32_t b_prev = (w0 & 0xFFFFFFu) + C.ibase;
   const bool b_cand = want && (uint32_t)t < nvalid && (w0 >> 24) == kt.tag && (P - b_prev) <= max_backward;
   wave_sync();
@@ -477,26 +543,10 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     SIM_COUNT(14, 1);
     uint64_t ft = QP_NOW();
     const uint32_t pos = g.position;
-    // ---- a step inside the literal spree (:208-236; the plain chain, the static dictionary no longer consulted) ----
-    // Behind `apply_random_heuristics` a position that finds nothing is followed by a jump: four stores two (four) bytes
-    // apart, the next search 9 (17) bytes on.  The searches of such a stretch — noise, floats — do not depend on each
-    // other as long as they all miss (no command, the distance cache stays), so the 16 lanes take the next 16 of
-    // them, pos + U t, and the group moves over the leading ones that miss for certain: lane 0 by the usual rules, the
-    // others only when the index saw the whole key run and found nothing in it (IX_FULLRUN, kind NONE: nothing the
-    // jumps before them leave unstored can change that) and no distance-cache candidate matches.  It stops in front of
-    // the first other one; a match there is remembered (spree_hit) and evaluated by a regular step.
-    const uint32_t arh = g.apply_random_heuristics;
-    const bool gate_closed0 = g.dict_matches < (g.dict_lookups >> 7);
-    const bool spree = can && pos >= arh && gate_closed0 && C.mode == 0u && !force_slow && g.ring_mask == 0xFFFFFFFFu &&
-                       C.spree_hit != pos;
-    const bool far = pos + 1u > arh + 4u * J.spree_window;
-    const uint32_t U = far ? 17u : 9u;
-    const uint32_t Pk = pos + (spree ? U * (uint32_t)t : (uint32_t)t);
-    // (units of one kind only, each with its jump and the compares of its search clear of the block's end)
-    const bool canl = can && (!spree || (Pk + 64u <= g.pos_end && (far || Pk + 1u <= arh + 4u * J.spree_window)));
+    const uint32_t Pk = pos + (uint32_t)t;
     // ---- evaluation of position Pk ----
-    const C16 cb = c_load16(g.data + (canl ? Pk : 0u));
-    const uint64_t rw = C.res[canl ? Pk : C.ibase];      // (a stream: C.res is the chunk's array shifted by its base — index 0 lies gigabytes below it)
+    const C16 cb = c_load16(g.data + (can ? Pk : 0u));
+    const uint64_t rw = C.res[can ? Pk : C.ibase];      // (a stream: C.res is the chunk's array shifted by its base — index 0 lies gigabytes below it)
     C16 pb[4];
     const uint32_t maxb = umin(Pk, limit);
     const uint32_t dcs[4] = {(uint32_t)g.dc[0], (uint32_t)g.dc[1], (uint32_t)g.dc[2], (uint32_t)g.dc[3]};
@@ -504,7 +554,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const uint32_t dcv = dcs[i];
-      d_cand[i] = canl && (dcv - 1u) < maxb;                  // 0 < distance <= max_backward
+      d_cand[i] = can && (dcv - 1u) < maxb;                   // 0 < distance <= max_backward
       pb[i] = c_load16(g.data + (d_cand[i] ? Pk - dcv : 0u));
     }
     // (len, earlier entry) orders the cache candidates like their scores do (see c_evaluate)
@@ -537,7 +587,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     }
     bool tainted = (rhi & IX_TAINT) != 0;
     {
-      const bool soft = canl && C.mode == 0u && kind <= IX_KIND_EXACT && c_taint_soft(rhi, kind);
+      const bool soft = can && C.mode == 0u && kind <= IX_KIND_EXACT && c_taint_soft(rhi, kind);
       if (wave_any(soft)) { if (c_taint_holds(C, soft, kind, Pk, b_dist)) tainted = false; }
     }
     const bool need = kind >= IX_KIND_LONG || (rhi & IX_DANGER) != 0 || tainted || d_long || force_slow || ring_risk ||
@@ -545,7 +595,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     uint32_t sc = b_wins ? b_score : dc_score;
     uint32_t ln = b_wins ? b_len : dc_len;
     uint32_t ds = b_wins ? b_dist : dc_dist;
-    uint32_t use16 = q_mask16(wave_ballot(canl && !need));
+    uint32_t use16 = q_mask16(wave_ballot(can && !need));
     QP_ADD(g, 8, ft);
     // ---- an undecidable first position: the exact search, then on with its result ----
     bool dead = false;                                          // this step cannot move the group
@@ -561,31 +611,6 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
       }
     }
     uint32_t hit16 = q_mask16(wave_ballot(sc > K_MIN_SCORE));
-    if (wave_any(spree)) {
-      const bool miss = t == 0 ? ((use16 & 1u) != 0u && sc == K_MIN_SCORE)
-                               : (canl && !need && sc == K_MIN_SCORE && kind == IX_KIND_NONE && (rhi & IX_FULLRUN) != 0u);
-      const uint32_t miss16 = q_mask16(wave_ballot(spree && miss));
-      const uint32_t n = (uint32_t)dev_ctz32(~miss16 | 0x10000u);           // units this step moves over
-      if (spree) {
-        if (n == 0u) g.status |= 0x80000000u;                               // (a match at pos itself: the generic step)
-        else {
-          g.position = pos + U * n;
-          g.insert_length += U * n;
-          g.stat_searches += n;
-          g.cmd_flags |= CMDF_SPREE;
-          C.spree_hit = (n < 16u && ((use16 & hit16) >> n) & 1u) ? pos + U * n : 0xFFFFFFFFu;
-        }
-      }
-      // what the jumps left unstored: [P + 1, P + U) but for P + 1, P + 1 + step, ...
-      const uint32_t nmax = wave_max_u32(spree ? n : 0u);
-      for (uint32_t k = 0; k < nmax; ++k) {
-        const bool on = spree && k < n;
-        const uint32_t a = pos + U * k + 1u;
-        c_mark_range(J, C, on, a, a + U - 1u, a, far ? 4u : 2u);
-      }
-      if (spree && n != 0u) C.frontier = pos + U * n;
-    }
-    const bool canr = can && !spree;                            // the groups on a regular step
     // ---- nothing found at the first position while the static dictionary is being consulted
     // (hash.h:179-202): probe it here.  A dictionary match starts the lazy evaluation, which the
     // generic step carries on with (it may ask the dictionary again at the next position).
@@ -597,7 +622,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
       // (not when the literal spree trips right behind this position: that step belongs to the generic path,
       // which searches the position itself — asking here as well would count the two lookups twice and close
       // the gate earlier than the reference does; found by tools/fuzz_index_sim.py)
-      const bool dq = canr && !gate_closed && (hit16 & 1u) == 0u && room != 0u;
+      const bool dq = can && !gate_closed && (hit16 & 1u) == 0u && room != 0u;
       if (wave_any(dq)) {
         QResult r;
         r.len = 0; r.distance = 0; r.score = K_MIN_SCORE; r.delta = 0;
@@ -618,7 +643,7 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     // lane t: does position t + 1 beat position t by the lazy-matching margin (:139)?
     const uint32_t sc_next = wave_row_ror(sc, 15);              // lane t reads lane (t + 1) & 15 of its group
     const uint32_t adv16 = q_mask16(wave_ballot(t < 15 && sc_next >= sc + 175u));
-    const uint32_t Uu = (uint32_t)dev_ctz32(~use16 | 0x10000u);                 // usable prefix
+    const uint32_t U = (uint32_t)dev_ctz32(~use16 | 0x10000u);                  // usable prefix
     const uint32_t m = (uint32_t)dev_ctz32(hit16 | 0x10000u);                   // first match
     // ... / the dictionary has to be asked
     const uint32_t missmax = gate_closed ? room : dict0 ? umin(room, 1u) : 0u;
@@ -627,23 +652,23 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
     // while the static dictionary is being consulted, a probe that finds nothing asks it:
     // only probes with a match are decidable here
     const uint32_t probes = (0x3FFFFu >> (17u - umin(last, 16u))) & ~(0x1FFFFu >> (16u - umin(m, 16u)));   // bits m + 1 .. last
-    const bool have = canr && !dead && m < 16u && m <= missmax && last < Uu &&
+    const bool have = can && !dead && m < 16u && m <= missmax && last < U &&
                       (gate_closed || (hit16 & probes) == probes);
-    const uint32_t L = umin(umin(m, Uu), missmax);              // literals this step may consume without a match
-    if (canr && !dead && !have && L != 0u) {
+    const uint32_t L = umin(umin(m, U), missmax);               // literals this step may consume without a match
+    if (can && !dead && !have && L != 0u) {
       g.position = pos + L;
       g.insert_length += L;
       g.stat_searches += L;
       C.frontier = pos + L;
     }
-    if (canr && !have && (dead || L == 0u)) { g.status |= 0x80000000u; }        // needs the generic step
+    if (can && !have && (dead || L == 0u)) { g.status |= 0x80000000u; }         // needs the generic step
 #if defined(BROTLI_AMD_SIMT_SIM)
-    if (canr && t == 0) {
+    if (can && t == 0) {
       if (have) g_sim_counts[0]++;                       // steps with a commit
       else if (dead) g_sim_counts[2]++;                  // dictionary match: lazy evaluation handed to the generic step
       else if (L != 0u) g_sim_counts[1]++;               // literal-only steps
-      else if (m < 16u && m < Uu && m <= missmax && last >= Uu) g_sim_counts[3]++;   // lazy chain runs into an undecidable position
-      else if (m < 16u && m < Uu && m <= missmax) g_sim_counts[4]++;                // lazy probe without a match, dictionary gate open
+      else if (m < 16u && m < U && m <= missmax && last >= U) g_sim_counts[3]++;   // lazy chain runs into an undecidable position
+      else if (m < 16u && m < U && m <= missmax) g_sim_counts[4]++;                // lazy probe without a match, dictionary gate open
       else if (missmax == 0u) g_sim_counts[5]++;         // spree / dictionary gate at the first position
       else g_sim_counts[6]++;
     }
@@ -679,10 +704,9 @@ DEV void c_group_fast(const JobParams& J, const DeviceTables* T, CShard& C, bool
         if (t == 0) {
           Command c;
           c.insert_len = ins; c.copy_len = sr_len; c.dist_extra = code; c.cmd_prefix = CMD_RAW;
-          c.dist_prefix = (uint16_t)((tt == 4u ? CMDF_NOPROBE : 0u) | g.cmd_flags | dflags | (umin(tt, 3u) << CMDF_DELAYED_SHIFT));
+          c.dist_prefix = (uint16_t)((tt == 4u ? CMDF_NOPROBE : 0u) | dflags | (umin(tt, 3u) << CMDF_DELAYED_SHIFT));
           g.cmds[g.r.ncmds] = c;
         }
-        g.cmd_flags = 0;
         ++g.r.ncmds;
         g.r.nlits += ins;
         g.insert_length = 0;
@@ -721,16 +745,6 @@ DEV uint32_t c_code_distance(uint32_t code, int32_t d0, int32_t d1, int32_t d2, 
   const uint32_t k = code - 4u, kk = k < 6u ? k : k - 6u;
   const uint32_t base = (uint32_t)(k < 6u ? d0 : d1), mag = (kk >> 1) + 1u;
   return (kk & 1u) ? base + mag : base - mag;
-}
-// Inclusive sum over the lanes 0 .. t of a group (row rotations, no LDS).
-DEV uint32_t q_incl_scan(uint32_t v) {
-  const int t = q_t();
-  uint32_t o;
-  o = wave_row_ror(v, 1); if (t >= 1) v += o;
-  o = wave_row_ror(v, 2); if (t >= 2) v += o;
-  o = wave_row_ror(v, 4); if (t >= 4) v += o;
-  o = wave_row_ror(v, 8); if (t >= 8) v += o;
-  return v;
 }
 // First event at or behind `from` (for the groups in `act`), `limit` if there is none below it: the 16 lanes of
 // a group look at 16 words of the bitmap per round.
@@ -993,7 +1007,6 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   }
   C.frontier = S0->ix_frontier;
   C.nslow = 0;
-  C.spree_hit = 0xFFFFFFFFu;
   C.tile_lo = 0;
   C.tile_hi = D.len;
   C.mode = tiled ? C_TILED : 0u;

@@ -328,79 +328,17 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
 // ---- level 2 + window search: one wave per (shard, bucket) -------------------------------
 DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + dev_mul24(135u, len) - dev_mul24(30u, log2floor(dist)); }
 
-// The bucket loop of FindLongestMatch (..64_simd_inc.h:246-292) for the 64 entries of a row of the sorted bucket
-// (LDS index rowbase + lane; the entries before an entry sit at its index - 1, - 2, ...).  rank = same-key entries
-// before it, nsucc = same-key entries after it.  Matches of up to 16 bytes are decided from LDS alone; longer ones
-// compare on in the input.  Writes srt[] and res[].
-//
-// LDS arrays of the sorted bucket, 20 bytes per entry: w0 (position | tag << 24), the filter word f, bytes 4..7,
-// bytes 8..15.  f = bytes 0..3 + tag * IX_FMUL: among entries of one tag, f is equal exactly when the first four
-// bytes are — "same tag and same first four bytes" (the two tests every slot of the reference's loop starts with,
-// :258-263) is ONE 4-byte compare per slot; two different tags can give the same f, so the tag is looked at again
-// where a candidate is evaluated.
-//
-// The search is VALU-bound (profiles/r04_d: ~1000 vector instructions per 64 entries at 71 % issue utilisation, two
-// thirds of them in a slot loop every lane walked to the wave's longest window — in text some lane of every row has
-// a frequent 5-gram with all 16 slots alive), so the work is levelled: after the filter the (entry, candidate) PAIRS
-// of the row — 1.3 per entry on text — are spread over the lanes, 64 per round: lane q finds its pair's owner by a
-// search in the exclusive prefix of the candidate counts (shuffles, no memory), evaluates the pair from LDS and
-// hands the result back with one LDS atomic (max of score | slot | length: the reference's arg-max with its
-// visiting order as the tie break is order-independent).  Candidates equal in 16 bytes go round once more the same
-// way, the two nearest of each entry first: two capped ones already decide the entry (IX_KIND_SLOW).
-#define IX_FMUL 0x9E3779B1u
-#define IX_FPAD 16u        // words in front of f[]: the filter reads f[index - 16 .. index - 1] unconditionally
-struct IxLds { const uint32_t* w0; const uint32_t* f; const uint32_t* b47; const uint64_t* d2; uint32_t* best; uint32_t* lng; uint32_t* cap; uint32_t* ncap; };
-// score (13 bits) | 16 - slot (5) | length (6): greater = what the reference's loop keeps
-DEV uint32_t ix_key(uint32_t len, uint32_t dist, uint32_t j) { return (ix_score(len, dist) << 11) | ((16u - j) << 6) | len; }
-// Position (0 .. 15) of the r-th set bit of a 16-bit mask, r < its population count.
-DEV uint32_t ix_nth_bit16(uint32_t m, uint32_t r) {
-  uint32_t pos = 0;
-  uint32_t c = (uint32_t)__builtin_popcount(m & 0xFFu);
-  if (r >= c) { r -= c; pos = 8u; m >>= 8; }
-  c = (uint32_t)__builtin_popcount(m & 0xFu);
-  if (r >= c) { r -= c; pos += 4u; m >>= 4; }
-  c = (uint32_t)__builtin_popcount(m & 3u);
-  if (r >= c) { r -= c; pos += 2u; m >>= 2; }
-  if (r >= (m & 1u)) pos += 1u;
-  return pos;
-}
-// Owner of pair q: the largest lane whose exclusive prefix is <= q (every lane takes part in the shuffles).
-DEV uint32_t ix_owner(uint32_t pre, uint32_t q) {
-  uint32_t lo = 0;
-#pragma unroll
-  for (uint32_t s = 32u; s != 0u; s >>= 1) {
-    const uint32_t v = wave_shfl(pre, (int)(lo + s));
-    if (v <= q) lo += s;
-  }
-  return lo;
-}
-// Candidate slot j of the entry at LDS index lo, up to 16 bytes: its key — 0 when it is none (another tag, beyond
-// the window) —, or `lng` when it is equal in all 16 bytes and may be longer; `ring`: see ix_window.
-template <bool STREAM>
-DEV uint32_t ix_pair(const IxGeom& g, const IxLds& S, uint32_t lo, uint32_t j, uint32_t oml, uint32_t rm, bool& lng, bool& ring) {
-  const uint32_t ow0 = S.w0[lo], qw = S.w0[lo - j];
-  const uint32_t po = ow0 & 0xFFFFFFu, pc = qw & 0xFFFFFFu;
-  lng = false; ring = false;
-  if ((qw >> 24) != (ow0 >> 24)) return 0u;                     // (f can agree across tags)
-  if (STREAM && po - pc > umin(po + g.base, g.maxdist)) return 0u;   // beyond the window (:239-241: it and everything older)
-  const uint32_t x = S.b47[lo - j] ^ S.b47[lo];
-  uint32_t l = x ? 4u + ((uint32_t)dev_ctz32(x) >> 3) : 8u;    // (first4 == current4 by the filter)
-  if (l == 8u) {
-    const uint64_t x2 = S.d2[lo - j] ^ S.d2[lo];
-    l = x2 ? 8u + ((uint32_t)dev_ctz64(x2) >> 3) : 16u;
-  }
-  if (l == 16u && oml > 16u) { lng = true; return 0u; }
-  const uint32_t len = umin(l, oml);
-  if (STREAM && ((((pc + g.base) & rm) + len > rm) || (((po + g.base) & rm) + len > rm))) ring = true;
-  return ix_key(len, po - pc, j);
-}
+// The bucket loop of FindLongestMatch (..64_simd_inc.h:246-292) for the entry at index li of the
+// LDS arrays (w0 / bytes 0..7 / bytes 8..15, in (key, position) order): the entries before it sit
+// at li - 1, li - 2, ...  rank = same-key entries before it, nsucc = same-key entries after it.
+// Matches of up to 16 bytes are decided from LDS alone; longer ones compare on in the input.
+// Writes srt[] and res[].
+struct IxLds { const uint32_t* w0; const uint64_t* d; const uint64_t* d2; };
 // (STREAM: a chunk of a tiled stream — the window limit, the ring's end and the key table exist there only; a plain
 //  shard's instantiation carries none of it)
 template <bool STREAM>
 DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool act, uint32_t rank, uint32_t nsucc,
-                   const IxLds& S, uint32_t rowbase, uint32_t sidx, uint32_t* srt, uint64_t* res, uint32_t* kt = nullptr, uint32_t nkeys = 0) {
-  const uint32_t lane = (uint32_t)wave_lane();
-  const uint32_t li = rowbase + lane;
+                   const IxLds& S, uint32_t li, uint32_t sidx, uint32_t* srt, uint64_t* res, uint32_t* kt = nullptr, uint32_t nkeys = 0) {
   if (STREAM && kt != nullptr && act) {
     // a stream's chunk: the key run's place in srt[], and how much of it lies in the chunk's own part
     const uint32_t pp = e.w0 & 0xFFFFFFu;
@@ -414,156 +352,126 @@ DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool 
   const bool danger = !STREAM && rank >= 65520u;
   const bool search = act && p >= g.own && ix_searchable(g, P);
   const uint32_t max_length = search ? ix_block_end(g, P) - P : 0u;
+  const uint32_t maxb = umin(P, g.maxdist);                     // max_backward (backward_references_inc.h:56-57)
   // the ring buffer's physical end (..64_simd_inc.h:243-249: no candidate is looked at once the current position is
   // within best_len of it, one that is within best_len of it is passed over): a candidate whose match does not reach
   // over the end — at either position — loses whenever one of the two rules would have applied to it (best_len is then
   // longer than its match), so only a candidate whose match does reach over it makes the search order-dependent —
   // the chain's to do
+  bool ringrisk = false;
   const uint32_t rm = STREAM ? g.ring_mask : 0xFFFFFFFFu;
-  const uint32_t nwin = search ? umin(rank, 16u) : 0u;
-  // (1) the filter: all 16 slots, loads independent of each other
-  const uint32_t my_f = (uint32_t)e.d + tag * IX_FMUL;
-  uint32_t cand = 0;
-#pragma unroll
-  for (uint32_t j = 1; j <= 16u; ++j) cand |= S.f[(int32_t)li - (int32_t)j] == my_f ? 1u << j : 0u;
-  cand &= (2u << nwin) - 2u;                                    // slots 1 .. nwin
-  const uint32_t ml6 = umin(max_length, 63u);                   // (lengths are compared up to IX_CAP = 40 only)
-  // (2) every entry its nearest candidate itself (half of the pairs on text, and no search for an owner) ...
-  {
-    uint32_t k0 = 0, l0 = 0;
-#if !defined(IX_NO_LOCAL_FIRST)   // (timing experiment: every pair through the rounds)
-    if (cand != 0) {
+  uint32_t best = 0, best_len = 0, best_dist = 0;               // exact candidates
+  uint32_t longmask = 0;
+#if defined(IX_NOWIN)       // (timing experiments only: results are wrong)
+  const uint32_t nwin = 0u;
 #else
-    if (false) {
+  const uint32_t nwin = search ? umin(rank, 16u) : 0u;
 #endif
-      const uint32_t j = (uint32_t)dev_ctz32(cand);
-      cand &= cand - 1u;
-      bool lng, ring;
-      k0 = ix_pair<STREAM>(g, S, li, j, ml6, rm, lng, ring);
-      l0 = (lng ? 1u << j : 0u) | (ring ? 0x80000000u : 0u);
+  const uint32_t nmax = (uint32_t)wave_max_u32(nwin);
+  for (uint32_t j = 1; j <= nmax; ++j) {
+    if (j > nwin) continue;
+    const uint32_t qw = S.w0[li - j];
+    if ((qw >> 24) != tag) continue;
+    const uint64_t x = S.d[li - j] ^ e.d;
+    uint32_t l = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
+    if (l < 4u) continue;                                       // first4 != current4
+    if (STREAM && p - (qw & 0xFFFFFFu) > maxb) continue;        // beyond the window (:239-241: it and everything older)
+    if (l == 8u) {
+      const uint64_t x2 = S.d2[li - j] ^ e.d2;
+      l = x2 ? 8u + ((uint32_t)dev_ctz64(x2) >> 3) : 16u;
+#if !defined(IX_NOLONG)     // (timing experiments only: results are wrong)
+      if (l == 16u && max_length > 16u) { longmask |= 1u << j; continue; }
+#endif
     }
-    S.best[lane] = k0; S.lng[lane] = l0;
+    const uint32_t len = umin(l, max_length);
+    if (STREAM && ((((qw & 0xFFFFFFu) + g.base) & rm) + len > rm || (P & rm) + len > rm)) ringrisk = true;
+    const uint32_t dist = p - (qw & 0xFFFFFFu);
+    const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
+    if (k > best) { best = k; best_len = len; best_dist = dist; }
   }
-  // ... then the other pairs that passed, 64 per round
-  if (wave_ballot(cand != 0) != 0) {
-    const uint32_t cnt = (uint32_t)__builtin_popcount(cand);
-    const uint32_t incl = wave_incl_scan(cnt), pre = incl - cnt;
-    const uint32_t T = wave_bcast(incl, 63);
-    const uint32_t cw = (cand >> 1) | (ml6 << 16);
-    wave_sync();
-    for (uint32_t base = 0; base < T; base += 64u) {
-      const uint32_t q = base + lane;
-      const bool on = q < T;
-      const uint32_t o = ix_owner(pre, on ? q : 0u);
-      const uint32_t opre = wave_shfl(pre, (int)o), ocw = wave_shfl(cw, (int)o);
-      if (on) {
-        const uint32_t j = 1u + ix_nth_bit16(ocw & 0xFFFFu, q - opre);
-        bool lng, ring;
-        const uint32_t k = ix_pair<STREAM>(g, S, rowbase + o, j, (ocw >> 16) & 63u, rm, lng, ring);
-        if (lng || ring) lds_atomic_or(&S.lng[o], (lng ? 1u << j : 0u) | (ring ? 0x80000000u : 0u));
-        if (k != 0u) lds_atomic_max(&S.best[o], k);
-      }
-    }
-  }
-  wave_sync();
-  const uint32_t lm = S.lng[lane];
-  const uint32_t longmask = lm & 0x1FFFEu;
-  bool ringrisk = STREAM && (lm >> 31) != 0u;
-  // (3) candidates equal in the first 16 bytes: compare on in the input (bytes 16..31; the few that are still equal
-  // fetch 32..39), pairs spread over the lanes again — the two nearest of every entry first, the others only where
-  // fewer than two of those reach the cap
-  uint32_t ncapped = 0, cap_key = 0;
+  // candidates equal in the first 16 bytes: compare on in the input, four candidates per
+  // round trip (bytes 16..31 first; the few that are still equal fetch 32..39)
+  uint32_t ncapped = 0, cap_key = 0, cap_dist = 0;
   if (wave_ballot(longmask != 0) != 0) {
-    S.cap[lane] = 0; S.ncap[lane] = 0;
-    uint32_t rest = longmask;
-    for (int pass = 0; pass < 2; ++pass) {
-      uint32_t now;
-      if (pass == 0) {
-        const uint32_t a = rest & (0u - rest), b1 = rest ^ a, b = b1 & (0u - b1);
-        now = a | b;
-      } else now = S.ncap[lane] >= 2u ? 0u : rest;
-      rest &= ~now;
-      if (wave_ballot(now != 0) == 0) continue;
-      const uint32_t cnt = (uint32_t)__builtin_popcount(now);
-      const uint32_t incl = wave_incl_scan(cnt), pre = incl - cnt;
-      const uint32_t T = wave_bcast(incl, 63);
-      const uint32_t cw = (now >> 1) | (ml6 << 16);
-      wave_sync();
-      for (uint32_t base = 0; base < T; base += 64u) {
-        const uint32_t q = base + lane;
-        const bool on = q < T;
-        const uint32_t o = ix_owner(pre, on ? q : 0u);
-        const uint32_t opre = wave_shfl(pre, (int)o), ocw = wave_shfl(cw, (int)o);
-        uint32_t j = 0, po = 0, pc = 0;
-        uint64_t mine[3] = {0, 0, 0}, c[2] = {0, 0};
-        if (on) {
-          j = 1u + ix_nth_bit16(ocw & 0xFFFFu, q - opre);
-          const uint32_t lo = rowbase + o;
-          po = S.w0[lo] & 0xFFFFFFu; pc = S.w0[lo - j] & 0xFFFFFFu;
-          __builtin_memcpy(mine, data + po + 16u, 24);
-          __builtin_memcpy(c, data + pc + 16u, 16);
-        }
-        const uint32_t oml = (ocw >> 16) & 63u;
-        const uint64_t x0 = c[0] ^ mine[0], x1 = c[1] ^ mine[1];
-        uint32_t ln = x0 ? 16u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 24u + ((uint32_t)dev_ctz64(x1) >> 3) : 32u;
-        const bool more = on && ln == 32u && oml > 32u;
-        if (wave_ballot(more) != 0) {
-          if (more) {
-            const uint64_t x2 = ld64(data + pc + 32u) ^ mine[2];
-            ln = x2 ? 32u + ((uint32_t)dev_ctz64(x2) >> 3) : 40u;
+    uint64_t mine[3] = {0, 0, 0};
+    if (longmask != 0) __builtin_memcpy(mine, data + p + 16u, 24);
+    while (wave_ballot(longmask != 0) != 0) {
+      // (two capped candidates make the search the chain's — IX_KIND_SLOW — whatever the others are: runs of zeros,
+      //  where all 16 candidates are equal for as long as one looks, stop after the first round)
+      if (ncapped >= 2u) longmask = 0;
+      uint32_t jj[4], qp[4], ln[4];
+      uint64_t c[4][2];
+      bool more = false;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        jj[u] = longmask != 0 ? (uint32_t)dev_ctz32(longmask) : 0u;
+        longmask &= longmask - 1u;
+        qp[u] = S.w0[li - jj[u]] & 0xFFFFFFu;
+        c[u][0] = c[u][1] = 0;
+        if (jj[u] != 0) __builtin_memcpy(c[u], data + qp[u] + 16u, 16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint64_t x0 = c[u][0] ^ mine[0], x1 = c[u][1] ^ mine[1];
+        ln[u] = x0 ? 16u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 24u + ((uint32_t)dev_ctz64(x1) >> 3) : 32u;
+        if (jj[u] != 0 && ln[u] == 32u && max_length > 32u) more = true;
+      }
+      if (wave_ballot(more) != 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (jj[u] != 0 && ln[u] == 32u && max_length > 32u) {
+            const uint64_t x0 = ld64(data + qp[u] + 32u) ^ mine[2];
+            ln[u] = x0 ? 32u + ((uint32_t)dev_ctz64(x0) >> 3) : 40u;
           }
-        }
-        if (on) {
-          const uint32_t len = umin(ln, oml);
-          const bool capped = len == IX_CAP && oml > IX_CAP;
-          if (STREAM) {
-            const uint32_t Po = po + g.base;
-            const uint32_t reach = capped ? ix_block_end(g, Po) - Po : len;          // (a capped one: as far as it may go)
-            if ((((pc + g.base) & rm) + reach > rm) || ((Po & rm) + reach > rm)) lds_atomic_or(&S.lng[o], 0x80000000u);
-          }
-          const uint32_t k = ix_key(len, po - pc, j);
-          if (capped) { lds_atomic_add(&S.ncap[o], 1u); lds_atomic_max(&S.cap[o], k); }
-          else lds_atomic_max(&S.best[o], k);
         }
       }
-      wave_sync();
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (jj[u] == 0) continue;
+        const uint32_t len = umin(ln[u], max_length);
+        const uint32_t dist = p - qp[u];
+        {
+          const uint32_t reach = (len == IX_CAP && max_length > IX_CAP) ? max_length : len;     // (a capped one: as far as it may go)
+          if (STREAM && (((qp[u] + g.base) & rm) + reach > rm || (P & rm) + reach > rm)) ringrisk = true;
+        }
+        const uint32_t k = (ix_score(len, dist) << 5) | (16u - jj[u]);
+        if (len == IX_CAP && max_length > IX_CAP) {
+          ++ncapped;
+          if (k > cap_key) { cap_key = k; cap_dist = dist; }
+        } else if (k > best) { best = k; best_len = len; best_dist = dist; }
+      }
     }
-    ncapped = S.ncap[lane];
-    cap_key = S.cap[lane];
-    if (STREAM) ringrisk = ringrisk || (S.lng[lane] >> 31) != 0u;
   }
-  const uint32_t best = S.best[lane];
   if (act) {
     srt[sidx] = e.w0;
-    uint32_t kind, len = 0, dist = 0, wj = 0;
+    uint32_t kind, len = 0, dist = 0;
     if (!search) kind = IX_KIND_NONE;
     else if (danger || ringrisk || ncapped >= 2u) kind = IX_KIND_SLOW;
     else if (ncapped == 1u) {
       // the long candidate's score can only grow with its real length
-      if (cap_key > best) { kind = IX_KIND_LONG; len = IX_CAP; wj = 16u - ((cap_key >> 6) & 31u); }
+      if (cap_key > best) { kind = IX_KIND_LONG; len = IX_CAP; dist = cap_dist; }
       else kind = IX_KIND_SLOW;
-    } else if (best != 0) { kind = IX_KIND_EXACT; len = best & 63u; wj = 16u - ((best >> 6) & 31u); }
+    } else if (best != 0) { kind = IX_KIND_EXACT; len = best_len; dist = best_dist; }
     else kind = IX_KIND_NONE;
-    if (wj != 0u) dist = p - (S.w0[li - wj] & 0xFFFFFFu);
     const uint32_t lo = (kind << 30) | (len << 24) | dist;
     const uint32_t hi = sidx | (umin(nsucc, 16u) << IX_NSUCC_SHIFT) | (danger ? IX_DANGER : 0u) |
                         ((!STREAM && rank <= 16u) ? IX_FULLRUN : 0u);
+#if defined(IX_NORES)        // (timing experiments only: results are wrong)
+    if (lo == 0x12345u) res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
+#elif defined(IX_RES_SORTED) // (timing experiments only)
+    res[sidx] = (uint64_t)lo | ((uint64_t)hi << 32);
+#else
     res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
+#endif
   }
 }
 
-// lds (words): [0, 128) bin starts, [128, 256) cursors of the sort — during the search best[64] + lng[64] —, then
-// w0[N], IX_FPAD + f[N], bytes 4..7 [N], bytes 8..15 [N] (2 words each), cap[64], ncap[64]; N = 64 * IX_LROWS entries of
-// the sorted bucket — or, for a bigger bucket, the (16 + 64) staged entries of the row being searched.  8000 bytes:
-// five waves per SIMD.
-#define IX_BUCKET_LDS_WORDS (256u + 64u * IX_LROWS * 5u + IX_FPAD + 128u)
-DEV void ix_lds_put(uint32_t* w0S, uint32_t* fS, uint32_t* b47S, uint64_t* d2S, uint32_t i, const IxEntry& e) {
-  w0S[i] = e.w0; fS[i] = (uint32_t)e.d + (e.w0 >> 24) * IX_FMUL; b47S[i] = (uint32_t)(e.d >> 32); d2S[i] = e.d2;
-}
-DEV void ix_lds_get(const uint32_t* w0S, const uint32_t* fS, const uint32_t* b47S, const uint64_t* d2S, uint32_t i, IxEntry& e) {
-  e.w0 = w0S[i];
-  e.d = (uint64_t)(fS[i] - (e.w0 >> 24) * IX_FMUL) | ((uint64_t)b47S[i] << 32);
-  e.d2 = d2S[i];
+// lds (words): [0, 128) bin starts, [128, 256) cursors, then w0[N], bytes 0..7 [N] (2 words each),
+// bytes 8..15 [N], N = 64 * IX_LROWS entries of the sorted bucket — or, for a bigger bucket, the
+// (16 + 64) staged entries of the row being searched
+#define IX_BUCKET_LDS_WORDS (256u + 64u * IX_LROWS * 5u)
+DEV void ix_lds_put(uint32_t* w0S, uint64_t* dS, uint64_t* d2S, uint32_t i, const IxEntry& e) {
+  w0S[i] = e.w0; dS[i] = e.d; d2S[i] = e.d2;
 }
 // (STREAM: the index chunks of a tiled stream — a kernel of its own, k_ix_bucket_s: the plain kernel carries neither
 //  the window limit / ring end / key table code nor the registers it pins.)
@@ -593,13 +501,10 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   uint32_t* cursor = lds + 128;
   const uint32_t NL = 64u * IX_LROWS;
   uint32_t* w0S = lds + 256;
-  uint32_t* fS = lds + 256 + NL + IX_FPAD;
-  uint32_t* b47S = fS + NL;
-  uint64_t* d2S = (uint64_t*)(b47S + NL);
+  uint64_t* dS = (uint64_t*)(lds + 256 + NL);
+  uint64_t* d2S = (uint64_t*)(lds + 256 + 3u * NL);
   IxLds S;
-  S.w0 = w0S; S.f = fS; S.b47 = b47S; S.d2 = d2S;
-  S.best = lds + 128; S.lng = lds + 192;
-  S.cap = b47S + 3u * NL; S.ncap = S.cap + 64;
+  S.w0 = w0S; S.d = dS; S.d2 = d2S;
   wave_sync();
   for (uint32_t b = (uint32_t)lane; b < 128u; b += 64u) bins[b] = 0;
   wave_sync();
@@ -643,7 +548,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       if (act) at = cursor[kl];
       wave_sync();
       if (act && rank + 1u == total) cursor[kl] = at + total;
-      if (act) ix_lds_put(w0S, fS, b47S, d2S, at + rank, row[r]);
+      if (act) ix_lds_put(w0S, dS, d2S, at + rank, row[r]);
       wave_sync();
     }
     for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
@@ -651,19 +556,32 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       const bool act = i < m;
       IxEntry e;
       e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
-      if (act) { ix_lds_get(w0S, fS, b47S, d2S, i, e); e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key; }
+      if (act) { e.w0 = w0S[i]; e.d = dS[i]; e.d2 = d2S[i]; e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key; }
       const uint32_t kl = e.w1 & lowmask;
       const uint32_t rank = act ? i - bins[kl] : 0u;
       const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
-      ix_window<STREAM>(g, data, e, act, rank, nsucc, S, r0, start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
+      ix_window<STREAM>(g, data, e, act, rank, nsucc, S, act ? i : 0u, start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
     }
     wave_sync();
     return;
   }
   // ---- a bigger bucket: sorted through HBM (ent -> ent2), searched row by row ----
-  for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-    const uint32_t i = r0 + (uint32_t)lane;
-    if (i < m) lds_atomic_add(&bins[ent[start + i] >> 24], 1u);     // (the entry carries its low key bits: no fetch)
+  // (Every bucket of a shard of a MiB, the one bucket a run of zeros fills.  A row's chain — entries, the bytes at
+  //  their positions, the search — is a wave's own here, one row after the other, so the loads run ahead of it: four
+  //  rows of entries per round trip while counting, the next row's entries under way while this one is ranked, and in
+  //  the search the entries two rows ahead and the bytes one row ahead.)
+  for (uint32_t r0 = 0; r0 < m; r0 += 256u) {
+    uint32_t v[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      const uint32_t i = r0 + u * 64u + (uint32_t)lane;
+      v[u] = ent[start + umin(i, m - 1u)];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; ++u) {
+      const uint32_t i = r0 + u * 64u + (uint32_t)lane;
+      if (i < m) lds_atomic_add(&bins[v[u] >> 24], 1u);          // (the entry carries its low key bits: no fetch)
+    }
   }
   wave_sync();
   {
@@ -676,38 +594,57 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     cursor[2 * lane + 1] = incl - b;
   }
   wave_sync();
-  for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-    const uint32_t i = r0 + (uint32_t)lane;
-    const bool act = i < m;
-    const uint32_t ew = act ? ent[start + i] : 0u;
-    const uint32_t kl = ew >> 24;
-    const uint64_t same = ix_match_any(act, kl, lowbits);
-    const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
-    const uint32_t total = (uint32_t)dev_popc64(same);
-    uint32_t at = 0;
-    if (act) at = cursor[kl];
-    wave_sync();
-    if (act && rank + 1u == total) cursor[kl] = at + total;
-    wave_sync();
-    if (act) ent2[start + at + rank] = ew;
+  {
+    uint32_t ahead = ent[start + umin((uint32_t)lane, m - 1u)];
+    for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+      const uint32_t i = r0 + (uint32_t)lane;
+      const bool act = i < m;
+      const uint32_t ew = ahead;
+      ahead = ent[start + umin(i + 64u, m - 1u)];
+      const uint32_t kl = ew >> 24;
+      const uint64_t same = ix_match_any(act, kl, lowbits);
+      const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
+      const uint32_t total = (uint32_t)dev_popc64(same);
+      uint32_t at = 0;
+      if (act) at = cursor[kl];
+      wave_sync();
+      if (act && rank + 1u == total) cursor[kl] = at + total;
+      wave_sync();
+      if (act) ent2[start + at + rank] = ew;
+    }
   }
   wave_sync();
   // staged entries 0..15 = the last 16 entries of the previous row, 16 + lane = this row's
-  for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-    const uint32_t i = r0 + (uint32_t)lane;
-    const bool act = i < m;
-    IxEntry e;
-    e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
-    if (act) { e.w0 = ent2[start + i]; ix_fetch(J, data, e); }
-    ix_lds_put(w0S, fS, b47S, d2S, 16u + (uint32_t)lane, e);
-    wave_sync();
-    const uint32_t kl = e.w1 & lowmask;
-    const uint32_t rank = act ? i - bins[kl] : 0u;
-    const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;
-    ix_window<STREAM>(g, data, e, act, rank, nsucc, S, 16u, start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
-    wave_sync();
-    if (lane >= 48) ix_lds_put(w0S, fS, b47S, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
-    wave_sync();
+  {
+    uint32_t w_next = ent2[start + umin((uint32_t)lane, m - 1u)];             // row 0's entries
+    uint64_t b_next[2];
+    __builtin_memcpy(b_next, data + (w_next & 0xFFFFFFu), 16);                 // ... and their bytes
+    uint32_t w_ahead = ent2[start + umin(64u + (uint32_t)lane, m - 1u)];       // row 1's entries
+    for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+      const uint32_t i = r0 + (uint32_t)lane;
+      const bool act = i < m;
+      IxEntry e;
+      e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
+      if (act) {
+        e.w0 = w_next; e.d = b_next[0]; e.d2 = b_next[1];
+        const KeyTag kt2 = hash_pos(e.d, J.hasher_type, J.bucket_bits);
+        e.w1 = kt2.key;
+        e.w0 = (e.w0 & 0xFFFFFFu) | (kt2.tag << 24);
+      }
+      // the next row's bytes, the entries of the row behind it
+      w_next = w_ahead;
+      __builtin_memcpy(b_next, data + (w_next & 0xFFFFFFu), 16);
+      w_ahead = ent2[start + umin(i + 128u, m - 1u)];
+      ix_lds_put(w0S, dS, d2S, 16u + (uint32_t)lane, e);
+      wave_sync();
+      const uint32_t kl = e.w1 & lowmask;
+      const uint32_t rank = act ? i - bins[kl] : 0u;
+      const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;
+      ix_window<STREAM>(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
+      wave_sync();
+      if (lane >= 48) ix_lds_put(w0S, dS, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
+      wave_sync();
+    }
   }
 }
 

@@ -258,9 +258,12 @@ def _noise_with_echoes(n, seed, echo_every=900, vocab=0):
 @pytest.mark.parametrize("seed,n,shard,echo,vocab", [(1, 150000, 0, 900, 0), (2, 200000, 70000, 300, 0), (3, 140000, 0, 5000, 0),
                                                      (4, 100000, 30000, 200, 7), (5, 180000, 0, 2500, 40)])
 def test_indexed_parse_literal_spree_steps(sim, oracle, seed, n, shard, echo, vocab):
-    """The spree steps of the chain's fast path (c_group_fast: 16 searches 9 / 17 bytes apart per step): noise with
-    echoes, block ends inside the spree (64 KiB blocks, shards of one and of several blocks), both hashers, small
-    alphabets (key runs longer than 16: no IX_FULLRUN), lanes in either order; equal to the forced exact search."""
+    """The literal spree (backward_references_inc.h:208-236) under the indexed parse: noise with echoes — most
+    positions unstored, nearly every search tainted, matches that interrupt the spree —, block ends inside it (64 KiB
+    blocks, shards of one and of several blocks), both hashers, small alphabets (key runs longer than 16: no
+    IX_FULLRUN), lanes in either order; equal to the forced exact search.  (Written for a variant of the chain's fast
+    path that took 16 spree searches per step — measured on the MI355X: +3 ms per GiB of text for nothing on the
+    mix, whose chain time is its sparse-zero shards', profiles/r04_e — and kept for what it covers.)"""
     data = _noise_with_echoes(n, seed, echo, vocab)
     for hint in (1 << 30, 0):
         want = _oracle_plan(oracle, data, hint, shard)

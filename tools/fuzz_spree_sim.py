@@ -1,4 +1,4 @@
-"""Offline fuzz of the chain's spree steps (k_chain.h c_group_fast) and of the tainted-result rule (IX_FULLRUN) on the
+"""Offline fuzz of the literal spree under the indexed parse and of the tainted-result rule (IX_FULLRUN, k_chain.h) on the
 simulator: noise / small alphabets / floats with echoes, random shard sizes, both hashers, every wave layout, lanes in
 either order, against the oracle's plan.
     python tools/fuzz_spree_sim.py SEED COUNT"""
