@@ -258,9 +258,6 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
             scratch[slot++] = (uint32_t)(lo_t + (int32_t)k);
             z &= ~(1u << k);
           }
-#if defined(BROTLI_AMD_SIMT_SIM)
-          if (fast && t == 0 && getenv("SIM_FASTWALK")) fprintf(stderr, "FASTWALK P %u j0 %u found %u +%u\n", P, j0, found, tot);
-#endif
           if (fast) {
             found += tot; total += totc;
             j0 += 128u;
