@@ -217,14 +217,14 @@ static int ensure_initialized(BrotliEncoderState* s) {
   if (s->lgwin < 10) s->lgwin = 10;
   if (s->lgwin > 24 && !s->large_window) s->lgwin = 24;
   /* What the kernels implement: qualities 2..4 (H2 / H3 / H4 / H54) and 5..9 (H68 / H58 / H6 / H5; H40 / H41 / H42 at
-     windows of 10..16 bits), default block size, default distance parameters, no base64 regions,
+     windows of 10..16 bits), any block size (BROTLI_PARAM_LGBLOCK), default distance parameters, no base64 regions,
      literal context modelling on, the x86-64 default hashers. */
   if (s->quality == 1) {
     /* The two-pass fragment compressor ignores mode, block size, distance
        parameters, context modelling, size hint and hasher selection
        (encode.c:1660-1664 branches before any of them is read). */
     if (s->large_window || s->shard_bytes != 0) s->failed = 1;
-  } else if (s->quality < 2 || s->quality > 9 || s->lgwin > 24 || s->large_window || s->lgblock != 0 ||
+  } else if (s->quality < 2 || s->quality > 9 || s->lgwin > 24 || s->large_window ||
       s->mode == 2 /* FONT: non-zero distance parameters, encode.c:616-640 */ ||
       s->npostfix != 0 || s->ndirect != 0 || s->base64_mode != 0 ||
       s->simd_hasher != 0 /* ENABLE / DISABLE change the hasher choice at q5-q7 */) {
@@ -294,11 +294,24 @@ static int push_dictionaries_to(BrotliEncoderState* s, int to_context) {
   if (to_context) return brotli_amd_ctx_set_dictionary(s->ctx, ch, s->ndicts) == BROTLI_AMD_OK;
   return brotli_amd_stream_attach_dictionary(s->stream, ch, s->ndicts) == BROTLI_AMD_OK;
 }
+/* BROTLI_PARAM_LGBLOCK as the device layer takes it (bits 24..28 of the flags; 0 = the quality's default), and the
+   input block it results in (ComputeLgBlock, quality.h:75-92: looked at from quality 4 on, clamped to 16 .. 24). */
+static uint32_t lgblock_flag(const BrotliEncoderState* s) {
+  const int lg = s->lgblock;
+  if (lg == 0 || s->quality < 4) return 0u;
+  return BROTLI_AMD_FLAG_LGBLOCK(lg < 16 ? 16 : lg > 24 ? 24 : lg);
+}
+static int eff_lgblock(const BrotliEncoderState* s) {
+  if (s->quality < 4) return 14;
+  if (s->lgblock != 0) return s->lgblock < 16 ? 16 : s->lgblock > 24 ? 24 : s->lgblock;
+  if (s->quality >= 9 && s->lgwin > 16) return s->lgwin < 18 ? s->lgwin : 18;
+  return 16;
+}
 static int open_stream(BrotliEncoderState* s) {
   if (s->stream) return 1;
   if (brotli_amd_stream_create(s->ctx, s->quality, s->lgwin, s->eff_hint, s->stream_offset,
                                (s->header_written == 2 ? BROTLI_AMD_FLAG_NO_HEADER : 0u) |
-                               (s->disable_ctx ? BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT : 0u),
+                               (s->disable_ctx ? BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT : 0u) | lgblock_flag(s),
                                &s->stream) != BROTLI_AMD_OK) return 0;
   if (s->ndicts && !push_dictionaries(s)) return 0;
   return 1;
@@ -374,7 +387,7 @@ static int wants_stream_tiles(const BrotliEncoderState* s, int op) {
   const char* e = getenv("BROTLI_AMD_STREAM_TILES");
   if (e && atoi(e) == 0) return 0;
   return s->quality == 5 && s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream && s->ndicts == 0 &&
-         s->stream_offset == 0 &&
+         s->stream_offset == 0 && eff_lgblock(s) == 16 &&
          s->lgwin >= 17 && s->lgwin <= 22 && s->in_len > ((size_t)1 << s->lgwin) - 16 && s->in_len < ((size_t)1 << 31);
 }
 
@@ -437,6 +450,7 @@ static int submit(BrotliEncoderState* s, int op) {
     p.is_last = op == OP_FINISH;
     if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
     if (s->disable_ctx) p.flags |= BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT;
+    p.flags |= lgblock_flag(s);
     if (stream_tiles) p.flags |= BROTLI_AMD_FLAG_STREAM_TILES;
     cap = brotli_amd_max_output(s->in_len, &p);
     if (cap == 0) return 0;
@@ -528,6 +542,7 @@ static int forward_pending_input(BrotliEncoderState* s, int force) {
     p.is_last = 0;
     if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
     if (s->disable_ctx) p.flags |= BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT;
+    p.flags |= lgblock_flag(s);
     cap = brotli_amd_max_output(whole, &p);
     if (cap == 0) return 0;
     if (!sync_context_dictionaries(s)) return 0;
@@ -662,10 +677,8 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
     /* UpdateSizeHint at the reference's first EncodeData (encode.c:1619-1632):
        when the first input block fills, or at the first op other than PROCESS. */
     if (!s->hint_fixed) {
-      /* flint, or the input block size: lgblock 16, at quality 9 min(18, lgwin) (quality.h:75-93) */
-      const uint64_t threshold = s->stream_offset ? 2u :
-          (s->quality >= 9 && s->lgwin > 16) ? ((uint64_t)1 << (s->lgwin < 18 ? s->lgwin : 18)) :
-          s->quality < 4 ? 16384u : 65536u;
+      /* flint, or the input block size (quality.h:75-93) */
+      const uint64_t threshold = s->stream_offset ? 2u : (uint64_t)1 << eff_lgblock(s);
       const uint64_t seen = s->total_in + a;
       if ((seen >= threshold || op != OP_PROCESS) && seen != 0) {   /* a hint of 0 stays open (:1620) */
         s->eff_hint = seen >= (1u << 30) ? (1u << 30) : (uint32_t)seen;

@@ -321,7 +321,7 @@ int upload_dictionary(BrotliAmdCtx* c, const BrotliAmdDictChunk* chunks, uint32_
 int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, JobPlan* plan) {
   if (len == 0) { fail(c, "empty job"); return BROTLI_AMD_UNSUPPORTED; }
   if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
-                p->is_last != 0, plan, /*tables_in_ws=*/false)) {
+                p->is_last != 0, plan, /*tables_in_ws=*/false, (int)((p->flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u))) {
     fail(c, "parameters outside the GPU path (quality %d lgwin %d)", p->quality, p->lgwin);
     return BROTLI_AMD_UNSUPPORTED;
   }
@@ -1000,7 +1000,7 @@ uint64_t brotli_amd_max_output(uint64_t len, const BrotliAmdJobParams* p) {
   JobPlan plan;
   if (len == 0) return 16;
   if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
-                p->is_last != 0, &plan)) return 0;
+                p->is_last != 0, &plan, true, (int)((p->flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u))) return 0;
   return plan.max_out_bytes;
 }
 
@@ -1015,8 +1015,9 @@ int brotli_amd_encode_device(BrotliAmdCtx* c, const void* d_in, uint64_t len,
   DeviceScope dev(c->device);
   if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   if (p->flags & BROTLI_AMD_FLAG_STREAM_TILES) {
-    if (p->quality != 5 || p->shard_size != 0 || p->stream_base != 0 || !p->is_last || c->d_cd || d_shard_sizes) {
-      fail(c, "BROTLI_AMD_FLAG_STREAM_TILES: quality 5, one whole stream, no dictionary");
+    if (p->quality != 5 || p->shard_size != 0 || p->stream_base != 0 || !p->is_last || c->d_cd || d_shard_sizes ||
+        ((p->flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u) != 0u) {
+      fail(c, "BROTLI_AMD_FLAG_STREAM_TILES: quality 5, one whole stream, no dictionary, the default block size");
       return BROTLI_AMD_UNSUPPORTED;
     }
     int src = BROTLI_AMD_ERROR;
@@ -1428,7 +1429,7 @@ int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t s
   if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
   BrotliAmdStream* s = new BrotliAmdStream();
   s->c = c;
-  if (!plan_params(quality, lgwin, size_hint, &s->J)) {
+  if (!plan_params(quality, lgwin, size_hint, &s->J, (int)((flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u))) {
     delete s;
     fail(c, "parameters outside the GPU path (quality %d lgwin %d)", quality, lgwin);
     return BROTLI_AMD_UNSUPPORTED;

@@ -32,7 +32,8 @@ static inline uint64_t plan_align(uint64_t x) { return (x + 255u) & ~(uint64_t)2
 // Derives the encoder parameters exactly as the reference does for
 // qualities 5..6 (c/enc/quality.h:59-223, encode.c:642-700).  Returns false for
 // parameter combinations this library does not implement on the GPU.
-static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobParams* J) {
+// lgblock: BROTLI_PARAM_LGBLOCK (0 = the default; looked at from quality 4 on, clamped to 16 .. 24: quality.h:75-92).
+static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobParams* J, int lgblock = 0) {
   memset(J, 0, sizeof(*J));
   if (quality < 2 || quality > 9) return false;      // q0-1: k_fast.h; q10-11: other algorithms
   if (lgwin > 24) return false;                      // large window: out of scope
@@ -41,6 +42,7 @@ static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobPa
   J->lgwin = lgwin;
   J->lgblock = quality < 4 ? 14 : 16;                // ComputeLgBlock, quality.h:75-92
   if (quality >= 9 && lgwin > 16) J->lgblock = lgwin < 18 ? lgwin : 18;
+  if (quality >= 4 && lgblock != 0) J->lgblock = lgblock < 16 ? 16 : lgblock > 24 ? 24 : lgblock;
   J->size_hint = size_hint;
   if (quality < 5) {
     // the quickly family: quality.h:176-179, template parameters hash.h:251-279, 329-338
@@ -85,12 +87,12 @@ static inline bool plan_params(int quality, int lgwin, uint32_t size_hint, JobPa
 // Partition plan + workspace layout.  shard_size == 0: one shard (Mode S).
 static inline bool plan_job(uint64_t len, int quality, int lgwin, uint32_t size_hint,
                             uint64_t shard_size, uint64_t stream_base, bool is_last,
-                            JobPlan* plan, bool tables_in_ws = true) {
+                            JobPlan* plan, bool tables_in_ws = true, int lgblock = 0) {
   if (size_hint == 0) {
     const uint64_t tot = stream_base + len;
     size_hint = tot >= (1u << 30) ? (1u << 30) : (uint32_t)tot;
   }
-  if (!plan_params(quality, lgwin, size_hint, &plan->J)) return false;
+  if (!plan_params(quality, lgwin, size_hint, &plan->J, lgblock)) return false;
   if (len == 0) return false;
   if (shard_size == 0 || shard_size >= len) shard_size = len;
   if (shard_size >= (3ull << 30)) return false;      // 32-bit positions, no wrap support

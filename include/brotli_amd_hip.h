@@ -56,6 +56,11 @@ typedef struct BrotliAmdJobParams {
   int32_t reserved;
 } BrotliAmdJobParams;
 
+#define BROTLI_AMD_FLAG_LGBLOCK_SHIFT 24 /* bits 24..28 of `flags` (jobs and streams): BROTLI_PARAM_LGBLOCK (encode.h:190-197), 0 = the
+                                           default of the quality; looked at from quality 4 on and clamped to 16 .. 24 as the
+                                           reference does (quality.h:75-92).  A tiled stream (BROTLI_AMD_FLAG_STREAM_TILES)
+                                           needs the default */
+#define BROTLI_AMD_FLAG_LGBLOCK(lg) (((uint32_t)(lg) & 31u) << BROTLI_AMD_FLAG_LGBLOCK_SHIFT)
 #define BROTLI_AMD_FLAG_NO_PAIR 1u    /* debugging: no speculative (p,p+1) search (k_parse) */
 #define BROTLI_AMD_FLAG_NO_QUAD 2u    /* always one shard per wave (k_parse) */
 #define BROTLI_AMD_FLAG_FORCE_SLOW 4u /* k_parse4: step-by-step candidate resolve */

@@ -187,8 +187,8 @@ long sim_encode(const char* tables_path, const uint8_t* in, size_t len, int qual
   HostTables ht;
   if (!host_tables_load(tables_path, &ht)) return -1;
   JobPlan plan;
-  if (!plan_job(len, quality, lgwin, size_hint, shard_size, stream_base, is_last != 0, &plan)) return -2;
-  plan.J.flags |= (uint32_t)flags;
+  if (!plan_job(len, quality, lgwin, size_hint, shard_size, stream_base, is_last != 0, &plan, true, (flags >> 24) & 31)) return -2;
+  plan.J.flags |= (uint32_t)flags & 0xFFFFFFu;       // (bits 24..28: BROTLI_PARAM_LGBLOCK)
   if (plan.J.quality != 5) plan.J.flags = (plan.J.flags & ~(JOB_FLAG_QUAD | JOB_FLAG_INDEXED)) | JOB_FLAG_DEEP;
   if (plan.J.flags & JOB_FLAG_INDEXED) plan_add_index(&plan, true);
   if ((plan.J.flags & JOB_FLAG_INDEXED) && getenv("SIM_TILE_KB"))
@@ -556,7 +556,8 @@ long sim_stream(const char* tables_path, const uint8_t* in, size_t len, int qual
   HostTables ht;
   if (!host_tables_load(tables_path, &ht)) return -1;
   JobParams J;
-  if (!plan_params(quality, lgwin, size_hint, &J)) return -2;
+  if (!plan_params(quality, lgwin, size_hint, &J, (reverse >> 24) & 31)) return -2;       // (bits 24..28 of `reverse`: BROTLI_PARAM_LGBLOCK)
+  reverse &= 1;
   if (quality != 5) J.flags |= JOB_FLAG_DEEP;
   const uint64_t mb = J.max_metablock_size;
   J.log2_lut_size = (uint32_t)(mb + 2);

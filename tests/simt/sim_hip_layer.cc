@@ -139,7 +139,8 @@ const char* brotli_amd_last_error(const BrotliAmdCtx* c) { return c ? c->err.c_s
 uint64_t brotli_amd_max_output(uint64_t len, const BrotliAmdJobParams* p) {
   JobPlan plan;
   if (len == 0) return 16;
-  if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base, p->is_last != 0, &plan)) return 0;
+  if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base, p->is_last != 0, &plan, true,
+                (int)((p->flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u))) return 0;
   return plan.max_out_bytes;
 }
 
@@ -149,8 +150,9 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len, con
   if (info) memset(info, 0, sizeof(*info));
   if (p->flags & BROTLI_AMD_FLAG_STREAM_TILES) {
     // (hip_layer.hip: run_stream_job)
-    if (p->quality != 5 || p->shard_size != 0 || p->stream_base != 0 || !p->is_last || c->dict.have)
-      return set_err(c, "BROTLI_AMD_FLAG_STREAM_TILES: quality 5, one whole stream, no dictionary", BROTLI_AMD_UNSUPPORTED);
+    if (p->quality != 5 || p->shard_size != 0 || p->stream_base != 0 || !p->is_last || c->dict.have ||
+        ((p->flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u) != 0u)
+      return set_err(c, "BROTLI_AMD_FLAG_STREAM_TILES: quality 5, one whole stream, no dictionary, the default block size", BROTLI_AMD_UNSUPPORTED);
     uint32_t sinfo[4] = {0, 0, 0, 0};
     int jflags = 0;
     if (p->flags & BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT) jflags |= (int)JOB_FLAG_NO_LITCTX;
@@ -165,7 +167,7 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len, con
   }
   JobPlan plan;
   if (len == 0 || !plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
-                            p->is_last != 0, &plan))
+                            p->is_last != 0, &plan, true, (int)((p->flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u)))
     return set_err(c, "parameters outside the GPU path", BROTLI_AMD_UNSUPPORTED);
   uint32_t lim = 0;
   // (a dictionary on the context: one shard per wave on the hash-table kernels, as hip_layer.hip does)
@@ -201,7 +203,7 @@ int brotli_amd_stream_create(BrotliAmdCtx* c, int quality, int lgwin, uint32_t s
   *out = nullptr;
   BrotliAmdStream* s = new BrotliAmdStream();
   s->c = c;
-  if (!plan_params(quality, lgwin, size_hint, &s->J)) { delete s; return set_err(c, "parameters outside the GPU path", BROTLI_AMD_UNSUPPORTED); }
+  if (!plan_params(quality, lgwin, size_hint, &s->J, (int)((flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u))) { delete s; return set_err(c, "parameters outside the GPU path", BROTLI_AMD_UNSUPPORTED); }
   JobParams& J = s->J;
   if (quality != 5) J.flags |= JOB_FLAG_DEEP;
   if (flags & BROTLI_AMD_FLAG_NO_HEADER) J.flags |= JOB_FLAG_NO_HEADER;
