@@ -377,3 +377,32 @@ def test_disable_literal_context_modeling(simabi, stock, quality, lgwin):
         p, f = drive(stock, piece, [(len(piece), 2 if off + (1 << 16) >= n else 1)], params + ((9, off),) if off else params)
         parts.append(p)
     assert fin and got == b"".join(parts)
+
+
+@pytest.mark.parametrize("quality,lgwin,lgblock", [(5, 22, 17), (5, 18, 20), (6, 20, 16), (9, 22, 16), (9, 20, 21), (4, 22, 18),
+                                                   (5, 22, 12), (7, 16, 24), (3, 20, 20)])
+def test_lgblock_parameter(simabi, stock, quality, lgwin, lgblock):
+    """BROTLI_PARAM_LGBLOCK (encode.h:190-197; ComputeLgBlock, quality.h:75-92: looked at from quality 4 on, clamped to
+    16 .. 24): the input block size changes where matches are cut, what is stitched, the ring and the largest
+    meta-block.  One FINISH, a stream fed in pieces with a flush, and a partition plan give the stock library's bytes —
+    and, where the parameter counts and differs from the default, not the default's."""
+    data = G.enwik_text(420000, seed=43, vocab=5000) + G.mixed_corpus(150000, seed=9)
+    n = len(data)
+    params = ((1, quality), (2, lgwin), (5, 1 << 20), (3, lgblock))
+    for ops in ([(n, 2)], [(100000, 0), (150001, 1), (n - 250001, 2)]):
+        want, fin_w = drive(stock, data, ops, params)
+        got, fin_g = drive(simabi, data, ops, params)
+        assert fin_w and fin_g and got == want, ops
+    default_lg = 14 if quality < 4 else (min(18, lgwin) if quality >= 9 and lgwin > 16 else 16)
+    eff = default_lg if quality < 4 else min(24, max(16, lgblock))
+    if eff != default_lg:
+        default, _ = drive(stock, data, [(n, 2)], params[:3])
+        assert default != want
+    shard = 200000
+    got, fin = drive(simabi, data, [(n, 2)], params + ((0x4D490001, shard),))
+    parts = []
+    for off in range(0, n, shard):
+        piece = data[off:off + shard]
+        p, f = drive(stock, piece, [(len(piece), 2 if off + shard >= n else 1)], params + ((9, off),) if off else params)
+        parts.append(p)
+    assert fin and got == b"".join(parts)
