@@ -112,7 +112,31 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
     bool sk = on && x < b && ix_storable(C.geo, x) && x + C.geo.htl <= ix_block_end(C.geo, x);
     if (sk && stride > 1u && ((x - sfirst) % stride) == 0u) sk = false;
     const uint32_t hi = sk ? c_res_hi(C, x) : 0u;
-    const uint32_t s = hi & 0xFFFFFFu, ns = sk ? (hi >> IX_NSUCC_SHIFT) & 31u : 0u;
+    const uint32_t s = hi & 0xFFFFFFu;
+    uint32_t ns = sk ? (hi >> IX_NSUCC_SHIFT) & 31u : 0u;
+    {
+      // A run (zeros, a gradient's plateaus): the 16 positions are neighbours in their key run too, each with 16
+      // successors — 16 dependent round trips for a set of 31 entries.  When the group's successors lie within 64
+      // sorted entries they are tainted as one stretch, 16 a step (an entry too many tainted is an exact search too
+      // many, never a different result).
+      const uint32_t lo_s = ns != 0u ? s + 1u : 0xFFFFFFFFu, hi_s = ns != 0u ? s + ns : 0u;
+      const uint32_t glo = ~q_max(~lo_s), ghi = q_max(hi_s);
+      const bool dense = on && ghi >= glo && ghi - glo < 64u;
+      if (wave_any(dense)) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) {
+          const uint32_t i = glo + 16u * k + (uint32_t)t;
+          if (dense && i <= ghi) {
+            const uint32_t p = (C.srt[i] & 0xFFFFFFu) + C.ibase;
+            if (p < C.tile_hi) {
+              uint32_t* w = (uint32_t*)(C.res + p) + 1;
+              *w = *w | IX_TAINT;
+            }
+          }
+        }
+        if (dense) ns = 0;
+      }
+    }
     const uint32_t nmax = wave_max_u32(ns);
     for (uint32_t j = 1; j <= nmax; ++j) {
       if (j <= ns) {
