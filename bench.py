@@ -561,8 +561,8 @@ def main():
         # session (profiles/traffic.json names its source), null for configurations without such a pass
         traffic, traffic_source = None, "not measured (no PMC pass on record for this configuration)"
         prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof) and args.workload == "text":
-            t = json.load(open(prof)).get("%d/%d" % (args.size_mb, args.shard_kb))
+        if os.path.exists(prof):
+            t = json.load(open(prof)).get("%d/%d" % (args.size_mb, args.shard_kb) + ("" if args.workload == "text" else "/silesia"))
             if t and t.get("kernel") == kernel:
                 traffic, traffic_source = t["hbm_bytes_per_launch"], "model input, not this run: " + t["source"]
         path_ms = ms_index + ms_parse
@@ -600,8 +600,8 @@ def main():
                                         "frac": round(path / HBM_PEAK_GBS, 5),
                                         "model": "SURVEY.md 8(d): %.0f B per input byte for the whole LZ77 parse" % algo},
                          "note": "%s: algorithmic bytes = %.1f B per input byte x %d bytes per launch; kernel "
-                                 "time %.3f ms (HIP events on the library's stream).  The kernel is bound by "
-                                 "latency and occupancy (its gathers, its LDS), not by bandwidth (DESIGN.md 5)" % (
+                                 "time %.3f ms (HIP events on the library's stream).  The kernel is bound by its "
+                                 "vector instructions (SQ counters: ~71 %% of the VALU issue slots), not by bandwidth (DESIGN.md 5)" % (
                                      kernel, k_bytes, n, k_ms)},
         }
         if world == 1:
