@@ -11,6 +11,7 @@
 
 #include <atomic>
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1107,17 +1108,24 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
   };
   // (Encoding a plan in batches while the next batch travels was measured and dropped: the chain
   // kernel takes as long for 1024 shards as for 8192, so every batch pays the whole latency.)
+  const bool hlog = getenv("BROTLI_AMD_TILE_LOG") != nullptr;       // host-side laps of the call, next to the device stages
+  auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   if (!stage()) return BROTLI_AMD_ERROR;
+  const double t1 = now();
   uint64_t n = 0;
   int rc = brotli_amd_encode_device(c, c->d_stage_in, len, p, c->d_stage_out, c->stage_out_cap, &n,
                                     nullptr, info);
   if (rc != BROTLI_AMD_OK) return rc;
+  const double t2 = now();
   *out_size = n;
   if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
   if (!big_copy(c, out, c->d_stage_out, n, false)) {
     fail(c, "D2H copy failed");
     return BROTLI_AMD_ERROR;
   }
+  if (hlog) fprintf(stderr, "  host: staging + H2D of %llu bytes %.1f ms, encode_device %.1f ms, D2H of %llu bytes %.1f ms\n",
+                    (unsigned long long)len, t1 - t0, t2 - t1, (unsigned long long)n, now() - t2);
   return BROTLI_AMD_OK;
 }
 
