@@ -701,10 +701,13 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
       s->calls[s->ncalls++] = a;
     }
     if (a && op != OP_PROCESS && s->in_len == 0 && a >= ((size_t)1 << 16) && s->quality != 1 &&
-        (s->shard_bytes != 0 || (s->quality != 5 && op == OP_FINISH && s->submitted == 0 && !s->stream))) {
-      /* A job (partition plan, or the one-shard job of qualities 6-9) whose whole input arrives
-         with the FLUSH / FINISH: it reads the caller's buffer, and writes the caller's output
-         buffer when nothing is waiting in front of it. */
+        (s->shard_bytes != 0 || (op == OP_FINISH && s->submitted == 0 && !s->stream))) {
+      /* A job (partition plan, the one-shard job of a one-shot call, the tiled stream of a long quality-5 one)
+         whose whole input arrives with the FLUSH / FINISH: it reads the caller's buffer, and writes the caller's
+         output buffer when nothing is waiting in front of it.  (Quality 5 without a plan went through the
+         instance's own buffers until round 4: a GiB copied in, 2 GiB of output buffer grown and the result copied
+         out were 250 of the 520 ms of the 1 GiB stock call, profiles/r04_g2_summary.txt.  Whatever submit() routes
+         to the serial device stream reads the caller's buffer just the same.) */
       uint8_t* const own = s->in_buf;
       int ok;
       s->in_buf = (uint8_t*)(uintptr_t)*next_in;

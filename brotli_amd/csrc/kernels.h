@@ -13,6 +13,9 @@
 #include "k_tile.h"
 
 // Register budgets (waves per SIMD the compiler must leave room for).
+#ifndef DEEP_WAVES
+#define DEEP_WAVES 2                   // waves per SIMD k_parse_deep is compiled for (161 VGPRs + scratch at 2)
+#endif
 #ifndef PARSE4_WAVES
 #define PARSE4_WAVES 4
 #endif
@@ -306,7 +309,7 @@ __global__ void __launch_bounds__(64) k_cmd_encode(JobArgs a) {
 
 // grid = nshards, block = 64: one shard per wave, E = slots / 64 entries per lane.
 template <int E>
-__global__ void __launch_bounds__(64, 2) k_parse_deep(JobArgs a) {
+__global__ void __launch_bounds__(64, DEEP_WAVES) k_parse_deep(JobArgs a) {
   __shared__ uint8_t lds_dup[D_DUP_SLOTS];
   const uint32_t shard = blockIdx.x;
   if (shard >= a.nshards) return;
