@@ -412,7 +412,9 @@ ALL_CONFIGS = [
     ("configs[1]: 1 GiB enwik-style text, quality 5, lgwin 22", []),
     ("configs[2]: 1 GiB random bytes, quality 1", ["--quality", "1", "--data", "random"]),
     ("configs[3] workload on one GPU: 1 GiB Silesia-style mix, quality 5, lgwin 22", ["--workload", "silesia"]),
-    ("configs[4]: 1 GiB text, quality 9, lgwin 24", ["--quality", "9", "--lgwin", "24", "--shard-kb", "512"]),
+    # (384 KiB shards: 2731 waves of k_parse_deep in flight instead of 2048 — 713 against 836 ms, ratio 3.169 against
+    #  3.210, profiles/r04_g3_summary.txt; 256 KiB shards would need 128 GiB of bucket tables)
+    ("configs[4]: 1 GiB text, quality 9, lgwin 24", ["--quality", "9", "--lgwin", "24", "--shard-kb", "384"]),
 ]
 
 

@@ -489,3 +489,25 @@ def test_q5_single_stream_emit_metadata_equals_reference(amd, stock):
     got, fin = drive(amd, data, ops)
     want, _ = drive(stock, data, ops)
     assert fin and got == want
+
+
+@pytest.mark.parametrize("quality,lgwin,lgblock", [(5, 22, 17), (5, 18, 20), (9, 22, 16), (6, 20, 21), (4, 22, 18), (5, 22, 12)])
+def test_lgblock_parameter_equals_reference(amd, stock, quality, lgwin, lgblock):
+    """BROTLI_PARAM_LGBLOCK (encode.h:190-197; quality.h:75-92) on the device: one FINISH (at quality 5 the tiled chain
+    with tiles of the caller's block size), a stream fed in pieces with a flush, a partition plan — the stock library's
+    bytes, shard by shard for the plan."""
+    data = G.enwik_text(1500000, seed=43, vocab=5000) + G.mixed_corpus(300000, seed=9)
+    n = len(data)
+    params = ((1, quality), (2, lgwin), (5, 1 << 21), (3, lgblock))
+    for ops in ([(n, 2)], [(300000, 0), (500001, 1), (n - 800001, 2)]):
+        want, fin_w = drive(stock, data, ops, params, out_chunk=1 << 20)
+        got, fin_g = drive(amd, data, ops, params, out_chunk=1 << 20)
+        assert fin_w and fin_g and got == want, ops
+    shard = 400000
+    got, fin = drive(amd, data, [(n, 2)], params + ((0x4D490001, shard),), out_chunk=1 << 20)
+    parts = []
+    for off in range(0, n, shard):
+        piece = data[off:off + shard]
+        p, f = drive(stock, piece, [(len(piece), 2 if off + shard >= n else 1)], params + ((9, off),) if off else params, out_chunk=1 << 20)
+        parts.append(p)
+    assert fin and got == b"".join(parts)

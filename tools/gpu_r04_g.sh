@@ -32,7 +32,7 @@ echo "== the other single-GPU configurations" | tee -a $O/summary.txt
 echo "q1 random rc $?" | tee -a $O/summary.txt
 ( time timeout 600 python bench.py --workload silesia --steps 3 ) > $O/bench_mix.json 2> $O/bench_mix.err
 echo "mix rc $?" | tee -a $O/summary.txt
-( time timeout 900 python bench.py --quality 9 --lgwin 24 --shard-kb 512 --steps 3 ) > $O/bench_q9.json 2> $O/bench_q9.err
+( time timeout 900 python bench.py --quality 9 --lgwin 24 --shard-kb 384 --steps 3 ) > $O/bench_q9.json 2> $O/bench_q9.err
 echo "q9 rc $?" | tee -a $O/summary.txt
 for set in FETCH_SIZE WRITE_SIZE; do
   rm -rf $O/pmcmix_$set
