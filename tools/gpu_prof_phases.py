@@ -6,7 +6,24 @@ import numpy as np, torch
 import gen_inputs as G
 from brotli_amd import hip
 N = int(os.environ.get("PROBE_MB", "256")) << 20
-data = G.enwik_text(N)
+KIND = os.environ.get("PROBE_KIND", "text")      # text / mix / zeros / floats / gradient / noise: one member kind of the mix alone
+if KIND == "text":
+    data = G.enwik_text(N)
+elif KIND == "mix":
+    data = G.mixed_corpus(N)
+else:
+    rng = np.random.default_rng(G.SEED)
+    if KIND == "zeros":
+        z = np.zeros(N, dtype=np.uint8)
+        pos = rng.integers(0, N, size=N // 50)
+        z[pos] = rng.integers(1, 256, size=pos.size)
+        data = z.tobytes()
+    elif KIND == "floats":
+        data = np.cumsum(rng.normal(size=N // 4)).astype(np.float32).tobytes()
+    elif KIND == "gradient":
+        data = ((np.arange(N) // 7 + rng.integers(0, 3, size=N)) & 255).astype(np.uint8).tobytes()
+    else:
+        data = G.random_bytes(N, G.SEED)
 ctx = hip.Context(0)
 d = hip.to_device(data)
 if os.environ.get("PROBE_CHAIN"):
@@ -18,7 +35,7 @@ for shard in [int(x) for x in os.environ.get("PROBE_SHARDS", "262144,65536").spl
         got, info = ctx.debug_parse(d, N, hip.make_params(5, 22, shard, 1 << 30))
     prof = info["prof"]; tot = sum(prof)
     iters = info["search_steps"]
-    print("PHASES shard=%d parse=%.1fms searches=%d cmds=%d total_cycles/shard-iter=%.0f" % (
+    print("PHASES kind=" + KIND + " shard=%d parse=%.1fms searches=%d cmds=%d total_cycles/shard-iter=%.0f" % (
         shard, info["ms_parse"], info["searches"], info["commands"], tot / max(1, iters)))
     for n, p in zip(names, prof):
         print("   %-10s %5.1f%%  %.0f cycles per search" % (n, 100.0 * p / tot, p / max(1, iters)))
