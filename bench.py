@@ -693,6 +693,11 @@ def main():
                 line["config"]["parity_full_sha256_equal"] = (
                     cb["sha256"] == line["config"]["gpu_output_sha256"] and cb["out_bytes"] == nbytes)
             line["config"]["single_stream_ratio"] = cb.get("single_stream_ratio")
+            # the ABI legs run on a context of the boundary library's own: this one's workspace goes first (quality 9 at
+            # 384 KiB shards holds 85 GiB of bucket tables — two of them do not fit beside each other)
+            ctx.close()
+            del d_out
+            torch.cuda.empty_cache()
             line["config"]["end_to_end_abi"] = end_to_end_abi(data, args.quality, args.lgwin, args.shard_kb, nbytes,
                                                              line["config"]["gpu_output_sha256"])
             line["config"]["stock_call_no_plan"] = stock_call(data, args.quality, args.lgwin)
