@@ -379,8 +379,7 @@ def test_disable_literal_context_modeling(simabi, stock, quality, lgwin):
     assert fin and got == b"".join(parts)
 
 
-@pytest.mark.parametrize("quality,lgwin,lgblock", [(5, 22, 17), (5, 18, 20), (6, 20, 16), (9, 22, 16), (9, 20, 21), (4, 22, 18),
-                                                   (5, 22, 12), (7, 16, 24), (3, 20, 20)])
+@pytest.mark.parametrize("quality,lgwin,lgblock", [(5, 22, 17), (5, 18, 20), (9, 22, 16), (4, 22, 18), (7, 16, 24), (3, 20, 20)])
 def test_lgblock_parameter(simabi, stock, quality, lgwin, lgblock):
     """BROTLI_PARAM_LGBLOCK (encode.h:190-197; ComputeLgBlock, quality.h:75-92: looked at from quality 4 on, clamped to
     16 .. 24): the input block size changes where matches are cut, what is stitched, the ring and the largest

@@ -255,8 +255,7 @@ def _noise_with_echoes(n, seed, echo_every=900, vocab=0):
     return bytes(out[:n])
 
 
-@pytest.mark.parametrize("seed,n,shard,echo,vocab", [(1, 150000, 0, 900, 0), (2, 200000, 70000, 300, 0), (3, 140000, 0, 5000, 0),
-                                                     (4, 100000, 30000, 200, 7), (5, 180000, 0, 2500, 40)])
+@pytest.mark.parametrize("seed,n,shard,echo,vocab", [(1, 150000, 0, 900, 0), (2, 200000, 70000, 300, 0), (4, 100000, 30000, 200, 7)])
 def test_indexed_parse_literal_spree_steps(sim, oracle, seed, n, shard, echo, vocab):
     """The literal spree (backward_references_inc.h:208-236) under the indexed parse: noise with echoes — most
     positions unstored, nearly every search tainted, matches that interrupt the spree —, block ends inside it (64 KiB
