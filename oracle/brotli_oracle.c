@@ -23,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+static int g_lgblock_param = 0;   /* oracle_set_lgblock */
+
 /* ------------------------------------------------------------------------ */
 /* Format data (loaded from the blob produced by tools/gen_tables.c).        */
 
@@ -943,6 +945,9 @@ static int PDictCreate(PDict* d, const uint8_t* source, size_t source_size) {
 
 /* AttachPreparedDictionary, compound_dictionary.c:182-211; n == 0 detaches everything.  The
    sources must stay alive while encodes run (the "lean" form references them). */
+/* BROTLI_PARAM_LGBLOCK of every encoder instance created from now on (0 = the default), encode.h:190-197. */
+void oracle_set_lgblock(int lgblock) { g_lgblock_param = lgblock; }
+
 int oracle_set_dictionary(const uint8_t* const* sources, const size_t* sizes, size_t n) {
   size_t i;
   for (i = 0; i < g_cd.num_chunks; ++i) {
@@ -2552,6 +2557,8 @@ size_t oracle_encode_shard(const uint8_t* in, size_t len, int quality, int lgwin
   s->flint = -2;
   s->lgblock = quality < 4 ? 14 : 16;   /* ComputeLgBlock, quality.h:75-93 */
   if (quality >= 9 && lgwin > 16) s->lgblock = lgwin < 18 ? lgwin : 18;
+  /* BROTLI_PARAM_LGBLOCK (oracle_set_lgblock): from quality 4 on, clamped to [16, 24] (quality.h:85-89) */
+  if (quality >= 4 && g_lgblock_param != 0) s->lgblock = g_lgblock_param < 16 ? 16 : g_lgblock_param > 24 ? 24 : g_lgblock_param;
   if (stream_offset != 0) {
     s->flint = 2;
     s->dist_cache[0] = s->dist_cache[1] = s->dist_cache[2] = s->dist_cache[3] = -16;

@@ -64,13 +64,15 @@ class Ref:
         return out.raw[:n.value]
 
     def encode_shard(self, data, quality, lgwin, size_hint, stream_offset,
-                     is_last, dictionaries=()):
+                     is_last, dictionaries=(), lgblock=0):
         """One instance per shard, SURVEY.md §8(e) contract; `dictionaries` are attached to it."""
         L = self.L
         st = L.BrotliEncoderCreateInstance(None, None, None)
         assert L.BrotliEncoderSetParameter(st, PARAM_QUALITY, quality)
         assert L.BrotliEncoderSetParameter(st, PARAM_LGWIN, lgwin)
         assert L.BrotliEncoderSetParameter(st, PARAM_SIZE_HINT, size_hint)
+        if lgblock:
+            assert L.BrotliEncoderSetParameter(st, PARAM_LGBLOCK, lgblock)
         if stream_offset:
             assert L.BrotliEncoderSetParameter(st, PARAM_STREAM_OFFSET,
                                                stream_offset)
@@ -225,6 +227,10 @@ class Oracle:
         sizes = (C.c_size_t * max(n, 1))(*[len(d) for d in dictionaries])
         assert self.L.oracle_set_dictionary(ptrs, sizes, n) == 1
         self._dict_keep = bufs
+
+    def set_lgblock(self, lgblock=0):
+        """BROTLI_PARAM_LGBLOCK of every encoder instance created from now on; 0 = the default."""
+        self.L.oracle_set_lgblock(int(lgblock))
 
     def encode_fast(self, data, lgwin=22, calls=None):
         """Quality 1; `calls` = [(nbytes, op), ...], default one FINISH call."""

@@ -113,6 +113,23 @@ def test_mode_p_matches_reference(ref, oracle, name, shard):
     assert ref.decompress(want, len(data)) == data
 
 
+@pytest.mark.parametrize("quality,lgwin,lgblock", [(5, 22, 17), (5, 18, 20), (9, 22, 16), (6, 20, 21), (4, 22, 18), (5, 22, 12),
+                                                   (7, 16, 24), (3, 20, 20)])
+def test_lgblock_parameter_matches_reference(ref, oracle, quality, lgwin, lgblock):
+    """BROTLI_PARAM_LGBLOCK (encode.h:190-197; ComputeLgBlock, quality.h:75-92): the restatement with the block size set
+    (oracle_set_lgblock) equals the reference with the parameter set — whole streams and shards with stream offsets."""
+    data = INPUTS["text_rand"] + INPUTS["mixed1m"][:300000]
+    hint = 1 << 20
+    try:
+        oracle.set_lgblock(lgblock)
+        for off, n, last in ((0, len(data), True), (0, 200000, False), (200000, 300001, False), (500001, len(data) - 500001, True)):
+            piece = data[off:off + n]
+            want = ref.encode_shard(piece, quality, lgwin, hint, off, last, lgblock=lgblock)
+            assert oracle.encode_shard(piece, quality, lgwin, hint, off, last) == want, (off, n)
+    finally:
+        oracle.set_lgblock(0)
+
+
 def test_large_hint_small_shards(ref, oracle):
     """H68 (size_hint >= 1 MiB) with shards far below 1 MiB, ragged tail,
     shards of 1, 2 and 3 bytes (flint edge cases, encode.c:1667-1708)."""
