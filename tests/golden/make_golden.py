@@ -79,6 +79,17 @@ DICT_PLAN_CASES = [
 ]
 
 
+# BROTLI_PARAM_LGBLOCK (encode.h:190-197): (input, quality, lgwin, lgblock, shard size)
+LGBLOCK_CASES = [
+    ({"kind": "text", "size": 1 << 20, "seed": 11}, 5, 22, 17, 0),
+    ({"kind": "text", "size": 3 << 20, "seed": 7}, 5, 18, 20, 1 << 20),
+    ({"kind": "mixed", "size": 2 << 20, "seed": 9}, 5, 22, 12, 1 << 19),      # (clamped to 16)
+    ({"kind": "text", "size": 1 << 20, "seed": 11}, 9, 22, 16, 0),
+    ({"kind": "text", "size": 1 << 20, "seed": 11}, 6, 20, 21, 1 << 18),
+    ({"kind": "file", "name": "alice29.txt"}, 4, 22, 18, 0),
+]
+
+
 def q1_calls(n, feed_kb):
     """[(nbytes, op)]: one FINISH call, or feed_kb KiB per PROCESS call and FINISH with the last
     one — as an extra empty call when n is a multiple of the feed (c/tools/brotli.c:1419-1463)."""
@@ -127,8 +138,16 @@ def main():
         dc.append({"input": spec, "quality": q, "lgwin": w, "shard_size": shard, "size": len(out),
                    "sha256": hashlib.sha256(out).hexdigest()})
         print(dc[-1])
+    lb = []
+    for spec, q, w, lg, shard in LGBLOCK_CASES:
+        data = G.make(spec)
+        out = ref.encode_plan(data, q, w, shard, lgblock=lg)
+        assert ref.decompress(out, len(data)) == data
+        lb.append({"input": spec, "quality": q, "lgwin": w, "lgblock": lg, "shard_size": shard, "size": len(out),
+                   "sha256": hashlib.sha256(out).hexdigest()})
+        print(lb[-1])
     json.dump({"generator": "oracle/_ref (google/brotli c/enc, gcc x86-64)",
-               "cases": cases, "quality1_cases": q1, "dictionary_cases": dc},
+               "cases": cases, "quality1_cases": q1, "dictionary_cases": dc, "lgblock_cases": lb},
               open(os.path.join(HERE, "golden.json"), "w"), indent=1)
 
 

@@ -146,7 +146,7 @@ class Ref:
         # encode.c:1590-1600: measure what actually left)
         return out.raw[:cap - avail_out.value]
 
-    def encode_plan(self, data, quality, lgwin, shard_size, dictionaries=()):
+    def encode_plan(self, data, quality, lgwin, shard_size, dictionaries=(), lgblock=0):
         n = len(data)
         if n == 0:
             return b"\x06"
@@ -159,7 +159,7 @@ class Ref:
             m = min(shard_size, n - off)
             parts.append(self.encode_shard(
                 data[off:off + m], quality, lgwin, hint, min(off, 1 << 30),
-                off + m == n, dictionaries))
+                off + m == n, dictionaries, lgblock=lgblock))
             off += m
         return b"".join(parts)
 

@@ -511,3 +511,18 @@ def test_lgblock_parameter_equals_reference(amd, stock, quality, lgwin, lgblock)
         p, f = drive(stock, piece, [(len(piece), 2 if off + shard >= n else 1)], params + ((9, off),) if off else params, out_chunk=1 << 20)
         parts.append(p)
     assert fin and got == b"".join(parts)
+
+
+def test_golden_vectors_lgblock(amd):
+    """tests/golden/golden.json `lgblock_cases`: sha256 of the reference's output with BROTLI_PARAM_LGBLOCK set, from
+    tests/golden/make_golden.py (the fixture travels, the reference tree does not).  The size hint is the reference
+    plan's: min(total, 1 << 30) for every shard."""
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))
+    for case in gold["lgblock_cases"]:
+        data = G.make(case["input"])
+        params = ((1, case["quality"]), (2, case["lgwin"]), (5, len(data)), (3, case["lgblock"]))
+        if case.get("shard_size"):
+            params += ((0x4D490001, case["shard_size"]),)
+        got, fin = drive(amd, data, [(len(data), 2)], params, out_chunk=1 << 20)
+        assert fin and len(got) == case["size"] and hashlib.sha256(got).hexdigest() == case["sha256"], case

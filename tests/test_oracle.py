@@ -167,6 +167,19 @@ def test_golden_vectors(oracle):
         assert hashlib.sha256(out).hexdigest() == case["sha256"], case
 
 
+def test_golden_vectors_lgblock(oracle):
+    """The golden vectors with BROTLI_PARAM_LGBLOCK set (tests/golden/make_golden.py: LGBLOCK_CASES)."""
+    golden = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+    try:
+        for c in golden["lgblock_cases"]:
+            data = G.make(c["input"])
+            oracle.set_lgblock(c["lgblock"])
+            out = oracle.encode_plan(data, c["quality"], c["lgwin"], c["shard_size"])
+            assert len(out) == c["size"] and hashlib.sha256(out).hexdigest() == c["sha256"], c
+    finally:
+        oracle.set_lgblock(0)
+
+
 def test_golden_vectors_dictionaries(oracle):
     gold = json.load(open(os.path.join(HERE, "golden", "golden.json")))
     for case in gold["dictionary_cases"]:
