@@ -13,7 +13,10 @@ encodes its own M MiB piece of one stream (BROTLI_PARAM_STREAM_OFFSET shards,
 encode.h:231-246) and the ranks concatenate the compressed pieces with one
 RCCL all-gather of sizes + one of (padded) payloads inside the timed region.
 
-Rank 0 prints ONE JSON line (driver contract) with two extra objects:
+Rank 0 prints the driver contract's JSON line — up to three times, each a superset of the one before (the timed
+region alone; + cpu_baseline / plans[] / parity; + the legs behind the headline, each run in a child process with a
+timeout): the LAST line is the complete one, and a run that ends early for any reason still leaves a parseable
+headline on stdout.  Two extra objects:
   roofline     — the dominant kernel (quality 5: k_ix_bucket, the sort inside the
                  index buckets + the window search of every position): its
                  algorithmic HBM bytes per launch (17 B per input
@@ -82,56 +85,63 @@ def host_cpu_info():
             "socket0_physical_cores": len(first_socket), "socket": s0}, first_socket
 
 
-def cpu_baseline(data, quality, lgwin, shard_size, size_hint, reps=5, other_plans=()):
+def data_file(data):
+    """The input as a file in memory-backed storage: what the CPU baseline's driver and the legs' child processes read."""
+    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
+    path = os.path.join(tmpdir, "brotli_amd_bench_%d.bin" % os.getpid())
+    with open(path, "wb") as f:
+        f.write(data)
+    return path
+
+
+def cpu_baseline(path, nbytes, quality, lgwin, shard_size, size_hint, reps=5, other_plans=()):
     """The reference encoder (oracle/_ref/libbrotli_ref.so, built from /root/reference by
     oracle/Makefile) driven by oracle/_ref/plan_bench (C, one pinned POSIX thread per physical
-    core of socket 0, one encoder instance per shard): (B2) the SAME partition plan as the GPU
+    core of socket 0, one encoder instance per shard) over the input file `path`: (B2) the SAME partition plan as the GPU
     run, median of `reps`, with the sha256 of the concatenated output; (B2') the reference at a
     plan that suits the CPU (8 MiB shards); (B1) one instance on one core (what c/enc does by
     itself).  Falls back to the Python thread pool over the oracle when the prebuilt reference
     is absent."""
-    import subprocess
-    import tempfile
     info, cpus = host_cpu_info()
     cores = max(1, len(cpus))
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so")
     drv = os.path.join(ROOT, "oracle", "_ref", "plan_bench")
     if os.path.exists(ref_so) and os.path.exists(drv):
-        tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-        path = os.path.join(tmpdir, "brotli_amd_bench_%d.bin" % os.getpid())
-        with open(path, "wb") as f:
-            f.write(data)
+        def run(src, threads, shard, nreps, pin):
+            cmd = [drv, ref_so, src, str(quality), str(lgwin), str(shard), str(threads),
+                   str(size_hint), str(nreps)]
+            if pin:
+                cmd.append(",".join(str(c) for c in pin))
+            r = subprocess.run(cmd, capture_output=True, text=True, check=True)
+            return json.loads(r.stdout.strip().splitlines()[-1])
+        run(path, cores, shard_size, 1, cpus)                      # warm-up, discarded
+        same = run(path, cores, shard_size, reps, cpus)
+        big = 8 << 20
+        best = run(path, cores, big, 3, cpus) if nbytes >= 4 * big else None
+        others = {sh: run(path, cores, sh, 3, cpus) for sh in other_plans}
+        one_n = min(nbytes, 64 << 20)
+        one_path = path + ".one"
         try:
-            def run(threads, shard, nreps, pin):
-                cmd = [drv, ref_so, path, str(quality), str(lgwin), str(shard), str(threads),
-                       str(size_hint), str(nreps)]
-                if pin:
-                    cmd.append(",".join(str(c) for c in pin))
-                r = subprocess.run(cmd, capture_output=True, text=True, check=True)
-                return json.loads(r.stdout.strip().splitlines()[-1])
-            run(cores, shard_size, 1, cpus)                      # warm-up, discarded
-            same = run(cores, shard_size, reps, cpus)
-            big = 8 << 20
-            best = run(cores, big, 3, cpus) if len(data) >= 4 * big else None
-            others = {sh: run(cores, sh, 3, cpus) for sh in other_plans}
-            one = data[:min(len(data), 64 << 20)]
-            with open(path, "wb") as f:
-                f.write(one)
-            single = run(1, 0, 1, cpus[:1])                      # one instance, one core
+            with open(path, "rb") as f, open(one_path, "wb") as g:
+                g.write(f.read(one_n))
+            single = run(one_path, 1, 0, 1, cpus[:1])                      # one instance, one core
         finally:
-            os.unlink(path)
+            try:
+                os.unlink(one_path)
+            except OSError:
+                pass
         out = {
             "value": round(same["MBps"], 1), "unit": "MB/s", "cores": cores, "kind": "reference",
             "sample": "the whole %d MiB input, same plan (%d shards of %d KiB), %d threads pinned to the "
                       "physical cores of socket %d (oracle/plan_bench.c), median of %d runs after one "
                       "warm-up, %.3f s, ratio %.3f" % (
-                          len(data) >> 20, same["shards"], shard_size >> 10, cores, info["socket"], reps,
+                          nbytes >> 20, same["shards"], shard_size >> 10, cores, info["socket"], reps,
                           same["seconds"], same["bytes"] / max(1, same["out_bytes"])),
             "cpu": info, "seconds_all": same["seconds_all"], "sha256": same["sha256"],
             "out_bytes": same["out_bytes"],
             "single_stream_1core_MBps": round(single["MBps"], 1),
             "single_stream_ratio": round(single["bytes"] / max(1, single["out_bytes"]), 4),
-            "single_stream_sample": "first %d MiB, one encoder instance, 1 thread" % (len(one) >> 20),
+            "single_stream_sample": "first %d MiB, one encoder instance, 1 thread" % (one_n >> 20),
         }
         if others:
             # the reference driven with the other partition plans of config.plans[] (same cores, median of 3)
@@ -147,6 +157,7 @@ def cpu_baseline(data, quality, lgwin, shard_size, size_hint, reps=5, other_plan
     from concurrent.futures import ThreadPoolExecutor
     from refharness import Oracle
     enc = Oracle()
+    data = open(path, "rb").read()
     nsh = min(-(-len(data) // shard_size), max(cores, 64))
     sample = data[:nsh * shard_size]
 
@@ -164,21 +175,36 @@ def cpu_baseline(data, quality, lgwin, shard_size, size_hint, reps=5, other_plan
                       "ratio %.3f" % (len(sample) >> 20, cores, dt, len(sample) / max(1, out_bytes))}
 
 
-def end_to_end_abi(data, quality, lgwin, shard_kb, want_bytes, want_sha):
-    """BASELINE.md section 3.4: host buffer -> BrotliEncoderCompress of the drop-in library
-    (libbrotlienc_amd.so, partition plan from BROTLI_AMD_SHARD_KB) -> host buffer, PCIe included.
-    Never the reported `value`."""
-    import hashlib
-    lib_path = os.path.join(ROOT, "brotli_amd", "lib", "libbrotlienc_amd.so")
-    if not os.path.exists(lib_path):
-        return None
-    os.environ["BROTLI_AMD_SHARD_KB"] = str(shard_kb)
+# ---- the legs behind the headline: each one a child process with a timeout ------------------------------------
+# Whatever happens in one of them — a GPU fault, a lost context, a timeout — the headline line is on stdout already
+# and the parent prints the line again, enriched with what did come back (round 4's driver run
+# ended without a line because the only print came after all of these).
+LEG_TIMEOUT_S = {"round_trip": 150, "abi": 150, "stock": 90, "stock_whole": 200}
+
+
+def _bind_encoder(lib_path):
     L = C.CDLL(lib_path)
     L.BrotliEncoderMaxCompressedSize.restype = C.c_size_t
     L.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
     L.BrotliEncoderCompress.restype = C.c_int
     L.BrotliEncoderCompress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_char_p,
                                         C.POINTER(C.c_size_t), C.c_char_p]
+    return L
+
+
+DROPIN = os.path.join(ROOT, "brotli_amd", "lib", "libbrotlienc_amd.so")
+
+
+def leg_abi(path, quality, lgwin, shard_kb, want_bytes, want_sha):
+    """BASELINE.md section 3.4: host buffer -> BrotliEncoderCompress of the drop-in library
+    (libbrotlienc_amd.so, partition plan from BROTLI_AMD_SHARD_KB) -> host buffer, PCIe included.
+    Never the reported `value`."""
+    import hashlib
+    if not os.path.exists(DROPIN):
+        return {"error": "libbrotlienc_amd.so missing"}
+    data = open(path, "rb").read()
+    os.environ["BROTLI_AMD_SHARD_KB"] = str(shard_kb)
+    L = _bind_encoder(DROPIN)
     cap = L.BrotliEncoderMaxCompressedSize(len(data))
     out = C.create_string_buffer(cap)
     times, n_out = [], 0
@@ -198,21 +224,18 @@ def end_to_end_abi(data, quality, lgwin, shard_kb, want_bytes, want_sha):
                     "median of 3 (the first includes context creation)" % shard_kb}
 
 
-def stock_call(data, quality, lgwin):
+def leg_stock(path, quality, lgwin):
     """What a caller that knows nothing of this library gets: BrotliEncoderCompress(quality, lgwin, ...) of the drop-in
     library with NO partition plan (BROTLI_AMD_SHARD_KB unset), on the first (1 << lgwin) - 16 bytes of the input — the
-    longest input a one-shot quality-5 call runs on the index + tiled chain; longer inputs take one wave per stream."""
-    lib_path = os.path.join(ROOT, "brotli_amd", "lib", "libbrotlienc_amd.so")
-    if not os.path.exists(lib_path) or quality != 5 or lgwin < 17:
+    longest input a one-shot quality-5 call runs on the index + tiled chain of ONE shard."""
+    if not os.path.exists(DROPIN) or quality != 5 or lgwin < 17:
         return None
     os.environ.pop("BROTLI_AMD_SHARD_KB", None)
-    L = C.CDLL(lib_path)
-    L.BrotliEncoderMaxCompressedSize.restype = C.c_size_t
-    L.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
-    L.BrotliEncoderCompress.restype = C.c_int
-    L.BrotliEncoderCompress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.c_char_p]
-    n = min(len(data), (1 << min(lgwin, 22)) - 16)
-    piece = data[:n]
+    L = _bind_encoder(DROPIN)
+    n = (1 << min(lgwin, 22)) - 16
+    with open(path, "rb") as f:
+        piece = f.read(n)
+    n = len(piece)
     cap = L.BrotliEncoderMaxCompressedSize(n)
     out = C.create_string_buffer(cap)
     times = []
@@ -226,6 +249,7 @@ def stock_call(data, quality, lgwin):
     dt = sorted(times[1:])[1]
     res = {"bytes": n, "MBps": round(n / 1e6 / dt, 1), "seconds_all": [round(t, 4) for t in times], "out_bytes": sz.value,
            "note": "one BrotliEncoderCompress call, no partition plan, pageable host buffers; median of calls 2-4"}
+    print(json.dumps(res), flush=True)
     try:
         from refharness import Ref, have_ref
         if have_ref():
@@ -235,53 +259,19 @@ def stock_call(data, quality, lgwin):
             res["bytes_equal_reference"] = want == out.raw[:sz.value]
     except Exception as e:
         res["reference"] = repr(e)[:200]
-    res["whole_input"] = stock_call_whole(data, quality, lgwin)
     return res
 
 
-def stock_call_whole(data, quality, lgwin, timeout_s=180):
+def leg_stock_whole(path, quality, lgwin):
     """The same stock call on the WHOLE input (1 GiB by default): longer than the window, it takes the tiled stream
-    path of the library (k_tile.h, JOB_FLAG_STREAMT) — or the serial device stream where the data does not suit it.
-    Run in a child process with a timeout, after everything else has been measured: whatever happens there, the
-    bench line is printed."""
-    if len(data) <= (1 << lgwin) or len(data) >= (1 << 31):
-        return None
-    tmpdir = "/dev/shm" if os.path.isdir("/dev/shm") else tempfile.gettempdir()
-    path = os.path.join(tmpdir, "brotli_amd_stock_%d.bin" % os.getpid())
-    try:
-        with open(path, "wb") as f:
-            f.write(data)
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--stock-call-child", path, str(quality), str(lgwin)],
-                           capture_output=True, text=True, timeout=timeout_s)
-        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-        if r.returncode != 0 or not lines:
-            return {"error": "child rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])}
-        return json.loads(lines[-1])
-    except subprocess.TimeoutExpired as e:
-        got = e.stdout.decode("utf-8", "replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
-        lines = [ln for ln in got.splitlines() if ln.startswith("{")]
-        res = json.loads(lines[-1]) if lines else {}
-        res["error"] = "child not through within %d s" % timeout_s
-        return res
-    except Exception as e:
-        return {"error": repr(e)[:300]}
-    finally:
-        try:
-            os.unlink(path)
-        except OSError:
-            pass
-
-
-def stock_call_child(path, quality, lgwin):
+    path of the library (k_tile.h, JOB_FLAG_STREAMT) — or the serial device stream where the data does not suit it."""
     import hashlib
     data = open(path, "rb").read()
     n = len(data)
+    if n <= (1 << lgwin) or n >= (1 << 31):
+        return None
     os.environ.pop("BROTLI_AMD_SHARD_KB", None)
-    L = C.CDLL(os.path.join(ROOT, "brotli_amd", "lib", "libbrotlienc_amd.so"))
-    L.BrotliEncoderMaxCompressedSize.restype = C.c_size_t
-    L.BrotliEncoderMaxCompressedSize.argtypes = [C.c_size_t]
-    L.BrotliEncoderCompress.restype = C.c_int
-    L.BrotliEncoderCompress.argtypes = [C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_char_p, C.POINTER(C.c_size_t), C.c_char_p]
+    L = _bind_encoder(DROPIN)
     cap = L.BrotliEncoderMaxCompressedSize(n)
     out = C.create_string_buffer(cap)
     times = []
@@ -291,8 +281,7 @@ def stock_call_child(path, quality, lgwin):
         ok = L.BrotliEncoderCompress(quality, lgwin, 0, n, data, C.byref(sz), out)
         times.append(time.perf_counter() - t0)
         if not ok:
-            print(json.dumps({"error": "BrotliEncoderCompress returned BROTLI_FALSE"}))
-            return
+            return {"error": "BrotliEncoderCompress returned BROTLI_FALSE"}
     sha = hashlib.sha256(out.raw[:sz.value]).hexdigest()
     res = {"bytes": n, "out_bytes": sz.value, "seconds_all": [round(t, 3) for t in times],
            "MBps": round(n / 1e6 / min(times[1:]), 1), "sha256": sha,
@@ -300,17 +289,84 @@ def stock_call_child(path, quality, lgwin):
                    "ways included; the best of calls 2-3 (the first one creates the context and its workspace)"}
     print(json.dumps(res), flush=True)          # (kept even if the reference leg below does not finish)
     try:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
         from refharness import Ref, have_ref
         if have_ref():
             t0 = time.perf_counter()
             want = Ref().compress(data, quality, lgwin)
             res["reference_1core_MBps"] = round(n / 1e6 / (time.perf_counter() - t0), 1)
             res["bytes_equal_reference"] = hashlib.sha256(want).hexdigest() == sha and len(want) == sz.value
-            print(json.dumps(res), flush=True)
     except Exception as e:
         res["reference"] = repr(e)[:200]
-        print(json.dumps(res), flush=True)
+    return res
+
+
+def leg_round_trip(path, quality, lgwin, shard_kb, size_hint):
+    """Round trip on the device: the shards of the plan decode as independent pieces (k_decode.h, one wave per shard)
+    and must give back the input."""
+    import torch
+    from brotli_amd import hip
+    data = open(path, "rb").read()
+    n, shard = len(data), shard_kb << 10
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    d_in = hip.to_device(data, 0)
+    ctx = hip.Context(0)
+    params = hip.make_params(quality, lgwin, shard, size_hint, stream_base=0, is_last=True)
+    d_out = torch.empty(ctx.max_output(n, params), dtype=torch.uint8, device=dev)
+    nsh = -(-n // shard)
+    d_sizes = torch.zeros(nsh, dtype=torch.int64, device=dev)
+    nb2, _ = ctx.encode_device(d_in, n, params, d_out, d_sizes)
+    sizes = d_sizes.cpu().tolist()
+    if nb2 + hip.DECODE_SLACK > d_out.numel() or sum(sizes) != nb2:
+        return {"error": "shard sizes do not add up"}
+    d_back = torch.empty(n + 64, dtype=torch.uint8, device=dev)
+    pieces = hip.plan_pieces(sizes, n, shard, lgwin)
+    res, dec_ms = ctx.decode_device(d_out, nb2, d_back, n, pieces, check=False)
+    errs = [r[1] for r in res if r[1]]
+    same = bool(torch.equal(d_back[:n], d_in[:n]))
+    return {"equal_to_input": same and not errs and res[-1][2] == 1, "pieces": len(pieces),
+            "piece_errors": len(errs), "decode_ms": round(dec_ms, 3),
+            "decode_GBps_of_output": round(n / 1e9 / (dec_ms / 1e3), 2) if dec_ms > 0 else None}
+
+
+LEGS = {"abi": leg_abi, "stock": leg_stock, "stock_whole": leg_stock_whole, "round_trip": leg_round_trip}
+
+
+def leg_main(argv):
+    """bench.py --leg <name> <path> <int args ...> [str]: runs one leg, prints its result as the last JSON line."""
+    name, path = argv[0], argv[1]
+    rest = [int(a) if a.lstrip("-").isdigit() else a for a in argv[2:]]
+    try:
+        res = LEGS[name](path, *rest)
+    except Exception as e:
+        res = {"error": repr(e)[:300]}
+    print(json.dumps(res), flush=True)
+
+
+def run_leg(name, path, *leg_args, timeout_s=None):
+    """Runs a leg in a child process; the last JSON line of its stdout, or {"error": ...}."""
+    timeout_s = timeout_s or LEG_TIMEOUT_S[name]
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", name, path] + [str(a) for a in leg_args]
+
+    def last_json(text):
+        lines = [ln for ln in (text or "").splitlines() if ln.startswith("{") or ln == "null"]
+        return json.loads(lines[-1]) if lines else None
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+        got = last_json(r.stdout)
+        if r.returncode != 0 or (got is None and "null" not in (r.stdout or "")):
+            res = got if isinstance(got, dict) else {}
+            res["error"] = "child rc %d: %s" % (r.returncode, (r.stderr or r.stdout)[-300:])
+            return res
+        return got
+    except subprocess.TimeoutExpired as e:
+        out = e.stdout.decode("utf-8", "replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
+        res = last_json(out)
+        res = res if isinstance(res, dict) else {}
+        res["error"] = "child not through within %d s" % timeout_s
+        return res
+    except Exception as e:
+        return {"error": repr(e)[:300]}
 
 
 def main_q1(args):
@@ -387,6 +443,7 @@ def main_q1(args):
                      "note": "dominant stage %s: %.3f ms per launch (HIP events on the library's stream), "
                              "algorithmic bytes %.0f per launch" % (dom, stage[dom], algo)},
     }
+    emit(line)          # the headline exists: printed before anything else can go wrong (the last line is the complete one)
     if not args.no_cpu_baseline:
         from refharness import Ref, have_ref, Oracle
         m = min(n, 256 << 20)
@@ -405,7 +462,7 @@ def main_q1(args):
                                     "kind": "reference",
                                     "sample": "first %d MiB, one reference encoder instance (the reference has no "
                                               "threads), %.2f s, ratio %.3f" % (m >> 20, dtc, len(sample) / len(out))}
-    print(json.dumps(line), flush=True)
+        emit(line)
 
 
 ALL_CONFIGS = [
@@ -438,7 +495,124 @@ def main_all_configs(args):
     sys.exit(rc)
 
 
-def main():
+class GpuJob:
+    """Everything of the measured path that touches the device: the input in HBM, the library's context, the step
+    (brotli_amd_encode_device through brotli_amd.hip, plus the RCCL concatenation at N > 1).  tests/test_bench_line.py
+    swaps this class for a stub to check what bench.py prints, and when, without a GPU."""
+
+    def __init__(self, args, rank, local_rank, world):
+        import torch
+        from brotli_amd import hip
+        self.torch, self.hip, self.args, self.rank, self.world = torch, hip, args, rank, world
+        self.dist = None
+        if world > 1 or os.environ.get("BENCH_FORCE_DIST"):   # the latter: exercise the RCCL path on one GPU
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            self.dist = dist
+        self.local_rank = local_rank
+        self.dev = torch.device("cuda", local_rank)
+        torch.cuda.set_device(self.dev)
+        self.gathered, self.stream, self.pad_hint = None, None, 0
+
+    def load(self, data, quality, lgwin, shard, size_hint):
+        hip, torch = self.hip, self.torch
+        self.n = len(data)
+        self.d_in = hip.to_device(data, self.local_rank)
+        self.ctx = hip.Context(self.local_rank)
+        self.params = hip.make_params(quality, lgwin, shard, size_hint, stream_base=self.rank * self.n,
+                                      is_last=(self.rank == self.world - 1))
+        self.d_out = torch.empty(self.ctx.max_output(self.n, self.params), dtype=torch.uint8, device=self.dev)
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def step(self):
+        got = {}
+
+        def encode_local():
+            got["nbytes"], got["info"] = self.ctx.encode_device(self.d_in, self.n, self.params, self.d_out)
+            return self.d_out, got["nbytes"]
+        if self.dist is not None:
+            # C1: one all-gather of the sizes, one of the padded payloads, padding stripped —
+            # all of it inside the timed region (brotli_amd/dist.py, shared with the gloo test)
+            from brotli_amd.dist import sharded_step
+            self.stream, _, self.gathered, self.pad_hint = sharded_step(encode_local, scratch=self.gathered,
+                                                                        pad_hint=self.pad_hint)
+        else:
+            encode_local()
+        return got["nbytes"], got["info"]
+
+    def reduce(self, dt, nbytes):
+        """(max of dt over the ranks, sum of the output bytes, (equal on all ranks, sha256, bytes) of the gathered stream)"""
+        if self.dist is None:
+            return dt, nbytes, None
+        torch, dist = self.torch, self.dist
+        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        from brotli_amd.dist import same_stream_on_all_ranks
+        ok, sha = same_stream_on_all_ranks(self.stream)
+        tot = torch.tensor([nbytes], dtype=torch.int64, device=self.dev)
+        dist.all_reduce(tot)
+        return float(t.item()), int(tot.item()), (ok, sha, int(self.stream.numel()))
+
+    def output_bytes(self, nbytes):
+        return self.d_out[:nbytes].cpu().numpy().tobytes()
+
+    def time_plan(self, quality, lgwin, kb, size_hint, reps=3):
+        """Another partition plan of the same input, timed the same way as the headline (device-resident input,
+        synchronize on both sides), outside the headline's timed region."""
+        import hashlib
+        hip, torch, n = self.hip, self.torch, self.n
+        p2 = hip.make_params(quality, lgwin, kb << 10, size_hint, stream_base=0, is_last=True)
+        cap2 = self.ctx.max_output(n, p2)
+        d_out2 = self.d_out if cap2 <= self.d_out.numel() else torch.empty(cap2, dtype=torch.uint8, device=self.dev)
+        self.ctx.encode_device(self.d_in, n, p2, d_out2)
+        torch.cuda.synchronize(self.dev)
+        t1 = time.perf_counter()
+        inf2 = []
+        nb2 = 0
+        for _ in range(reps):
+            nb2, i2 = self.ctx.encode_device(self.d_in, n, p2, d_out2)
+            inf2.append(i2)
+        torch.cuda.synchronize(self.dev)
+        dt2 = (time.perf_counter() - t1) / reps
+        comp2 = d_out2[:nb2].cpu().numpy().tobytes()
+        return {"shard_KiB": kb, "shards": inf2[-1]["nshards"], "MBps": round(n / 1e6 / dt2, 1),
+                "ms_per_step": round(dt2 * 1e3, 3), "ratio": round(n / nb2, 4), "compressed_bytes": nb2,
+                "sha256": hashlib.sha256(comp2).hexdigest(), "headline": False, "steps": reps,
+                "stage_ms": {k: round(sum(i.get(k, 0.0) for i in inf2) / len(inf2), 3) for k in
+                             ("ms_total", "ms_index", "ms_ix_bucket", "ms_parse", "ms_build", "ms_store")},
+                "tile_sweeps": inf2[-1].get("tile_sweeps"),
+                "tile_fallback_shards": inf2[-1].get("tile_fallback_shards")}
+
+    def close(self):
+        """Gives the device back: the legs behind the headline run in processes of their own (quality 9 at 384 KiB
+        shards holds 85 GiB of bucket tables, the stock call wants ~85 B per input byte)."""
+        try:
+            self.ctx.close()
+            self.d_out = self.d_in = self.gathered = self.stream = None
+            self.torch.cuda.empty_cache()
+        except Exception:
+            pass
+
+    def finish(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def emit(line):
+    """One JSON line on stdout, flushed: the driver parses the LAST line; every earlier one is the same line with
+    fewer optional fields, so that whatever ends the process early leaves a complete headline behind."""
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -448,6 +622,8 @@ def main():
     ap.add_argument("--quality", type=int, default=5)
     ap.add_argument("--lgwin", type=int, default=22)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="skip the legs behind the headline (device round trip, "
+                    "BrotliEncoderCompress end to end, the stock calls)")
     ap.add_argument("--workload", choices=["text", "silesia"], default="text",
                     help="text: BASELINE configs[1] (enwik-style); silesia: configs[3] (Silesia-style mix, "
                          "size-mb MiB per GPU: 8 GiB on 8 GPUs)")
@@ -456,16 +632,13 @@ def main():
     ap.add_argument("--all-configs", action="store_true",
                     help="one line per single-GPU BASELINE configuration (configs[1], [2], [4], and [3]'s workload on one "
                          "GPU), each with the reference timed beside it on this box's host cores")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.all_configs:
         return main_all_configs(args)
     if args.quality == 1:
         return main_q1(args)
 
-    import numpy as np
-    import torch
     import gen_inputs as G
-    from brotli_amd import hip
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -473,76 +646,27 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
                  % (args.gpus, args.gpus))
-    dist = None
-    if world > 1 or os.environ.get("BENCH_FORCE_DIST"):   # the latter: exercise the RCCL path on one GPU
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+    job = GpuJob(args, rank, local_rank, world)
 
     n = args.size_mb << 20
     shard = args.shard_kb << 10
     total = n * world
     size_hint = min(total, 1 << 30)
     data = G.enwik_text(n, seed=G.SEED + rank) if args.workload == "text" else G.mixed_corpus(n, seed=G.SEED + rank)
-    d_in = hip.to_device(data, local_rank)
-    ctx = hip.Context(local_rank)
-    params = hip.make_params(args.quality, args.lgwin, shard, size_hint, stream_base=rank * n,
-                             is_last=(rank == world - 1))
-    cap = ctx.max_output(n, params)
-    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
-
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    gathered = None
-    stream = None
-    pad_hint = 0
-
-    def step():
-        nonlocal gathered, stream, pad_hint
-        got = {}
-
-        def encode_local():
-            got["nbytes"], got["info"] = ctx.encode_device(d_in, n, params, d_out)
-            return d_out, got["nbytes"]
-        if dist is not None:
-            # C1: one all-gather of the sizes, one of the padded payloads, padding stripped —
-            # all of it inside the timed region (brotli_amd/dist.py, shared with the gloo test)
-            from brotli_amd.dist import sharded_step
-            stream, _, gathered, pad_hint = sharded_step(encode_local, scratch=gathered, pad_hint=pad_hint)
-        else:
-            encode_local()
-        return got["nbytes"], got["info"]
+    job.load(data, args.quality, args.lgwin, shard, size_hint)
 
     for _ in range(args.warmup):
-        step()
-    barrier()
+        job.step()
+    job.barrier()
     t0 = time.perf_counter()
     infos = []
     nbytes = 0
     for _ in range(args.steps):
-        nbytes, info = step()
+        nbytes, info = job.step()
         infos.append(info)
-    barrier()
+    job.barrier()
     dt = time.perf_counter() - t0
-    stream_check = None
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        from brotli_amd.dist import same_stream_on_all_ranks
-        stream_check = same_stream_on_all_ranks(stream)
-        tot_out = torch.tensor([nbytes], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot_out)
-        out_total = int(tot_out.item())
-    else:
-        out_total = nbytes
+    dt, out_total, stream_check = job.reduce(dt, nbytes)
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -559,8 +683,8 @@ def main():
             k_ms, k_bytes = ms_parse, (algo if not indexed else 9.0 + 16.0 * 0.4)
         achieved = k_bytes * n / (k_ms / 1e3) / 1e9
         # HBM bytes of the dominant kernel: not measured by this process (the counters need rocprofv3 around it) — from
-        # the PMC passes of the same command in tools/gpu_r03_f.sh, calibrated on known byte counts in the same
-        # session (profiles/traffic.json names its source), null for configurations without such a pass
+        # the PMC passes of the same command in this round's GPU sessions, calibrated on known byte counts
+        # (profiles/traffic.json names its source), null for configurations without such a pass
         traffic, traffic_source = None, "not measured (no PMC pass on record for this configuration)"
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
@@ -587,7 +711,7 @@ def main():
                 "compressed_bytes": out_total, "ratio": round(total / out_total, 4),
                 "gathered_stream": None if stream_check is None else {
                     "sha256": stream_check[1], "equal_on_all_ranks": stream_check[0],
-                    "bytes": int(stream.numel()), "concatenation_inside_timed_region": True},
+                    "bytes": stream_check[2], "concatenation_inside_timed_region": True},
                 "parse_ms_per_step": [round(i["ms_index"] + i["ms_parse"], 1) for i in infos],
                 "stage_ms": {k: round(avg(k), 3) for k in
                              ("ms_total", "ms_init", "ms_index", "ms_ix_bucket", "ms_parse", "ms_build", "ms_store", "ms_gather")},
@@ -603,112 +727,91 @@ def main():
                                         "model": "SURVEY.md 8(d): %.0f B per input byte for the whole LZ77 parse" % algo},
                          "note": "%s: algorithmic bytes = %.1f B per input byte x %d bytes per launch; kernel "
                                  "time %.3f ms (HIP events on the library's stream).  The kernel is bound by its "
-                                 "vector instructions (SQ counters: ~71 %% of the VALU issue slots), not by bandwidth (DESIGN.md 5)" % (
+                                 "vector instructions (SQ counters, DESIGN.md 5), not by bandwidth" % (
                                      kernel, k_bytes, n, k_ms)},
+            "line": "1 of up to 3: the timed region (cpu_baseline, plans[] and the legs behind the headline follow)",
         }
-        if world == 1:
-            # round trip on the device, outside the timed region: the shards of the plan decode as
-            # independent pieces (k_decode.h, one wave per shard) and must give back the input
-            try:
-                nsh = -(-n // shard)
-                d_sizes = torch.zeros(nsh, dtype=torch.int64, device=dev)
-                nb2, _ = ctx.encode_device(d_in, n, params, d_out, d_sizes)
-                sizes = d_sizes.cpu().tolist()
-                if nb2 + hip.DECODE_SLACK <= d_out.numel() and sum(sizes) == nb2:
-                    d_back = torch.empty(n + 64, dtype=torch.uint8, device=dev)
-                    pieces = hip.plan_pieces(sizes, n, shard, args.lgwin)
-                    res, dec_ms = ctx.decode_device(d_out, nb2, d_back, n, pieces, check=False)
-                    errs = [r[1] for r in res if r[1]]
-                    same = bool(torch.equal(d_back[:n], d_in[:n]))
-                    line["config"]["device_round_trip"] = {
-                        "equal_to_input": same and not errs and res[-1][2] == 1, "pieces": len(pieces),
-                        "piece_errors": len(errs), "decode_ms": round(dec_ms, 3),
-                        "decode_GBps_of_output": round(n / 1e9 / (dec_ms / 1e3), 2) if dec_ms > 0 else None}
-                    del d_back
-            except Exception as e:   # the encoder's line must not depend on the decoder
-                line["config"]["device_round_trip"] = {"error": repr(e)[:300]}
+        # (1) the headline exists: print it.  Everything below only adds fields to it.
+        emit(line)
         if world == 1 and not args.no_cpu_baseline:
-            # spot check of the bytes against the oracle on the first shards, then the baseline
-            from refharness import Oracle
-            o = Oracle()
-            comp = d_out[:nbytes].cpu().numpy().tobytes()
-            k = min(4, -(-n // shard))
-            want = b"".join(o.encode_shard(data[i * shard:(i + 1) * shard], args.quality, args.lgwin,
-                                           size_hint, min(i * shard, 1 << 30), (i + 1) * shard >= n)
-                            for i in range(k))
-            line["config"]["spot_check_first_shards_bit_exact"] = comp[:len(want)] == want
             import hashlib
-            line["config"]["gpu_output_sha256"] = hashlib.sha256(comp).hexdigest()
-            # config.plans[]: the headline plan and the other one of {128 KiB, 1 MiB} (the plan
-            # whose ratio is close to the single stream's), each with ratio, MB/s, whole-output sha256 and the reference
-            # driven with the same plan on this box's cores.  Timed the same way as the headline (device-resident input,
-            # synchronize on both sides), outside the headline's timed region.
+            cfg = line["config"]
+            comp = job.output_bytes(nbytes)
+            cfg["gpu_output_sha256"] = hashlib.sha256(comp).hexdigest()
+            # spot check of the bytes against the oracle on the first shards
+            try:
+                from refharness import Oracle
+                o = Oracle()
+                k = min(4, -(-n // shard))
+                want = b"".join(o.encode_shard(data[i * shard:(i + 1) * shard], args.quality, args.lgwin,
+                                               size_hint, min(i * shard, 1 << 30), (i + 1) * shard >= n)
+                                for i in range(k))
+                cfg["spot_check_first_shards_bit_exact"] = comp[:len(want)] == want
+            except Exception as e:
+                cfg["spot_check_first_shards_bit_exact"] = repr(e)[:200]
+            del comp
+            # config.plans[]: the headline plan and the other one of {128 KiB, 1 MiB} (the plan whose ratio is close
+            # to the single stream's), each with ratio, MB/s, whole-output sha256 and the reference driven with the
+            # same plan on this box's cores
             plans = [{"shard_KiB": args.shard_kb, "shards": infos[-1]["nshards"], "MBps": round(value, 1),
                       "ms_per_step": round(ms_step, 3), "ratio": round(total / out_total, 4), "compressed_bytes": out_total,
-                      "sha256": line["config"]["gpu_output_sha256"], "headline": True}]
+                      "sha256": cfg["gpu_output_sha256"], "headline": True}]
             other_kb = []
             if args.quality == 5 and args.workload == "text" and args.shard_kb in (128, 1024):
                 other_kb = [1024 if args.shard_kb == 128 else 128]
+            elif args.quality == 9 and args.shard_kb in (384, 512):
+                other_kb = [512 if args.shard_kb == 384 else 384]       # (both plans, not the kinder one)
             for kb in other_kb:
                 try:
-                    p2 = hip.make_params(args.quality, args.lgwin, kb << 10, size_hint, stream_base=0, is_last=True)
-                    cap2 = ctx.max_output(n, p2)
-                    d_out2 = d_out if cap2 <= d_out.numel() else torch.empty(cap2, dtype=torch.uint8, device=dev)
-                    ctx.encode_device(d_in, n, p2, d_out2)
-                    torch.cuda.synchronize(dev)
-                    t1 = time.perf_counter()
-                    inf2 = []
-                    for _ in range(3):
-                        nb2, i2 = ctx.encode_device(d_in, n, p2, d_out2)
-                        inf2.append(i2)
-                    torch.cuda.synchronize(dev)
-                    dt2 = (time.perf_counter() - t1) / 3
-                    comp2 = d_out2[:nb2].cpu().numpy().tobytes()
-                    plans.append({"shard_KiB": kb, "shards": inf2[-1]["nshards"], "MBps": round(n / 1e6 / dt2, 1),
-                                  "ms_per_step": round(dt2 * 1e3, 3), "ratio": round(n / nb2, 4), "compressed_bytes": nb2,
-                                  "sha256": hashlib.sha256(comp2).hexdigest(), "headline": False, "steps": 3,
-                                  "stage_ms": {k: round(sum(i.get(k, 0.0) for i in inf2) / len(inf2), 3) for k in
-                                               ("ms_total", "ms_index", "ms_ix_bucket", "ms_parse", "ms_build", "ms_store")},
-                                  "tile_sweeps": inf2[-1].get("tile_sweeps"),
-                                  "tile_fallback_shards": inf2[-1].get("tile_fallback_shards")})
-                    del comp2
-                    if d_out2 is not d_out:
-                        del d_out2
+                    plans.append(job.time_plan(args.quality, args.lgwin, kb, size_hint))
                 except Exception as e:
                     plans.append({"shard_KiB": kb, "error": repr(e)[:300]})
-            cb = cpu_baseline(data, args.quality, args.lgwin, shard, size_hint,
-                              other_plans=[kb << 10 for kb in other_kb if "error" not in plans[-1]])
-            line["cpu_baseline"] = cb
-            for pl in plans:
-                ref = ({"MBps": cb["value"], "sha256": cb.get("sha256"), "out_bytes": cb.get("out_bytes")} if pl.get("headline")
-                       else cb.get("other_plans", {}).get(str(pl["shard_KiB"])))
-                if ref and "MBps" in pl:
-                    pl["reference_same_plan_MBps"] = ref["MBps"]
-                    pl["x_reference_same_plan"] = round(pl["MBps"] / ref["MBps"], 2)
-                    pl["sha256_equal_reference"] = ref.get("sha256") == pl["sha256"] and ref.get("out_bytes") == pl["compressed_bytes"]
-            line["config"]["plans"] = plans
-            # the reference encoded the WHOLE input with the same plan in this
-            # run; its concatenated output must be the GPU's, byte for byte
-            if "sha256" in cb:
-                line["config"]["parity_full_sha256_equal"] = (
-                    cb["sha256"] == line["config"]["gpu_output_sha256"] and cb["out_bytes"] == nbytes)
-            line["config"]["single_stream_ratio"] = cb.get("single_stream_ratio")
-            # the ABI legs run on a context of the boundary library's own: this one's workspace goes first (quality 9 at
-            # 384 KiB shards holds 85 GiB of bucket tables — two of them do not fit beside each other)
-            ctx.close()
-            del d_out
-            torch.cuda.empty_cache()
-            line["config"]["end_to_end_abi"] = end_to_end_abi(data, args.quality, args.lgwin, args.shard_kb, nbytes,
-                                                             line["config"]["gpu_output_sha256"])
-            line["config"]["stock_call_no_plan"] = stock_call(data, args.quality, args.lgwin)
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            cfg["plans"] = plans
+            # the device is not needed by the baseline: give it back before the host cores are timed
+            job.close()
+            path = data_file(data)
+            try:
+                cb = cpu_baseline(path, len(data), args.quality, args.lgwin, shard, size_hint,
+                                  other_plans=[p["shard_KiB"] << 10 for p in plans[1:] if "error" not in p])
+                line["cpu_baseline"] = cb
+                for pl in plans:
+                    ref = ({"MBps": cb["value"], "sha256": cb.get("sha256"), "out_bytes": cb.get("out_bytes"),
+                            "seconds_all": cb.get("seconds_all")} if pl.get("headline")
+                           else cb.get("other_plans", {}).get(str(pl["shard_KiB"])))
+                    if ref and "MBps" in pl:
+                        pl["reference_same_plan_MBps"] = ref["MBps"]
+                        pl["reference_seconds_all"] = ref.get("seconds_all")
+                        pl["x_reference_same_plan"] = round(pl["MBps"] / ref["MBps"], 2)     # (GPU mean of K steps / CPU median)
+                        pl["sha256_equal_reference"] = ref.get("sha256") == pl["sha256"] and ref.get("out_bytes") == pl["compressed_bytes"]
+                # the reference encoded the WHOLE input with the same plan in this
+                # run; its concatenated output must be the GPU's, byte for byte
+                if "sha256" in cb:
+                    cfg["parity_full_sha256_equal"] = (cb["sha256"] == cfg["gpu_output_sha256"] and cb["out_bytes"] == nbytes)
+                cfg["single_stream_ratio"] = cb.get("single_stream_ratio")
+                # (2) headline + baseline + plans + parity
+                line["line"] = "2 of up to 3: with cpu_baseline, plans[] and the whole-output parity (the legs follow)"
+                emit(line)
+                if not args.no_legs:
+                    legs = [("device_round_trip", "round_trip", (args.quality, args.lgwin, args.shard_kb, size_hint)),
+                            ("end_to_end_abi", "abi", (args.quality, args.lgwin, args.shard_kb, nbytes, cfg["gpu_output_sha256"]))]
+                    for key, name, largs in legs:
+                        cfg[key] = run_leg(name, path, *largs)
+                    sc = run_leg("stock", path, args.quality, args.lgwin)
+                    if isinstance(sc, dict) and "error" not in sc:
+                        sc["whole_input"] = run_leg("stock_whole", path, args.quality, args.lgwin)
+                    cfg["stock_call_no_plan"] = sc
+                    line["line"] = "3 of 3: complete"
+                    emit(line)
+            finally:
+                try:
+                    os.unlink(path)
+                except OSError:
+                    pass
+    job.finish()
 
 
 if __name__ == "__main__":
-    if len(sys.argv) == 5 and sys.argv[1] == "--stock-call-child":
-        stock_call_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]))
+    if len(sys.argv) >= 4 and sys.argv[1] == "--leg":
+        leg_main(sys.argv[2:])
     else:
         main()

@@ -500,7 +500,7 @@ static size_t feed_threshold(const BrotliEncoderState* s) {
   const char* e = getenv("BROTLI_AMD_FEED_KB");       /* default: 256 MiB of shards / 4 MiB of one stream */
   size_t kb = e ? (size_t)strtoull(e, NULL, 10) : (s->shard_bytes ? (256u << 10) : (4u << 10));
   if (!e && s->shard_bytes == 0 && s->quality == 5 && s->lgwin >= 17 && s->lgwin <= 22 && s->ndicts == 0 &&
-      !s->stream && s->submitted == 0 && s->size_hint != 0 && s->stream_offset == 0) {
+      !s->stream && s->submitted == 0 && s->size_hint != 0 && s->stream_offset == 0 && eff_lgblock(s) == 16) {
     /* One quality-5 stream whose size was announced (BROTLI_PARAM_SIZE_HINT: the CLI does that for files): the input
        is held until FINISH, so that the whole stream takes the tiled stream path (submit / wants_stream_tiles) instead
        of going to the serial device stream 4 MiB at a time.  BROTLI_AMD_HOLD_MB bounds what is held (default 1024;

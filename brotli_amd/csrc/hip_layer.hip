@@ -1000,6 +1000,13 @@ const char* brotli_amd_last_error(const BrotliAmdCtx* c) { return c ? c->err.c_s
 uint64_t brotli_amd_max_output(uint64_t len, const BrotliAmdJobParams* p) {
   JobPlan plan;
   if (len == 0) return 16;
+  if ((p->flags & BROTLI_AMD_FLAG_STREAM_TILES) && p->quality == 5 && p->shard_size == 0 && p->stream_base == 0) {
+    // a held stream on the tiled path: the stream's own bound (len + 8 per possible meta-block), not the 2 n of a
+    // one-shard job — a 1 GiB call does not ask its caller for 2 GiB (a stream that leaves the tiles answers
+    // BROTLI_AMD_SERIAL and writes nothing, whatever the capacity)
+    JobPlan sp;
+    if (plan_stream(len, p->lgwin, p->size_hint, 2048u, /*ix_in_ws=*/true, &sp)) return sp.max_out_bytes + 8;
+  }
   if (!plan_job(len, p->quality, p->lgwin, p->size_hint, p->shard_size, p->stream_base,
                 p->is_last != 0, &plan, true, (int)((p->flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u))) return 0;
   return plan.max_out_bytes;
@@ -1290,6 +1297,7 @@ struct BrotliAmdStream {
   ShardState* d_state = nullptr;
   uint32_t* d_counters = nullptr;
   uint64_t fed = 0;
+  uint64_t flushed = 0;             // `fed` when the last FLUSH / FINISH completed: nothing older is waiting for a meta-block
   bool finished = false;
   std::vector<uint8_t> host_out;
   // attached dictionaries (k_dict.h): the device copies of the chunks and of the CompoundDict
@@ -1410,7 +1418,9 @@ bool stream_run(BrotliAmdStream* s, const uint8_t* data, uint64_t len, int op) {
     else hipLaunchKernelGGL(k_parse_deep<4>, dim3(1), dim3(64), 0, c->stream, a);
     {
       HipRun R{c->stream};
-      run_build_store(R, a, 1u, use_wide(J, J.max_metablock_size), []() {});
+      // (the many-wave build / store for what can actually be pending — a FLUSH of a few hundred bytes keeps the two
+      //  one-wave kernels)
+      run_build_store(R, a, 1u, use_wide(J, std::min<uint64_t>(J.max_metablock_size, s->fed - s->flushed)), []() {});
     }
     uint32_t counters[16];
     HIP_OK(c, hipMemcpyAsync(counters, s->d_counters, sizeof(counters), hipMemcpyDeviceToHost, c->stream));
@@ -1461,6 +1471,7 @@ int brotli_amd_stream_write(BrotliAmdStream* s, const uint8_t* data, uint64_t le
   if (s->finished) { fail(c, "stream already finished"); return BROTLI_AMD_ERROR; }
   if (op < 0 || op > 3) { fail(c, "bad stream op"); return BROTLI_AMD_UNSUPPORTED; }
   if (!stream_run(s, data, len, op)) return BROTLI_AMD_ERROR;
+  if (op != BROTLI_AMD_OP_PROCESS) s->flushed = s->fed;
   if (op == BROTLI_AMD_OP_FINISH) s->finished = true;
   *out = s->host_out.data();
   *out_len = s->host_out.size();

@@ -52,8 +52,12 @@ def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0
     both = [int(v) for v in sizes.cpu()]                     # the step's one host read
     host_sizes, hints = both[0::2], both[1::2]
     if any(h != hints[0] for h in hints):
-        # pad_hint must be the same on every rank (sharded_step's comes from gathered sizes, so it is): ranks that
-        # disagree have just exchanged slots of different sizes
+        # pad_hint must be the same on every rank (compared raw: stricter than the slots it rounds to, so a caller bug
+        # shows even while the slots still agree).  sharded_step's hint is the `pad` an earlier
+        # step returned, computed from the gathered sizes, hence identical everywhere by construction — the speculative
+        # gather above relies on that (it is what keeps the host read out from between the two collectives).  Ranks
+        # that get here with different slots were handed hints from somewhere else: their payload gather has already
+        # run with mismatched counts, so this is a diagnosis of a caller bug, not a recovery.
         raise ValueError("gather_stream: pad_hint differs between ranks: %r" % (hints,))
     need = round_up(max(host_sizes))
     if need > pad:

@@ -52,7 +52,7 @@ def pytest_runtest_logstart(nodeid, location):
             tr.ensure_newline()
             tr.write_line("[test start] %s" % nodeid)
             tr._tw.flush()
-        if os.environ.get("GRAFT_REPO_ROOT") or os.path.isdir("/dev/kfd"):
+        if os.environ.get("GRAFT_REPO_ROOT") or os.path.exists("/dev/kfd"):
             d = os.path.join(ROOT, "gpurun_out")
             os.makedirs(d, exist_ok=True)
             with open(os.path.join(d, "last_test.txt"), "a") as f:
@@ -70,6 +70,13 @@ def pytest_configure(config):
     except (ImportError, ValueError, OSError):
         pass
     _CONFIG[:] = [config]
+    # gpurun_out/last_test.txt names the test that was running when a GPU process died: one run's record, not a growing log
+    if (os.environ.get("GRAFT_REPO_ROOT") or os.path.exists("/dev/kfd")) and not os.environ.get("PYTEST_XDIST_WORKER"):
+        try:
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            open(os.path.join(ROOT, "gpurun_out", "last_test.txt"), "w").close()
+        except OSError:
+            pass
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
     config.addinivalue_line("markers", "timeout: per-test limit (pytest-timeout; ignored when the plugin is absent)")
     # Build the test-only checkers if they are missing (seconds).
