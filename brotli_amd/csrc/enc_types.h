@@ -58,6 +58,10 @@ struct JobParams {
   uint64_t sbm_off;             // JOB_FLAG_STREAMT: the stream's three position bitmaps (unstored / as last seen / events), workspace offset
   uint64_t sbm_stride;          //   and the bytes of one of them
   uint64_t skt_off;             // JOB_FLAG_STREAMT: per chunk, seven words per bucket key (k_tile.h: StreamKeyTable), workspace offset
+  uint64_t big_off;             // JOB_FLAG_INDEXED: the block lists of the buckets too big for LDS (k_index.h: IxBigHeader + 8 lists), workspace offset
+  uint64_t big_cap;             //   and the records one list holds
+  uint32_t ix_giant;            //   a bucket above this many entries goes to the lists (below: searched by the wave that sorted it)
+  uint32_t ix_pad;
 };
 #define JOB_FLAG_NO_PAIR 1u   // debugging: disable the (p, p+1) speculative pair
 #define JOB_FLAG_QUAD 2u       // four shards per wave (k_parse4.h); set by the host when legal

@@ -467,6 +467,21 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
                        (IX_CHUNK + (3u << plan.J.ix_nb_log2)) * 4u, c->stream, a);
     HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
     hipLaunchKernelGGL(k_ix_bucket, dim3(ix_bucket_grid(plan.J, (uint32_t)nshards)), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_ix_big, dim3(IX_BIG_GRID), dim3(64), 0, c->stream, a);
+#if defined(IX_PROFILE)   // (experiment builds only: wave-cycles per phase of k_ix_bucket, summed over the waves)
+    {
+      uint64_t prof[16];
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipMemcpyFromSymbol(prof, HIP_SYMBOL(ix_prof), sizeof(prof));
+      double tot = 0;
+      for (int k = 0; k < 8; ++k) tot += (double)prof[k];
+      fprintf(stderr, "IXPROF");
+      for (int k = 0; k < 8; ++k) fprintf(stderr, " p%d=%.1f%%", k, 100.0 * (double)prof[k] / (tot > 0 ? tot : 1));
+      fprintf(stderr, " total=%.3g wave-cycles\n", tot);
+      memset(prof, 0, sizeof(prof));
+      (void)hipMemcpyToSymbol(HIP_SYMBOL(ix_prof), prof, sizeof(prof));
+    }
+#endif
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
     if (getenv("BROTLI_AMD_INDEX_ONLY")) {   // timing experiments: stop after the index kernels
       HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -765,6 +780,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     hipLaunchKernelGGL(k_ix_scatter, dim3(nchunks * plan.J.ix_slices), dim3(64), (IX_CHUNK + (3u << plan.J.ix_nb_log2)) * 4u, c->stream, x); each("k_ix_scatter");
     HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
     hipLaunchKernelGGL(k_ix_bucket_s, dim3(ix_bucket_grid(plan.J, nchunks)), dim3(64), 0, c->stream, x); each("k_ix_bucket_s");
+    hipLaunchKernelGGL(k_ix_big_s, dim3(IX_BIG_GRID), dim3(64), 0, c->stream, x); each("k_ix_big_s");
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
   }
   lap("index");

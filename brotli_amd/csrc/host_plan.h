@@ -161,7 +161,7 @@ static inline uint64_t plan_add_index_for(JobPlan* plan, std::vector<ShardDesc>&
   // Few buckets per wave = many waves per shard: the waves of one shard run on one XCD
   // (kernels.h), and with ~2 shards in flight per XCD the res[] lines its buckets fill stay in
   // that L2 until they are complete (measured: profiles/r02_d_*).
-  plan->J.ix_bpw = longest <= (160u << 10) ? 2u : 4u;
+  plan->J.ix_bpw = longest <= (160u << 10) ? 2u : 1u;      // (long shards: every bucket is searched block by block by its wave — 40.4 / 40.9 / 41.7 ms at 1 / 2 / 4, profiles/r05)
   plan->J.flags |= JOB_FLAG_INDEXED;
   IxLayout L;
   ix_layout(longest, slices, nb, &L);
@@ -169,6 +169,19 @@ static inline uint64_t plan_add_index_for(JobPlan* plan, std::vector<ShardDesc>&
     uint64_t off = plan->ws_bytes;
     for (ShardDesc& D : units) { D.ix_off = off; off = plan_align(off + L.bytes); }
     plan->ws_bytes = off;
+  }
+  {
+    // The buckets too big for LDS are searched in blocks of IX_BIG_BLOCK sorted entries by k_ix_big, which takes them
+    // from eight lists (unit u is XCD u % 8's, as in k_ix_bucket): a unit has at most len / IX_BIG_BLOCK + buckets of them.
+    uint64_t per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t u = 0; u < units.size(); ++u) per[u & 7u] += units[u].len / IX_BIG_BLOCK + (1ull << nb);
+    uint64_t cap = 0;
+    for (int x = 0; x < 8; ++x) if (per[x] > cap) cap = per[x];
+    plan->J.big_cap = cap + 8;
+    plan->J.ix_giant = 4096u;
+    if (const char* e = getenv("BROTLI_AMD_IX_GIANT")) { const long v = atol(e); if (v >= 320 && v <= (1 << 24)) plan->J.ix_giant = (uint32_t)v; }   // experiment knob
+    plan->J.big_off = plan->ws_bytes;
+    plan->ws_bytes = plan_align(plan->ws_bytes + IX_BIG_HEADER_BYTES + 8ull * plan->J.big_cap * sizeof(uint64_t));
   }
   return L.bytes;
 }

@@ -137,15 +137,25 @@ DEV void c_mark_range(const JobParams& J, CShard& C, bool act, uint32_t a, uint3
         if (dense) ns = 0;
       }
     }
+    // Four successors a round trip: their sorted entries with one load, their res[] words loaded together, then
+    // stored (one successor a round was three dependent accesses each — a third of the cycles of a shard of floats,
+    // where the literal spree leaves every other position unstored: profiles/r04_h).
     const uint32_t nmax = wave_max_u32(ns);
-    for (uint32_t j = 1; j <= nmax; ++j) {
-      if (j <= ns) {
-        const uint32_t p = (C.srt[s + j] & 0xFFFFFFu) + C.ibase;
-        if (p < C.tile_hi) {     // (a tiled job: successors in later tiles are told by k_tile_events)
-          uint32_t* w = (uint32_t*)(C.res + p) + 1;
-          *w = *w | IX_TAINT;      // (lanes that hit the same word write the same bit)
-        }
+    for (uint32_t j0 = 0; j0 < nmax; j0 += 4u) {
+      uint32_t e4[4] = {0, 0, 0, 0};
+      if (j0 < ns) __builtin_memcpy(e4, C.srt + s + j0 + 1u, 16);      // (srt[] ends with 16 bytes of slack: k_index_layout.h)
+      uint32_t* w[4];
+      uint32_t v[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        const uint32_t p = (e4[u] & 0xFFFFFFu) + C.ibase;
+        // (a tiled job: successors in later tiles are told by k_tile_events)
+        w[u] = (j0 + u < ns && p < C.tile_hi) ? (uint32_t*)(C.res + p) + 1 : nullptr;
+        v[u] = w[u] ? *w[u] : 0u;
       }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u)
+        if (w[u] && !(v[u] & IX_TAINT)) *w[u] = v[u] | IX_TAINT;         // (lanes that hit the same word write the same bit)
     }
     const uint32_t m16 = q_mask16(wave_ballot(sk));
 #if defined(BROTLI_AMD_SIMT_SIM)

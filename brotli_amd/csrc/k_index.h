@@ -132,7 +132,7 @@ DEV uint32_t ix_slice_len(uint32_t n, uint32_t slices) {
 // grid = nshards * slices.  Counts the storable positions of the slice per bucket;
 // cnt[bucket * slices + w].  Also clears the slice's part of the unstored-position bitmap.
 DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
-                  uint32_t w, uint32_t* lds_cnt) {
+                  uint32_t w, uint32_t* lds_cnt, bool first_wave) {
   const int lane = wave_lane();
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
@@ -172,6 +172,8 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
     uint32_t* ev = (uint32_t*)bm.ev;
     for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) { prev[i] = 0; ev[i] = 0; }
   }
+  // the block lists of the buckets too big for LDS (ix_bucket fills them, ix_big empties them): the job's first wave
+  if (first_wave && lane < 16) ((uint32_t*)(ws + J.big_off))[lane] = 0;
   wave_sync();
 }
 
@@ -325,160 +327,381 @@ DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input
   }
 }
 
+// (experiment builds: IX_NT = the entries are read, and srt[] is written, with the streaming hint)
+#if defined(IX_NT)
+#define IX_LD_STREAM(p) __builtin_nontemporal_load(p)
+#define IX_ST_STREAM(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define IX_LD_STREAM(p) (*(p))
+#define IX_ST_STREAM(p, v) (*(p) = (v))
+#endif
 // ---- level 2 + window search: one wave per (shard, bucket) -------------------------------
 DEV uint32_t ix_score(uint32_t len, uint32_t dist) { return 1920u + dev_mul24(135u, len) - dev_mul24(30u, log2floor(dist)); }
+// A candidate as ONE comparable word: score (13 bits: <= 1920 + 135 * IX_CAP) | 16 - j (visiting order: the nearer
+// candidate wins a tie, ..64_simd_inc.h:282 `score > best_score` in the order of the walk) | length (6 bits).  The
+// arg-max of the bucket loop is a v_max_u32 per candidate; length and distance are read back from the winner.
+DEV uint32_t ix_cand_key(uint32_t len, uint32_t dist, uint32_t j) { return (ix_score(len, dist) << 11) | ((16u - j) << 6) | len; }
 
-// The bucket loop of FindLongestMatch (..64_simd_inc.h:246-292) for the entry at index li of the
-// LDS arrays (w0 / bytes 0..7 / bytes 8..15, in (key, position) order): the entries before it sit
-// at li - 1, li - 2, ...  rank = same-key entries before it, nsucc = same-key entries after it.
-// Matches of up to 16 bytes are decided from LDS alone; longer ones compare on in the input.
-// Writes srt[] and res[].
-struct IxLds { const uint32_t* w0; const uint64_t* d; const uint64_t* d2; };
+// The sorted bucket (or a block of it) in LDS, in (key, position) order: w0 = position | tag << 24, bytes 0..7,
+// bytes 8..15 of the entry, and a word per entry that first carries what the sort knows of the entry (its place in
+// its key run) and then the block's work list (ix_prepare's words, the entries with many candidates first).
+struct IxLds { uint32_t* w0; uint64_t* d; uint64_t* d2; uint32_t* aux; };
+
+// ix_prepare's word: LDS slot (9 bits) | successors in the key run, capped at 16 (5) | IX_FULLRUN (1) | IX_DANGER (1)
+// | the slots j = 1..16 before the entry that hold a candidate (bit j - 1; 16 bits)
+#define IXW_NSUCC_SHIFT 9u
+#define IXW_FULLRUN (1u << 14)
+#define IXW_DANGER (1u << 15)
+#define IXW_NONE 0xFFFFFFFFu
+
+DEV uint64_t ix_res_word(uint32_t kind, uint32_t len, uint32_t dist, uint32_t sidx, uint32_t word) {
+  const uint32_t lo = (kind << 30) | (len << 24) | dist;
+  const uint32_t hi = sidx | (((word >> IXW_NSUCC_SHIFT) & 31u) << IX_NSUCC_SHIFT) | ((word & IXW_DANGER) ? IX_DANGER : 0u) |
+                      ((word & IXW_FULLRUN) ? IX_FULLRUN : 0u);
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
+// What the bucket loop of FindLongestMatch (..64_simd_inc.h:246-292) will look at for the entry in LDS slot x:
+// of the (up to) 16 entries before it in its key run, the ones with its tag (:263: the tag filter), inside the window
+// (a stream, :239-241).  rank = same-key entries before it, nsucc = same-key entries after it, sidx = its index in
+// srt[].  Writes srt[].  An entry without a candidate (41 % of the positions of text) gets its res[] here and is
+// not listed (IXW_NONE); the others return their word.
 // (STREAM: a chunk of a tiled stream — the window limit, the ring's end and the key table exist there only; a plain
 //  shard's instantiation carries none of it)
 template <bool STREAM>
-DEV void ix_window(const IxGeom& g, const uint8_t* data, const IxEntry& e, bool act, uint32_t rank, uint32_t nsucc,
-                   const IxLds& S, uint32_t li, uint32_t sidx, uint32_t* srt, uint64_t* res, uint32_t* kt = nullptr, uint32_t nkeys = 0) {
+DEV uint32_t ix_prepare(const IxGeom& g, const IxLds& S, uint32_t x, bool act, uint32_t key, uint32_t rank, uint32_t nsucc,
+                        uint32_t sidx, uint32_t* srt, uint64_t* res, uint32_t* kt, uint32_t nkeys, bool* disorder) {
+  const uint32_t w = S.w0[x];
+  const uint32_t p = w & 0xFFFFFFu;
+  const uint32_t P = p + g.base;                                // its position in the shard / stream
+  const uint32_t before = S.w0[(int)x - 1] & 0xFFFFFFu;         // (slot -1 of the first entry: never used, rank == 0)
+  if (act && rank != 0u && before >= p) *disorder = true;       // a key run must be in position order
   if (STREAM && kt != nullptr && act) {
     // a stream's chunk: the key run's place in srt[], and how much of it lies in the chunk's own part
-    const uint32_t pp = e.w0 & 0xFFFFFFu;
-    if (rank == 0u) { kt[SKT_RS * nkeys + e.w1] = sidx; kt[SKT_RL * nkeys + e.w1] = nsucc + 1u; }
-    if (pp >= g.ownc && (rank == 0u || (S.w0[li - 1u] & 0xFFFFFFu) < g.ownc)) kt[SKT_OWN * nkeys + e.w1] = nsucc + 1u;
+    if (rank == 0u) { kt[SKT_RS * nkeys + key] = sidx; kt[SKT_RL * nkeys + key] = nsucc + 1u; }
+    if (p >= g.ownc && (rank == 0u || before < g.ownc)) kt[SKT_OWN * nkeys + key] = nsucc + 1u;
   }
-  const uint32_t p = e.w0 & 0xFFFFFFu, tag = e.w0 >> 24;
-  const uint32_t P = p + g.base;                                // its position in the shard / stream
-  // (a stream: what the 16-bit counter hides depends on the stores since the stream's start — k_tile.h finds those
-  //  positions once the chunks before this one are parsed)
-  const bool danger = !STREAM && rank >= 65520u;
+  if (act) IX_ST_STREAM(&srt[sidx], w);
   const bool search = act && p >= g.own && ix_searchable(g, P);
-  const uint32_t max_length = search ? ix_block_end(g, P) - P : 0u;
-  const uint32_t maxb = umin(P, g.maxdist);                     // max_backward (backward_references_inc.h:56-57)
-  // the ring buffer's physical end (..64_simd_inc.h:243-249: no candidate is looked at once the current position is
-  // within best_len of it, one that is within best_len of it is passed over): a candidate whose match does not reach
-  // over the end — at either position — loses whenever one of the two rules would have applied to it (best_len is then
-  // longer than its match), so only a candidate whose match does reach over it makes the search order-dependent —
-  // the chain's to do
-  bool ringrisk = false;
-  const uint32_t rm = STREAM ? g.ring_mask : 0xFFFFFFFFu;
-  uint32_t best = 0, best_len = 0, best_dist = 0;               // exact candidates
-  uint32_t longmask = 0;
 #if defined(IX_NOWIN)       // (timing experiments only: results are wrong)
   const uint32_t nwin = 0u;
 #else
   const uint32_t nwin = search ? umin(rank, 16u) : 0u;
 #endif
-  const uint32_t nmax = (uint32_t)wave_max_u32(nwin);
-  for (uint32_t j = 1; j <= nmax; ++j) {
-    if (j > nwin) continue;
-    const uint32_t qw = S.w0[li - j];
-    if ((qw >> 24) != tag) continue;
-    const uint64_t x = S.d[li - j] ^ e.d;
-    uint32_t l = x ? ((uint32_t)dev_ctz64(x) >> 3) : 8u;
-    if (l < 4u) continue;                                       // first4 != current4
-    if (STREAM && p - (qw & 0xFFFFFFu) > maxb) continue;        // beyond the window (:239-241: it and everything older)
-    if (l == 8u) {
-      const uint64_t x2 = S.d2[li - j] ^ e.d2;
-      l = x2 ? 8u + ((uint32_t)dev_ctz64(x2) >> 3) : 16u;
-#if !defined(IX_NOLONG)     // (timing experiments only: results are wrong)
-      if (l == 16u && max_length > 16u) { longmask |= 1u << j; continue; }
-#endif
-    }
-    const uint32_t len = umin(l, max_length);
-    if (STREAM && ((((qw & 0xFFFFFFu) + g.base) & rm) + len > rm || (P & rm) + len > rm)) ringrisk = true;
-    const uint32_t dist = p - (qw & 0xFFFFFFu);
-    const uint32_t k = (ix_score(len, dist) << 5) | (16u - j);
-    if (k > best) { best = k; best_len = len; best_dist = dist; }
+  const uint32_t maxb = umin(P, g.maxdist);                     // max_backward (backward_references_inc.h:56-57)
+  uint32_t mask = 0;
+#pragma unroll
+  for (uint32_t j = 1; j <= 16u; ++j) {
+    const uint32_t qw = S.w0[(int)x - (int)j];                  // (slots below 0 hold other words of the wave's LDS: masked by nwin)
+    bool c = ((qw ^ w) >> 24) == 0u;
+    if (STREAM) c = c && p - (qw & 0xFFFFFFu) <= maxb;          // beyond the window (:239-241: it and everything older)
+    mask |= c ? 1u << (j - 1u) : 0u;
   }
-  // candidates equal in the first 16 bytes: compare on in the input, four candidates per
-  // round trip (bytes 16..31 first; the few that are still equal fetch 32..39)
-  uint32_t ncapped = 0, cap_key = 0, cap_dist = 0;
-  if (wave_ballot(longmask != 0) != 0) {
-    uint64_t mine[3] = {0, 0, 0};
-    if (longmask != 0) __builtin_memcpy(mine, data + p + 16u, 24);
-    while (wave_ballot(longmask != 0) != 0) {
-      // (two capped candidates make the search the chain's — IX_KIND_SLOW — whatever the others are: runs of zeros,
-      //  where all 16 candidates are equal for as long as one looks, stop after the first round)
-      if (ncapped >= 2u) longmask = 0;
-      uint32_t jj[4], qp[4], ln[4];
-      uint64_t c[4][2];
-      bool more = false;
+  mask &= (1u << nwin) - 1u;
+  // (a stream: what the 16-bit counter hides depends on the stores since the stream's start — k_tile.h finds those
+  //  positions once the chunks before this one are parsed)
+  const bool danger = !STREAM && rank >= 65520u;
+  const uint32_t word = x | (umin(nsucc, 16u) << IXW_NSUCC_SHIFT) | ((!STREAM && rank <= 16u) ? IXW_FULLRUN : 0u) |
+                        (danger ? IXW_DANGER : 0u) | (mask << 16);
+  if (!act) return IXW_NONE;
+  if (mask == 0u) {
+#if defined(IX_NTRES)     // (experiment: streaming stores)
+    __builtin_nontemporal_store(ix_res_word(search && danger ? IX_KIND_SLOW : IX_KIND_NONE, 0u, 0u, sidx, word), &res[p]);
+#elif defined(IX_NORES)    // (timing experiments only: results are wrong)
+    { const uint64_t v_ = ix_res_word(search && danger ? IX_KIND_SLOW : IX_KIND_NONE, 0u, 0u, sidx, word); if ((uint32_t)v_ == 0x12345u) res[p] = v_; }
+#else
+    res[p] = ix_res_word(search && danger ? IX_KIND_SLOW : IX_KIND_NONE, 0u, 0u, sidx, word);
+#endif
+    return IXW_NONE;
+  }
+  return word;
+}
+
+// The work list of a block: the words of ix_prepare, the entries with many candidates first (three classes: a row of
+// 64 lanes then walks about equally many — on text 26 % of the positions have sixteen candidates, 8 % have one).
+// Slots by ballots: no LDS atomics, no scan.  words[]: this lane's words, row by row (IXW_NONE: none).  Returns the
+// length of the list in S.aux[].
+template <int NROWS>
+DEV uint32_t ix_worklist(const IxLds& S, const uint32_t (&words)[NROWS], uint32_t nrows) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  const uint64_t below = (1ull << lane) - 1ull;
+  uint32_t n_hi = 0, n_mid = 0, n_lo = 0;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        jj[u] = longmask != 0 ? (uint32_t)dev_ctz32(longmask) : 0u;
-        longmask &= longmask - 1u;
-        qp[u] = S.w0[li - jj[u]] & 0xFFFFFFu;
-        c[u][0] = c[u][1] = 0;
-        if (jj[u] != 0) __builtin_memcpy(c[u], data + qp[u] + 16u, 16);
-      }
+  for (uint32_t r = 0; r < (uint32_t)NROWS; ++r) {
+    if (r >= nrows) break;
+    const bool have = words[r] != IXW_NONE;
+    const uint32_t e = (uint32_t)__builtin_popcount(words[r] >> 16);
+    n_hi += (uint32_t)dev_popc64(wave_ballot(have && e >= 11u));
+    n_mid += (uint32_t)dev_popc64(wave_ballot(have && e >= 4u && e < 11u));
+    n_lo += (uint32_t)dev_popc64(wave_ballot(have && e < 4u));
+  }
+  uint32_t at_hi = 0, at_mid = n_hi, at_lo = n_hi + n_mid;
+  wave_sync();
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint64_t x0 = c[u][0] ^ mine[0], x1 = c[u][1] ^ mine[1];
-        ln[u] = x0 ? 16u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 24u + ((uint32_t)dev_ctz64(x1) >> 3) : 32u;
-        if (jj[u] != 0 && ln[u] == 32u && max_length > 32u) more = true;
+  for (uint32_t r = 0; r < (uint32_t)NROWS; ++r) {
+    if (r >= nrows) break;
+    const bool have = words[r] != IXW_NONE;
+    const uint32_t e = (uint32_t)__builtin_popcount(words[r] >> 16);
+    const uint64_t b_hi = wave_ballot(have && e >= 11u), b_mid = wave_ballot(have && e >= 4u && e < 11u), b_lo = wave_ballot(have && e < 4u);
+    uint32_t slot;
+    if (e >= 11u) slot = at_hi + (uint32_t)dev_popc64(b_hi & below);
+    else if (e >= 4u) slot = at_mid + (uint32_t)dev_popc64(b_mid & below);
+    else slot = at_lo + (uint32_t)dev_popc64(b_lo & below);
+    if (have) S.aux[slot] = words[r];
+    at_hi += (uint32_t)dev_popc64(b_hi); at_mid += (uint32_t)dev_popc64(b_mid); at_lo += (uint32_t)dev_popc64(b_lo);
+  }
+  wave_sync();
+  return n_hi + n_mid + n_lo;
+}
+
+#if defined(IX_PROFILE)
+#define IX_T0 , ix_t0, ix_acc
+#define IX_LAP(k) do { const uint64_t t_ = (uint64_t)clock64(); ix_acc[k] += t_ - ix_t0; ix_t0 = t_; } while (0)
+__device__ uint64_t ix_prof[16];
+#else
+#define IX_T0
+#define IX_LAP(k) do {} while (0)
+#endif
+
+// The bucket loop itself for the block's work list (S.aux[0 .. n)), a row of 64 entries at a time: candidates of up
+// to 16 bytes are decided from LDS alone — two candidates per lane and round trip —; the ones equal in all 16 bytes
+// compare on in the input (bytes 16 .. IX_CAP - 1 in one round trip, four candidates at a time).  Writes res[].
+template <bool STREAM>
+DEV void ix_search_block(const IxGeom& g, const uint8_t* data, const IxLds& S, uint32_t n, uint32_t sbase, uint64_t* res
+#if defined(IX_PROFILE)
+                         , uint64_t& ix_t0, uint64_t (&ix_acc)[8]
+#endif
+                         ) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  for (uint32_t r0 = 0; r0 < n; r0 += 64u) {
+    const bool act = r0 + lane < n;
+    const uint32_t word = act ? S.aux[r0 + lane] : 0u;
+    const uint32_t x = act ? word & 511u : 16u;
+    uint32_t mask = act ? word >> 16 : 0u;
+    const uint32_t w = S.w0[x];
+    const uint64_t ed = S.d[x], ed2 = S.d2[x];
+    const uint32_t p = w & 0xFFFFFFu;
+    const uint32_t P = p + g.base;
+    const uint32_t max_length = act ? ix_block_end(g, P) - P : 0u;            // (listed: the position is searchable)
+    // the ring buffer's physical end (..64_simd_inc.h:243-249: no candidate is looked at once the current position is
+    // within best_len of it, one that is within best_len of it is passed over): a candidate whose match does not reach
+    // over the end — at either position — loses whenever one of the two rules would have applied to it (best_len is
+    // then longer than its match), so only a candidate whose match does reach over it makes the search order-dependent
+    // — the chain's to do
+    bool ringrisk = false;
+    const uint32_t rm = STREAM ? g.ring_mask : 0xFFFFFFFFu;
+    uint32_t best = 0, longmask = 0;                                          // ix_cand_key of the best exact candidate
+    auto eval = [&](uint32_t j, uint32_t qw, uint64_t qd, uint64_t qd2) {
+      const uint32_t q = qw & 0xFFFFFFu;
+      const uint64_t xx = qd ^ ed;
+      uint32_t l = xx ? ((uint32_t)dev_ctz64(xx) >> 3) : 8u;
+      if (l < 4u) return;                                                     // first4 != current4
+      if (l == 8u) {
+        const uint64_t x2 = qd2 ^ ed2;
+        l = x2 ? 8u + ((uint32_t)dev_ctz64(x2) >> 3) : 16u;
+#if !defined(IX_NOLONG)     // (timing experiments only: results are wrong)
+        if (l == 16u && max_length > 16u) { longmask |= 1u << j; return; }
+#endif
       }
-      if (wave_ballot(more) != 0) {
+      const uint32_t len = umin(l, max_length);
+      if (STREAM && (((q + g.base) & rm) + len > rm || (P & rm) + len > rm)) ringrisk = true;
+      best = umax(best, ix_cand_key(len, p - q, j));
+    };
+    while (wave_ballot(mask != 0u) != 0ull) {
+      if (mask == 0u) continue;
+      const uint32_t j1 = (uint32_t)dev_ctz32(mask) + 1u;
+      mask &= mask - 1u;
+      const bool two = mask != 0u;
+      const uint32_t j2 = two ? (uint32_t)dev_ctz32(mask) + 1u : j1;
+      mask &= mask - 1u;
+      const int i1 = (int)x - (int)j1, i2 = (int)x - (int)j2;
+      const uint32_t qw1 = S.w0[i1], qw2 = S.w0[i2];
+      const uint64_t qd1 = S.d[i1], qe1 = S.d2[i1], qd2 = S.d[i2], qe2 = S.d2[i2];
+      eval(j1, qw1, qd1, qe1);
+      if (two) eval(j2, qw2, qd2, qe2);
+    }
+    IX_LAP(5);
+    uint32_t ncapped = 0, cap_key = 0;
+    if (wave_ballot(longmask != 0) != 0) {
+      uint64_t mine[3] = {0, 0, 0};
+      if (longmask != 0) __builtin_memcpy(mine, data + p + 16u, 24);
+      while (wave_ballot(longmask != 0) != 0) {
+        // (two capped candidates make the search the chain's — IX_KIND_SLOW — whatever the others are: runs of zeros,
+        //  where all 16 candidates are equal for as long as one looks, stop after the first round)
+        if (ncapped >= 2u) longmask = 0;
+        uint32_t jj[4], qp[4];
+        uint64_t c[4][3];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          if (jj[u] != 0 && ln[u] == 32u && max_length > 32u) {
-            const uint64_t x0 = ld64(data + qp[u] + 32u) ^ mine[2];
-            ln[u] = x0 ? 32u + ((uint32_t)dev_ctz64(x0) >> 3) : 40u;
-          }
+          jj[u] = longmask != 0 ? (uint32_t)dev_ctz32(longmask) : 0u;
+          longmask &= longmask - 1u;
+          qp[u] = S.w0[(int)x - (int)jj[u]] & 0xFFFFFFu;
+          c[u][0] = c[u][1] = c[u][2] = 0;
+          if (jj[u] != 0) __builtin_memcpy(c[u], data + qp[u] + 16u, 24);
         }
-      }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (jj[u] == 0) continue;
-        const uint32_t len = umin(ln[u], max_length);
-        const uint32_t dist = p - qp[u];
-        {
-          const uint32_t reach = (len == IX_CAP && max_length > IX_CAP) ? max_length : len;     // (a capped one: as far as it may go)
-          if (STREAM && (((qp[u] + g.base) & rm) + reach > rm || (P & rm) + reach > rm)) ringrisk = true;
+        for (int u = 0; u < 4; ++u) {
+          if (jj[u] == 0) continue;
+          const uint64_t x0 = c[u][0] ^ mine[0], x1 = c[u][1] ^ mine[1], x2 = c[u][2] ^ mine[2];
+          const uint32_t ln = x0 ? 16u + ((uint32_t)dev_ctz64(x0) >> 3) : x1 ? 24u + ((uint32_t)dev_ctz64(x1) >> 3) :
+                              x2 ? 32u + ((uint32_t)dev_ctz64(x2) >> 3) : 40u;
+          const uint32_t len = umin(ln, max_length);
+          const bool capped = len == IX_CAP && max_length > IX_CAP;
+          {
+            const uint32_t reach = capped ? max_length : len;                 // (a capped one: as far as it may go)
+            if (STREAM && (((qp[u] + g.base) & rm) + reach > rm || (P & rm) + reach > rm)) ringrisk = true;
+          }
+          const uint32_t k = ix_cand_key(len, p - qp[u], jj[u]);
+          if (capped) { ++ncapped; cap_key = umax(cap_key, k); }
+          else best = umax(best, k);
         }
-        const uint32_t k = (ix_score(len, dist) << 5) | (16u - jj[u]);
-        if (len == IX_CAP && max_length > IX_CAP) {
-          ++ncapped;
-          if (k > cap_key) { cap_key = k; cap_dist = dist; }
-        } else if (k > best) { best = k; best_len = len; best_dist = dist; }
       }
     }
-  }
-  if (act) {
-    srt[sidx] = e.w0;
-    uint32_t kind, len = 0, dist = 0;
-    if (!search) kind = IX_KIND_NONE;
-    else if (danger || ringrisk || ncapped >= 2u) kind = IX_KIND_SLOW;
-    else if (ncapped == 1u) {
-      // the long candidate's score can only grow with its real length
-      if (cap_key > best) { kind = IX_KIND_LONG; len = IX_CAP; dist = cap_dist; }
-      else kind = IX_KIND_SLOW;
-    } else if (best != 0) { kind = IX_KIND_EXACT; len = best_len; dist = best_dist; }
-    else kind = IX_KIND_NONE;
-    const uint32_t lo = (kind << 30) | (len << 24) | dist;
-    const uint32_t hi = sidx | (umin(nsucc, 16u) << IX_NSUCC_SHIFT) | (danger ? IX_DANGER : 0u) |
-                        ((!STREAM && rank <= 16u) ? IX_FULLRUN : 0u);
-#if defined(IX_NORES)        // (timing experiments only: results are wrong)
-    if (lo == 0x12345u) res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
-#elif defined(IX_RES_SORTED) // (timing experiments only)
-    res[sidx] = (uint64_t)lo | ((uint64_t)hi << 32);
+    IX_LAP(6);
+    if (act) {
+      const bool danger = (word & IXW_DANGER) != 0u;
+      uint32_t kind, key = 0;
+      if (danger || ringrisk || ncapped >= 2u) kind = IX_KIND_SLOW;
+      else if (ncapped == 1u) {
+        // the long candidate's score can only grow with its real length
+        if (cap_key > best) { kind = IX_KIND_LONG; key = cap_key; }
+        else kind = IX_KIND_SLOW;
+      } else if (best != 0) { kind = IX_KIND_EXACT; key = best; }
+      else kind = IX_KIND_NONE;
+      uint32_t len = 0, dist = 0;
+      if (key != 0u) {
+        len = key & 63u;
+        dist = p - (S.w0[(int)x - (int)(16u - ((key >> 6) & 31u))] & 0xFFFFFFu);
+      }
+#if defined(IX_NTRES)
+      __builtin_nontemporal_store(ix_res_word(kind, len, dist, sbase + x, word), &res[p]);
+#elif defined(IX_NORES)       // (timing experiments only: results are wrong)
+      { const uint64_t v_ = ix_res_word(kind, len, dist, sbase + x, word); if ((uint32_t)v_ == 0x12345u) res[p] = v_; }
 #else
-    res[p] = (uint64_t)lo | ((uint64_t)hi << 32);
+      res[p] = ix_res_word(kind, len, dist, sbase + x, word);
 #endif
+    }
+    IX_LAP(7);
   }
 }
 
-// lds (words): [0, 128) bin starts, [128, 256) cursors, then w0[N], bytes 0..7 [N] (2 words each),
-// bytes 8..15 [N], N = 64 * IX_LROWS entries of the sorted bucket — or, for a bigger bucket, the
-// (16 + 64) staged entries of the row being searched
-#define IX_BUCKET_LDS_WORDS (256u + 64u * IX_LROWS * 5u)
-DEV void ix_lds_put(uint32_t* w0S, uint64_t* dS, uint64_t* d2S, uint32_t i, const IxEntry& e) {
-  w0S[i] = e.w0; dS[i] = e.d; d2S[i] = e.d2;
+#define IX_BUCKET_LDS_WORDS (256u + 64u * IX_LROWS * 6u)
+#define IX_BROWS (IX_LROWS - 1u)
+DEV void ix_lds_put(const IxLds& S, uint32_t i, const IxEntry& e) {
+  S.w0[i] = e.w0; S.d[i] = e.d; S.d2[i] = e.d2;
 }
+
+// One block of a big bucket (a record of the lists): the sorted entries [k * IX_BIG_BLOCK, ...) of bucket `bucket` of
+// unit D, with the 16 entries before them as look-back.  LDS slots 0..15 = the look-back, 16 + i = entry i of the block.
+// In three steps, so that a wave has the next block's loads under way while it searches this one.
+struct IxBigCtx {
+  IxGeom g;
+  const uint8_t* data;
+  const uint32_t* ent2;
+  const uint32_t* keep;
+  uint32_t* srt;
+  uint64_t* res;
+  uint32_t* kt;
+  uint32_t start, m, b0, nb, unit, bucket;
+};
+template <bool STREAM>
+DEV void ix_big_ctx(const JobParams& J, const ShardDesc* units, const uint8_t* input, uint8_t* ws, uint64_t rec, IxBigCtx& c) {
+  c.unit = (uint32_t)(rec >> 40);
+  c.bucket = (uint32_t)(rec >> 28) & 0xFFFu;
+  const ShardDesc& D = units[c.unit];
+  c.g = ix_geom(J, D);
+  IxLayout L;
+  ix_layout(c.g.len, J.ix_slices, J.ix_nb_log2, &L);
+  uint8_t* base = ws + D.ix_off;
+  c.data = input + D.in_off;
+  const uint32_t* cnt = (const uint32_t*)(base + L.cnt);
+  c.ent2 = (const uint32_t*)(base + L.ent2);
+  c.srt = (uint32_t*)(base + L.srt);
+  c.res = (uint64_t*)(base + L.res);
+  c.kt = nullptr;
+  if (STREAM) c.kt = (uint32_t*)(ws + J.skt_off + (uint64_t)(c.g.ownc == 0u ? 0u : (c.g.base >> J.chunk_log2) + 1u) * skt_chunk_bytes((uint32_t)J.bucket_bits));
+  c.start = cnt[c.bucket * J.ix_slices];
+  c.m = cnt[(c.bucket + 1u) * J.ix_slices] - c.start;
+  c.keep = (const uint32_t*)(base + L.ent) + c.start;
+  c.b0 = ((uint32_t)rec & 0xFFFFFFFu) * IX_BIG_BLOCK;
+  c.nb = umin(IX_BIG_BLOCK, c.m - c.b0);
+}
+// rows 0 .. 3: the block; "row" 4: the 16 entries before it; binsr: the two bin starts this lane keeps in LDS
+struct IxBigRegs { uint32_t wn[IX_BROWS + 1u]; uint64_t bn[IX_BROWS + 1u][2]; uint32_t binsr[2]; };
+DEV void ix_big_fetch(const IxBigCtx& c, IxBigRegs& r, bool with_bins = true) {
+  const uint32_t lane = (uint32_t)wave_lane();
+#pragma unroll
+  for (uint32_t q = 0; q < IX_BROWS; ++q) r.wn[q] = c.ent2[c.start + umin(c.b0 + q * 64u + lane, c.m - 1u)];
+  r.wn[IX_BROWS] = c.ent2[c.start + (c.b0 >= 16u ? c.b0 - 16u + (lane & 15u) : 0u)];
+  if (with_bins) {
+    r.binsr[0] = c.keep[2u * lane];
+    r.binsr[1] = c.keep[2u * lane + 1u];
+  }
+#pragma unroll
+  for (uint32_t q = 0; q <= IX_BROWS; ++q) __builtin_memcpy(r.bn[q], c.data + (r.wn[q] & 0xFFFFFFu), 16);
+}
+// The block's entries go from the registers to LDS (keyr: their keys stay with the lanes).
+DEV void ix_big_stage(const JobParams& J, const IxBigCtx& c, const IxBigRegs& r, const IxLds& S, uint32_t* bins, uint32_t (&keyr)[IX_BROWS]) {
+  const uint32_t lane = (uint32_t)wave_lane();
+  wave_sync();
+  bins[2u * lane] = r.binsr[0];
+  bins[2u * lane + 1u] = r.binsr[1];
+#pragma unroll
+  for (uint32_t q = 0; q <= IX_BROWS; ++q) {
+    IxEntry e;
+    e.w0 = r.wn[q]; e.d = r.bn[q][0]; e.d2 = r.bn[q][1];
+    const KeyTag kt2 = hash_pos(e.d, J.hasher_type, J.bucket_bits);
+    e.w0 = (e.w0 & 0xFFFFFFu) | (kt2.tag << 24);
+    if (q < IX_BROWS) {
+      keyr[q] = kt2.key;
+      if (q * 64u < c.nb) ix_lds_put(S, 16u + q * 64u + lane, e);              // (lanes beyond the block: a copy of the last entry, never used)
+    } else if (lane < 16u) ix_lds_put(S, lane, e);                               // (the first block's look-back: never used, rank <= index)
+  }
+  wave_sync();
+}
+template <bool STREAM>
+DEV void ix_big_search(const JobParams& J, const IxBigCtx& c, const IxLds& S, const uint32_t* bins, const uint32_t (&keyr)[IX_BROWS]) {
+  const uint32_t lane = (uint32_t)wave_lane();
+#if defined(IX_PROFILE)
+  uint64_t ix_t0 = (uint64_t)clock64();
+  uint64_t ix_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  const int lowbits = J.bucket_bits - (int)J.ix_nb_log2;    // 4 .. 7
+  const uint32_t lowmask = (1u << lowbits) - 1u;
+  const uint32_t nkeys = STREAM ? 1u << J.bucket_bits : 0u;
+  uint32_t words[IX_BROWS];
+  bool disorder = false;
+#pragma unroll
+  for (uint32_t r = 0; r < IX_BROWS; ++r) {
+    words[r] = IXW_NONE;
+    if (r * 64u >= c.nb) break;
+    const uint32_t q = r * 64u + lane, i = c.b0 + q;
+    const bool act = q < c.nb;
+    const uint32_t kl = keyr[r] & lowmask;
+    const uint32_t rank = act ? i - bins[kl] : 0u;
+    const uint32_t nsucc = act ? (kl == lowmask ? c.m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
+    words[r] = ix_prepare<STREAM>(c.g, S, 16u + (act ? q : 0u), act, keyr[r], rank, nsucc, c.start + i, c.srt, c.res, c.kt, nkeys, &disorder);
+  }
+  const uint32_t nlist = ix_worklist<IX_BROWS>(S, words, (c.nb + 63u) / 64u);
+  ix_search_block<STREAM>(c.g, c.data, S, nlist, c.start + c.b0 - 16u, c.res IX_T0);
+  wave_sync();
+}
+
+// lds (words): [0, 128) bin starts, [128, 256) cursors — the 17 counters of ix_worklist once the sort is done —,
+// then w0[N], bytes 0..7 [N] (2 words each), bytes 8..15 [N], aux[N]; N = 64 * IX_LROWS entries of the sorted bucket —
+// or, for a bigger bucket, 16 entries of look-back and a block of IX_BROWS rows being searched
 // (STREAM: the index chunks of a tiled stream — a kernel of its own, k_ix_bucket_s: the plain kernel carries neither
 //  the window limit / ring end / key table code nor the registers it pins.)
 template <bool STREAM>
 DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
-                   uint32_t bucket, uint32_t* lds) {
+                   uint32_t bucket, uint32_t* lds, uint32_t unit) {
+  const uint32_t xcd = unit & 7u;
   const int lane = wave_lane();
+#if defined(IX_PROFILE)
+  uint64_t ix_t0 = (uint64_t)clock64();
+  uint64_t ix_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  struct IxFlush { uint64_t (&a)[8]; uint32_t b; __device__ ~IxFlush() { if (wave_lane() == 0 && (b & 63u) == 0u) for (int k = 0; k < 8; ++k) atomicAdd((unsigned long long*)&ix_prof[k], (unsigned long long)a[k]); } } ix_flush{ix_acc, bucket};
+#endif
   const IxGeom g = ix_geom(J, D);
   IxLayout L;
   ix_layout(g.len, J.ix_slices, J.ix_nb_log2, &L);
@@ -491,6 +714,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   uint64_t* res = (uint64_t*)(base + L.res);
   uint32_t* kt = nullptr;
   if (STREAM) kt = (uint32_t*)(ws + J.skt_off + (uint64_t)(g.ownc == 0u ? 0u : (g.base >> J.chunk_log2) + 1u) * skt_chunk_bytes((uint32_t)J.bucket_bits));
+  const uint32_t nkeys = STREAM ? 1u << J.bucket_bits : 0u;
   const uint32_t start = cnt[bucket * J.ix_slices];
   const uint32_t end = cnt[(bucket + 1u) * J.ix_slices];   // (the last one reads the total)
   const uint32_t m = end - start;
@@ -500,11 +724,11 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
   uint32_t* bins = lds;
   uint32_t* cursor = lds + 128;
   const uint32_t NL = 64u * IX_LROWS;
-  uint32_t* w0S = lds + 256;
-  uint64_t* dS = (uint64_t*)(lds + 256 + NL);
-  uint64_t* d2S = (uint64_t*)(lds + 256 + 3u * NL);
   IxLds S;
-  S.w0 = w0S; S.d = dS; S.d2 = d2S;
+  S.w0 = lds + 256;
+  S.d = (uint64_t*)(lds + 256 + NL);
+  S.d2 = (uint64_t*)(lds + 256 + 3u * NL);
+  S.aux = lds + 256 + 5u * NL;
   wave_sync();
   for (uint32_t b = (uint32_t)lane; b < 128u; b += 64u) bins[b] = 0;
   wave_sync();
@@ -515,7 +739,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     for (uint32_t r = 0; r < IX_LROWS; ++r) {
       const uint32_t i = r * 64u + (uint32_t)lane;
       row[r].w0 = row[r].w1 = 0; row[r].d = row[r].d2 = 0;
-      if (i < m) row[r].w0 = ent[start + i];
+      if (i < m) row[r].w0 = IX_LD_STREAM(&ent[start + i]);
     }
 #pragma unroll
     for (uint32_t r = 0; r < IX_LROWS; ++r) {
@@ -526,50 +750,77 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
       }
     }
     wave_sync();
+    IX_LAP(0);
     {
       const uint32_t a = bins[2 * lane], b = bins[2 * lane + 1];
       const uint32_t incl = wave_incl_scan(a + b);
       wave_sync();
       bins[2 * lane] = incl - a - b;
       bins[2 * lane + 1] = incl - b;
-      cursor[2 * lane] = incl - a - b;
-      cursor[2 * lane + 1] = incl - b;
     }
     wave_sync();
+    IX_LAP(1);
+    uint32_t words[IX_LROWS];
+    // The entries arrive in position order.  First the slots are handed out by LDS atomics — the LDS unit serves the
+    // lanes of one atomic in lane order and a wave's atomics in program order, which already IS position order —; but
+    // nothing promises the former, so ix_prepare checks every key run (one look at the entry before, which it reads
+    // anyway) and a bucket that fails is placed once more with its ranks counted by ballots.
+    for (uint32_t attempt = 0; attempt < 2u; ++attempt) {
+      cursor[2 * lane] = bins[2 * lane];
+      cursor[2 * lane + 1] = bins[2 * lane + 1];
+      wave_sync();
 #pragma unroll
-    for (uint32_t r = 0; r < IX_LROWS; ++r) {
-      if (r * 64u >= m) break;
-      const bool act = r * 64u + (uint32_t)lane < m;
-      const uint32_t kl = row[r].w1 & lowmask;
-      const uint64_t same = ix_match_any(act, kl, lowbits);
-      const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
-      const uint32_t total = (uint32_t)dev_popc64(same);
-      uint32_t at = 0;
-      if (act) at = cursor[kl];
+      for (uint32_t r = 0; r < IX_LROWS; ++r) {
+        if (r * 64u >= m) break;
+        const bool act = r * 64u + (uint32_t)lane < m;
+        const uint32_t kl = row[r].w1 & lowmask;
+        uint32_t at = 0;
+        if (attempt == 0u) {
+          if (act) at = lds_atomic_add(&cursor[kl], 1u);
+        } else {
+          const uint64_t same = ix_match_any(act, kl, lowbits);
+          const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
+          const uint32_t total = (uint32_t)dev_popc64(same);
+          if (act) at = cursor[kl];
+          wave_sync();
+          if (act && rank + 1u == total) cursor[kl] = at + total;
+          at += rank;
+          wave_sync();
+        }
+        if (act) {
+          ix_lds_put(S, at, row[r]);
+          // its place in its key run: same-key entries before it (9 bits), after it (9), the key's low bits
+          const uint32_t b0 = bins[kl], b1 = kl == lowmask ? m : bins[kl + 1u];
+          S.aux[at] = (at - b0) | ((b1 - at - 1u) << 9) | (kl << 18);
+        }
+      }
       wave_sync();
-      if (act && rank + 1u == total) cursor[kl] = at + total;
-      if (act) ix_lds_put(w0S, dS, d2S, at + rank, row[r]);
-      wave_sync();
+      IX_LAP(2);
+      bool disorder = false;
+#pragma unroll
+      for (uint32_t r = 0; r < IX_LROWS; ++r) {
+        words[r] = 0xFFFFFFFFu;
+        if (r * 64u >= m) break;
+        const uint32_t i = r * 64u + (uint32_t)lane;
+        const bool act = i < m;
+        const uint32_t a = act ? S.aux[i] : 0u;
+        words[r] = ix_prepare<STREAM>(g, S, act ? i : 16u, act, (bucket << lowbits) | (a >> 18), a & 511u, (a >> 9) & 511u,
+                                      start + i, srt, res, kt, nkeys, &disorder);
+      }
+      if (wave_ballot(disorder) == 0ull) break;
     }
-    for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-      const uint32_t i = r0 + (uint32_t)lane;
-      const bool act = i < m;
-      IxEntry e;
-      e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
-      if (act) { e.w0 = w0S[i]; e.d = dS[i]; e.d2 = d2S[i]; e.w1 = hash_pos(e.d, J.hasher_type, J.bucket_bits).key; }
-      const uint32_t kl = e.w1 & lowmask;
-      const uint32_t rank = act ? i - bins[kl] : 0u;
-      const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
-      ix_window<STREAM>(g, data, e, act, rank, nsucc, S, act ? i : 0u, start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
-    }
+    IX_LAP(3);
+    const uint32_t nlist = ix_worklist<IX_LROWS>(S, words, (m + 63u) / 64u);
+    IX_LAP(4);
+    ix_search_block<STREAM>(g, data, S, nlist, start, res IX_T0);
     wave_sync();
     return;
   }
-  // ---- a bigger bucket: sorted through HBM (ent -> ent2), searched row by row ----
+  // ---- a bigger bucket: sorted through HBM (ent -> ent2), searched block by block ----
   // (Every bucket of a shard of a MiB, the one bucket a run of zeros fills.  A row's chain — entries, the bytes at
   //  their positions, the search — is a wave's own here, one row after the other, so the loads run ahead of it: four
   //  rows of entries per round trip while counting, the next row's entries under way while this one is ranked, and in
-  //  the search the entries two rows ahead and the bytes one row ahead.)
+  //  the search the next block's entries and bytes while this one is searched.)
   for (uint32_t r0 = 0; r0 < m; r0 += 256u) {
     uint32_t v[4];
 #pragma unroll
@@ -614,36 +865,81 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     }
   }
   wave_sync();
-  // staged entries 0..15 = the last 16 entries of the previous row, 16 + lane = this row's
+  if (m > J.ix_giant) {
+    // A giant bucket (a run of zeros is ONE bucket of a whole shard): its key runs' starts go where its unsorted
+    // entries were (ent[start .. start + 128)), and its blocks of IX_BIG_BLOCK sorted entries onto this XCD's list —
+    // k_ix_big searches them, as many waves at a time as there are blocks.
+    uint32_t* keep = (uint32_t*)(base + L.ent) + start;
+    keep[2 * lane] = bins[2 * lane];
+    keep[2 * lane + 1] = bins[2 * lane + 1];
+    uint32_t* hdr = (uint32_t*)(ws + J.big_off);
+    uint64_t* list = (uint64_t*)(ws + J.big_off + IX_BIG_HEADER_BYTES) + (uint64_t)xcd * J.big_cap;
+    const uint32_t nblk = (m + IX_BIG_BLOCK - 1u) / IX_BIG_BLOCK;
+    uint32_t at = 0;
+    if (lane == 0) at = glb_atomic_add(&hdr[xcd], nblk);
+    at = wave_bcast(at, 0);
+    for (uint32_t k = (uint32_t)lane; k < nblk; k += 64u)
+      if (at + k < J.big_cap) list[at + k] = (uint64_t)k | ((uint64_t)bucket << 28) | ((uint64_t)unit << 40);
+    wave_sync();
+    return;
+  }
+  // The others, block by block, by this wave: the next block's entries and bytes under way while this one is searched.
   {
-    uint32_t w_next = ent2[start + umin((uint32_t)lane, m - 1u)];             // row 0's entries
-    uint64_t b_next[2];
-    __builtin_memcpy(b_next, data + (w_next & 0xFFFFFFu), 16);                 // ... and their bytes
-    uint32_t w_ahead = ent2[start + umin(64u + (uint32_t)lane, m - 1u)];       // row 1's entries
-    for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-      const uint32_t i = r0 + (uint32_t)lane;
-      const bool act = i < m;
-      IxEntry e;
-      e.w0 = e.w1 = 0xFFFFFFFFu; e.d = e.d2 = 0;
-      if (act) {
-        e.w0 = w_next; e.d = b_next[0]; e.d2 = b_next[1];
-        const KeyTag kt2 = hash_pos(e.d, J.hasher_type, J.bucket_bits);
-        e.w1 = kt2.key;
-        e.w0 = (e.w0 & 0xFFFFFFu) | (kt2.tag << 24);
+    IxBigCtx c;
+    c.g = g; c.data = data; c.ent2 = ent2; c.keep = nullptr; c.srt = srt; c.res = res; c.kt = kt;
+    c.start = start; c.m = m; c.unit = unit; c.bucket = bucket;
+    IxBigRegs regs;
+    regs.binsr[0] = bins[2 * lane];
+    regs.binsr[1] = bins[2 * lane + 1];
+    c.b0 = 0; c.nb = umin(IX_BIG_BLOCK, m);
+    ix_big_fetch(c, regs, false);
+    for (uint32_t b0 = 0; b0 < m; b0 += IX_BIG_BLOCK) {
+      IxBigCtx cur = c;
+      cur.b0 = b0; cur.nb = umin(IX_BIG_BLOCK, m - b0);
+      uint32_t keyr[IX_BROWS];
+      ix_big_stage(J, cur, regs, S, bins, keyr);
+      if (b0 + IX_BIG_BLOCK < m) {
+        c.b0 = b0 + IX_BIG_BLOCK; c.nb = umin(IX_BIG_BLOCK, m - c.b0);
+        ix_big_fetch(c, regs, false);
       }
-      // the next row's bytes, the entries of the row behind it
-      w_next = w_ahead;
-      __builtin_memcpy(b_next, data + (w_next & 0xFFFFFFu), 16);
-      w_ahead = ent2[start + umin(i + 128u, m - 1u)];
-      ix_lds_put(w0S, dS, d2S, 16u + (uint32_t)lane, e);
-      wave_sync();
-      const uint32_t kl = e.w1 & lowmask;
-      const uint32_t rank = act ? i - bins[kl] : 0u;
-      const uint32_t nsucc = act ? (kl == lowmask ? m : bins[kl + 1u]) - i - 1u : 0u;
-      ix_window<STREAM>(g, data, e, act, rank, nsucc, S, 16u + (uint32_t)lane, start + i, srt, res, kt, STREAM ? 1u << J.bucket_bits : 0u);
-      wave_sync();
-      if (lane >= 48) ix_lds_put(w0S, dS, d2S, (uint32_t)lane - 48u, e);   // the next row's look-back
-      wave_sync();
+      ix_big_search<STREAM>(J, cur, S, bins, keyr);
+    }
+  }
+}
+
+// grid = 8 * waves per XCD; workgroup b works on XCD b % 8's list, IX_BIG_PULL records at a time.
+#define IX_BIG_PULL 8u
+template <bool STREAM>
+DEV void ix_big(const JobParams& J, const ShardDesc* units, const uint8_t* input, uint8_t* ws, uint32_t xcd, uint32_t* lds) {
+  uint32_t* hdr = (uint32_t*)(ws + J.big_off);
+  const uint64_t* list = (const uint64_t*)(ws + J.big_off + IX_BIG_HEADER_BYTES) + (uint64_t)xcd * J.big_cap;
+  const uint32_t total = umin(hdr[xcd], (uint32_t)J.big_cap);
+  uint32_t* bins = lds;
+  const uint32_t NL = 64u * IX_LROWS;
+  IxLds S;
+  S.w0 = lds + 256;
+  S.d = (uint64_t*)(lds + 256 + NL);
+  S.d2 = (uint64_t*)(lds + 256 + 3u * NL);
+  S.aux = lds + 256 + 5u * NL;
+  for (;;) {
+    uint32_t at = 0;
+    if (wave_lane() == 0) at = glb_atomic_add(&hdr[8u + xcd], IX_BIG_PULL);
+    at = wave_bcast(at, 0);
+    if (at >= total) break;
+    const uint32_t n = umin(IX_BIG_PULL, total - at);
+    IxBigCtx next;
+    IxBigRegs regs;
+    ix_big_ctx<STREAM>(J, units, input, ws, list[at], next);
+    ix_big_fetch(next, regs);
+    for (uint32_t u = 0; u < n; ++u) {
+      const IxBigCtx cur = next;
+      uint32_t keyr[IX_BROWS];
+      ix_big_stage(J, cur, regs, S, bins, keyr);
+      if (u + 1u < n) {                                        // the next block's loads, under way during this one's search
+        ix_big_ctx<STREAM>(J, units, input, ws, list[at + u + 1u], next);
+        ix_big_fetch(next, regs);
+      }
+      ix_big_search<STREAM>(J, cur, S, bins, keyr);
     }
   }
 }

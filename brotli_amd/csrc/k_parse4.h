@@ -304,7 +304,13 @@ DEV QResult q_resolve_slow(const QShard& g, bool want, uint32_t P, uint32_t max_
     if (!want || !ok || stopped) continue;
     if (cur_masked + best_len > rm) { stopped = true; continue; }
     if ((prev_i & rm) + best_len > rm) continue;
-    if (q_ring_byte(g, P + best_len) != q_ring_byte(g, prev_i + best_len)) continue;
+    // The byte gate from the lengths already measured (len_i = the whole match, up to max_length): a match longer than
+    // best_len agrees at best_len; one that ends AT best_len, inside the block, differs there.  Only a shorter one —
+    // its first mismatch lies before the byte asked about — or one that ends with the block has to look.
+    if (len_i <= best_len) {
+      if (len_i == best_len && len_i < max_length) continue;
+      if (q_ring_byte(g, P + best_len) != q_ring_byte(g, prev_i + best_len)) continue;
+    }
     if (!(len_i >= 3 || (len_i == 2 && i < 2))) continue;
     if (!(r.score < score_i)) continue;
     best_len = len_i;
@@ -319,17 +325,22 @@ DEV QResult q_resolve_slow(const QShard& g, bool want, uint32_t P, uint32_t max_
     if (!want || !ok || stopped) continue;
     if (cur_masked + best_len > rm) { stopped = true; continue; }
     if ((prev_j & rm) + best_len > rm) continue;
-    bool pass = true;
-    for (uint32_t k = best_len - 3; k <= best_len; ++k) {
-      if (q_ring_byte(g, P + k) != q_ring_byte(g, prev_j + k)) { pass = false; break; }
+    // (the four gate bytes best_len - 3 .. best_len, ..64_simd_inc.h:265-270, the same way: with 16 equally long
+    //  candidates — runs of zeros — this loop was 20 candidates x 8 dependent loads, 62 % of such a shard's cycles,
+    //  profiles/r04_h)
+    if (len_j <= best_len) {
+      if (len_j + 3u >= best_len && len_j < max_length) continue;
+      bool pass = true;
+      for (uint32_t k = best_len - 3; k <= best_len; ++k) {
+        if (q_ring_byte(g, P + k) != q_ring_byte(g, prev_j + k)) { pass = false; break; }
+      }
+      if (!pass) continue;
     }
-    if (!pass) continue;
     if (len_j < 4) continue;
     if (!(r.score < score_j)) continue;
     best_len = len_j;
     r.len = len_j; r.distance = P - prev_j; r.score = score_j;
   }
-  (void)max_length;
   return r;
 }
 

@@ -23,8 +23,8 @@
 #define CHAIN_WAVES 3
 #endif
 #ifndef IXB_WAVES
-#define IXB_WAVES 5
-#endif
+#define IXB_WAVES 4                    // k_ix_bucket: 8.7 KB of LDS per wave admit 18 waves per CU either way; at five waves per SIMD
+#endif                                 //   (96 VGPRs) the search spills (profiles/r05_ix*: 29.4 against 28.3 ms)
 #ifndef BUILD_WAVES
 #define BUILD_WAVES 4
 #endif
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(64) k_ix_count(JobArgs a) {
   __shared__ uint32_t lds_cnt[IX_NB_MAX];
   const uint32_t shard = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
   if (shard >= a.nshards) return;
-  ix_count(a.J, a.shards[shard], a.input, a.ws, w, lds_cnt);
+  ix_count(a.J, a.shards[shard], a.input, a.ws, w, lds_cnt, blockIdx.x == 0);
 }
 // grid = nshards, block = 64
 __global__ void __launch_bounds__(64) k_ix_scan(JobArgs a) {
@@ -149,7 +149,7 @@ DEV void ix_bucket_kernel(const JobArgs& a, uint32_t* lds_b) {
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
   const uint32_t shard = (slot / per) * 8u + xcd, b0 = (slot % per) * a.J.ix_bpw;
   if (shard >= a.nshards) return;
-  for (uint32_t b = b0; b < b0 + a.J.ix_bpw; ++b) ix_bucket<STREAM>(a.J, a.shards[shard], a.input, a.ws, b, lds_b);
+  for (uint32_t b = b0; b < b0 + a.J.ix_bpw; ++b) ix_bucket<STREAM>(a.J, a.shards[shard], a.input, a.ws, b, lds_b, shard);
 }
 static inline uint32_t ix_bucket_grid(const JobParams& J, uint32_t nshards) {
   return ((nshards + 7u) / 8u) * 8u * ((1u << J.ix_nb_log2) / J.ix_bpw);
@@ -162,6 +162,17 @@ __global__ void __launch_bounds__(64, IXB_WAVES) k_ix_bucket(JobArgs a) {
 __global__ void __launch_bounds__(64, IXB_WAVES) k_ix_bucket_s(JobArgs a) {
   __shared__ uint32_t lds_b[IX_BUCKET_LDS_WORDS];
   ix_bucket_kernel<true>(a, lds_b);
+}
+// The buckets too big for LDS, block by block (k_index.h: ix_big): a fixed grid of IX_BIG_GRID workgroups — 8 XCDs x
+// the waves one XCD holds — takes the blocks from the lists k_ix_bucket wrote; few blocks = few waves with work.
+#define IX_BIG_GRID (8u * 32u * 4u * IXB_WAVES)
+__global__ void __launch_bounds__(64, IXB_WAVES) k_ix_big(JobArgs a) {
+  __shared__ uint32_t lds_b[IX_BUCKET_LDS_WORDS];
+  ix_big<false>(a.J, a.shards, a.input, a.ws, blockIdx.x & 7u, lds_b);
+}
+__global__ void __launch_bounds__(64, IXB_WAVES) k_ix_big_s(JobArgs a) {
+  __shared__ uint32_t lds_b[IX_BUCKET_LDS_WORDS];
+  ix_big<true>(a.J, a.shards, a.input, a.ws, blockIdx.x & 7u, lds_b);
 }
 // grid = ceil(nshards / shards per wave), block = 64; dynamic LDS: shards per wave * C_GROUP_LDS_WORDS * 4 bytes
 __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain(JobArgs a) {

@@ -3,9 +3,9 @@
 Rank r encodes the contiguous piece [r * piece, (r + 1) * piece) of one stream
 as BROTLI_PARAM_STREAM_OFFSET shards (c/include/brotli/encode.h:231-246); the
 compressed pieces are byte-aligned, so the stream is their concatenation in
-rank order.  The only collective on the data path is one all-gather of the
-sizes and one all-gather of the payloads padded to the largest piece (RCCL over
-xGMI with backend "nccl"; "gloo" on CPU tensors in the tests).
+rank order.  The only collective on the data path is ONE all-gather per step:
+every rank's slot carries its size in a 16-byte header in front of its padded
+piece (RCCL over xGMI with backend "nccl"; "gloo" on CPU tensors in the tests).
 """
 import torch
 import torch.distributed as dist
@@ -16,59 +16,63 @@ def rank_params(rank, world, piece_bytes, total_bytes):
     return rank * piece_bytes, rank == world - 1, min(total_bytes, 1 << 30)
 
 
-def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0):
-    """local: 1-D uint8 tensor holding this rank's compressed piece in local[:nbytes].  Returns (padded
-    all-gather buffer, sizes as a list of ints, padded_piece_len); the stream is
-    cat(buffer[r * pad : r * pad + sizes[r]]).
+HDR = 16   # bytes in front of every rank's slot: its compressed size and the slot hint it came with (two int64)
 
-    Both collectives are enqueued back to back: the payload gather does not wait for the host to read the
-    sizes.  Its slot size is `pad_hint` (what the previous step needed — the steps of a job compress the
-    same pieces) or, the first time, this rank's own size plus a margin; the ONE host read of the step —
-    the gathered sizes, needed to cut the padding off anyway — tells afterwards whether every piece fitted,
-    and only a piece that did not makes the gather run again with the right slot."""
+
+def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0):
+    """local: 1-D uint8 tensor holding this rank's compressed piece in local[:nbytes].  Returns (all-gather buffer,
+    sizes as a list of ints, slot bytes); the stream is cat(buffer[r * slot + HDR : r * slot + HDR + sizes[r]]).
+
+    ONE all-gather per step: every rank contributes a slot of `pad_hint` bytes (rounded up to `align`) = a 16-byte
+    header (its size, its hint) + its piece + padding, so the sizes travel with the payload and the step's one host
+    read — the headers, needed to cut the padding off anyway — comes after the collective.  The hint is what the
+    previous step needed (the steps of a job compress the same pieces); the first step of a job has none and asks for
+    the sizes first (one small all-gather more, once), as does a step whose piece did not fit its slot."""
     world = dist.get_world_size(group)
     dev = local.device
-    sizes = torch.zeros(2 * world, dtype=torch.int64, device=dev)
-    mine = torch.tensor([nbytes, int(pad_hint)], dtype=torch.int64, device=dev)       # (the hint travels with the size: checked below)
-    dist.all_gather_into_tensor(sizes, mine, group=group)
-
-    def gather(pad, local, scratch):
-        if local.numel() < pad:
-            grown = torch.zeros(pad, dtype=torch.uint8, device=dev)
-            grown[:nbytes] = local[:nbytes]
-            local = grown
-        if scratch is None or scratch.numel() < world * pad:
-            scratch = torch.empty(world * pad, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(scratch[:world * pad], local[:pad].contiguous(), group=group)
-        return scratch
 
     def round_up(v):
         return (int(v) + align - 1) // align * align
-    # every rank must choose the same slot: the hint is the same everywhere (it comes from gathered sizes);
-    # without one the slot has to wait for the sizes
-    pad = round_up(pad_hint) if pad_hint else 0
-    if pad:
-        scratch = gather(pad, local, scratch)
-    both = [int(v) for v in sizes.cpu()]                     # the step's one host read
-    host_sizes, hints = both[0::2], both[1::2]
-    if any(h != hints[0] for h in hints):
-        # pad_hint must be the same on every rank (compared raw: stricter than the slots it rounds to, so a caller bug
-        # shows even while the slots still agree).  sharded_step's hint is the `pad` an earlier
-        # step returned, computed from the gathered sizes, hence identical everywhere by construction — the speculative
-        # gather above relies on that (it is what keeps the host read out from between the two collectives).  Ranks
-        # that get here with different slots were handed hints from somewhere else: their payload gather has already
-        # run with mismatched counts, so this is a diagnosis of a caller bug, not a recovery.
-        raise ValueError("gather_stream: pad_hint differs between ranks: %r" % (hints,))
-    need = round_up(max(host_sizes))
-    if need > pad:
-        pad = need
-        scratch = gather(pad, local, scratch)
-    return scratch, host_sizes, pad
+
+    def gather(slot, scratch):
+        send = torch.zeros(slot, dtype=torch.uint8, device=dev)
+        send[:HDR] = torch.tensor([nbytes, int(pad_hint)], dtype=torch.int64).view(torch.uint8).to(dev)
+        n = min(nbytes, slot - HDR)
+        send[HDR:HDR + n] = local[:n]
+        if scratch is None or scratch.numel() < world * slot:
+            scratch = torch.empty(world * slot, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(scratch[:world * slot], send, group=group)
+        head = scratch[:world * slot].view(world, slot)[:, :HDR].contiguous().cpu()      # the step's one host read
+        both = head.view(torch.int64).view(world, 2)
+        return scratch, [int(v) for v in both[:, 0]], [int(v) for v in both[:, 1]]
+
+    slot = round_up(pad_hint) if pad_hint else 0
+    if slot > HDR:
+        scratch, sizes, hints = gather(slot, scratch)
+        if any(h != hints[0] for h in hints):
+            # pad_hint must be the same on every rank (compared raw: stricter than the slots it rounds to, so a caller bug
+            # shows even while the slots still agree).  sharded_step's hint is the slot an earlier step returned, computed
+            # from the gathered sizes, hence identical everywhere by construction — the gather above relies on that.  Ranks
+            # that get here with different slots were handed hints from somewhere else: their collective has already run
+            # with mismatched counts, so this is a diagnosis of a caller bug, not a recovery.
+            raise ValueError("gather_stream: pad_hint differs between ranks: %r" % (hints,))
+        if max(sizes) <= slot - HDR:
+            return scratch, sizes, slot
+    else:
+        # no (usable) hint yet: the sizes first
+        mine = torch.tensor([nbytes], dtype=torch.int64, device=dev)
+        allsz = torch.zeros(world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allsz, mine, group=group)
+        sizes = [int(v) for v in allsz.cpu()]
+    slot = round_up(max(sizes) + HDR)
+    pad_hint = slot                                              # (what this gather's headers carry: the same on every rank)
+    scratch, sizes, _ = gather(slot, scratch)
+    return scratch, sizes, slot
 
 
 def compact(buffer, sizes, pad):
-    """Removes the padding: the final contiguous stream (uint8 tensor).  `sizes`: host integers."""
-    return torch.cat([buffer[r * pad:r * pad + n] for r, n in enumerate(sizes)])
+    """Removes the headers and the padding: the final contiguous stream (uint8 tensor).  `sizes`: host integers."""
+    return torch.cat([buffer[r * pad + HDR:r * pad + HDR + n] for r, n in enumerate(sizes)])
 
 
 def sharded_step(encode_local, group=None, scratch=None, pad_hint=0):

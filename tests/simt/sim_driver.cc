@@ -34,6 +34,7 @@ void run_index(const JobArgs& a, int reverse) {
   run(k_ix_scan, a, a.nshards, 64, reverse);
   run(k_ix_scatter, a, a.nshards * a.J.ix_slices, 64, reverse);
   run((a.J.flags & JOB_FLAG_STREAMT) ? k_ix_bucket_s : k_ix_bucket, a, ix_bucket_grid(a.J, a.nshards), 64, reverse);
+  run((a.J.flags & JOB_FLAG_STREAMT) ? k_ix_big_s : k_ix_big, a, 8u * 3u, 64, reverse);      // (three waves per list)
 }
 void run_parse_kernel(JobArgs a, int reverse, int round = 0) {
   if (a.J.flags & JOB_FLAG_QUICK) {

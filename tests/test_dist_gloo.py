@@ -83,3 +83,64 @@ def test_two_rank_gather_concatenates_stream(ref):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2]
+
+
+def _worker_mix(rank, world, port, q):
+    """bench.py --workload silesia --gpus N in small: every rank has a piece of its OWN (the Silesia-style mix, seed +
+    rank), the stream is the pieces in rank order; three steps, the slot hint handed on as bench.py's steps do."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import gen_inputs as G
+    from brotli_amd.dist import rank_params, same_stream_on_all_ranks, sharded_step
+    from refharness import Oracle
+    o = Oracle()
+    piece, shard = 96 << 10, 32 << 10
+    total = piece * world
+    base, is_last, size_hint = rank_params(rank, world, piece, total)
+
+    def encode_piece(r):
+        data = G.mixed_corpus(piece, seed=G.SEED + r)
+        b, last, hint = rank_params(r, world, piece, total)
+        return b"".join(o.encode_shard(data[off:off + shard], 5, 22, hint, b + off, last and off + shard >= piece)
+                        for off in range(0, piece, shard))
+    comp = encode_piece(rank)
+
+    def encode_local():
+        local = torch.zeros(len(comp) + 4096, dtype=torch.uint8)
+        local[:len(comp)] = torch.frombuffer(bytearray(comp), dtype=torch.uint8)
+        return local, len(comp)
+    scratch, pad, stream_t, sizes = None, 0, None, None
+    for _ in range(3):
+        stream_t, sizes, scratch, pad = sharded_step(encode_local, scratch=scratch, pad_hint=pad)
+    same, _ = same_stream_on_all_ranks(stream_t)
+    ok = same and sizes[rank] == len(comp) and sum(sizes) == stream_t.numel()
+    if rank == 0:
+        # rank 0 checks the whole stream against every rank's piece encoded here, and that it decodes to the inputs
+        want = b"".join(encode_piece(r) for r in range(world))
+        ok = ok and stream_t.numpy().tobytes() == want
+        from refharness import Ref, have_ref
+        if have_ref():
+            plain = b"".join(G.mixed_corpus(piece, seed=G.SEED + r) for r in range(world))
+            ok = ok and Ref().decompress(want, len(plain)) == plain
+    q.put((rank, ok, int(stream_t.numel())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_mix_pieces_concatenate_to_one_stream(ref):
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker_mix, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert len({n for _, _, n in res}) == 1
