@@ -317,29 +317,42 @@ DEV QResult q_resolve_slow(const QShard& g, bool want, uint32_t P, uint32_t max_
     r.len = len_i; r.distance = P - prev_i; r.score = score_i;
   }
   if (best_len < 3) best_len = 3;
-  stopped = false;
-  for (int j = 0; j < 16; ++j) {
-    const int src = (int)((head + (uint32_t)j) & 15u);
-    const bool ok = q_bcast(b_ok ? 1u : 0u, src) != 0;
-    const uint32_t len_j = q_bcast(b_len, src), prev_j = q_bcast(b_prev, src), score_j = q_bcast(b_score, src);
-    if (!want || !ok || stopped) continue;
-    if (cur_masked + best_len > rm) { stopped = true; continue; }
-    if ((prev_j & rm) + best_len > rm) continue;
-    // (the four gate bytes best_len - 3 .. best_len, ..64_simd_inc.h:265-270, the same way: with 16 equally long
-    //  candidates — runs of zeros — this loop was 20 candidates x 8 dependent loads, 62 % of such a shard's cycles,
-    //  profiles/r04_h)
-    if (len_j <= best_len) {
-      if (len_j + 3u >= best_len && len_j < max_length) continue;
-      bool pass = true;
-      for (uint32_t k = best_len - 3; k <= best_len; ++k) {
-        if (q_ring_byte(g, P + k) != q_ring_byte(g, prev_j + k)) { pass = false; break; }
+  // The bucket slots in ring order starting at `head` (:246-292), replayed a winner at a time: given the best match
+  // so far, every lane decides for ITS slot whether the walk would take it — the two rules of the ring's end, the
+  // four gate bytes best_len - 3 .. best_len (:265-270), length, score — and the first such slot in visiting order is
+  // the walk's next winner: the slots before it fail against the very state they would meet.  A round per winner
+  // (two or three) instead of 16 dependent steps.  The gate from the lengths already measured (len = the whole match,
+  // up to max_length): a match longer than best_len agrees on all four bytes; one that ends in best_len - 3 ..
+  // best_len, inside the block, differs there; only a shorter one — its mismatch lies before the bytes asked about —
+  // or one that ends with the block has to look: two 4-byte loads for all such slots of the group at once.  (With 16
+  // equally long candidates — runs of zeros — the walk was 20 candidates x 8 dependent loads, 62 % of such a shard's
+  // cycles: profiles/r04_h, r05.)
+  {
+    const int t = q_t();
+    const uint32_t myj = ((uint32_t)t - head) & 15u;                  // this lane's slot is the myj-th the walk visits
+    uint32_t next_j = 0;
+    bool live = want;
+    while (wave_any(live)) {
+      if (live && cur_masked + best_len > rm) live = false;          // (:243-245: nothing more is looked at)
+      bool elig = live && b_ok && myj >= next_j && b_len >= 4u && r.score < b_score && !((b_prev & rm) + best_len > rm);
+      if (elig && b_len <= best_len) {
+        if (b_len + 3u >= best_len && b_len < max_length) elig = false;
+        else if (P + best_len < g.pos_end) elig = ld32(g.data + P + best_len - 3u) == ld32(g.data + b_prev + best_len - 3u);
+        else {
+          for (uint32_t k = best_len - 3; k <= best_len; ++k)
+            if (q_ring_byte(g, P + k) != q_ring_byte(g, b_prev + k)) { elig = false; break; }
+        }
       }
-      if (!pass) continue;
+      const uint32_t first = q_max(elig ? 16u - myj : 0u);            // 16 - (the lowest visiting index of an eligible slot)
+      if (first == 0u) live = false;
+      const int src = (int)((head + (16u - first)) & 15u);
+      const uint32_t len_w = q_bcast(b_len, src), prev_w = q_bcast(b_prev, src), score_w = q_bcast(b_score, src);
+      if (live) {
+        best_len = len_w;
+        r.len = len_w; r.distance = P - prev_w; r.score = score_w;
+        next_j = 16u - first + 1u;
+      }
     }
-    if (len_j < 4) continue;
-    if (!(r.score < score_j)) continue;
-    best_len = len_j;
-    r.len = len_j; r.distance = P - prev_j; r.score = score_j;
   }
   return r;
 }
