@@ -17,6 +17,7 @@ DEV uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 DEV uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 
 // ---- wave scans -------------------------------------------------------------
+#if defined(BROTLI_AMD_SIMT_SIM) || defined(WAVE_SCAN_BPERMUTE)
 DEV uint32_t wave_incl_scan(uint32_t v) {
   const int lane = wave_lane();
   uint32_t x = v;
@@ -27,6 +28,22 @@ DEV uint32_t wave_incl_scan(uint32_t v) {
   }
   return x;
 }
+#else
+// Inclusive prefix sum over the wave in six VALU instructions with DPP operands: four shifts inside the rows of 16
+// lanes (row_shr:1 / 2 / 4 / 8, zeros shifted in), then lane 15 of a row added to the row behind it (row_bcast:15,
+// rows 1 and 3) and lane 31 to the upper half (row_bcast:31) — no trip through the LDS crossbar (six dependent
+// ds_bpermute cost ~700 cycles of latency; k_store runs ~2000 scans per 128 KiB shard).  tools/scan_probe.hip checks it
+// against the shuffle form on the device.
+DEV uint32_t wave_incl_scan(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+  return v;
+}
+#endif
 
 // ---- hashing ---------------------------------------------------------------
 // H68: hash_longest_match64_simd_inc.h:26-32 (five bytes, 15-bit key + 8-bit

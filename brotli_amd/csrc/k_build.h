@@ -247,14 +247,24 @@ DEV void decide_contexts(BuildCtx& b, uint32_t start, uint32_t length) {
 // Commands [c0, c1) of the meta-block (c0 a multiple of 64), given where they begin: source position `pos`, first
 // literal index `nlits`, first distance index `ndist`.  The whole meta-block in one call (k_build) or one part of it
 // per wave (k_wide.h: the parts' starting values come from a scan over their totals).
+// lds_tables: b.lds has room behind word 160 for the two context LUTs and the context map (k_build: yes) — a literal's
+// context then costs one 4-byte load of the input (the literal and the two bytes before it) and three LDS reads instead
+// of three dependent trips to memory; the literal loop is a third of k_build on text and most of it on noise.
 DEV void build_streams_range(BuildCtx& b, uint32_t c0, uint32_t c1, uint32_t pos, uint32_t nlits, uint32_t ndist,
-                             uint32_t* nlits_out, uint32_t* ndist_out) {
+                             uint32_t* nlits_out, uint32_t* ndist_out, bool lds_tables = false) {
   const int lane = wave_lane();
   const uint8_t* clut = b.T->context_lut;
   const uint8_t* cmap = k_ctx_maps[b.map_kind];
   const bool use_ctx = b.nc > 1;
   uint32_t* s_start = b.lds;        // [65] first literal index of command i of the step
   uint32_t* s_src = b.lds + 65;     // [64] source position of that literal
+  uint8_t* t_clut = (uint8_t*)(b.lds + 160);     // [512]
+  uint8_t* t_cmap = t_clut + 512;                // [64]
+  if (lds_tables && use_ctx) {
+    for (uint32_t i = (uint32_t)lane; i < 128u; i += 64u) ((uint32_t*)t_clut)[i] = ((const uint32_t*)clut)[i];
+    if (lane < 16) ((uint32_t*)t_cmap)[lane] = ((const uint32_t*)cmap)[lane];
+    wave_sync();
+  }
   for (uint32_t base = c0; base < c1; base += 64) {
     const uint32_t i = base + (uint32_t)lane;
     const bool valid = i < c1;
@@ -289,10 +299,17 @@ DEV void build_streams_range(BuildCtx& b, uint32_t c0, uint32_t c1, uint32_t pos
         if (s_start[mid] <= L) lo = mid; else hi = mid - 1;
       }
       const uint32_t p = s_src[lo] + (L - s_start[lo]);
-      uint32_t v = b.data[p];
-      if (use_ctx) {
-        const uint32_t p1 = p >= 1 ? b.data[p - 1] : 0u, p2 = p >= 2 ? b.data[p - 2] : 0u;
-        v |= (uint32_t)cmap[clut[p1] | clut[256 + p2]] << 8;
+      uint32_t v;
+      if (lds_tables && use_ctx && p >= 2u) {
+        const uint32_t w3 = ld32(b.data + p - 2u);               // bytes p - 2, p - 1, p (and one more)
+        v = (w3 >> 16) & 0xFFu;
+        v |= (uint32_t)t_cmap[t_clut[(w3 >> 8) & 0xFFu] | t_clut[256u + (w3 & 0xFFu)]] << 8;
+      } else {
+        v = b.data[p];
+        if (use_ctx) {
+          const uint32_t p1 = p >= 1 ? b.data[p - 1] : 0u, p2 = p >= 2 ? b.data[p - 2] : 0u;
+          v |= (uint32_t)cmap[clut[p1] | clut[256 + p2]] << 8;
+        }
       }
       b.lits[L] = (uint16_t)v;
     }
@@ -306,7 +323,7 @@ DEV void build_streams_range(BuildCtx& b, uint32_t c0, uint32_t c1, uint32_t pos
   *ndist_out = ndist;
 }
 DEV void build_streams(BuildCtx& b, uint32_t start, uint32_t ncmds, uint32_t* nlits_out, uint32_t* ndist_out) {
-  build_streams_range(b, 0u, ncmds, start, 0u, 0u, nlits_out, ndist_out);
+  build_streams_range(b, 0u, ncmds, start, 0u, 0u, nlits_out, ndist_out, true);
 }
 
 // ---- greedy block splitter -------------------------------------------------------
