@@ -204,7 +204,9 @@ DEV void ix_scan(const JobParams& J, const ShardDesc& D, uint8_t* ws) {
 // counting-sorted by bucket inside the chunk (entries packed as chunk-relative position | low key bits |
 // bucket), then copied out index by index — neighbours in LDS are neighbours in their bucket's
 // range, and a bucket's share of a chunk leaves as one contiguous piece.
+#ifndef IX_CHUNK
 #define IX_CHUNK 2048u
+#endif
 #define IX_CHUNK_RANKED 48u   // up to this many entries of a chunk in one bucket are ranked by counting
 #define IX_SCATTER_LDS_WORDS (IX_CHUNK + 3u * IX_NB_MAX)
 DEV void ix_scatter(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
