@@ -179,7 +179,7 @@ def cpu_baseline(path, nbytes, quality, lgwin, shard_size, size_hint, reps=5, ot
 # Whatever happens in one of them — a GPU fault, a lost context, a timeout — the headline line is on stdout already
 # and the parent prints the line again, enriched with what did come back (round 4's driver run
 # ended without a line because the only print came after all of these).
-LEG_TIMEOUT_S = {"round_trip": 150, "abi": 150, "stock": 90, "stock_whole": 200}
+LEG_TIMEOUT_S = {"round_trip": 150, "abi": 150, "stock": 90, "stock_whole": 200, "process_fed": 150}
 
 
 def _bind_encoder(lib_path):
@@ -329,7 +329,46 @@ def leg_round_trip(path, quality, lgwin, shard_kb, size_hint):
             "decode_GBps_of_output": round(n / 1e9 / (dec_ms / 1e3), 2) if dec_ms > 0 else None}
 
 
-LEGS = {"abi": leg_abi, "stock": leg_stock, "stock_whole": leg_stock_whole, "round_trip": leg_round_trip}
+def leg_process_fed(path, quality, lgwin, piece_kb, max_mb):
+    """A stream handed over in PROCESS calls of piece_kb KiB with no BROTLI_PARAM_SIZE_HINT, then FINISH (what the Python
+    module's Compressor.process or the CLI on a pipe does): the first max_mb MiB of the input through
+    BrotliEncoderCompressStream of the drop-in library, next to the reference library driven the same way."""
+    import hashlib
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_abi import _bind, drive
+    with open(path, "rb") as f:
+        data = f.read(max_mb << 20)
+    os.environ.pop("BROTLI_AMD_SHARD_KB", None)
+    piece = piece_kb << 10
+    ops = [(piece, 0)] * (len(data) // piece) + [(len(data) % piece, 2)]
+    params = ((1, quality), (2, lgwin))
+    L = _bind(DROPIN)
+    times = []
+    got = b""
+    for _ in range(2):
+        t0 = time.perf_counter()
+        got, fin = drive(L, data, ops, params=params, out_chunk=1 << 24)
+        times.append(time.perf_counter() - t0)
+        if not fin:
+            return {"error": "stream not finished"}
+    res = {"bytes": len(data), "piece_KiB": piece_kb, "MBps": round(len(data) / 1e6 / times[-1], 1), "seconds_all": [round(t, 3) for t in times],
+           "out_bytes": len(got), "sha256": hashlib.sha256(bytes(got)).hexdigest(),
+           "note": "PROCESS calls of %d KiB without a size hint, then FINISH; pageable host buffers, the second of two runs" % piece_kb}
+    print(json.dumps(res), flush=True)
+    try:
+        from refharness import have_ref
+        if have_ref():
+            R = _bind(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
+            t0 = time.perf_counter()
+            want, _ = drive(R, data, ops, params=params, out_chunk=1 << 24)
+            res["reference_1core_MBps"] = round(len(data) / 1e6 / (time.perf_counter() - t0), 1)
+            res["bytes_equal_reference"] = bytes(want) == bytes(got)
+    except Exception as e:
+        res["reference"] = repr(e)[:200]
+    return res
+
+
+LEGS = {"abi": leg_abi, "stock": leg_stock, "stock_whole": leg_stock_whole, "round_trip": leg_round_trip, "process_fed": leg_process_fed}
 
 
 def leg_main(argv):
@@ -799,6 +838,7 @@ def main(argv=None):
                     sc = run_leg("stock", path, args.quality, args.lgwin)
                     if isinstance(sc, dict) and "error" not in sc:
                         sc["whole_input"] = run_leg("stock_whole", path, args.quality, args.lgwin)
+                        sc["process_fed_256MiB"] = run_leg("process_fed", path, args.quality, args.lgwin, 1024, 256)
                     cfg["stock_call_no_plan"] = sc
                     line["line"] = "3 of 3: complete"
                     emit(line)

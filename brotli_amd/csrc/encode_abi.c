@@ -50,6 +50,7 @@ struct BrotliEncoderStateStruct {
   /* produced, not yet taken */
   /* one FLUSH / FINISH call that brings its whole input and has room for the output: the job
      reads the caller's input and writes the caller's output (no staging copies on the host) */
+  int tail_finish;       /* this FINISH brought no input and what PROCESS calls brought before ends on an input-block boundary */
   uint8_t* direct_out;
   size_t direct_cap, direct_n;
   uint8_t* out_buf;
@@ -370,6 +371,17 @@ static int submit_serial(BrotliEncoderState* s, int op) {
     if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
     return 0;
   }
+  if (s->tail_finish && op == OP_FINISH && s->in_len != 0) {
+    /* the complete blocks as the PROCESS calls they came in (encoded with is_last = 0), then the empty FINISH */
+    if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_PROCESS, &out, &out_len) != BROTLI_AMD_OK) {
+      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      return 0;
+    }
+    s->submitted += s->in_len;
+    s->in_len = 0;
+    s->header_written = 1;
+    if (!out_append(s, out, (size_t)out_len)) return 0;
+  }
   if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, op, &out, &out_len) != BROTLI_AMD_OK) {
     if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
     return 0;
@@ -378,6 +390,16 @@ static int submit_serial(BrotliEncoderState* s, int op) {
   s->in_len = 0;
   s->header_written = 1;
   return out_append(s, out, (size_t)out_len);
+}
+
+/* Can the rule that closes a meta-block (encode.c:1141-1166: literals or commands >= a eighth of the largest
+   meta-block, or no room for another input block) apply to an input of n bytes at all?  (tail_finish: a one-shard job
+   writes the one-shot form, right as long as the last block cannot have closed its meta-block.) */
+static int metablock_may_close(const BrotliEncoderState* s, size_t n) {
+  const int lgb = eff_lgblock(s);
+  const int rb = 1 + (s->lgwin > lgb ? s->lgwin : lgb);
+  const size_t mm = (size_t)1 << (rb < 24 ? rb : 24);
+  return n >= mm / 8;
 }
 
 /* A whole quality-5 stream in one FINISH that is longer than the window (BrotliEncoderCompress of a big buffer, the
@@ -398,7 +420,7 @@ static int submit(BrotliEncoderState* s, int op) {
   if (stream_tiles) {
     /* (the plan code below with shard size 0 and the flag; BROTLI_AMD_SERIAL sends it to submit_serial) */
   } else if (s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream &&
-      s->in_len != 0 && s->ndicts == 0 &&
+      s->in_len != 0 && s->ndicts == 0 && !(s->tail_finish && metablock_may_close(s, s->in_len)) &&
       (s->quality != 5 || (s->lgwin >= 17 && s->in_len <= ((size_t)1 << (s->lgwin < 22 ? s->lgwin : 22)) - 16))) {
     /* Everything in one FINISH (BrotliEncoderCompress, the CLI on a small file): the same bytes come from a
        one-shard job (falls through to the plan code below with shard size 0 = one shard).  Qualities 6-9: any
@@ -451,7 +473,7 @@ static int submit(BrotliEncoderState* s, int op) {
     if (s->header_written == 2 && p.stream_base == 0) p.flags |= BROTLI_AMD_FLAG_NO_HEADER;
     if (s->disable_ctx) p.flags |= BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT;
     p.flags |= lgblock_flag(s);
-    if (stream_tiles) p.flags |= BROTLI_AMD_FLAG_STREAM_TILES;
+    if (stream_tiles) p.flags |= BROTLI_AMD_FLAG_STREAM_TILES | (s->tail_finish ? BROTLI_AMD_FLAG_TAIL_FINISH : 0u);
     cap = brotli_amd_max_output(s->in_len, &p);
     if (cap == 0) return 0;
     if (!sync_context_dictionaries(s)) return 0;
@@ -500,15 +522,21 @@ static size_t feed_threshold(const BrotliEncoderState* s) {
   const char* e = getenv("BROTLI_AMD_FEED_KB");       /* default: 256 MiB of shards / 4 MiB of one stream */
   size_t kb = e ? (size_t)strtoull(e, NULL, 10) : (s->shard_bytes ? (256u << 10) : (4u << 10));
   if (!e && s->shard_bytes == 0 && s->quality == 5 && s->lgwin >= 17 && s->lgwin <= 22 && s->ndicts == 0 &&
-      !s->stream && s->submitted == 0 && s->size_hint != 0 && s->stream_offset == 0 && eff_lgblock(s) == 16) {
-    /* One quality-5 stream whose size was announced (BROTLI_PARAM_SIZE_HINT: the CLI does that for files): the input
-       is held until FINISH, so that the whole stream takes the tiled stream path (submit / wants_stream_tiles) instead
-       of going to the serial device stream 4 MiB at a time.  BROTLI_AMD_HOLD_MB bounds what is held (default 1024;
-       0 = never); input beyond the announced size goes to the serial stream as before. */
+      !s->stream && s->submitted == 0 && s->stream_offset == 0 && eff_lgblock(s) == 16) {
+    /* One quality-5 stream fed with PROCESS calls (the CLI, Compressor.process of the Python module): the input is held
+       until FINISH, so that the whole stream takes the tiled stream path (submit / wants_stream_tiles) instead of going
+       to the serial device stream 4 MiB at a time — what the stream looks like does not depend on how the calls cut it
+       (encode.c:1666-1681 re-blocks the input; the size hint is latched by the first full block either way, above).
+       Announced (BROTLI_PARAM_SIZE_HINT: the CLI does that for files): held up to the announced size; not announced:
+       up to BROTLI_AMD_HOLD_MB (default 1024; 0 = never hold).  A FLUSH, or input beyond that, goes to the serial
+       stream as before. */
     const char* h = getenv("BROTLI_AMD_HOLD_MB");
     const char* t = getenv("BROTLI_AMD_STREAM_TILES");
     const size_t cap_mb = h ? (size_t)strtoull(h, NULL, 10) : 1024u;
-    if (!(t && atoi(t) == 0) && ((size_t)s->size_hint >> 20) < cap_mb) return (size_t)s->size_hint + 1u;
+    if (!(t && atoi(t) == 0) && cap_mb != 0) {
+      if (s->size_hint == 0) return cap_mb << 20;
+      if (((size_t)s->size_hint >> 20) < cap_mb) return (size_t)s->size_hint + 1u;
+    }
   }
   if (kb == 0) kb = 1;
   return kb << 10;
@@ -742,7 +770,12 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
       *available_in = 0;
     }
     if (op != OP_PROCESS) {
+      /* The reference encodes a block as soon as PROCESS calls have filled it (encode.c:1700-1712), not knowing that the
+         stream ends there: a FINISH that brings nothing then finds the last block done with is_last = 0 (submit). */
+      s->tail_finish = op == OP_FINISH && a == 0 && s->in_len != 0 && s->stream_offset == 0 &&
+                       (s->in_len & (((size_t)1 << eff_lgblock(s)) - 1u)) == 0;
       if (!submit(s, op)) { s->failed = 1; return BROTLI_FALSE; }
+      s->tail_finish = 0;
       s->stream_state = op == OP_FINISH ? ST_FINISHED : ST_FLUSH_REQUESTED;
     } else if (!forward_pending_input(s, 0)) {
       s->failed = 1;

@@ -56,6 +56,8 @@ struct BrotliAmdCtx {
   ShardDesc* d_mdesc = nullptr;
   ShardState* d_mstate = nullptr;
   uint64_t* d_moff = nullptr;
+  bool tail_fix = false;              // the last stream job: stream_tail_fix (host_plan.h) applies to its output
+  uint64_t tail_bit = 0, tail_total_bits = 0;
   uint64_t chunk_cap = 0, mb_cap = 0;
   uint8_t* d_stage_in = nullptr;    // encode_host staging
   uint8_t* d_stage_out = nullptr;
@@ -719,7 +721,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     c->d_mdesc = nullptr; c->d_mstate = nullptr; c->d_moff = nullptr; c->mb_cap = 0;
     HIP_OK(c, hipMalloc((void**)&c->d_mdesc, mcap * sizeof(ShardDesc)));
     HIP_OK(c, hipMalloc((void**)&c->d_mstate, mcap * sizeof(ShardState)));
-    HIP_OK(c, hipMalloc((void**)&c->d_moff, (mcap + 1) * sizeof(uint64_t)));
+    HIP_OK(c, hipMalloc((void**)&c->d_moff, (mcap + 3) * sizeof(uint64_t)));     // (+ 2: what stream_tail_fix needs, k_tile.h stream_scan)
     c->mb_cap = mcap;
   }
   HIP_OK(c, hipEventRecord(c->ev[6], c->stream));
@@ -919,8 +921,12 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
   if (tc[TILE_CNT_RBCHG] == 0) break;
   HIP_OK(c, hipMemsetAsync(c->d_mstate, 0, mcap * sizeof(ShardState), c->stream));
   }
-  uint64_t total_bits = 0;
-  HIP_OK(c, hipMemcpy(&total_bits, c->d_moff + nmb, 8, hipMemcpyDeviceToHost));
+  uint64_t tail[3] = {0, 0, 0};          // bits of the stream; stream_tail_fix applies (0 / 1), at which bit
+  HIP_OK(c, hipMemcpy(tail, c->d_moff + nmb, sizeof(tail), hipMemcpyDeviceToHost));
+  const uint64_t total_bits = tail[0];
+  c->tail_fix = (p->flags & BROTLI_AMD_FLAG_TAIL_FINISH) != 0 && tail[1] != 0;
+  c->tail_bit = tail[2];
+  c->tail_total_bits = total_bits;
   const uint64_t total = (total_bits + 7) / 8;
   *out_size = total;
   if (total + 8 > out_cap) { c->err = "output capacity too small"; *rc = BROTLI_AMD_OVERFLOW; return true; }
@@ -1045,6 +1051,7 @@ int brotli_amd_encode_device(BrotliAmdCtx* c, const void* d_in, uint64_t len,
       return BROTLI_AMD_UNSUPPORTED;
     }
     int src = BROTLI_AMD_ERROR;
+    c->tail_fix = false;
     if (!run_stream_job(c, len, p, (const uint8_t*)d_in, (uint8_t*)d_out, out_cap, out_size, info, &src))
       return c->err.find("device fault") != std::string::npos ? BROTLI_AMD_DEVICE_FAULT : BROTLI_AMD_ERROR;
     if (src == BROTLI_AMD_SERIAL) c->err = "the stream left the tiled path";
@@ -1142,10 +1149,18 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
   if (rc != BROTLI_AMD_OK) return rc;
   const double t2 = now();
   *out_size = n;
-  if (n > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
+  const bool tail_fix = (p->flags & BROTLI_AMD_FLAG_STREAM_TILES) != 0 && c->tail_fix;
+  if (n + (tail_fix ? 1u : 0u) > out_cap) { c->err = "output capacity too small"; return BROTLI_AMD_OVERFLOW; }
   if (!big_copy(c, out, c->d_stage_out, n, false)) {
     fail(c, "D2H copy failed");
     return BROTLI_AMD_ERROR;
+  }
+  if (tail_fix) {
+    // (the stream came in PROCESS calls ending on a block boundary, the FINISH came empty, and the rule of the cuts
+    //  closes the last meta-block there: host_plan.h — a few MB of bits moved by one, on the host)
+    out[n] = 0;
+    *out_size = stream_tail_fix(out, c->tail_bit, c->tail_total_bits);
+    c->tail_fix = false;
   }
   if (hlog) fprintf(stderr, "  host: staging + H2D of %llu bytes %.1f ms, encode_device %.1f ms, D2H of %llu bytes %.1f ms\n",
                     (unsigned long long)len, t1 - t0, t2 - t1, (unsigned long long)n, now() - t2);

@@ -293,6 +293,34 @@ static inline bool plan_stream(uint64_t len, int lgwin, uint32_t size_hint, uint
   return true;
 }
 
+// BROTLI_AMD_FLAG_TAIL_FINISH: the caller's stream came in PROCESS calls that ended exactly on an input-block boundary
+// and the FINISH brought nothing.  The reference then encodes the last block BEFORE it knows the stream ends
+// (encode.c:1700-1712: EncodeData(is_last = 0) as soon as the block is full): when the rule of encode.c:1141-1166
+// closes the meta-block there, it leaves with ISLAST = 0 and the FINISH adds the empty last meta-block
+// (encode.c:1175-1184, brotli_bit_stream.c "ISLAST + ISEMPTY"); when the rule lets it wait for more, the FINISH
+// flushes it with ISLAST = 1 — the one-shot stream.  The tiled stream writes the one-shot form; in the first case this
+// turns it into the other.  The header of a last meta-block is ISLAST 1, ISLASTEMPTY 0, MNIBBLES, MLEN - 1; of one that is
+// not last: ISLAST 0, MNIBBLES, MLEN - 1, ISUNCOMPRESSED 0 (RFC 7932 section 9.2; brotli_bit_stream.c StoreCompressed
+// MetaBlockHeader) — the same number of bits: the length field moves down by one, nothing behind the header moves,
+// and "11" + padding close the stream.  (A raw last meta-block is followed by the empty one either way.  What is_last
+// means for the reference's "is raw shorter" comparison, encode.c:604, is not redone: a last meta-block within a byte
+// of that threshold AND closed by the rule AND behind such a call sequence.)
+// out holds (total_bits + 7) / 8 bytes (+ 1 spare); returns the new size in bytes.
+static inline uint64_t stream_tail_fix(uint8_t* out, uint64_t islast_bit, uint64_t total_bits) {
+  auto get = [&](uint64_t b) -> uint32_t { return (out[b >> 3] >> (b & 7u)) & 1u; };
+  auto put = [&](uint64_t b, uint32_t v) { out[b >> 3] = (uint8_t)((out[b >> 3] & ~(1u << (b & 7u))) | (v << (b & 7u))); };
+  const uint32_t nibbles = 4u + (get(islast_bit + 2u) | (get(islast_bit + 3u) << 1));
+  const uint32_t field = 2u + 4u * nibbles;                   // MNIBBLES + MLEN - 1
+  put(islast_bit, 0u);
+  for (uint32_t k = 0; k < field; ++k) put(islast_bit + 1u + k, get(islast_bit + 2u + k));
+  put(islast_bit + 1u + field, 0u);                           // ISUNCOMPRESSED
+  uint64_t dst = total_bits;
+  put(dst++, 1u);                                             // ISLAST
+  put(dst++, 1u);                                             // ISEMPTY
+  while ((dst & 7u) != 0u) put(dst++, 0u);
+  return dst >> 3;
+}
+
 // Which parse kernel a plan runs on and in which wave layout (api_flags: BROTLI_AMD_FLAG_*
 // of include/brotli_amd_hip.h: 1 NO_PAIR, 2 NO_QUAD, 4 FORCE_SLOW, 8 NO_HEADER).  Returns
 // false when a shard is too long for the kernel its quality needs (*limit = the bound).

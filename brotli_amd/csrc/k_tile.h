@@ -340,8 +340,9 @@ DEV void stream_emit_mb(const JobParams& J, const ShardDesc& D, const uint8_t* i
 // block of tile t when the literals / commands gathered since the last cut reach the limits or the next block would
 // not fit (encode.c:1141-1166).  Writes TileRec::cut (tile t + 1 begins a meta-block) and TileRec::cmd_off; with
 // `finalize` also the meta-blocks' descriptions.
+#define TILE_CNT_TAILCLOSED 9 // the stream's last block closes its meta-block by the rule of encode.c:1141-1166 (see stream_tail_fix)
 DEV void stream_cuts(const JobParams& J, const ShardDesc& D, TileRec* R, const uint8_t* input, ShardDesc* md, ShardState* ms,
-                     uint32_t mcap, uint32_t* counters, bool finalize) {
+                     uint32_t mcap, uint32_t* counters, bool finalize, uint8_t* ws) {
   const uint32_t lane = (uint32_t)wave_lane();
   const uint32_t nt = D.ntiles;
   const uint64_t block = 1ull << J.lgblock;
@@ -399,6 +400,20 @@ DEV void stream_cuts(const JobParams& J, const ShardDesc& D, TileRec* R, const u
   if (finalize) {
     if (m < mcap) { if (lane == 0) stream_emit_mb(J, D, input, md, ms, m, s_tile, nt - 1u, mb_cmd_lo, accC, accL, true); }
     else overflow = true;
+    if (lane == 0) {
+      // Would the reference, given the stream's last block with MORE input expected (a PROCESS call that ends on a block
+      // boundary, the FINISH coming empty), have closed the meta-block behind it?  The rule of the cuts above, with the
+      // counts as they stand before the trailing insert-only command (encode.c:1160-1166 test num_literals_ /
+      // num_commands_ before :1169-1173 adds it).  What follows from it: stream_tail_fix (host_plan.h).
+      const TileRec& z = R[nt - 1u];
+      uint32_t tl = accL, tc = accC;
+      if (z.out_ncmds != 0u) {
+        const Command lc = (c_tile_slot(ws, D, J, z.buf, nt - 1u) + (nt == 1u ? 0u : 1u))[z.out_ncmds - 1u];
+        if ((lc.copy_len & 0x1FFFFFFu) == 0u) { tl -= lc.insert_len; tc -= 1u; }
+      }
+      const uint64_t nb = (uint64_t)(nt - 1u) - s_tile + 1u;
+      counters[TILE_CNT_TAILCLOSED] = (tl >= J.max_literals || tc >= J.max_commands || (nb + 1u) * block > (uint64_t)J.max_metablock_size) ? 1u : 0u;
+    }
     ++m;
     if (lane == 0) {
       counters[TILE_CNT_NMB] = m;
@@ -682,6 +697,10 @@ DEV void stream_scan(const JobParams& J, const ShardDesc& D, ShardState* ms, uin
     S.mb_was_raw = raw ? 1u : 0u;
   }
   moff[nmb] = o;
+  // for stream_tail_fix: does the last meta-block carry ISLAST itself (a raw one never does) and has the rule of the
+  // cuts closed it; the bit its ISLAST sits at
+  moff[nmb + 1u] = (nmb != 0u && ms[nmb - 1u].mb_was_raw == 0u && counters[TILE_CNT_TAILCLOSED] != 0u) ? 1u : 0u;
+  moff[nmb + 2u] = nmb != 0u ? moff[nmb - 1u] + (nmb == 1u ? hb : 0u) : 0u;
   if (fault) glb_atomic_add(&counters[TILE_CNT_RAW], 1u);
 }
 

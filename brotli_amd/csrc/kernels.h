@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(64) k_tile_fallback(JobArgs a) {
 // ---- a tiled stream (JOB_FLAG_STREAMT, k_tile.h) ----
 // grid = 1, block = 64
 __global__ void __launch_bounds__(64) k_stream_cuts(JobArgs a) {
-  stream_cuts(a.J, a.shards[0], a.trecs, a.input, a.mdesc, a.mstate, a.mcap, a.counters, a.aux != 0);
+  stream_cuts(a.J, a.shards[0], a.trecs, a.input, a.mdesc, a.mstate, a.mcap, a.counters, a.aux != 0, a.ws);
 }
 // grid = ceil(ntiles / 64), block = 64
 __global__ void __launch_bounds__(64) k_stream_verify(JobArgs a) {

@@ -288,7 +288,7 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   std::vector<ShardDesc> mdesc(plan.mcap);
   std::vector<ShardState> mstate(plan.mcap);
   memset(mstate.data(), 0, mstate.size() * sizeof(ShardState));
-  std::vector<uint64_t> moff(plan.mcap + 1, 0);
+  std::vector<uint64_t> moff(plan.mcap + 3, 0);
   std::vector<uint8_t> sout(plan.max_out_bytes + 64, 0);
   std::vector<double> log2lut;
   DeviceTables T;
@@ -427,9 +427,13 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   memset(mstate.data(), 0, mstate.size() * sizeof(ShardState));
   }
   run(k_stream_place, a, nmb * STREAM_PLACE_PARTS, 256, reverse);
-  const uint64_t nbytes = (moff[nmb] + 7) / 8;
-  if (nbytes > out_cap) return -4;
+  uint64_t nbytes = (moff[nmb] + 7) / 8;
+  if (nbytes + 1 > out_cap) return -4;
   memcpy(out, sout.data(), nbytes);
+  if ((flags & (int)JOB_FLAG_TAILFIN) != 0 && moff[nmb + 1] != 0) {      // (hip_layer.hip: brotli_amd_encode_host)
+    out[nbytes] = 0;
+    nbytes = stream_tail_fix(out, moff[nmb + 2], moff[nmb]);
+  }
   return (long)nbytes;
 }
 

@@ -157,6 +157,7 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len, con
     int jflags = 0;
     if (p->flags & BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT) jflags |= (int)JOB_FLAG_NO_LITCTX;
     if (p->flags & BROTLI_AMD_FLAG_NO_HEADER) jflags |= (int)JOB_FLAG_NO_HEADER;
+    if (p->flags & BROTLI_AMD_FLAG_TAIL_FINISH) jflags |= (int)JOB_FLAG_TAILFIN;
     const long n = sim_encode_stream(c->tables.c_str(), in, (size_t)len, p->lgwin, p->size_hint, 0, jflags, out, (size_t)out_cap, sinfo);
     if (info) info->reserved = sinfo[1] | (sinfo[2] << 8) | ((sinfo[0] >> 8) << 16);
     if (n == -10 || n == -2) return set_err(c, "the stream left the tiled path", BROTLI_AMD_SERIAL);

@@ -49,6 +49,27 @@ def test_text_longer_than_the_window(amd, stock, mib, lgwin, seed):
     assert got == want
 
 
+@pytest.mark.parametrize("mib,piece_kb,seed,tail", [(40, 1024, 11, 4321), (24, 64, 12, 4321), (64, 1024, 13, 0), (40, 64, 14, 0), (88, 1024, 15, 0)])
+def test_process_fed_stream_without_a_size_hint(amd, stock, mib, piece_kb, seed, tail):
+    """What Compressor.process of the Python module (or the CLI on a pipe) does: PROCESS calls of 1 MiB / 64 KiB, no
+    BROTLI_PARAM_SIZE_HINT, then FINISH.  The library holds the pieces and parses the whole stream in tiles at the FINISH;
+    the size hint is the one the reference latches at its first full block (1 MiB: H68; 64 KiB: H58 for the whole
+    stream), so the bytes are the stock library's driven the same way."""
+    from test_gpu_abi import drive
+    # (tail 0: the PROCESS calls end on a block boundary and the FINISH comes empty — the reference has encoded the
+    #  last block with is_last = 0 by then: host_plan.h stream_tail_fix)
+    data = bytes(G.enwik_text((mib << 20) + tail, seed=seed))
+    piece = piece_kb << 10
+    ops = [(piece, 0)] * (len(data) // piece) + [(len(data) % piece, 2)]
+    t = time.time()
+    got, fin = drive(amd, data, ops, out_chunk=1 << 22)
+    dt = time.time() - t
+    want, fin2 = drive(stock, data, ops, out_chunk=1 << 22)
+    assert fin and fin2 and bytes(got) == bytes(want)
+    print("process-fed %d MiB in %d KiB pieces: %.2f s = %.0f MB/s" % (mib, piece_kb, dt, len(data) / 1e6 / dt))
+    assert dt < 30.0          # (the serial device stream needs minutes for this)
+
+
 def test_english_keeps_the_dictionary_gate_open(amd, stock):
     """alice29.txt over and over with synthetic text in between, 12 MiB (half of the positions end up unstored: the copies
     are tens of kilobytes long, several sweeps): the static dictionary's gate stays open behind

@@ -189,3 +189,26 @@ def test_stock_call_through_the_boundary(ref, monkeypatch):
         assert fin and fin2 and bytes(got) == bytes(want)
     monkeypatch.setenv("BROTLI_AMD_STREAM_TILES", "0")
     assert call(text[:200000], 17) == ref.compress(text[:200000], 5, 17)
+
+
+@pytest.mark.parametrize("lgwin,blocks", [(17, 1), (17, 2), (17, 3), (17, 4), (17, 7), (17, 8), (18, 2), (18, 3), (18, 9)])
+def test_process_calls_ending_on_a_block_boundary_then_an_empty_finish(ref, lgwin, blocks):
+    """PROCESS calls that fill the last input block exactly, then FINISH with nothing: the reference has encoded that
+    block with is_last = 0 already (encode.c:1700-1712) — when the rule of encode.c:1141-1166 closes the meta-block
+    there, it leaves with ISLAST = 0 and an empty last meta-block follows, which is NOT the one-shot stream (3 and 7
+    blocks of this text at lgwin 17).  The library holds such input for one job (with or without an announced size):
+    the tiled stream with BROTLI_AMD_FLAG_TAIL_FINISH (host_plan.h: stream_tail_fix), a one-shard job where the rule
+    cannot apply, the serial stream fed the same way otherwise."""
+    from test_abi_on_sim import SIM_ABI
+    from test_gpu_abi import _bind, drive
+    from refharness import ROOT, TABLES
+    os.environ["BROTLI_AMD_TABLES"] = TABLES
+    L = _bind(SIM_ABI)
+    stock = _bind(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
+    text = bytes(G.enwik_text(blocks * 65536, seed=12))
+    for hint in (0, len(text)):
+        params = ((2, lgwin),) + (((5, hint),) if hint else ())
+        ops = [(65536, 0)] * blocks + [(0, 2)]
+        got, fin = drive(L, text, ops, params=params)
+        want, fin2 = drive(stock, text, ops, params=params)
+        assert fin and fin2 and bytes(got) == bytes(want), (lgwin, blocks, hint)
