@@ -470,6 +470,14 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
     hipLaunchKernelGGL(k_ix_bucket, dim3(ix_bucket_grid(plan.J, (uint32_t)nshards)), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_big, dim3(IX_BIG_GRID), dim3(64), 0, c->stream, a);
+    if (getenv("BROTLI_AMD_IX_DEBUG")) {     // diagnostics: the lists' header (records per XCD, cursors, buckets placed twice)
+      uint32_t hdr[18];
+      (void)hipStreamSynchronize(c->stream);
+      (void)hipMemcpy(hdr, c->d_ws + plan.J.big_off, sizeof(hdr), hipMemcpyDeviceToHost);
+      fprintf(stderr, "IXDEBUG shards %u giant %u cap %llu off %llu: big blocks per XCD %u %u %u %u %u %u %u %u; cursors %u %u; buckets placed twice: small %u, big %u\n",
+              (unsigned)nshards, plan.J.ix_giant, (unsigned long long)plan.J.big_cap, (unsigned long long)plan.J.big_off,
+              hdr[0], hdr[1], hdr[2], hdr[3], hdr[4], hdr[5], hdr[6], hdr[7], hdr[8], hdr[9], hdr[16], hdr[17]);
+    }
 #if defined(IX_PROFILE)   // (experiment builds only: wave-cycles per phase of k_ix_bucket, summed over the waves)
     {
       uint64_t prof[16];

@@ -179,7 +179,7 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
     for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) { prev[i] = 0; ev[i] = 0; }
   }
   // the block lists of the buckets too big for LDS (ix_bucket fills them, ix_big empties them): the job's first wave
-  if (first_wave && lane < 16) ((uint32_t*)(ws + J.big_off))[lane] = 0;
+  if (first_wave && lane < 32) ((uint32_t*)(ws + J.big_off))[lane] = 0;     // ([0, 8) records, [8, 16) cursors, 16 / 17 diagnostics)
   wave_sync();
 }
 
@@ -681,7 +681,7 @@ DEV void ix_big_stage(const JobParams& J, const IxBigCtx& c, const IxBigRegs& r,
   wave_sync();
 }
 template <bool STREAM>
-DEV void ix_big_search(const JobParams& J, const IxBigCtx& c, const IxLds& S, const uint32_t* bins, const uint32_t (&keyr)[IX_BROWS]) {
+DEV bool ix_big_search(const JobParams& J, const IxBigCtx& c, const IxLds& S, const uint32_t* bins, const uint32_t (&keyr)[IX_BROWS], bool checked) {
   const uint32_t lane = (uint32_t)wave_lane();
 #if defined(IX_PROFILE)
   uint64_t ix_t0 = (uint64_t)clock64();
@@ -703,9 +703,11 @@ DEV void ix_big_search(const JobParams& J, const IxBigCtx& c, const IxLds& S, co
     const uint32_t nsucc = act ? (kl == lowmask ? c.m : bins[kl + 1u]) - i - 1u : 0u;   // entries after this one in its key run
     words[r] = ix_prepare<STREAM>(c.g, S, 16u + (act ? q : 0u), act, keyr[r], rank, nsucc, c.start + i, c.srt, c.res, c.kt, nkeys, &disorder);
   }
+  if (checked && wave_ballot(disorder) != 0ull) return true;   // (the caller sorts the bucket again, by ranks)
   const uint32_t nlist = ix_worklist<IX_BROWS>(S, words, (c.nb + 63u) / 64u);
   ix_search_block<STREAM>(c.g, c.data, S, nlist, c.start + c.b0 - 16u, c.res IX_T0);
   wave_sync();
+  return false;
 }
 
 // lds (words): [0, 128) bin starts, [128, 256) cursors — the 17 counters of ix_worklist once the sort is done —,
@@ -829,6 +831,7 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
                                       start + i, srt, res, kt, nkeys, &disorder);
       }
       if (wave_ballot(disorder) == 0ull) break;
+      if (lane == 0) glb_atomic_add(&((uint32_t*)(ws + J.big_off))[16], 1u);     // (diagnostics: buckets placed a second time)
     }
     IX_LAP(3);
     const uint32_t nlist = ix_worklist<IX_LROWS>(S, words, (m + 63u) / 64u);
@@ -866,46 +869,57 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     cursor[2 * lane + 1] = incl - b;
   }
   wave_sync();
-  {
-    uint32_t ahead = ent[start + umin((uint32_t)lane, m - 1u)];
-    for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
-      const uint32_t i = r0 + (uint32_t)lane;
-      const bool act = i < m;
-      const uint32_t ew = ahead;
-      ahead = ent[start + umin(i + 64u, m - 1u)];
-      const uint32_t kl = ew >> 24;
-      const uint64_t same = ix_match_any(act, kl, lowbits);
-      const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
-      const uint32_t total = (uint32_t)dev_popc64(same);
-      uint32_t at = 0;
-      if (act) at = cursor[kl];
-      wave_sync();
-      if (act && rank + 1u == total) cursor[kl] = at + total;
-      wave_sync();
-      if (act) ent2[start + at + rank] = ew;
-    }
-  }
-  wave_sync();
-  if (m > J.ix_giant) {
-    // A giant bucket (a run of zeros is ONE bucket of a whole shard): its key runs' starts go where its unsorted
-    // entries were (ent[start .. start + 128)), and its blocks of IX_BIG_BLOCK sorted entries onto this XCD's list —
-    // k_ix_big searches them, as many waves at a time as there are blocks.
-    uint32_t* keep = (uint32_t*)(base + L.ent) + start;
-    keep[2 * lane] = bins[2 * lane];
-    keep[2 * lane + 1] = bins[2 * lane + 1];
-    uint32_t* hdr = (uint32_t*)(ws + J.big_off);
-    uint64_t* list = (uint64_t*)(ws + J.big_off + IX_BIG_HEADER_BYTES) + (uint64_t)xcd * J.big_cap;
-    const uint32_t nblk = (m + IX_BIG_BLOCK - 1u) / IX_BIG_BLOCK;
-    uint32_t at = 0;
-    if (lane == 0) at = glb_atomic_add(&hdr[xcd], nblk);
-    at = wave_bcast(at, 0);
-    for (uint32_t k = (uint32_t)lane; k < nblk; k += 64u)
-      if (at + k < J.big_cap) list[at + k] = (uint64_t)k | ((uint64_t)bucket << 28) | ((uint64_t)unit << 40);
+  // Entries to their places in ent2.  A bucket this wave searches itself (<= ix_giant entries) takes its slots from LDS
+  // atomics first, as the small buckets do — the atomics of a wave come out in position order, which the search
+  // checks for every key run — and is sorted again with ranks counted by ballots when a check fails; a giant bucket,
+  // searched by other waves, is ranked at once.
+  for (uint32_t attempt = m > J.ix_giant ? 1u : 0u; attempt < 2u; ++attempt) {
+    cursor[2 * lane] = bins[2 * lane];
+    cursor[2 * lane + 1] = bins[2 * lane + 1];
     wave_sync();
-    return;
-  }
-  // The others, block by block, by this wave: the next block's entries and bytes under way while this one is searched.
-  {
+    {
+      uint32_t ahead = ent[start + umin((uint32_t)lane, m - 1u)];
+      for (uint32_t r0 = 0; r0 < m; r0 += 64u) {
+        const uint32_t i = r0 + (uint32_t)lane;
+        const bool act = i < m;
+        const uint32_t ew = ahead;
+        ahead = ent[start + umin(i + 64u, m - 1u)];
+        const uint32_t kl = ew >> 24;
+        if (attempt == 0u) {
+          if (act) ent2[start + lds_atomic_add(&cursor[kl], 1u)] = ew;
+        } else {
+          const uint64_t same = ix_match_any(act, kl, lowbits);
+          const uint32_t rank = (uint32_t)dev_popc64(same & ((1ull << lane) - 1ull));
+          const uint32_t total = (uint32_t)dev_popc64(same);
+          uint32_t at = 0;
+          if (act) at = cursor[kl];
+          wave_sync();
+          if (act && rank + 1u == total) cursor[kl] = at + total;
+          wave_sync();
+          if (act) ent2[start + at + rank] = ew;
+        }
+      }
+    }
+    wave_sync();
+    if (m > J.ix_giant) {
+      // A giant bucket (a run of zeros is ONE bucket of a whole shard): its key runs' starts go where its unsorted
+      // entries were (ent[start .. start + 128)), and its blocks of IX_BIG_BLOCK sorted entries onto this XCD's list —
+      // k_ix_big searches them, as many waves at a time as there are blocks.
+      uint32_t* keep = (uint32_t*)(base + L.ent) + start;
+      keep[2 * lane] = bins[2 * lane];
+      keep[2 * lane + 1] = bins[2 * lane + 1];
+      uint32_t* hdr = (uint32_t*)(ws + J.big_off);
+      uint64_t* list = (uint64_t*)(ws + J.big_off + IX_BIG_HEADER_BYTES) + (uint64_t)xcd * J.big_cap;
+      const uint32_t nblk = (m + IX_BIG_BLOCK - 1u) / IX_BIG_BLOCK;
+      uint32_t at = 0;
+      if (lane == 0) at = glb_atomic_add(&hdr[xcd], nblk);
+      at = wave_bcast(at, 0);
+      for (uint32_t k = (uint32_t)lane; k < nblk; k += 64u)
+        if (at + k < J.big_cap) list[at + k] = (uint64_t)k | ((uint64_t)bucket << 28) | ((uint64_t)unit << 40);
+      wave_sync();
+      return;
+    }
+    // The others, block by block, by this wave: the next block's entries and bytes under way while this one is searched.
     IxBigCtx c;
     c.g = g; c.data = data; c.ent2 = ent2; c.keep = nullptr; c.srt = srt; c.res = res; c.kt = kt;
     c.start = start; c.m = m; c.unit = unit; c.bucket = bucket;
@@ -914,7 +928,8 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
     regs.binsr[1] = bins[2 * lane + 1];
     c.b0 = 0; c.nb = umin(IX_BIG_BLOCK, m);
     ix_big_fetch(c, regs, false);
-    for (uint32_t b0 = 0; b0 < m; b0 += IX_BIG_BLOCK) {
+    bool again = false;
+    for (uint32_t b0 = 0; b0 < m && !again; b0 += IX_BIG_BLOCK) {
       IxBigCtx cur = c;
       cur.b0 = b0; cur.nb = umin(IX_BIG_BLOCK, m - b0);
       uint32_t keyr[IX_BROWS];
@@ -923,8 +938,11 @@ DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input,
         c.b0 = b0 + IX_BIG_BLOCK; c.nb = umin(IX_BIG_BLOCK, m - c.b0);
         ix_big_fetch(c, regs, false);
       }
-      ix_big_search<STREAM>(J, cur, S, bins, keyr);
+      again = ix_big_search<STREAM>(J, cur, S, bins, keyr, attempt == 0u);
     }
+    wave_sync();
+    if (!again) break;                                         // (attempt 1 cannot fail: its order is exact)
+    if (lane == 0) glb_atomic_add(&((uint32_t*)(ws + J.big_off))[17], 1u);     // (diagnostics, as word 16)
   }
 }
 
@@ -960,7 +978,7 @@ DEV void ix_big(const JobParams& J, const ShardDesc* units, const uint8_t* input
         ix_big_ctx<STREAM>(J, units, input, ws, list[at + u + 1u], next);
         ix_big_fetch(next, regs);
       }
-      ix_big_search<STREAM>(J, cur, S, bins, keyr);
+      (void)ix_big_search<STREAM>(J, cur, S, bins, keyr, false);
     }
   }
 }

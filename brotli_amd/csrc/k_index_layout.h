@@ -18,7 +18,8 @@
                                               //   wave, five waves per SIMD (8 rows: 11 KB, 3.5 waves, +5.7 ms per GiB — profiles/r03_c)
 #endif
 #define IX_BIG_BLOCK 256u                     // a bucket too big for LDS is searched in blocks of this many sorted entries (k_ix_big)
-#define IX_BIG_HEADER_BYTES 256u              //   the lists' header: [0, 8) records per list, [8, 16) the next record to hand out
+#define IX_BIG_HEADER_BYTES 256u              //   the lists' header (words): [0, 8) records per list, [8, 16) the next record to hand out,
+                                              //   16 / 17 buckets the LDS-atomic placement had to place again (small / big: diagnostics)
 #define IX_CAP 40u                            // bytes compared per candidate by ix_bucket
 #define IX_KIND_NONE 0u
 #define IX_KIND_EXACT 1u                      // (len, distance) is the bucket loop's result
