@@ -528,8 +528,8 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       const dim3 cgrid((ntiles + gpw - 1) / gpw);
       const uint32_t clds = gpw * C_GROUP_LDS_WORDS * 4u;
       const bool tlog = getenv("BROTLI_AMD_TILE_LOG") != nullptr;
+      double t_prev = 0;                           // (this job's own: contexts on other threads log independently)
       auto lap = [&](const char* what) {           // (diagnostics: wall time per stage, with a sync each)
-        static double t_prev = 0;
         if (!tlog) return;
         (void)hipStreamSynchronize(c->stream);
         timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
