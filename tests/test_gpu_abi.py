@@ -491,7 +491,9 @@ def test_q5_single_stream_emit_metadata_equals_reference(amd, stock):
     assert fin and got == want
 
 
-@pytest.mark.parametrize("quality,lgwin,lgblock", [(5, 22, 17), (5, 18, 20), (9, 22, 16), (6, 20, 21), (4, 22, 18), (5, 22, 12)])
+# ((5, 22, 23) / (5, 24, 24): blocks longer than the largest chain tile — quality 5 then runs the plain chain over the
+#  whole shard, host_plan.h plan_add_tiles: correct and slow)
+@pytest.mark.parametrize("quality,lgwin,lgblock", [(5, 22, 17), (5, 18, 20), (9, 22, 16), (6, 20, 21), (4, 22, 18), (5, 22, 12), (5, 22, 23), (5, 24, 24)])
 def test_lgblock_parameter_equals_reference(amd, stock, quality, lgwin, lgblock):
     """BROTLI_PARAM_LGBLOCK (encode.h:190-197; quality.h:75-92) on the device: one FINISH (at quality 5 the tiled chain
     with tiles of the caller's block size), a stream fed in pieces with a flush, a partition plan — the stock library's
