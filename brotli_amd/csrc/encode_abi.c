@@ -398,6 +398,7 @@ static int submit_serial(BrotliEncoderState* s, int op) {
 static int metablock_may_close(const BrotliEncoderState* s, size_t n) {
   const int lgb = eff_lgblock(s);
   const int rb = 1 + (s->lgwin > lgb ? s->lgwin : lgb);
+  if (s->quality < 4) return 1;          /* (no block splitting: flushed at 12 287 symbols, encode.c:1151-1153) */
   const size_t mm = (size_t)1 << (rb < 24 ? rb : 24);
   return n >= mm / 8;
 }

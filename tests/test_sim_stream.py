@@ -212,3 +212,22 @@ def test_process_calls_ending_on_a_block_boundary_then_an_empty_finish(ref, lgwi
         got, fin = drive(L, text, ops, params=params)
         want, fin2 = drive(stock, text, ops, params=params)
         assert fin and fin2 and bytes(got) == bytes(want), (lgwin, blocks, hint)
+
+
+@pytest.mark.parametrize("quality,lgwin,block", [(2, 18, 16384), (3, 20, 16384), (4, 18, 65536), (6, 18, 65536), (9, 17, 1 << 18), (7, 16, 65536), (5, 16, 65536)])
+def test_empty_finish_behind_complete_blocks_at_the_other_qualities(ref, quality, lgwin, block):
+    """The same call sequence at qualities 2 - 4 and 6 - 9 and at the small windows: one-shard jobs where the rule
+    that closes a meta-block cannot apply, the serial device stream fed as the caller fed the library otherwise."""
+    from test_abi_on_sim import SIM_ABI
+    from test_gpu_abi import _bind, drive
+    from refharness import ROOT, TABLES
+    os.environ["BROTLI_AMD_TABLES"] = TABLES
+    L = _bind(SIM_ABI)
+    stock = _bind(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
+    for k in (1, 2, 3, 5, 8):
+        text = bytes(G.enwik_text(k * block, seed=12 + k))
+        params = ((1, quality), (2, lgwin))
+        ops = [(block, 0)] * k + [(0, 2)]
+        got, fin = drive(L, text, ops, params=params)
+        want, fin2 = drive(stock, text, ops, params=params)
+        assert fin and fin2 and bytes(got) == bytes(want), (quality, lgwin, k)
