@@ -142,7 +142,7 @@ DEV void wide_streams(const JobParams& J, const ShardDesc& D, const ShardState* 
   for (uint32_t p = k; p < w.nparts; p += K) {
     const uint32_t c0 = p * WIDE_CMD_PART, c1 = umin(c0 + WIDE_CMD_PART, ncmds);
     uint32_t nl, nd;
-    build_streams_range(b, c0, c1, S->mb_start + w.parts[p].pos_off, w.parts[p].lit_off, w.parts[p].dist_off, &nl, &nd);
+    build_streams_range(b, c0, c1, S->mb_start + w.parts[p].pos_off, w.parts[p].lit_off, w.parts[p].dist_off, &nl, &nd, true);
   }
 }
 

@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(64) k_wide_scan1(JobArgs a) {
 __global__ void __launch_bounds__(64) k_wide_streams(JobArgs a) {
   const uint32_t m = blockIdx.x / a.wide_k;
   if (m >= a.nshards) return;
-  __shared__ uint32_t lds[132];
+  __shared__ uint32_t lds[160 + 144];      // [0, 129) the step's literal starts / sources, [160, 304) the context tables (k_build.h)
   wide_streams(a.J, a.shards[m], &a.states[m], a.T, a.input, a.ws, blockIdx.x % a.wide_k, a.wide_k, lds);
 }
 __global__ void __launch_bounds__(64) k_wide_split(JobArgs a) {
