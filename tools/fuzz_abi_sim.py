@@ -30,6 +30,20 @@ def one(seed):
         pieces.append(G.enwik_text(int(rng.integers(20000, 90000)), seed=seed, vocab=3000))
     data = b"".join(pieces)
     ops, off = [], 0
+    whole_blocks = rng.integers(0, 5) == 0
+    if whole_blocks:
+        # calls of whole input blocks and an empty FINISH (the CLI on a file whose size is a multiple of its reads): the
+        # reference encodes the last block before it knows the stream ends (encode.c:1700-1712; host_plan.h stream_tail_fix)
+        blk = 16384 if quality in (2, 3) else 65536
+        nblk = int(rng.integers(1, 7))
+        while len(data) < nblk * blk:
+            data += G.enwik_text(70000, seed=seed + len(data), vocab=3000)
+        data = data[:nblk * blk]
+        per = int(rng.choice([1, 1, 2, 3])) * blk
+        while off < len(data):
+            m = min(per, len(data) - off)
+            ops.append((m, 0))
+            off += m
     while off < len(data):
         m = int(min(len(data) - off, rng.choice([1, 7, 300, 2048, 5000, 30000, 70000])))
         r = rng.integers(0, 10)
@@ -43,7 +57,10 @@ def one(seed):
         else:
             ops.append((m, 0))
         off += m
-    ops.append((0, 2)) if rng.integers(0, 2) else ops.__setitem__(-1, (ops[-1][0], 2 if ops[-1][1] != 3 else 3))
+    if whole_blocks:
+        ops.append((0, 2))
+    else:
+        ops.append((0, 2)) if rng.integers(0, 2) else ops.__setitem__(-1, (ops[-1][0], 2 if ops[-1][1] != 3 else 3))
     if ops[-1][1] != 2:
         ops.append((0, 2))
     params = [(1, quality), (2, lgwin)]
