@@ -398,8 +398,9 @@ static int submit_serial(BrotliEncoderState* s, int op) {
 static int metablock_may_close(const BrotliEncoderState* s, size_t n) {
   const int lgb = eff_lgblock(s);
   const int rb = 1 + (s->lgwin > lgb ? s->lgwin : lgb);
-  if (s->quality < 4) return 1;          /* (no block splitting: flushed at 12 287 symbols, encode.c:1151-1153) */
   const size_t mm = (size_t)1 << (rb < 24 ? rb : 24);
+  if (s->quality < 4) return 1;          /* (no block splitting: flushed at 12 287 symbols, encode.c:1151-1153) */
+  if (s->stream_offset != 0) return 1;   /* (the flint block shifts the boundaries: not reasoned about) */
   return n >= mm / 8;
 }
 
@@ -773,8 +774,10 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
     if (op != OP_PROCESS) {
       /* The reference encodes a block as soon as PROCESS calls have filled it (encode.c:1700-1712), not knowing that the
          stream ends there: a FINISH that brings nothing then finds the last block done with is_last = 0 (submit). */
-      s->tail_finish = op == OP_FINISH && a == 0 && s->in_len != 0 && s->stream_offset == 0 &&
-                       (s->in_len & (((size_t)1 << eff_lgblock(s)) - 1u)) == 0;
+      /* (behind a stream offset the two "flint" bytes are a block of their own, encode.c:1686-1694: no arithmetic here —
+          such a stream goes to the serial device stream call by call, metablock_may_close) */
+      s->tail_finish = op == OP_FINISH && a == 0 && s->in_len != 0 &&
+                       (s->stream_offset != 0 || (s->in_len & (((size_t)1 << eff_lgblock(s)) - 1u)) == 0);
       if (!submit(s, op)) { s->failed = 1; return BROTLI_FALSE; }
       s->tail_finish = 0;
       s->stream_state = op == OP_FINISH ? ST_FINISHED : ST_FLUSH_REQUESTED;
