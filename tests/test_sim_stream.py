@@ -231,3 +231,22 @@ def test_empty_finish_behind_complete_blocks_at_the_other_qualities(ref, quality
         got, fin = drive(L, text, ops, params=params)
         want, fin2 = drive(stock, text, ops, params=params)
         assert fin and fin2 and bytes(got) == bytes(want), (quality, lgwin, k)
+
+
+@pytest.mark.parametrize("reverse", [0, 1])
+def test_every_big_bucket_on_the_lists_of_k_ix_big(sim, ref, monkeypatch, reverse):
+    """BROTLI_AMD_IX_GIANT=320: every bucket too big for LDS goes onto the block lists and is searched by k_ix_big /
+    k_ix_big_s (by default only the ones above 2048 entries do — a run of zeros —, the others are walked by the wave that
+    sorted them): a stream with a raw meta-block, and a plan of two long shards, in both lane orders."""
+    monkeypatch.setenv("BROTLI_AMD_IX_GIANT", "320")
+    rng = np.random.default_rng(9)
+    text = bytes(G.enwik_text(500000, seed=3))
+    data = text[:200000] + bytes(rng.integers(0, 256, 150000, dtype=np.uint8)) + bytes(200000) + text[200000:420000]
+    got, info = sim.encode_stream(data, lgwin=17, reverse=reverse)
+    assert got == ref.compress(data, 5, 17)
+    from refharness import Oracle
+    from test_sim_kernels import IX_LAYOUTS, _oracle_plan
+    from simharness import Sim
+    plan = bytes(G.enwik_text(320 << 10, seed=21, vocab=4000))
+    want = _oracle_plan(Oracle(), plan, 1 << 30, 160 << 10)
+    assert Sim().encode(plan, 5, 22, 1 << 30, 160 << 10, flags=IX_LAYOUTS["groups4"], reverse=reverse) == want
