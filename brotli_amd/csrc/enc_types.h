@@ -85,7 +85,7 @@ struct JobParams {
 #define JOB_FLAG_VIEWALL 16384u // (per launch) k_chain_tiles parses tiles again in a later pass (k_tile.h:
                                //   gate_walk): the bitmap holds what the other tiles left unstored — the events that told so
                                //   in the first pass are used up —, so every search is done exactly against it
-#define JOB_FLAG_TAILFIN 32768u // (simulator driver only: BROTLI_AMD_FLAG_TAIL_FINISH of the call, host_plan.h: stream_tail_fix)
+#define JOB_FLAG_TAILFIN 32768u // BROTLI_AMD_FLAG_TAIL_FINISH of the call (host_plan.h: stream_tail_fix; k_tile.h: stream_scan)
 #define JOB_FLAG_SWEEP 2048u   // (per launch) k_chain replays the tiles' previous commands and parses again only where an
                                //   event is pending
 

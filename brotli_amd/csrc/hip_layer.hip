@@ -683,6 +683,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
   if (!plan_stream(len, p->lgwin, p->size_hint, warm, /*ix_in_ws=*/false, &plan, &region)) { *rc = BROTLI_AMD_SERIAL; return true; }
   if (p->flags & BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT) plan.J.flags |= JOB_FLAG_NO_LITCTX;
   if (p->flags & BROTLI_AMD_FLAG_NO_HEADER) plan.J.flags |= JOB_FLAG_NO_HEADER;
+  if (p->flags & BROTLI_AMD_FLAG_TAIL_FINISH) plan.J.flags |= JOB_FLAG_TAILFIN;
   const uint32_t ntiles = (uint32_t)plan.tiles.size(), nchunks = plan.J.nchunks, mcap = plan.mcap;
   {
     // ≈ 85 bytes of device memory per input byte (index chunks with their look-back, two command slots per tile,

@@ -302,9 +302,8 @@ static inline bool plan_stream(uint64_t len, int lgwin, uint32_t size_hint, uint
 // turns it into the other.  The header of a last meta-block is ISLAST 1, ISLASTEMPTY 0, MNIBBLES, MLEN - 1; of one that is
 // not last: ISLAST 0, MNIBBLES, MLEN - 1, ISUNCOMPRESSED 0 (RFC 7932 section 9.2; brotli_bit_stream.c StoreCompressed
 // MetaBlockHeader) — the same number of bits: the length field moves down by one, nothing behind the header moves,
-// and "11" + padding close the stream.  (A raw last meta-block is followed by the empty one either way.  What is_last
-// means for the reference's "is raw shorter" comparison, encode.c:604, is not redone: a last meta-block within a byte
-// of that threshold AND closed by the rule AND behind such a call sequence.)
+// and "11" + padding close the stream.  (A raw last meta-block is followed by the empty one either way; the reference's
+// "is raw shorter" comparison, encode.c:604, is made without the last meta-block's padding then: k_tile.h stream_scan.)
 // out holds (total_bits + 7) / 8 bytes (+ 1 spare); returns the new size in bytes.
 static inline uint64_t stream_tail_fix(uint8_t* out, uint64_t islast_bit, uint64_t total_bits) {
   auto get = [&](uint64_t b) -> uint32_t { return (out[b >> 3] >> (b & 7u)) & 1u; };

@@ -681,7 +681,9 @@ DEV void stream_scan(const JobParams& J, const ShardDesc& D, ShardState* ms, uin
     bool raw = S.mb_was_raw == 1u;
     if (S.mb_was_raw == 2u) {
       uint64_t sx = (m == 0 ? T : (o & 7u) + T);
-      if (last) sx = (sx + 7u) & ~(uint64_t)7u;
+      // (JOB_FLAG_TAILFIN and the rule closed the last meta-block: the reference wrote it with is_last = 0 — no padding
+      //  in its comparison — and the empty last one behind it; stream_tail_fix, host_plan.h)
+      if (last && !((J.flags & JOB_FLAG_TAILFIN) != 0u && counters[TILE_CNT_TAILCLOSED] != 0u)) sx = (sx + 7u) & ~(uint64_t)7u;
       raw = (uint64_t)bytes + 4u < (sx >> 3);
     }
     moff[m] = o;
