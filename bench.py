@@ -53,9 +53,44 @@ HBM_ACHIEVABLE_GBS = 6300.0        # what a copy kernel reache
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s peak
 
 
+def cgroup_cpu():
+    """The CPU bandwidth limit of this process's cgroup (v2 cpu.max, v1 cpu.cfs_quota_us / cfs_period_us) as a number of
+    CPUs (None: unlimited or unreadable), and the throttling counters (periods in which the group was stopped)."""
+    quota, throttled, periods = None, None, None
+    try:
+        rel = "/"
+        for ln in open("/proc/self/cgroup"):
+            parts = ln.strip().split(":", 2)
+            if len(parts) == 3 and (parts[1] == "" or "cpu" in parts[1].split(",")):
+                rel = parts[2]
+                if parts[1] != "":
+                    break
+        for base in ("/sys/fs/cgroup" + rel, "/sys/fs/cgroup/cpu" + rel, "/sys/fs/cgroup", "/sys/fs/cgroup/cpu"):
+            if os.path.exists(base + "/cpu.max"):
+                q, per = open(base + "/cpu.max").read().split()[:2]
+                quota = None if q == "max" else float(q) / float(per)
+            elif os.path.exists(base + "/cpu.cfs_quota_us"):
+                q = float(open(base + "/cpu.cfs_quota_us").read())
+                per = float(open(base + "/cpu.cfs_period_us").read())
+                quota = None if q <= 0 else q / per
+            else:
+                continue
+            for ln in open(base + "/cpu.stat"):
+                k, v = ln.split()[:2]
+                if k == "nr_throttled":
+                    throttled = int(v)
+                if k == "nr_periods":
+                    periods = int(v)
+            break
+    except (OSError, ValueError):
+        pass
+    return {"quota_cpus": quota, "nr_throttled": throttled, "nr_periods": periods}
+
+
 def host_cpu_info():
     """CPU model, socket count and one logical CPU per physical core of socket 0 (BASELINE.md
-    section 3.3: the baseline runs pinned to the physical cores of ONE socket)."""
+    section 3.3: the baseline runs pinned to the physical cores of ONE socket); info["smt_siblings"] = the other
+    hardware threads of those cores (same order), [] where the box shows none."""
     model = "unknown"
     try:
         for ln in open("/proc/cpuinfo"):
@@ -80,9 +115,29 @@ def host_cpu_info():
             if p == min(pk):
                 first_socket.append(c)
     s0 = min(pk) if pk else 0
-    first_socket = [c for c in first_socket]   # logical CPUs, one per physical core of socket s0
+    siblings = []
+    for c in first_socket:
+        try:
+            txt = open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c).read().strip()
+        except OSError:
+            txt = ""
+        sib = []
+        for part in txt.split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                sib += list(range(int(a), int(b) + 1))
+            elif part:
+                sib.append(int(part))
+        siblings += [x for x in sib if x != c and x in allowed]
+    numa = None
+    try:
+        numa = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit()])
+    except OSError:
+        pass
     return {"model": model, "sockets": max(1, len(pk)), "logical_cpus": len(allowed),
-            "socket0_physical_cores": len(first_socket), "socket": s0}, first_socket
+            "socket0_physical_cores": len(first_socket), "socket": s0, "smt_siblings": siblings,
+            "numa_nodes": numa, "cgroup_cpu_quota": cgroup_cpu()["quota_cpus"],
+            "loadavg": (open("/proc/loadavg").read().split()[:3] if os.path.exists("/proc/loadavg") else None)}, first_socket
 
 
 def data_file(data):
@@ -94,7 +149,84 @@ def data_file(data):
     return path
 
 
-def cpu_baseline(path, nbytes, quality, lgwin, shard_size, size_hint, reps=5, other_plans=()):
+def cpu_scaling(run, path, nbytes, shard_size, cpus, smt, sample_mb=256):
+    """How the reference scales over this box's cores at the headline plan, and what it takes to make it fast: the
+    first `sample_mb` MiB of the input, oracle/plan_bench.c driven (a) at all physical cores of socket 0 with each
+    allocator / worker variant (glibc malloc — mmap + munmap of ~2.7 MiB per instance —, glibc arenas, a per-worker
+    pool behind the reference's alloc hooks, forked processes with and without the pool), (b) with the best of those at
+    1, 8, 16, 32 ... threads up to the SMT siblings.  Returns the table and the fastest configuration."""
+    cores = len(cpus)
+    n = min(nbytes, sample_mb << 20)
+    sample = path + ".scal"
+    with open(path, "rb") as f, open(sample, "wb") as g:
+        g.write(f.read(n))
+    try:
+        variants = [("malloc, threads", {}),
+                    ("glibc arenas (no mmap per block), threads", {"PLAN_BENCH_ALLOC": "arena"}),
+                    ("per-worker pool behind alloc_func, threads", {"PLAN_BENCH_ALLOC": "pool"}),
+                    ("malloc, forked processes", {"PLAN_BENCH_PROCS": "1"}),
+                    ("per-worker pool, forked processes", {"PLAN_BENCH_ALLOC": "pool", "PLAN_BENCH_PROCS": "1"})]
+        at_full = []
+
+        def throttled():
+            return cgroup_cpu()["nr_throttled"]
+        for label, env in variants:
+            th0 = throttled()
+            r = run(sample, cores, shard_size, 3, cpus, env)
+            at_full.append({"variant": label, "env": env, "threads": cores, "MBps": round(r["MBps"], 1),
+                            "seconds_all": r["seconds_all"],
+                            "cgroup_throttled_periods": None if th0 is None else throttled() - th0})
+        best_v = max(at_full, key=lambda v: v["MBps"])
+        quota = cgroup_cpu()["quota_cpus"]
+        counts = sorted(set([1] + [t for t in (8, 16, 32, 64, 128) if t < cores] + [cores] +
+                            ([int(quota)] if quota and 1 <= int(quota) < cores else [])))
+        curve = []
+        for t in counts:
+            th0 = throttled()
+            r = run(sample, t, shard_size, 1 if t == 1 else 3, cpus[:t], best_v["env"])
+            curve.append({"threads": t, "cpus": "one per physical core", "MBps": round(r["MBps"], 1), "seconds_all": r["seconds_all"],
+                          "cgroup_throttled_periods": None if th0 is None else throttled() - th0})
+        if smt:
+            both = list(cpus) + list(smt)
+            r = run(sample, len(both), shard_size, 3, both, best_v["env"])
+            curve.append({"threads": len(both), "cpus": "physical cores + their SMT siblings", "MBps": round(r["MBps"], 1)})
+        one = curve[0]["MBps"]
+        for c in curve:
+            c["x_one_thread"] = round(c["MBps"] / one, 2)
+            c["parallel_efficiency"] = round(c["MBps"] / one / min(c["threads"], cores), 3)
+        top = max(curve, key=lambda c: c["MBps"])
+        use_smt = top["cpus"].startswith("physical cores +")
+        best = {"env": best_v["env"], "variant": best_v["variant"], "threads": top["threads"],
+                "cpus": (list(cpus) + list(smt)) if use_smt else list(cpus[:top["threads"]]), "MBps_on_sample": top["MBps"]}
+        if quota and top["threads"] <= 2 * quota and quota < cores:
+            bound = ("the CPU bandwidth limit of this box's cgroup: cpu.max allows %.0f CPUs' worth of run time per period, so the "
+                     "curve is ~linear up to %d threads and flat or falling beyond (the kernel stops the group for the rest of "
+                     "each period: cgroup_throttled_periods).  It is not the reference, the allocator (variants above) or the "
+                     "partition plan that stops scaling here; a whole %d-core socket could not be measured on this box"
+                     % (quota, int(quota), cores))
+        else:
+            bound = "no cgroup CPU limit in the way: see the curve for where the reference itself stops scaling"
+        return {"sample": "first %d MiB of the input, the headline plan (%d KiB shards), oracle/plan_bench.c; the main thread "
+                          "pins itself to the CPU list before it reads the input (first touch on the workers' socket)" % (n >> 20, shard_size >> 10),
+                "cgroup_cpu_quota": quota, "bounded_by": bound,
+                "one_thread_MBps": one,
+                "whole_socket_if_scaling_held_MBps": round(one * cores * (top["MBps"] / one / min(top["threads"], cores)), 1),
+                "whole_socket_note": "one thread's rate x %d physical cores x the parallel efficiency measured at the best thread count — "
+                                     "an extrapolation, NOT a measurement (printed so that the multiple against this box's throttled "
+                                     "baseline is not mistaken for one against a full socket)" % cores,
+                "variants_at_all_physical_cores": [{k: v for k, v in a.items() if k != "env"} for a in at_full],
+                "curve_with_best_variant": curve, "best": best,
+                "malloc_threads_MBps": at_full[0]["MBps"],
+                "gain_over_round5_setting": round(top["MBps"] / at_full[0]["MBps"], 3)}
+    finally:
+        try:
+            os.unlink(sample)
+        except OSError:
+            pass
+
+
+def cpu_baseline(path, nbytes, quality, lgwin, shard_size, size_hint, reps=5, other_plans=(), scaling_study=True,
+                 bounded=False):
     """The reference encoder (oracle/_ref/libbrotli_ref.so, built from /root/reference by
     oracle/Makefile) driven by oracle/_ref/plan_bench (C, one pinned POSIX thread per physical
     core of socket 0, one encoder instance per shard) over the input file `path`: (B2) the SAME partition plan as the GPU
@@ -107,19 +239,42 @@ def cpu_baseline(path, nbytes, quality, lgwin, shard_size, size_hint, reps=5, ot
     ref_so = os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so")
     drv = os.path.join(ROOT, "oracle", "_ref", "plan_bench")
     if os.path.exists(ref_so) and os.path.exists(drv):
-        def run(src, threads, shard, nreps, pin):
+        def run(src, threads, shard, nreps, pin, mode=None):
             cmd = [drv, ref_so, src, str(quality), str(lgwin), str(shard), str(threads),
                    str(size_hint), str(nreps)]
             if pin:
                 cmd.append(",".join(str(c) for c in pin))
-            r = subprocess.run(cmd, capture_output=True, text=True, check=True)
+            env = dict(os.environ)
+            for k, v in (mode or {}).items():
+                env[k] = v
+            r = subprocess.run(cmd, capture_output=True, text=True, check=True, env=env)
             return json.loads(r.stdout.strip().splitlines()[-1])
-        run(path, cores, shard_size, 1, cpus)                      # warm-up, discarded
-        same = run(path, cores, shard_size, reps, cpus)
+        # The denominator is the FASTEST way found to drive the reference on this box: allocator,
+        # threads or processes, thread count up to the SMT siblings — measured on a bounded sample first
+        scaling = None
+        mode, threads, pin = None, cores, cpus
+        if os.environ.get("BENCH_CPU_MODE"):
+            # (a leg of `other_configs`: the configuration the headline's scaling study found fastest)
+            try:
+                m = json.loads(os.environ["BENCH_CPU_MODE"])
+                mode, threads, pin = m.get("env"), int(m["threads"]), list(m["cpus"])
+            except (ValueError, KeyError):
+                pass
+        if bounded:
+            reps, scaling_study, other_plans = 1, False, ()
+        if scaling_study and nbytes >= (64 << 20):
+            try:
+                scaling = cpu_scaling(run, path, nbytes, shard_size, cpus, info.get("smt_siblings") or [])
+                mode, threads, pin = scaling["best"]["env"], scaling["best"]["threads"], scaling["best"]["cpus"]
+            except Exception as e:
+                scaling = {"error": repr(e)[:300]}
+        if not bounded:
+            run(path, threads, shard_size, 1, pin, mode)                  # warm-up, discarded
+        same = run(path, threads, shard_size, reps, pin, mode)
         big = 8 << 20
-        best = run(path, cores, big, 3, cpus) if nbytes >= 4 * big else None
-        others = {sh: run(path, cores, sh, 3, cpus) for sh in other_plans}
-        one_n = min(nbytes, 64 << 20)
+        best = run(path, threads, big, 3 if reps > 1 else 1, pin, mode) if nbytes >= 4 * big and reps > 1 else None
+        others = {sh: run(path, threads, sh, 3, pin, mode) for sh in other_plans}
+        one_n = min(nbytes, (16 << 20) if bounded else (64 << 20))
         one_path = path + ".one"
         try:
             with open(path, "rb") as f, open(one_path, "wb") as g:
@@ -132,17 +287,26 @@ def cpu_baseline(path, nbytes, quality, lgwin, shard_size, size_hint, reps=5, ot
                 pass
         out = {
             "value": round(same["MBps"], 1), "unit": "MB/s", "cores": cores, "kind": "reference",
-            "sample": "the whole %d MiB input, same plan (%d shards of %d KiB), %d threads pinned to the "
-                      "physical cores of socket %d (oracle/plan_bench.c), median of %d runs after one "
-                      "warm-up, %.3f s, ratio %.3f" % (
-                          nbytes >> 20, same["shards"], shard_size >> 10, cores, info["socket"], reps,
-                          same["seconds"], same["bytes"] / max(1, same["out_bytes"])),
+            "threads": threads, "workers": same.get("workers"), "alloc": same.get("alloc"),
+            "sample": "the whole %d MiB input, same plan (%d shards of %d KiB), %d %s (%s) pinned to the "
+                      "physical cores%s of socket %d (oracle/plan_bench.c) — the fastest configuration of `scaling` —, "
+                      "median of %d run(s)%s, %.3f s, ratio %.3f" % (
+                          nbytes >> 20, same["shards"], shard_size >> 10, threads, same.get("workers", "threads"),
+                          same.get("alloc", "malloc"), " and their SMT siblings" if threads > cores else "", info["socket"], reps,
+                          "" if bounded else " after one warm-up", same["seconds"], same["bytes"] / max(1, same["out_bytes"])),
             "cpu": info, "seconds_all": same["seconds_all"], "sha256": same["sha256"],
             "out_bytes": same["out_bytes"],
             "single_stream_1core_MBps": round(single["MBps"], 1),
             "single_stream_ratio": round(single["bytes"] / max(1, single["out_bytes"]), 4),
             "single_stream_sample": "first %d MiB, one encoder instance, 1 thread" % (one_n >> 20),
         }
+        if scaling is not None:
+            out["scaling"] = scaling
+            if "curve_with_best_variant" in scaling:
+                one = scaling["curve_with_best_variant"][0]["MBps"]
+                out["parallel_efficiency"] = round(same["MBps"] / (one * cores), 3)
+                out["parallel_efficiency_note"] = ("whole-input rate / (one thread's rate on the sample x %d physical cores); "
+                                                   "see scaling.curve_with_best_variant for where it flattens" % cores)
         if others:
             # the reference driven with the other partition plans of config.plans[] (same cores, median of 3)
             out["other_plans"] = {str(sh >> 10): {"MBps": round(r["MBps"], 1), "sha256": r["sha256"], "out_bytes": r["out_bytes"],
@@ -462,6 +626,12 @@ def main_q1(args):
     out_b = float(nbytes)
     algo = {"ms_parse": 2.0 * n, "ms_store": 2.0 * n + out_b, "ms_place": 2.0 * out_b}[dom]
     achieved = algo / (stage[dom] / 1e3) / 1e9
+    traffic, traffic_source = None, "not measured (no PMC pass on record for this configuration)"
+    prof = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(prof):
+        t = json.load(open(prof)).get("q1/%d/%s" % (args.size_mb, args.data))
+        if t and t.get("kernel") == kernel:
+            traffic, traffic_source = t["hbm_bytes_per_launch"], "model input, not this run: " + t["source"]
     line = {
         "metric": "encode MB/s at quality 1, lgwin %d, %d MiB %s input; bit-exact vs c/enc" % (
             args.lgwin, args.size_mb, args.data),
@@ -478,29 +648,52 @@ def main_q1(args):
             "stage_ms": stage,
         },
         "roofline": {"bound": "hbm", "kernel": kernel, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                      "note": "dominant stage %s: %.3f ms per launch (HIP events on the library's stream), "
                              "algorithmic bytes %.0f per launch" % (dom, stage[dom], algo)},
     }
     emit(line)          # the headline exists: printed before anything else can go wrong (the last line is the complete one)
     if not args.no_cpu_baseline:
+        import hashlib
         from refharness import Ref, have_ref, Oracle
-        m = min(n, 256 << 20)
+        m = n if n <= (1 << 30) else (256 << 20)       # (the reference does ~0.75 GB/s at quality 1: the whole GiB is 1.4 s)
         sample = d_in[:m].cpu().numpy().tobytes() if data is None else data[:m]
         # spot check: the first 16 MiB against the oracle
         k = min(n, 16 << 20)
         nb2, _ = ctx.encode_fast_device(d_in, k, d_out, args.lgwin)
         line["config"]["spot_check_first_16MiB_bit_exact"] = \
             d_out[:nb2 // 8].cpu().numpy().tobytes() == Oracle().encode_fast(sample[:k], args.lgwin)
-        if have_ref():
+        ref_so = os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so")
+        drv = os.path.join(ROOT, "oracle", "_ref", "plan_bench")
+        if have_ref() and not calls and os.path.exists(drv):
+            # one reference instance, one FINISH call, timed inside oracle/plan_bench.c (no Python buffers in the timing)
+            path = data_file(sample)
+            try:
+                _, cpus = host_cpu_info()
+                cmd = [drv, ref_so, path, "1", str(args.lgwin), "0", "1", str(min(len(sample), 1 << 30)), "1", str(cpus[0] if cpus else 0)]
+                rr = json.loads(subprocess.run(cmd, capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+            finally:
+                os.unlink(path)
+            line["cpu_baseline"] = {"value": round(rr["MBps"], 1), "unit": "MB/s", "cores": 1, "kind": "reference",
+                                    "sample": "%s %d MiB, one reference encoder instance, one FINISH call (the reference has no "
+                                              "threads; quality 1 needs no plan: its fragments are the stream's own), %.2f s, ratio %.3f" % (
+                                                  "the whole" if m == n else "first", m >> 20, rr["seconds"], rr["bytes"] / max(1, rr["out_bytes"])),
+                                    "sha256": rr["sha256"], "out_bytes": rr["out_bytes"]}
+            if m == n:
+                nb3, _ = step()
+                got = d_out[:(nb3 + 7) // 8].cpu().numpy().tobytes()
+                line["config"]["gpu_output_sha256"] = hashlib.sha256(got).hexdigest()
+                line["config"]["parity_full_sha256_equal"] = (line["config"]["gpu_output_sha256"] == rr["sha256"] and len(got) == rr["out_bytes"])
+        elif have_ref():
             r = Ref()
+            sample = sample[:256 << 20]
             t0 = time.perf_counter()
             out = r.encode_calls(sample, 1, args.lgwin, [(len(sample), 2)])
             dtc = time.perf_counter() - t0
             line["cpu_baseline"] = {"value": round(len(sample) / 1e6 / dtc, 1), "unit": "MB/s", "cores": 1,
                                     "kind": "reference",
                                     "sample": "first %d MiB, one reference encoder instance (the reference has no "
-                                              "threads), %.2f s, ratio %.3f" % (m >> 20, dtc, len(sample) / len(out))}
+                                              "threads), %.2f s, ratio %.3f" % (len(sample) >> 20, dtc, len(sample) / len(out))}
         emit(line)
 
 
@@ -532,6 +725,60 @@ def main_all_configs(args):
         line["config_label"] = label
         print(json.dumps(line), flush=True)
     sys.exit(rc)
+
+
+OTHER_CONFIGS = [
+    # (label, extra argv, reuses the parent's text file, timeout s)
+    ("configs[2]: random bytes, quality 1, lgwin 22, one call", ["--quality", "1", "--data", "random", "--steps", "10", "--warmup", "2"], False, 120),
+    ("configs[4]: text, quality 9, lgwin 24, 512 KiB plan", ["--quality", "9", "--lgwin", "24", "--shard-kb", "512", "--steps", "3", "--warmup", "1"], True, 200),
+    ("configs[3] workload on one GPU: Silesia-style mix, quality 5, lgwin 22, 128 KiB plan", ["--workload", "silesia", "--steps", "3", "--warmup", "1"], False, 200),
+]
+
+
+def other_configs(path, size_mb, cpu_mode):
+    """BASELINE configs[2], [4] and the workload of [3] on this GPU, each a bounded child run of this script (its own
+    process, context and timeout): value, roofline, cpu_baseline (ONE run of the reference with the same plan / call on
+    the whole input, in the CPU configuration the headline's scaling study found fastest) and the whole-output sha256
+    parity.  What comes back is that run's last JSON line, cut down to the fields named."""
+    out = []
+    for label, extra, reuse, timeout_s in OTHER_CONFIGS:
+        cmd = [sys.executable, os.path.abspath(__file__), "--size-mb", str(size_mb), "--no-legs", "--bounded-baseline",
+               "--no-other-configs"] + extra + (["--input-file", path] if reuse else [])
+        env = dict(os.environ)
+        if cpu_mode:
+            env["BENCH_CPU_MODE"] = json.dumps({"env": cpu_mode.get("env"), "threads": cpu_mode.get("threads"), "cpus": cpu_mode.get("cpus")})
+        t0 = time.perf_counter()
+        text = ""
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+            text, err = r.stdout, (None if r.returncode == 0 else "child rc %d: %s" % (r.returncode, (r.stderr or "")[-300:]))
+        except subprocess.TimeoutExpired as e:
+            text = e.stdout.decode("utf-8", "replace") if isinstance(e.stdout, bytes) else (e.stdout or "")
+            err = "child not through within %d s" % timeout_s
+        except Exception as e:
+            err = repr(e)[:300]
+        lines = [ln for ln in (text or "").splitlines() if ln.startswith("{")]
+        item = {"config": label, "wall_s": round(time.perf_counter() - t0, 1)}
+        if lines:
+            d = json.loads(lines[-1])
+            c = d.get("config", {})
+            item.update({"metric": d.get("metric"), "value": d.get("value"), "unit": d.get("unit"), "steps": d.get("steps"),
+                         "ms_per_step": d.get("ms_per_step"), "dtype": d.get("dtype"), "workload": c.get("workload"),
+                         "partition_plan": c.get("partition_plan") or c.get("call_pattern"),
+                         "ratio": c.get("ratio"), "stage_ms": c.get("stage_ms"),
+                         "roofline": {k: v for k, v in (d.get("roofline") or {}).items() if k != "parse_path"},
+                         "parity_full_sha256_equal": c.get("parity_full_sha256_equal"),
+                         "gpu_output_sha256": c.get("gpu_output_sha256")})
+            cb = d.get("cpu_baseline")
+            if cb:
+                item["cpu_baseline"] = {k: cb.get(k) for k in ("value", "unit", "cores", "threads", "workers", "alloc", "kind", "sample",
+                                                                "sha256", "single_stream_1core_MBps") if k in cb}
+                if cb.get("value"):
+                    item["x_cpu_baseline"] = round(d["value"] / cb["value"], 2)
+        if err:
+            item["error"] = err
+        out.append(item)
+    return out
 
 
 class GpuJob:
@@ -668,6 +915,12 @@ def main(argv=None):
                          "size-mb MiB per GPU: 8 GiB on 8 GPUs)")
     ap.add_argument("--data", choices=["text", "random"], default="text", help="quality 1 only")
     ap.add_argument("--feed-kb", type=int, default=0, help="quality 1 only: KiB per CompressStream call (0 = one call)")
+    ap.add_argument("--input-file", default=None, help="read the input from this file instead of generating it (the legs of "
+                    "`other_configs` reuse the parent's text)")
+    ap.add_argument("--bounded-baseline", action="store_true", help="cpu_baseline with one run of the same plan and no "
+                    "scaling study (the legs of `other_configs`)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the bounded legs for BASELINE configs[2], [4] and "
+                    "[3]'s workload (`other_configs` of the last line)")
     ap.add_argument("--all-configs", action="store_true",
                     help="one line per single-GPU BASELINE configuration (configs[1], [2], [4], and [3]'s workload on one "
                          "GPU), each with the reference timed beside it on this box's host cores")
@@ -691,7 +944,10 @@ def main(argv=None):
     shard = args.shard_kb << 10
     total = n * world
     size_hint = min(total, 1 << 30)
-    data = G.enwik_text(n, seed=G.SEED + rank) if args.workload == "text" else G.mixed_corpus(n, seed=G.SEED + rank)
+    if args.input_file and os.path.exists(args.input_file) and os.path.getsize(args.input_file) == n and world == 1:
+        data = open(args.input_file, "rb").read()
+    else:
+        data = G.enwik_text(n, seed=G.SEED + rank) if args.workload == "text" else G.mixed_corpus(n, seed=G.SEED + rank)
     job.load(data, args.quality, args.lgwin, shard, size_hint)
 
     for _ in range(args.warmup):
@@ -727,7 +983,8 @@ def main(argv=None):
         traffic, traffic_source = None, "not measured (no PMC pass on record for this configuration)"
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
-            t = json.load(open(prof)).get("%d/%d" % (args.size_mb, args.shard_kb) + ("" if args.workload == "text" else "/silesia"))
+            t = json.load(open(prof)).get(("" if args.quality == 5 else "q%d/" % args.quality) + "%d/%d" % (args.size_mb, args.shard_kb) +
+                                          ("" if args.workload == "text" else "/silesia"))
             if t and t.get("kernel") == kernel:
                 traffic, traffic_source = t["hbm_bytes_per_launch"], "model input, not this run: " + t["source"]
         path_ms = ms_index + ms_parse
@@ -796,7 +1053,9 @@ def main(argv=None):
                       "ms_per_step": round(ms_step, 3), "ratio": round(total / out_total, 4), "compressed_bytes": out_total,
                       "sha256": cfg["gpu_output_sha256"], "headline": True}]
             other_kb = []
-            if args.quality == 5 and args.workload == "text" and args.shard_kb in (128, 1024):
+            if args.bounded_baseline:
+                pass
+            elif args.quality == 5 and args.workload == "text" and args.shard_kb in (128, 1024):
                 other_kb = [1024 if args.shard_kb == 128 else 128]
             elif args.quality == 9 and args.shard_kb in (384, 512):
                 other_kb = [512 if args.shard_kb == 384 else 384]       # (both plans, not the kinder one)
@@ -811,7 +1070,8 @@ def main(argv=None):
             path = data_file(data)
             try:
                 cb = cpu_baseline(path, len(data), args.quality, args.lgwin, shard, size_hint,
-                                  other_plans=[p["shard_KiB"] << 10 for p in plans[1:] if "error" not in p])
+                                  other_plans=[p["shard_KiB"] << 10 for p in plans[1:] if "error" not in p],
+                                  bounded=args.bounded_baseline)
                 line["cpu_baseline"] = cb
                 for pl in plans:
                     ref = ({"MBps": cb["value"], "sha256": cb.get("sha256"), "out_bytes": cb.get("out_bytes"),
@@ -822,6 +1082,10 @@ def main(argv=None):
                         pl["reference_seconds_all"] = ref.get("seconds_all")
                         pl["x_reference_same_plan"] = round(pl["MBps"] / ref["MBps"], 2)     # (GPU mean of K steps / CPU median)
                         pl["sha256_equal_reference"] = ref.get("sha256") == pl["sha256"] and ref.get("out_bytes") == pl["compressed_bytes"]
+                        ws = (cb.get("scaling") or {}).get("whole_socket_if_scaling_held_MBps")
+                        if ws and pl.get("headline"):
+                            # (an extrapolated denominator — cpu_baseline.scaling.whole_socket_note — beside the measured one)
+                            pl["x_whole_socket_extrapolated"] = round(pl["MBps"] / ws, 2)
                 # the reference encoded the WHOLE input with the same plan in this
                 # run; its concatenated output must be the GPU's, byte for byte
                 if "sha256" in cb:
@@ -840,8 +1104,13 @@ def main(argv=None):
                         sc["whole_input"] = run_leg("stock_whole", path, args.quality, args.lgwin)
                         sc["process_fed_256MiB"] = run_leg("process_fed", path, args.quality, args.lgwin, 1024, 256)
                     cfg["stock_call_no_plan"] = sc
-                    line["line"] = "3 of 3: complete"
+                    line["line"] = "3 of 4: the legs of the headline configuration (other_configs follows)" if not args.no_other_configs else "3 of 3: complete"
                     emit(line)
+                    if not args.no_other_configs and args.quality == 5 and args.workload == "text":
+                        mode = (cb.get("scaling") or {}).get("best")
+                        line["other_configs"] = other_configs(path, args.size_mb, mode)
+                        line["line"] = "4 of 4: complete"
+                        emit(line)
             finally:
                 try:
                     os.unlink(path)

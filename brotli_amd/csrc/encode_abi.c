@@ -51,6 +51,12 @@ struct BrotliEncoderStateStruct {
   /* one FLUSH / FINISH call that brings its whole input and has room for the output: the job
      reads the caller's input and writes the caller's output (no staging copies on the host) */
   int tail_finish;       /* this FINISH brought no input and what PROCESS calls brought before ends on an input-block boundary */
+  int empty_finish;      /* this FINISH brought no input while bytes of earlier PROCESS calls are still held here */
+  /* the boundary's BROTLI_AMD_* knobs, read once when the instance is created (not with getenv() per call) */
+  long env_feed_kb;      /* BROTLI_AMD_FEED_KB, -1: not set */
+  long env_hold_mb;      /* BROTLI_AMD_HOLD_MB, -1: not set */
+  int env_stream_tiles;  /* BROTLI_AMD_STREAM_TILES, -1: not set */
+  int env_verbose;       /* BROTLI_AMD_VERBOSE set */
   uint8_t* direct_out;
   size_t direct_cap, direct_n;
   uint8_t* out_buf;
@@ -93,7 +99,6 @@ static int grow(BrotliEncoderState* s, uint8_t** buf, size_t* cap, size_t used, 
   *cap = c;
   return 1;
 }
-static int verbose(void) { return getenv("BROTLI_AMD_VERBOSE") != NULL; }
 
 static void tables_path(char* out, size_t cap) {
   const char* env = getenv("BROTLI_AMD_TABLES");
@@ -157,6 +162,13 @@ BrotliEncoderState* BrotliEncoderCreateInstance(brotli_amd_alloc_func alloc_func
   if (e) s->shard_bytes = strtoull(e, NULL, 10) << 10;
   e = getenv("BROTLI_AMD_DEVICE");
   if (e) s->device = atoi(e);
+  e = getenv("BROTLI_AMD_FEED_KB");
+  s->env_feed_kb = e ? (long)strtoull(e, NULL, 10) : -1;
+  e = getenv("BROTLI_AMD_HOLD_MB");
+  s->env_hold_mb = e ? (long)strtoull(e, NULL, 10) : -1;
+  e = getenv("BROTLI_AMD_STREAM_TILES");
+  s->env_stream_tiles = e ? atoi(e) : -1;
+  s->env_verbose = getenv("BROTLI_AMD_VERBOSE") != NULL;
   return s;
 }
 
@@ -232,7 +244,7 @@ static int ensure_initialized(BrotliEncoderState* s) {
     s->failed = 1;
   }
   if (s->failed) {
-    if (verbose())
+    if (s->env_verbose)
       fprintf(stderr, "brotli_amd: parameters outside the GPU path (quality %d, lgwin %d); "
                       "no CPU fallback exists\n", s->quality, s->lgwin);
     return 0;
@@ -241,7 +253,7 @@ static int ensure_initialized(BrotliEncoderState* s) {
   s->ctx = pool_take(s->device);
   if (!s->ctx && brotli_amd_ctx_create(s->device, path, &s->ctx) != BROTLI_AMD_OK) {
     s->failed = 1;
-    if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+    if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
     return 0;
   }
   /* a pooled context may still carry its previous user's dictionaries */
@@ -338,7 +350,7 @@ static int submit_fast(BrotliEncoderState* s, int op) {
     dst = s->out_buf + s->out_len;
     if (brotli_amd_encode_fast_host(s->ctx, s->in_buf, s->in_len, s->calls, s->ncalls, &p, dst, cap,
                                     &nbits, &info) != BROTLI_AMD_OK) {
-      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
       return 0;
     }
     nbytes = (size_t)(nbits >> 3);
@@ -368,13 +380,15 @@ static int submit_serial(BrotliEncoderState* s, int op) {
   const uint8_t* out;
   uint64_t out_len;
   if (!open_stream(s)) {
-    if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+    if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
     return 0;
   }
-  if (s->tail_finish && op == OP_FINISH && s->in_len != 0) {
-    /* the complete blocks as the PROCESS calls they came in (encoded with is_last = 0), then the empty FINISH */
+  if (s->empty_finish && op == OP_FINISH && s->in_len != 0) {
+    /* what the caller did: the held bytes as the PROCESS calls they came in — the reference encodes every block they
+       complete with is_last = 0 (encode.c:1700-1712), counted from the last flush, i.e. over submitted + in_len, not over
+       what happens to be held here — then the empty FINISH (which takes an incomplete last block with it) */
     if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_PROCESS, &out, &out_len) != BROTLI_AMD_OK) {
-      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
       return 0;
     }
     s->submitted += s->in_len;
@@ -383,7 +397,7 @@ static int submit_serial(BrotliEncoderState* s, int op) {
     if (!out_append(s, out, (size_t)out_len)) return 0;
   }
   if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, op, &out, &out_len) != BROTLI_AMD_OK) {
-    if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+    if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
     return 0;
   }
   s->submitted += s->in_len;
@@ -408,8 +422,7 @@ static int metablock_may_close(const BrotliEncoderState* s, size_t n) {
    CLI on a big file): the tiled stream path of the HIP layer (BROTLI_AMD_FLAG_STREAM_TILES; k_tile.h) parses all its
    input blocks at once.  BROTLI_AMD_STREAM_TILES=0 keeps such streams on the serial device stream. */
 static int wants_stream_tiles(const BrotliEncoderState* s, int op) {
-  const char* e = getenv("BROTLI_AMD_STREAM_TILES");
-  if (e && atoi(e) == 0) return 0;
+  if (s->env_stream_tiles == 0) return 0;
   return s->quality == 5 && s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream && s->ndicts == 0 &&
          s->stream_offset == 0 && eff_lgblock(s) == 16 &&
          s->lgwin >= 17 && s->lgwin <= 22 && s->in_len > ((size_t)1 << s->lgwin) - 16 && s->in_len < ((size_t)1 << 31);
@@ -493,7 +506,7 @@ static int submit(BrotliEncoderState* s, int op) {
       }
       if (rc == BROTLI_AMD_SERIAL) return submit_serial(s, op);
       if (rc != BROTLI_AMD_OVERFLOW) {
-        if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+        if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
         return 0;
       }
       n = 0;
@@ -503,7 +516,7 @@ static int submit(BrotliEncoderState* s, int op) {
       const int rc = brotli_amd_encode_host(s->ctx, s->in_buf, s->in_len, &p, s->out_buf + s->out_len, cap, &n, &info);
       if (rc == BROTLI_AMD_SERIAL) return submit_serial(s, op);
       if (rc != BROTLI_AMD_OK) {
-        if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+        if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
         return 0;
       }
     }
@@ -521,8 +534,8 @@ static int submit(BrotliEncoderState* s, int op) {
    size from the last flush either way, so the bytes do not depend on when a shard is submitted.
    One encoder instance: the device stream takes input with BROTLI_AMD_OP_PROCESS. */
 static size_t feed_threshold(const BrotliEncoderState* s) {
-  const char* e = getenv("BROTLI_AMD_FEED_KB");       /* default: 256 MiB of shards / 4 MiB of one stream */
-  size_t kb = e ? (size_t)strtoull(e, NULL, 10) : (s->shard_bytes ? (256u << 10) : (4u << 10));
+  const int e = s->env_feed_kb >= 0;                   /* default: 256 MiB of shards / 4 MiB of one stream */
+  size_t kb = e ? (size_t)s->env_feed_kb : (s->shard_bytes ? (256u << 10) : (4u << 10));
   if (!e && s->shard_bytes == 0 && s->quality == 5 && s->lgwin >= 17 && s->lgwin <= 22 && s->ndicts == 0 &&
       !s->stream && s->submitted == 0 && s->stream_offset == 0 && eff_lgblock(s) == 16) {
     /* One quality-5 stream fed with PROCESS calls (the CLI, Compressor.process of the Python module): the input is held
@@ -532,11 +545,12 @@ static size_t feed_threshold(const BrotliEncoderState* s) {
        Announced (BROTLI_PARAM_SIZE_HINT: the CLI does that for files): held up to the announced size; not announced:
        up to BROTLI_AMD_HOLD_MB (default 1024; 0 = never hold).  A FLUSH, or input beyond that, goes to the serial
        stream as before. */
-    const char* h = getenv("BROTLI_AMD_HOLD_MB");
-    const char* t = getenv("BROTLI_AMD_STREAM_TILES");
-    const size_t cap_mb = h ? (size_t)strtoull(h, NULL, 10) : 1024u;
-    if (!(t && atoi(t) == 0) && cap_mb != 0) {
-      if (s->size_hint == 0) return cap_mb << 20;
+    const size_t cap_mb = s->env_hold_mb >= 0 ? (size_t)s->env_hold_mb : 1024u;
+    /* (a stream nobody announced a size for — a pipe — is held up to a quarter of that: output starts to flow, and host
+        memory stays bounded, sooner) */
+    const size_t cap_unannounced = s->env_hold_mb >= 0 ? cap_mb : 256u;
+    if (s->env_stream_tiles != 0 && cap_mb != 0) {
+      if (s->size_hint == 0) return cap_unannounced << 20;
       if (((size_t)s->size_hint >> 20) < cap_mb) return (size_t)s->size_hint + 1u;
     }
   }
@@ -550,7 +564,7 @@ static int forward_pending_input(BrotliEncoderState* s, int force) {
     uint64_t out_len;
     if (!open_stream(s)) return 0;
     if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_PROCESS, &out, &out_len) != BROTLI_AMD_OK) {
-      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
       return 0;
     }
     s->submitted += s->in_len;
@@ -579,7 +593,7 @@ static int forward_pending_input(BrotliEncoderState* s, int force) {
     if (s->out_pos == s->out_len) s->out_pos = s->out_len = 0;
     if (!grow(s, &s->out_buf, &s->out_cap, s->out_len, s->out_len + cap)) return 0;
     if (brotli_amd_encode_host(s->ctx, s->in_buf, whole, &p, s->out_buf + s->out_len, cap, &n, &info) != BROTLI_AMD_OK) {
-      if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+      if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
       return 0;
     }
     s->out_len += (size_t)n;
@@ -626,7 +640,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
     size_t hb, i;
     const int single5 = s->quality >= 2 && s->quality <= 9 && s->shard_bytes == 0;
     if (s->quality != 1 && !single5) {
-      if (verbose()) fprintf(stderr, "brotli_amd: BROTLI_OPERATION_EMIT_METADATA needs quality 1 or an "
+      if (s->env_verbose) fprintf(stderr, "brotli_amd: BROTLI_OPERATION_EMIT_METADATA needs quality 1 or an "
                                      "unpartitioned quality-5 stream\n");
       return BROTLI_FALSE;
     }
@@ -657,7 +671,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
         if (!open_stream(s)) { s->failed = 1; return BROTLI_FALSE; }
         if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_FLUSH_OPEN, &o, &on) != BROTLI_AMD_OK ||
             brotli_amd_stream_take_partial(s->stream, &s->carry_bits, &s->carry_value) != BROTLI_AMD_OK) {
-          if (verbose()) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+          if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
           s->failed = 1;
           return BROTLI_FALSE;
         }
@@ -776,10 +790,14 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
          stream ends there: a FINISH that brings nothing then finds the last block done with is_last = 0 (submit). */
       /* (behind a stream offset the two "flint" bytes are a block of their own, encode.c:1686-1694: no arithmetic here —
           such a stream goes to the serial device stream call by call, metablock_may_close) */
-      s->tail_finish = op == OP_FINISH && a == 0 && s->in_len != 0 &&
+      /* (tail_finish chooses between the one-shard / tiled job and the serial stream, where nothing was submitted yet and
+          in_len is the whole stream; the serial stream itself replays the calls whatever the alignment: empty_finish) */
+      s->empty_finish = op == OP_FINISH && a == 0 && s->in_len != 0;
+      s->tail_finish = s->empty_finish &&
                        (s->stream_offset != 0 || (s->in_len & (((size_t)1 << eff_lgblock(s)) - 1u)) == 0);
       if (!submit(s, op)) { s->failed = 1; return BROTLI_FALSE; }
       s->tail_finish = 0;
+      s->empty_finish = 0;
       s->stream_state = op == OP_FINISH ? ST_FINISHED : ST_FLUSH_REQUESTED;
     } else if (!forward_pending_input(s, 0)) {
       s->failed = 1;

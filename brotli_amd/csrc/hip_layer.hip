@@ -14,11 +14,51 @@
 #include <chrono>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 #include "../../include/brotli_amd_hip.h"
 #include "host_plan.h"
 #include "kernels.h"
+
+// The BROTLI_AMD_* experiment knobs of this layer, read when a context is created (and by brotli_amd_refresh_env, for
+// tools and tests that flip one between jobs) instead of with getenv() on the launch path of every job: a library that
+// promises re-entrancy must not race a caller's setenv() there.
+struct EnvKnobs {
+  bool plain_copy = false, ix_debug = false, index_only = false, tile_log = false;
+  int copy_threads = 0;          // 0: the default (4)
+  int indexed = -1;              // -1: not set
+  uint32_t ix_bpw = 0;           // 0: the planner's choice
+  int tile_kb = -1, tile_warm = -1, cgroups = -1, sweep_groups = 0, decode_variant = -1;
+  long wide_kb = 0;              // 0: not set
+  int wide = -1;
+  int wide_k = 0;
+  int tile_log_level = 0;
+};
+static EnvKnobs g_env;
+static std::mutex g_env_mutex;
+static int env_int(const char* name, int unset) { const char* e = getenv(name); return e ? atoi(e) : unset; }
+static void env_read() {
+  std::lock_guard<std::mutex> lock(g_env_mutex);
+  EnvKnobs k;
+  k.plain_copy = getenv("BROTLI_AMD_PLAIN_COPY") != nullptr;
+  k.ix_debug = getenv("BROTLI_AMD_IX_DEBUG") != nullptr;
+  k.index_only = getenv("BROTLI_AMD_INDEX_ONLY") != nullptr;
+  k.tile_log = getenv("BROTLI_AMD_TILE_LOG") != nullptr;
+  k.tile_log_level = env_int("BROTLI_AMD_TILE_LOG", 0);
+  k.copy_threads = env_int("BROTLI_AMD_COPY_THREADS", 0);
+  k.indexed = env_int("BROTLI_AMD_INDEXED", -1);
+  k.ix_bpw = (uint32_t)env_int("BROTLI_AMD_IX_BPW", 0);
+  k.tile_kb = env_int("BROTLI_AMD_TILE_KB", -1);
+  k.tile_warm = env_int("BROTLI_AMD_TILE_WARM", -1);
+  k.cgroups = env_int("BROTLI_AMD_CGROUPS", -1);
+  k.sweep_groups = env_int("BROTLI_AMD_SWEEP_GROUPS", 0);
+  k.decode_variant = env_int("BROTLI_AMD_DECODE_VARIANT", -1);
+  if (const char* e = getenv("BROTLI_AMD_WIDE_KB")) k.wide_kb = atol(e);
+  k.wide = env_int("BROTLI_AMD_WIDE", -1);
+  k.wide_k = env_int("BROTLI_AMD_WIDE_K", 0);
+  g_env = k;
+}
 
 struct BrotliAmdCtx {
   int device = 0;
@@ -97,11 +137,11 @@ struct BrotliAmdCtx {
 static const uint64_t PIN_CHUNK = 8ull << 20;
 static bool big_copy(BrotliAmdCtx* c, uint8_t* dst, const uint8_t* src, uint64_t len, bool to_device) {
   if (len == 0) return true;
-  if (len < 2 * PIN_CHUNK || getenv("BROTLI_AMD_PLAIN_COPY") != nullptr)
+  if (len < 2 * PIN_CHUNK || g_env.plain_copy)
     return hipMemcpy(dst, src, len, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost) == hipSuccess;
   if (c->lanes.empty()) {
     int T = 4;
-    if (const char* e = getenv("BROTLI_AMD_COPY_THREADS")) { const int v = atoi(e); if (v >= 1 && v <= 16) T = v; }
+    if (g_env.copy_threads >= 1 && g_env.copy_threads <= 16) T = g_env.copy_threads;
     std::vector<BrotliAmdCtx::CopyLane> lanes((size_t)T);
     bool ok = true;
     for (auto& l : lanes) {
@@ -339,11 +379,10 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
   // Quality 5 on shards that fit the window: the position index + table-free chain.
   c->ix_region_bytes = 0;
   if ((plan->J.flags & JOB_FLAG_QUAD) && !(api_flags & BROTLI_AMD_FLAG_NO_INDEX)) {
-    const char* e = getenv("BROTLI_AMD_INDEXED");
-    if (!e || atoi(e) != 0) {
+    if (g_env.indexed != 0) {
       c->ix_region_bytes = plan_add_index(plan, /*ix_in_ws=*/false);
-      if (const char* b = getenv("BROTLI_AMD_IX_BPW")) {          // experiment knob: 1, 2, 4, 8
-        const uint32_t v = (uint32_t)atoi(b);
+      {                                                             // experiment knob: 1, 2, 4, 8
+        const uint32_t v = g_env.ix_bpw;
         if (v == 1 || v == 2 || v == 4 || v == 8) plan->J.ix_bpw = v;
       }
       plan->J.flags &= ~(uint32_t)JOB_FLAG_DUO;
@@ -353,8 +392,8 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
       // (profiles/r03_n_tile_size.txt): parse 40.1 ms with 64 KiB tiles, 43.4 with 128 KiB; 512 … 2048 bytes of warm-up
       // within 0.3 ms of each other.
       uint32_t tile_kb = 64, tile_warm = 2048;
-      if (const char* e = getenv("BROTLI_AMD_TILE_KB")) tile_kb = (uint32_t)atoi(e);
-      if (const char* e = getenv("BROTLI_AMD_TILE_WARM")) tile_warm = (uint32_t)atoi(e);
+      if (g_env.tile_kb >= 0) tile_kb = (uint32_t)g_env.tile_kb;
+      if (g_env.tile_warm >= 0) tile_warm = (uint32_t)g_env.tile_warm;
       if (tile_kb != 0 && !(api_flags & BROTLI_AMD_FLAG_FORCE_SLOW)) plan_add_tiles(plan, tile_kb, tile_warm);
       // shards per wave of k_chain: one 16-lane group per shard, as many waves as stay resident
       const uint64_t resident = (uint64_t)c->num_cus * 4u * CHAIN_WAVES;
@@ -363,7 +402,7 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
       // wave win as soon as there are enough shards to give every SIMD a wave
       (void)resident;
       uint32_t v = ns >= 1024 ? 4u : ns >= 512 ? 2u : 1u;
-      if (const char* g = getenv("BROTLI_AMD_CGROUPS")) v = (uint32_t)atoi(g);
+      if (g_env.cgroups >= 0) v = (uint32_t)g_env.cgroups;
       plan->J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
       if (v == 1 || v == 2) plan->J.flags |= v << JOB_FLAG_GROUPS_SHIFT;
     }
@@ -400,12 +439,12 @@ struct HipRun {
 uint32_t use_wide(const JobParams& J, uint64_t longest) {
   bool wide = J.quality >= 5;
   uint64_t bound = 512u << 10;
-  if (const char* e = getenv("BROTLI_AMD_WIDE_KB")) { const long v = atol(e); if (v > 0 && v <= (1 << 20)) bound = (uint64_t)v << 10; }
+  if (g_env.wide_kb > 0 && g_env.wide_kb <= (1 << 20)) bound = (uint64_t)g_env.wide_kb << 10;
   wide = wide && longest >= bound;
-  if (const char* e = getenv("BROTLI_AMD_WIDE")) wide = atoi(e) != 0;
+  if (g_env.wide >= 0) wide = g_env.wide != 0;
   if (!wide) return 0u;
   uint64_t k = (longest + (32u << 10) - 1u) / (32u << 10);
-  if (const char* e = getenv("BROTLI_AMD_WIDE_K")) { const int v = atoi(e); if (v >= 1) k = (uint64_t)v; }
+  if (g_env.wide_k >= 1) k = (uint64_t)g_env.wide_k;
   return k < 1u ? 1u : k > WIDE_K_MAX ? WIDE_K_MAX : (uint32_t)k;
 }
 
@@ -470,7 +509,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     HIP_OK(c, hipEventRecord(c->ev_ixb, c->stream));
     hipLaunchKernelGGL(k_ix_bucket, dim3(ix_bucket_grid(plan.J, (uint32_t)nshards)), dim3(64), 0, c->stream, a);
     hipLaunchKernelGGL(k_ix_big, dim3(IX_BIG_GRID), dim3(64), 0, c->stream, a);
-    if (getenv("BROTLI_AMD_IX_DEBUG")) {     // diagnostics: the lists' header (records per XCD, cursors, buckets placed twice)
+    if (g_env.ix_debug) {     // diagnostics: the lists' header (records per XCD, cursors, buckets placed twice)
       uint32_t hdr[18];
       (void)hipStreamSynchronize(c->stream);
       (void)hipMemcpy(hdr, c->d_ws + plan.J.big_off, sizeof(hdr), hipMemcpyDeviceToHost);
@@ -493,7 +532,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
     }
 #endif
     HIP_OK(c, hipEventRecord(c->ev_ix, c->stream));
-    if (getenv("BROTLI_AMD_INDEX_ONLY")) {   // timing experiments: stop after the index kernels
+    if (g_env.index_only) {   // timing experiments: stop after the index kernels
       HIP_OK(c, hipStreamSynchronize(c->stream));
       if (info) {
         HIP_OK(c, hipEventElapsedTime(&ms_index, c->ev[1], c->ev_ix)); info->ms_index = ms_index;
@@ -527,7 +566,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
       // the tiles' parses, then verify / events / sweep until nothing is pending (k_tile.h)
       const dim3 cgrid((ntiles + gpw - 1) / gpw);
       const uint32_t clds = gpw * C_GROUP_LDS_WORDS * 4u;
-      const bool tlog = getenv("BROTLI_AMD_TILE_LOG") != nullptr;
+      const bool tlog = g_env.tile_log;
       double t_prev = 0;                           // (this job's own: contexts on other threads log independently)
       auto lap = [&](const char* what) {           // (diagnostics: wall time per stage, with a sync each)
         if (!tlog) return;
@@ -578,7 +617,7 @@ bool run_rounds(BrotliAmdCtx* c, JobPlan& plan, const uint8_t* d_in, int stages,
         // a sweep is a few hundred dependent steps per tile around its events: few tiles per wave, so that a tile
         // does not wait for the steps of three others (BROTLI_AMD_SWEEP_GROUPS: 1, 2 or 4 tiles per wave)
         uint32_t sg = 2;        // (measured, profiles/r03_e: 1 GiB text in 1 MiB shards: sweep 23 / 17 ms with 1 / 2 tiles per wave)
-        if (const char* e = getenv("BROTLI_AMD_SWEEP_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) sg = (uint32_t)v; }
+        { const int v = g_env.sweep_groups; if (v == 1 || v == 2 || v == 4) sg = (uint32_t)v; }
         b.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
         if (sg != 4) b.J.flags |= sg << JOB_FLAG_GROUPS_SHIFT;
         hipLaunchKernelGGL(k_chain_sweep, dim3((ntiles + sg - 1) / sg), dim3(64), sg * C_GROUP_LDS_WORDS * 4u, c->stream, b);
@@ -678,7 +717,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
                     uint64_t out_cap, uint64_t* out_size, BrotliAmdJobInfo* info, int* rc) {
   JobPlan plan;
   uint32_t warm = 2048;
-  if (const char* e = getenv("BROTLI_AMD_TILE_WARM")) warm = (uint32_t)atoi(e);
+  if (g_env.tile_warm >= 0) warm = (uint32_t)g_env.tile_warm;
   uint64_t region = 0;
   if (!plan_stream(len, p->lgwin, p->size_hint, warm, /*ix_in_ws=*/false, &plan, &region)) { *rc = BROTLI_AMD_SERIAL; return true; }
   if (p->flags & BROTLI_AMD_FLAG_NO_LITERAL_CONTEXT) plan.J.flags |= JOB_FLAG_NO_LITCTX;
@@ -761,9 +800,8 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
   a.moff = c->d_moff;
   a.sout = d_out;
   a.mcap = mcap;
-  const char* tlog_env = getenv("BROTLI_AMD_TILE_LOG");
-  const bool tlog = tlog_env != nullptr;
-  const bool tlog_each = tlog && atoi(tlog_env) >= 2;     // 2: synchronize and report behind every launch (names a faulting kernel)
+  const bool tlog = g_env.tile_log;
+  const bool tlog_each = tlog && g_env.tile_log_level >= 2;     // 2: synchronize and report behind every launch (names a faulting kernel)
   double t_prev = 0;
   auto each = [&](const char* what) {
     if (!tlog_each) return;
@@ -868,7 +906,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     JobArgs b = a;
     b.J.flags |= JOB_FLAG_SWEEP;
     uint32_t sg = 2;
-    if (const char* e = getenv("BROTLI_AMD_SWEEP_GROUPS")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) sg = (uint32_t)v; }
+    { const int v = g_env.sweep_groups; if (v == 1 || v == 2 || v == 4) sg = (uint32_t)v; }
     b.J.flags &= ~(3u << JOB_FLAG_GROUPS_SHIFT);
     if (sg != 4) b.J.flags |= sg << JOB_FLAG_GROUPS_SHIFT;
     hipLaunchKernelGGL(k_chain_sweep, dim3((ntiles + sg - 1) / sg), dim3(64), sg * C_GROUP_LDS_WORDS * 4u, c->stream, b); each("k_chain_sweep");
@@ -968,10 +1006,13 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
 
 extern "C" {
 
+void brotli_amd_refresh_env(void) { env_read(); }
+
 int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** out) {
   *out = nullptr;
   BrotliAmdCtx* c = new BrotliAmdCtx();
   *out = c;   // returned even on failure so the caller can read the error
+  env_read();
   c->device = device;
   c->tables_path = tables_path;
   if (!host_tables_load(tables_path, &c->ht)) {
@@ -1147,7 +1188,7 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
   };
   // (Encoding a plan in batches while the next batch travels was measured and dropped: the chain
   // kernel takes as long for 1024 shards as for 8192, so every batch pays the whole latency.)
-  const bool hlog = getenv("BROTLI_AMD_TILE_LOG") != nullptr;       // host-side laps of the call, next to the device stages
+  const bool hlog = g_env.tile_log;       // host-side laps of the call, next to the device stages
   auto now = []() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   if (!stage()) return BROTLI_AMD_ERROR;
@@ -1621,7 +1662,7 @@ int brotli_amd_decode_device(BrotliAmdCtx* c, const void* d_in, uint64_t in_len,
     a.npieces = (uint32_t)npieces;
     // measurement switches (tools/gpu_decode_variants.py): BROTLI_AMD_DECODE_VARIANT = waves per SIMD (4 / 8),
     // + 16 = no LDS cache
-    const int variant = getenv("BROTLI_AMD_DECODE_VARIANT") ? atoi(getenv("BROTLI_AMD_DECODE_VARIANT")) : DECODE_WAVES;
+    const int variant = g_env.decode_variant >= 0 ? g_env.decode_variant : DECODE_WAVES;
     a.flags = (variant & 16) ? DEC_ARG_NO_LDS_CACHE : 0u;
     a.pad = 0;
     HIP_OK(c, hipEventRecord(c->ev[0], c->stream));

@@ -96,7 +96,9 @@ DEV void bits_entropy_wave(const uint32_t* const* a, const uint32_t* const* g, u
   const int lane = wave_lane();
   if ((uint32_t)lane < ne) sums[lane] = 0;
   wave_sync();
-  for (uint32_t e = 0; e < ne; ++e) {
+#pragma unroll
+  for (uint32_t e = 0; e < 3u; ++e) {          // (ne <= 3; unrolled: a[] / g[] stay in registers)
+    if (e >= ne) break;
     uint32_t part = 0;
     for (uint32_t k = (uint32_t)lane; k < n; k += 64) {
       const uint32_t p = (a[e] ? a[e][k] : 0u) + (g[e] ? g[e][k] : 0u);

@@ -67,8 +67,17 @@ DEV uint32_t dict_prefix32(const DB32& a, const DB32& b) {
 // readable behind), cur_masked = position & ring mask, dc = the four last distances,
 // max_ring_distance = the `dictionary_start` of the call site, max_distance = params->dist.max_distance.
 // Only the hashers with a compound variant call this (backward_references.c:194-243).
+// (The distance cache comes as four VALUES: indexed by the lane through a pointer it pinned the caller's whole shard
+//  state in scratch memory — k_parse4.h, q_dc_entry.)
+DEV int32_t dict_dc_pick(int32_t d0, int32_t d1, int32_t d2, int32_t d3, int i) {
+  int32_t d = d3;
+  d = i == 2 ? d2 : d;
+  d = i == 1 ? d1 : d;
+  d = i == 0 ? d0 : d;
+  return d;
+}
 DEV void compound_lookup(const CompoundDict* cd, const uint8_t* cur, uint32_t cur_masked, uint32_t ring_mask,
-                         const int32_t* dc, uint32_t max_length, uint32_t max_ring_distance,
+                         int32_t dc0, int32_t dc1, int32_t dc2, int32_t dc3, uint32_t max_length, uint32_t max_ring_distance,
                          uint32_t max_distance, SearchResult& out) {
   const int lane = wave_lane();
   DB32 cur32;
@@ -90,8 +99,9 @@ DEV void compound_lookup(const CompoundDict* cd, const uint8_t* cur, uint32_t cu
     if (lane < 32) {
       if ((uint32_t)lane < n_items) { offset = ch.items[s0 + (uint32_t)lane]; cand = true; }
     } else if (lane < 36) {
-      const uint32_t distance = (uint32_t)dc[lane - 32];
-      if (dc[lane - 32] > 0 && distance > boundary && distance <= distance_offset) {
+      const int32_t dcl = dict_dc_pick(dc0, dc1, dc2, dc3, lane - 32);
+      const uint32_t distance = (uint32_t)dcl;
+      if (dcl > 0 && distance > boundary && distance <= distance_offset) {
         offset = distance_offset - distance;
         cand = offset < source_size;
       }
@@ -144,7 +154,7 @@ DEV void compound_lookup(const CompoundDict* cd, const uint8_t* cur, uint32_t cu
       if (len_i > best_len) best_len = len_i;
       out.len = len_i;
       out.len_code_delta = 0;
-      out.distance = (uint32_t)dc[i];
+      out.distance = (uint32_t)dict_dc_pick(dc0, dc1, dc2, dc3, i);
       out.score = best_score;
     }
     if (best_len < 3) best_len = 3;

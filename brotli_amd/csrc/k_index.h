@@ -166,6 +166,9 @@ DEV void ix_count(const JobParams& J, const ShardDesc& D, const uint8_t* input, 
   uint32_t* skip = (uint32_t*)bm.skip;
   const uint32_t w_lo = lo / 32u, w_hi = (umin(lo + per, g.len + 128u) + 31u) / 32u;
   for (uint32_t i = w_lo + (uint32_t)lane; i < w_hi; i += 64u) skip[i] = 0;
+#if defined(IX_RES4X)
+  if (IX_RES4X == 3) { uint32_t* r4 = (uint32_t*)(base + L.res); for (uint32_t i = lo + (uint32_t)lane; i < hi; i += 64u) r4[i] = 0; }
+#endif
   if (g.stream) {
     // the chunk's key table (k_tile.h): every slice clears its share
     const uint32_t cj = g.ownc == 0u ? 0u : (g.base >> J.chunk_log2) + 1u;
@@ -428,6 +431,10 @@ DEV uint32_t ix_prepare(const IxGeom& g, const IxLds& S, uint32_t x, bool act, u
   if (mask == 0u) {
 #if defined(IX_NTRES)     // (experiment: streaming stores)
     __builtin_nontemporal_store(ix_res_word(search && danger ? IX_KIND_SLOW : IX_KIND_NONE, 0u, 0u, sidx, word), &res[p]);
+#elif defined(IX_RES4X)    // (timing experiments only: results are wrong)
+    { const uint64_t v_ = ix_res_word(search && danger ? IX_KIND_SLOW : IX_KIND_NONE, 0u, 0u, sidx, word);
+      if (IX_RES4X != 3 || rank > 16u) ((uint32_t*)res)[p] = (uint32_t)v_;
+      if (IX_RES4X >= 6) ((uint16_t*)((uint32_t*)res + g.len))[p] = (uint16_t)(v_ >> 32); }
 #elif defined(IX_NORES)    // (timing experiments only: results are wrong)
     { const uint64_t v_ = ix_res_word(search && danger ? IX_KIND_SLOW : IX_KIND_NONE, 0u, 0u, sidx, word); if ((uint32_t)v_ == 0x12345u) res[p] = v_; }
 #else
@@ -596,6 +603,10 @@ DEV void ix_search_block(const IxGeom& g, const uint8_t* data, const IxLds& S, u
       }
 #if defined(IX_NTRES)
       __builtin_nontemporal_store(ix_res_word(kind, len, dist, sbase + x, word), &res[p]);
+#elif defined(IX_RES4X)       // (timing experiments only: results are wrong)
+      { const uint64_t v_ = ix_res_word(kind, len, dist, sbase + x, word);
+        if (IX_RES4X != 3 || kind != IX_KIND_NONE || !(word & IXW_FULLRUN)) ((uint32_t*)res)[p] = (uint32_t)v_;
+        if (IX_RES4X >= 6) ((uint16_t*)((uint32_t*)res + g.len))[p] = (uint16_t)(v_ >> 32); }
 #elif defined(IX_NORES)       // (timing experiments only: results are wrong)
       { const uint64_t v_ = ix_res_word(kind, len, dist, sbase + x, word); if ((uint32_t)v_ == 0x12345u) res[p] = v_; }
 #else

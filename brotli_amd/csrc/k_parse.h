@@ -85,8 +85,10 @@ DEV uint32_t common_prefix32(const B32& a, const B32& b) {
 
 // hash.h:80-100: the derived entries of the distance cache.
 DEV int32_t dist_cache_entry(const ParseCtx& c, int i) {
-  if (i < 4) return c.dc[i];
-  const int base = i < 10 ? c.dc[0] : c.dc[1];
+  // (values, not c.dc[i]: an index through the member's address keeps the whole ParseCtx in scratch memory — k_parse4.h, q_dc_entry)
+  const int32_t d0 = c.dc[0], d1 = c.dc[1], d2 = c.dc[2], d3 = c.dc[3];
+  if (i < 4) { int32_t d = d3; d = i == 2 ? d2 : d; d = i == 1 ? d1 : d; d = i == 0 ? d0 : d; return d; }
+  const int base = i < 10 ? d0 : d1;
   const int k = (i < 10 ? i - 4 : i - 10);
   const int mag = (k >> 1) + 1;
   return (k & 1) ? base + mag : base - mag;
@@ -368,7 +370,7 @@ DEV SearchResult search_pair(ParseCtx& c, uint32_t posA, PendingB& B) {
   insert_searched(c, posA, keyA, tagA, tag2A, numA);
   const uint32_t dictionary_start = umin(posA + c.stream_offset, c.max_backward_limit);
   if (ra.score == K_MIN_SCORE) dict_search(c, posA, c.pos_end - posA, dictionary_start + c.gap, ra);
-  if (c.cd) compound_lookup(c.cd, c.data + posA, posA & c.ring_mask, c.ring_mask, c.dc, c.pos_end - posA,
+  if (c.cd) compound_lookup(c.cd, c.data + posA, posA & c.ring_mask, c.ring_mask, c.dc[0], c.dc[1], c.dc[2], c.dc[3], c.pos_end - posA,
                             dictionary_start, K_DIST_MAX_DISTANCE, ra);
   return ra;
 }
@@ -379,7 +381,7 @@ DEV SearchResult finalize_b(ParseCtx& c, PendingB& B) {
   insert_searched(c, B.pos, B.key, B.tag, B.tag2, B.num);
   const uint32_t dictionary_start = umin(B.pos + c.stream_offset, c.max_backward_limit);
   if (r.score == K_MIN_SCORE) dict_search(c, B.pos, c.pos_end - B.pos, dictionary_start + c.gap, r);
-  if (c.cd) compound_lookup(c.cd, c.data + B.pos, B.pos & c.ring_mask, c.ring_mask, c.dc, c.pos_end - B.pos,
+  if (c.cd) compound_lookup(c.cd, c.data + B.pos, B.pos & c.ring_mask, c.ring_mask, c.dc[0], c.dc[1], c.dc[2], c.dc[3], c.pos_end - B.pos,
                             dictionary_start, K_DIST_MAX_DISTANCE, r);
   B.valid = false;
   return r;

@@ -171,8 +171,18 @@ DEV uint32_t q_ring_byte(const QShard& g, uint32_t x) {
   return g.pos_end > g.ring_mask ? g.data[x - g.ring_mask - 1u] : 0u;
 }
 
+// (The four entries are read first and the choice is made between VALUES: with a load in every arm of the conditional
+//  the optimizer forms a load through a phi of pointers into the shard state, which then cannot be kept in registers —
+//  the whole QShard lived in scratch memory in k_parse_deep and k_parse_quick until round 6: .private_segment_fixed_size
+//  464, every read of g.position a round trip, half a terabyte of scratch writes per GiB at quality 9,
+//  profiles/r06_pmc_q9_before.txt.)
 DEV uint32_t q_dc_entry(const QShard& g, int i) {
-  return (uint32_t)(i == 0 ? g.dc[0] : i == 1 ? g.dc[1] : i == 2 ? g.dc[2] : g.dc[3]);
+  const uint32_t d0 = (uint32_t)g.dc[0], d1 = (uint32_t)g.dc[1], d2 = (uint32_t)g.dc[2], d3 = (uint32_t)g.dc[3];
+  uint32_t d = d3;
+  d = i == 2 ? d2 : d;
+  d = i == 1 ? d1 : d;
+  d = i == 0 ? d0 : d;
+  return d;
 }
 
 // Match length of data[a..] and data[b..] beyond the first 32 bytes
@@ -406,7 +416,7 @@ DEV void q_compound_lookup(const JobParams& J, const QShard& g, uint32_t P, uint
   if (!g.cd) return;
   SearchResult sr;
   sr.len = r.len; sr.distance = r.distance; sr.score = r.score; sr.len_code_delta = r.delta;
-  compound_lookup(g.cd, g.data + P, P & J.ring_mask, J.ring_mask, g.dc, max_length,
+  compound_lookup(g.cd, g.data + P, P & J.ring_mask, J.ring_mask, g.dc[0], g.dc[1], g.dc[2], g.dc[3], max_length,
                   umin(P + g.stream_offset, J.max_backward_limit), K_DIST_MAX_DISTANCE, sr);
   r.len = sr.len; r.distance = sr.distance; r.score = sr.score; r.delta = sr.len_code_delta;
 }

@@ -35,16 +35,11 @@
 
 #define D_DUP_SLOTS 4096u
 
-DEV uint32_t d_max(uint32_t v) {   // maximum over the 64 lanes, in every lane
-  v = q_max(v);
-  const int lane = wave_lane();
-  uint32_t o = wave_shfl(v, lane ^ 16);
-  v = o > v ? o : v;
-  o = wave_shfl(v, lane ^ 32);
-  v = o > v ? o : v;
-  return v;
-}
-DEV uint32_t d_from(uint32_t v, int src) { return wave_shfl(v, src); }
+// Maximum over the 64 lanes, in every lane: DPP row reductions + four readlanes (wave.h).  (Until round 6 a 16-lane
+// reduction + two ds_bpermute round trips: seven of them were 15 % of a search — profiles/r06_c_q9_phases.txt.)
+DEV uint32_t d_max(uint32_t v) { return wave_max_u32(v); }
+// Value of lane `src` (wave-uniform) in every lane: one readlane.
+DEV uint32_t d_from(uint32_t v, int src) { return wave_bcast(v, src); }
 
 // hash.h:80-100: the sixteen entries of the prepared distance cache.
 DEV uint32_t d_dc_entry(const QShard& g, int i) {
@@ -186,28 +181,59 @@ DEV QResult d_resolve_slow(const JobParams& J, const DeepGeom& G, const QShard& 
   return r;
 }
 
+// The next search's bytes (and, -DDEEP_PREFETCH=2, its bucket counter and record), requested at the END of this search —
+// behind this search's own loads, which come back in order, and behind the insertion of P, so that the record is
+// current — and used when the next search is at P + 1: four of five are (no match: the next literal; a match: the lazy
+// probe, backward_references_inc.h:122-160).  A search is three dependent round trips — bytes at P -> key -> counter +
+// record -> candidate strings.  A StoreRange / the spree's stores in between drop the prefetch.
+// (Round 6 first requested everything at the START of the search: no gain — the wait moved from the record to the
+//  candidate strings, profiles/r06_d_q9_phases_prefetch.txt.)
+#ifndef DEEP_PREFETCH
+#define DEEP_PREFETCH 1
+#endif
+#define D_PF_NONE 0xFFFFFFFFu
 template <int E>
-DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* T, QShard& g, uint32_t P) {
+struct DeepPf { uint32_t pos, key, num; uint64_t ent[E]; B32 cur; };
+
+template <int E>
+DEV void d_fetch_record(const DeepGeom& G, const QShard& g, uint32_t key, uint32_t& num, uint64_t (&ent)[E]) {
+  const int lane = wave_lane();
+  const uint8_t* mine = g.table + (size_t)key * G.rec_bytes + (uint32_t)lane * (8u * (uint32_t)E);
+  const bool in_rec = (uint32_t)lane < G.slots;        // quality 6: 32 slots, upper lanes idle
+  num = g.nums[key];
+#pragma unroll
+  for (int k = 0; k < E; ++k) ent[k] = in_rec ? ld64(mine + 8 * k) : 0ull;
+}
+
+template <int E>
+DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* T, QShard& g, uint32_t P, DeepPf<E>& pf) {
   const int lane = wave_lane();
   const int ndist = J.ndist;
+  uint64_t qt = QP_NOW();
   const uint32_t max_length = g.pos_end - P;
   const uint32_t max_backward = umin(P, J.max_backward_limit);
-  const B32 cur32 = load_b32(g.data + P);
+  const bool ahead = DEEP_PREFETCH >= 1 && pf.pos == P;  // (wave-uniform)
+  B32 cur32;
+  if (ahead) cur32 = pf.cur; else cur32 = load_b32(g.data + P);
   // distance-cache probes: independent of the hash table, requested first
   const uint32_t backward = d_dc_entry(g, lane & 15);
   const bool d_cand = lane < ndist && (int32_t)backward > 0 && backward <= max_backward;
   const uint32_t d_prev = P - backward;
   const B32 pd = load_b32(g.data + (d_cand ? d_prev : P));
   const KeyTag kt = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits);
-  const uint8_t* rec = g.table + (size_t)kt.key * G.rec_bytes;
-  const uint32_t num = g.nums[kt.key];
+  uint32_t num;
   uint64_t ent[E];
-  {
-    const uint8_t* mine = rec + (uint32_t)lane * (8u * (uint32_t)E);
-    const bool in_rec = (uint32_t)lane < G.slots;      // quality 6: 32 slots, upper lanes idle
+  if (DEEP_PREFETCH >= 2 && ahead) {
+    num = pf.num;
 #pragma unroll
-    for (int k = 0; k < E; ++k) ent[k] = in_rec ? ld64(mine + 8 * k) : 0ull;
+    for (int k = 0; k < E; ++k) ent[k] = pf.ent[k];
+  } else {
+    d_fetch_record<E>(G, g, kt.key, num, ent);
   }
+#if defined(Q_PROFILE)
+  if (ent[0] == 0x123456789ull) g.status |= 0x40000000u;     // (profiling: waits for the record before the lap)
+#endif
+  QP_ADD(g, 0, qt);                                          // bytes at P -> key -> counter + record
   // visible slots and scan order (newest first)
   uint32_t visible;
   if (G.tagged) {
@@ -250,6 +276,7 @@ DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* 
     for (int k = 0; k < E; ++k)
       if (b_cand[k] && b_len[k] == 32u && max_length > 32u) b_len[k] = q_extend(g.data, P, b_prev[k], max_length);
   }
+  QP_ADD(g, 1, qt);                                          // candidate strings, lengths, extensions
   // scores (hash.h:123-138)
   uint32_t d_score = 135u * d_len + 1935u;
   if (lane != 0) d_score -= 39u + ((0x1CA10u >> ((uint32_t)lane & 0xEu)) & 0xEu);
@@ -259,7 +286,10 @@ DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* 
   const uint32_t d_best = d_max(d_key);
   const bool d_win = d_key != 0 && d_key == d_best;
   const uint32_t dc_len = d_best >> 5;
-  const uint32_t dc_score = d_best ? d_max(d_win ? d_score : 0u) : K_MIN_SCORE;
+  // (the winner's score from its length and lane: no second reduction)
+  const uint32_t d_wl = 31u - (d_best & 31u);
+  uint32_t dc_score = K_MIN_SCORE;
+  if (d_best) { dc_score = 135u * dc_len + 1935u; if (d_wl != 0) dc_score -= 39u + ((0x1CA10u >> (d_wl & 0xEu)) & 0xEu); }
   const uint32_t dc_len3 = dc_len < 3u ? 3u : dc_len;
   // block-end edge: another cache candidate as long as the winner and reaching
   // the end of the block can be let through the gate by the byte past the block
@@ -274,7 +304,7 @@ DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* 
     const uint32_t key = ok ? (b_score[k] << 9) | (511u - b_logical[k]) : 0u;
     if (key > my_key) { my_key = key; my_len = b_len[k]; my_dist = P - b_prev[k]; }
   }
-  {
+  if (g.pos_end > J.ring_mask) {      // (a stream as long as its ring buffer: nothing below can trigger before that)
     // a candidate that sits within a match length of the physical end of the ring may be skipped
     // by the reference (it does not follow matches across that end): rare, resolved step by step
     uint32_t longest = d_cand ? d_len : 0u;
@@ -294,22 +324,26 @@ DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* 
   const uint32_t b_best_score = best >> 9;
   QResult r;
   if (best != 0 && b_best_score > dc_score && b_best_score > K_MIN_SCORE) {
-    const bool win = my_key == best;
-    r.len = d_max(win ? my_len : 0u);
-    r.distance = d_max(win ? my_dist : 0u);
+    // the winner's lane from its place in the scan (the key's low bits): two readlanes instead of two reductions
+    const uint32_t logical = 511u - (best & 511u);
+    const int wl = (int)(((G.tagged ? (num + 1u + logical) : (num - 1u - logical)) & G.mask) & 63u);
+    r.len = d_from(my_len, wl);
+    r.distance = d_from(my_dist, wl);
     r.score = b_best_score;
   } else if (d_best != 0) {
     r.len = dc_len;
-    r.distance = d_max(d_win ? backward : 0u);
+    r.distance = d_from(backward, (int)d_wl);
     r.score = dc_score;
   } else {
     r.len = 0; r.distance = 0; r.score = K_MIN_SCORE;
   }
   r.delta = 0;
+  QP_ADD(g, 2, qt);                                          // scores, reductions
   if (slow) {
     r = d_resolve_slow<E>(J, G, g, P, max_length, num, visible, d_cand, d_len, d_prev, d_score,
                           b_cand, b_len, b_prev, b_score);
   }
+  QP_ADD(g, 3, qt);                                          // step-by-step resolve
   // insert P
   {
     const uint32_t ts = num & G.mask;
@@ -319,9 +353,21 @@ DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* 
       g.nums[kt.key] = (uint16_t)(G.tagged ? num - 1u : num + 1u);
     }
   }
+  // the search after this one, most likely: P + 1
+  pf.pos = D_PF_NONE;
+  if (DEEP_PREFETCH >= 1 && P + 1u < g.pos_end) {
+    pf.pos = P + 1u;
+    pf.cur = load_b32(g.data + P + 1u);
+    if (DEEP_PREFETCH >= 2) {
+      pf.key = hash_pos((cur32.q[0] >> 8) | (cur32.q[1] << 56), J.hasher_type, J.bucket_bits).key;
+      d_fetch_record<E>(G, g, pf.key, pf.num, pf.ent);
+    }
+  }
   wave_sync();
+  QP_ADD(g, 4, qt);                                          // insert
   q_dict_search(J, T, g, r.score == K_MIN_SCORE, P, max_length, r);
   q_compound_lookup(J, g, P, max_length, r);
+  QP_ADD(g, 5, qt);                                          // dictionaries
   return r;
 }
 
@@ -420,10 +466,15 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
   g.pf_val = g.pf_acc = 0;
   g.role = 0;
   g.state = Q_PRE;
+  for (int i = 0; i < 12; ++i) g.prof[i] = 0;
+  uint64_t dt = QP_NOW();
+  DeepPf<E> pf;
+  pf.pos = D_PF_NONE;
 
   while (g.state != Q_DONE) {       // all state is wave-uniform here
+    QP_ADD(g, 8, dt);                                        // driver
     if (g.state == Q_PRE) q_driver_pre(J, g);
-    if (g.state == Q_SETUP) d_setup_block<E>(J, G, g, lds_dup);
+    if (g.state == Q_SETUP) { d_setup_block<E>(J, G, g, lds_dup); pf.pos = D_PF_NONE; }
     if (g.state == Q_SEARCH && !(g.position + htl < g.pos_end)) {
       g.insert_length += g.pos_end - g.position;
       g.r.last_insert_len = g.insert_length;
@@ -431,7 +482,9 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     }
     if (g.state == Q_SEARCH || g.state == Q_LAZY) {
       const uint32_t P = g.position + (g.state == Q_LAZY ? 1u : 0u);
-      const QResult cur = d_search<E>(J, G, T, g, P);
+      dt = QP_NOW();
+      const QResult cur = d_search<E>(J, G, T, g, P, pf);
+      dt = QP_NOW();
       g.stat_searches++;
       bool commit = false;
       if (g.state == Q_SEARCH) {
@@ -493,7 +546,10 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
         g.insert_length = 0;
         g.position += g.sr_len;
       }
+      QP_ADD(g, 6, dt);                                      // decide + commit
+      if (g.st_count != 0) pf.pos = D_PF_NONE;               // (a StoreRange / the spree's stores: the prefetched record may be theirs)
       d_drain_stores<E>(J, G, g, lds_dup);
+      QP_ADD(g, 7, dt);                                      // StoreRange
     }
     if (g.state == Q_POST) q_driver_post(J, g, writer);
   }
@@ -516,6 +572,9 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
     }
     S->stat_searches += g.stat_searches;
     S->stat_pairs += g.stat_searches;
+#if defined(Q_PROFILE)
+    for (int i = 0; i < 12; ++i) S->prof[i] += g.prof[i];
+#endif
   }
   wave_sync();
 }

@@ -135,6 +135,19 @@ static __device__ const uint32_t k_copy_base[24] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 
 static __device__ const uint8_t k_copy_extra[24] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 2, 2, 3, 3,
     4, 4, 5, 5, 6, 7, 8, 9, 10, 24};
 
+// Element i (0 .. 2, not a compile-time constant: a lane's own category, a job number) of a three-element member of
+// StoreCtx / StoreMeta, chosen between VALUES: an index through the member's address keeps the whole struct — and
+// through StoreCtx::J the kernel's arguments — in scratch memory (k_store had .private_segment_fixed_size 1160 until
+// round 6; the same story as q_dc_entry, k_parse4.h).
+template <class T>
+DEV T sel3(const T (&a)[3], uint32_t i) {
+  const T v0 = dev_opaque(a[0]), v1 = dev_opaque(a[1]), v2 = dev_opaque(a[2]);
+  T r = v2;
+  r = i == 1u ? v1 : r;
+  r = i == 0u ? v0 : r;
+  return r;
+}
+
 struct StoreCtx {
   const JobParams* J;
   const uint8_t* data;
@@ -322,6 +335,7 @@ DEV void store_ctx_init(StoreCtx& s, StoreMeta& M, const JobParams& J, const Sha
   s.lsum = (uint32_t*)(ws + D.scratch_off + ((uint64_t)mb_cap / 256u + 64u) * 8u);
   s.lcode = s.lsum + (mb_cap + 16u);
   s.nc = s.info->num_contexts;
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
     s.types[c] = s.mb + s.L.types[c];
     s.lengths[c] = (const uint32_t*)(s.mb + s.L.lengths[c]);
@@ -346,11 +360,14 @@ DEV void store_small_histos(StoreCtx& s, const StoreMeta& M, uint32_t* lds_store
   cmap_nrle = 0; cmap_max_prefix = 0;
   if (lane < 3) {
     const int c = lane;
-    for (uint32_t i = 0; i < M.ntypes[c] + 2; ++i) sc->type_histo[c][i] = 0;
+    const uint32_t ntypes_c = sel3(M.ntypes, (uint32_t)c), nblocks_c = sel3(M.nblocks, (uint32_t)c);
+    const uint8_t* types_c = sel3(s.types, (uint32_t)c);
+    const uint32_t* lengths_c = sel3(s.lengths, (uint32_t)c);
+    for (uint32_t i = 0; i < ntypes_c + 2; ++i) sc->type_histo[c][i] = 0;
     for (uint32_t i = 0; i < 26; ++i) sc->len_histo[c][i] = 0;
-    for (uint32_t b = 0; b < M.nblocks[c]; ++b) {
-      if (b != 0) ++sc->type_histo[c][block_type_code(s.types[c], b)];
-      ++sc->len_histo[c][block_length_prefix_code(s.lengths[c][b])];
+    for (uint32_t b = 0; b < nblocks_c; ++b) {
+      if (b != 0) ++sc->type_histo[c][block_type_code(types_c, b)];
+      ++sc->len_histo[c][block_length_prefix_code(lengths_c[b])];
     }
   } else if (lane == 3 || lane == 4) {
     // Trivial context maps (:794-830): literal (only when nc == 1), distance.
@@ -389,11 +406,11 @@ DEV void store_code_job(StoreCtx& s, const StoreMeta& M, uint32_t j, uint32_t cm
   bool skip = false;
   if (j < 3) {
     histo = sc->type_histo[j]; depth = sc->type_depth[j]; bits = sc->type_bits[j];
-    length = M.ntypes[j] + 2; skip = M.ntypes[j] <= 1;
+    length = sel3(M.ntypes, j) + 2; skip = sel3(M.ntypes, j) <= 1;
   } else if (j < 6) {
     const uint32_t c = j - 3;
     histo = sc->len_histo[c]; depth = sc->len_depth[c]; bits = sc->len_bits[c];
-    length = 26; skip = M.ntypes[c] <= 1;
+    length = 26; skip = sel3(M.ntypes, c) <= 1;
   } else if (j == 6) {
     histo = sc->cmap_histo[0]; depth = sc->cmap_depth[0]; bits = sc->cmap_bits[0];
     length = lit_cmap_alpha; skip = M.nhist[0] <= 1;
@@ -404,10 +421,11 @@ DEV void store_code_job(StoreCtx& s, const StoreMeta& M, uint32_t j, uint32_t cm
     uint32_t h = j - 8;
     int c = 0;
     if (h >= M.nhist[0]) { h -= M.nhist[0]; c = 1; if (h >= M.nhist[1]) { h -= M.nhist[1]; c = 2; } }
-    histo = (const uint32_t*)(s.mb + s.L.histos[c]) + (size_t)h * alpha[c];
-    depth = (uint8_t*)(s.mb + s.L.depths[c]) + (size_t)h * alpha[c];
-    bits = (uint16_t*)(s.mb + s.L.bits[c]) + (size_t)h * alpha[c];
-    length = alpha[c];
+    const uint32_t alpha_c = c == 0 ? 256u : c == 1 ? 704u : 64u;
+    histo = (const uint32_t*)(s.mb + sel3(s.L.histos, (uint32_t)c)) + (size_t)h * alpha_c;
+    depth = (uint8_t*)(s.mb + sel3(s.L.depths, (uint32_t)c)) + (size_t)h * alpha_c;
+    bits = (uint16_t*)(s.mb + sel3(s.L.bits, (uint32_t)c)) + (size_t)h * alpha_c;
+    length = alpha_c;
   }
   uint32_t nb = 0;
   if (!skip && J.quality == 2 && j >= 8) {
@@ -443,6 +461,7 @@ DEV void store_code_job(StoreCtx& s, const StoreMeta& M, uint32_t j, uint32_t cm
 DEV void store_switch_codes(StoreCtx& s, const StoreMeta& M) {
   const int lane = wave_lane();
   SmallCodes* sc = s.small;
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
     for (uint32_t b = (uint32_t)lane; b < M.nblocks[c]; b += 64) {
       uint64_t v = 0;
@@ -484,6 +503,7 @@ DEV void store_header(StoreCtx& s, const StoreMeta& M, BitSink& sink, uint32_t l
     sink_put(sink, mnibbles * 4u, bytes - 1u);
     if (!is_last) sink_put(sink, 1, 0);
   }
+#pragma unroll
   for (int c = 0; c < 3; ++c) {
     sink_varlen_uint8(sink, M.ntypes[c] - 1u);
     if (M.ntypes[c] > 1) {

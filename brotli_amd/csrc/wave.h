@@ -177,4 +177,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 
 #define DEV __device__ __forceinline__
 
+// The value x, in a form the optimizer cannot look through (an empty asm statement that "modifies" it; nothing on the
+// simulator).  Used where a choice between LOADED values must stay a choice between values: the optimizer otherwise
+// folds select(load a[1], load a[2]) into a load through a computed address, and a struct that is indexed through a
+// computed address cannot be kept in registers (k_store.h, sel3).
+#if defined(BROTLI_AMD_SIMT_SIM)
+template <class T> static inline T dev_opaque(T x) { return x; }
+#else
+template <class T> __device__ __forceinline__ T dev_opaque(T x) { asm volatile("" : "+v"(x)); return x; }
+#endif
+
 #endif  // BROTLI_AMD_CSRC_WAVE_H_

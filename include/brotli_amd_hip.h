@@ -100,6 +100,10 @@ typedef struct BrotliAmdJobInfo {
 
 /* `tables_path`: brotli_amd/data/brotli_tables.bin (RFC 7932 format data). */
 int brotli_amd_ctx_create(int device, const char* tables_path, BrotliAmdCtx** ctx);
+/* The BROTLI_AMD_* experiment knobs of the device layer (tile size, index / chain layouts, logging ...) are read from
+   the environment when a context is created, not on the launch path of a job; a tool or test that changes one between
+   two jobs of a living context calls this to have them read again.  Not for use beside running jobs. */
+void brotli_amd_refresh_env(void);
 void brotli_amd_ctx_destroy(BrotliAmdCtx* ctx);
 const char* brotli_amd_last_error(const BrotliAmdCtx* ctx);
 

@@ -10,16 +10,33 @@
  *
  *   plan_bench <libbrotli_ref.so> <input file> <quality> <lgwin> <shard_size>
  *              <threads> [size_hint [reps [cpu,cpu,...]]]
+ *
+ * What is tried to make the baseline as fast as the box allows — environment:
+ *   PLAN_BENCH_ALLOC=pool   every worker hands the reference's alloc_func / free_func hooks
+ *                           (c/include/brotli/encode.h:289-307) a private pool that keeps freed blocks by size: an
+ *                           instance per shard allocates the same ~2.7 MiB (hash table, ring buffer, command buffer)
+ *                           every time, which glibc serves with mmap + page faults + munmap — and every munmap of a
+ *                           64-thread process interrupts the other 63 cores (TLB shootdown);
+ *   PLAN_BENCH_ALLOC=arena  glibc tuned instead (M_MMAP_THRESHOLD / M_TRIM_THRESHOLD raised: blocks stay in the
+ *                           per-thread arenas);
+ *   PLAN_BENCH_PROCS=1      the workers are forked processes (one address space each: no shared mmap lock, no
+ *                           cross-core TLB shootdowns), sizes and bytes through shared memory;
+ *   the main thread pins itself to the CPU list before it allocates and reads the input, so the input's pages are
+ *   first touched on the workers' socket (NUMA-local).
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <malloc.h>
 #include <pthread.h>
 #include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <sys/wait.h>
 #include <time.h>
+#include <unistd.h>
 
 typedef void* (*create_fn)(void*, void*, void*);
 typedef void (*destroy_fn)(void*);
@@ -37,10 +54,39 @@ static const uint8_t* g_in;
 static size_t g_len, g_shard, g_nshards;
 static int g_quality, g_lgwin;
 static uint32_t g_hint;
-static volatile size_t g_next;
+static volatile size_t* g_next;   /* (shared memory: the forked workers take shards from the same counter) */
 static uint64_t* g_sizes;
 static uint8_t** g_outs;      /* per-shard compressed bytes of the last repetition */
+static uint8_t* g_shm_out;    /* PLAN_BENCH_PROCS: shard k's bytes at k * g_shm_stride */
+static size_t g_shm_stride;
 static int g_cpus[1024], g_ncpus;
+static int g_pool, g_procs;
+
+/* ---- PLAN_BENCH_ALLOC=pool: a worker's private allocator behind the reference's hooks ------- */
+typedef struct PoolBlock { size_t size; struct PoolBlock* next; } PoolBlock;
+typedef struct { PoolBlock* free_list; } Pool;
+static void* pool_alloc(void* opaque, size_t size) {
+  Pool* P = (Pool*)opaque;
+  PoolBlock** pp = &P->free_list;
+  PoolBlock* b;
+  for (; *pp; pp = &(*pp)->next)
+    if ((*pp)->size == size) { b = *pp; *pp = b->next; return (void*)(b + 1); }
+  b = (PoolBlock*)malloc(sizeof(PoolBlock) + size);
+  if (!b) return NULL;
+  b->size = size;
+  return (void*)(b + 1);
+}
+static void pool_free(void* opaque, void* ptr) {
+  Pool* P = (Pool*)opaque;
+  PoolBlock* b;
+  if (!ptr) return;
+  b = (PoolBlock*)ptr - 1;
+  b->next = P->free_list;
+  P->free_list = b;
+}
+static void pool_release(Pool* P) {
+  while (P->free_list) { PoolBlock* b = P->free_list; P->free_list = b->next; free(b); }
+}
 
 /* ---- sha256 (FIPS 180-4), for the whole-output parity check --------------- */
 typedef struct { uint32_t h[8]; uint8_t buf[64]; uint64_t n; } Sha;
@@ -101,6 +147,7 @@ static void* worker(void* arg) {
   uint8_t* out = NULL;
   size_t cap = 0;
   const long tid = (long)arg;
+  Pool pool = {NULL};
   if (g_ncpus) {
     cpu_set_t set;
     CPU_ZERO(&set);
@@ -108,7 +155,7 @@ static void* worker(void* arg) {
     pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
   }
   for (;;) {
-    size_t k = __sync_fetch_and_add(&g_next, 1);
+    size_t k = __sync_fetch_and_add(g_next, 1);
     size_t off, n, avail_in, avail_out, total = 0;
     const uint8_t* next_in;
     uint8_t* next_out;
@@ -118,7 +165,7 @@ static void* worker(void* arg) {
     off = k * g_shard;
     n = g_len - off < g_shard ? g_len - off : g_shard;
     if (cap < 2 * n + 1024) { cap = 2 * n + 1024; out = (uint8_t*)realloc(out, cap); }
-    st = Create(NULL, NULL, NULL);
+    st = g_pool ? Create((void*)pool_alloc, (void*)pool_free, &pool) : Create(NULL, NULL, NULL);
     SetParameter(st, 1 /* QUALITY */, (uint32_t)g_quality);
     SetParameter(st, 2 /* LGWIN */, (uint32_t)g_lgwin);
     SetParameter(st, 5 /* SIZE_HINT */, g_hint);
@@ -133,11 +180,15 @@ static void* worker(void* arg) {
     } while (avail_in || HasMoreOutput(st));
     g_sizes[k] = total;
     /* keep the bytes for the output hash (outside the hot loop of the encoder) */
-    g_outs[k] = (uint8_t*)realloc(g_outs[k], total ? total : 1);
-    memcpy(g_outs[k], out, total);
+    if (g_shm_out) memcpy(g_shm_out + k * g_shm_stride, out, total);
+    else {
+      g_outs[k] = (uint8_t*)realloc(g_outs[k], total ? total : 1);
+      memcpy(g_outs[k], out, total);
+    }
     Destroy(st);
   }
   free(out);
+  pool_release(&pool);
   return NULL;
 }
 
@@ -158,7 +209,28 @@ int main(int argc, char** argv) {
   double times[64], sorted[64], median;
   char hex[65];
   Sha sha;
+  const char* alloc_mode = getenv("PLAN_BENCH_ALLOC");
   if (argc < 7) { fprintf(stderr, "usage: see source\n"); return 1; }
+  g_pool = alloc_mode && strcmp(alloc_mode, "pool") == 0;
+  g_procs = getenv("PLAN_BENCH_PROCS") && atoi(getenv("PLAN_BENCH_PROCS")) != 0;
+  if (alloc_mode && strcmp(alloc_mode, "arena") == 0) {
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_TOP_PAD, 64 << 20);
+  }
+  if (argc > 9) {
+    /* the CPU list first: the main thread moves there before it touches the input's pages */
+    char* c = argv[9];
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    while (*c && g_ncpus < 1024) {
+      g_cpus[g_ncpus] = (int)strtol(c, &c, 10);
+      CPU_SET(g_cpus[g_ncpus], &set);
+      ++g_ncpus;
+      if (*c == ',') ++c;
+    }
+    if (g_ncpus) sched_setaffinity(0, sizeof(set), &set);
+  }
   lib = dlopen(argv[1], RTLD_NOW);
   if (!lib) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
   Create = (create_fn)dlsym(lib, "BrotliEncoderCreateInstance");
@@ -187,22 +259,37 @@ int main(int argc, char** argv) {
   reps = argc > 8 ? atoi(argv[8]) : 1;
   if (reps < 1) reps = 1;
   if (reps > 64) reps = 64;
-  if (argc > 9) {
-    char* s = argv[9];
-    while (*s && g_ncpus < 1024) {
-      g_cpus[g_ncpus++] = (int)strtol(s, &s, 10);
-      if (*s == ',') ++s;
-    }
-  }
   g_nshards = (g_len + g_shard - 1) / g_shard;
-  g_sizes = (uint64_t*)calloc(g_nshards, 8);
+  if (g_procs) {
+    /* counter, sizes and output bytes where forked workers and the parent both see them */
+    g_shm_stride = 2 * g_shard + 1024;
+    g_next = (volatile size_t*)mmap(NULL, 4096 + g_nshards * 8, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    g_shm_out = (uint8_t*)mmap(NULL, g_nshards * g_shm_stride, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+    if (g_next == MAP_FAILED || g_shm_out == MAP_FAILED) { perror("mmap"); return 1; }
+    g_sizes = (uint64_t*)((uint8_t*)g_next + 4096);
+  } else {
+    g_next = (volatile size_t*)calloc(1, sizeof(size_t));
+    g_sizes = (uint64_t*)calloc(g_nshards, 8);
+  }
   g_outs = (uint8_t**)calloc(g_nshards, sizeof(uint8_t*));
   th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
   for (r = 0; r < reps; ++r) {
-    g_next = 0;
+    *g_next = 0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (i = 0; i < threads; ++i) pthread_create(&th[i], NULL, worker, (void*)(long)i);
-    for (i = 0; i < threads; ++i) pthread_join(th[i], NULL);
+    if (g_procs) {
+      for (i = 0; i < threads; ++i) {
+        const pid_t pid = fork();
+        if (pid < 0) { perror("fork"); return 1; }
+        if (pid == 0) { worker((void*)(long)i); _exit(0); }
+      }
+      for (i = 0; i < threads; ++i) {
+        int st = 0;
+        if (wait(&st) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) { fprintf(stderr, "a worker process failed\n"); return 2; }
+      }
+    } else {
+      for (i = 0; i < threads; ++i) pthread_create(&th[i], NULL, worker, (void*)(long)i);
+      for (i = 0; i < threads; ++i) pthread_join(th[i], NULL);
+    }
     clock_gettime(CLOCK_MONOTONIC, &t1);
     times[r] = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
   }
@@ -210,10 +297,14 @@ int main(int argc, char** argv) {
   qsort(sorted, (size_t)reps, sizeof(double), cmp_double);
   median = (reps & 1) ? sorted[reps / 2] : 0.5 * (sorted[reps / 2 - 1] + sorted[reps / 2]);
   sha_init(&sha);
-  for (k = 0; k < g_nshards; ++k) { out_total += g_sizes[k]; sha_update(&sha, g_outs[k], g_sizes[k]); }
+  for (k = 0; k < g_nshards; ++k) {
+    out_total += g_sizes[k];
+    sha_update(&sha, g_shm_out ? g_shm_out + k * g_shm_stride : g_outs[k], g_sizes[k]);
+  }
   sha_final(&sha, hex);
-  printf("{\"bytes\": %zu, \"shards\": %zu, \"threads\": %d, \"pinned_cpus\": %d, \"reps\": %d, "
-         "\"seconds\": %.6f, \"MBps\": %.2f, \"seconds_all\": [", g_len, g_nshards, threads, g_ncpus,
+  printf("{\"bytes\": %zu, \"shards\": %zu, \"threads\": %d, \"pinned_cpus\": %d, \"alloc\": \"%s\", \"workers\": \"%s\", "
+         "\"reps\": %d, \"seconds\": %.6f, \"MBps\": %.2f, \"seconds_all\": [", g_len, g_nshards, threads, g_ncpus,
+         alloc_mode ? alloc_mode : "malloc", g_procs ? "processes" : "threads",
          reps, median, (double)g_len / 1e6 / median);
   for (r = 0; r < reps; ++r) printf("%s%.6f", r ? ", " : "", times[r]);
   printf("], \"out_bytes\": %llu, \"sha256\": \"%s\"}\n", (unsigned long long)out_total, hex);

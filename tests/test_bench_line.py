@@ -74,3 +74,15 @@ def test_a_leg_that_dies_leaves_an_error_not_an_exception():
     import bench
     res = bench.run_leg("stock", "/nonexistent/input.bin", 5, 22, timeout_s=60)
     assert res is None or "error" in res
+
+
+def test_other_configs_leg_failures_are_reported_not_raised(monkeypatch, tmp_path):
+    """`other_configs` of the last line: every configuration is a child run of bench.py with a timeout; one that cannot
+    run (no GPU here) comes back as an item with `error`, the others still run."""
+    import bench
+    monkeypatch.setattr(bench, "OTHER_CONFIGS", [("configs[2] stand-in", ["--quality", "1", "--data", "random", "--steps", "1", "--warmup", "0"], False, 120)])
+    f = tmp_path / "in.bin"
+    f.write_bytes(b"x" * (1 << 20))
+    res = bench.other_configs(str(f), 1, {"env": {}, "threads": 1, "cpus": [0]})
+    assert len(res) == 1 and res[0]["config"] == "configs[2] stand-in"
+    assert "error" in res[0] or res[0].get("value", 0) > 0

@@ -1,7 +1,7 @@
 """The tiled quality-5 chain (JOB_FLAG_TILED; k_chain.h tiles / sweeps, k_tile.h) on the GPU box through the HIP
 C ABI: long shards whose chain tiles all parse at once.  The reference itself (oracle/_ref, one encoder instance per
 shard on the host cores) encodes the same input with the same plan; the sha256 of its concatenated output must be
-ours.  BROTLI_AMD_TILE_KB selects the tile size (the library reads it per job)."""
+ours.  BROTLI_AMD_TILE_KB selects the tile size (read at context creation and by hip.refresh_env())."""
 import hashlib
 import os
 
@@ -27,13 +27,18 @@ def _encode(ctx, data, shard, tile_kb, monkeypatch, lgwin=22):
     import torch
     from brotli_amd import hip
     monkeypatch.setenv("BROTLI_AMD_TILE_KB", str(tile_kb))
-    n = len(data)
-    hint = min(n, 1 << 30)
-    params = hip.make_params(5, lgwin, shard, hint)
-    d_in = hip.to_device(data, 0)
-    d_out = torch.empty(ctx.max_output(n, params), dtype=torch.uint8, device="cuda:0")
-    nbytes, info = ctx.encode_device(d_in, n, params, d_out)
-    comp = d_out[:nbytes].cpu().numpy().tobytes()
+    hip.refresh_env()             # (the library reads its knobs when a context is created: this one exists already)
+    try:
+        n = len(data)
+        hint = min(n, 1 << 30)
+        params = hip.make_params(5, lgwin, shard, hint)
+        d_in = hip.to_device(data, 0)
+        d_out = torch.empty(ctx.max_output(n, params), dtype=torch.uint8, device="cuda:0")
+        nbytes, info = ctx.encode_device(d_in, n, params, d_out)
+        comp = d_out[:nbytes].cpu().numpy().tobytes()
+    finally:
+        monkeypatch.delenv("BROTLI_AMD_TILE_KB")
+        hip.refresh_env()
     return comp, info
 
 

@@ -233,6 +233,30 @@ def test_empty_finish_behind_complete_blocks_at_the_other_qualities(ref, quality
         assert fin and fin2 and bytes(got) == bytes(want), (quality, lgwin, k)
 
 
+@pytest.mark.parametrize("quality,lgwin,feed_kb,ops", [
+    (9, 17, 320, [(327680, 0), (196608, 0), (0, 2)]),        # forwarded 320 KiB (not a multiple of the 256 KiB block), 512 KiB in all
+    (9, 17, 320, [(327680, 0), (196608 + 1000, 0), (0, 2)]),  # the same with an incomplete last block
+    (6, 18, 100, [(102400, 0), (28672, 0), (0, 2)]),           # 100 KiB forwarded, 128 KiB = two blocks in all
+])
+def test_empty_finish_behind_an_unaligned_forward(ref, monkeypatch, quality, lgwin, feed_kb, ops):
+    """PROCESS forwarded part of the input before the empty FINISH (BROTLI_AMD_FEED_KB), and what is still held is not
+    a whole number of blocks although the stream is: the reference counts its blocks from the stream's start
+    (encode.c:1700-1712), so the last one was encoded with is_last = 0 and the FINISH adds an empty meta-block — the
+    serial stream is fed the calls as they came (the alignment test looked at the held bytes only)."""
+    from test_abi_on_sim import SIM_ABI
+    from test_gpu_abi import _bind, drive
+    from refharness import ROOT, TABLES
+    os.environ["BROTLI_AMD_TABLES"] = TABLES
+    monkeypatch.setenv("BROTLI_AMD_FEED_KB", str(feed_kb))
+    L = _bind(SIM_ABI)
+    stock = _bind(os.path.join(ROOT, "oracle", "_ref", "libbrotli_ref.so"))
+    text = bytes(G.enwik_text(sum(n for n, _ in ops), seed=31))
+    params = ((1, quality), (2, lgwin))
+    got, fin = drive(L, text, ops, params=params)
+    want, fin2 = drive(stock, text, ops, params=params)
+    assert fin and fin2 and bytes(got) == bytes(want)
+
+
 @pytest.mark.parametrize("reverse", [0, 1])
 def test_every_big_bucket_on_the_lists_of_k_ix_big(sim, ref, monkeypatch, reverse):
     """BROTLI_AMD_IX_GIANT=320: every bucket too big for LDS goes onto the block lists and is searched by k_ix_big /

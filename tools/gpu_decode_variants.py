@@ -28,6 +28,7 @@ for quality in (5,):
     print("input %d MiB, %d pieces of %d KiB, %d compressed bytes, setup %.1f s" % (mib, len(pieces), shard >> 10, nbytes, time.time() - t0), flush=True)
     for variant in (4, 8, 4 + 16, 8 + 16, 4, 8):
         os.environ["BROTLI_AMD_DECODE_VARIANT"] = str(variant)
+        hip.refresh_env()
         ms_all = []
         for rep in range(3):
             res, ms = ctx.decode_device(d_out, nbytes, d_back, n, pieces)

@@ -18,6 +18,7 @@ for shard in [int(x) for x in os.environ.get("PROBE_SHARDS", "131072").split(","
             os.environ["BROTLI_AMD_IX_BPW"] = str(bpw)
         else:
             os.environ.pop("BROTLI_AMD_IX_BPW", None)
+        hip.refresh_env()
         ms, msb = [], []
         for rep in range(3):
             got, info = ctx.debug_parse(d, N, hip.make_params(5, 22, shard, 1 << 30))

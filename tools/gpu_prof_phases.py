@@ -26,13 +26,16 @@ else:
         data = G.random_bytes(N, G.SEED)
 ctx = hip.Context(0)
 d = hip.to_device(data)
-if os.environ.get("PROBE_CHAIN"):
+QUALITY, LGWIN = int(os.environ.get("PROBE_QUALITY", "5")), int(os.environ.get("PROBE_LGWIN", "22"))
+if QUALITY >= 6:
+    names = ["bytes at P -> counter + record", "candidate strings", "scores + reductions", "step-by-step resolve", "insert", "dictionaries", "decide + commit", "StoreRange", "driver", "-", "-", "-"]
+elif os.environ.get("PROBE_CHAIN"):
     names = ["top/driver/marks", "loads -> dc len", "eval rest + bcast", "lean loop", "sr fetch + commit", "generic", "accounting", "post", "FAST loads+eval", "FAST exact fix", "FAST group logic", "FAST commit+marks"]
 else:
   names = ["record(after P bytes)", "ext+rest of cand", "resolve", "insert", "dict", "decide", "stores", "driver", "bytes at P", "dc strings", "bucket strings", "-"]
 for shard in [int(x) for x in os.environ.get("PROBE_SHARDS", "262144,65536").split(",")]:
     for rep in range(2):
-        got, info = ctx.debug_parse(d, N, hip.make_params(5, 22, shard, 1 << 30))
+        got, info = ctx.debug_parse(d, N, hip.make_params(QUALITY, LGWIN, shard, 1 << 30))
     prof = info["prof"]; tot = sum(prof)
     iters = info["search_steps"]
     print("PHASES kind=" + KIND + " shard=%d parse=%.1fms searches=%d cmds=%d total_cycles/shard-iter=%.0f" % (
