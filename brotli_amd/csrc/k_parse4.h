@@ -171,18 +171,14 @@ DEV uint32_t q_ring_byte(const QShard& g, uint32_t x) {
   return g.pos_end > g.ring_mask ? g.data[x - g.ring_mask - 1u] : 0u;
 }
 
-// (The four entries are read first and the choice is made between VALUES: with a load in every arm of the conditional
-//  the optimizer forms a load through a phi of pointers into the shard state, which then cannot be kept in registers —
-//  the whole QShard lived in scratch memory in k_parse_deep and k_parse_quick until round 6: .private_segment_fixed_size
-//  464, every read of g.position a round trip, half a terabyte of scratch writes per GiB at quality 9,
-//  profiles/r06_pmc_q9_before.txt.)
+// (Written as a conditional over the four members — not g.dc[i], and nothing may index g.dc through its address, k_dict.h's
+//  compound_lookup included: one such index keeps the whole QShard in scratch memory, where every read of g.position is a
+//  round trip.  k_parse_deep and k_parse_quick ran that way until round 6: .private_segment_fixed_size 464, half a
+//  terabyte of scratch writes per GiB at quality 9, profiles/r06_pmc_q9_before.txt.  Reading all four entries first and
+//  selecting between the values costs k_chain 2.8 ms per GiB — profiles/r06_g_ab_q_dc_entry.txt — and is not needed once
+//  nothing pins the struct.)
 DEV uint32_t q_dc_entry(const QShard& g, int i) {
-  const uint32_t d0 = (uint32_t)g.dc[0], d1 = (uint32_t)g.dc[1], d2 = (uint32_t)g.dc[2], d3 = (uint32_t)g.dc[3];
-  uint32_t d = d3;
-  d = i == 2 ? d2 : d;
-  d = i == 1 ? d1 : d;
-  d = i == 0 ? d0 : d;
-  return d;
+  return (uint32_t)(i == 0 ? g.dc[0] : i == 1 ? g.dc[1] : i == 2 ? g.dc[2] : g.dc[3]);
 }
 
 // Match length of data[a..] and data[b..] beyond the first 32 bytes

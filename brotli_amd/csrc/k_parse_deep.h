@@ -67,6 +67,17 @@ DEV DeepGeom deep_geom(const JobParams& J) {
 // byte offset of slot s inside a record: a lane's E entries are contiguous
 template <int E>
 DEV uint32_t deep_slot_offset(uint32_t s) { return ((s & 63u) * (uint32_t)E + (s >> 6)) * 8u; }
+// (Round 6 tried two other shapes for qualities 7 - 9, measured and dropped — profiles/r06_i_*: positions and
+//  fingerprints in arrays of their own, 749 against 663 ms per GiB at 512 KiB shards (eight narrow loads per lane instead
+//  of two wide ones); and on top of that four consecutive positions searched at once by 16-lane groups, 840 ms: a bucket
+//  of a common 5-gram holds up to 256 candidates that all pass the fingerprint, and 16 lanes walk them in 16 rounds
+//  where the whole wave compares them in one.)
+DEV uint8_t* d_rec(const DeepGeom& G, const QShard& g, uint32_t key) { return g.table + (size_t)key * G.rec_bytes; }
+template <int E>
+DEV void d_put_entry(const DeepGeom& G, const QShard& g, uint32_t key, uint32_t s, uint32_t pos, uint32_t tag2, uint32_t tag) {
+  const uint64_t e = q_entry(pos, tag2, tag, 0);
+  __builtin_memcpy(d_rec(G, g, key) + deep_slot_offset<E>(s), &e, 8);
+}
 
 // ---- ordered insertion of up to 64 positions ------------------------------------------
 template <int E>
@@ -99,10 +110,7 @@ DEV void d_store64(const JobParams& J, const DeepGeom& G, const QShard& g, bool 
   if (act) {
     // the reference's serial loop leaves only the newest `slots` of a same-key run
     const uint32_t s = (G.tagged ? num - below : num + below) & G.mask;
-    if (total - below <= G.slots) {
-      const uint64_t e = q_entry(pos, kt.tag2, kt.tag, 0);
-      __builtin_memcpy(g.table + (size_t)kt.key * G.rec_bytes + deep_slot_offset<E>(s), &e, 8);
-    }
+    if (total - below <= G.slots) d_put_entry<E>(G, g, kt.key, s, pos, kt.tag2, kt.tag);
     if (below + 1 == total) g.nums[kt.key] = (uint16_t)(G.tagged ? num - total : num + total);
   }
   wave_sync();
@@ -191,6 +199,7 @@ DEV QResult d_resolve_slow(const JobParams& J, const DeepGeom& G, const QShard& 
 #ifndef DEEP_PREFETCH
 #define DEEP_PREFETCH 1
 #endif
+
 #define D_PF_NONE 0xFFFFFFFFu
 template <int E>
 struct DeepPf { uint32_t pos, key, num; uint64_t ent[E]; B32 cur; };
@@ -198,7 +207,7 @@ struct DeepPf { uint32_t pos, key, num; uint64_t ent[E]; B32 cur; };
 template <int E>
 DEV void d_fetch_record(const DeepGeom& G, const QShard& g, uint32_t key, uint32_t& num, uint64_t (&ent)[E]) {
   const int lane = wave_lane();
-  const uint8_t* mine = g.table + (size_t)key * G.rec_bytes + (uint32_t)lane * (8u * (uint32_t)E);
+  const uint8_t* mine = d_rec(G, g, key) + (uint32_t)lane * (8u * (uint32_t)E);
   const bool in_rec = (uint32_t)lane < G.slots;        // quality 6: 32 slots, upper lanes idle
   num = g.nums[key];
 #pragma unroll
@@ -348,8 +357,7 @@ DEV QResult d_search(const JobParams& J, const DeepGeom& G, const DeviceTables* 
   {
     const uint32_t ts = num & G.mask;
     if ((uint32_t)lane == (ts & 63u)) {
-      const uint64_t e = q_entry(P, kt.tag2, kt.tag, 0);
-      __builtin_memcpy(g.table + (size_t)kt.key * G.rec_bytes + deep_slot_offset<E>(ts), &e, 8);
+      d_put_entry<E>(G, g, kt.key, ts, P, kt.tag2, kt.tag);
       g.nums[kt.key] = (uint16_t)(G.tagged ? num - 1u : num + 1u);
     }
   }
@@ -547,7 +555,12 @@ DEV void parse_deep_round(const JobParams& J, const ShardDesc& D, ShardState* S,
         g.position += g.sr_len;
       }
       QP_ADD(g, 6, dt);                                      // decide + commit
-      if (g.st_count != 0) pf.pos = D_PF_NONE;               // (a StoreRange / the spree's stores: the prefetched record may be theirs)
+      if (DEEP_PREFETCH >= 2 && g.st_count != 0) pf.pos = D_PF_NONE;   // (a StoreRange / the spree's stores: the prefetched record may be theirs)
+      if (DEEP_PREFETCH == 1 && pf.pos != g.position && g.state == Q_SEARCH && g.position < g.pos_end) {
+        // the search goes on somewhere else (behind a copy, behind the spree's skip): its bytes travel during the stores
+        pf.pos = g.position;
+        pf.cur = load_b32(g.data + g.position);
+      }
       d_drain_stores<E>(J, G, g, lds_dup);
       QP_ADD(g, 7, dt);                                      // StoreRange
     }

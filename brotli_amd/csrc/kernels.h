@@ -25,6 +25,9 @@
 #ifndef IXB_WAVES
 #define IXB_WAVES 4                    // k_ix_bucket: 8.7 KB of LDS per wave admit 18 waves per CU either way; at five waves per SIMD
 #endif                                 //   (96 VGPRs) the search spills (profiles/r05_ix*: 29.4 against 28.3 ms)
+#ifndef TILE_WAVES
+#define TILE_WAVES CHAIN_WAVES         // k_chain_tiles / k_chain_sweep (experiment knob: they spill at 168 VGPRs)
+#endif
 #ifndef BUILD_WAVES
 #define BUILD_WAVES 4
 #endif
@@ -190,7 +193,7 @@ __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain(JobArgs a) {
 }
 // The same for the tiles of a tiled job (grid = ceil(ntiles / tiles per wave)): their first parse, and a sweep.
 // (k_tile_verify looks at the tiles' records; errors surface there.)
-__global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain_tiles(JobArgs a) {
+__global__ void __launch_bounds__(64, TILE_WAVES) k_chain_tiles(JobArgs a) {
 #if defined(BROTLI_AMD_SIMT_SIM)
   __shared__ uint32_t lds_c[C_LDS_WORDS];
 #else
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain_tiles(JobArgs a) {
 #endif
   chain_round<1>(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_c, a.tiles, a.trecs, a.ntiles, a.chunks);
 }
-__global__ void __launch_bounds__(64, CHAIN_WAVES) k_chain_sweep(JobArgs a) {
+__global__ void __launch_bounds__(64, TILE_WAVES) k_chain_sweep(JobArgs a) {
 #if defined(BROTLI_AMD_SIMT_SIM)
   __shared__ uint32_t lds_c[C_LDS_WORDS];
 #else

@@ -96,7 +96,9 @@ class BrotliAmdError(RuntimeError):
 def refresh_env():
     """Has the library read its BROTLI_AMD_* experiment knobs again (it reads them when a context is created): for tools
     and tests that change one between two jobs of a living context."""
-    load_library().brotli_amd_refresh_env()
+    L = load_library()
+    if hasattr(L, "brotli_amd_refresh_env"):
+        L.brotli_amd_refresh_env()
 
 
 def load_library(path=LIB_PATH):
@@ -107,8 +109,11 @@ def load_library(path=LIB_PATH):
     L = C.CDLL(path)
     L.brotli_amd_ctx_create.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
     L.brotli_amd_ctx_destroy.argtypes = [C.c_void_p]
-    L.brotli_amd_refresh_env.argtypes = []
-    L.brotli_amd_refresh_env.restype = None
+    try:
+        L.brotli_amd_refresh_env.argtypes = []
+        L.brotli_amd_refresh_env.restype = None
+    except AttributeError:      # (an experiment build of an older tree, BROTLI_AMD_HIP_LIB)
+        pass
     L.brotli_amd_last_error.argtypes = [C.c_void_p]
     L.brotli_amd_last_error.restype = C.c_char_p
     L.brotli_amd_max_output.argtypes = [C.c_uint64, C.POINTER(JobParams)]
