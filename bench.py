@@ -195,9 +195,14 @@ def cpu_scaling(run, path, nbytes, shard_size, cpus, smt, sample_mb=256):
             c["x_one_thread"] = round(c["MBps"] / one, 2)
             c["parallel_efficiency"] = round(c["MBps"] / one / min(c["threads"], cores), 3)
         top = max(curve, key=lambda c: c["MBps"])
+        # (of the points within 3 % of the fastest, the one with the fewest threads: past a CPU quota the curve is noise)
+        top = min([c for c in curve if c["MBps"] >= 0.97 * top["MBps"]], key=lambda c: c["threads"])
         use_smt = top["cpus"].startswith("physical cores +")
         best = {"env": best_v["env"], "variant": best_v["variant"], "threads": top["threads"],
                 "cpus": (list(cpus) + list(smt)) if use_smt else list(cpus[:top["threads"]]), "MBps_on_sample": top["MBps"]}
+        # the largest thread count that ran unthrottled (inside the quota): what the extrapolation to a socket rests on
+        free = max([c for c in curve if c["cpus"] == "one per physical core" and (not quota or c["threads"] <= quota)] or [curve[0]],
+                   key=lambda c: c["threads"])
         if quota and top["threads"] <= 2 * quota and quota < cores:
             bound = ("the CPU bandwidth limit of this box's cgroup: cpu.max allows %.0f CPUs' worth of run time per period, so the "
                      "curve is ~linear up to %d threads and flat or falling beyond (the kernel stops the group for the rest of "
@@ -210,10 +215,11 @@ def cpu_scaling(run, path, nbytes, shard_size, cpus, smt, sample_mb=256):
                           "pins itself to the CPU list before it reads the input (first touch on the workers' socket)" % (n >> 20, shard_size >> 10),
                 "cgroup_cpu_quota": quota, "bounded_by": bound,
                 "one_thread_MBps": one,
-                "whole_socket_if_scaling_held_MBps": round(one * cores * (top["MBps"] / one / min(top["threads"], cores)), 1),
-                "whole_socket_note": "one thread's rate x %d physical cores x the parallel efficiency measured at the best thread count — "
-                                     "an extrapolation, NOT a measurement (printed so that the multiple against this box's throttled "
-                                     "baseline is not mistaken for one against a full socket)" % cores,
+                "whole_socket_if_scaling_held_MBps": round(one * cores * free["parallel_efficiency"], 1),
+                "whole_socket_note": "one thread's rate x %d physical cores x the parallel efficiency measured at %d threads, the largest "
+                                     "count the cgroup did not throttle — an extrapolation, NOT a measurement (printed so that the "
+                                     "multiple against this box's throttled baseline is not mistaken for one against a full socket)"
+                                     % (cores, free["threads"]),
                 "variants_at_all_physical_cores": [{k: v for k, v in a.items() if k != "env"} for a in at_full],
                 "curve_with_best_variant": curve, "best": best,
                 "malloc_threads_MBps": at_full[0]["MBps"],
@@ -286,8 +292,8 @@ def cpu_baseline(path, nbytes, quality, lgwin, shard_size, size_hint, reps=5, ot
             except OSError:
                 pass
         out = {
-            "value": round(same["MBps"], 1), "unit": "MB/s", "cores": cores, "kind": "reference",
-            "threads": threads, "workers": same.get("workers"), "alloc": same.get("alloc"),
+            "value": round(same["MBps"], 1), "unit": "MB/s", "cores": threads, "kind": "reference",
+            "threads": threads, "physical_cores_of_the_socket": cores, "workers": same.get("workers"), "alloc": same.get("alloc"),
             "sample": "the whole %d MiB input, same plan (%d shards of %d KiB), %d %s (%s) pinned to the "
                       "physical cores%s of socket %d (oracle/plan_bench.c) — the fastest configuration of `scaling` —, "
                       "median of %d run(s)%s, %.3f s, ratio %.3f" % (

@@ -546,11 +546,8 @@ static size_t feed_threshold(const BrotliEncoderState* s) {
        up to BROTLI_AMD_HOLD_MB (default 1024; 0 = never hold).  A FLUSH, or input beyond that, goes to the serial
        stream as before. */
     const size_t cap_mb = s->env_hold_mb >= 0 ? (size_t)s->env_hold_mb : 1024u;
-    /* (a stream nobody announced a size for — a pipe — is held up to a quarter of that: output starts to flow, and host
-        memory stays bounded, sooner) */
-    const size_t cap_unannounced = s->env_hold_mb >= 0 ? cap_mb : 256u;
     if (s->env_stream_tiles != 0 && cap_mb != 0) {
-      if (s->size_hint == 0) return cap_unannounced << 20;
+      if (s->size_hint == 0) return cap_mb << 20;
       if (((size_t)s->size_hint >> 20) < cap_mb) return (size_t)s->size_hint + 1u;
     }
   }
@@ -562,15 +559,24 @@ static int forward_pending_input(BrotliEncoderState* s, int force) {
   if (s->shard_bytes == 0) {
     const uint8_t* out;
     uint64_t out_len;
+    size_t off = 0;
     if (!open_stream(s)) return 0;
-    if (brotli_amd_stream_write(s->stream, s->in_buf, s->in_len, BROTLI_AMD_OP_PROCESS, &out, &out_len) != BROTLI_AMD_OK) {
-      if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
-      return 0;
+    /* in pieces of 4 MiB (what the stream was fed with before inputs were held for the tiled path): a hold that ran into
+       its cap hands over up to a GiB here, which as ONE call would want device buffers of several GiB and keep the
+       caller waiting for all of it; the bytes do not depend on how the calls cut the input */
+    while (off < s->in_len) {
+      const size_t n = s->in_len - off < ((size_t)4 << 20) ? s->in_len - off : ((size_t)4 << 20);
+      if (brotli_amd_stream_write(s->stream, s->in_buf + off, n, BROTLI_AMD_OP_PROCESS, &out, &out_len) != BROTLI_AMD_OK) {
+        if (s->env_verbose) fprintf(stderr, "brotli_amd: %s\n", brotli_amd_last_error(s->ctx));
+        return 0;
+      }
+      if (!out_append(s, out, (size_t)out_len)) return 0;
+      off += n;
     }
     s->submitted += s->in_len;
     s->in_len = 0;
     s->header_written = 1;
-    return out_append(s, out, (size_t)out_len);
+    return 1;
   } else {
     BrotliAmdJobParams p;
     BrotliAmdJobInfo info;

@@ -97,6 +97,7 @@ struct BrotliAmdCtx {
   ShardState* d_mstate = nullptr;
   uint64_t* d_moff = nullptr;
   bool tail_fix = false;              // the last stream job: stream_tail_fix (host_plan.h) applies to its output
+  bool from_host = false;             // brotli_amd_encode_device is being called by brotli_amd_encode_host
   uint64_t tail_bit = 0, tail_total_bits = 0;
   uint64_t chunk_cap = 0, mb_cap = 0;
   uint8_t* d_stage_in = nullptr;    // encode_host staging
@@ -1094,6 +1095,12 @@ int brotli_amd_encode_device(BrotliAmdCtx* c, const void* d_in, uint64_t len,
   *out_size = 0;
   DeviceScope dev(c->device);
   if (!dev.ok) { fail(c, "hipSetDevice failed"); return BROTLI_AMD_ERROR; }
+  if ((p->flags & BROTLI_AMD_FLAG_TAIL_FINISH) && !c->from_host) {
+    // the flag's second half — the rewrite of the last meta-block's header — is done on the host by brotli_amd_encode_host;
+    // a device-side caller would get the one-shot form with the raw / compressed decision of the other
+    fail(c, "BROTLI_AMD_FLAG_TAIL_FINISH is honoured by brotli_amd_encode_host only");
+    return BROTLI_AMD_UNSUPPORTED;
+  }
   if (p->flags & BROTLI_AMD_FLAG_STREAM_TILES) {
     if (p->quality != 5 || p->shard_size != 0 || p->stream_base != 0 || !p->is_last || c->d_cd || d_shard_sizes ||
         ((p->flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u) != 0u) {
@@ -1194,8 +1201,10 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len,
   if (!stage()) return BROTLI_AMD_ERROR;
   const double t1 = now();
   uint64_t n = 0;
+  c->from_host = true;
   int rc = brotli_amd_encode_device(c, c->d_stage_in, len, p, c->d_stage_out, c->stage_out_cap, &n,
                                     nullptr, info);
+  c->from_host = false;
   if (rc != BROTLI_AMD_OK) return rc;
   const double t2 = now();
   *out_size = n;

@@ -169,12 +169,24 @@ __global__ void __launch_bounds__(64, IXB_WAVES) k_ix_bucket_s(JobArgs a) {
 // The buckets too big for LDS, block by block (k_index.h: ix_big): a fixed grid of IX_BIG_GRID workgroups — 8 XCDs x
 // the waves one XCD holds — takes the blocks from the lists k_ix_bucket wrote; few blocks = few waves with work.
 #define IX_BIG_GRID (8u * 32u * 4u * IXB_WAVES)
+// (A list that did not take all the records k_ix_bucket had for it — the planner's bound, plan_add_index_for, is
+//  coupled to IX_BIG_BLOCK, ix_giant and the assignment of units to XCDs — would leave blocks unsearched and their
+//  res[] / srt[] entries stale: the job is failed through the fault counter the host reads, not finished with wrong
+//  bytes.  ADVICE round 5.)
+DEV void ix_big_check_overflow(const JobArgs& a) {
+  if (blockIdx.x < 8u && threadIdx.x == 0) {
+    const uint32_t* hdr = (const uint32_t*)(a.ws + a.J.big_off);
+    if (hdr[blockIdx.x] > (uint32_t)a.J.big_cap) glb_atomic_add(&a.counters[1], 1u);
+  }
+}
 __global__ void __launch_bounds__(64, IXB_WAVES) k_ix_big(JobArgs a) {
   __shared__ uint32_t lds_b[IX_BUCKET_LDS_WORDS];
+  ix_big_check_overflow(a);
   ix_big<false>(a.J, a.shards, a.input, a.ws, blockIdx.x & 7u, lds_b);
 }
 __global__ void __launch_bounds__(64, IXB_WAVES) k_ix_big_s(JobArgs a) {
   __shared__ uint32_t lds_b[IX_BUCKET_LDS_WORDS];
+  ix_big_check_overflow(a);
   ix_big<true>(a.J, a.shards, a.input, a.ws, blockIdx.x & 7u, lds_b);
 }
 // grid = ceil(nshards / shards per wave), block = 64; dynamic LDS: shards per wave * C_GROUP_LDS_WORDS * 4 bytes

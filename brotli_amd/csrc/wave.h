@@ -75,6 +75,12 @@ static inline uint32_t wave_max_u32(uint32_t v) {
 
 #include <hip/hip_runtime.h>
 
+// The cross-lane code of this directory (row_ror / row_shr / row_bcast DPP controls, 64-lane ballots, v_readlane) is
+// wave64 GCN / CDNA code: another target would assemble it wrongly or not at all, so it is refused here.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "brotli_amd kernels are written for gfx950 (wave64, DPP row_bcast): build with --offload-arch=gfx950"
+#endif
+
 __device__ __forceinline__ int wave_lane() { return (int)(threadIdx.x & 63); }
 
 // 64-bit mask of lanes whose predicate holds (s_and / v_cmp into an SGPR pair).

@@ -19,6 +19,14 @@ def rank_params(rank, world, piece_bytes, total_bytes):
 HDR = 16   # bytes in front of every rank's slot: its compressed size and the slot hint it came with (two int64)
 
 
+class SlotHint(int):
+    """The slot size a gather_stream call ended with, as handed back for the next step.  Only such a value — computed
+    from sizes every rank has seen, hence the same on all of them — lets the next step start with the payload collective;
+    any other hint is a number some caller made up, possibly a different one on every rank, and a collective entered with
+    different counts does not raise under RCCL: it hangs.  (the comparison used to come AFTER
+    the payload gather.)"""
+
+
 def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0):
     """local: 1-D uint8 tensor holding this rank's compressed piece in local[:nbytes].  Returns (all-gather buffer,
     sizes as a list of ints, slot bytes); the stream is cat(buffer[r * slot + HDR : r * slot + HDR + sizes[r]]).
@@ -26,8 +34,9 @@ def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0
     ONE all-gather per step: every rank contributes a slot of `pad_hint` bytes (rounded up to `align`) = a 16-byte
     header (its size, its hint) + its piece + padding, so the sizes travel with the payload and the step's one host
     read — the headers, needed to cut the padding off anyway — comes after the collective.  The hint is what the
-    previous step needed (the steps of a job compress the same pieces); the first step of a job has none and asks for
-    the sizes first (one small all-gather more, once), as does a step whose piece did not fit its slot."""
+    previous step needed (the steps of a job compress the same pieces) and must be the SlotHint that step returned; the
+    first step of a job has none and asks for the sizes first (one small all-gather more, once), as does a step whose
+    piece did not fit its slot, and a step handed a plain number (not trusted to agree between ranks)."""
     world = dist.get_world_size(group)
     dev = local.device
 
@@ -46,20 +55,17 @@ def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0
         both = head.view(torch.int64).view(world, 2)
         return scratch, [int(v) for v in both[:, 0]], [int(v) for v in both[:, 1]]
 
-    slot = round_up(pad_hint) if pad_hint else 0
+    # Only a hint an earlier gather returned (SlotHint) is the same on every rank by construction: the payload collective
+    # goes first with that one.  Anything else asks for the sizes first — a fixed-size collective that cannot mismatch.
+    slot = round_up(pad_hint) if isinstance(pad_hint, SlotHint) and pad_hint else 0
     if slot > HDR:
         scratch, sizes, hints = gather(slot, scratch)
-        if any(h != hints[0] for h in hints):
-            # pad_hint must be the same on every rank (compared raw: stricter than the slots it rounds to, so a caller bug
-            # shows even while the slots still agree).  sharded_step's hint is the slot an earlier step returned, computed
-            # from the gathered sizes, hence identical everywhere by construction — the gather above relies on that.  Ranks
-            # that get here with different slots were handed hints from somewhere else: their collective has already run
-            # with mismatched counts, so this is a diagnosis of a caller bug, not a recovery.
+        if any(h != hints[0] for h in hints):            # (cannot happen with SlotHint values of one job; kept as an assertion)
             raise ValueError("gather_stream: pad_hint differs between ranks: %r" % (hints,))
         if max(sizes) <= slot - HDR:
-            return scratch, sizes, slot
+            return scratch, sizes, SlotHint(slot)
     else:
-        # no (usable) hint yet: the sizes first
+        # no trusted hint: the sizes first
         mine = torch.tensor([nbytes], dtype=torch.int64, device=dev)
         allsz = torch.zeros(world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(allsz, mine, group=group)
@@ -67,7 +73,7 @@ def gather_stream(local, nbytes, group=None, scratch=None, align=256, pad_hint=0
     slot = round_up(max(sizes) + HDR)
     pad_hint = slot                                              # (what this gather's headers carry: the same on every rank)
     scratch, sizes, _ = gather(slot, scratch)
-    return scratch, sizes, slot
+    return scratch, sizes, SlotHint(slot)
 
 
 def compact(buffer, sizes, pad):

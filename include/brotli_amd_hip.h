@@ -76,7 +76,8 @@ typedef struct BrotliAmdJobParams {
                                           caller runs it through brotli_amd_stream_* instead */
 #define BROTLI_AMD_FLAG_TAIL_FINISH 128u /* with BROTLI_AMD_FLAG_STREAM_TILES through brotli_amd_encode_host: the stream reached the caller's
                                            encoder in PROCESS calls ending on an input-block boundary, the FINISH came empty
-                                           (encode.c:1700-1712) — the last meta-block is closed as the reference closes it then */
+                                           (encode.c:1700-1712) — the last meta-block is closed as the reference closes it then;
+                                           brotli_amd_encode_device refuses the flag (BROTLI_AMD_UNSUPPORTED): half of it is host work */
 #define BROTLI_AMD_FLAG_NO_INDEX 16u  /* quality 5: hash-table parse (k_parse4) instead of the position index
                                          (k_index.h + k_chain.h) */
 
