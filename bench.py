@@ -17,8 +17,10 @@ Rank 0 prints the driver contract's JSON line — up to three times, each a supe
 region alone; + cpu_baseline / plans[] / parity; + the legs behind the headline, each run in a child process with a
 timeout): the LAST line is the complete one, and a run that ends early for any reason still leaves a parseable
 headline on stdout.  Two extra objects:
-  roofline     — the dominant kernel (quality 5: k_ix_bucket, the sort inside the
-                 index buckets + the window search of every position): its
+  roofline     — the dominant kernel (quality 5: k_ix_bucket with k_ix_big behind it —
+                 the sort inside the index buckets + the window search of every
+                 position; the second kernel takes the blocks of the buckets too
+                 big for one wave, and the HIP events bracket the pair): its
                  algorithmic HBM bytes per launch (17 B per input
                  byte) / its HIP-event time, measured live on the library's
                  stream; `parse_path` beside it prices the whole LZ77 parse
@@ -978,7 +980,9 @@ def main(argv=None):
         algo = ALGO_BYTES_PER_INPUT_BYTE[args.quality]
         indexed = args.quality == 5 and ms_ixb > 0
         if indexed and ms_ixb >= ms_parse:
-            kernel, k_ms, k_bytes = "k_ix_bucket", ms_ixb, IX_BUCKET_BYTES_PER_INPUT_BYTE
+            # (the HIP events bracket k_ix_bucket and k_ix_big, which searches the blocks of the buckets too big for one wave
+            #  right behind it — a tenth of the positions of the bench text: rocprofv3 shows the two separately, 25.5 + 3.3 ms)
+            kernel, k_ms, k_bytes = "k_ix_bucket+k_ix_big", ms_ixb, IX_BUCKET_BYTES_PER_INPUT_BYTE
         else:
             kernel = "k_chain" if indexed else ("k_parse4" if args.quality == 5 else "k_parse_quick" if args.quality < 5 else "k_parse_deep")
             k_ms, k_bytes = ms_parse, (algo if not indexed else 9.0 + 16.0 * 0.4)

@@ -501,7 +501,9 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
     // ---- compressed meta-block header (section 9.2) ----
     DecBlocks blk[3];
     bool ok = true;
-    for (int c = 0; c < 3 && ok; ++c) {
+#pragma unroll                  // (blk[] indexed by constants only: it stays in registers — see k_store.h, sel3)
+    for (int c = 0; c < 3; ++c) {
+      if (!ok) break;
       uint32_t* bt = arena + DEC_A_BLOCK_TREES + (uint32_t)c * DEC_BT_STRIDE;
       blk[c].ntypes = dec_read_count256(b);
       blk[c].type = 0;
@@ -671,11 +673,13 @@ DEV void decode_piece(const DecArgs& a, uint32_t piece, uint32_t* lds) {
       if (dcode < 16u) {
         // 0..3: the ring; 4..9: last -1 +1 -2 +2 -3 +3; 10..15: second last likewise
         int32_t d;
-        if (dcode < 4u) d = ring[dcode];
+        // (chosen between the four values, not ring[dcode]: a computed index would keep the ring in scratch memory)
+        const int32_t r0 = ring[0], r1 = ring[1], r2 = ring[2], r3 = ring[3];
+        if (dcode < 4u) d = dcode == 0u ? r0 : dcode == 1u ? r1 : dcode == 2u ? r2 : r3;
         else {
           const uint32_t r = dcode - 4u, which = r >= 6u ? 1u : 0u, q = which ? r - 6u : r;
           const int32_t mag = (int32_t)(q >> 1) + 1;
-          d = ring[which] + ((q & 1u) ? mag : -mag);
+          d = (which ? r1 : r0) + ((q & 1u) ? mag : -mag);
         }
         if (d <= 0) { error = DEC_ERR_DISTANCE; break; }
         distance = (uint32_t)d;

@@ -20,6 +20,9 @@ else:
         data = z.tobytes()
     elif KIND == "floats":
         data = np.cumsum(rng.normal(size=N // 4)).astype(np.float32).tobytes()
+    elif KIND == "rows":
+        a = rng.integers(0, 10 ** 6, size=N // 18 + 1)
+        data = b"".join(b"%08d|%06d|OK\n" % (i, v) for i, v in enumerate(a))[:N]
     elif KIND == "gradient":
         data = ((np.arange(N) // 7 + rng.integers(0, 3, size=N)) & 255).astype(np.uint8).tobytes()
     else:
