@@ -370,13 +370,16 @@ int plan_from_params(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p,
     return BROTLI_AMD_UNSUPPORTED;
   }
   uint32_t too_long = 0;
-  // with dictionaries attached to the context every shard looks them up after each search: that lives in the
-  // one-shard-per-wave kernels (k_parse / k_parse_deep / k_parse_quick), thousands of which run side by side
-  const uint32_t api_flags = p->flags | (c->d_cd ? (uint32_t)(BROTLI_AMD_FLAG_NO_QUAD | BROTLI_AMD_FLAG_NO_INDEX) : 0u);
+  // with dictionaries attached to the context every shard looks them up after each search: at quality 5 that lives in
+  // the hash-table kernel with four shards per wave (k_parse4.h, compound_lookup16: round 6 — the one-shard-per-wave
+  // k_parse did 0.4 GB/s) for shards that fit the window, not in the indexed parse; at the other qualities in the
+  // one-shard-per-wave kernels (k_parse_deep / k_parse_quick)
+  const uint32_t api_flags = p->flags | (c->d_cd ? (uint32_t)BROTLI_AMD_FLAG_NO_INDEX : 0u);
   if (!plan_choose_kernels(plan, api_flags, c->num_cus, &too_long)) {
     fail(c, "quality %d needs shards of at most %u bytes", plan->J.quality, too_long);
     return BROTLI_AMD_UNSUPPORTED;
   }
+  if (c->d_cd) plan->J.flags &= ~(uint32_t)JOB_FLAG_DUO;      // (the scout groups of k_parse4 do not look dictionaries up)
   // Quality 5 on shards that fit the window: the position index + table-free chain.
   c->ix_region_bytes = 0;
   if ((plan->J.flags & JOB_FLAG_QUAD) && !(api_flags & BROTLI_AMD_FLAG_NO_INDEX)) {

@@ -184,6 +184,184 @@ DEV void compound_lookup(const CompoundDict* cd, const uint8_t* cur, uint32_t cu
   }
 }
 
+// ---- the same for 16-lane groups (k_parse4.h: up to four shards per wave, each group at a position of its own) ----
+// `want`: this group has a search to improve.  Lane t of a group takes distance-cache entry t (t < 4), then item t and
+// item 16 + t of the key; every cross-lane step is taken by all four groups together, what a group decides from it is
+// replicated in its lanes.  The walk only visits the candidates that can change anything — at least four bytes long,
+// inside the distance limit: the reference's other conditions have no side effect (hash.h:599-633).
+DEV uint32_t dict_extend_from32(const uint8_t* a, const uint8_t* b, uint32_t limit) {
+  uint32_t off = 32;
+  while (off + 8 <= limit) {
+    const uint64_t x = ld64(a + off) ^ ld64(b + off);
+    if (x) return off + ((uint32_t)dev_ctz64(x) >> 3);
+    off += 8;
+  }
+  while (off < limit && a[off] == b[off]) ++off;
+  return off;
+}
+DEV uint32_t dict_group_from(uint32_t v, int src_t) {      // lane (group base | src_t)'s value, src_t per group
+  return wave_shfl(v, (wave_lane() & 48) | src_t);
+}
+// (DictAhead: the first chunk's key range and this lane's two items, requested by the caller while its own search was
+//  under way — the bytes at the position are all they depend on —, so that of the lookup's three dependent round
+//  trips, key range -> items -> dictionary bytes, only the last one is left behind the search.)
+struct DictAhead { uint32_t s0, n, off0, off1; };
+DEV DictAhead dict_ahead16(const CompoundDict* cd, bool want, uint64_t first8) {
+  DictAhead a;
+  a.s0 = a.n = a.off0 = a.off1 = 0;
+  if (want) {
+    const DictChunk& ch = cd->chunks[0];
+    const uint32_t key = dict_key(first8, ch.bucket_bits);
+    a.s0 = ch.starts[key];
+    a.n = ch.starts[key + 1] - a.s0;
+    const uint32_t t = (uint32_t)(wave_lane() & 15);
+    if (t < a.n) a.off0 = ch.items[a.s0 + t];
+    if (16u + t < a.n) a.off1 = ch.items[a.s0 + 16u + t];
+  }
+  return a;
+}
+DEV void compound_lookup16(const CompoundDict* cd, bool want, const uint8_t* cur, uint32_t cur_masked, uint32_t ring_mask,
+                           int32_t dc0, int32_t dc1, int32_t dc2, int32_t dc3, uint32_t max_length,
+                           uint32_t max_ring_distance, uint32_t max_distance, SearchResult& out, const DictAhead& ahead) {
+  const int t = wave_lane() & 15;
+  const int gshift = wave_lane() & 48;
+  DB32 cur32;
+  __builtin_memcpy(&cur32, cur, 32);
+  const uint32_t nchunks = cd->num_chunks, total = cd->total_size;
+  for (uint32_t d = 0; d < nchunks; ++d) {
+    const DictChunk& ch = cd->chunks[d];
+    const uint8_t* source = ch.source;
+    const uint32_t source_size = ch.source_size;
+    const uint32_t distance_offset = max_ring_distance + total - ch.offset;
+    const uint32_t boundary = distance_offset - source_size;
+    const uint32_t key = dict_key(cur32.q[0], ch.bucket_bits);
+    uint32_t s0 = 0, n_items = 0;
+    if (d == 0u) { s0 = ahead.s0; n_items = want ? ahead.n : 0u; }
+    else if (want) { s0 = ch.starts[key]; n_items = ch.starts[key + 1] - s0; }   // <= 32
+    uint32_t best_score = out.score, best_len = out.len;
+    // ---- the four last distances that point into the chunk (hash.h:569-593) ----
+    {
+      bool cand = false;
+      uint32_t offset = 0, len = 0;
+      if (want && t < 4) {
+        const int32_t dcl = dict_dc_pick(dc0, dc1, dc2, dc3, t);
+        const uint32_t distance = (uint32_t)dcl;
+        if (dcl > 0 && distance > boundary && distance <= distance_offset) {
+          offset = distance_offset - distance;
+          cand = offset < source_size;
+        }
+      }
+      if (cand) {
+        const uint32_t limit = umin(source_size - offset, max_length);
+        DB32 src32;
+        __builtin_memcpy(&src32, source + offset, 32);
+        const uint32_t m = dict_prefix32(cur32, src32);
+        len = umin(m, limit);
+        if (m == 32u && limit > 32u) len = dict_extend_from32(cur, source + offset, limit);
+      }
+      const uint64_t any4 = wave_ballot(cand);
+      const uint32_t mask4 = (uint32_t)(any4 >> gshift) & 0xFu;
+      uint32_t l4[4] = {0, 0, 0, 0};
+      if (any4 != 0ull) {                      // (rare: a last distance points into a dictionary only behind a match there)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) l4[i] = dict_group_from(len, i);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (!((mask4 >> i) & 1u)) continue;
+        const uint32_t len_i = l4[i];
+        if (len_i < 2) continue;
+        uint32_t score = 135u * len_i + 1935u;
+        if (!(best_score < score)) continue;
+        if (i != 0) score -= 39u + ((0x1CA10u >> (i & 0xE)) & 0xEu);
+        if (!(best_score < score)) continue;
+        best_score = score;
+        if (len_i > best_len) best_len = len_i;
+        out.len = len_i;
+        out.len_code_delta = 0;
+        out.distance = (uint32_t)dict_dc_pick(dc0, dc1, dc2, dc3, i);
+        out.score = best_score;
+      }
+    }
+    if (best_len < 3) best_len = 3;
+    // ---- the key's items, newest first, sixteen at a time ----
+    for (uint32_t h = 0; h < 2u; ++h) {
+      if (!(wave_ballot(want && n_items > 16u * h) != 0ull)) break;
+      const uint32_t it = 16u * h + (uint32_t)t;
+      const bool cand = want && it < n_items;
+      uint32_t offset = 0, limit = 0, len = 0;
+      if (cand) {
+        offset = d == 0u ? (h == 0u ? ahead.off0 : ahead.off1) : ch.items[s0 + it];
+        limit = umin(source_size - offset, max_length);
+        DB32 src32;
+        __builtin_memcpy(&src32, source + offset, 32);
+        const uint32_t m = dict_prefix32(cur32, src32);
+        len = umin(m, limit);
+        if (m == 32u && limit > 32u) len = dict_extend_from32(cur, source + offset, limit);
+      }
+      // (an item is taken only with a score above the best so far, which never falls: what does not beat the score
+      //  the walk starts with is left out as well — most of a key's items, once the search itself found something)
+      const bool worth = cand && len >= 4u && distance_offset - offset <= max_distance &&
+                         1920u + 135u * len - 30u * log2floor(distance_offset - offset) > best_score;
+      uint32_t m16 = (uint32_t)(wave_ballot(worth) >> gshift) & 0xFFFFu;
+      while (wave_ballot(m16 != 0u) != 0ull) {
+        const bool act = m16 != 0u;
+        const int tt = act ? dev_ctz32(m16) : 0;
+        m16 &= m16 - 1u;
+        const uint32_t off_t = dict_group_from(offset, tt), len_t = dict_group_from(len, tt), limit_t = dict_group_from(limit, tt);
+        if (!act) continue;
+        const uint32_t distance = distance_offset - off_t;
+        if (cur_masked + best_len > ring_mask || best_len >= limit_t) continue;
+        if (len_t <= best_len) {
+          if (len_t + 3u >= best_len) continue;
+          if (ld32(cur + best_len - 3u) != ld32(source + off_t + best_len - 3u)) continue;
+        }
+        const uint32_t score = 1920u + 135u * len_t - 30u * log2floor(distance);
+        if (!(best_score < score)) continue;
+        best_score = score;
+        best_len = len_t;
+        out.len = len_t;
+        out.len_code_delta = 0;
+        out.distance = distance;
+        out.score = best_score;
+      }
+    }
+  }
+}
+
+// compound_extend for a 16-lane group: 16 bytes a step.  `run`: this group extends.
+DEV uint32_t compound_extend16(const CompoundDict* cd, bool run, const uint8_t* data_at_pos, uint32_t bytes,
+                               uint32_t cmd_dist, uint32_t max_distance, uint32_t last_copy_len) {
+  const int t = wave_lane() & 15;
+  const int gshift = wave_lane() & 48;
+  const uint32_t total = cd->total_size;
+  run = run && (cmd_dist - max_distance - 1u) < total && last_copy_len < cmd_dist - max_distance;
+  uint32_t address = run ? total - (cmd_dist - max_distance) + last_copy_len : 0u;
+  uint32_t gained = 0;
+  run = run && bytes != 0 && address < total;
+  while (wave_ballot(run) != 0ull) {
+    uint32_t room = 0;
+    bool ok = false;
+    if (run) {
+      uint32_t k = 0;
+      while (address >= cd->chunks[k].offset + cd->chunks[k].source_size) ++k;
+      const DictChunk& ch = cd->chunks[k];
+      const uint32_t in_chunk = address - ch.offset;
+      room = umin(umin(ch.source_size - in_chunk, bytes), 16u);
+      ok = (uint32_t)t < room && data_at_pos[gained + (uint32_t)t] == ch.source[in_chunk + (uint32_t)t];
+    }
+    const uint32_t m = (uint32_t)(wave_ballot(ok) >> gshift) & 0xFFFFu;
+    if (run) {
+      const uint32_t n = (m == 0xFFFFu) ? 16u : (uint32_t)dev_ctz32(~m);
+      gained += n;
+      bytes -= n;
+      address += n;
+      if (n < room || bytes == 0 || address >= total) run = false;
+    }
+  }
+  return gained;
+}
+
 // The part of ExtendLastCommand that continues a copy inside the attached dictionary
 // (c/enc/encode.c:930-961): the last command's distance points `cmd_dist - max_distance` bytes
 // before the end of the compound dictionary; the copy is extended while input and dictionary agree,

@@ -416,6 +416,16 @@ DEV void q_compound_lookup(const JobParams& J, const QShard& g, uint32_t P, uint
                   umin(P + g.stream_offset, J.max_backward_limit), K_DIST_MAX_DISTANCE, sr);
   r.len = sr.len; r.distance = sr.distance; r.score = sr.score; r.delta = sr.len_code_delta;
 }
+// The same for the 16-lane groups of k_parse4 (four shards per wave; `want` per group).
+DEV void q_compound_lookup16(const JobParams& J, const QShard& g, bool want, uint32_t P, uint32_t max_length, QResult& r,
+                             const DictAhead& ahead) {
+  if (!g.cd) return;                                   // (a kernel argument: the same for the whole wave)
+  SearchResult sr;
+  sr.len = r.len; sr.distance = r.distance; sr.score = r.score; sr.len_code_delta = r.delta;
+  compound_lookup16(g.cd, want, g.data + (want ? P : 0u), P & J.ring_mask, J.ring_mask, g.dc[0], g.dc[1], g.dc[2], g.dc[3],
+                    max_length, umin(P + g.stream_offset, J.max_backward_limit), K_DIST_MAX_DISTANCE, sr, ahead);
+  if (want) { r.len = sr.len; r.distance = sr.distance; r.score = sr.score; r.delta = sr.len_code_delta; }
+}
 DEV void q_compound_extend(const QShard& g, Command& last, uint32_t cmd_dist, uint32_t max_distance,
                            uint32_t& bytes, uint32_t& pos) {
   if (!g.cd || cmd_dist <= max_distance) return;
@@ -449,7 +459,8 @@ DEV void q_insert(QShard& g, bool act, uint32_t P, const QIns& in) {
 
 // Searches position P for every group with want set (hash table and distance
 // cache only); the caller inserts P (q_insert) and runs the dictionary probe.
-DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool want, uint32_t P, QIns& ins) {
+DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool want, uint32_t P, QIns& ins,
+                     DictAhead* dict_ahead = nullptr) {
   const int t = q_t();
   const int ndist = J.ndist;
   const uint32_t max_length = g.pos_end - P;
@@ -473,6 +484,8 @@ DEV QResult q_search(const JobParams& J, const DeviceTables* T, QShard& g, bool 
   const uint32_t d_prev = P - backward;
   const B32 pd = load_b32(g.data + (d_cand ? d_prev : (want ? P : 0u)));
   const KeyTag kt = hash_pos(cur32.q[0], J.hasher_type, J.bucket_bits);
+  // attached dictionaries: the first chunk's key range and items travel beside the bucket record (k_dict.h)
+  if (dict_ahead != nullptr && g.cd != nullptr) *dict_ahead = dict_ahead16(g.cd, want && g.role == 0, cur32.q[0]);
 #if defined(Q_PROFILE)
   if (wave_any(want && kt.key == 0x7FFFFFFFu)) g.pf_acc++;   // (profiling fence: bytes at P consumed)
 #endif
@@ -732,8 +745,8 @@ DEV void q_setup_extend(const JobParams& J, QShard& g, bool want) {
   const int t = q_t();
   const uint32_t htl = hasher_htl(J.hasher_type);
   uint32_t bytes = g.blk_bytes, pos = g.blk_pos;
-  bool ext = false;
-  uint32_t cmd_dist = 0;
+  bool ext = false, dext = false;
+  uint32_t cmd_dist = 0, dext_max = 0;
   Command last;
   last.insert_len = last.copy_len = last.dist_extra = 0;
   last.cmd_prefix = last.dist_prefix = 0;
@@ -758,7 +771,13 @@ DEV void q_setup_extend(const JobParams& J, QShard& g, bool want) {
     }
     const bool code_ok = distance_code < 16u || distance_code - 15u == cmd_dist;
     ext = code_ok && g.dc[0] > 0 && cmd_dist <= max_distance;
+    dext = code_ok && !ext && cmd_dist > max_distance;     // (encode.c:930-961: the copy continues inside the attached dictionary)
+    dext_max = max_distance;
     if (!code_ok) last.insert_len = 0xFFFFFFFFu;   // marker: leave the command alone
+  }
+  if (g.cd) {
+    const uint32_t gained = compound_extend16(g.cd, dext, g.data + pos, bytes, cmd_dist, dext_max, last.copy_len & 0x1FFFFFFu);
+    if (dext) { last.copy_len += gained; bytes -= gained; pos += gained; }
   }
   bool running = ext;
   while (wave_any(running)) {
@@ -818,7 +837,7 @@ DEV void q_commit(const JobParams& J, QShard& g, bool commit, uint32_t htl) {
 #endif
   }
   g.apply_random_heuristics = g.position + 2u * g.sr_len + J.spree_window;
-  const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit);
+  const uint32_t dictionary_start = umin(g.position + g.stream_offset, J.max_backward_limit) + g.gap;
   const uint32_t distance_code = compute_distance_code(g.sr_dist, dictionary_start, g.dc);
   if (g.sr_dist <= dictionary_start && distance_code > 0) {
     g.dc[3] = g.dc[2]; g.dc[2] = g.dc[1]; g.dc[1] = g.dc[0]; g.dc[0] = (int32_t)g.sr_dist;
@@ -896,7 +915,7 @@ DEV uint32_t q_groups_per_wave(const JobParams& J) {
 // ---- the kernel body: up to four shards per wave ---------------------------------------
 DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* states,
                       uint32_t nshards, const DeviceTables* T, const uint8_t* input, uint8_t* ws,
-                      uint32_t wave_index, uint8_t* lds_dup) {
+                      uint32_t wave_index, uint8_t* lds_dup, const CompoundDict* cd = nullptr) {
   const int t = q_t();
   const uint32_t gpw = q_groups_per_wave(J);
   const bool duo = (J.flags & JOB_FLAG_DUO) != 0;          // gpw <= 2: a shard owns two groups
@@ -917,6 +936,8 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
   g.wsb = ws;
   g.shard = alive ? shard : 0u;
   g.stream_offset = D.stream_offset;
+  g.cd = cd;
+  g.gap = cd ? cd->total_size : 0u;
   regs_load(g.r, S0);
   for (int i = 0; i < 4; ++i) g.dc[i] = S0->dist_cache[i];
   g.dict_lookups = S0->dict_lookups;
@@ -954,7 +975,9 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
       const uint32_t P0 = g.position + (g.state == Q_LAZY ? 1u : 0u);
       const uint32_t P = P0 + g.role;
       QIns ins;
-      QResult mine = q_search(J, T, g, want, P, ins);
+      DictAhead dahead;
+      dahead.s0 = dahead.n = dahead.off0 = dahead.off1 = 0;
+      QResult mine = q_search(J, T, g, want, P, ins, &dahead);
       uint64_t qt = QP_NOW();
       q_insert(g, want && g.role == 0, P, ins);
       wave_sync();
@@ -962,6 +985,8 @@ DEV void parse4_round(const JobParams& J, const ShardDesc* shards, ShardState* s
       // static dictionary when nothing was found (hash.h:179-202); its two counters are
       // stream state, so the scout probes after the primary and continues from its counts
       q_dict_search(J, T, g, want && g.role == 0 && mine.score == K_MIN_SCORE, P, g.pos_end - P, mine);
+      // attached dictionaries (backward_references_inc.h:115-119, 147-152; the planner gives such jobs no scout groups)
+      q_compound_lookup16(J, g, want && g.role == 0, P, g.pos_end - P, mine, dahead);
       QResult r0 = mine, r1 = mine;
       bool r1_ok = false;
       uint32_t dl1 = 0, dm1 = 0;

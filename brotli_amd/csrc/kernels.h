@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(64) k_parse(JobArgs a) {
 // grid = ceil(nshards / 4), block = 64: four shards per wave.
 __global__ void __launch_bounds__(64, PARSE4_WAVES) k_parse4(JobArgs a) {
   __shared__ uint8_t lds_dup[Q_GROUPS * Q_DUP_SLOTS];
-  parse4_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_dup);
+  parse4_round(a.J, a.shards, a.states, a.nshards, a.T, a.input, a.ws, blockIdx.x, lds_dup, a.cd);
   const uint32_t gpw = q_groups_per_wave(a.J);
   const bool duo = (a.J.flags & JOB_FLAG_DUO) != 0;
   const uint32_t gi = (threadIdx.x >> 4) >> (duo ? 1 : 0);

@@ -171,8 +171,9 @@ int brotli_amd_encode_host(BrotliAmdCtx* c, const uint8_t* in, uint64_t len, con
                             p->is_last != 0, &plan, true, (int)((p->flags >> BROTLI_AMD_FLAG_LGBLOCK_SHIFT) & 31u)))
     return set_err(c, "parameters outside the GPU path", BROTLI_AMD_UNSUPPORTED);
   uint32_t lim = 0;
-  // (a dictionary on the context: one shard per wave on the hash-table kernels, as hip_layer.hip does)
-  if (!plan_choose_kernels(&plan, p->flags | (c->dict.have ? 2u : 0u), 256, &lim)) return set_err(c, "shard too long", BROTLI_AMD_UNSUPPORTED);
+  // (a dictionary on the context: the hash-table kernels, no scout groups, as hip_layer.hip does)
+  if (!plan_choose_kernels(&plan, p->flags, 256, &lim)) return set_err(c, "shard too long", BROTLI_AMD_UNSUPPORTED);
+  if (c->dict.have) plan.J.flags &= ~(uint32_t)JOB_FLAG_DUO;
   const long n = run_plan_on_sim(c, plan, in, (size_t)len, out, (size_t)out_cap);
   if (n == -4) return set_err(c, "output capacity too small", BROTLI_AMD_OVERFLOW);
   if (n < 0) return set_err(c, "device fault", BROTLI_AMD_DEVICE_FAULT);

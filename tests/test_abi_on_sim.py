@@ -155,6 +155,25 @@ def test_attached_dictionaries_in_a_partition_plan(simabi, ref, oracle, quality,
     assert len(want) < len(plain)
 
 
+@pytest.mark.parametrize("groups", [4, 2])
+def test_dictionary_plan_on_the_four_shards_per_wave_kernel(simabi, ref, monkeypatch, groups):
+    """Quality 5 with dictionaries in a plan runs on k_parse4 since round 6 (compound_lookup16: a 16-lane group per
+    shard looks the dictionaries up; until then one shard per wave on k_parse): four and two shards per wave, each
+    group at a position of its own — shards of different lengths, three chunks, a copy that runs on into the
+    dictionary across a block boundary (ExtendLastCommand's dictionary branch), next to the reference driven with the
+    same plan."""
+    monkeypatch.setenv("BROTLI_AMD_QGROUPS", str(groups))
+    for seed, n, dbytes, nchunks, shard in ((3, 300000, 90000, 3, 40000), (4, 200000, 30000, 1, 1 << 16)):
+        data, chunks = G.dictionary_case(n, dbytes, nchunks, seed=seed)
+        # a stretch of the first chunk, longer than a block boundary can cut, in the middle of the input
+        data = data[:131000] + bytes(chunks[0][100:3100]) + data[131000:]
+        want = ref.encode_plan(data, 5, 22, shard, dictionaries=chunks)
+        assert ref.decompress_with(want, len(data), chunks) == data
+        params = ((1, 5), (2, 22), (5, len(data)), (0x4D490001, shard))
+        got, fin = drive(simabi, data, [(len(data), 2)], params, dictionaries=chunks)
+        assert fin and got == want, (groups, seed)
+
+
 def test_large_dictionary_wider_index_and_saturated_keys(simabi, stock):
     """A dictionary past 2 MiB gets a wider index (one more key bit per doubling, compound_dictionary.c:
     163-170) and a run of repeats fills keys past their 32 entries (only the newest 32 stay); the
