@@ -158,12 +158,17 @@ DEV void compound_lookup(const CompoundDict* cd, const uint8_t* cur, uint32_t cu
       out.score = best_score;
     }
     if (best_len < 3) best_len = 3;
-    for (uint32_t t = 0; t < n_items; ++t) {                        // hash.h:599-633
-      const uint32_t off_t = wave_bcast(offset, (int)t);
-      const uint32_t len_t = wave_bcast(len, (int)t);
-      const uint32_t limit_t = wave_bcast(limit, (int)t);
+    // (only the items that can change anything are visited, in order: four bytes long, inside the distance limit, with
+    //  a score above the one the walk starts with — the best score never falls, the other conditions have no side effect)
+    uint64_t worth = wave_ballot(lane < 32 && cand && len >= 4u && distance_offset - offset <= max_distance &&
+                                 1920u + 135u * len - 30u * log2floor(distance_offset - offset) > best_score);
+    while (worth != 0ull) {                                         // hash.h:599-633
+      const int t = dev_ctz64(worth);
+      worth &= worth - 1ull;
+      const uint32_t off_t = wave_bcast(offset, t);
+      const uint32_t len_t = wave_bcast(len, t);
+      const uint32_t limit_t = wave_bcast(limit, t);
       const uint32_t distance = distance_offset - off_t;
-      if (distance > max_distance) continue;
       if (cur_masked + best_len > ring_mask || best_len >= limit_t) continue;
       if (len_t <= best_len) {
         // the gate compares the four bytes ending at best_len: a candidate that differs at or
