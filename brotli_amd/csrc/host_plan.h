@@ -230,7 +230,10 @@ static inline bool plan_stream(uint64_t len, int lgwin, uint32_t size_hint, uint
                                JobPlan* plan, uint64_t* ix_region_bytes = nullptr) {
   if (size_hint == 0) size_hint = len >= (1u << 30) ? (1u << 30) : (uint32_t)len;
   if (!plan_params(5, lgwin, size_hint, &plan->J)) return false;
-  if (lgwin < 17 || lgwin > 22) return false;          // (entries hold 24-bit positions of a chunk and its look-back)
+  // (entries hold 24-bit positions of a chunk and its look-back: two windows up to lgwin 23; at lgwin 24 — what the
+  //  CLI chooses for every file above 8 MiB, c/tools/brotli.c:1434-1447 — a stream that fits ONE chunk, i.e. the window)
+  if (lgwin < 17 || lgwin > 24) return false;
+  if (lgwin == 24 && len > (1ull << 24)) return false;
   if (len >= (1ull << 31)) return false;
   JobParams& J = plan->J;
   const uint32_t tl = (uint32_t)J.lgblock;

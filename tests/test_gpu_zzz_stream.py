@@ -49,6 +49,23 @@ def test_text_longer_than_the_window(amd, stock, mib, lgwin, seed):
     assert got == want
 
 
+@pytest.mark.parametrize("nbytes,lgwin,seed", [((6 << 20) + 777, 23, 31), ((12 << 20) + 5, 24, 32), (1 << 24, 24, 33),
+                                               ((1 << 24) - 16, 24, 34), ((40 << 20) + 99, 23, 35), ((5 << 20), 24, 36),
+                                               ((16 << 20) + 4321, 23, 37)])
+def test_the_windows_the_cli_chooses(amd, stock, nbytes, lgwin, seed):
+    """lgwin 23 / 24 — what the reference's CLI picks by itself for a file above 4 MiB / 8 MiB (c/tools/brotli.c:1434-1447).
+    An index chunk with its look-back is two windows of 24-bit positions: every length at lgwin 23 (2.4 and 5 laps of
+    the 16 MiB ring here), and at lgwin 24 the streams that fit one chunk — a file up to 16 MiB, i.e. every file for which
+    the CLI's choice of 24 still covers the whole file.  Longer streams at lgwin 24 stay on the serial device stream."""
+    data = bytes(G.enwik_text(nbytes, seed=seed))
+    got, dt = one_shot(amd, data, lgwin)
+    want, _ = one_shot(stock, data, lgwin)
+    assert got == want
+    got, dt = one_shot(amd, data, lgwin)
+    print("lgwin %d, %.1f MiB: %.3f s = %.0f MB/s" % (lgwin, nbytes / 1048576.0, dt, nbytes / 1e6 / dt))
+    assert dt < 1.5           # (the serial device stream: ~2 MB/s)
+
+
 @pytest.mark.parametrize("mib,piece_kb,seed,tail", [(40, 1024, 11, 4321), (24, 64, 12, 4321), (64, 1024, 13, 0), (40, 64, 14, 0), (88, 1024, 15, 0)])
 def test_process_fed_stream_without_a_size_hint(amd, stock, mib, piece_kb, seed, tail):
     """What Compressor.process of the Python module (or the CLI on a pipe) does: PROCESS calls of 1 MiB / 64 KiB, no
@@ -149,6 +166,15 @@ def test_reference_cli_on_a_big_file(tmp_path):
     got = subprocess.run([cli, "-q", "5", "-w", "22", "-c", str(src)], capture_output=True, env=env, check=True).stdout
     want = subprocess.run([cli_ref, "-q", "5", "-w", "22", "-c", str(src)], capture_output=True, check=True).stdout
     assert got == want
+    # no -w: the CLI chooses lgwin 24 for a file of 8 ... 16 MiB (and 23 for 4 ... 8 MiB), which still covers the file
+    for n in (13 << 20, (7 << 20) + 31):
+        src.write_bytes(bytes(G.enwik_text(n, seed=78)))
+        t = time.time()
+        got = subprocess.run([cli, "-q", "5", "-c", str(src)], capture_output=True, env=env, check=True).stdout
+        dt = time.time() - t
+        want = subprocess.run([cli_ref, "-q", "5", "-c", str(src)], capture_output=True, check=True).stdout
+        assert got == want
+        assert dt < 20.0      # (process start + context creation included; the serial stream needs ~2 MB/s)
 
 
 def run_isolated(args, timeout_s, env=None):
