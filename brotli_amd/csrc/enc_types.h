@@ -53,7 +53,7 @@ struct JobParams {
   uint32_t flush_symbols;       // qualities 2 - 3: a meta-block is cut once literals + commands reach this (encode.c:1150-1153); 0 = never
   uint32_t tile_log2;           // JOB_FLAG_TILED: log2 of the bytes of a chain tile (a multiple of the input block), k_chain.h
   uint32_t tile_warm;           //   bytes before a tile's first block that its speculative parse starts from
-  uint32_t chunk_log2;          // JOB_FLAG_STREAMT: log2 of the bytes of an index chunk (>= lgwin: a chunk's look-back covers the window)
+  uint32_t chunk_log2;          // JOB_FLAG_STREAMT: log2 of the bytes of an index chunk (lgwin: a chunk's look-back covers the window; lgwin - 1: IxGeom::older)
   uint32_t nchunks;
   uint64_t sbm_off;             // JOB_FLAG_STREAMT: the stream's three position bitmaps (unstored / as last seen / events), workspace offset
   uint64_t sbm_stride;          //   and the bytes of one of them

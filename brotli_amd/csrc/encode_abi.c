@@ -426,7 +426,7 @@ static int wants_stream_tiles(const BrotliEncoderState* s, int op) {
   return s->quality == 5 && s->shard_bytes == 0 && op == OP_FINISH && s->submitted == 0 && !s->stream && s->ndicts == 0 &&
          s->stream_offset == 0 && eff_lgblock(s) == 16 &&
          s->lgwin >= 17 && s->lgwin <= 24 && s->in_len > ((size_t)1 << (s->lgwin < 22 ? s->lgwin : 22)) - 16 &&
-         s->in_len < ((size_t)1 << 31) && (s->lgwin < 24 || s->in_len <= ((size_t)1 << 24));
+         s->in_len < ((size_t)1 << 31);
 }
 
 /* Hands everything buffered to the device and applies `op` (1 flush, 2 finish). */
@@ -548,10 +548,8 @@ static size_t feed_threshold(const BrotliEncoderState* s) {
        stream as before. */
     const size_t cap_mb = s->env_hold_mb >= 0 ? (size_t)s->env_hold_mb : 1024u;
     if (s->env_stream_tiles != 0 && cap_mb != 0) {
-      /* (lgwin 24: the tiled path takes a stream that fits the window — 16 MiB — and nothing longer, host_plan.h plan_stream) */
-      const size_t most = s->lgwin == 24 ? ((size_t)1 << 24) : (size_t)-1;
-      if (s->size_hint == 0) return (cap_mb << 20) <= most ? cap_mb << 20 : most + 1u;
-      if (((size_t)s->size_hint >> 20) < cap_mb && (size_t)s->size_hint <= most) return (size_t)s->size_hint + 1u;
+      if (s->size_hint == 0) return cap_mb << 20;
+      if (((size_t)s->size_hint >> 20) < cap_mb) return (size_t)s->size_hint + 1u;
     }
   }
   if (kb == 0) kb = 1;

@@ -231,9 +231,9 @@ static inline bool plan_stream(uint64_t len, int lgwin, uint32_t size_hint, uint
   if (size_hint == 0) size_hint = len >= (1u << 30) ? (1u << 30) : (uint32_t)len;
   if (!plan_params(5, lgwin, size_hint, &plan->J)) return false;
   // (entries hold 24-bit positions of a chunk and its look-back: two windows up to lgwin 23; at lgwin 24 — what the
-  //  CLI chooses for every file above 8 MiB, c/tools/brotli.c:1434-1447 — a stream that fits ONE chunk, i.e. the window)
+  //  CLI chooses for every file above 8 MiB, c/tools/brotli.c:1434-1447 — one chunk for a stream that fits the window,
+  //  chunks of half a window for a longer one: below)
   if (lgwin < 17 || lgwin > 24) return false;
-  if (lgwin == 24 && len > (1ull << 24)) return false;
   if (len >= (1ull << 31)) return false;
   JobParams& J = plan->J;
   const uint32_t tl = (uint32_t)J.lgblock;
@@ -242,7 +242,13 @@ static inline bool plan_stream(uint64_t len, int lgwin, uint32_t size_hint, uint
   J.tile_log2 = tl;
   J.tile_warm = warm_bytes < 256u ? 256u : warm_bytes > (1u << tl) / 2u ? (1u << tl) / 2u : warm_bytes;
   J.chunk_log2 = (uint32_t)lgwin;
-  const uint64_t C = 1ull << J.chunk_log2;
+  // lgwin 24 and longer than one chunk: chunks of HALF a window (2^23 own positions + 2^23 of look-back = 24 bits).  The
+  // searches with fewer than 16 same-key entries before them in their chunk — the only ones whose ring can hold something
+  // from below the chunk — are the chain's, which goes on in the chunk before (k_index.h IxGeom::older, k_chain.h
+  // c_search_exact, k_tile.h stream_events).  BROTLI_AMD_HALF_CHUNKS=1: the same for every window (tests: the simulator
+  // cannot run streams of several 16 MiB windows).
+  if (lgwin == 24 && len > (1ull << 24)) J.chunk_log2 = 23u;
+  if (const char* e = getenv("BROTLI_AMD_HALF_CHUNKS")) { if (atoi(e) == 1 && lgwin - 1 >= (int)tl) J.chunk_log2 = (uint32_t)lgwin - 1u; }  const uint64_t C = 1ull << J.chunk_log2;
   J.nchunks = (uint32_t)((len + C - 1) / C);
   J.flags |= JOB_FLAG_INDEXED | JOB_FLAG_TILED | JOB_FLAG_STREAMT | JOB_FLAG_QUAD;
   J.log2_lut_size = J.max_metablock_size + 2u;

@@ -40,6 +40,12 @@ struct CShard {
   uint64_t* res;
   const uint32_t* srt;
   uint32_t ibase;        // position of the local position 0 of `srt`'s entries (a stream's index chunk; 0 otherwise)
+  // a stream whose chunks are shorter than the window (IxGeom::older): the chunk before this one — its sorted array,
+  // its base and its key table (k_index_layout.h SKT_*) — where an exact search goes on once the key run of its own
+  // chunk is used up; null otherwise
+  const uint32_t* srt_old;
+  const uint32_t* kt_old;
+  uint32_t ibase_old;
   uint8_t* skip;         // bit (x - geo.first): storable position x was NOT stored by the parse
   uint32_t frontier;     // every storable position below it is either stored or marked in `skip`
   uint32_t nslow;
@@ -331,6 +337,37 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
       if (sidx - (int32_t)j0 <= count_from) counted = true;     // everything from count_from up is in
     }
   }
+  {
+    // The key run of this chunk is used up and the ring is not full: the entries of the key below the chunk's base
+    // are the part of the run of the chunk before that lies in ITS look-back (run start, run length and own-part length
+    // from its key table), newest last.  Entries beyond the window end the walk: everything behind them is older.
+    // scratch[] takes their indices with bit 31 set.
+    const uint32_t nk = 1u << J.bucket_bits;
+    bool more = want && C.srt_old != nullptr && found < 16u;      // (the groups of a wave parse tiles of different chunks)
+    uint32_t rs2 = 0, n2 = 0;
+    if (more) {
+      rs2 = C.kt_old[SKT_RS * nk + kt.key];
+      n2 = C.kt_old[SKT_RL * nk + kt.key] - C.kt_old[SKT_OWN * nk + kt.key];
+    }
+    uint32_t j2 = 0;
+    while (wave_any(more && j2 < n2)) {
+      const bool on = more && j2 < n2;
+      const bool ok = on && j2 + (uint32_t)t < n2;
+      const uint32_t idx2 = rs2 + n2 - 1u - (j2 + (uint32_t)t);
+      const uint32_t q = ok ? (C.srt_old[idx2] & 0xFFFFFFu) + C.ibase_old : 0u;
+      const bool inwin = ok && P - q <= max_backward;
+      const bool stored = inwin && !(((C.mode & C_VIEW_ALL) != 0 || q >= C.tile_lo) && c_skipped(C, q));
+      const uint32_t s16 = q_mask16(wave_ballot(stored));
+      const uint32_t out16 = q_mask16(wave_ballot(ok && !inwin));
+      const uint32_t slot = found + (uint32_t)__builtin_popcount(s16 & ((1u << t) - 1u));
+      if (stored && slot < 16u) scratch[slot] = idx2 | 0x80000000u;
+      if (on) {
+        found += (uint32_t)__builtin_popcount(s16);
+        j2 += 16u;
+        if (found >= 16u || out16 != 0u) more = false;
+      }
+    }
+  }
   wave_sync();
   if (want && danger && t == 0) { scratch[16] = kt.key; scratch[17] = (uint32_t)sidx; scratch[18] = total; }
   if (want && danger && (C.mode & C_TILED) != 0) C.mode |= C_BAD;      // (the carried store count is a serial matter)
@@ -339,8 +376,10 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   uint32_t nvalid = umin(found, 16u);
   if (danger) { const uint32_t n = total & 0xFFFFu; nvalid = n < 16u ? n : 16u; }
   if (sdanger) nvalid = umin(nvalid, svis);
-  const uint32_t w0 = (uint32_t)t < nvalid ? C.srt[scratch[t]] : 0u;
-  const uint32_t b_prev = (w0 & 0xFFFFFFu) + C.ibase;
+  const uint32_t sc = (uint32_t)t < nvalid ? scratch[t] : 0u;
+  const bool from_old = (sc >> 31) != 0u;                       // (set only where C.srt_old exists)
+  const uint32_t w0 = (uint32_t)t < nvalid ? (from_old ? C.srt_old[sc & 0x7FFFFFFFu] : C.srt[sc]) : 0u;
+  const uint32_t b_prev = (w0 & 0xFFFFFFu) + (from_old ? C.ibase_old : C.ibase);
   const bool b_cand = want && (uint32_t)t < nvalid && (w0 >> 24) == kt.tag && (P - b_prev) <= max_backward;
   wave_sync();
   uint32_t b_len = 0, d_len = 0;
@@ -1012,6 +1051,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   for (int i = 0; i < 12; ++i) g.prof[i] = 0;
   g.state = (alive && !S0->done && !S0->mb_valid && !S0->error) ? Q_PRE : Q_DONE;
   C.geo = ix_geom(J, D);
+  C.srt_old = nullptr; C.kt_old = nullptr; C.ibase_old = 0;
   IxLayout L;
   uint8_t* evb;                                        // the event bitmap (sweeps)
   if (tiled && (J.flags & JOB_FLAG_STREAMT) != 0) {
@@ -1023,6 +1063,16 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
     C.res = (uint64_t*)(ixb + L.res) - K.ix_base;
     C.srt = (const uint32_t*)(ixb + L.srt);
     C.ibase = K.ix_base;
+    if (J.chunk_log2 < (uint32_t)J.lgwin && K.ix_base != 0u) {
+      // (chunks of half a window: chunk cj - 1 holds what lies between the window's far end and this chunk's base)
+      const uint32_t cj = umin(lo >> J.chunk_log2, J.nchunks - 1u);
+      const ShardDesc& K2 = chunks[cj - 1u];
+      IxLayout L2;
+      ix_layout(K2.len, J.ix_slices, J.ix_nb_log2, &L2);
+      C.srt_old = (const uint32_t*)(ws + K2.ix_off + L2.srt);
+      C.ibase_old = K2.ix_base;
+      C.kt_old = (const uint32_t*)(ws + J.skt_off + (uint64_t)(cj - 1u) * skt_chunk_bytes((uint32_t)J.bucket_bits));
+    }
     C.skip = ws + J.sbm_off;
     evb = ws + J.sbm_off + 2u * J.sbm_stride;
     if (D.len > J.ring_mask) g.ring_mask = J.ring_mask;

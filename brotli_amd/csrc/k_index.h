@@ -49,10 +49,15 @@
 // positions [0, len): the index kernels work in local positions (24 bits in an entry) and ask these functions about
 // local + base; [0, own) is the chunk's look-back (candidates for the searches from `own` on, not searched itself —
 // the chunk before this one searches them).
-struct IxGeom { uint32_t n, first, lgblock, htl, len, base, own, ownc, maxdist, ring_mask; bool stream; };
+// `older`: the chunk's look-back is shorter than the window (chunk_log2 < lgwin: a stream at lgwin 24, whose chunks are
+// half a window so that a chunk with its look-back stays within 24-bit positions) — a search with fewer than 16
+// same-key entries before it in the chunk may have candidates below the chunk's base: the chain's to do (k_chain.h,
+// c_search_exact goes on in the chunk before).
+struct IxGeom { uint32_t n, first, lgblock, htl, len, base, own, ownc, maxdist, ring_mask; bool stream, older; };
 DEV IxGeom ix_geom(const JobParams& J, const ShardDesc& D) {
   IxGeom g;
   g.stream = D.ix_glen != 0u;
+  g.older = g.stream && J.chunk_log2 < (uint32_t)J.lgwin && D.ix_base != 0u;
   g.n = g.stream ? D.ix_glen : D.len;
   g.len = D.len;
   g.base = D.ix_base;
@@ -425,10 +430,14 @@ DEV uint32_t ix_prepare(const IxGeom& g, const IxLds& S, uint32_t x, bool act, u
   // (a stream: what the 16-bit counter hides depends on the stores since the stream's start — k_tile.h finds those
   //  positions once the chunks before this one are parsed)
   const bool danger = !STREAM && rank >= 65520u;
-  const uint32_t word = x | (umin(nsucc, 16u) << IXW_NSUCC_SHIFT) | ((!STREAM && rank <= 16u) ? IXW_FULLRUN : 0u) |
+  // (STREAM, g.older: fewer than 16 same-key entries before it here and a window that reaches below the chunk — the
+  //  word's IXW_FULLRUN bit, which a stream does not use, carries it to ix_search_block; res[] gets IX_KIND_SLOW)
+  const bool older = STREAM && g.older && search && rank < 16u && P - maxb < g.base;
+  const uint32_t word = x | (umin(nsucc, 16u) << IXW_NSUCC_SHIFT) | (((!STREAM && rank <= 16u) || older) ? IXW_FULLRUN : 0u) |
                         (danger ? IXW_DANGER : 0u) | (mask << 16);
   if (!act) return IXW_NONE;
   if (mask == 0u) {
+    if (older) { res[p] = ix_res_word(IX_KIND_SLOW, 0u, 0u, sidx, word & ~IXW_FULLRUN); return IXW_NONE; }
 #if defined(IX_NTRES)     // (experiment: streaming stores)
     __builtin_nontemporal_store(ix_res_word(search && danger ? IX_KIND_SLOW : IX_KIND_NONE, 0u, 0u, sidx, word), &res[p]);
 #elif defined(IX_RES4X)    // (timing experiments only: results are wrong)
@@ -589,7 +598,8 @@ DEV void ix_search_block(const IxGeom& g, const uint8_t* data, const IxLds& S, u
     if (act) {
       const bool danger = (word & IXW_DANGER) != 0u;
       uint32_t kind, key = 0;
-      if (danger || ringrisk || ncapped >= 2u) kind = IX_KIND_SLOW;
+      const bool older = STREAM && (word & IXW_FULLRUN) != 0u;
+      if (danger || ringrisk || ncapped >= 2u || older) kind = IX_KIND_SLOW;
       else if (ncapped == 1u) {
         // the long candidate's score can only grow with its real length
         if (cap_key > best) { kind = IX_KIND_LONG; key = cap_key; }
@@ -610,7 +620,7 @@ DEV void ix_search_block(const IxGeom& g, const uint8_t* data, const IxLds& S, u
 #elif defined(IX_NORES)       // (timing experiments only: results are wrong)
       { const uint64_t v_ = ix_res_word(kind, len, dist, sbase + x, word); if ((uint32_t)v_ == 0x12345u) res[p] = v_; }
 #else
-      res[p] = ix_res_word(kind, len, dist, sbase + x, word);
+      res[p] = ix_res_word(kind, len, dist, sbase + x, STREAM ? word & ~IXW_FULLRUN : word);
 #endif
     }
     IX_LAP(7);

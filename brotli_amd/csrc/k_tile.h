@@ -494,6 +494,7 @@ DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* 
       const uint32_t x = i * 32u + (uint32_t)dev_ctz32(diff);
       const uint32_t key = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits).key;
       const uint32_t xt = (J.flags & JOB_FLAG_SWEEP) ? 0xFFFFFFFFu : x >> J.tile_log2;
+      uint32_t stored = 0;
       for (uint32_t c = cj; c <= cj + 1u && c < J.nchunks; ++c) {
         const ShardDesc& K = chunks[c];
         IxLayout L;
@@ -503,10 +504,30 @@ DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* 
         const uint64_t* res = (const uint64_t*)(kb + L.res);
         const uint32_t total = ((const uint32_t*)(kb + L.cnt))[J.ix_slices << J.ix_nb_log2];
         const uint32_t s = (uint32_t)(res[x - K.ix_base] >> 32) & 0xFFFFFFu;
-        uint32_t stored = 0;
+        stored = 0;
         for (uint32_t j = s + 1u; j < total && stored < 16u; ++j) {
           const uint32_t q = (srt[j] & 0xFFFFFFu) + K.ix_base;
           if (hash_pos(ld64(data + q), J.hasher_type, J.bucket_bits).key != key) break;
+          if ((q >> J.tile_log2) != xt) glb_atomic_or(&ev[q >> 5], 1u << (q & 31u));
+          if (!((skip[q >> 5] >> (q & 31u)) & 1u)) ++stored;
+        }
+      }
+      if (J.chunk_log2 < (uint32_t)J.lgwin && cj + 2u < J.nchunks && stored < 16u) {
+        // chunks of half a window: the key run of chunk cj + 1 ended before 16 stored successors were seen — the
+        // searches of chunk cj + 2's own part that still have x in their ring do not find x in their chunk (they are
+        // exact searches that go on in the chunk before theirs: k_index.h IxGeom::older, k_chain.h c_search_exact);
+        // the walk goes on through the own part of the key's run there, as far as the window reaches
+        const ShardDesc& K = chunks[cj + 2u];
+        IxLayout L;
+        ix_layout(K.len, J.ix_slices, J.ix_nb_log2, &L);
+        const uint32_t* srt = (const uint32_t*)(ws + K.ix_off + L.srt);
+        const uint32_t* kt = (const uint32_t*)(ws + J.skt_off + (uint64_t)(cj + 2u) * skt_chunk_bytes((uint32_t)J.bucket_bits));
+        const uint32_t nk = 1u << J.bucket_bits;
+        const uint32_t rl = kt[SKT_RL * nk + key], own = kt[SKT_OWN * nk + key];
+        const uint32_t j0 = kt[SKT_RS * nk + key] + rl - own;
+        for (uint32_t j = j0; j < j0 + own && stored < 16u; ++j) {
+          const uint32_t q = (srt[j] & 0xFFFFFFu) + K.ix_base;
+          if (q - x > J.max_backward_limit) break;
           if ((q >> J.tile_log2) != xt) glb_atomic_or(&ev[q >> 5], 1u << (q & 31u));
           if (!((skip[q >> 5] >> (q & 31u)) & 1u)) ++stored;
         }

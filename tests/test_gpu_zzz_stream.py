@@ -198,6 +198,34 @@ def test_stock_call_between_the_sizes(mib):
     assert rc == 0 and lines and lines[-1].get("bytes_equal_reference") is True, (rc, lines[-2:], err)
 
 
+@pytest.mark.parametrize("mib,lgwin,kind,env", [(40, 24, "text", None), (100, 24, "text", None), (40, 24, "mix", None),
+                                                 (48, 22, "text", {"BROTLI_AMD_HALF_CHUNKS": "1"}),
+                                                 (20, 19, "mix", {"BROTLI_AMD_HALF_CHUNKS": "1"})])
+def test_lgwin_24_longer_than_the_window(mib, lgwin, kind, env):
+    """What the CLI does to every file above 16 MiB: lgwin 24 and a stream longer than the window.  A chunk with its
+    look-back has to stay within 24-bit positions, so the chunks are HALF a window there (host_plan.h plan_stream): a
+    search with fewer than 16 same-key entries before it in its chunk is the chain's, which goes on in the chunk before
+    (k_index.h IxGeom::older, k_chain.h c_search_exact, k_tile.h stream_events).  BROTLI_AMD_HALF_CHUNKS=1 runs the
+    smaller windows the same way.  Each next to the reference library, in a process of its own."""
+    rc, lines, err = run_isolated([mib, lgwin, kind, 2, "--ref"], 600, env=env)
+    rec = lines[-1] if lines else {}
+    print(json.dumps(rec))
+    assert rc == 0 and rec.get("bytes_equal_reference") is True, (rc, lines[-2:], err)
+    if kind == "text":
+        assert rec["MBps_best"] > 100.0      # (the serial device stream: ~2 MB/s; the mix settles in ~17 passes at any window: ~8 MB/s)
+
+
+def test_1gib_cli_default_window():
+    """`brotli -q 5 file` of a 1 GiB file = BrotliEncoderCompress(5, 24): bytes of the reference (sha256)."""
+    rc, lines, err = run_isolated([1024, 24, "text", 2, "--ref"], 900)
+    rec = lines[-1] if lines else {}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "stock_call_1GiB_lgwin24.json"), "w") as f:
+        json.dump({"rc": rc, "lines": lines, "stderr_tail": err[-500:]}, f)
+    print(json.dumps(rec))
+    assert rc == 0 and rec.get("bytes_equal_reference") is True, (rc, lines[-2:], err)
+
+
 def test_1gib_stock_call():
     """The metric's own call: BrotliEncoderCompress(5, 22) of 1 GiB with no vendor setting, byte-identical to the
     reference's (sha256), timed from the host buffer to the host buffer (PCIe both ways included); the second call
