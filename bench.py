@@ -351,7 +351,7 @@ def cpu_baseline(path, nbytes, quality, lgwin, shard_size, size_hint, reps=5, ot
 # Whatever happens in one of them — a GPU fault, a lost context, a timeout — the headline line is on stdout already
 # and the parent prints the line again, enriched with what did come back (round 4's driver run
 # ended without a line because the only print came after all of these).
-LEG_TIMEOUT_S = {"round_trip": 150, "abi": 150, "stock": 90, "stock_whole": 200, "process_fed": 150}
+LEG_TIMEOUT_S = {"round_trip": 150, "abi": 150, "stock": 90, "stock_whole": 200, "process_fed": 150, "concurrent": 90}
 
 
 def _bind_encoder(lib_path):
@@ -540,7 +540,59 @@ def leg_process_fed(path, quality, lgwin, piece_kb, max_mb):
     return res
 
 
-LEGS = {"abi": leg_abi, "stock": leg_stock, "stock_whole": leg_stock_whole, "round_trip": leg_round_trip, "process_fed": leg_process_fed}
+def leg_concurrent(path, quality, lgwin, mib, threads, calls):
+    """T caller threads, each making stock one-shot calls of `mib` MiB on an encoder instance of its own (the library
+    lends each a device context with its own HIP stream): what a server compressing many files at once does.  One call of
+    a few MiB is a string of small latency-bound kernels; the device is filled by having many in flight (the library
+    asks the HIP runtime for 32 hardware queues, hip_layer.hip env_read).  Aggregate rate, sha256 of every thread's last
+    output against the reference library's."""
+    import hashlib
+    import threading
+    n = (mib << 20) - 16
+    with open(path, "rb") as f:
+        datas = [f.read(mib << 20)[:n] for _ in range(min(threads, 8))]
+    os.environ.pop("BROTLI_AMD_SHARD_KB", None)
+    L = _bind_encoder(DROPIN)
+    cap = L.BrotliEncoderMaxCompressedSize(n)
+    want = None
+    try:
+        from refharness import Ref, have_ref
+        if have_ref():
+            r = Ref()
+            want = [hashlib.sha256(r.compress(d, quality, lgwin)).hexdigest() for d in datas]
+    except Exception:
+        want = None
+    outs = [C.create_string_buffer(cap) for _ in range(threads)]
+    bad = []
+
+    def work(k, reps):
+        for rep in range(reps):
+            sz = C.c_size_t(cap)
+            ok = L.BrotliEncoderCompress(quality, lgwin, 0, n, datas[k % len(datas)], C.byref(sz), outs[k])
+            if not ok or (want is not None and rep == reps - 1 and
+                          hashlib.sha256(outs[k].raw[:sz.value]).hexdigest() != want[k % len(datas)]):
+                bad.append(k)
+
+    def wave(nthreads, reps):
+        ws = [threading.Thread(target=work, args=(k, reps)) for k in range(nthreads)]
+        t0 = time.perf_counter()
+        [t.start() for t in ws]
+        [t.join() for t in ws]
+        return time.perf_counter() - t0
+
+    wave(threads, 1)                           # every thread's context and workspace exist
+    one = wave(1, calls)
+    dt = wave(threads, calls)
+    return {"threads": threads, "MiB_per_call": mib, "calls": threads * calls, "seconds": round(dt, 4),
+            "aggregate_MBps": round(threads * calls * n / 1e6 / dt, 1), "one_thread_MBps": round(calls * n / 1e6 / one, 1),
+            "ms_per_call_in_flight": round(dt / calls * 1e3, 2), "bytes_equal_reference": (not bad) if want is not None else None,
+            "GPU_MAX_HW_QUEUES": (lambda g: (g(b"GPU_MAX_HW_QUEUES") or b"").decode() or None)(
+                (lambda lc: (setattr(lc.getenv, "restype", C.c_char_p), lc.getenv)[1])(C.CDLL(None))),
+            "note": "stock BrotliEncoderCompress calls from %d threads at once, no partition plan, pageable host buffers" % threads}
+
+
+LEGS = {"abi": leg_abi, "stock": leg_stock, "stock_whole": leg_stock_whole, "round_trip": leg_round_trip, "process_fed": leg_process_fed,
+        "concurrent": leg_concurrent}
 
 
 def leg_main(argv):
@@ -1113,6 +1165,9 @@ def main(argv=None):
                     if isinstance(sc, dict) and "error" not in sc:
                         sc["whole_input"] = run_leg("stock_whole", path, args.quality, args.lgwin)
                         sc["process_fed_256MiB"] = run_leg("process_fed", path, args.quality, args.lgwin, 1024, 256)
+                        # what the reference's CLI does to a big file when no -w is given: lgwin 24 (c/tools/brotli.c:1434-1447)
+                        sc["whole_input_cli_default_lgwin24"] = run_leg("stock_whole", path, args.quality, 24)
+                        sc["concurrent_4MiB_calls"] = run_leg("concurrent", path, args.quality, args.lgwin, 4, 16, 4)
                     cfg["stock_call_no_plan"] = sc
                     line["line"] = "3 of 4: the legs of the headline configuration (other_configs follows)" if not args.no_other_configs else "3 of 3: complete"
                     emit(line)

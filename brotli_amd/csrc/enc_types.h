@@ -86,6 +86,9 @@ struct JobParams {
                                //   gate_walk): the bitmap holds what the other tiles left unstored — the events that told so
                                //   in the first pass are used up —, so every search is done exactly against it
 #define JOB_FLAG_TAILFIN 32768u // BROTLI_AMD_FLAG_TAIL_FINISH of the call (host_plan.h: stream_tail_fix; k_tile.h: stream_scan)
+#define JOB_FLAG_IXSPREAD 65536u // fewer than 8 index units (one shard, a short stream's chunks): a unit's buckets go to workgroups
+                                //   of every XCD and its big blocks to all eight lists of k_ix_big — eight times the waves at work,
+                                //   against keeping a unit's res[] lines in one L2, which pays only when every XCD has a unit (kernels.h)
 #define JOB_FLAG_SWEEP 2048u   // (per launch) k_chain replays the tiles' previous commands and parses again only where an
                                //   event is pending
 

@@ -120,7 +120,7 @@ static void tables_path(char* out, size_t cap) {
 /* Device contexts are expensive (HIP context, tables, a workspace sized for the largest job so
    far): an encoder instance borrows one from a small process-wide pool and hands it back when it
    is destroyed, so a program that compresses many buffers pays for the set-up once. */
-#define CTX_POOL 8
+#define CTX_POOL 32
 static pthread_mutex_t g_pool_lock = PTHREAD_MUTEX_INITIALIZER;
 static struct { BrotliAmdCtx* ctx; int device; } g_pool[CTX_POOL];
 

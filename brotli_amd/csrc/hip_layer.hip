@@ -58,6 +58,17 @@ static void env_read() {
   k.wide = env_int("BROTLI_AMD_WIDE", -1);
   k.wide_k = env_int("BROTLI_AMD_WIDE_K", 0);
   g_env = k;
+  // Callers that compress many buffers at once (a server: one encoder instance per thread, each with a context and
+  // a HIP stream of its own) are limited by the runtime's hardware queues, not by the device: the HIP runtime maps all
+  // streams of a process onto GPU_MAX_HW_QUEUES (default 4) queues, and a job of a few MiB is a string of small,
+  // latency-bound kernels — sixteen 4 MiB calls in flight gave 0.65 GB/s with 4 queues and 2.2 GB/s with 32
+  // (profiles/r06_s_*).  Asked for here, before the first HIP call of the process where this library makes it; a value
+  // the user set stays, BROTLI_AMD_HW_QUEUES=0 leaves the variable alone.  (A process that initialised HIP earlier —
+  // torch — has made its choice already.)
+  {
+    const int q = env_int("BROTLI_AMD_HW_QUEUES", 32);
+    if (q > 0) { char v[16]; snprintf(v, sizeof(v), "%d", q); setenv("GPU_MAX_HW_QUEUES", v, 0); }
+  }
 }
 
 struct BrotliAmdCtx {

@@ -173,8 +173,11 @@ static inline uint64_t plan_add_index_for(JobPlan* plan, std::vector<ShardDesc>&
   {
     // The buckets too big for LDS are searched in blocks of IX_BIG_BLOCK sorted entries by k_ix_big, which takes them
     // from eight lists (unit u is XCD u % 8's, as in k_ix_bucket): a unit has at most len / IX_BIG_BLOCK + buckets of them.
+    // Fewer than eight units (JOB_FLAG_IXSPREAD): a unit's buckets are spread over the lists, (unit + bucket) % 8 — any
+    // list may get up to all of them.
+    if (units.size() < 8u) plan->J.flags |= JOB_FLAG_IXSPREAD;
     uint64_t per[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (size_t u = 0; u < units.size(); ++u) per[u & 7u] += units[u].len / IX_BIG_BLOCK + (1ull << nb);
+    for (size_t u = 0; u < units.size(); ++u) per[(plan->J.flags & JOB_FLAG_IXSPREAD) ? 0u : (u & 7u)] += units[u].len / IX_BIG_BLOCK + (1ull << nb);
     uint64_t cap = 0;
     for (int x = 0; x < 8; ++x) if (per[x] > cap) cap = per[x];
     plan->J.big_cap = cap + 8;

@@ -739,7 +739,7 @@ DEV bool ix_big_search(const JobParams& J, const IxBigCtx& c, const IxLds& S, co
 template <bool STREAM>
 DEV void ix_bucket(const JobParams& J, const ShardDesc& D, const uint8_t* input, uint8_t* ws,
                    uint32_t bucket, uint32_t* lds, uint32_t unit) {
-  const uint32_t xcd = unit & 7u;
+  const uint32_t xcd = ((J.flags & JOB_FLAG_IXSPREAD) ? unit + bucket : unit) & 7u;      // (the list its big blocks go to)
   const int lane = wave_lane();
 #if defined(IX_PROFILE)
   uint64_t ix_t0 = (uint64_t)clock64();

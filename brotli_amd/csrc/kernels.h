@@ -150,11 +150,13 @@ template <bool STREAM>
 DEV void ix_bucket_kernel(const JobArgs& a, uint32_t* lds_b) {
   const uint32_t per = (1u << a.J.ix_nb_log2) / a.J.ix_bpw;
   const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
-  const uint32_t shard = (slot / per) * 8u + xcd, b0 = (slot % per) * a.J.ix_bpw;
+  uint32_t shard = (slot / per) * 8u + xcd, b0 = (slot % per) * a.J.ix_bpw;
+  if (a.J.flags & JOB_FLAG_IXSPREAD) { shard = blockIdx.x / per; b0 = (blockIdx.x % per) * a.J.ix_bpw; }     // (grid = nshards * per)
   if (shard >= a.nshards) return;
   for (uint32_t b = b0; b < b0 + a.J.ix_bpw; ++b) ix_bucket<STREAM>(a.J, a.shards[shard], a.input, a.ws, b, lds_b, shard);
 }
 static inline uint32_t ix_bucket_grid(const JobParams& J, uint32_t nshards) {
+  if (J.flags & JOB_FLAG_IXSPREAD) return nshards * ((1u << J.ix_nb_log2) / J.ix_bpw);
   return ((nshards + 7u) / 8u) * 8u * ((1u << J.ix_nb_log2) / J.ix_bpw);
 }
 __global__ void __launch_bounds__(64, IXB_WAVES) k_ix_bucket(JobArgs a) {
