@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 
 #include "../../include/brotli_amd_encode.h"
 #include "../../include/brotli_amd_hip.h"
@@ -46,6 +47,7 @@ struct BrotliEncoderStateStruct {
   /* input not yet handed to the device */
   uint8_t* in_buf;
   size_t in_len, in_cap;
+  size_t in_mapped;          /* != 0: in_buf is an anonymous mapping of that many bytes (grow_in), not an allocation */
   uint64_t total_in, submitted;
   /* produced, not yet taken */
   /* one FLUSH / FINISH call that brings its whole input and has room for the output: the job
@@ -97,6 +99,42 @@ static int grow(BrotliEncoderState* s, uint8_t** buf, size_t* cap, size_t used, 
   st_free(s, *buf);
   *buf = n;
   *cap = c;
+  return 1;
+}
+
+/* The held input (feed_threshold: a stream fed by PROCESS calls is kept until FINISH): from 4 MiB on an anonymous
+   mapping of its own — grown in place by mremap, with transparent huge pages asked for — instead of allocations that
+   double: those copied the held bytes again at every doubling and took a page fault per 4 KiB of every new buffer,
+   which was most of the time of a PROCESS-fed 256 MiB (0.42 s against 0.09 s for the same bytes in one call).  Custom
+   allocation functions are honoured as before. */
+static void free_in(BrotliEncoderState* s) {
+  if (s->in_mapped) munmap(s->in_buf, s->in_mapped); else st_free(s, s->in_buf);
+  s->in_buf = NULL;
+  s->in_cap = s->in_mapped = 0;
+}
+static int grow_in(BrotliEncoderState* s, size_t need) {
+  size_t c;
+  void* n;
+  if (need <= s->in_cap) return 1;
+  if (s->alloc || need < ((size_t)4 << 20)) return grow(s, &s->in_buf, &s->in_cap, s->in_len, need);
+  c = s->in_cap > ((size_t)4 << 20) ? s->in_cap : ((size_t)4 << 20);
+  if (s->size_hint > c && need <= (size_t)s->size_hint + 65536) c = (size_t)s->size_hint + 65536;   /* announced: once */
+  while (c < need) c *= 2;
+  c = (c + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+  if (s->in_mapped) {
+    n = mremap(s->in_buf, s->in_mapped, c, MREMAP_MAYMOVE);
+    if (n == MAP_FAILED) return 0;
+  } else {
+    n = mmap(NULL, c, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (n == MAP_FAILED) return 0;
+    if (s->in_len) memcpy(n, s->in_buf, s->in_len);
+    st_free(s, s->in_buf);
+  }
+#ifdef MADV_HUGEPAGE
+  (void)madvise(n, c, MADV_HUGEPAGE);
+#endif
+  s->in_buf = (uint8_t*)n;
+  s->in_cap = s->in_mapped = c;
   return 1;
 }
 
@@ -182,7 +220,7 @@ void BrotliEncoderDestroyInstance(BrotliEncoderState* s) {
       pool_give(s->ctx, s->device);
     }
   }
-  st_free(s, s->in_buf);
+  free_in(s);
   st_free(s, s->out_buf);
   st_free(s, s->calls);
   st_free(s, s);
@@ -785,7 +823,7 @@ BROTLI_BOOL BrotliEncoderCompressStream(BrotliEncoderState* s, int op, size_t* a
       return BROTLI_TRUE;
     }
     if (a) {
-      if (!grow(s, &s->in_buf, &s->in_cap, s->in_len, s->in_len + a)) return BROTLI_FALSE;
+      if (!grow_in(s, s->in_len + a)) return BROTLI_FALSE;
       memcpy(s->in_buf + s->in_len, *next_in, a);
       s->in_len += a;
       s->total_in += a;

@@ -106,6 +106,14 @@ def load_library(path=LIB_PATH):
         raise BrotliAmdError(
             "HIP library %s is missing: run `python -c 'import __graft_entry__ "
             "as g; g.build()'` (no CPU fallback exists)" % path)
+    # torch first: its wheel carries a HIP / HSA runtime of its own under the same SONAMEs.  Loaded first, this library
+    # binds to that copy and the process has ONE runtime; the other way round there are two, and the second one to
+    # initialise finds no device ("No HIP GPUs are available" from torch: tools/gpu_kinds_groups.py met it).  The device
+    # tensors this module hands the library are torch's, so torch is needed anyway.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     L.brotli_amd_ctx_create.argtypes = [C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]
     L.brotli_amd_ctx_destroy.argtypes = [C.c_void_p]
