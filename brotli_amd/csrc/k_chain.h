@@ -263,7 +263,7 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
     // each were the whole chain time of the Silesia-style mix (profiles/r04_d) — and their bits of the bitmap come with
     // one 8-byte load. ----
     bool fast = false;
-    {
+    if (C.mode == 0u) {       // (tiled jobs: measured without effect on the streams that walk far — rows, sparse zeros: profiles/r06_r)
       const int32_t hi_idx = sidx - 1 - (int32_t)j0, far_idx = hi_idx - 127;
       const bool tryf = on0 && far_idx >= 0;
       if (wave_any(tryf)) {
@@ -285,11 +285,6 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
             for (int k = 0; k < 8; ++k) z |= (((uint32_t)(bw >> ((e8[k] & 0xFFFFFFu) + C.ibase - p0)) & 1u) ^ 1u) << k;
           } else if (fast) {
             for (int k = 0; k < 8; ++k) z |= (c_skipped(C, (e8[k] & 0xFFFFFFu) + C.ibase) ? 0u : 1u) << k;
-          }
-          if (fast && (C.mode & C_TILED) != 0 && (C.mode & C_VIEW_ALL) == 0) {
-            // (round 0 of a tiled job: what lies below the tile counts as stored, as in the entry-by-entry walk below)
-#pragma unroll
-            for (int k = 0; k < 8; ++k) z |= ((e8[k] & 0xFFFFFFu) + C.ibase < C.tile_lo ? 1u : 0u) << k;
           }
           uint32_t zc = z;                                        // ... of them, the ones the store count takes in
           if (lo_t < count_from) { const int32_t sh = count_from - lo_t; zc = sh >= 8 ? 0u : (z >> sh) << sh; }

@@ -50,6 +50,37 @@ def test_text_streams(sim, ref, n, lgwin, seed):
     assert info[2] >= (2 if n > 200000 else 1)
 
 
+@pytest.mark.parametrize("n,lgwin,seed,kind", [(430000, 17, 2, "text"), (600000, 18, 3, "text"), (500000, 17, 4, "mix"),
+                                                (250000, 23, 1, "text"), (330000, 24, 2, "text")])
+def test_chunks_of_half_a_window(sim, ref, monkeypatch, n, lgwin, seed, kind):
+    """lgwin 24 beyond 16 MiB — what the reference's CLI chooses for every big file — has index chunks of HALF a window, so
+    that a chunk with its look-back stays within the 24-bit positions of an index entry (host_plan.h plan_stream): a search
+    with fewer than 16 same-key entries before it in its chunk is exact and goes on in the chunk before (k_index.h
+    IxGeom::older, k_chain.h c_search_exact), a changed store bit raises events two chunks on (k_tile.h stream_events).
+    BROTLI_AMD_HALF_CHUNKS=1 splits every window that way: at lgwin 17 a chunk is ONE tile and most searches take the new
+    path.  (The last two cases: lgwin 23 / 24 themselves, streams inside one chunk.)  The `-m gpu` suite runs 40 MiB ... 1 GiB
+    at lgwin 24."""
+    if lgwin < 23:
+        monkeypatch.setenv("BROTLI_AMD_HALF_CHUNKS", "1")
+    data = bytes(G.enwik_text(n, seed=seed)) if kind == "text" else bytes(G.mixed_corpus(n, seed=seed))
+    got, info = sim.encode_stream(data, lgwin=lgwin, reverse=seed & 1)
+    if got is None and kind == "mix":
+        pytest.skip("the mix left the tiled path (reasons %#x): nothing to compare" % info[0])
+    assert got is not None and got == ref.compress(data, 5, lgwin)
+
+
+def test_half_chunks_with_a_counter_wrap(sim, ref, monkeypatch):
+    """The 16-bit store counter's zones (k_stream_zones) over chunks of half a window: the stream of
+    test_counter_wrap_changes_the_bytes_and_is_followed."""
+    monkeypatch.setenv("BROTLI_AMD_HALF_CHUNKS", "1")
+    rng = np.random.default_rng(1)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(5, 10)), dtype=np.uint8)) + b" " for _ in range(2)]
+    n = 1300000
+    data = (bytes(rng.integers(97, 123, 30000, dtype=np.uint8)) + b"".join(words[i] for i in rng.integers(0, 2, n // 5)))[:n]
+    got, info = sim.encode_stream(data, lgwin=17)
+    assert got == ref.compress(data, 5, 17)
+
+
 def test_counter_wrap_changes_the_bytes_and_is_followed(sim, ref, monkeypatch):
     """Two words in random order behind 30 kB of noise (which closes the static-dictionary gate): every inner
     4-byte key is stored more than 65536 times, and the first searches behind a wrap see fewer ring slots
@@ -189,6 +220,29 @@ def test_stock_call_through_the_boundary(ref, monkeypatch):
         assert fin and fin2 and bytes(got) == bytes(want)
     monkeypatch.setenv("BROTLI_AMD_STREAM_TILES", "0")
     assert call(text[:200000], 17) == ref.compress(text[:200000], 5, 17)
+
+
+def test_stock_call_at_the_windows_the_cli_chooses(ref, monkeypatch):
+    """encode_abi.c's routing at lgwin 23 / 24 (c/tools/brotli.c:1434-1447 picks them for files above 4 MiB): an input
+    that the one-shard job does not take (above 4 MiB - 16) goes to the tiled stream; the bytes are the reference's.
+    BROTLI_AMD_VERBOSE would say so if it had gone to the serial stream (minutes on the simulator for this size)."""
+    from test_abi_on_sim import SIM_ABI
+    from test_gpu_abi import _bind
+    from refharness import ROOT, TABLES
+    import subprocess
+    import time
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "simt")], check=True)
+    monkeypatch.setenv("BROTLI_AMD_TABLES", TABLES)
+    L = _bind(SIM_ABI)
+    data = bytes(G.enwik_text((4 << 20) + 70000, seed=44))
+    for lgwin in (23, 24):
+        cap = L.BrotliEncoderMaxCompressedSize(len(data))
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t(cap)
+        t0 = time.time()
+        assert L.BrotliEncoderCompress(5, lgwin, 0, len(data), data, C.byref(n), out)
+        assert out.raw[:n.value] == ref.compress(data, 5, lgwin)
+        assert time.time() - t0 < 400
 
 
 @pytest.mark.parametrize("lgwin,blocks", [(17, 1), (17, 2), (17, 3), (17, 4), (17, 7), (17, 8), (18, 2), (18, 3), (18, 9)])
