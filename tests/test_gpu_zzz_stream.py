@@ -51,7 +51,8 @@ def test_text_longer_than_the_window(amd, stock, mib, lgwin, seed):
 
 @pytest.mark.parametrize("nbytes,lgwin,seed", [((6 << 20) + 777, 23, 31), ((12 << 20) + 5, 24, 32), (1 << 24, 24, 33),
                                                ((1 << 24) - 16, 24, 34), ((40 << 20) + 99, 23, 35), ((5 << 20), 24, 36),
-                                               ((16 << 20) + 4321, 23, 37)])
+                                               ((16 << 20) + 4321, 23, 37), ((1 << 24) + 1, 24, 38),
+                                               ((1 << 24) + 65536 + 5, 24, 39), ((3 << 23) + 17, 24, 40)])
 def test_the_windows_the_cli_chooses(amd, stock, nbytes, lgwin, seed):
     """lgwin 23 / 24 — what the reference's CLI picks by itself for a file above 4 MiB / 8 MiB (c/tools/brotli.c:1434-1447).
     An index chunk with its look-back is two windows of 24-bit positions: every length at lgwin 23 (2.4 and 5 laps of
