@@ -153,7 +153,7 @@ struct TileRec {
   // the static dictionary's two counters (hash.h:49-50, 186) moved by this much during the tile's parse: with the gate
   // taken as open (TILE_GATE_OPEN) the true counters at a tile's start are the sums over the tiles before
   uint32_t dlookups, dmatches;
-  uint32_t pad;
+  uint32_t pad;            // tile 0: successor walks of the event kernels in this pass, in units of 4096 entries (k_tile.h tile_walk_over)
   // the gate hypothesis this tile is (to be) parsed with: 0 closed, 1 open for good, 2 from the exact counters in_l / in_m
   // (the tile in which it may close: k_tile.h, gate_walk)
   uint32_t hyp, in_l, in_m;

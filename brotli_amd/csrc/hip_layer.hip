@@ -897,6 +897,8 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     {
       JobArgs e = a;
       if (passes != 0) e.J.flags |= JOB_FLAG_SWEEP;
+      hipLaunchKernelGGL(k_stream_flips, egrid, dim3(64), 0, c->stream, e); each("k_stream_flips");
+      hipLaunchKernelGGL(k_stream_flipcheck, dim3(1), dim3(64), 0, c->stream, e); each("k_stream_flipcheck");
       hipLaunchKernelGGL(k_stream_events, egrid, dim3(64), 0, c->stream, e); each("k_stream_events");
     }
     hipLaunchKernelGGL(k_stream_skclear, egrid, dim3(64), 0, c->stream, a); each("k_stream_skclear");

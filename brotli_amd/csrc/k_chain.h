@@ -49,6 +49,7 @@ struct CShard {
   uint8_t* skip;         // bit (x - geo.first): storable position x was NOT stored by the parse
   uint32_t frontier;     // every storable position below it is either stored or marked in `skip`
   uint32_t nslow;
+  uint32_t walked;       // tiled jobs: sorted entries the exact searches of this tile walked over in this launch (c_search_exact)
   // tiled jobs (JOB_FLAG_TILED): this group parses [tile_lo, tile_hi) of the shard; only positions of the tile
   // are marked / tainted by it (the bitmap's words never straddle tiles: tiles are multiples of 32 positions
   // counted from geo.first)
@@ -334,6 +335,7 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
       total += (uint32_t)__builtin_popcount(n16);
       if (te < 16u) exhausted = true;
       j0 += 16u;
+      C.walked += 16u;
       if (sidx - (int32_t)j0 <= count_from) counted = true;     // everything from count_from up is in
     }
   }
@@ -364,6 +366,7 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
       if (on) {
         found += (uint32_t)__builtin_popcount(s16);
         j2 += 16u;
+        C.walked += 16u;
         if (found >= 16u || out16 != 0u) more = false;
       }
     }
@@ -371,6 +374,10 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   wave_sync();
   if (want && danger && t == 0) { scratch[16] = kt.key; scratch[17] = (uint32_t)sidx; scratch[18] = total; }
   if (want && danger && (C.mode & C_TILED) != 0) C.mode |= C_BAD;      // (the carried store count is a serial matter)
+  // (a tile whose exact searches walk more than 1024 entries per position of the tile — stores so sparse that the 16 stored
+  //  predecessors lie thousands of entries back, search after search: a constant background — goes the serial way, where
+  //  the ring is a table: k_tile.h tile_walk_over has the measurement)
+  if ((C.mode & C_TILED) != 0 && (C.walked >> 10) > (C.tile_hi - C.tile_lo) + 4096u) C.mode |= C_BAD;
   // slots the 16-bit counter leaves visible (:250-257): all 16 once it has seen 16 stores,
   // and — only reachable after a wrap — count mod 65536 when that is below 16
   uint32_t nvalid = umin(found, 16u);
@@ -1088,6 +1095,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   }
   C.frontier = S0->ix_frontier;
   C.nslow = 0;
+  C.walked = 0;
   C.tile_lo = 0;
   C.tile_hi = D.len;
   C.mode = tiled ? C_TILED : 0u;

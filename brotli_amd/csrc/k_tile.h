@@ -39,6 +39,24 @@
 // (grid = nshards, block = 64; between the tiles' first launch and a second one that parses the restarted tiles
 // only) un-runs them, k_tile_restart_clear (grid = units * ix_slices) wipes their bitmaps.
 #define TILE_CNT_RESTART 7
+#define TILE_CNT_PREFLIPS 10  // a stream: changed store bits counted BEFORE k_stream_events walks their successors (k_stream_flips)
+// The successor walks of the event kernels (up to the 16th STORED successor of a changed position) are as long as the
+// runs of unstored entries they cross: on a constant background with a rare token now and then — one key, nearly
+// every position inside a clipped copy — that is the rest of the key run for every changed bit, 800 s for 8 MB before
+// the "too many changes" rule could send the stream to the serial path (tools/gpu_fuzz_windows.py, seed 2).  Three
+// things keep that from happening: a stream counts its changed bits before it walks (k_stream_flips); a changed,
+// unstored position whose predecessor in the key run changed too does not walk at all (the predecessor's walk passes
+// over it and ends where its own would: stream_events); and, as the net under both, the walks of one pass are charged
+// to tile 0 of the shard in units of 4096 entries (TileRec::pad) — beyond 1024 entries per input byte the shard goes
+// the serial way at once (a stream with 150 KB of noise and 200 KB of zeros in 770 KB walks 65 per byte and settles).
+DEV bool tile_walk_over(TileRec* t0, uint32_t len, uint32_t* counters) {
+  const uint32_t units = glb_atomic_add(&t0->pad, 1u) + 1u;
+  if (units > len / 4u + 4096u) {
+    if (!(t0->flags & TILE_BAD)) { glb_atomic_or(&t0->flags, TILE_BAD | TILE_WHY_EVENTS); glb_atomic_add(&counters[TILE_CNT_BAD], 1u); }
+    return true;
+  }
+  return (t0->flags & TILE_BAD) != 0;
+}
 DEV void tile_unrun(TileRec& r, uint32_t hyp) {
   r.hyp = hyp;
   r.flags &= ~(TILE_RAN | TILE_START_EVENT | TILE_CHANGED);
@@ -119,6 +137,7 @@ DEV void tile_verify(const JobParams& J, const ShardDesc& D, ShardState* S, Tile
   // a shard most of whose searches the tiles would have to do twice is better off on the plain chain
   if (R[0].nflips > D.len / 32u + 64u) why |= TILE_WHY_EVENTS;
   R[0].nflips = 0;
+  R[0].pad = 0;                  // (tile_walk_over: the walks of the next pass)
   // the static dictionary's gate (hash.h:186): with tiles parsed as if it stayed open for good, the counters at a
   // tile's start are tile 0's plus the tiles' before — it cannot close inside a tile whose start has
   // matches >= (lookups + the tile's lookups) >> 7 (matches only grow, lookups end at that sum): gate_walk
@@ -191,7 +210,7 @@ DEV void tile_events(const JobParams& J, const ShardDesc& D, const uint8_t* inpu
   const uint32_t total = ((const uint32_t*)(base + L.cnt))[J.ix_slices << J.ix_nb_log2];    // sorted entries of the shard
   const uint32_t per = ix_slice_len(D.len, J.ix_slices);
   const uint32_t w_lo = (w * per) / 32u, w_hi = umin(((w + 1u) * per) / 32u, (D.len + 31u) / 32u);
-  uint32_t flips = 0;
+  uint32_t flips = 0, walked = 0;
   for (uint32_t i = w_lo + lane; i < w_hi; i += 64u) {
     const uint32_t cur = skip[i];
     uint32_t diff = cur ^ prev[i];
@@ -210,6 +229,7 @@ DEV void tile_events(const JobParams& J, const ShardDesc& D, const uint8_t* inpu
       const uint32_t xt = (J.flags & JOB_FLAG_SWEEP) ? 0xFFFFFFFFu : (x - first) >> J.tile_log2;
       uint32_t stored = 0;
       for (uint32_t j = s + 1u; j < total && stored < 16u; ++j) {
+        if ((++walked & 4095u) == 0u && tile_walk_over(&trecs[D.tile_base], D.len, counters)) return;
         const uint32_t q = srt[j] & 0xFFFFFFu;
         if (hash_pos(ld64(data + q), J.hasher_type, J.bucket_bits).key != key) break;
         const uint32_t b = q - first;
@@ -434,6 +454,7 @@ DEV void stream_verify(const JobParams& J, const ShardDesc& D, TileRec* R, uint3
     //  far better — the bound only keeps literal-spree data, of which most positions are unstored, off the sweeps)
     if (c.nflips > D.len / 2u + 64u) why |= TILE_WHY_EVENTS;
     c.nflips = 0;
+    c.pad = 0;                   // (tile_walk_over: the walks of the next pass)
   }
   // (tiles sent back by gate_walk are parsed at the top of the next pass: their joins are checked then)
   const bool pending = !(c.flags & TILE_RAN) || (t + 1u < D.ntiles && !(R[t + 1u].flags & TILE_RAN));
@@ -468,6 +489,30 @@ DEV void stream_verify(const JobParams& J, const ShardDesc& D, TileRec* R, uint3
   }
 }
 
+// grid = nchunks * ix_slices, block = 64, then one thread: the store bits that changed since the last pass, counted
+// before anything is walked; more than half of the stream's positions = the rule of stream_verify, applied while it
+// still saves the work (k_stream_events returns at once for a stream that is TILE_BAD).
+DEV void stream_flipcount(const JobParams& J, const ShardDesc& D, uint8_t* ws, const TileRec* trecs, uint32_t cj, uint32_t w, uint32_t* counters) {
+  if (trecs[0].flags & TILE_BAD) return;
+  const uint32_t lane = (uint32_t)wave_lane();
+  const uint32_t* skip = (const uint32_t*)(ws + J.sbm_off);
+  const uint32_t* prev = (const uint32_t*)(ws + J.sbm_off + J.sbm_stride);
+  const uint32_t own_lo = cj << J.chunk_log2;
+  const uint32_t own_hi = umin(D.len, (cj + 1u) << J.chunk_log2);
+  const uint32_t per = ix_slice_len(own_hi - own_lo, J.ix_slices);
+  const uint32_t w_lo = (own_lo + w * per) / 32u, w_hi = umin((own_lo + (w + 1u) * per) / 32u, (own_hi + 31u) / 32u);
+  uint32_t flips = 0;
+  for (uint32_t i = w_lo + lane; i < w_hi; i += 64u) flips += (uint32_t)__builtin_popcount(skip[i] ^ prev[i]);
+  if (flips != 0) glb_atomic_add(&counters[TILE_CNT_PREFLIPS], flips);
+}
+DEV void stream_flipcheck(const ShardDesc& D, TileRec* trecs, uint32_t* counters) {
+  if (counters[TILE_CNT_PREFLIPS] > D.len / 2u + 64u && !(trecs[0].flags & TILE_BAD)) {
+    trecs[0].flags |= TILE_BAD | TILE_WHY_EVENTS;
+    glb_atomic_add(&counters[TILE_CNT_BAD], 1u);
+  }
+  counters[TILE_CNT_PREFLIPS] = 0;
+}
+
 // grid = nchunks * ix_slices, block = 64: the words of the stream's bitmap that lie in the chunk's own part.  A
 // position whose bit changed is looked up in its own chunk and in the next one (where it is look-back): its
 // successors in both key runs are the searches its store was, or now is, a candidate of.
@@ -476,22 +521,23 @@ DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* 
   if (trecs[0].flags & TILE_BAD) return;
   const uint32_t lane = (uint32_t)wave_lane();
   const uint32_t* skip = (const uint32_t*)(ws + J.sbm_off);
-  uint32_t* prev = (uint32_t*)(ws + J.sbm_off + J.sbm_stride);
+  const uint32_t* prev = (const uint32_t*)(ws + J.sbm_off + J.sbm_stride);
   uint32_t* ev = (uint32_t*)(ws + J.sbm_off + 2u * J.sbm_stride);
   const uint8_t* data = input + D.in_off;
   const uint32_t own_lo = cj << J.chunk_log2;
   const uint32_t own_hi = umin(D.len, (cj + 1u) << J.chunk_log2);
   const uint32_t per = ix_slice_len(own_hi - own_lo, J.ix_slices);
   const uint32_t w_lo = (own_lo + w * per) / 32u, w_hi = umin((own_lo + (w + 1u) * per) / 32u, (own_hi + 31u) / 32u);
-  uint32_t flips = 0;
+  uint32_t flips = 0, walked = 0;
   for (uint32_t i = w_lo + lane; i < w_hi; i += 64u) {
     const uint32_t cur = skip[i];
     uint32_t diff = cur ^ prev[i];
     if (diff == 0) continue;
-    prev[i] = cur;
+    // (prev[] is brought up to date by k_stream_skcount, the next kernel: the walks below ask it about other positions)
     flips += (uint32_t)__builtin_popcount(diff);
     for (; diff != 0; diff &= diff - 1u) {
       const uint32_t x = i * 32u + (uint32_t)dev_ctz32(diff);
+      const bool x_unstored = ((cur >> (x & 31u)) & 1u) != 0u;
       const uint32_t key = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits).key;
       const uint32_t xt = (J.flags & JOB_FLAG_SWEEP) ? 0xFFFFFFFFu : x >> J.tile_log2;
       uint32_t stored = 0;
@@ -505,7 +551,16 @@ DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* 
         const uint32_t total = ((const uint32_t*)(kb + L.cnt))[J.ix_slices << J.ix_nb_log2];
         const uint32_t s = (uint32_t)(res[x - K.ix_base] >> 32) & 0xFFFFFFu;
         stored = 0;
+        if (x_unstored && s != 0u) {
+          // the entry before x in this chunk's key run changed as well: its walk (this pass, some other lane — it is
+          // looked up in this chunk too) visits x, everything x's own walk would visit, and ends where that would end,
+          // x not being a store; what it leaves out by the first pass's tile rule lies in ITS tile, in front of x's
+          const uint32_t qp = (srt[s - 1u] & 0xFFFFFFu) + K.ix_base;
+          if (hash_pos(ld64(data + qp), J.hasher_type, J.bucket_bits).key == key &&
+              (((skip[qp >> 5] ^ prev[qp >> 5]) >> (qp & 31u)) & 1u) != 0u) { stored = 16u; continue; }
+        }
         for (uint32_t j = s + 1u; j < total && stored < 16u; ++j) {
+          if ((++walked & 4095u) == 0u && tile_walk_over(&trecs[0], D.len, counters)) return;
           const uint32_t q = (srt[j] & 0xFFFFFFu) + K.ix_base;
           if (hash_pos(ld64(data + q), J.hasher_type, J.bucket_bits).key != key) break;
           if ((q >> J.tile_log2) != xt) glb_atomic_or(&ev[q >> 5], 1u << (q & 31u));
@@ -526,6 +581,7 @@ DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* 
         const uint32_t rl = kt[SKT_RL * nk + key], own = kt[SKT_OWN * nk + key];
         const uint32_t j0 = kt[SKT_RS * nk + key] + rl - own;
         for (uint32_t j = j0; j < j0 + own && stored < 16u; ++j) {
+          if ((++walked & 4095u) == 0u && tile_walk_over(&trecs[0], D.len, counters)) return;
           const uint32_t q = (srt[j] & 0xFFFFFFu) + K.ix_base;
           if (q - x > J.max_backward_limit) break;
           if ((q >> J.tile_log2) != xt) glb_atomic_or(&ev[q >> 5], 1u << (q & 31u));
@@ -597,8 +653,11 @@ DEV void stream_skcount(const JobParams& J, const ShardDesc& D, const uint8_t* i
   const uint32_t own_lo = c << J.chunk_log2, own_hi = umin(D.len, (c + 1u) << J.chunk_log2);
   const uint32_t per = ix_slice_len(own_hi - own_lo, J.ix_slices);
   const uint32_t w_lo = (own_lo + w * per) / 32u, w_hi = umin((own_lo + (w + 1u) * per) / 32u, (own_hi + 31u) / 32u);
+  uint32_t* prev = (uint32_t*)(ws + J.sbm_off + J.sbm_stride);
   for (uint32_t i = w_lo + lane; i < w_hi; i += 64u) {
-    for (uint32_t v = skip[i]; v != 0; v &= v - 1u) {
+    const uint32_t cur = skip[i];
+    if (prev[i] != cur) prev[i] = cur;           // (what k_stream_events of the next pass compares with)
+    for (uint32_t v = cur; v != 0; v &= v - 1u) {
       const uint32_t x = i * 32u + (uint32_t)dev_ctz32(v);
       glb_atomic_add(&sk[hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits).key], 1u);
     }

@@ -277,6 +277,14 @@ __global__ void __launch_bounds__(64) k_stream_cuts(JobArgs a) {
 __global__ void __launch_bounds__(64) k_stream_verify(JobArgs a) {
   stream_verify(a.J, a.shards[0], a.trecs, blockIdx.x * 64u + threadIdx.x, a.counters);
 }
+// grid = nchunks * ix_slices, block = 64; then grid = 1, block = 64 (one thread works)
+__global__ void __launch_bounds__(64) k_stream_flips(JobArgs a) {
+  const uint32_t cj = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;
+  if (cj < a.J.nchunks) stream_flipcount(a.J, a.shards[0], a.ws, a.trecs, cj, w, a.counters);
+}
+__global__ void __launch_bounds__(64) k_stream_flipcheck(JobArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) stream_flipcheck(a.shards[0], a.trecs, a.counters);
+}
 // grid = nchunks * ix_slices, block = 64
 __global__ void __launch_bounds__(64) k_stream_events(JobArgs a) {
   const uint32_t cj = blockIdx.x / a.J.ix_slices, w = blockIdx.x % a.J.ix_slices;

@@ -361,6 +361,8 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
     {
       JobArgs e = a;
       if (rounds != 0 || getenv("SIM_EVENTS_ALL")) e.J.flags |= JOB_FLAG_SWEEP;
+      run(k_stream_flips, e, a.J.nchunks * a.J.ix_slices, 64, reverse);
+      run(k_stream_flipcheck, e, 1, 64, reverse);
       run(k_stream_events, e, a.J.nchunks * a.J.ix_slices, 64, reverse);
     }
     lap("events");
