@@ -31,7 +31,10 @@
 #include "k_index.h"
 #include "k_parse4.h"
 
-#define C_GROUP_LDS_WORDS 20u                                          // 16 ring slots of c_search_exact + its carried store count
+#define C_GROUP_LDS_WORDS 24u                                          // 16 ring slots of c_search_exact + its carried store count (16..18)
+                                                                       //   + the chunk before the tile's (19: its base or C_NO_OLDER, 20 / 21: its
+                                                                       //   index region's offset, 22: its length) + entries walked by exact searches (23)
+#define C_NO_OLDER 0xFFFFFFFFu
 #define C_LDS_WORDS (Q_GROUPS * C_GROUP_LDS_WORDS)
 
 struct CShard {
@@ -40,16 +43,11 @@ struct CShard {
   uint64_t* res;
   const uint32_t* srt;
   uint32_t ibase;        // position of the local position 0 of `srt`'s entries (a stream's index chunk; 0 otherwise)
-  // a stream whose chunks are shorter than the window (IxGeom::older): the chunk before this one — its sorted array,
-  // its base and its key table (k_index_layout.h SKT_*) — where an exact search goes on once the key run of its own
-  // chunk is used up; null otherwise
-  const uint32_t* srt_old;
-  const uint32_t* kt_old;
-  uint32_t ibase_old;
+  // (a stream whose chunks are shorter than the window, IxGeom::older: where the chunk before the tile's lies is kept in
+  //  the group's LDS words 19..22, not here — four more registers in this struct cost the tile kernels 12 % in spills)
   uint8_t* skip;         // bit (x - geo.first): storable position x was NOT stored by the parse
   uint32_t frontier;     // every storable position below it is either stored or marked in `skip`
   uint32_t nslow;
-  uint32_t walked;       // tiled jobs: sorted entries the exact searches of this tile walked over in this launch (c_search_exact)
   // tiled jobs (JOB_FLAG_TILED): this group parses [tile_lo, tile_hi) of the shard; only positions of the tile
   // are marked / tainted by it (the bitmap's words never straddle tiles: tiles are multiples of 32 positions
   // counted from geo.first)
@@ -335,28 +333,36 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
       total += (uint32_t)__builtin_popcount(n16);
       if (te < 16u) exhausted = true;
       j0 += 16u;
-      C.walked += 16u;
+      if (t == 0 && (C.mode & C_TILED) != 0) scratch[23] += 16u;
       if (sidx - (int32_t)j0 <= count_from) counted = true;     // everything from count_from up is in
     }
   }
+  const uint32_t* srt_old = nullptr;
+  uint32_t ibase_old = C_NO_OLDER;
   {
     // The key run of this chunk is used up and the ring is not full: the entries of the key below the chunk's base
     // are the part of the run of the chunk before that lies in ITS look-back (run start, run length and own-part length
     // from its key table), newest last.  Entries beyond the window end the walk: everything behind them is older.
     // scratch[] takes their indices with bit 31 set.
     const uint32_t nk = 1u << J.bucket_bits;
-    bool more = want && C.srt_old != nullptr && found < 16u;      // (the groups of a wave parse tiles of different chunks)
+    ibase_old = scratch[19];
+    bool more = want && ibase_old != C_NO_OLDER && found < 16u;   // (the groups of a wave parse tiles of different chunks)
     uint32_t rs2 = 0, n2 = 0;
     if (more) {
-      rs2 = C.kt_old[SKT_RS * nk + kt.key];
-      n2 = C.kt_old[SKT_RL * nk + kt.key] - C.kt_old[SKT_OWN * nk + kt.key];
+      IxLayout L2;
+      ix_layout(scratch[22], J.ix_slices, J.ix_nb_log2, &L2);
+      srt_old = (const uint32_t*)(g.wsb + (((uint64_t)scratch[21] << 32) | scratch[20]) + L2.srt);
+      // (chunk j has the base (j - 1) << chunk_log2: the key table of the chunk that base belongs to)
+      const uint32_t* kt_old = (const uint32_t*)(g.wsb + J.skt_off + (uint64_t)((ibase_old >> J.chunk_log2) + 1u) * skt_chunk_bytes((uint32_t)J.bucket_bits));
+      rs2 = kt_old[SKT_RS * nk + kt.key];
+      n2 = kt_old[SKT_RL * nk + kt.key] - kt_old[SKT_OWN * nk + kt.key];
     }
     uint32_t j2 = 0;
     while (wave_any(more && j2 < n2)) {
       const bool on = more && j2 < n2;
       const bool ok = on && j2 + (uint32_t)t < n2;
       const uint32_t idx2 = rs2 + n2 - 1u - (j2 + (uint32_t)t);
-      const uint32_t q = ok ? (C.srt_old[idx2] & 0xFFFFFFu) + C.ibase_old : 0u;
+      const uint32_t q = ok ? (srt_old[idx2] & 0xFFFFFFu) + ibase_old : 0u;
       const bool inwin = ok && P - q <= max_backward;
       const bool stored = inwin && !(((C.mode & C_VIEW_ALL) != 0 || q >= C.tile_lo) && c_skipped(C, q));
       const uint32_t s16 = q_mask16(wave_ballot(stored));
@@ -366,7 +372,7 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
       if (on) {
         found += (uint32_t)__builtin_popcount(s16);
         j2 += 16u;
-        C.walked += 16u;
+        if (t == 0) scratch[23] += 16u;
         if (found >= 16u || out16 != 0u) more = false;
       }
     }
@@ -377,16 +383,16 @@ DEV QResult c_search_exact(const JobParams& J, CShard& C, bool want, uint32_t P,
   // (a tile whose exact searches walk more than 1024 entries per position of the tile — stores so sparse that the 16 stored
   //  predecessors lie thousands of entries back, search after search: a constant background — goes the serial way, where
   //  the ring is a table: k_tile.h tile_walk_over has the measurement)
-  if ((C.mode & C_TILED) != 0 && (C.walked >> 10) > (C.tile_hi - C.tile_lo) + 4096u) C.mode |= C_BAD;
+  if ((C.mode & C_TILED) != 0 && want && (scratch[23] >> 10) > (C.tile_hi - C.tile_lo) + 4096u) C.mode |= C_BAD;
   // slots the 16-bit counter leaves visible (:250-257): all 16 once it has seen 16 stores,
   // and — only reachable after a wrap — count mod 65536 when that is below 16
   uint32_t nvalid = umin(found, 16u);
   if (danger) { const uint32_t n = total & 0xFFFFu; nvalid = n < 16u ? n : 16u; }
   if (sdanger) nvalid = umin(nvalid, svis);
   const uint32_t sc = (uint32_t)t < nvalid ? scratch[t] : 0u;
-  const bool from_old = (sc >> 31) != 0u;                       // (set only where C.srt_old exists)
-  const uint32_t w0 = (uint32_t)t < nvalid ? (from_old ? C.srt_old[sc & 0x7FFFFFFFu] : C.srt[sc]) : 0u;
-  const uint32_t b_prev = (w0 & 0xFFFFFFu) + (from_old ? C.ibase_old : C.ibase);
+  const bool from_old = (sc >> 31) != 0u;                       // (set only by the walk above)
+  const uint32_t w0 = (uint32_t)t < nvalid ? (from_old ? srt_old[sc & 0x7FFFFFFFu] : C.srt[sc]) : 0u;
+  const uint32_t b_prev = (w0 & 0xFFFFFFu) + (from_old ? ibase_old : C.ibase);
   const bool b_cand = want && (uint32_t)t < nvalid && (w0 >> 24) == kt.tag && (P - b_prev) <= max_backward;
   wave_sync();
   uint32_t b_len = 0, d_len = 0;
@@ -1058,7 +1064,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   for (int i = 0; i < 12; ++i) g.prof[i] = 0;
   g.state = (alive && !S0->done && !S0->mb_valid && !S0->error) ? Q_PRE : Q_DONE;
   C.geo = ix_geom(J, D);
-  C.srt_old = nullptr; C.kt_old = nullptr; C.ibase_old = 0;
+  if (t == 0 && gi < gpw) { scratch[19] = C_NO_OLDER; scratch[23] = 0; }
   IxLayout L;
   uint8_t* evb;                                        // the event bitmap (sweeps)
   if (tiled && (J.flags & JOB_FLAG_STREAMT) != 0) {
@@ -1074,11 +1080,7 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
       // (chunks of half a window: chunk cj - 1 holds what lies between the window's far end and this chunk's base)
       const uint32_t cj = umin(lo >> J.chunk_log2, J.nchunks - 1u);
       const ShardDesc& K2 = chunks[cj - 1u];
-      IxLayout L2;
-      ix_layout(K2.len, J.ix_slices, J.ix_nb_log2, &L2);
-      C.srt_old = (const uint32_t*)(ws + K2.ix_off + L2.srt);
-      C.ibase_old = K2.ix_base;
-      C.kt_old = (const uint32_t*)(ws + J.skt_off + (uint64_t)(cj - 1u) * skt_chunk_bytes((uint32_t)J.bucket_bits));
+      if (t == 0) { scratch[19] = K2.ix_base; scratch[20] = (uint32_t)K2.ix_off; scratch[21] = (uint32_t)(K2.ix_off >> 32); scratch[22] = K2.len; }
     }
     C.skip = ws + J.sbm_off;
     evb = ws + J.sbm_off + 2u * J.sbm_stride;
@@ -1095,7 +1097,6 @@ DEV void chain_round(const JobParams& J, const ShardDesc* shards, ShardState* st
   }
   C.frontier = S0->ix_frontier;
   C.nslow = 0;
-  C.walked = 0;
   C.tile_lo = 0;
   C.tile_hi = D.len;
   C.mode = tiled ? C_TILED : 0u;
