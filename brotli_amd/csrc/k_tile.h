@@ -540,7 +540,8 @@ DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* 
       const bool x_unstored = ((cur >> (x & 31u)) & 1u) != 0u;
       const uint32_t key = hash_pos(ld64(data + x), J.hasher_type, J.bucket_bits).key;
       const uint32_t xt = (J.flags & JOB_FLAG_SWEEP) ? 0xFFFFFFFFu : x >> J.tile_log2;
-      uint32_t stored = 0;
+      uint32_t stored = 0, xlast = x;
+      const bool halfc = J.chunk_log2 < (uint32_t)J.lgwin;
       for (uint32_t c = cj; c <= cj + 1u && c < J.nchunks; ++c) {
         const ShardDesc& K = chunks[c];
         IxLayout L;
@@ -559,12 +560,20 @@ DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* 
           if (hash_pos(ld64(data + qp), J.hasher_type, J.bucket_bits).key == key &&
               (((skip[qp >> 5] ^ prev[qp >> 5]) >> (qp & 31u)) & 1u) != 0u) { stored = 16u; continue; }
         }
+        xlast = x;
+        bool stretch = halfc;
         for (uint32_t j = s + 1u; j < total && stored < 16u; ++j) {
           if ((++walked & 4095u) == 0u && tile_walk_over(&trecs[0], D.len, counters)) return;
           const uint32_t q = (srt[j] & 0xFFFFFFu) + K.ix_base;
           if (hash_pos(ld64(data + q), J.hasher_type, J.bucket_bits).key != key) break;
           if ((q >> J.tile_log2) != xt) glb_atomic_or(&ev[q >> 5], 1u << (q & 31u));
-          if (!((skip[q >> 5] >> (q & 31u)) & 1u)) ++stored;
+          const uint32_t sq = skip[q >> 5];
+          if (!((sq >> (q & 31u)) & 1u)) { ++stored; stretch = false; }
+          else if (stretch) {
+            // (the entries right behind x that do not walk because of x: changed and unstored, one after the other —
+            //  the walk into chunk cj + 2 below has to reach as far as the LAST of them sees)
+            if (((sq ^ prev[q >> 5]) >> (q & 31u)) & 1u) xlast = q; else stretch = false;
+          }
         }
       }
       if (J.chunk_log2 < (uint32_t)J.lgwin && cj + 2u < J.nchunks && stored < 16u) {
@@ -583,7 +592,7 @@ DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* 
         for (uint32_t j = j0; j < j0 + own && stored < 16u; ++j) {
           if ((++walked & 4095u) == 0u && tile_walk_over(&trecs[0], D.len, counters)) return;
           const uint32_t q = (srt[j] & 0xFFFFFFu) + K.ix_base;
-          if (q - x > J.max_backward_limit) break;
+          if (q - xlast > J.max_backward_limit) break;
           if ((q >> J.tile_log2) != xt) glb_atomic_or(&ev[q >> 5], 1u << (q & 31u));
           if (!((skip[q >> 5] >> (q & 31u)) & 1u)) ++stored;
         }
@@ -697,34 +706,47 @@ DEV void stream_zones(const JobParams& J, const ShardDesc& D, const ShardDesc* c
     const uint32_t k = kg * 64u + (uint32_t)src;
     const uint32_t rs = kt[SKT_RS * nk + k], rl = wave_bcast(rl_l, src), B = wave_bcast(b_l, src);
     const uint32_t zlo = wave_bcast(zlo_l, src), zhi = wave_bcast(zhi_l, src);
-    // the run, 64 entries per step: `stored` = stores of the key before the entry
+    // the run, 64 entries per step: `stored` = stores of the key before the entry.  Four steps' loads go out together —
+    // sorted entry, then its word of the bitmap: two dependent round trips per step were 6.5 ms a launch for the most
+    // common key of a 16 MiB chunk (a run of several hundred thousand entries on ONE wave), four launches a 256 MiB
+    // stream: a quarter of its time at lgwin 24 (profiles/r06_x) — the steps themselves only pass `stored` on.
     uint32_t stored = B, nlo = 0xFFFFFFFFu, nhi = 0;
-    for (uint32_t i0 = 0; i0 < rl; i0 += 64u) {
-      const uint32_t i = i0 + lane;
-      const bool in = i < rl;
-      const uint32_t w0 = in ? srt[rs + i] : 0u;
-      const uint32_t p = w0 & 0xFFFFFFu, P = p + K.ix_base;
-      const bool st = in && !((skip[P >> 5] >> (P & 31u)) & 1u);
-      const uint64_t sm = wave_ballot(st);
-      const uint32_t before = stored + (uint32_t)dev_popc64(sm & ((1ull << lane) - 1ull));     // the counter when this entry is searched
-      const uint32_t vis = before & 0xFFFFu;
-      const bool zone = in && before >= 65536u && vis < 16u && p >= K.ix_ownc;
-      const bool old = in && rs + i >= zlo && rs + i < zhi;
-      if (zone || old) {
-        const uint64_t r = res[p];
-        const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
-        uint32_t nlo2 = lo, nhi2 = hi;
-        if (zone) { nlo2 = (IX_KIND_SLOW << 30) | vis; nhi2 = hi | IX_DANGER; }
-        else if (hi & IX_DANGER) { nlo2 = IX_KIND_SLOW << 30; nhi2 = hi & ~IX_DANGER; }
-        if (nlo2 != lo || nhi2 != hi) {
-          res[p] = (uint64_t)nlo2 | ((uint64_t)nhi2 << 32);
-          glb_atomic_or(&ev[P >> 5], 1u << (P & 31u));
-          ++changes;
+    for (uint32_t i00 = 0; i00 < rl; i00 += 256u) {
+      uint32_t w4[4], s4[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) { const uint32_t i = i00 + 64u * u + lane; w4[u] = i < rl ? srt[rs + i] : 0u; }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) { const uint32_t P = (w4[u] & 0xFFFFFFu) + K.ix_base; s4[u] = i00 + 64u * u + lane < rl ? skip[P >> 5] : 0u; }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        const uint32_t i0 = i00 + 64u * u;
+        if (i0 >= rl) break;
+        const uint32_t i = i0 + lane;
+        const bool in = i < rl;
+        const uint32_t w0 = w4[u];
+        const uint32_t p = w0 & 0xFFFFFFu, P = p + K.ix_base;
+        const bool st = in && !((s4[u] >> (P & 31u)) & 1u);
+        const uint64_t sm = wave_ballot(st);
+        const uint32_t before = stored + (uint32_t)dev_popc64(sm & ((1ull << lane) - 1ull));     // the counter when this entry is searched
+        const uint32_t vis = before & 0xFFFFu;
+        const bool zone = in && before >= 65536u && vis < 16u && p >= K.ix_ownc;
+        const bool old = in && rs + i >= zlo && rs + i < zhi;
+        if (zone || old) {
+          const uint64_t r = res[p];
+          const uint32_t lo = (uint32_t)r, hi = (uint32_t)(r >> 32);
+          uint32_t nlo2 = lo, nhi2 = hi;
+          if (zone) { nlo2 = (IX_KIND_SLOW << 30) | vis; nhi2 = hi | IX_DANGER; }
+          else if (hi & IX_DANGER) { nlo2 = IX_KIND_SLOW << 30; nhi2 = hi & ~IX_DANGER; }
+          if (nlo2 != lo || nhi2 != hi) {
+            res[p] = (uint64_t)nlo2 | ((uint64_t)nhi2 << 32);
+            glb_atomic_or(&ev[P >> 5], 1u << (P & 31u));
+            ++changes;
+          }
         }
+        const uint64_t zm = wave_ballot(zone);
+        if (zm != 0) { nlo = umin(nlo, rs + i0 + (uint32_t)dev_ctz64(zm)); nhi = umax(nhi, rs + i0 + 64u - (uint32_t)__builtin_clzll(zm)); }
+        stored += (uint32_t)dev_popc64(sm);
       }
-      const uint64_t zm = wave_ballot(zone);
-      if (zm != 0) { nlo = umin(nlo, rs + i0 + (uint32_t)dev_ctz64(zm)); nhi = umax(nhi, rs + i0 + 64u - (uint32_t)__builtin_clzll(zm)); }
-      stored += (uint32_t)dev_popc64(sm);
     }
     if (lane == 0) { kt[SKT_ZLO * nk + k] = nhi > nlo ? nlo : 0u; kt[SKT_ZHI * nk + k] = nhi > nlo ? nhi : 0u; }
   }

@@ -69,6 +69,17 @@ def test_chunks_of_half_a_window(sim, ref, monkeypatch, n, lgwin, seed, kind):
     assert got is not None and got == ref.compress(data, 5, lgwin)
 
 
+@pytest.mark.parametrize("seed", [31042, 31054])
+def test_half_chunks_changed_stretch_reaches_two_chunks_on(sim, ref, monkeypatch, seed):
+    """tools/fuzz_stream_sim.py with BROTLI_AMD_HALF_CHUNKS=1, seeds 31042 / 31054: a changed, unstored position that
+    leaves its successor walk to the changed entry before it (k_tile.h stream_events) — the walk into the chunk after
+    next ended where the window of the FIRST entry of such a stretch ends, though the last one's reaches further."""
+    monkeypatch.setenv("BROTLI_AMD_HALF_CHUNKS", "1")
+    data, lgwin, kind = fuzz_stream_sim.make(seed)
+    got, info = sim.encode_stream(data, lgwin=lgwin, reverse=seed & 1)
+    assert got is not None and got == ref.compress(data, 5, lgwin)
+
+
 def test_half_chunks_with_a_counter_wrap(sim, ref, monkeypatch):
     """The 16-bit store counter's zones (k_stream_zones) over chunks of half a window: the stream of
     test_counter_wrap_changes_the_bytes_and_is_followed."""
