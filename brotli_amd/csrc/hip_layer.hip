@@ -851,7 +851,11 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
   const uint32_t nkg = (1u << plan.J.bucket_bits) / 64u;
   const dim3 egrid(nchunks * plan.J.ix_slices);
   hipLaunchKernelGGL(k_stream_kprefix, dim3(nkg), dim3(64), 0, c->stream, a); each("k_stream_kprefix");
-  hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, a); each("k_stream_zones");
+  {
+    JobArgs z = a;
+    z.aux = 1;                   // (every key run; the launches of the pass loop walk the ones that changed: SKT_DIRTY)
+    hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, z); each("k_stream_zones");
+  }
   HIP_OK(c, hipEventRecord(c->ev[2], c->stream));
   const uint32_t gpw = ntiles >= 1024 ? 4u : ntiles >= 512 ? 2u : 1u;
   {
@@ -904,8 +908,8 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     hipLaunchKernelGGL(k_stream_skclear, egrid, dim3(64), 0, c->stream, a); each("k_stream_skclear");
     hipLaunchKernelGGL(k_stream_skcount, egrid, dim3(64), 0, c->stream, a); each("k_stream_skcount");
     hipLaunchKernelGGL(k_stream_kprefix, dim3(nkg), dim3(64), 0, c->stream, a); each("k_stream_kprefix");
-    hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, a); each("k_stream_zones");
     a.aux = 0;
+    hipLaunchKernelGGL(k_stream_zones, dim3(nchunks * nkg), dim3(64), 0, c->stream, a); each("k_stream_zones");
     hipLaunchKernelGGL(k_stream_cuts, dim3(1), dim3(64), 0, c->stream, a); each("k_stream_cuts");
     hipLaunchKernelGGL(k_stream_verify, dim3((ntiles + 63u) / 64u), dim3(64), 0, c->stream, a); each("k_stream_verify");
     HIP_OK(c, hipMemcpyAsync(tc, c->d_counters, sizeof(tc), hipMemcpyDeviceToHost, c->stream));

@@ -67,7 +67,9 @@ static inline IX_HD void ix_layout(uint64_t n, uint32_t slices, uint32_t nb_log2
 #define SKT_B 4u
 #define SKT_ZLO 5u
 #define SKT_ZHI 6u
-#define SKT_WORDS 7u
+#define SKT_DIRTY 7u                          // != 0: k_stream_zones has to walk the run again — a store bit of the run changed
+                                              //   (k_stream_events) or the stores before it did (k_stream_kprefix); cleared by the walk
+#define SKT_WORDS 8u
 static inline IX_HD uint64_t skt_chunk_bytes(uint32_t bucket_bits) { return (uint64_t)SKT_WORDS * 4u << bucket_bits; }
 
 // ---- chain tiles (JOB_FLAG_TILED, enc_types.h) ----------------------------------------------

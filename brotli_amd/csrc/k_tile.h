@@ -544,6 +544,8 @@ DEV void stream_events(const JobParams& J, const ShardDesc& D, const ShardDesc* 
       const bool halfc = J.chunk_log2 < (uint32_t)J.lgwin;
       for (uint32_t c = cj; c <= cj + 1u && c < J.nchunks; ++c) {
         const ShardDesc& K = chunks[c];
+        // (the store counter's zones of this key in this chunk are to be looked at again: stream_zones)
+        ((uint32_t*)(ws + J.skt_off + (uint64_t)c * skt_chunk_bytes((uint32_t)J.bucket_bits)))[(SKT_DIRTY << J.bucket_bits) + key] = 1u;
         IxLayout L;
         ix_layout(K.len, J.ix_slices, J.ix_nb_log2, &L);
         const uint8_t* kb = ws + K.ix_off;
@@ -679,12 +681,16 @@ DEV void stream_kprefix(const JobParams& J, uint8_t* ws, uint32_t key) {
   uint32_t run = 0;
   for (uint32_t c = 0; c < J.nchunks; ++c) {
     uint32_t* kt = stream_kt(J, ws, c);
-    kt[SKT_B * nk + key] = run;
+    if (kt[SKT_B * nk + key] != run) { kt[SKT_B * nk + key] = run; kt[SKT_DIRTY * nk + key] = 1u; }
     if (c >= 1u) { const uint32_t* kp = stream_kt(J, ws, c - 1u); run += kp[SKT_OWN * nk + key] - kp[SKT_SK * nk + key]; }
   }
 }
 // grid = nchunks * keys / 64, block = 64: the wave's 64 keys of chunk c, one after the other.
-DEV void stream_zones(const JobParams& J, const ShardDesc& D, const ShardDesc* chunks, uint8_t* ws, uint32_t c, uint32_t kg, uint32_t* counters) {
+// Only the runs that changed since they were walked last are walked again (SKT_DIRTY; `all`: the first launch): a
+// store bit of the run flipped, or the number of stores in front of it did.  The walk is bound by its loads — an
+// entry and its word of the bitmap per position of the chunk and its look-back: 6 ms a launch, four launches a stream,
+// a quarter of the time of 256 MiB at lgwin 24 when every launch walked everything (profiles/r06_x).
+DEV void stream_zones(const JobParams& J, const ShardDesc& D, const ShardDesc* chunks, uint8_t* ws, uint32_t c, uint32_t kg, uint32_t* counters, bool all) {
   const uint32_t lane = (uint32_t)wave_lane();
   const uint32_t nk = 1u << J.bucket_bits;
   uint32_t* kt = stream_kt(J, ws, c);
@@ -699,7 +705,9 @@ DEV void stream_zones(const JobParams& J, const ShardDesc& D, const ShardDesc* c
   const uint32_t rl_l = kt[SKT_RL * nk + key], b_l = kt[SKT_B * nk + key], zlo_l = kt[SKT_ZLO * nk + key], zhi_l = kt[SKT_ZHI * nk + key];
   // a wrap inside the run (however few of its entries are stored, the run cannot wrap if this says no), or marks
   // of an earlier pass to look after
-  uint64_t todo = wave_ballot((rl_l != 0u && (b_l & 0xFFFFu) + rl_l >= 65536u) || zhi_l > zlo_l);
+  const bool dirty_l = all || kt[SKT_DIRTY * nk + key] != 0u;
+  if (dirty_l && !all) kt[SKT_DIRTY * nk + key] = 0u;
+  uint64_t todo = wave_ballot(dirty_l && ((rl_l != 0u && (b_l & 0xFFFFu) + rl_l >= 65536u) || zhi_l > zlo_l));
   uint32_t changes = 0;
   for (; todo != 0; todo &= todo - 1ull) {
     const int src = dev_ctz64(todo);

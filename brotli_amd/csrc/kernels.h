@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(64) k_stream_kprefix(JobArgs a) {
 __global__ void __launch_bounds__(64) k_stream_zones(JobArgs a) {
   const uint32_t per = (1u << a.J.bucket_bits) / 64u;
   const uint32_t cj = blockIdx.x / per, kg = blockIdx.x % per;
-  if (cj < a.J.nchunks) stream_zones(a.J, a.shards[0], a.chunks, a.ws, cj, kg, a.counters);
+  if (cj < a.J.nchunks) stream_zones(a.J, a.shards[0], a.chunks, a.ws, cj, kg, a.counters, a.aux != 0u);
 }
 // grid = ntiles, block = 64
 __global__ void __launch_bounds__(64) k_stream_finish(JobArgs a) {

@@ -336,7 +336,9 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
   // the searches behind a wrap of the 16-bit store counter, as far as they can be told before the parse
   const bool zones = !getenv("SIM_NO_ZONES");      // (test knob: without them a stream with a counter wrap comes out wrong)
   if (zones) run(k_stream_kprefix, a, nkg, 64, reverse);
+  a.aux = 1;                       // (every key run; the pass loop's launches walk the ones that changed: SKT_DIRTY)
   if (zones) run(k_stream_zones, a, a.J.nchunks * nkg, 64, reverse);
+  a.aux = 0;
   lap("zones0");
   run(k_chain_tiles, a, (a.ntiles + gpw - 1) / gpw, 64, reverse);
   lap("first parse");
@@ -369,9 +371,9 @@ long sim_encode_stream(const char* tables_path, const uint8_t* in, size_t len, i
     run(k_stream_skclear, a, a.J.nchunks * a.J.ix_slices, 64, reverse);
     run(k_stream_skcount, a, a.J.nchunks * a.J.ix_slices, 64, reverse);
     if (zones) run(k_stream_kprefix, a, nkg, 64, reverse);
+    a.aux = 0;
     if (zones) run(k_stream_zones, a, a.J.nchunks * nkg, 64, reverse);
     lap("zones");
-    a.aux = 0;
     run(k_stream_cuts, a, 1, 64, reverse);
     run(k_stream_verify, a, (a.ntiles + 63) / 64, 64, reverse);
     lap("cuts+verify");
