@@ -720,11 +720,21 @@ DEV void stream_zones(const JobParams& J, const ShardDesc& D, const ShardDesc* c
     // stream: a quarter of its time at lgwin 24 (profiles/r06_x) — the steps themselves only pass `stored` on.
     uint32_t stored = B, nlo = 0xFFFFFFFFu, nhi = 0;
     for (uint32_t i00 = 0; i00 < rl; i00 += 256u) {
+      if (all) {
+        // the first launch: nothing is unstored yet (k_ix_count cleared the bitmap), the counter at entry i is B + i —
+        // straight to the next 256 entries that hold a zone, without loading a bitmap word
+        const uint32_t v = B + i00, r = v & 0xFFFFu;
+        uint32_t i = r < 16u ? i00 : i00 + (65536u - r);
+        if (B + i < 65536u) i = 65536u - B;
+        if (i >= rl) break;
+        i00 = i & ~63u;
+        stored = B + i00;
+      }
       uint32_t w4[4], s4[4];
 #pragma unroll
       for (uint32_t u = 0; u < 4u; ++u) { const uint32_t i = i00 + 64u * u + lane; w4[u] = i < rl ? srt[rs + i] : 0u; }
 #pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) { const uint32_t P = (w4[u] & 0xFFFFFFu) + K.ix_base; s4[u] = i00 + 64u * u + lane < rl ? skip[P >> 5] : 0u; }
+      for (uint32_t u = 0; u < 4u; ++u) { const uint32_t P = (w4[u] & 0xFFFFFFu) + K.ix_base; s4[u] = (!all && i00 + 64u * u + lane < rl) ? skip[P >> 5] : 0u; }
 #pragma unroll
       for (uint32_t u = 0; u < 4u; ++u) {
         const uint32_t i0 = i00 + 64u * u;
