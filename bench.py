@@ -977,6 +977,12 @@ class GpuJob:
 def emit(line):
     """One JSON line on stdout, flushed: the driver parses the LAST line; every earlier one is the same line with
     fewer optional fields, so that whatever ends the process early leaves a complete headline behind."""
+    try:
+        # (RCCL prints a version banner through C stdio when its communicator is created; left in that buffer it would
+        #  come out at exit, BEHIND the last JSON line — seen in the world-size-1 run of the RCCL path)
+        C.CDLL(None).fflush(None)
+    except Exception:
+        pass
     sys.stdout.write(json.dumps(line) + "\n")
     sys.stdout.flush()
 
