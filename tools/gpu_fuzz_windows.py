@@ -7,6 +7,7 @@ occurrences in between), lengths around the chunk boundaries:
   kind 2  a constant background with rare tokens that come again 9 ... 15 MiB later (rare keys: the far candidates are in the ring)
   kind 3  text with rare binary tokens repeated far back
   kind 4  tiny vocabulary (keys stored more than 65536 times: the store counter's zones over half-window chunks)
+FUZZ_LGWINS=20,21,22: the same at smaller windows (one window of look-back per chunk).
 Prints one line per seed; exit code 1 on a mismatch."""
 import ctypes as C, hashlib, os, sys, time
 import numpy as np
@@ -18,7 +19,7 @@ from stock_call import bind
 
 def make(seed):
     rng = np.random.default_rng(seed)
-    lgwin = int(rng.choice([24, 24, 24, 23]))
+    lgwin = int(rng.choice([int(v) for v in os.environ["FUZZ_LGWINS"].split(",")] if os.environ.get("FUZZ_LGWINS") else [24, 24, 24, 23]))
     W = 1 << lgwin
     kind = seed % 5
     n = int(rng.integers(W + 70000, 3 * W + 200000)) if kind != 4 else int(rng.integers(W + 70000, 2 * W))
@@ -40,7 +41,7 @@ def make(seed):
             buf = np.frombuffer(bytes(G.enwik_text(n, seed=seed)), dtype=np.uint8).copy()
         ntok = int(rng.integers(200, 3000))
         toks = [rng.integers(0, 256, int(rng.integers(6, 40)), dtype=np.uint8) for _ in range(ntok)]
-        back = int(rng.integers(9 << 20, 15 << 20)) if lgwin == 24 else int(rng.integers(5 << 20, 7 << 20))
+        back = int(rng.integers(9 << 20, 15 << 20)) if lgwin == 24 else int(rng.integers(5 << 20, 7 << 20)) if lgwin == 23 else int(rng.integers((W >> 1) + (W >> 3), W - (W >> 4)))
         first = rng.integers(0, max(1, n - back - 64), ntok)
         for t, p in zip(toks, first):
             p = int(p)
