@@ -869,7 +869,7 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
     hipLaunchKernelGGL(k_chain_tiles, dim3((ntiles + gpw - 1) / gpw), dim3(64), gpw * C_GROUP_LDS_WORDS * 4u, c->stream, f); each("k_chain_tiles");
   }
   lap("second parse");
-  uint32_t tc[16], sweeps = 0, reasons = 0, nmb = 0, passes = 0;
+  uint32_t tc[16], sweeps = 0, reasons = 0, nmb = 0, passes = 0, chaotic = 0;
   auto reasons_of = [&]() -> bool {
     TileRec r0;
     HIP_OK(c, hipMemcpy(&r0, c->d_trecs, sizeof(TileRec), hipMemcpyDeviceToHost));
@@ -924,6 +924,17 @@ bool run_stream_job(BrotliAmdCtx* c, uint64_t len, const BrotliAmdJobParams* p, 
       return true;
     }
     if (tc[TILE_CNT_START] == 0 && tc[TILE_CNT_FLIPS] == 0 && tc[TILE_CNT_RESTART] == 0) { settled = true; break; }
+    // Data on which a tile's parse depends chaotically on what was stored in front of it (arrays of floats: the literal
+    // spree's phase behind every short match) never settles: pass after pass more than half of ALL tiles come back with
+    // a new in-state (178, 195, 166, 164 ... of 256 for 16 MiB of floats, 24 passes = 12 s before the serial stream took
+    // over).  A stream whose passes 1 .. 4 each changed the in-state of more than 40 % of its tiles goes there now; slow
+    // settlers stay (table rows: 35 % falling; the mix, whose chaotic members are an eighth of its tiles).
+    if (pass >= 1 && pass <= 4 && outer == 0) chaotic += tc[TILE_CNT_START] > ntiles / 5u * 2u ? 1u : 0u;
+    if (pass == 4 && outer == 0 && chaotic == 4u) {
+      if (info) info->reserved = sweeps | ((TILE_WHY_EVENTS >> 8) << 16);
+      *rc = BROTLI_AMD_SERIAL;
+      return true;
+    }
     JobArgs b = a;
     b.J.flags |= JOB_FLAG_SWEEP;
     uint32_t sg = 2;
